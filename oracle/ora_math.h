@@ -1,0 +1,204 @@
+// TEST INFRASTRUCTURE ONLY -- CPU oracle for the Pies hot path. PARITY UNPINNED (see README.md).
+//
+// Minimal vector/matrix arithmetic restating the *published* glm semantics the reference relies on
+// (g-truc/glm, un-vendored submodule, commit unpinned: /root/reference/.gitmodules:1-3).
+// Only the operations the hot path uses are restated, with glm's documented evaluation order:
+//   dot(a,b)      = a.x*b.x + a.y*b.y + a.z*b.z           (left-associated)
+//   length(v)     = sqrt(dot(v,v))
+//   normalize(v)  = v * (1/sqrt(dot(v,v)))                 (glm::inversesqrt = 1/sqrt)
+//   mat3          = 3 columns, m[c][r]                     (column-major)
+//   inverse(mat3) = cofactors * (1/det)
+// Nothing under oracle/ may be linked, imported or executed by the product (pies_amd/, include/).
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+namespace ora {
+
+struct vec3 {
+  float x = 0.f, y = 0.f, z = 0.f;
+  vec3() = default;
+  vec3(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {}
+  explicit vec3(float s) : x(s), y(s), z(s) {}
+  float& operator[](int i) { return (&x)[i]; }
+  const float& operator[](int i) const { return (&x)[i]; }
+};
+
+inline vec3 operator+(const vec3& a, const vec3& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline vec3 operator-(const vec3& a, const vec3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline vec3 operator-(const vec3& a) { return {-a.x, -a.y, -a.z}; }
+inline vec3 operator*(const vec3& a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline vec3 operator*(float s, const vec3& a) { return {s * a.x, s * a.y, s * a.z}; }
+inline vec3 operator*(const vec3& a, const vec3& b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline vec3 operator/(const vec3& a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+inline vec3& operator+=(vec3& a, const vec3& b) { a = a + b; return a; }
+inline vec3& operator-=(vec3& a, const vec3& b) { a = a - b; return a; }
+
+inline float dot(const vec3& a, const vec3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline float length(const vec3& a) { return std::sqrt(dot(a, a)); }
+inline vec3 normalize(const vec3& a) { return a * (1.0f / std::sqrt(dot(a, a))); }
+inline vec3 cross(const vec3& a, const vec3& b) {
+  return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
+}
+inline float clampf(float v, float lo, float hi) { return std::fmin(std::fmax(v, lo), hi); }
+inline float fractf(float v) { return v - std::floor(v); }
+
+// Column-major 3x3: c[col][row], like glm::mat3.
+struct mat3 {
+  vec3 c[3];
+  mat3() = default;
+  mat3(const vec3& c0, const vec3& c1, const vec3& c2) { c[0] = c0; c[1] = c1; c[2] = c2; }
+  vec3& operator[](int i) { return c[i]; }
+  const vec3& operator[](int i) const { return c[i]; }
+};
+
+// glm operator*(mat3, mat3): result[c][r] = A[0][r]*B[c][0] + A[1][r]*B[c][1] + A[2][r]*B[c][2]
+inline mat3 operator*(const mat3& A, const mat3& B) {
+  mat3 R;
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r)
+      R[c][r] = A[0][r] * B[c][0] + A[1][r] * B[c][1] + A[2][r] * B[c][2];
+  return R;
+}
+
+// glm operator*(mat3, vec3): m[0]*v.x + m[1]*v.y + m[2]*v.z per row
+inline vec3 operator*(const mat3& m, const vec3& v) {
+  return {m[0][0] * v.x + m[1][0] * v.y + m[2][0] * v.z,
+          m[0][1] * v.x + m[1][1] * v.y + m[2][1] * v.z,
+          m[0][2] * v.x + m[1][2] * v.y + m[2][2] * v.z};
+}
+
+inline float determinant(const mat3& m) {
+  return +m[0][0] * (m[1][1] * m[2][2] - m[2][1] * m[1][2]) -
+         m[1][0] * (m[0][1] * m[2][2] - m[2][1] * m[0][2]) +
+         m[2][0] * (m[0][1] * m[1][2] - m[1][1] * m[0][2]);
+}
+
+inline mat3 inverse(const mat3& m) {
+  float ood = 1.0f / determinant(m);
+  mat3 I;
+  I[0][0] = +(m[1][1] * m[2][2] - m[2][1] * m[1][2]) * ood;
+  I[1][0] = -(m[1][0] * m[2][2] - m[2][0] * m[1][2]) * ood;
+  I[2][0] = +(m[1][0] * m[2][1] - m[2][0] * m[1][1]) * ood;
+  I[0][1] = -(m[0][1] * m[2][2] - m[2][1] * m[0][2]) * ood;
+  I[1][1] = +(m[0][0] * m[2][2] - m[2][0] * m[0][2]) * ood;
+  I[2][1] = -(m[0][0] * m[2][1] - m[2][0] * m[0][1]) * ood;
+  I[0][2] = +(m[0][1] * m[1][2] - m[1][1] * m[0][2]) * ood;
+  I[1][2] = -(m[0][0] * m[1][2] - m[1][0] * m[0][2]) * ood;
+  I[2][2] = +(m[0][0] * m[1][1] - m[1][0] * m[0][1]) * ood;
+  return I;
+}
+
+inline mat3 transpose(const mat3& m) {
+  mat3 T;
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) T[c][r] = m[r][c];
+  return T;
+}
+
+// Column-major 4x4 (only used for region transforms; setup time).
+struct mat4 {
+  float m[16];  // m[4*col + row]
+};
+// glm operator*(mat4, vec4) sums as (m0*x + m1*y) + (m2*z + m3*w); here w = 1.
+inline void mul_point(const mat4& M, const vec3& p, float out[4]) {
+  for (int r = 0; r < 4; ++r)
+    out[r] = (M.m[0 + r] * p.x + M.m[4 + r] * p.y) + (M.m[8 + r] * p.z + M.m[12 + r] * 1.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 SVD by one-sided (Hestenes) Jacobi.  The reference calls Eigen::JacobiSVD<Matrix3f> with
+// full U and V (/root/reference/Src/Constraints.cpp:97-99, 225-227); Eigen (fork
+// nithinp7/eigen.git, /root/reference/.gitmodules:10-12) is an empty, un-vendored submodule, so its
+// rounding cannot be reproduced.  What the hot path consumes is only  U * f(S) * V^T, which is
+// independent of the SVD algorithm and of the sign/order conventions of U and V; this routine
+// therefore restates the mathematical definition:  A*V = B with orthogonal columns,
+// s_i = |b_i|, u_i = b_i / s_i.   Fixed sweep count -> no data-dependent control flow.
+// ---------------------------------------------------------------------------------------------
+#ifndef ORA_SVD_SWEEPS
+#define ORA_SVD_SWEEPS 5
+#endif
+constexpr int kSvdSweeps = ORA_SVD_SWEEPS;
+
+struct Svd3 {
+  float b[3][3];  // b[i] = i-th column of A*V  (= s_i * u_i)
+  float v[3][3];  // v[i] = i-th column of V
+  float s[3];     // singular values (>= 0, unsorted)
+};
+
+inline void jacobi_pair(Svd3& d, int p, int q) {
+  float* bp = d.b[p];
+  float* bq = d.b[q];
+  float alpha = bp[0] * bp[0] + bp[1] * bp[1] + bp[2] * bp[2];
+  float beta = bq[0] * bq[0] + bq[1] * bq[1] + bq[2] * bq[2];
+  float gamma = bp[0] * bq[0] + bp[1] * bq[1] + bp[2] * bq[2];
+  float cs = 1.0f, sn = 0.0f;
+  if (gamma != 0.0f) {
+    float zeta = (beta - alpha) / (2.0f * gamma);
+    float t = 1.0f / (std::fabs(zeta) + std::sqrt(1.0f + zeta * zeta));
+    if (zeta < 0.0f) t = -t;
+    cs = 1.0f / std::sqrt(1.0f + t * t);
+    sn = cs * t;
+  }
+  for (int k = 0; k < 3; ++k) {
+    float x = bp[k], y = bq[k];
+    bp[k] = cs * x - sn * y;
+    bq[k] = sn * x + cs * y;
+    float vx = d.v[p][k], vy = d.v[q][k];
+    d.v[p][k] = cs * vx - sn * vy;
+    d.v[q][k] = sn * vx + cs * vy;
+  }
+}
+
+// a[r][c] row-major input.
+inline Svd3 svd3(const float a[3][3]) {
+  Svd3 d;
+  for (int i = 0; i < 3; ++i)
+    for (int k = 0; k < 3; ++k) {
+      d.b[i][k] = a[k][i];
+      d.v[i][k] = (i == k) ? 1.0f : 0.0f;
+    }
+  for (int sweep = 0; sweep < kSvdSweeps; ++sweep) {
+    jacobi_pair(d, 0, 1);
+    jacobi_pair(d, 0, 2);
+    jacobi_pair(d, 1, 2);
+  }
+  for (int i = 0; i < 3; ++i)
+    d.s[i] = std::sqrt(d.b[i][0] * d.b[i][0] + d.b[i][1] * d.b[i][1] + d.b[i][2] * d.b[i][2]);
+  return d;
+}
+
+constexpr float kSvdTiny = 1.0e-18f;
+
+// out[r][c] = sum_i u_i[r] * snew[i] * v_i[c], with u_i = b_i / s_i.  A direction whose singular
+// value underflows (collapsed element) gets u_i from the right-handed completion of the other two;
+// if two collapse the terms are dropped (the reference's result is arbitrary there as well).
+inline void svd3_recompose(const Svd3& d, const float snew[3], float out[3][3]) {
+  float u[3][3];
+  bool ok[3];
+  int nbad = 0;
+  for (int i = 0; i < 3; ++i) {
+    ok[i] = d.s[i] > kSvdTiny;
+    if (!ok[i]) ++nbad;
+    float inv = ok[i] ? 1.0f / d.s[i] : 0.0f;
+    for (int k = 0; k < 3; ++k) u[i][k] = d.b[i][k] * inv;
+  }
+  if (nbad == 1) {
+    int k = !ok[0] ? 0 : (!ok[1] ? 1 : 2);
+    int i = (k + 1) % 3, j = (k + 2) % 3;
+    // orientation of the completion follows det(V): keeps det(U)*det(V) = +1
+    float detv = d.v[0][0] * (d.v[1][1] * d.v[2][2] - d.v[1][2] * d.v[2][1]) -
+                 d.v[0][1] * (d.v[1][0] * d.v[2][2] - d.v[1][2] * d.v[2][0]) +
+                 d.v[0][2] * (d.v[1][0] * d.v[2][1] - d.v[1][1] * d.v[2][0]);
+    float sg = detv < 0.0f ? -1.0f : 1.0f;
+    u[k][0] = sg * (u[i][1] * u[j][2] - u[i][2] * u[j][1]);
+    u[k][1] = sg * (u[i][2] * u[j][0] - u[i][0] * u[j][2]);
+    u[k][2] = sg * (u[i][0] * u[j][1] - u[i][1] * u[j][0]);
+  }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c)
+      out[r][c] = (u[0][r] * snew[0]) * d.v[0][c] + (u[1][r] * snew[1]) * d.v[1][c] +
+                  (u[2][r] * snew[2]) * d.v[2][c];
+}
+
+}  // namespace ora
