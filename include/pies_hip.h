@@ -1,0 +1,171 @@
+/* pies_hip.h -- C ABI of the MI355X (gfx950) implementation of the Pies solver loop.
+ *
+ * The reference (nithinp7/Pies) has no FFI: hosts include <Pies/Solver.h> and call the C++ class
+ * (Include/Pies/Solver.h:40-116 in the reference tree).  This header is the boundary a binding for that
+ * class would use: plain pointers and sizes, no C++ or torch types.  `include/Pies/Solver.h` in this
+ * repository is the C++ drop-in class written on top of it.  Each entry point cites the reference
+ * interface it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *  - every call returns 0 (PIES_OK) or a PIES_ERR_* code; pies_last_error() gives the text;
+ *  - one handle = one HIP device + one stream; calls on one handle are serialised by the caller
+ *    (the reference solver is single-caller as well);
+ *  - inputs are copied, no caller buffer is retained;
+ *  - node ids returned/accepted are global (offset by the node count at the time of the add*),
+ *    exactly like the reference's add and create functions (Src/PrimitiveUtilities.cpp:53-57,358);
+ *  - there is no CPU fallback: without a gfx950 device pies_create fails.
+ */
+#ifndef PIES_HIP_H
+#define PIES_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIES_ABI_VERSION 1
+
+typedef struct pies_solver pies_solver_t;
+
+/* Pies::SolverOptions, field for field (Include/Pies/Solver.h:23-38). solver: 0 = PBD, 1 = PD. */
+typedef struct pies_options {
+  float fixedTimestepSize;                   /* 0.012f */
+  uint32_t timeSubsteps;                     /* 1 */
+  uint32_t iterations;                       /* 4 */
+  uint32_t collisionStabilizationIterations; /* 4 */
+  float collisionThresholdDistance;          /* 0.1f */
+  float collisionThickness;                  /* 0.05f */
+  float gravity;                             /* 10.0f */
+  float damping;                             /* 0.006f */
+  float friction;                            /* 0.01f */
+  float staticFrictionThreshold;             /* 0.f */
+  float floorHeight;                         /* 0.0f */
+  float gridSpacing;                         /* 2.0f */
+  uint32_t threadCount;                      /* 8 (accepted; only orders PD floor contacts) */
+  int32_t solver;                            /* 1 (PD) */
+} pies_options_t;
+
+enum {
+  PIES_OK = 0,
+  PIES_ERR_INVALID = 1,     /* bad argument (null, out-of-range node id, size mismatch) */
+  PIES_ERR_HIP = 2,         /* HIP runtime error, or no gfx950 device */
+  PIES_ERR_STATE = 3,       /* call not valid in the handle's current state */
+  PIES_ERR_UNSUPPORTED = 4  /* feature not available in this build */
+};
+
+enum { PIES_SOLVER_PBD = 0, PIES_SOLVER_PD = 1 }; /* Pies::SolverName, Solver.h:21 */
+
+/* constraint containers, in the order Solver::tickPBD / tickPD visit them */
+enum {
+  PIES_POSITION = 0, /* PositionConstraint      Constraints.cpp:58-74  */
+  PIES_DISTANCE = 1, /* DistanceConstraint      Constraints.cpp:11-56  */
+  PIES_TET = 2,      /* TetrahedralConstraint   Constraints.cpp:76-184 */
+  PIES_VOLUME = 3,   /* VolumeConstraint        Constraints.cpp:186-310 (PD only) */
+  PIES_BEND = 4,     /* BendConstraint          Constraints.cpp:312-394 */
+  PIES_SHAPE = 5,    /* ShapeMatchingConstraint ShapeMatchingConstraint.cpp:6-122 (PD only) */
+  PIES_GOAL = 6,     /* GoalMatchingConstraint  ShapeMatchingConstraint.cpp:124-177 (PD only) */
+  PIES_TRIANGLES = 7,
+  PIES_LINES = 8,
+  PIES_NODES = 9
+};
+
+/* How the sequential Gauss-Seidel sweeps of tickPBD (Solver.cpp:58-75) are mapped to the device.
+ *  EXACT    : dependency levels of the container order; bit-identical to processing the containers
+ *             sequentially in the order the host added the constraints (the reference's semantics).
+ *  COLOURED : greedy graph colouring; identical to a sequential sweep over the containers re-ordered
+ *             colour by colour (pies_get_order returns that order).  Fewer, larger launches. */
+enum { PIES_SCHEDULE_EXACT = 0, PIES_SCHEDULE_COLOURED = 1 };
+
+enum {
+  PIES_FLAG_RELEASE_HINGE = 0,  /* Solver::releaseHinge (Solver.h:52, Solver.cpp:59) */
+  PIES_FLAG_NODE_COLLISIONS = 1 /* extension, default 1: 0 skips the PBD node-node pass (Solver.cpp:81-130) */
+};
+
+/* node state selectors for pies_read_nodes / pies_write_nodes */
+enum { PIES_NODE_POSITION = 0, PIES_NODE_PREV_POSITION = 1, PIES_NODE_VELOCITY = 2, PIES_NODE_RADIUS = 3, PIES_NODE_INV_MASS = 4 };
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+/* Solver::Solver(const SolverOptions&) (Solver.cpp:11-17).  options == NULL -> reference defaults. */
+int pies_create(const pies_options_t* options, int device, pies_solver_t** out);
+/* Solver::~Solver (Solver.cpp:19-23) */
+int pies_destroy(pies_solver_t* s);
+/* Solver::clear (Solver.cpp:488-507); also resets the PD system. */
+int pies_clear(pies_solver_t* s);
+const char* pies_last_error(const pies_solver_t* s);
+int pies_abi_version(void);
+void pies_default_options(pies_options_t* out);
+/* Solver::getOptions (Solver.h:71) */
+int pies_get_options(const pies_solver_t* s, pies_options_t* out);
+
+/* ---- scene construction (setup time; host side) --------------------------------------------- */
+/* Solver::addNodes (PrimitiveUtilities.cpp:42-75): mass 1, radius 0.5, velocity 0.  pos: n x 3. */
+int pies_add_nodes(pies_solver_t* s, uint32_t n, const float* pos, uint32_t* first_id);
+/* Bulk node append with explicit state; vel/radius/inv_mass may be NULL (0 / 0.5 / 1). */
+int pies_add_nodes_ex(pies_solver_t* s, uint32_t n, const float* pos, const float* vel, const float* radius,
+                      const float* inv_mass, uint32_t* first_id);
+/* create*Constraint factories (Constraints.cpp:39-56, 65-74, 130-184, 257-310, 368-394): rest state is
+ * taken from the nodes' current positions, like the reference factories do. ids: n x {1,2,4,4,4}. */
+int pies_add_position_constraints(pies_solver_t* s, uint32_t n, const uint32_t* ids, float w);
+int pies_add_distance_constraints(pies_solver_t* s, uint32_t n, const uint32_t* ids, float w);
+int pies_add_tet_constraints(pies_solver_t* s, uint32_t n, const uint32_t* ids, float w, float min_strain, float max_strain);
+int pies_add_volume_constraints(pies_solver_t* s, uint32_t n, const uint32_t* ids, float w, float compression, float stretching);
+int pies_add_bend_constraints(pies_solver_t* s, uint32_t n, const uint32_t* ids, float w);
+/* Solver::_triangles entries (Solver.h:194); ids: n x 3 */
+int pies_add_triangles(pies_solver_t* s, uint32_t n, const uint32_t* ids);
+/* Solver::createTetBox (PrimitiveUtilities.cpp:330-618) on a W x H x D lattice (reference: 3x3x3, hinged
+ * 10x2x10).  flags bit0: push VolumeConstraints too (the reference always does); bit1: surface triangles. */
+int pies_create_tet_box(pies_solver_t* s, uint32_t W, uint32_t H, uint32_t D, const float translation[3], float scale,
+                        const float velocity[3], float w, float mass, uint32_t flags);
+/* Solver::createBox (PrimitiveUtilities.cpp:620-847) on a W x H x D lattice (reference: 5x5x5).
+ * existing != 0: only add the distance constraints, over an existing lattice starting at node existing_first. */
+int pies_create_box(pies_solver_t* s, uint32_t W, uint32_t H, uint32_t D, const float translation[3], float scale,
+                    float w, int existing, uint32_t existing_first, uint32_t flags);
+/* Solver::createSheet (:849-976, reference 20x20) and Solver::createBendSheet (:1127-1289, reference 10x10) */
+int pies_create_sheet(pies_solver_t* s, uint32_t W, uint32_t H, const float translation[3], float scale, float mass, float w);
+int pies_create_bend_sheet(pies_solver_t* s, uint32_t W, uint32_t H, const float translation[3], float scale, float w);
+
+/* ---- configuration -------------------------------------------------------------------------- */
+int pies_set_flag(pies_solver_t* s, int flag, int value);
+int pies_set_schedule(pies_solver_t* s, int schedule);
+/* Builds schedules, uploads to HBM and captures the substep graph.  Called implicitly by pies_tick
+ * when the scene changed. */
+int pies_finalize(pies_solver_t* s);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+/* Solver::tick (Solver.cpp:25-38): timeSubsteps substeps of tickPBD / tickPD, then positions are copied
+ * back so that pies_read_nodes / Solver::getVertices are current (Solver.cpp:157,393).  No-op once failed. */
+int pies_tick(pies_solver_t* s);
+/* Same work, but neither the host copy-back nor a stream synchronisation: state stays in HBM. */
+int pies_tick_async(pies_solver_t* s);
+int pies_synchronize(pies_solver_t* s);
+/* _simFailed latch (Solver.cpp:26-28,853-856) */
+int pies_failed(const pies_solver_t* s, int* failed);
+
+/* ---- state access --------------------------------------------------------------------------- */
+int pies_count(const pies_solver_t* s, int what, uint32_t* out);
+/* out: n x 3 floats for POSITION/PREV_POSITION/VELOCITY, n floats for RADIUS/INV_MASS */
+int pies_read_nodes(pies_solver_t* s, int what, float* out, uint32_t n);
+int pies_write_nodes(pies_solver_t* s, int what, const float* in, uint32_t n);
+/* node ids of a container, flattened, in the order the host added them */
+int pies_get_ids(const pies_solver_t* s, int type, uint32_t* out, uint32_t capacity);
+/* rest data in host order: DISTANCE target (1), TET/VOLUME Qinv column-major (9), BEND angle (1) */
+int pies_get_rest(const pies_solver_t* s, int type, float* out, uint32_t capacity);
+/* Execution order of a container under the current schedule: order[slot] = index in host order.
+ * batch_offsets (may be NULL) receives n_batches+1 slot offsets; batches run one after another. */
+int pies_get_order(pies_solver_t* s, int type, uint32_t* order, uint32_t capacity);
+int pies_get_batches(pies_solver_t* s, int type, uint32_t* batch_offsets, uint32_t capacity, uint32_t* n_batches);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+/* One un-graphed substep in which every launch of kernel class `kernel` is bracketed by the dispatch's
+ * own start/stop timestamps (hipExtLaunchKernelGGL).  Returns launches and summed device time. */
+enum { PIES_KERNEL_PREDICT = 0, PIES_KERNEL_POSITION = 1, PIES_KERNEL_DISTANCE = 2, PIES_KERNEL_TET = 3,
+       PIES_KERNEL_BEND = 4, PIES_KERNEL_FLOOR = 5, PIES_KERNEL_VELOCITY = 6, PIES_KERNEL_COUNT = 7 };
+int pies_profile_substep(pies_solver_t* s, int kernel, uint32_t* launches, double* total_ms, uint64_t* units);
+/* launches per substep of the captured graph, per kernel class (PIES_KERNEL_COUNT entries) */
+int pies_launch_counts(pies_solver_t* s, uint32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIES_HIP_H */

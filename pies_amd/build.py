@@ -1,0 +1,85 @@
+"""Builds pies_amd/lib/libpies_hip.so (HIP kernels + C ABI) for gfx950 with hipcc.
+
+The library is built in-tree so that it travels with the repository snapshot to the GPU box; object
+files are cached under pies_amd/lib/obj and rebuilt when a source or header is newer.
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+LIB = os.path.join(LIBDIR, "libpies_hip.so")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+
+ARCH = "gfx950"
+# -ffp-contract=off: device arithmetic is the plain IEEE sequence in the source (no implicit FMA), which
+# makes results reproducible on a host bit for bit; see DESIGN.md "Numerics".
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+          "-I", INCLUDE]
+DEVICE = [f"--offload-arch={ARCH}"]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP library cannot be built")
+    return exe
+
+
+def sources():
+    out = []
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith(".hip") or f.endswith(".cpp"):
+            out.append(os.path.join(CSRC, f))
+    return out
+
+
+def _newest_header():
+    t = os.path.getmtime(os.path.join(INCLUDE, "pies_hip.h"))
+    for f in os.listdir(CSRC):
+        if f.endswith(".h"):
+            t = max(t, os.path.getmtime(os.path.join(CSRC, f)))
+    return max(t, os.path.getmtime(os.path.abspath(__file__)))
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), _newest_header()):
+        return obj, False
+    cmd = [_hipcc(), "-c", src, "-o", obj] + COMMON
+    if src.endswith(".hip"):
+        cmd += DEVICE
+    else:
+        cmd += ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj, True
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJDIR, exist_ok=True)
+    srcs = sources()
+    with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
+        res = list(ex.map(lambda s: _compile(s, force), srcs))
+    objs = [o for o, _ in res]
+    rebuilt = any(c for _, c in res)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [_hipcc(), "-shared", "-o", LIB] + objs + DEVICE + ["-Wl,--no-undefined"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        if verbose:
+            print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,549 @@
+// C ABI (include/pies_hip.h): handle lifetime, upload to HBM, substep graph capture, tick, state access.
+// The substep itself is Solver::tickPBD (Src/Solver.cpp:40-160) / tickPD (:162-486) re-expressed as a
+// fixed sequence of kernel launches captured once into a hipGraph: at 100k particles a conflict-free
+// batch runs for a few microseconds, so un-graphed launches would be host-bound.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "solver_state.h"
+
+using namespace pies;
+
+namespace pies {
+
+#define HIP_TRY(s, expr)                                                                                   \
+  do {                                                                                                     \
+    hipError_t e__ = (expr);                                                                               \
+    if (e__ != hipSuccess)                                                                                 \
+      return fail((s), PIES_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));                  \
+  } while (0)
+
+static void destroy_graph(pies_solver* s) {
+  if (s->graphExec) (void)hipGraphExecDestroy(s->graphExec);
+  if (s->graph) (void)hipGraphDestroy(s->graph);
+  s->graphExec = nullptr;
+  s->graph = nullptr;
+}
+
+static void free_device(pies_solver* s) {
+  destroy_graph(s);
+  for (void* p : s->allocations) (void)hipFree(p);
+  s->allocations.clear();
+  s->nd = NodeArrays{nullptr, nullptr, nullptr, nullptr, 0};
+  s->d_pc_id = nullptr; s->d_pc_tw = nullptr;
+  s->d_dc_ids = nullptr; s->d_dc_rw = nullptr;
+  s->d_tc_ids = nullptr; s->d_tc_q0 = s->d_tc_q1 = s->d_tc_q2 = nullptr;
+  s->d_bc_ids = nullptr; s->d_bc_aw = nullptr;
+}
+
+template <class T> static int upload(pies_solver* s, const std::vector<T>& h, T** d) {
+  *d = nullptr;
+  if (h.empty()) return PIES_OK;
+  void* p = nullptr;
+  HIP_TRY(s, hipMalloc(&p, h.size() * sizeof(T)));
+  s->allocations.push_back(p);
+  HIP_TRY(s, hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s->stream));
+  *d = static_cast<T*>(p);
+  return PIES_OK;
+}
+
+static int upload_nodes(pies_solver* s) {
+  const uint32_t n = s->nodeCount();
+  std::vector<float4> pos(n), prev(n), vel(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    pos[i] = make_float4(s->h_pos[3 * i], s->h_pos[3 * i + 1], s->h_pos[3 * i + 2], s->h_invMass[i]);
+    prev[i] = make_float4(s->h_prev[3 * i], s->h_prev[3 * i + 1], s->h_prev[3 * i + 2], 0.f);
+    vel[i] = make_float4(s->h_vel[3 * i], s->h_vel[3 * i + 1], s->h_vel[3 * i + 2], 0.f);
+  }
+  if (n) {
+    HIP_TRY(s, hipMemcpyAsync(s->nd.pos, pos.data(), n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(s, hipMemcpyAsync(s->nd.prev, prev.data(), n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(s, hipMemcpyAsync(s->nd.vel, vel.data(), n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(s, hipMemcpyAsync(s->nd.radius, s->h_radius.data(), n * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(s, hipStreamSynchronize(s->stream));  // the staging vectors die with this scope
+  }
+  s->hostNodesDirty = false;
+  s->deviceAhead = false;
+  return PIES_OK;
+}
+
+// Host mirror <- HBM (positions, previous positions, velocities).
+static int download_nodes(pies_solver* s) {
+  const uint32_t n = s->nd.n;
+  if (!s->deviceAhead || n == 0) { s->deviceAhead = false; return PIES_OK; }
+  std::vector<float4> buf(n);
+  float* dst[3] = {s->h_pos.data(), s->h_prev.data(), s->h_vel.data()};
+  const float4* src[3] = {s->nd.pos, s->nd.prev, s->nd.vel};
+  for (int a = 0; a < 3; ++a) {
+    HIP_TRY(s, hipMemcpyAsync(buf.data(), src[a], n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    for (uint32_t i = 0; i < n; ++i) {
+      dst[a][3 * i] = buf[i].x;
+      dst[a][3 * i + 1] = buf[i].y;
+      dst[a][3 * i + 2] = buf[i].z;
+    }
+  }
+  s->deviceAhead = false;
+  return PIES_OK;
+}
+
+int scene_sync_host(pies_solver* s) {
+  if (hipSetDevice(s->device) != hipSuccess) return fail(s, PIES_ERR_HIP, "hipSetDevice failed");
+  return download_nodes(s);
+}
+
+// One PBD substep as a launch sequence (Solver.cpp:45-159).  `timer`/`timedKernel` select one kernel
+// class for per-dispatch timing (profile pass); counts (optional) tallies launches per class.
+static void enqueue_pbd_substep(pies_solver* s, int timedKernel, LaunchTimer* timer, uint32_t* counts) {
+  hipStream_t st = s->stream;
+  const float dt = s->opt.fixedTimestepSize / s->opt.timeSubsteps;
+  auto T = [&](int k) -> LaunchTimer* { return (timer && timedKernel == k) ? timer : nullptr; };
+  auto C = [&](int k) { if (counts) ++counts[k]; };
+
+  launch_predict(st, s->nd, dt, s->opt.gravity, T(PIES_KERNEL_PREDICT));
+  C(PIES_KERNEL_PREDICT);
+  for (uint32_t it = 0; it < s->opt.iterations; ++it) {
+    if (!s->releaseHinge)
+      for (const Batch& b : s->plan[PIES_POSITION].batches) {
+        launch_position(st, s->nd.pos, s->d_pc_id, s->d_pc_tw, b.start, b.count, T(PIES_KERNEL_POSITION));
+        C(PIES_KERNEL_POSITION);
+      }
+    for (const Batch& b : s->plan[PIES_DISTANCE].batches) {
+      launch_distance(st, s->nd.pos, s->d_dc_ids, s->d_dc_rw, b.start, b.count, T(PIES_KERNEL_DISTANCE));
+      C(PIES_KERNEL_DISTANCE);
+    }
+    for (const Batch& b : s->plan[PIES_TET].batches) {
+      launch_tet(st, s->nd.pos, s->d_tc_ids, s->d_tc_q0, s->d_tc_q1, s->d_tc_q2, b.start, b.count, T(PIES_KERNEL_TET));
+      C(PIES_KERNEL_TET);
+    }
+    for (const Batch& b : s->plan[PIES_BEND].batches) {
+      launch_bend(st, s->nd.pos, s->d_bc_ids, s->d_bc_aw, b.start, b.count, T(PIES_KERNEL_BEND));
+      C(PIES_KERNEL_BEND);
+    }
+    launch_floor(st, s->nd, s->opt.floorHeight, T(PIES_KERNEL_FLOOR));
+    C(PIES_KERNEL_FLOOR);
+  }
+  launch_velocity(st, s->nd, dt, s->opt.damping, s->opt.friction, s->opt.floorHeight, T(PIES_KERNEL_VELOCITY));
+  C(PIES_KERNEL_VELOCITY);
+}
+
+static int capture_graph(pies_solver* s) {
+  destroy_graph(s);
+  std::memset(s->launchCounts, 0, sizeof(s->launchCounts));
+  if (s->nd.n == 0) return PIES_OK;
+  HIP_TRY(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+  enqueue_pbd_substep(s, -1, nullptr, s->launchCounts);
+  hipError_t e = hipStreamEndCapture(s->stream, &s->graph);
+  if (e != hipSuccess) return fail(s, PIES_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+  HIP_TRY(s, hipGraphInstantiate(&s->graphExec, s->graph, nullptr, nullptr, 0));
+  return PIES_OK;
+}
+
+}  // namespace pies
+
+extern "C" {
+
+int pies_abi_version(void) { return PIES_ABI_VERSION; }
+
+void pies_default_options(pies_options_t* o) {
+  if (!o) return;
+  o->fixedTimestepSize = 0.012f;
+  o->timeSubsteps = 1;
+  o->iterations = 4;
+  o->collisionStabilizationIterations = 4;
+  o->collisionThresholdDistance = 0.1f;
+  o->collisionThickness = 0.05f;
+  o->gravity = 10.0f;
+  o->damping = 0.006f;
+  o->friction = 0.01f;
+  o->staticFrictionThreshold = 0.f;
+  o->floorHeight = 0.0f;
+  o->gridSpacing = 2.0f;
+  o->threadCount = 8;
+  o->solver = PIES_SOLVER_PD;
+}
+
+int pies_create(const pies_options_t* options, int device, pies_solver_t** out) {
+  if (!out) return PIES_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return PIES_ERR_HIP;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return PIES_ERR_HIP;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return PIES_ERR_HIP;  // kernels are built for gfx950 only
+  if (hipSetDevice(device) != hipSuccess) return PIES_ERR_HIP;
+  pies_solver* s = new pies_solver();
+  if (options) s->opt = *options; else pies_default_options(&s->opt);
+  if (s->opt.timeSubsteps == 0) s->opt.timeSubsteps = 1;
+  s->device = device;
+  if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete s;
+    return PIES_ERR_HIP;
+  }
+  *out = s;
+  return PIES_OK;
+}
+
+int pies_destroy(pies_solver_t* s) {
+  if (!s) return PIES_OK;
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  free_device(s);
+  if (s->h_stage) (void)hipHostFree(s->h_stage);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+  return PIES_OK;
+}
+
+int pies_clear(pies_solver_t* s) {
+  if (!s) return PIES_ERR_INVALID;
+  (void)hipSetDevice(s->device);
+  (void)hipStreamSynchronize(s->stream);
+  free_device(s);
+  s->h_pos.clear(); s->h_prev.clear(); s->h_vel.clear(); s->h_radius.clear(); s->h_invMass.clear();
+  s->h_position.clear(); s->h_distance.clear(); s->h_tet.clear(); s->h_volume.clear(); s->h_bend.clear();
+  s->h_triangles.clear(); s->h_lines.clear();
+  for (Plan& p : s->plan) { p.order.clear(); p.batches.clear(); }
+  s->constraintId = 0;
+  s->sceneDirty = true;
+  s->deviceAhead = false;
+  s->hostNodesDirty = false;
+  return PIES_OK;  // like the reference, the failure latch is not reset (Solver.cpp:488-507)
+}
+
+const char* pies_last_error(const pies_solver_t* s) { return s ? s->error.c_str() : "null handle"; }
+
+int pies_get_options(const pies_solver_t* s, pies_options_t* out) {
+  if (!s || !out) return PIES_ERR_INVALID;
+  *out = s->opt;
+  return PIES_OK;
+}
+
+int pies_set_flag(pies_solver_t* s, int flag, int value) {
+  if (!s) return PIES_ERR_INVALID;
+  bool* target = flag == PIES_FLAG_RELEASE_HINGE ? &s->releaseHinge : flag == PIES_FLAG_NODE_COLLISIONS ? &s->nodeCollisions : nullptr;
+  if (!target) return fail(s, PIES_ERR_INVALID, "pies_set_flag: unknown flag");
+  if (*target != (value != 0)) {
+    *target = value != 0;
+    if (int rc = scene_sync_host(s)) return rc;
+    s->sceneDirty = true;  // the launch sequence changes: re-capture
+  }
+  return PIES_OK;
+}
+
+int pies_set_schedule(pies_solver_t* s, int schedule) {
+  if (!s) return PIES_ERR_INVALID;
+  if (schedule != PIES_SCHEDULE_EXACT && schedule != PIES_SCHEDULE_COLOURED) return fail(s, PIES_ERR_INVALID, "unknown schedule");
+  if (schedule != s->schedule) {
+    if (int rc = scene_sync_host(s)) return rc;
+    s->schedule = schedule;
+    s->sceneDirty = true;
+  }
+  return PIES_OK;
+}
+
+int pies_finalize(pies_solver_t* s) {
+  if (!s) return PIES_ERR_INVALID;
+  HIP_TRY(s, hipSetDevice(s->device));
+  if (!s->sceneDirty) {
+    if (s->hostNodesDirty) return upload_nodes(s);
+    return PIES_OK;
+  }
+  if (s->opt.solver == PIES_SOLVER_PD) return fail(s, PIES_ERR_UNSUPPORTED, "PD solver: not available in this build yet");
+  if (s->nodeCollisions && s->opt.solver == PIES_SOLVER_PBD)
+    return fail(s, PIES_ERR_UNSUPPORTED, "PBD node-node collisions: not available in this build yet; clear PIES_FLAG_NODE_COLLISIONS");
+  if (int rc = download_nodes(s)) return rc;
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  free_device(s);
+
+  const uint32_t n = s->nodeCount();
+  // ---- plans ----
+  {
+    std::vector<uint32_t> ids;
+    ids.resize(s->h_position.size());
+    for (size_t i = 0; i < ids.size(); ++i) ids[i] = s->h_position[i].id;
+    build_plan({ids.data(), 1, (uint32_t)s->h_position.size(), 0x1}, n, s->schedule, s->plan[PIES_POSITION]);
+    ids.resize(2 * s->h_distance.size());
+    for (size_t i = 0; i < s->h_distance.size(); ++i) { ids[2 * i] = s->h_distance[i].ids[0]; ids[2 * i + 1] = s->h_distance[i].ids[1]; }
+    // a distance projection moves node a only (Constraints.cpp:34-36); node b is read
+    build_plan({ids.data(), 2, (uint32_t)s->h_distance.size(), 0x1}, n, s->schedule, s->plan[PIES_DISTANCE]);
+    ids.resize(4 * s->h_tet.size());
+    for (size_t i = 0; i < s->h_tet.size(); ++i) std::memcpy(&ids[4 * i], s->h_tet[i].ids, 16);
+    build_plan({ids.data(), 4, (uint32_t)s->h_tet.size(), 0xF}, n, s->schedule, s->plan[PIES_TET]);
+    ids.resize(4 * s->h_bend.size());
+    for (size_t i = 0; i < s->h_bend.size(); ++i) std::memcpy(&ids[4 * i], s->h_bend[i].ids, 16);
+    build_plan({ids.data(), 4, (uint32_t)s->h_bend.size(), 0xF}, n, s->schedule, s->plan[PIES_BEND]);
+  }
+  // ---- node arrays ----
+  if (n) {
+    void* p;
+    HIP_TRY(s, hipMalloc(&p, n * sizeof(float4))); s->allocations.push_back(p); s->nd.pos = (float4*)p;
+    HIP_TRY(s, hipMalloc(&p, n * sizeof(float4))); s->allocations.push_back(p); s->nd.prev = (float4*)p;
+    HIP_TRY(s, hipMalloc(&p, n * sizeof(float4))); s->allocations.push_back(p); s->nd.vel = (float4*)p;
+    HIP_TRY(s, hipMalloc(&p, n * sizeof(float))); s->allocations.push_back(p); s->nd.radius = (float*)p;
+    s->nd.n = n;
+    if (s->h_stage_n < n) {
+      if (s->h_stage) (void)hipHostFree(s->h_stage);
+      s->h_stage = nullptr;
+      HIP_TRY(s, hipHostMalloc((void**)&s->h_stage, n * sizeof(float4), hipHostMallocDefault));
+      s->h_stage_n = n;
+    }
+  }
+  if (int rc = upload_nodes(s)) return rc;
+  // ---- constraint records, in schedule order ----
+  {
+    const Plan& pl = s->plan[PIES_POSITION];
+    std::vector<uint32_t> id(pl.order.size());
+    std::vector<float4> tw(pl.order.size());
+    for (size_t k = 0; k < pl.order.size(); ++k) {
+      const HostPosition& c = s->h_position[pl.order[k]];
+      id[k] = c.id;
+      tw[k] = make_float4(c.target[0], c.target[1], c.target[2], c.w);
+    }
+    if (int rc = upload(s, id, &s->d_pc_id)) return rc;
+    if (int rc = upload(s, tw, &s->d_pc_tw)) return rc;
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+  }
+  {
+    const Plan& pl = s->plan[PIES_DISTANCE];
+    std::vector<uint2> id(pl.order.size());
+    std::vector<float2> rw(pl.order.size());
+    for (size_t k = 0; k < pl.order.size(); ++k) {
+      const HostDistance& c = s->h_distance[pl.order[k]];
+      id[k] = make_uint2(c.ids[0], c.ids[1]);
+      rw[k] = make_float2(c.target, c.w);
+    }
+    if (int rc = upload(s, id, &s->d_dc_ids)) return rc;
+    if (int rc = upload(s, rw, &s->d_dc_rw)) return rc;
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+  }
+  {
+    const Plan& pl = s->plan[PIES_TET];
+    std::vector<uint4> id(pl.order.size());
+    std::vector<float4> q0(pl.order.size()), q1(pl.order.size()), q2(pl.order.size());
+    for (size_t k = 0; k < pl.order.size(); ++k) {
+      const HostTet& c = s->h_tet[pl.order[k]];
+      id[k] = make_uint4(c.ids[0], c.ids[1], c.ids[2], c.ids[3]);
+      q0[k] = make_float4(c.qinv[0], c.qinv[1], c.qinv[2], c.qinv[3]);
+      q1[k] = make_float4(c.qinv[4], c.qinv[5], c.qinv[6], c.qinv[7]);
+      q2[k] = make_float4(c.qinv[8], c.lo, c.hi, c.w);
+    }
+    if (int rc = upload(s, id, &s->d_tc_ids)) return rc;
+    if (int rc = upload(s, q0, &s->d_tc_q0)) return rc;
+    if (int rc = upload(s, q1, &s->d_tc_q1)) return rc;
+    if (int rc = upload(s, q2, &s->d_tc_q2)) return rc;
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+  }
+  {
+    const Plan& pl = s->plan[PIES_BEND];
+    std::vector<uint4> id(pl.order.size());
+    std::vector<float2> aw(pl.order.size());
+    for (size_t k = 0; k < pl.order.size(); ++k) {
+      const HostBend& c = s->h_bend[pl.order[k]];
+      id[k] = make_uint4(c.ids[0], c.ids[1], c.ids[2], c.ids[3]);
+      aw[k] = make_float2(c.angle, c.w);
+    }
+    if (int rc = upload(s, id, &s->d_bc_ids)) return rc;
+    if (int rc = upload(s, aw, &s->d_bc_aw)) return rc;
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+  }
+  if (int rc = capture_graph(s)) return rc;
+  s->sceneDirty = false;
+  return PIES_OK;
+}
+
+int pies_tick_async(pies_solver_t* s) {
+  if (!s) return PIES_ERR_INVALID;
+  if (s->simFailed) return PIES_OK;  // Solver.cpp:26-28
+  if (s->sceneDirty || s->hostNodesDirty)
+    if (int rc = pies_finalize(s)) return rc;
+  HIP_TRY(s, hipSetDevice(s->device));
+  if (s->nd.n == 0) return PIES_OK;
+  for (uint32_t sub = 0; sub < s->opt.timeSubsteps; ++sub) HIP_TRY(s, hipGraphLaunch(s->graphExec, s->stream));
+  s->deviceAhead = true;
+  return PIES_OK;
+}
+
+int pies_synchronize(pies_solver_t* s) {
+  if (!s) return PIES_ERR_INVALID;
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  return PIES_OK;
+}
+
+int pies_tick(pies_solver_t* s) {
+  if (!s) return PIES_ERR_INVALID;
+  if (s->simFailed) return PIES_OK;
+  if (int rc = pies_tick_async(s)) return rc;
+  const uint32_t n = s->nd.n;
+  if (n == 0) return PIES_OK;
+  // Solver.cpp:157 : _vertices[i].position = position -- one D2H copy per tick
+  HIP_TRY(s, hipMemcpyAsync(s->h_stage, s->nd.pos, n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  for (uint32_t i = 0; i < n; ++i) {
+    s->h_pos[3 * i] = s->h_stage[i].x;
+    s->h_pos[3 * i + 1] = s->h_stage[i].y;
+    s->h_pos[3 * i + 2] = s->h_stage[i].z;
+  }
+  return PIES_OK;
+}
+
+int pies_failed(const pies_solver_t* s, int* failed) {
+  if (!s || !failed) return PIES_ERR_INVALID;
+  *failed = s->simFailed ? 1 : 0;
+  return PIES_OK;
+}
+
+int pies_count(const pies_solver_t* s, int what, uint32_t* out) {
+  if (!s || !out) return PIES_ERR_INVALID;
+  switch (what) {
+    case PIES_POSITION: *out = (uint32_t)s->h_position.size(); break;
+    case PIES_DISTANCE: *out = (uint32_t)s->h_distance.size(); break;
+    case PIES_TET: *out = (uint32_t)s->h_tet.size(); break;
+    case PIES_VOLUME: *out = (uint32_t)s->h_volume.size(); break;
+    case PIES_BEND: *out = (uint32_t)s->h_bend.size(); break;
+    case PIES_SHAPE: *out = 0; break;
+    case PIES_GOAL: *out = 0; break;
+    case PIES_TRIANGLES: *out = (uint32_t)(s->h_triangles.size() / 3); break;
+    case PIES_LINES: *out = (uint32_t)s->h_lines.size(); break;
+    case PIES_NODES: *out = s->nodeCount(); break;
+    default: return PIES_ERR_INVALID;
+  }
+  return PIES_OK;
+}
+
+int pies_read_nodes(pies_solver_t* s, int what, float* out, uint32_t n) {
+  if (!s || (!out && n)) return PIES_ERR_INVALID;
+  if (n != s->nodeCount()) return fail(s, PIES_ERR_INVALID, "pies_read_nodes: n does not match the node count");
+  HIP_TRY(s, hipSetDevice(s->device));
+  if (int rc = download_nodes(s)) return rc;
+  const std::vector<float>* src = nullptr;
+  switch (what) {
+    case PIES_NODE_POSITION: src = &s->h_pos; break;
+    case PIES_NODE_PREV_POSITION: src = &s->h_prev; break;
+    case PIES_NODE_VELOCITY: src = &s->h_vel; break;
+    case PIES_NODE_RADIUS: src = &s->h_radius; break;
+    case PIES_NODE_INV_MASS: src = &s->h_invMass; break;
+    default: return fail(s, PIES_ERR_INVALID, "pies_read_nodes: unknown selector");
+  }
+  if (!src->empty()) std::memcpy(out, src->data(), src->size() * sizeof(float));
+  return PIES_OK;
+}
+
+int pies_write_nodes(pies_solver_t* s, int what, const float* in, uint32_t n) {
+  if (!s || (!in && n)) return PIES_ERR_INVALID;
+  if (n != s->nodeCount()) return fail(s, PIES_ERR_INVALID, "pies_write_nodes: n does not match the node count");
+  HIP_TRY(s, hipSetDevice(s->device));
+  if (int rc = download_nodes(s)) return rc;
+  std::vector<float>* dst = nullptr;
+  switch (what) {
+    case PIES_NODE_POSITION: dst = &s->h_pos; break;
+    case PIES_NODE_PREV_POSITION: dst = &s->h_prev; break;
+    case PIES_NODE_VELOCITY: dst = &s->h_vel; break;
+    case PIES_NODE_RADIUS: dst = &s->h_radius; break;
+    case PIES_NODE_INV_MASS: dst = &s->h_invMass; break;
+    default: return fail(s, PIES_ERR_INVALID, "pies_write_nodes: unknown selector");
+  }
+  if (!dst->empty()) std::memcpy(dst->data(), in, dst->size() * sizeof(float));
+  s->hostNodesDirty = true;
+  return PIES_OK;
+}
+
+int pies_get_ids(const pies_solver_t* s, int type, uint32_t* out, uint32_t capacity) {
+  if (!s || !out) return PIES_ERR_INVALID;
+  size_t k = 0;
+  auto put = [&](uint32_t v) { if (k < capacity) out[k] = v; ++k; };
+  switch (type) {
+    case PIES_POSITION: for (auto& c : s->h_position) put(c.id); break;
+    case PIES_DISTANCE: for (auto& c : s->h_distance) { put(c.ids[0]); put(c.ids[1]); } break;
+    case PIES_TET: for (auto& c : s->h_tet) for (uint32_t v : c.ids) put(v); break;
+    case PIES_VOLUME: for (auto& c : s->h_volume) for (uint32_t v : c.ids) put(v); break;
+    case PIES_BEND: for (auto& c : s->h_bend) for (uint32_t v : c.ids) put(v); break;
+    case PIES_TRIANGLES: for (uint32_t v : s->h_triangles) put(v); break;
+    case PIES_LINES: for (uint32_t v : s->h_lines) put(v); break;
+    default: return PIES_ERR_INVALID;
+  }
+  return k <= capacity ? PIES_OK : PIES_ERR_INVALID;
+}
+
+int pies_get_rest(const pies_solver_t* s, int type, float* out, uint32_t capacity) {
+  if (!s || !out) return PIES_ERR_INVALID;
+  size_t k = 0;
+  auto put = [&](float v) { if (k < capacity) out[k] = v; ++k; };
+  switch (type) {
+    case PIES_DISTANCE: for (auto& c : s->h_distance) put(c.target); break;
+    case PIES_TET: for (auto& c : s->h_tet) for (float v : c.qinv) put(v); break;
+    case PIES_VOLUME: for (auto& c : s->h_volume) for (float v : c.qinv) put(v); break;
+    case PIES_BEND: for (auto& c : s->h_bend) put(c.angle); break;
+    default: return PIES_ERR_INVALID;
+  }
+  return k <= capacity ? PIES_OK : PIES_ERR_INVALID;
+}
+
+int pies_get_order(pies_solver_t* s, int type, uint32_t* order, uint32_t capacity) {
+  if (!s || !order || type < PIES_POSITION || type > PIES_BEND) return PIES_ERR_INVALID;
+  if (s->sceneDirty)
+    if (int rc = pies_finalize(s)) return rc;
+  const Plan& pl = s->plan[type];
+  if (pl.order.size() > capacity) return fail(s, PIES_ERR_INVALID, "pies_get_order: capacity too small");
+  if (!pl.order.empty()) std::memcpy(order, pl.order.data(), pl.order.size() * sizeof(uint32_t));
+  return PIES_OK;
+}
+
+int pies_get_batches(pies_solver_t* s, int type, uint32_t* offs, uint32_t capacity, uint32_t* n_batches) {
+  if (!s || !n_batches || type < PIES_POSITION || type > PIES_BEND) return PIES_ERR_INVALID;
+  if (s->sceneDirty)
+    if (int rc = pies_finalize(s)) return rc;
+  const Plan& pl = s->plan[type];
+  *n_batches = (uint32_t)pl.batches.size();
+  if (offs) {
+    if (pl.batches.size() + 1 > capacity) return fail(s, PIES_ERR_INVALID, "pies_get_batches: capacity too small");
+    for (size_t b = 0; b < pl.batches.size(); ++b) offs[b] = pl.batches[b].start;
+    offs[pl.batches.size()] = pl.batches.empty() ? 0 : pl.batches.back().start + pl.batches.back().count;
+  }
+  return PIES_OK;
+}
+
+int pies_launch_counts(pies_solver_t* s, uint32_t* out) {
+  if (!s || !out) return PIES_ERR_INVALID;
+  if (s->sceneDirty)
+    if (int rc = pies_finalize(s)) return rc;
+  std::memcpy(out, s->launchCounts, sizeof(s->launchCounts));
+  return PIES_OK;
+}
+
+int pies_profile_substep(pies_solver_t* s, int kernel, uint32_t* launches, double* total_ms, uint64_t* units) {
+  if (!s || kernel < 0 || kernel >= PIES_KERNEL_COUNT) return PIES_ERR_INVALID;
+  if (s->sceneDirty || s->hostNodesDirty)
+    if (int rc = pies_finalize(s)) return rc;
+  HIP_TRY(s, hipSetDevice(s->device));
+  LaunchTimer timer;
+  const uint32_t want = std::min<uint32_t>(s->launchCounts[kernel], 8192);
+  timer.starts.resize(want);
+  timer.stops.resize(want);
+  for (uint32_t i = 0; i < want; ++i) {
+    HIP_TRY(s, hipEventCreate(&timer.starts[i]));
+    HIP_TRY(s, hipEventCreate(&timer.stops[i]));
+  }
+  enqueue_pbd_substep(s, kernel, &timer, nullptr);
+  s->deviceAhead = true;
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  double ms = 0.0;
+  for (size_t i = 0; i < timer.used; ++i) {
+    float e = 0.f;
+    HIP_TRY(s, hipEventElapsedTime(&e, timer.starts[i], timer.stops[i]));
+    ms += e;
+  }
+  for (uint32_t i = 0; i < want; ++i) {
+    (void)hipEventDestroy(timer.starts[i]);
+    (void)hipEventDestroy(timer.stops[i]);
+  }
+  if (launches) *launches = (uint32_t)timer.used;
+  if (total_ms) *total_ms = ms;
+  if (units) *units = timer.units;
+  return PIES_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+// Internal state of one pies_solver handle: host mirror of the scene (authoritative until the first
+// tick / after a read-back), schedules, HBM buffers, the captured substep graph.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/pies_hip.h"
+#include "kernels.h"
+
+namespace pies {
+
+struct HostPosition {
+  uint32_t id;
+  float target[3];
+  float w;
+};
+struct HostDistance {
+  uint32_t ids[2];
+  float target;
+  float w;
+};
+struct HostTet {  // TetrahedralConstraint and VolumeConstraint share the rest data
+  uint32_t ids[4];
+  float qinv[9];  // column-major (glm layout): qinv[3*col + row]
+  float lo, hi;   // minStrain/maxStrain or minOmega/maxOmega
+  float w;
+  float AtA[16];  // row-major 4x4, A^T A (B = I so AtB = A^T)
+  float A[16];    // row-major 4x4
+};
+struct HostBend {
+  uint32_t ids[4];
+  float angle;
+  float w;
+};
+
+struct Batch {
+  uint32_t start, count;
+};
+
+// Execution plan of one constraint container: slot -> host index, and conflict-free batches of slots.
+struct Plan {
+  std::vector<uint32_t> order;
+  std::vector<Batch> batches;
+};
+
+template <class T> struct DevArray {
+  T* p = nullptr;
+  size_t n = 0;
+};
+
+}  // namespace pies
+
+struct pies_solver {
+  pies_options_t opt;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string error;
+
+  bool releaseHinge = false;
+  bool nodeCollisions = true;
+  bool simFailed = false;
+  int schedule = PIES_SCHEDULE_EXACT;
+
+  // ---- host mirror ----
+  std::vector<float> h_pos, h_prev, h_vel;  // n x 3
+  std::vector<float> h_radius, h_invMass;   // n
+  std::vector<pies::HostPosition> h_position;
+  std::vector<pies::HostDistance> h_distance;
+  std::vector<pies::HostTet> h_tet, h_volume;
+  std::vector<pies::HostBend> h_bend;
+  std::vector<uint32_t> h_triangles;  // 3 per triangle
+  std::vector<uint32_t> h_lines;
+  uint32_t constraintId = 0;
+
+  bool sceneDirty = true;    // topology/rest data changed: rebuild plans + upload everything
+  bool deviceAhead = false;  // device node state is newer than the host mirror
+  bool hostNodesDirty = false;  // host node state edited (pies_write_nodes): upload nodes only
+
+  // ---- plans ----
+  pies::Plan plan[5];  // PIES_POSITION .. PIES_BEND
+
+  // ---- HBM ----
+  pies::NodeArrays nd{nullptr, nullptr, nullptr, nullptr, 0};
+  uint32_t* d_pc_id = nullptr;
+  float4* d_pc_tw = nullptr;
+  uint2* d_dc_ids = nullptr;
+  float2* d_dc_rw = nullptr;
+  uint4* d_tc_ids = nullptr;
+  float4 *d_tc_q0 = nullptr, *d_tc_q1 = nullptr, *d_tc_q2 = nullptr;
+  uint4* d_bc_ids = nullptr;
+  float2* d_bc_aw = nullptr;
+  std::vector<void*> allocations;
+  float4* h_stage = nullptr;  // pinned staging for the per-tick position read-back
+  size_t h_stage_n = 0;
+
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graphExec = nullptr;
+  uint32_t launchCounts[PIES_KERNEL_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+
+  uint32_t nodeCount() const { return static_cast<uint32_t>(h_radius.size()); }
+};
+
+namespace pies {
+// scene.cpp
+int fail(pies_solver* s, int code, const std::string& msg);
+// schedule.cpp : op = up to 4 node ids; bit i of writeMask set if node i is written.
+struct OpView {
+  const uint32_t* ids;  // count * stride entries
+  uint32_t stride;      // node ids per op
+  uint32_t count;
+  uint8_t writeMask;    // same for every op of a container
+};
+void build_plan(const OpView& ops, uint32_t nodeCount, int schedule, Plan& out);
+}  // namespace pies

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950) device; run with -m gpu")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_api
+    oracle_api.lib()
+    return oracle_api
+
+
+@pytest.fixture(scope="session")
+def pies():
+    """The product binding.  GPU tests must run on the HIP library: no fallback, fail loudly."""
+    from pies_amd import capi
+    capi.load()
+    return capi

@@ -1,0 +1,193 @@
+"""GPU parity of the PBD substep (Src/Solver.cpp:40-160) against the CPU oracle, through the C ABI.
+
+Tolerance: the device arithmetic is the same IEEE fp32 sequence as the oracle's (no FMA contraction,
+correctly rounded sqrt/div), so positions are expected to agree bit for bit; the gate is
+max|dpos| <= 1e-5 * lattice spacing after T <= 10 ticks (north_star: "a stated FP tolerance on node
+positions"), and exact equality is reported (and required where no libm call is involved)."""
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # x lattice spacing (1.0)
+
+
+def _pair(pies, oracle, dims, iterations, schedule, ticks, seed=7, amp=0.05, **beam):
+    g = pies.Solver(scenes.pbd_options(pies, iterations))
+    o = oracle.OracleSolver(scenes.pbd_options(oracle, iterations))
+    for s in (g, o):
+        scenes.build_beam(s, dims, **beam)
+        scenes.perturb(s, seed, amp)
+        s.set_flag(1, 0)  # node-node collisions off (BASELINE configs 1-2)
+    g.set_schedule(schedule)
+    if schedule == pies.SCHEDULE_COLOURED:
+        for t in (pies.POSITION, pies.DISTANCE, pies.TET, pies.BEND):
+            if g.count(t):
+                o.permute(t, g.order(t))
+    g.tick(ticks)
+    o.tick(ticks)
+    return g, o
+
+
+def _check(g, o, exact=True):
+    for name in ("positions", "velocities", "prev_positions"):
+        a, b = getattr(g, name), getattr(o, name)
+        assert np.isfinite(a).all()
+        d = np.abs(a - b).max()
+        assert d <= TOL, (name, d)
+        if exact:
+            assert np.array_equal(a, b), (name, d)
+
+
+def test_scene_arrays_match_oracle(pies, oracle):
+    g = pies.Solver(scenes.pbd_options(pies, 1))
+    o = oracle.OracleSolver(scenes.pbd_options(oracle, 1))
+    for s in (g, o):
+        scenes.build_beam(s, (4, 5, 6), volume=True, triangles=True)
+    for t in (pies.DISTANCE, pies.TET, pies.VOLUME, pies.TRIANGLES, pies.LINES):
+        assert np.array_equal(g.ids(t), o.ids(t))
+    for t in (pies.DISTANCE, pies.TET, pies.VOLUME):
+        assert np.array_equal(g.rest(t), o.rest(t))
+    assert np.array_equal(g.positions, o.positions)
+    assert np.array_equal(g.radii, o.radii) and np.array_equal(g.inv_masses, o.inv_masses)
+
+
+@pytest.mark.parametrize("schedule", [0, 1])
+def test_config1_l1k_pbd(pies, oracle, schedule):
+    """BASELINE config 1: 10x10x10 lattice, distance + tet-strain, 10 iterations."""
+    g, o = _pair(pies, oracle, scenes.L1K, 10, schedule, ticks=5)
+    _check(g, o)
+
+
+@pytest.mark.parametrize("schedule", [0, 1])
+def test_distance_only(pies, oracle, schedule):
+    g, o = _pair(pies, oracle, (6, 7, 5), 4, schedule, ticks=8, tets=False)
+    _check(g, o)
+
+
+@pytest.mark.parametrize("schedule", [0, 1])
+def test_tets_only_with_inversion(pies, oracle, schedule):
+    # large perturbation: inverted and strongly compressed elements exercise the sigma flip and clamps
+    g, o = _pair(pies, oracle, (5, 4, 6), 6, schedule, ticks=4, amp=0.8, distance=False)
+    _check(g, o)
+
+
+def test_exact_schedule_is_reference_order(pies, oracle):
+    """EXACT never needs the oracle to replay an order: it is the container order."""
+    g, o = _pair(pies, oracle, (7, 3, 9), 5, pies.SCHEDULE_EXACT, ticks=3)
+    assert np.array_equal(g.positions, o.positions)
+
+
+def test_coloured_batches_are_conflict_free(pies):
+    g = pies.Solver(scenes.pbd_options(pies, 1))
+    scenes.build_beam(g, (6, 6, 6))
+    g.set_flag(1, 0)
+    g.set_schedule(pies.SCHEDULE_COLOURED)
+    for t, writes in ((pies.DISTANCE, [0]), (pies.TET, [0, 1, 2, 3])):
+        ids, order, offs = g.ids(t), g.order(t), g.batches(t)
+        assert sorted(order.tolist()) == list(range(len(ids)))
+        for b in range(len(offs) - 1):
+            sel = ids[order[offs[b]:offs[b + 1]]]
+            written = sel[:, writes].ravel()
+            assert len(np.unique(written)) == len(written)
+            reads = np.setdiff1d(sel.ravel(), written)
+            assert len(np.intersect1d(reads, written)) == 0
+
+
+def test_floor_and_friction(pies, oracle):
+    # beam resting on / penetrating the floor: clamp, and the velocity pass's hard-coded speed 5.0
+    g, o = _pair(pies, oracle, (5, 5, 5), 4, 0, ticks=10, translation=(0.0, 0.2, 0.0))
+    _check(g, o)
+    assert (g.positions[:, 1] >= g.radii - 1e-6).all()
+
+
+def test_sheet_position_constraints_and_release_hinge(pies, oracle):
+    for hinge in (0, 1):
+        g = pies.Solver(scenes.pbd_options(pies, 6))
+        o = oracle.OracleSolver(scenes.pbd_options(oracle, 6))
+        for s in (g, o):
+            s.create_sheet(9, 7, translation=(0, 3, 0), scale=0.5, mass=2.0, w=0.7)
+            scenes.perturb(s, 3, 0.05)
+            s.set_flag(1, 0)
+            s.set_flag(0, hinge)
+        g.tick(4)
+        o.tick(4)
+        _check(g, o)
+
+
+def test_bend_sheet(pies, oracle):
+    # acosf differs between device libm and glibc by a few ulp: tolerance only
+    g = pies.Solver(scenes.pbd_options(pies, 5))
+    o = oracle.OracleSolver(scenes.pbd_options(oracle, 5))
+    for s in (g, o):
+        s.create_bend_sheet(8, 8, translation=(0, 4, 0), scale=1.0, w=0.6)
+        scenes.perturb(s, 5, 0.1)
+        s.set_flag(1, 0)
+    g.tick(5)
+    o.tick(5)
+    _check(g, o, exact=False)
+
+
+def test_random_graph_ragged(pies, oracle):
+    """Non-lattice connectivity, duplicate position constraints, batch sizes not a multiple of 64/256."""
+    rng = np.random.default_rng(11)
+    n = 777
+    pos = rng.uniform(0, 6, size=(n, 3)).astype(np.float32) + np.float32([0, 3, 0])
+    tets = np.array([rng.choice(n, 4, replace=False) for _ in range(1501)], dtype=np.uint32)
+    dist = np.array([rng.choice(n, 2, replace=False) for _ in range(2003)], dtype=np.uint32)
+    pins = np.array([3, 3, 10, 500, 3], dtype=np.uint32)
+    im = rng.uniform(0.5, 2.0, size=n).astype(np.float32)
+    for schedule in (0, 1):
+        g = pies.Solver(scenes.pbd_options(pies, 3))
+        o = oracle.OracleSolver(scenes.pbd_options(oracle, 3))
+        for s in (g, o):
+            s.add_nodes_raw(pos, radius=0.1, invMass=im)
+            s.add_position(pins, 0.3)
+            s.add_distance(dist, 0.4)
+            s.add_tet(tets, 0.02)
+            s.set_flag(1, 0)
+        g.set_schedule(schedule)
+        if schedule == 1:
+            for t in (pies.POSITION, pies.DISTANCE, pies.TET):
+                o.permute(t, g.order(t))
+        g.tick(3)
+        o.tick(3)
+        _check(g, o)
+
+
+def test_empty_and_unconstrained(pies, oracle):
+    g = pies.Solver(scenes.pbd_options(pies, 2))
+    g.set_flag(1, 0)
+    g.tick()  # no nodes: no-op
+    assert g.count(pies.NODES) == 0
+    o = oracle.OracleSolver(scenes.pbd_options(oracle, 2))
+    p = np.float32([[0, 5, 0], [1, 0.2, 0], [2, 9, 3]])
+    for s in (g, o):
+        s.addNodes(p)
+        s.set_flag(1, 0)
+        s.tick(20)
+    _check(g, o)
+
+
+def test_edit_after_tick_and_substeps(pies, oracle):
+    g = pies.Solver(scenes.pbd_options(pies, 3, timeSubsteps=3))
+    o = oracle.OracleSolver(scenes.pbd_options(oracle, 3, timeSubsteps=3))
+    for s in (g, o):
+        scenes.build_beam(s, (3, 3, 3))
+        s.set_flag(1, 0)
+        s.tick(2)
+        scenes.build_beam(s, (3, 4, 3), translation=(6, 4, 0))  # second body appended after ticking
+        s.tick(2)
+    _check(g, o)
+
+
+def test_config2_l100k_one_tick(pies, oracle):
+    """BASELINE config 2 at full size (20x20x250, 20 iterations): one tick against the oracle, coloured
+    schedule replayed, plus a checksum over both schedules' launch plans."""
+    g, o = _pair(pies, oracle, scenes.L100K, 20, pies.SCHEDULE_COLOURED, ticks=1)
+    assert g.count(pies.TET) == 539334 and g.count(pies.DISTANCE) == 649156
+    _check(g, o)
+    lc = g.launch_counts()
+    assert lc["tet"] == 20 * (len(g.batches(pies.TET)) - 1)
