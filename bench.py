@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Benchmark of the Pies PBD substep on MI355X (BASELINE.json metric: substeps/sec and
+constraint-projections/sec at 100k particles, HBM GB/s vs peak).
+
+A "step" is one Solver::tick = `timeSubsteps` (1) substep of BASELINE config 2: the 20x20x250 lattice
+(100 000 particles, 649 156 distance + 539 334 tet-strain constraints), PBD, 20 iterations, node-node
+collisions off, synthetic perturbed rest state already resident in HBM.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one body per GPU)
+
+Rank 0 prints ONE JSON line.  `value` is whole-job substeps/s (N independent bodies, weak scaling; the
+only collective is the timing barrier / max-reduce).  `roofline` is measured live for the dominant kernel
+(tet-strain projection) from the dispatches' own start/stop timestamps; `cpu_baseline` is the CPU oracle
+(a single-threaded restatement of the reference loop) timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+import scenes  # noqa: E402
+from pies_amd import capi  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec)
+# algorithmic bytes per unit (DESIGN.md "Kernels")
+BYTES = {"predict": 48, "position": 44, "distance": 52, "tet": 160, "bend": 136, "floor": 20, "velocity": 40}
+ITERATIONS = 20
+
+
+def dist_env():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def aggregate(elapsed_s, units, dist=None):
+    """max-over-ranks time and summed units (the only communication of the whole job)."""
+    if dist is None:
+        return elapsed_s, units
+    import torch
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([elapsed_s], dtype=torch.float64, device=dev)
+    u = torch.tensor([units], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(u.item())
+
+
+def build_scene(mod, dims, seed, schedule=None, device=None):
+    """The same synthetic scene through the product (mod = capi, device given) or the oracle."""
+    opts = scenes.pbd_options(mod, ITERATIONS)
+    s = mod.Solver(opts, device=device) if device is not None else mod.OracleSolver(opts)
+    scenes.build_beam(s, dims)
+    scenes.perturb(s, seed, 0.05)
+    s.set_flag(1, 0)
+    if schedule is not None:
+        s.set_schedule(schedule)
+    return s
+
+
+def timed_ticks(solver, steps, warmup, barrier):
+    solver.tick_async(warmup)
+    solver.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    solver.tick_async(steps)
+    solver.synchronize()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def kernel_profile(solver, reps=3):
+    """Per kernel class: launches per substep, average dispatch duration (us), algorithmic GB/s."""
+    out = {}
+    for k, name in enumerate(capi.KERNEL_NAMES):
+        launches = ms = units = 0
+        for _ in range(reps):
+            n, m, u = solver.profile_substep(k)
+            launches, ms, units = launches + n, ms + m, units + u
+        if launches == 0:
+            continue
+        out[name] = {
+            "launches_per_substep": launches // reps,
+            "avg_us": 1e3 * ms / launches,
+            "units_per_launch": units / launches,
+            "algorithmic_GBs": BYTES[name] * units / (ms * 1e-3) / 1e9 if ms > 0 else None,
+        }
+    return out
+
+
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (collected
+    separately, see profiles/README.md); None when no pass has been recorded for this round."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel_name, {}).get("hbm_bytes_per_launch")
+    except OSError:
+        return None
+
+
+def cpu_baseline(dims, ticks):
+    import oracle_api as ora
+    o = build_scene(ora, dims, 1234)
+    o.tick(1)  # warm caches / page-in
+    t0 = time.perf_counter()
+    o.tick(ticks)
+    dt = time.perf_counter() - t0
+    return {
+        "value": ticks / dt, "unit": "substeps/s", "cores": 1, "kind": "port",
+        "sample": "%d ticks of the same %dx%dx%d workload (20 iterations, oracle/pies_oracle.cpp, g++ -O2, 1 thread; "
+                  "the reference's projection loops are single-threaded, Src/Solver.cpp:58-75)" % ((ticks,) + tuple(dims)),
+        "projections_per_sec": ticks * scenes.projections_per_substep(o, ora, ITERATIONS) / dt,
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--dims", type=int, nargs=3, default=list(scenes.L100K))
+    ap.add_argument("--schedule", choices=["coloured", "exact"], default="coloured")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-order measurement")
+    ap.add_argument("--cpu-ticks", type=int, default=4)
+    args = ap.parse_args()
+
+    rank, local_rank, world = dist_env()
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        sync_t = torch.zeros(1, device="cuda")
+
+        def barrier():
+            dist.all_reduce(sync_t)  # RCCL over xGMI: 4-byte all-reduce as the barrier
+            torch.cuda.synchronize()
+    else:
+        def barrier():
+            pass
+
+    dims = tuple(args.dims)
+    sched = capi.SCHEDULE_COLOURED if args.schedule == "coloured" else capi.SCHEDULE_EXACT
+    g = build_scene(capi, dims, 1234 + rank, schedule=sched, device=local_rank)
+    g.finalize()
+    substeps_per_tick = g.options.timeSubsteps
+    proj = scenes.projections_per_substep(g, capi, ITERATIONS)
+
+    elapsed = timed_ticks(g, args.steps, args.warmup, barrier)
+    elapsed, total_substeps = aggregate(elapsed, args.steps * substeps_per_tick, dist)
+    assert np.isfinite(g.positions).all()
+
+    result = None
+    if rank == 0:
+        value = total_substeps / elapsed
+        prof = kernel_profile(g)
+        dom = "tet" if "tet" in prof else max(prof, key=lambda k: prof[k]["avg_us"] * prof[k]["launches_per_substep"])
+        achieved = prof[dom]["algorithmic_GBs"]
+        lc = g.launch_counts()
+        result = {
+            "metric": "substeps/sec @100k particles (PBD distance+tet-strain, 20 iterations)",
+            "value": value, "unit": "substeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %dx%dx%d lattice beam, %d particles, %d distance + %d tet-strain "
+                                   "constraints, PBD, %d iterations, 1 substep/tick, one body per GPU"
+                                   % (dims + (g.count(capi.NODES), g.count(capi.DISTANCE), g.count(capi.TET), ITERATIONS)),
+                       "schedule": args.schedule, "parallelism": "replicas x%d" % world,
+                       "launches_per_substep": sum(lc.values())},
+            "projections_per_sec": value * proj,
+            "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_" + dom),
+                         "avg_launch_us": prof[dom]["avg_us"], "bytes_per_launch": BYTES[dom] * prof[dom]["units_per_launch"]},
+            "kernels": prof,
+        }
+        # whole-substep algorithmic traffic over wall time (includes launch gaps)
+        per_substep_bytes = (BYTES["predict"] + BYTES["velocity"] + ITERATIONS * BYTES["floor"]) * g.count(capi.NODES) + ITERATIONS * (
+            BYTES["distance"] * g.count(capi.DISTANCE) + BYTES["tet"] * g.count(capi.TET) + BYTES["position"] * g.count(capi.POSITION)
+            + BYTES["bend"] * g.count(capi.BEND))
+        result["substep_algorithmic_GBs_per_gpu"] = per_substep_bytes * (value / world) / 1e9
+    g.close()
+
+    if rank == 0 and world == 1:
+        if not args.no_exact and args.schedule == "coloured":
+            e = build_scene(capi, dims, 1234, schedule=capi.SCHEDULE_EXACT, device=local_rank)
+            e.finalize()
+            steps = max(2, min(args.steps, 10))
+            el = timed_ticks(e, steps, 1, lambda: None)
+            result["exact_order"] = {"value": steps * substeps_per_tick / el, "unit": "substeps/s",
+                                     "launches_per_substep": sum(e.launch_counts().values()), "steps": steps,
+                                     "note": "schedule EXACT: bit-identical to the reference's container-order sweep"}
+            e.close()
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(dims, args.cpu_ticks)
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

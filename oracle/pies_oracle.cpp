@@ -187,6 +187,12 @@ struct VolumeCon : ConBase<4> {
   }
 };
 
+// The reference calls acos on a float (Constraints.cpp:339, 385).  libm acosf implementations differ by
+// an ulp between platforms; evaluating in double and rounding once gives the correctly rounded float
+// result (up to double-rounding ties), which any conforming acosf is within 1 ulp of, and which a
+// device can reproduce exactly.
+static inline float acos_f(float d) { return static_cast<float>(std::acos(static_cast<double>(d))); }
+
 // Constraints.cpp:312-366
 struct BendCon : ConBase<4> {
   float initialAngle = 0.f;
@@ -206,7 +212,7 @@ struct BendCon : ConBase<4> {
     vec3 n2 = p2Xp4 / l24;
     float d = dot(n1, n2);
     float d2 = d * d;
-    float C = std::acos(d) - initialAngle;
+    float C = acos_f(d) - initialAngle;
     out[0] = x1.position;
     out[1] = x2.position;
     out[2] = x3.position;
@@ -892,7 +898,7 @@ static BendCon makeBend(uint32_t id, float w, const Node& x1, const Node& x2, co
   vec3 n2 = normalize(cross(p2, p4));
   BendCon c;
   c.init(id, w, I4, I4, {x1.id, x2.id, x3.id, x4.id});
-  c.initialAngle = std::acos(dot(n1, n2));
+  c.initialAngle = acos_f(dot(n1, n2));
   return c;
 }
 

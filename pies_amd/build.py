@@ -51,11 +51,10 @@ def _compile(src, force):
     obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), _newest_header()):
         return obj, False
-    cmd = [_hipcc(), "-c", src, "-o", obj] + COMMON
     if src.endswith(".hip"):
-        cmd += DEVICE
-    else:
-        cmd += ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include"]
+        cmd = [_hipcc(), "-c", src, "-o", obj] + COMMON + DEVICE
+    else:  # host-only translation units: plain C++ against the HIP runtime API
+        cmd = [_hipcc(), "-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-c", src, "-o", obj] + COMMON
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

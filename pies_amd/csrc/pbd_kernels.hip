@@ -220,7 +220,8 @@ __global__ void __launch_bounds__(kBlock) k_bend(float4* __restrict__ pos, const
   const float l23 = sqrtf(dotv(c23, c23)), l24 = sqrtf(dotv(c24, c24));
   const V3 n1 = divv(c23, l23), n2 = divv(c24, l24);
   const float d = dotv(n1, n2);
-  const float C = acosf(d) - aw.x;
+  // acos in double, rounded once: the correctly rounded float value, identical on host and device
+  const float C = static_cast<float>(acos(static_cast<double>(d))) - aw.x;
   const V3 q3 = divv(addv(crossv(p2, n2), mulv(crossv(n1, p2), d)), l23);
   const V3 q4 = divv(addv(crossv(p2, n1), mulv(crossv(n2, p2), d)), l24);
   const V3 q2 = subv(negv(divv(addv(crossv(p3, n2), mulv(crossv(n1, p3), d)), l23)),

@@ -110,7 +110,7 @@ void push_bend(pies_solver* s, const uint32_t ids[4], float w) {
   std::memcpy(b.ids, ids, sizeof(b.ids));
   const P3 x1 = node_pos(s, ids[0]);
   const P3 p2 = node_pos(s, ids[1]) - x1, p3 = node_pos(s, ids[2]) - x1, p4 = node_pos(s, ids[3]) - x1;
-  b.angle = std::acos(dot3(normalize3(cross3(p2, p3)), normalize3(cross3(p2, p4))));
+  b.angle = static_cast<float>(std::acos(static_cast<double>(dot3(normalize3(cross3(p2, p3)), normalize3(cross3(p2, p4))))));
   b.w = w;
   s->h_bend.push_back(b);
   ++s->constraintId;
