@@ -113,41 +113,55 @@ inline void mul_point(const mat4& M, const vec3& p, float out[4]) {
 // rounding cannot be reproduced.  What the hot path consumes is only  U * f(S) * V^T, which is
 // independent of the SVD algorithm and of the sign/order conventions of U and V; this routine
 // therefore restates the mathematical definition:  A*V = B with orthogonal columns,
-// s_i = |b_i|, u_i = b_i / s_i.   Fixed sweep count -> no data-dependent control flow.
+// s_i = |b_i|, u_i = b_i / s_i.
+//
+// Column pairs are rotated until every pair is orthogonal to working precision
+// (|b_p.b_q| <= kSvdTol * |b_p||b_q|), like Eigen's JacobiSVD sweeps until no off-diagonal exceeds
+// its threshold.  The rotation for a pair with a = |b_p|^2, b = |b_q|^2, g = b_p.b_q is the one
+// that zeroes the new inner product:  tan(theta) = sign(b-a)*2g / (|b-a| + sqrt((b-a)^2 + 4g^2)).
+// Products and sums inside this routine use fused multiply-adds (std::fmaf is exact and portable).
 // ---------------------------------------------------------------------------------------------
-#ifndef ORA_SVD_SWEEPS
-#define ORA_SVD_SWEEPS 5
+#ifndef ORA_SVD_MAX_SWEEPS
+#define ORA_SVD_MAX_SWEEPS 8
 #endif
-constexpr int kSvdSweeps = ORA_SVD_SWEEPS;
+constexpr int kSvdMaxSweeps = ORA_SVD_MAX_SWEEPS;
+#ifndef ORA_SVD_TOL
+#define ORA_SVD_TOL 4.76837158203125e-07f /* 4 * 2^-23 */
+#endif
+constexpr float kSvdTol2 = ORA_SVD_TOL * ORA_SVD_TOL;
 
 struct Svd3 {
   float b[3][3];  // b[i] = i-th column of A*V  (= s_i * u_i)
   float v[3][3];  // v[i] = i-th column of V
   float s[3];     // singular values (>= 0, unsorted)
+  int sweeps = 0;
 };
 
-inline void jacobi_pair(Svd3& d, int p, int q) {
+inline float dot3f(const float* x, const float* y) { return std::fmaf(x[2], y[2], std::fmaf(x[1], y[1], x[0] * y[0])); }
+
+inline bool jacobi_pair(Svd3& d, int p, int q) {
   float* bp = d.b[p];
   float* bq = d.b[q];
-  float alpha = bp[0] * bp[0] + bp[1] * bp[1] + bp[2] * bp[2];
-  float beta = bq[0] * bq[0] + bq[1] * bq[1] + bq[2] * bq[2];
-  float gamma = bp[0] * bq[0] + bp[1] * bq[1] + bp[2] * bq[2];
-  float cs = 1.0f, sn = 0.0f;
-  if (gamma != 0.0f) {
-    float zeta = (beta - alpha) / (2.0f * gamma);
-    float t = 1.0f / (std::fabs(zeta) + std::sqrt(1.0f + zeta * zeta));
-    if (zeta < 0.0f) t = -t;
-    cs = 1.0f / std::sqrt(1.0f + t * t);
-    sn = cs * t;
-  }
+  const float alpha = dot3f(bp, bp);
+  const float beta = dot3f(bq, bq);
+  const float gamma = dot3f(bp, bq);
+  if (!(gamma * gamma > kSvdTol2 * (alpha * beta))) return false;
+  const float delta = beta - alpha;
+  const float g2 = gamma + gamma;
+  const float h = std::sqrt(std::fmaf(delta, delta, g2 * g2));
+  const float c1 = h + std::fabs(delta);           // proportional to cos(theta)
+  const float s1 = delta < 0.0f ? -g2 : g2;        // proportional to sin(theta)
+  const float inv = 1.0f / std::sqrt(std::fmaf(c1, c1, s1 * s1));
+  const float cs = c1 * inv, sn = s1 * inv;
   for (int k = 0; k < 3; ++k) {
-    float x = bp[k], y = bq[k];
-    bp[k] = cs * x - sn * y;
-    bq[k] = sn * x + cs * y;
-    float vx = d.v[p][k], vy = d.v[q][k];
-    d.v[p][k] = cs * vx - sn * vy;
-    d.v[q][k] = sn * vx + cs * vy;
+    const float x = bp[k], y = bq[k];
+    bp[k] = std::fmaf(cs, x, -(sn * y));
+    bq[k] = std::fmaf(sn, x, cs * y);
+    const float vx = d.v[p][k], vy = d.v[q][k];
+    d.v[p][k] = std::fmaf(cs, vx, -(sn * vy));
+    d.v[q][k] = std::fmaf(sn, vx, cs * vy);
   }
+  return true;
 }
 
 // a[r][c] row-major input.
@@ -158,47 +172,49 @@ inline Svd3 svd3(const float a[3][3]) {
       d.b[i][k] = a[k][i];
       d.v[i][k] = (i == k) ? 1.0f : 0.0f;
     }
-  for (int sweep = 0; sweep < kSvdSweeps; ++sweep) {
-    jacobi_pair(d, 0, 1);
-    jacobi_pair(d, 0, 2);
-    jacobi_pair(d, 1, 2);
+  for (d.sweeps = 0; d.sweeps < kSvdMaxSweeps; ++d.sweeps) {
+    bool r01 = jacobi_pair(d, 0, 1);
+    bool r02 = jacobi_pair(d, 0, 2);
+    bool r12 = jacobi_pair(d, 1, 2);
+    if (!(r01 || r02 || r12)) break;
   }
-  for (int i = 0; i < 3; ++i)
-    d.s[i] = std::sqrt(d.b[i][0] * d.b[i][0] + d.b[i][1] * d.b[i][1] + d.b[i][2] * d.b[i][2]);
+  for (int i = 0; i < 3; ++i) d.s[i] = std::sqrt(dot3f(d.b[i], d.b[i]));
   return d;
 }
 
 constexpr float kSvdTiny = 1.0e-18f;
 
-// out[r][c] = sum_i u_i[r] * snew[i] * v_i[c], with u_i = b_i / s_i.  A direction whose singular
-// value underflows (collapsed element) gets u_i from the right-handed completion of the other two;
-// if two collapse the terms are dropped (the reference's result is arbitrary there as well).
+// out[r][c] = sum_i u_i[r] * snew[i] * v_i[c], with u_i = b_i / s_i, evaluated as
+// sum_i (b_i[r] * (snew[i]/s_i)) * v_i[c].  A direction whose singular value underflows (collapsed
+// element) gets u_i from the oriented completion of the other two; if two collapse the terms are
+// dropped (the reference's result is arbitrary there as well).
 inline void svd3_recompose(const Svd3& d, const float snew[3], float out[3][3]) {
-  float u[3][3];
+  float t[3][3];  // t[i] = u_i * snew[i]
   bool ok[3];
   int nbad = 0;
   for (int i = 0; i < 3; ++i) {
     ok[i] = d.s[i] > kSvdTiny;
     if (!ok[i]) ++nbad;
-    float inv = ok[i] ? 1.0f / d.s[i] : 0.0f;
-    for (int k = 0; k < 3; ++k) u[i][k] = d.b[i][k] * inv;
+    float g = ok[i] ? snew[i] / d.s[i] : 0.0f;
+    for (int k = 0; k < 3; ++k) t[i][k] = d.b[i][k] * g;
   }
   if (nbad == 1) {
     int k = !ok[0] ? 0 : (!ok[1] ? 1 : 2);
     int i = (k + 1) % 3, j = (k + 2) % 3;
+    float ui[3], uj[3];
+    for (int c = 0; c < 3; ++c) { ui[c] = d.b[i][c] / d.s[i]; uj[c] = d.b[j][c] / d.s[j]; }
     // orientation of the completion follows det(V): keeps det(U)*det(V) = +1
     float detv = d.v[0][0] * (d.v[1][1] * d.v[2][2] - d.v[1][2] * d.v[2][1]) -
                  d.v[0][1] * (d.v[1][0] * d.v[2][2] - d.v[1][2] * d.v[2][0]) +
                  d.v[0][2] * (d.v[1][0] * d.v[2][1] - d.v[1][1] * d.v[2][0]);
-    float sg = detv < 0.0f ? -1.0f : 1.0f;
-    u[k][0] = sg * (u[i][1] * u[j][2] - u[i][2] * u[j][1]);
-    u[k][1] = sg * (u[i][2] * u[j][0] - u[i][0] * u[j][2]);
-    u[k][2] = sg * (u[i][0] * u[j][1] - u[i][1] * u[j][0]);
+    float sg = (detv < 0.0f ? -1.0f : 1.0f) * snew[k];
+    t[k][0] = sg * (ui[1] * uj[2] - ui[2] * uj[1]);
+    t[k][1] = sg * (ui[2] * uj[0] - ui[0] * uj[2]);
+    t[k][2] = sg * (ui[0] * uj[1] - ui[1] * uj[0]);
   }
   for (int r = 0; r < 3; ++r)
     for (int c = 0; c < 3; ++c)
-      out[r][c] = (u[0][r] * snew[0]) * d.v[0][c] + (u[1][r] * snew[1]) * d.v[1][c] +
-                  (u[2][r] * snew[2]) * d.v[2][c];
+      out[r][c] = std::fmaf(t[2][r], d.v[2][c], std::fmaf(t[1][r], d.v[1][c], t[0][r] * d.v[0][c]));
 }
 
 }  // namespace ora

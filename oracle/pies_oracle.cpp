@@ -1288,7 +1288,7 @@ void ora_tick(ora_solver* s) { s->tick(); }
 
 // ------------------------------- single-operation entry points (KATs) ------------------------
 // a: row-major 3x3; out: row-major U*diag(snew)*V^T with snew = clamp(s) (+ flip) as the tet functor
-void ora_svd3(const float* a, float* s_out, float* b_out, float* v_out) {
+int ora_svd3(const float* a, float* s_out, float* b_out, float* v_out) {
   float A[3][3];
   for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) A[r][c] = a[3 * r + c];
   Svd3 d = svd3(A);
@@ -1296,6 +1296,15 @@ void ora_svd3(const float* a, float* s_out, float* b_out, float* v_out) {
     s_out[i] = d.s[i];
     for (int k = 0; k < 3; ++k) { b_out[3 * i + k] = d.b[i][k]; v_out[3 * i + k] = d.v[i][k]; }
   }
+  return d.sweeps;
+}
+// out (row-major) = U * diag(snew) * V^T for the decomposition of a
+void ora_svd3_recompose(const float* a, const float* snew, float* out) {
+  float A[3][3], O[3][3];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) A[r][c] = a[3 * r + c];
+  Svd3 d = svd3(A);
+  svd3_recompose(d, snew, O);
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) out[3 * r + c] = O[r][c];
 }
 static std::vector<Node> four(const float* x) {
   std::vector<Node> n(4);

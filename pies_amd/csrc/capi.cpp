@@ -133,6 +133,15 @@ static int capture_graph(pies_solver* s) {
   destroy_graph(s);
   std::memset(s->launchCounts, 0, sizeof(s->launchCounts));
   if (s->nd.n == 0) return PIES_OK;
+  if (const char* e = std::getenv("PIES_NO_GRAPH"); e && e[0] == '1') {
+    // count launches without running them: a capture that is thrown away
+    HIP_TRY(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    enqueue_pbd_substep(s, -1, nullptr, s->launchCounts);
+    hipGraph_t tmp = nullptr;
+    HIP_TRY(s, hipStreamEndCapture(s->stream, &tmp));
+    if (tmp) (void)hipGraphDestroy(tmp);
+    return PIES_OK;
+  }
   HIP_TRY(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
   enqueue_pbd_substep(s, -1, nullptr, s->launchCounts);
   hipError_t e = hipStreamEndCapture(s->stream, &s->graph);
@@ -361,7 +370,10 @@ int pies_tick_async(pies_solver_t* s) {
     if (int rc = pies_finalize(s)) return rc;
   HIP_TRY(s, hipSetDevice(s->device));
   if (s->nd.n == 0) return PIES_OK;
-  for (uint32_t sub = 0; sub < s->opt.timeSubsteps; ++sub) HIP_TRY(s, hipGraphLaunch(s->graphExec, s->stream));
+  for (uint32_t sub = 0; sub < s->opt.timeSubsteps; ++sub) {
+    if (s->graphExec) HIP_TRY(s, hipGraphLaunch(s->graphExec, s->stream));
+    else enqueue_pbd_substep(s, -1, nullptr, nullptr);  // PIES_NO_GRAPH=1: eager launches (debug / tracing)
+  }
   s->deviceAhead = true;
   return PIES_OK;
 }

@@ -10,7 +10,13 @@ namespace pies {
 
 #define PIES_DEV __device__ __forceinline__
 
-constexpr int kSvdSweeps = 5;       // one-sided Jacobi sweeps; 4 already reach fp32 round-off on 3x3
+// One-sided (Hestenes) Jacobi SVD of a 3x3: column pairs of B = A*V are rotated until every pair is
+// orthogonal to working precision, |b_p.b_q| <= kSvdTol |b_p||b_q|  (at most kSvdMaxSweeps sweeps; a
+// typical deformation gradient needs 2-3 rotating sweeps plus the final check sweep).  Per rotation:
+// 2 sqrt + 1 division, everything else fused multiply-adds.
+constexpr int kSvdMaxSweeps = 8;
+constexpr float kSvdTol = 4.76837158203125e-07f;  // 4 * 2^-23
+constexpr float kSvdTol2 = kSvdTol * kSvdTol;
 constexpr float kSvdTiny = 1.0e-18f;
 
 struct Svd3 {
@@ -19,27 +25,30 @@ struct Svd3 {
   float s[3];
 };
 
-template <int P, int Q> PIES_DEV void jacobi_pair(Svd3& d) {
-  const float alpha = d.b[P][0] * d.b[P][0] + d.b[P][1] * d.b[P][1] + d.b[P][2] * d.b[P][2];
-  const float beta = d.b[Q][0] * d.b[Q][0] + d.b[Q][1] * d.b[Q][1] + d.b[Q][2] * d.b[Q][2];
-  const float gamma = d.b[P][0] * d.b[Q][0] + d.b[P][1] * d.b[Q][1] + d.b[P][2] * d.b[Q][2];
-  float cs = 1.0f, sn = 0.0f;
-  if (gamma != 0.0f) {
-    const float zeta = (beta - alpha) / (2.0f * gamma);
-    float t = 1.0f / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));
-    if (zeta < 0.0f) t = -t;
-    cs = 1.0f / sqrtf(1.0f + t * t);
-    sn = cs * t;
-  }
+PIES_DEV float dot3f(const float x[3], const float y[3]) { return fmaf(x[2], y[2], fmaf(x[1], y[1], x[0] * y[0])); }
+
+template <int P, int Q> PIES_DEV bool jacobi_pair(Svd3& d) {
+  const float alpha = dot3f(d.b[P], d.b[P]);
+  const float beta = dot3f(d.b[Q], d.b[Q]);
+  const float gamma = dot3f(d.b[P], d.b[Q]);
+  if (!(gamma * gamma > kSvdTol2 * (alpha * beta))) return false;
+  const float delta = beta - alpha;
+  const float g2 = gamma + gamma;
+  const float h = sqrtf(fmaf(delta, delta, g2 * g2));
+  const float c1 = h + fabsf(delta);        // ~ cos(theta)
+  const float s1 = delta < 0.0f ? -g2 : g2; // ~ sin(theta):  tan = sign(delta)*2g / (|delta| + h)
+  const float inv = 1.0f / sqrtf(fmaf(c1, c1, s1 * s1));
+  const float cs = c1 * inv, sn = s1 * inv;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const float x = d.b[P][k], y = d.b[Q][k];
-    d.b[P][k] = cs * x - sn * y;
-    d.b[Q][k] = sn * x + cs * y;
+    d.b[P][k] = fmaf(cs, x, -(sn * y));
+    d.b[Q][k] = fmaf(sn, x, cs * y);
     const float vx = d.v[P][k], vy = d.v[Q][k];
-    d.v[P][k] = cs * vx - sn * vy;
-    d.v[Q][k] = sn * vx + cs * vy;
+    d.v[P][k] = fmaf(cs, vx, -(sn * vy));
+    d.v[Q][k] = fmaf(sn, vx, cs * vy);
   }
+  return true;
 }
 
 // a[r][c]: row-major input.  A*V = B with orthogonal columns; s_i = |b_i|.
@@ -51,53 +60,57 @@ PIES_DEV void svd3(const float a[3][3], Svd3& d) {
       d.b[i][k] = a[k][i];
       d.v[i][k] = (i == k) ? 1.0f : 0.0f;
     }
-#pragma unroll
-  for (int sweep = 0; sweep < kSvdSweeps; ++sweep) {
-    jacobi_pair<0, 1>(d);
-    jacobi_pair<0, 2>(d);
-    jacobi_pair<1, 2>(d);
+  for (int sweep = 0; sweep < kSvdMaxSweeps; ++sweep) {
+    const bool r01 = jacobi_pair<0, 1>(d);
+    const bool r02 = jacobi_pair<0, 2>(d);
+    const bool r12 = jacobi_pair<1, 2>(d);
+    if (!(r01 || r02 || r12)) break;
   }
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
-    d.s[i] = sqrtf(d.b[i][0] * d.b[i][0] + d.b[i][1] * d.b[i][1] + d.b[i][2] * d.b[i][2]);
+  for (int i = 0; i < 3; ++i) d.s[i] = sqrtf(dot3f(d.b[i], d.b[i]));
 }
 
-template <int K, int I, int J> PIES_DEV void complete_u(float u[3][3], float sg) {
-  u[K][0] = sg * (u[I][1] * u[J][2] - u[I][2] * u[J][1]);
-  u[K][1] = sg * (u[I][2] * u[J][0] - u[I][0] * u[J][2]);
-  u[K][2] = sg * (u[I][0] * u[J][1] - u[I][1] * u[J][0]);
+template <int K, int I, int J> PIES_DEV void complete_t(const Svd3& d, float t[3][3], float sg) {
+  float ui[3], uj[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    ui[c] = d.b[I][c] / d.s[I];
+    uj[c] = d.b[J][c] / d.s[J];
+  }
+  t[K][0] = sg * (ui[1] * uj[2] - ui[2] * uj[1]);
+  t[K][1] = sg * (ui[2] * uj[0] - ui[0] * uj[2]);
+  t[K][2] = sg * (ui[0] * uj[1] - ui[1] * uj[0]);
 }
 
-// out[r][c] = sum_i (u_i[r] * snew[i]) * v_i[c],  u_i = b_i / s_i.  A collapsed direction
-// (s_i <= kSvdTiny) gets u_i from the oriented completion of the other two; two collapsed
+// out[r][c] = sum_i (b_i[r] * snew[i]/s_i) * v_i[c]  ( = U diag(snew) V^T ).  A collapsed direction
+// (s_i <= kSvdTiny) takes u_i from the oriented completion of the other two; two collapsed
 // directions are dropped.
 PIES_DEV void svd3_recompose(const Svd3& d, const float snew[3], float out[3][3]) {
-  float u[3][3];
+  float t[3][3];
   const bool ok0 = d.s[0] > kSvdTiny, ok1 = d.s[1] > kSvdTiny, ok2 = d.s[2] > kSvdTiny;
-  const float i0 = ok0 ? 1.0f / d.s[0] : 0.0f;
-  const float i1 = ok1 ? 1.0f / d.s[1] : 0.0f;
-  const float i2 = ok2 ? 1.0f / d.s[2] : 0.0f;
+  const float g0 = ok0 ? snew[0] / d.s[0] : 0.0f;
+  const float g1 = ok1 ? snew[1] / d.s[1] : 0.0f;
+  const float g2 = ok2 ? snew[2] / d.s[2] : 0.0f;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    u[0][k] = d.b[0][k] * i0;
-    u[1][k] = d.b[1][k] * i1;
-    u[2][k] = d.b[2][k] * i2;
+    t[0][k] = d.b[0][k] * g0;
+    t[1][k] = d.b[1][k] * g1;
+    t[2][k] = d.b[2][k] * g2;
   }
   const int nbad = (ok0 ? 0 : 1) + (ok1 ? 0 : 1) + (ok2 ? 0 : 1);
   if (nbad == 1) {  // rare: a flattened element
     const float detv = d.v[0][0] * (d.v[1][1] * d.v[2][2] - d.v[1][2] * d.v[2][1]) -
                        d.v[0][1] * (d.v[1][0] * d.v[2][2] - d.v[1][2] * d.v[2][0]) +
                        d.v[0][2] * (d.v[1][0] * d.v[2][1] - d.v[1][1] * d.v[2][0]);
-    const float sg = detv < 0.0f ? -1.0f : 1.0f;
-    if (!ok0) complete_u<0, 1, 2>(u, sg);
-    else if (!ok1) complete_u<1, 2, 0>(u, sg);
-    else complete_u<2, 0, 1>(u, sg);
+    const float sgn = detv < 0.0f ? -1.0f : 1.0f;
+    if (!ok0) complete_t<0, 1, 2>(d, t, sgn * snew[0]);
+    else if (!ok1) complete_t<1, 2, 0>(d, t, sgn * snew[1]);
+    else complete_t<2, 0, 1>(d, t, sgn * snew[2]);
   }
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-      out[r][c] = (u[0][r] * snew[0]) * d.v[0][c] + (u[1][r] * snew[1]) * d.v[1][c] + (u[2][r] * snew[2]) * d.v[2][c];
+    for (int c = 0; c < 3; ++c) out[r][c] = fmaf(t[2][r], d.v[2][c], fmaf(t[1][r], d.v[1][c], t[0][r] * d.v[0][c]));
 }
 
 PIES_DEV float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }

@@ -11,23 +11,29 @@
 // there is no GEMM-shaped work, hence no MFMA.
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
+
 #include "dev_math.h"
 #include "kernels.h"
 
 namespace pies {
 
-constexpr int kBlock = 256;  // 4 waves of 64
+constexpr int kBlock = 256;  // streaming kernels: 4 waves of 64
+#ifndef PIES_PROJ_BLOCK
+#define PIES_PROJ_BLOCK 256
+#endif
+constexpr int kProjBlock = PIES_PROJ_BLOCK;  // projection kernels (64 measured no faster at 100k, slower at 1M)
 
-static inline dim3 grid_for(uint32_t n) { return dim3((n + kBlock - 1) / kBlock); }
+static inline dim3 grid_for(uint32_t n, int block) { return dim3((n + block - 1) / block); }
 
-#define PIES_LAUNCH(kernel, n_items, st, timer, ...)                                                        \
+#define PIES_LAUNCH(kernel, block, n_items, st, timer, ...)                                                        \
   do {                                                                                                      \
     hipEvent_t ev_a__, ev_b__;                                                                              \
     if ((timer) != nullptr && (timer)->next(&ev_a__, &ev_b__)) {                                            \
       (timer)->units += (n_items);                                                                          \
-      hipExtLaunchKernelGGL(kernel, grid_for(n_items), dim3(kBlock), 0, st, ev_a__, ev_b__, 0, __VA_ARGS__); \
+      hipExtLaunchKernelGGL(kernel, grid_for(n_items, block), dim3(block), 0, st, ev_a__, ev_b__, 0, __VA_ARGS__); \
     } else {                                                                                                \
-      hipLaunchKernelGGL(kernel, grid_for(n_items), dim3(kBlock), 0, st, __VA_ARGS__);                      \
+      hipLaunchKernelGGL(kernel, grid_for(n_items, block), dim3(block), 0, st, __VA_ARGS__);                  \
     }                                                                                                       \
   } while (0)
 
@@ -90,9 +96,9 @@ __global__ void __launch_bounds__(kBlock) k_velocity(const float4* __restrict__ 
 // ----------------------------------------------------------------------------------------------
 // PositionConstraint (Constraints.cpp:58-63 through Constraints.h:121-129): pos += w*(fixed - pos)
 // ----------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_position(float4* __restrict__ pos, const uint32_t* __restrict__ ids,
+__global__ void __launch_bounds__(kProjBlock) k_position(float4* __restrict__ pos, const uint32_t* __restrict__ ids,
                                                      const float4* __restrict__ target_w, uint32_t start, uint32_t count) {
-  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t t = blockIdx.x * kProjBlock + threadIdx.x;
   if (t >= count) return;
   const uint32_t c = start + t;
   const uint32_t id = ids[c];
@@ -108,9 +114,9 @@ __global__ void __launch_bounds__(kBlock) k_position(float4* __restrict__ pos, c
 // DistanceConstraint (Constraints.cpp:11-37): only node a moves, by the full correction.
 // 52 algorithmic B/projection: ids 8 + rest,w 8 + two position reads 24 + one position write 12.
 // ----------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_distance(float4* __restrict__ pos, const uint2* __restrict__ ids,
+__global__ void __launch_bounds__(kProjBlock) k_distance(float4* __restrict__ pos, const uint2* __restrict__ ids,
                                                      const float2* __restrict__ rest_w, uint32_t start, uint32_t count) {
-  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t t = blockIdx.x * kProjBlock + threadIdx.x;
   if (t >= count) return;
   const uint32_t c = start + t;
   const uint2 id = ids[c];
@@ -138,10 +144,11 @@ __global__ void __launch_bounds__(kBlock) k_distance(float4* __restrict__ pos, c
 // 160 algorithmic B/projection: ids 16 + Qinv 36 + (min,max,w) 12 + 4 position reads 48 + 4 writes 48.
 // Record layout: q0 = Qinv col0 + Qinv[1][0], q1 = Qinv[1][1..2] + Qinv[2][0..1], q2 = Qinv[2][2], min, max, w.
 // ----------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_tet(float4* __restrict__ pos, const uint4* __restrict__ ids,
+template <int VARIANT>
+__global__ void __launch_bounds__(kProjBlock) k_tet(float4* __restrict__ pos, const uint4* __restrict__ ids,
                                                 const float4* __restrict__ q0, const float4* __restrict__ q1,
                                                 const float4* __restrict__ q2, uint32_t start, uint32_t count) {
-  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t t = blockIdx.x * kProjBlock + threadIdx.x;
   if (t >= count) return;
   const uint32_t c = start + t;
   const uint4 id = ids[c];
@@ -156,6 +163,11 @@ __global__ void __launch_bounds__(kBlock) k_tet(float4* __restrict__ pos, const 
   float F[3][3];
   mat3_mul_cm(P, qi, F);
   // the reference hands Eigen the matrix F_(r,c) = F[r][c] (Constraints.cpp:93-95)
+  if (VARIANT == 1) {  // experiment: no SVD at all (memory/latency floor)
+    x2.x += w * (F[0][0] - x2.x); x3.y += w * (F[1][1] - x3.y); x4.z += w * (F[2][2] - x4.z); x1.x += w * (F[0][1] - x1.x);
+    pos[id.x] = x1; pos[id.y] = x2; pos[id.z] = x3; pos[id.w] = x4;
+    return;
+  }
   Svd3 d;
   svd3(F, d);
   float s[3];
@@ -207,9 +219,9 @@ PIES_DEV V3 mulv(const V3& a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 PIES_DEV V3 divv(const V3& a, float s) { return {a.x / s, a.y / s, a.z / s}; }
 PIES_DEV V3 negv(const V3& a) { return {-a.x, -a.y, -a.z}; }
 
-__global__ void __launch_bounds__(kBlock) k_bend(float4* __restrict__ pos, const uint4* __restrict__ ids,
+__global__ void __launch_bounds__(kProjBlock) k_bend(float4* __restrict__ pos, const uint4* __restrict__ ids,
                                                  const float2* __restrict__ angle_w, uint32_t start, uint32_t count) {
-  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t t = blockIdx.x * kProjBlock + threadIdx.x;
   if (t >= count) return;
   const uint32_t c = start + t;
   const uint4 id = ids[c];
@@ -250,36 +262,38 @@ __global__ void __launch_bounds__(kBlock) k_bend(float4* __restrict__ pos, const
 // ----------------------------------------------------------------------------------------------
 void launch_predict(hipStream_t st, const NodeArrays& nd, float dt, float gravity, LaunchTimer* t) {
   if (nd.n == 0) return;
-  PIES_LAUNCH(k_predict, nd.n, st, t, nd.pos, nd.prev, nd.vel, nd.n, dt, gravity);
+  PIES_LAUNCH(k_predict, kBlock, nd.n, st, t, nd.pos, nd.prev, nd.vel, nd.n, dt, gravity);
 }
 void launch_floor(hipStream_t st, const NodeArrays& nd, float floorHeight, LaunchTimer* t) {
   if (nd.n == 0) return;
-  PIES_LAUNCH(k_floor, nd.n, st, t, nd.pos, nd.radius, nd.n, floorHeight);
+  PIES_LAUNCH(k_floor, kBlock, nd.n, st, t, nd.pos, nd.radius, nd.n, floorHeight);
 }
 void launch_velocity(hipStream_t st, const NodeArrays& nd, float dt, float damping, float friction, float floorHeight,
                      LaunchTimer* t) {
   if (nd.n == 0) return;
-  PIES_LAUNCH(k_velocity, nd.n, st, t, nd.pos, nd.prev, nd.vel, nd.radius, nd.n, dt, damping, friction, floorHeight);
+  PIES_LAUNCH(k_velocity, kBlock, nd.n, st, t, nd.pos, nd.prev, nd.vel, nd.radius, nd.n, dt, damping, friction, floorHeight);
 }
 void launch_position(hipStream_t st, float4* pos, const uint32_t* ids, const float4* target_w, uint32_t start,
                      uint32_t count, LaunchTimer* t) {
   if (count == 0) return;
-  PIES_LAUNCH(k_position, count, st, t, pos, ids, target_w, start, count);
+  PIES_LAUNCH(k_position, kProjBlock, count, st, t, pos, ids, target_w, start, count);
 }
 void launch_distance(hipStream_t st, float4* pos, const uint2* ids, const float2* rest_w, uint32_t start, uint32_t count,
                      LaunchTimer* t) {
   if (count == 0) return;
-  PIES_LAUNCH(k_distance, count, st, t, pos, ids, rest_w, start, count);
+  PIES_LAUNCH(k_distance, kProjBlock, count, st, t, pos, ids, rest_w, start, count);
 }
 void launch_tet(hipStream_t st, float4* pos, const uint4* ids, const float4* q0, const float4* q1, const float4* q2,
                 uint32_t start, uint32_t count, LaunchTimer* t) {
   if (count == 0) return;
-  PIES_LAUNCH(k_tet, count, st, t, pos, ids, q0, q1, q2, start, count);
+  static const int variant = [] { const char* e = getenv("PIES_EXP_TET"); return e ? atoi(e) : 0; }();
+  if (variant == 1) { PIES_LAUNCH(k_tet<1>, kProjBlock, count, st, t, pos, ids, q0, q1, q2, start, count); return; }
+  PIES_LAUNCH(k_tet<0>, kProjBlock, count, st, t, pos, ids, q0, q1, q2, start, count);
 }
 void launch_bend(hipStream_t st, float4* pos, const uint4* ids, const float2* angle_w, uint32_t start, uint32_t count,
                  LaunchTimer* t) {
   if (count == 0) return;
-  PIES_LAUNCH(k_bend, count, st, t, pos, ids, angle_w, start, count);
+  PIES_LAUNCH(k_bend, kProjBlock, count, st, t, pos, ids, angle_w, start, count);
 }
 
 }  // namespace pies
