@@ -508,7 +508,7 @@ struct BandedLLT {
   }
 
   bool factor(const SparseSym& A) {
-    const size_t W = bw + 1;
+    const ptrdiff_t W = static_cast<ptrdiff_t>(bw) + 1;
     L.assign(static_cast<size_t>(n) * W, 0.0f);
     for (uint32_t io = 0; io < n; ++io)
       for (auto& kv : A.rows[io]) {
@@ -517,9 +517,9 @@ struct BandedLLT {
       }
     for (uint32_t i = 0; i < n; ++i) {
       uint32_t j0 = i > bw ? i - bw : 0;
-      float* Li = &L[i * W + (bw - i)];  // Li[j] valid for j0 <= j <= i
+      float* Li = L.data() + (static_cast<ptrdiff_t>(i) * W + bw - i);  // Li[j] valid for j0 <= j <= i
       for (uint32_t j = j0; j <= i; ++j) {
-        const float* Lj = &L[j * W + (bw - j)];
+        const float* Lj = L.data() + (static_cast<ptrdiff_t>(j) * W + bw - j);
         uint32_t k0 = std::max(j0, j > bw ? j - bw : 0u);
         float s = Li[j];
         for (uint32_t k = k0; k < j; ++k) s -= Li[k] * Lj[k];
@@ -536,11 +536,11 @@ struct BandedLLT {
 
   // x (old ordering, stride 1 column) <- A^-1 b
   void solve(const float* b, float* x) const {
-    const size_t W = bw + 1;
+    const ptrdiff_t W = static_cast<ptrdiff_t>(bw) + 1;
     std::vector<float> y(n);
     for (uint32_t i = 0; i < n; ++i) {
       uint32_t j0 = i > bw ? i - bw : 0;
-      const float* Li = &L[i * W + (bw - i)];
+      const float* Li = L.data() + (static_cast<ptrdiff_t>(i) * W + bw - i);
       float s = b[perm[i]];
       for (uint32_t k = j0; k < i; ++k) s -= Li[k] * y[k];
       y[i] = s / Li[i];

@@ -1,0 +1,184 @@
+"""Pins the CPU oracle (oracle/pies_oracle.cpp) -- the reference has no tests or fixtures ("parity
+unpinned"), so the pins are fp64 golden vectors (tests/golden/make_golden.py) and analytic known answers.
+
+Tolerances: a single projection against fp64: 2e-5 absolute on O(1) values (fp32 SVD); whole-loop tiny
+scenes: 2e-4 * spacing after <= 6 ticks (fp32 vs fp64 drift)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_api as O
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+def test_svd_fixed_against_fp64():
+    d = load("svd_fixed.npz")
+    worst = 0.0
+    for A, exp in zip(d["A"], d["expected"]):
+        # the tet functor on a unit reference tet at the origin reproduces fixed(F): x = (0, F cols), Qinv = I
+        x = np.vstack([np.zeros(3, np.float32), A.T])
+        out = O.project_tet(x, np.eye(3, dtype=np.float32).reshape(9), float(d["lo"]), float(d["hi"]))
+        Fh = out[1:].T
+        cond = np.linalg.cond(A.astype(np.float64))
+        tol = 2e-5 if cond < 1e3 else 2e-4
+        err = np.abs(Fh - exp).max()
+        assert err <= tol, (err, cond)
+        worst = max(worst, err)
+    assert worst > 0  # not trivially identical
+
+
+@pytest.mark.parametrize("name,fn", [("tet_projection.npz", O.project_tet), ("volume_projection.npz", O.project_volume)])
+def test_tet_and_volume_projection_against_fp64(name, fn):
+    d = load(name)
+    for x, q, exp in zip(d["x"], d["qinv"], d["expected"]):
+        out = fn(x, q, float(d["lo"]), float(d["hi"]))
+        scale = max(1.0, np.abs(exp).max())
+        assert np.abs(out - exp).max() <= 5e-5 * scale
+
+
+def test_distance_projection_against_fp64():
+    d = load("distance_projection.npz")
+    for x, t, exp in zip(d["x"], d["target"], d["expected"]):
+        out = O.project_distance(x, float(t))
+        assert np.abs(out - exp).max() <= 1e-5
+        if np.linalg.norm(x[1] - x[0]) > 1e-3:
+            assert abs(np.linalg.norm(out[1] - out[0]) - t) <= 1e-5  # |pa - pb| = target
+        assert np.array_equal(out[1], x[1])  # node b never moves (Constraints.cpp:34-36)
+
+
+def test_bend_projection_against_fp64():
+    d = load("bend_projection.npz")
+    for x, im, a, exp in zip(d["x"], d["invMass"], d["angle"], d["expected"]):
+        out = O.project_bend(x, im, float(a))
+        scale = max(1.0, np.abs(exp - x).max())
+        assert np.abs(out - exp).max() <= 2e-4 * scale
+
+
+# ---- analytic known answers --------------------------------------------------------------------
+REST = np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]])
+
+
+def test_rest_tet_projects_to_identity_columns():
+    q, AtA = O.tet_rest(REST)
+    assert np.allclose(q.reshape(3, 3), np.eye(3))
+    out = O.project_tet(REST, q)
+    assert np.allclose(out, np.vstack([np.zeros(3), np.eye(3)]), atol=1e-6)
+    # A = [0; Qinv^T D] with D = [-1 1 0 0; -1 0 1 0; -1 0 0 1]  =>  A^T A for the unit tet
+    A = np.zeros((4, 4)); A[1:] = np.array([[-1, 1, 0, 0], [-1, 0, 1, 0], [-1, 0, 0, 1]])
+    assert np.allclose(AtA, A.T @ A)
+
+
+@pytest.mark.parametrize("s,expect", [(0.5, 0.8), (0.9, 0.9), (1.7, 1.0)])
+def test_uniformly_scaled_tet_is_clamped(s, expect):
+    q, _ = O.tet_rest(REST)
+    out = O.project_tet(REST * np.float32(s), q)
+    assert np.allclose(out[1:], expect * np.eye(3), atol=2e-6)
+
+
+def test_rotated_tet_keeps_rotation():
+    q, _ = O.tet_rest(REST)
+    c, s = np.cos(0.7), np.sin(0.7)
+    R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+    x = (REST.astype(np.float64) @ R.T * 1.3 + [3, 1, -2]).astype(np.float32)
+    out = O.project_tet(x, q)
+    assert np.allclose(out[1:].T, R, atol=3e-6)  # F = 1.3 R -> clamp to 1.0 -> R (columns)
+
+
+def test_mirrored_tet_flips_smallest_singular_value():
+    q, _ = O.tet_rest(REST)
+    # F = diag(1,1,-0.9) = U S V^T with U = diag(1,1,-1): negating sigma_3 (Constraints.cpp:106-108)
+    # un-inverts the element: Fhat = U diag(1,1,-0.9) V^T = diag(1,1,+0.9), det > 0
+    x = REST.copy(); x[3, 2] = -0.9
+    out = O.project_tet(x, q)
+    assert np.allclose(out[1:].T, np.diag([1, 1, 0.9]), atol=2e-6)
+
+
+def test_volume_projection_restores_unit_volume():
+    q, _ = O.tet_rest(REST)
+    x = REST * np.float32([1.2, 0.9, 1.1])
+    out = O.project_volume(x, q, 1.0, 1.0)
+    assert abs(np.linalg.det(out[1:].T.astype(np.float64)) - 1.0) < 1e-5
+    assert np.allclose(O.project_volume(REST, q, 1.0, 1.0)[1:], np.eye(3), atol=1e-6)  # idempotent at rest
+
+
+def test_node_range_matches_definition():
+    # Solver.cpp:877-901 with r = 0.5, pad 0.5, scale 2: R = 0.5 grid units
+    r = O.node_range([2.2, -0.1, 7.9], 0.5, 2.0)
+    assert r.tolist() == [0, -1, 3, 2, 2, 2]  # e.g. y: min = -0.05 - 0.5 = -0.55 -> cell -1, ceil(0.45 + 1) = 2
+    assert O.node_range([0, 0, 0], 200.0, 2.0)[3:].tolist() == [0, 0, 0]  # > 50 cells: empty range
+
+
+# ---- whole-loop restatements on tiny scenes -----------------------------------------------------
+def _tiny_pbd(d):
+    W, H, D = (int(v) for v in d["dims"])
+    o = O.OracleSolver(solver=O.PBD, iterations=int(d["iterations"]))
+    o.create_tet_box(W, H, D, translation=d["translation"], scale=float(d["spacing"]), w=float(d["w_tet"]), volume=False,
+                     triangles=False)
+    o.create_box(W, H, D, scale=float(d["spacing"]), w=float(d["w_dist"]), existing_offset=0, triangles=False)
+    o.set_radii(np.full(W * H * D, d["radius"], np.float32))
+    o.set_flag(O.FLAG_NODE_COLLISIONS, int(d["collisions"]))
+    return o
+
+
+@pytest.mark.parametrize("coll", [0, 1])
+def test_pbd_tiny_scene_against_fp64_restatement(coll):
+    """One tick at a time from the stored float32 state (the PBD dynamics amplify rounding noise ~100x per
+    tick, see make_golden.py); tolerance 2e-4 * spacing per tick."""
+    d = load("pbd_tiny_coll%d.npz" % coll)
+    o = _tiny_pbd(d)
+    for t in range(len(d["pos"]) - 1):
+        o.set_positions(d["pos"][t]); o.set_velocities(d["vel"][t])
+        o.tick()
+        assert np.abs(o.positions - d["pos"][t + 1]).max() <= 2e-4, t
+        assert np.abs(o.velocities - d["vel"][t + 1]).max() <= 2e-4 / 0.012, t
+    if coll:
+        assert o.collision_pairs > 0
+
+
+def test_pd_tiny_scene_against_fp64_restatement():
+    d = load("pd_tiny.npz")
+    W, H, D = (int(v) for v in d["dims"])
+    o = O.OracleSolver(solver=O.PD, iterations=int(d["iterations"]))
+    o.create_tet_box(W, H, D, translation=d["translation"], w=1.0, volume=True, triangles=True)
+    o.add_position(d["pins"], float(d["w_pin"]))
+    o.set_positions(d["pos"]); o.set_prev_positions(d["pos"]); o.set_velocities(d["vel"])
+    for exp in d["expected"]:
+        o.tick()
+        assert np.abs(o.positions - exp).max() <= 2e-4
+    assert o.count(O.STATICS) > 0  # the floor contacts were exercised
+
+
+def test_pd_rest_state_is_a_fixed_point_without_gravity():
+    o = O.OracleSolver(solver=O.PD, iterations=3, gravity=0.0)
+    o.create_tet_box(3, 3, 3, translation=(0, 5, 0), w=1.0)
+    p0 = o.positions
+    o.tick(3)
+    assert np.abs(o.positions - p0).max() < 5e-5  # fp32 round-off of the M/h^2-weighted solve, no drift
+
+
+def test_pbd_free_fall_and_floor():
+    o = O.OracleSolver(solver=O.PBD, iterations=2)
+    o.addNodes([[0, 3, 0]])
+    o.set_flag(O.FLAG_NODE_COLLISIONS, 0)
+    o.tick()
+    dt = 0.012
+    assert np.allclose(o.positions[0], [0, 3 - 10 * dt * dt, 0], atol=1e-6)
+    assert np.allclose(o.velocities[0], [0, (1 - 0.006) * (-10 * dt), 0], atol=1e-5)
+    o.tick(400)
+    assert abs(o.positions[0, 1] - 0.5) < 1e-6  # rests on the floor at y = radius
+
+
+def test_two_overlapping_spheres_are_pushed_apart():
+    # Solver.cpp:85-130: each ordered pair in each shared cell relaxes 85 % of the overlap
+    o = O.OracleSolver(solver=O.PBD, iterations=1, gravity=0.0)
+    o.addNodes([[0.0, 5, 0], [0.8, 5, 0]])
+    o.tick()
+    p = o.positions
+    assert p[1, 0] - p[0, 0] > 0.8 and abs((p[0, 0] + p[1, 0]) - 0.8) < 1e-6
+    assert o.collision_pairs >= 2
