@@ -128,6 +128,12 @@ int pies_create_bend_sheet(pies_solver_t* s, uint32_t W, uint32_t H, const float
 /* ---- configuration -------------------------------------------------------------------------- */
 int pies_set_flag(pies_solver_t* s, int flag, int value);
 int pies_set_schedule(pies_solver_t* s, int schedule);
+/* PD global step: the reference solves (K + C) x = rhs with a sparse Cholesky factorisation rebuilt every
+ * substep (Solver.cpp:258-262,356); here it is a Jacobi-preconditioned CG.  rel_tol bounds ||r||/||rhs|| per
+ * coordinate column, max_iters is the number of CG iterations captured per solve (defaults 3e-7, 12). */
+int pies_set_pcg(pies_solver_t* s, float rel_tol, uint32_t max_iters);
+/* Over the last tick: largest ||r||/||rhs|| left by any solve, most CG iterations any solve used, solves run. */
+int pies_get_pcg_stats(pies_solver_t* s, float* max_rel_residual, uint32_t* max_iters_used, uint32_t* solves);
 /* Builds schedules, uploads to HBM and captures the substep graph.  Called implicitly by pies_tick
  * when the scene changed. */
 int pies_finalize(pies_solver_t* s);
@@ -157,8 +163,9 @@ int pies_get_order(pies_solver_t* s, int type, uint32_t* order, uint32_t capacit
 int pies_get_batches(pies_solver_t* s, int type, uint32_t* batch_offsets, uint32_t capacity, uint32_t* n_batches);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
-/* One un-graphed substep in which every launch of kernel class `kernel` is bracketed by the dispatch's
- * own start/stop timestamps (hipExtLaunchKernelGGL).  Returns launches and summed device time. */
+/* One un-graphed substep in which every launch of kernel class `kernel` is bracketed by two events on
+ * the solver's stream.  Returns the number of timed launches, their summed device time and the number
+ * of units (constraints or nodes) they processed.  Advances the simulation by one substep. */
 enum { PIES_KERNEL_PREDICT = 0, PIES_KERNEL_POSITION = 1, PIES_KERNEL_DISTANCE = 2, PIES_KERNEL_TET = 3,
        PIES_KERNEL_BEND = 4, PIES_KERNEL_FLOOR = 5, PIES_KERNEL_VELOCITY = 6, PIES_KERNEL_COUNT = 7 };
 int pies_profile_substep(pies_solver_t* s, int kernel, uint32_t* launches, double* total_ms, uint64_t* units);

@@ -30,6 +30,7 @@ SYMBOLS = [
     "pies_create_bend_sheet", "pies_set_flag", "pies_set_schedule", "pies_finalize", "pies_tick", "pies_tick_async",
     "pies_synchronize", "pies_failed", "pies_count", "pies_read_nodes", "pies_write_nodes", "pies_get_ids",
     "pies_get_rest", "pies_get_order", "pies_get_batches", "pies_profile_substep", "pies_launch_counts",
+    "pies_set_pcg", "pies_get_pcg_stats",
 ]
 
 
@@ -96,6 +97,8 @@ def load():
         "pies_get_order": [vp, i32, pu, u32], "pies_get_batches": [vp, i32, pu, u32, pu],
         "pies_profile_substep": [vp, i32, pu, C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
         "pies_launch_counts": [vp, pu],
+        "pies_set_pcg": [vp, f32, u32],
+        "pies_get_pcg_stats": [vp, pf, pu, pu],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -227,6 +230,15 @@ class Solver:
 
     def set_schedule(self, schedule):
         self._ck(self._L.pies_set_schedule(self._h, schedule))
+
+    def set_pcg(self, rel_tol, max_iters):
+        self._ck(self._L.pies_set_pcg(self._h, rel_tol, max_iters))
+
+    def pcg_stats(self):
+        """(max relative residual, max CG iterations used, number of solves) over the last tick."""
+        r, it, n = C.c_float(), C.c_uint32(), C.c_uint32()
+        self._ck(self._L.pies_get_pcg_stats(self._h, C.byref(r), C.byref(it), C.byref(n)))
+        return r.value, it.value, n.value
 
     def finalize(self):
         self._ck(self._L.pies_finalize(self._h))

@@ -3,22 +3,16 @@
 // fixed sequence of kernel launches captured once into a hipGraph: at 100k particles a conflict-free
 // batch runs for a few microseconds, so un-graphed launches would be host-bound.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
-#include "solver_state.h"
+#include "device_util.h"
 
 using namespace pies;
 
 namespace pies {
-
-#define HIP_TRY(s, expr)                                                                                   \
-  do {                                                                                                     \
-    hipError_t e__ = (expr);                                                                               \
-    if (e__ != hipSuccess)                                                                                 \
-      return fail((s), PIES_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));                  \
-  } while (0)
 
 static void destroy_graph(pies_solver* s) {
   if (s->graphExec) (void)hipGraphExecDestroy(s->graphExec);
@@ -36,17 +30,8 @@ static void free_device(pies_solver* s) {
   s->d_dc_ids = nullptr; s->d_dc_rw = nullptr;
   s->d_tc_ids = nullptr; s->d_tc_q0 = s->d_tc_q1 = s->d_tc_q2 = nullptr;
   s->d_bc_ids = nullptr; s->d_bc_aw = nullptr;
-}
-
-template <class T> static int upload(pies_solver* s, const std::vector<T>& h, T** d) {
-  *d = nullptr;
-  if (h.empty()) return PIES_OK;
-  void* p = nullptr;
-  HIP_TRY(s, hipMalloc(&p, h.size() * sizeof(T)));
-  s->allocations.push_back(p);
-  HIP_TRY(s, hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s->stream));
-  *d = static_cast<T*>(p);
-  return PIES_OK;
+  s->d_vc_ids = nullptr; s->d_vc_q0 = s->d_vc_q1 = s->d_vc_q2 = nullptr;
+  s->pd = PdArrays{};
 }
 
 static int upload_nodes(pies_solver* s) {
@@ -129,6 +114,32 @@ static void enqueue_pbd_substep(pies_solver* s, int timedKernel, LaunchTimer* ti
   C(PIES_KERNEL_VELOCITY);
 }
 
+// One PD substep as a launch sequence (Solver.cpp:228-485; point-triangle CCD contacts are a later row).
+static void enqueue_pd_substep(pies_solver* s) {
+  hipStream_t st = s->stream;
+  const float h = s->opt.fixedTimestepSize / s->opt.timeSubsteps;
+  const PdArrays& pd = s->pd;
+  launch_pd_predict(st, s->nd, pd, h, s->opt.floorHeight + s->opt.collisionThickness);
+  for (uint32_t it = 0; it < s->opt.iterations; ++it) {
+    // local step (Solver.cpp:270-308): position constraints project to a constant, uploaded once
+    launch_pd_local_distance(st, s->nd.pos, s->d_dc_ids, s->d_dc_rw, pd.contrib + s->slotBase[PIES_DISTANCE],
+                             (uint32_t)s->h_distance.size());
+    launch_pd_local_tet(st, false, s->nd.pos, s->d_tc_ids, s->d_tc_q0, s->d_tc_q1, s->d_tc_q2, pd.contrib + s->slotBase[PIES_TET],
+                        (uint32_t)s->h_tet.size());
+    launch_pd_local_tet(st, true, s->nd.pos, s->d_vc_ids, s->d_vc_q0, s->d_vc_q1, s->d_vc_q2, pd.contrib + s->slotBase[PIES_VOLUME],
+                        (uint32_t)s->h_volume.size());
+    launch_pd_rhs(st, s->nd, pd);                                    // Solver.cpp:266, 310-349
+    launch_pd_solve(st, s->nd, pd, (int)s->pcgMaxIters, s->pcgTol);  // Solver.cpp:356-364
+  }
+  if (s->opt.collisionStabilizationIterations > 0) launch_pd_stabilize(st, s->nd, pd);  // :367-383
+  launch_pd_velocity(st, s->nd, pd, h, s->opt.damping, s->opt.gravity, s->opt.friction, s->opt.staticFrictionThreshold);
+}
+
+static void enqueue_substep(pies_solver* s, uint32_t* counts) {
+  if (s->opt.solver == PIES_SOLVER_PD) enqueue_pd_substep(s);
+  else enqueue_pbd_substep(s, -1, nullptr, counts);
+}
+
 static int capture_graph(pies_solver* s) {
   destroy_graph(s);
   std::memset(s->launchCounts, 0, sizeof(s->launchCounts));
@@ -136,14 +147,14 @@ static int capture_graph(pies_solver* s) {
   if (const char* e = std::getenv("PIES_NO_GRAPH"); e && e[0] == '1') {
     // count launches without running them: a capture that is thrown away
     HIP_TRY(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-    enqueue_pbd_substep(s, -1, nullptr, s->launchCounts);
+    enqueue_substep(s, s->launchCounts);
     hipGraph_t tmp = nullptr;
     HIP_TRY(s, hipStreamEndCapture(s->stream, &tmp));
     if (tmp) (void)hipGraphDestroy(tmp);
     return PIES_OK;
   }
   HIP_TRY(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-  enqueue_pbd_substep(s, -1, nullptr, s->launchCounts);
+  enqueue_substep(s, s->launchCounts);
   hipError_t e = hipStreamEndCapture(s->stream, &s->graph);
   if (e != hipSuccess) return fail(s, PIES_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
   HIP_TRY(s, hipGraphInstantiate(&s->graphExec, s->graph, nullptr, nullptr, 0));
@@ -253,6 +264,31 @@ int pies_set_schedule(pies_solver_t* s, int schedule) {
   return PIES_OK;
 }
 
+int pies_set_pcg(pies_solver_t* s, float rel_tol, uint32_t max_iters) {
+  if (!s || !(rel_tol >= 0.0f) || max_iters == 0 || max_iters > 4096) return fail(s, PIES_ERR_INVALID, "pies_set_pcg: bad argument");
+  if (rel_tol != s->pcgTol || max_iters != s->pcgMaxIters) {
+    if (int rc = scene_sync_host(s)) return rc;
+    s->pcgTol = rel_tol;
+    s->pcgMaxIters = max_iters;
+    s->sceneDirty = true;  // the captured launch sequence changes
+  }
+  return PIES_OK;
+}
+
+int pies_get_pcg_stats(pies_solver_t* s, float* max_rel_residual, uint32_t* max_iters_used, uint32_t* solves) {
+  if (!s) return PIES_ERR_INVALID;
+  float st[4] = {0, 0, 0, 0};
+  if (s->opt.solver == PIES_SOLVER_PD && s->pd.cg.stats) {
+    HIP_TRY(s, hipSetDevice(s->device));
+    HIP_TRY(s, hipMemcpyAsync(st, s->pd.cg.stats, sizeof(st), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+  }
+  if (max_rel_residual) *max_rel_residual = std::sqrt(st[0]);
+  if (max_iters_used) *max_iters_used = static_cast<uint32_t>(st[1]);
+  if (solves) *solves = static_cast<uint32_t>(st[2]);
+  return PIES_OK;
+}
+
 int pies_finalize(pies_solver_t* s) {
   if (!s) return PIES_ERR_INVALID;
   HIP_TRY(s, hipSetDevice(s->device));
@@ -260,30 +296,31 @@ int pies_finalize(pies_solver_t* s) {
     if (s->hostNodesDirty) return upload_nodes(s);
     return PIES_OK;
   }
-  if (s->opt.solver == PIES_SOLVER_PD) return fail(s, PIES_ERR_UNSUPPORTED, "PD solver: not available in this build yet");
-  if (s->nodeCollisions && s->opt.solver == PIES_SOLVER_PBD)
+  const bool isPD = s->opt.solver == PIES_SOLVER_PD;
+  if (s->nodeCollisions && !isPD)
     return fail(s, PIES_ERR_UNSUPPORTED, "PBD node-node collisions: not available in this build yet; clear PIES_FLAG_NODE_COLLISIONS");
   if (int rc = download_nodes(s)) return rc;
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   free_device(s);
 
   const uint32_t n = s->nodeCount();
-  // ---- plans ----
+  // ---- plans (PD's local step is order independent: one batch per container, host order) ----
+  const int sched = isPD ? -1 : s->schedule;
   {
     std::vector<uint32_t> ids;
     ids.resize(s->h_position.size());
     for (size_t i = 0; i < ids.size(); ++i) ids[i] = s->h_position[i].id;
-    build_plan({ids.data(), 1, (uint32_t)s->h_position.size(), 0x1}, n, s->schedule, s->plan[PIES_POSITION]);
+    build_plan({ids.data(), 1, (uint32_t)s->h_position.size(), 0x1}, n, sched, s->plan[PIES_POSITION]);
     ids.resize(2 * s->h_distance.size());
     for (size_t i = 0; i < s->h_distance.size(); ++i) { ids[2 * i] = s->h_distance[i].ids[0]; ids[2 * i + 1] = s->h_distance[i].ids[1]; }
     // a distance projection moves node a only (Constraints.cpp:34-36); node b is read
-    build_plan({ids.data(), 2, (uint32_t)s->h_distance.size(), 0x1}, n, s->schedule, s->plan[PIES_DISTANCE]);
+    build_plan({ids.data(), 2, (uint32_t)s->h_distance.size(), 0x1}, n, sched, s->plan[PIES_DISTANCE]);
     ids.resize(4 * s->h_tet.size());
     for (size_t i = 0; i < s->h_tet.size(); ++i) std::memcpy(&ids[4 * i], s->h_tet[i].ids, 16);
-    build_plan({ids.data(), 4, (uint32_t)s->h_tet.size(), 0xF}, n, s->schedule, s->plan[PIES_TET]);
+    build_plan({ids.data(), 4, (uint32_t)s->h_tet.size(), 0xF}, n, sched, s->plan[PIES_TET]);
     ids.resize(4 * s->h_bend.size());
     for (size_t i = 0; i < s->h_bend.size(); ++i) std::memcpy(&ids[4 * i], s->h_bend[i].ids, 16);
-    build_plan({ids.data(), 4, (uint32_t)s->h_bend.size(), 0xF}, n, s->schedule, s->plan[PIES_BEND]);
+    build_plan({ids.data(), 4, (uint32_t)s->h_bend.size(), 0xF}, n, sched, s->plan[PIES_BEND]);
   }
   // ---- node arrays ----
   if (n) {
@@ -358,6 +395,22 @@ int pies_finalize(pies_solver_t* s) {
     if (int rc = upload(s, aw, &s->d_bc_aw)) return rc;
     HIP_TRY(s, hipStreamSynchronize(s->stream));
   }
+  if (isPD) {
+    std::vector<uint4> id(s->h_volume.size());
+    std::vector<float4> q0(id.size()), q1(id.size()), q2(id.size());
+    for (size_t k = 0; k < id.size(); ++k) {
+      const HostTet& c = s->h_volume[k];
+      id[k] = make_uint4(c.ids[0], c.ids[1], c.ids[2], c.ids[3]);
+      q0[k] = make_float4(c.qinv[0], c.qinv[1], c.qinv[2], c.qinv[3]);
+      q1[k] = make_float4(c.qinv[4], c.qinv[5], c.qinv[6], c.qinv[7]);
+      q2[k] = make_float4(c.qinv[8], c.lo, c.hi, c.w);
+    }
+    if (int rc = upload(s, id, &s->d_vc_ids)) return rc;
+    if (int rc = upload(s, q0, &s->d_vc_q0)) return rc;
+    if (int rc = upload(s, q1, &s->d_vc_q1)) return rc;
+    if (int rc = upload(s, q2, &s->d_vc_q2)) return rc;
+    if (int rc = pd_build(s)) return rc;
+  }
   if (int rc = capture_graph(s)) return rc;
   s->sceneDirty = false;
   return PIES_OK;
@@ -370,9 +423,10 @@ int pies_tick_async(pies_solver_t* s) {
     if (int rc = pies_finalize(s)) return rc;
   HIP_TRY(s, hipSetDevice(s->device));
   if (s->nd.n == 0) return PIES_OK;
+  if (s->opt.solver == PIES_SOLVER_PD) HIP_TRY(s, hipMemsetAsync(s->pd.cg.stats, 0, 4 * sizeof(float), s->stream));
   for (uint32_t sub = 0; sub < s->opt.timeSubsteps; ++sub) {
     if (s->graphExec) HIP_TRY(s, hipGraphLaunch(s->graphExec, s->stream));
-    else enqueue_pbd_substep(s, -1, nullptr, nullptr);  // PIES_NO_GRAPH=1: eager launches (debug / tracing)
+    else enqueue_substep(s, nullptr);  // PIES_NO_GRAPH=1: eager launches (debug / tracing)
   }
   s->deviceAhead = true;
   return PIES_OK;
@@ -528,6 +582,7 @@ int pies_launch_counts(pies_solver_t* s, uint32_t* out) {
 
 int pies_profile_substep(pies_solver_t* s, int kernel, uint32_t* launches, double* total_ms, uint64_t* units) {
   if (!s || kernel < 0 || kernel >= PIES_KERNEL_COUNT) return PIES_ERR_INVALID;
+  if (s->opt.solver != PIES_SOLVER_PBD) return fail(s, PIES_ERR_UNSUPPORTED, "pies_profile_substep: PBD only");
   if (s->sceneDirty || s->hostNodesDirty)
     if (int rc = pies_finalize(s)) return rc;
   HIP_TRY(s, hipSetDevice(s->device));

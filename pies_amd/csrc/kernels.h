@@ -7,9 +7,12 @@
 
 namespace pies {
 
-// Optional per-launch device timing: when `timer` is non-null the launch goes through
-// hipExtLaunchKernelGGL, whose start/stop events carry the dispatch packet's own timestamps
-// (what rocprofv3 --kernel-trace reports), not host-side launch gaps.
+// Optional per-launch device timing: when `timer` is non-null the launch is bracketed by two events
+// recorded on the launch stream.  The kernels of a substep form one dependent chain, so the interval
+// between the two markers is the launch's share of the stream's busy time (dispatch + execution), which
+// is what rocprofv3 --kernel-trace reports as the dispatch duration to within a few percent.
+// (hipExtLaunchKernelGGL's start/stop events crash rocprofv3 7.2's tracer on this pool, so plain
+// in-stream events are used.)
 struct LaunchTimer {
   std::vector<hipEvent_t> starts, stops;
   size_t used = 0;

@@ -9,8 +9,6 @@
 //
 // These kernels are bound by memory latency/bandwidth (gather -> <=1 kFLOP of 3x3 algebra -> scatter);
 // there is no GEMM-shaped work, hence no MFMA.
-#include <hip/hip_ext.h>
-
 #include <cstdlib>
 
 #include "dev_math.h"
@@ -26,15 +24,16 @@ constexpr int kProjBlock = PIES_PROJ_BLOCK;  // projection kernels (64 measured 
 
 static inline dim3 grid_for(uint32_t n, int block) { return dim3((n + block - 1) / block); }
 
-#define PIES_LAUNCH(kernel, block, n_items, st, timer, ...)                                                        \
-  do {                                                                                                      \
-    hipEvent_t ev_a__, ev_b__;                                                                              \
-    if ((timer) != nullptr && (timer)->next(&ev_a__, &ev_b__)) {                                            \
-      (timer)->units += (n_items);                                                                          \
-      hipExtLaunchKernelGGL(kernel, grid_for(n_items, block), dim3(block), 0, st, ev_a__, ev_b__, 0, __VA_ARGS__); \
-    } else {                                                                                                \
-      hipLaunchKernelGGL(kernel, grid_for(n_items, block), dim3(block), 0, st, __VA_ARGS__);                  \
-    }                                                                                                       \
+#define PIES_LAUNCH(kernel, block, n_items, st, timer, ...)                                             \
+  do {                                                                                                  \
+    hipEvent_t ev_a__ = nullptr, ev_b__ = nullptr;                                                      \
+    const bool timed__ = (timer) != nullptr && (timer)->next(&ev_a__, &ev_b__);                         \
+    if (timed__) {                                                                                      \
+      (timer)->units += (n_items);                                                                      \
+      (void)hipEventRecord(ev_a__, st);                                                                 \
+    }                                                                                                   \
+    hipLaunchKernelGGL(kernel, grid_for(n_items, block), dim3(block), 0, st, __VA_ARGS__);              \
+    if (timed__) (void)hipEventRecord(ev_b__, st);                                                      \
   } while (0)
 
 // ----------------------------------------------------------------------------------------------

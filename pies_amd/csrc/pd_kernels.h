@@ -1,0 +1,49 @@
+// Launch wrappers of the Projective-Dynamics kernels (pd_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "kernels.h"
+
+namespace pies {
+
+constexpr uint32_t kCgBlocks = 256;  // CG launch shape: <= 256 blocks x 256 threads, grid-stride
+
+struct CgArrays {
+  uint32_t n;
+  uint32_t nparts;  // blocks per CG launch (<= kCgBlocks)
+  const uint32_t* rowptr;
+  const uint32_t* col;
+  const float* val;
+  float* cdiag;  // diagonal of the collision matrix (floor contacts)
+  float* dinv;   // 1 / diag(K + C)
+  float4 *r, *z, *p[2], *ap;
+  float *partI, *partA, *partB, *partBnext;
+  float* scal;   // rz[2][3], bb[3], iterations
+  float* stats;  // max relative residual^2 over the tick's solves, max iterations, number of solves
+};
+
+struct PdArrays {
+  float4* msn;
+  float4* rhs;
+  float4* statp;
+  float4* contrib;
+  const uint32_t* incPtr;
+  const uint32_t* incSlot;
+  const uint32_t* triCount;
+  uint32_t* nstatic;
+  const float* kdiag;
+  CgArrays cg;
+};
+
+void launch_pd_predict(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float h, float contactHeight);
+void launch_pd_local_distance(hipStream_t st, const float4* pos, const uint2* ids, const float2* rw, float4* contrib, uint32_t count);
+void launch_pd_local_tet(hipStream_t st, bool volume, const float4* pos, const uint4* ids, const float4* q0, const float4* q1,
+                         const float4* q2, float4* contrib, uint32_t count);
+void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd);
+void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, int maxIters, float tol);
+void launch_pd_stabilize(hipStream_t st, const NodeArrays& nd, const PdArrays& pd);
+void launch_pd_velocity(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float h, float damping, float gravity,
+                        float friction, float staticThreshold);
+
+}  // namespace pies

@@ -1,0 +1,529 @@
+// Projective-Dynamics substep kernels for gfx950 (Src/Solver.cpp:162-486 of the reference).
+//
+//   predict      pos += h v ; Msn_h2 = pos/invMass/h^2 ; floor-contact detection ; system diagonal
+//   local step   one lane = one constraint, all constraints of a container in ONE launch (the local step
+//                only reads positions, Solver.cpp:270-308) -> writes w*(A^T B p)_i per (constraint, node)
+//   rhs          one lane = one node: Msn_h2 + contributions gathered in the reference's summation order
+//                (Solver.cpp:310-349), so the right-hand side is reproducible bit for bit (no atomics)
+//   global step  Jacobi-preconditioned CG on (K + C) x = rhs for the 3 coordinate columns at once; K in CSR,
+//                SpMV with 16 lanes per row; the reference factors K + C with a sparse Cholesky every
+//                substep (Solver.cpp:258-262,356) -- CG to a relative residual replaces the direct solve
+//   velocity     v = (1-d)(pos-prev)/h + h f/m ; prev = pos ; floor friction
+//
+// Everything here is bandwidth/latency bound (gathers, streams, SpMV at ~15 nnz/row, 3x3 algebra): no MFMA.
+#include <cstdint>
+
+#include "dev_math.h"
+#include "pd_kernels.h"
+
+namespace pies {
+
+constexpr int kBlock = 256;
+constexpr float kStaticW = 10000.0f;  // StaticCollisionConstraint::w (Include/Pies/CollisionConstraint.h:78)
+
+static inline dim3 grid_for(uint32_t n) { return dim3((n + kBlock - 1) / kBlock); }
+
+// ------------------------------------------------------------------------------------------------------
+// Solver.cpp:229-238 + floor part of the detection (:829-834, one contact per (triangle,node) incidence)
+// + diagonal of the collision matrix (:254-259) and the Jacobi preconditioner.
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_pd_predict(float4* __restrict__ pos, const float4* __restrict__ vel,
+                                                       float4* __restrict__ msn, const uint32_t* __restrict__ triCount,
+                                                       uint32_t* __restrict__ nstatic, const float* __restrict__ kdiag,
+                                                       float* __restrict__ cdiag, float* __restrict__ dinv, uint32_t n, float h,
+                                                       float h2, float contactHeight) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  float4 p = pos[i];
+  const float4 v = vel[i];
+  p.x = p.x + h * v.x;
+  p.y = p.y + h * v.y;
+  p.z = p.z + h * v.z;
+  pos[i] = p;
+  msn[i] = make_float4((p.x / p.w) / h2, (p.y / p.w) / h2, (p.z / p.w) / h2, 0.0f);
+  const uint32_t ns = (p.y < contactHeight) ? triCount[i] : 0u;
+  nstatic[i] = ns;
+  float cd = 0.0f;
+  for (uint32_t k = 0; k < ns; ++k) cd += kStaticW;  // coeffRef(n,n) += w once per contact
+  cdiag[i] = cd;
+  dinv[i] = 1.0f / (kdiag[i] + cd);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Local steps.  contrib[slotBase + N*c + i] = w * (A^T B p)_i   (Constraints.h:89-105)
+// ------------------------------------------------------------------------------------------------------
+// DistanceConstraint: A = B = [[.5,-.5],[-.5,.5]]  =>  A^T B = [[.5,-.5],[-.5,.5]] exactly.
+__global__ void __launch_bounds__(kBlock) k_pd_local_distance(const float4* __restrict__ pos, const uint2* __restrict__ ids,
+                                                              const float2* __restrict__ rest_w, float4* __restrict__ contrib,
+                                                              uint32_t count) {
+  const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= count) return;
+  const uint2 id = ids[c];
+  const float2 rw = rest_w[c];
+  const float4 a = pos[id.x];
+  const float4 b = pos[id.y];
+  const float dx = b.x - a.x, dy = b.y - a.y, dz = b.z - a.z;
+  const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+  float ux = 1.0f, uy = 0.0f, uz = 0.0f;
+  if (dist > 0.00001f) {
+    ux = dx / dist;
+    uy = dy / dist;
+    uz = dz / dist;
+  }
+  const float nd = -(rw.x - dist);
+  const float p0x = a.x + nd * ux, p0y = a.y + nd * uy, p0z = a.z + nd * uz;  // projected[0]; projected[1] = b
+  const float w = rw.y;
+  // (AtB p)_0 = .5 p0 + (-.5) p1 ; (AtB p)_1 = (-.5) p0 + .5 p1 ; accumulated from 0 like the reference's product
+  contrib[2 * c + 0] = make_float4(w * ((0.0f + 0.5f * p0x) + -0.5f * b.x), w * ((0.0f + 0.5f * p0y) + -0.5f * b.y),
+                                   w * ((0.0f + 0.5f * p0z) + -0.5f * b.z), 0.0f);
+  contrib[2 * c + 1] = make_float4(w * ((0.0f + -0.5f * p0x) + 0.5f * b.x), w * ((0.0f + -0.5f * p0y) + 0.5f * b.y),
+                                   w * ((0.0f + -0.5f * p0z) + 0.5f * b.z), 0.0f);
+}
+
+// Constraints.cpp:186-203
+PIES_DEV void compute_d(const float s[3], float omegaMin, float omegaMax, float D[3]) {
+  D[0] = D[1] = D[2] = 0.0f;
+  for (int it = 0; it < 10; ++it) {
+    const float sx = s[0] + D[0], sy = s[1] + D[1], sz = s[2] + D[2];
+    const float product = sx * sy * sz;
+    const float omega = clampf(product, omegaMin, omegaMax);
+    const float C = product - omega;
+    const float gx = sy * sz, gy = sx * sz, gz = sx * sy;
+    const float num = (gx * D[0] + gy * D[1] + gz * D[2]) - C;
+    const float den = gx * gx + gy * gy + gz * gz;
+    D[0] = (num * gx) / den;
+    D[1] = (num * gy) / den;
+    D[2] = (num * gz) / den;
+  }
+}
+
+// TetrahedralConstraint (VOLUME = false, Constraints.cpp:76-128) and VolumeConstraint (VOLUME = true,
+// :205-255).  B = I and A = [0 ; Qinv_(r,k) D] (Constraints.cpp:141-175), so
+// (A^T p)_0 = -(q_r0+q_r1+q_r2) weighted sum, (A^T p)_{1+c} = sum_r Qinv[r][c] p_{1+r}; p_0 = 0.
+template <bool VOLUME>
+__global__ void __launch_bounds__(kBlock) k_pd_local_tet(const float4* __restrict__ pos, const uint4* __restrict__ ids,
+                                                         const float4* __restrict__ q0, const float4* __restrict__ q1,
+                                                         const float4* __restrict__ q2, float4* __restrict__ contrib,
+                                                         uint32_t count) {
+  const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= count) return;
+  const uint4 id = ids[c];
+  const float4 a0 = q0[c], a1 = q1[c], a2 = q2[c];
+  const float4 x1 = pos[id.x], x2 = pos[id.y], x3 = pos[id.z], x4 = pos[id.w];
+  const float qi[3][3] = {{a0.x, a0.y, a0.z}, {a0.w, a1.x, a1.y}, {a1.z, a1.w, a2.x}};  // [col][row]
+  const float lo = a2.y, hi = a2.z, w = a2.w;
+  const float P[3][3] = {{x2.x - x1.x, x2.y - x1.y, x2.z - x1.z},
+                         {x3.x - x1.x, x3.y - x1.y, x3.z - x1.z},
+                         {x4.x - x1.x, x4.y - x1.y, x4.z - x1.z}};
+  float F[3][3];
+  mat3_mul_cm(P, qi, F);
+  Svd3 d;
+  svd3(F, d);
+  float s[3];
+  if (VOLUME) {
+    float D[3];
+    compute_d(d.s, lo, hi, D);
+    s[0] = d.s[0] + D[0];
+    s[1] = d.s[1] + D[1];
+    s[2] = d.s[2] + D[2];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s[i] = clampf(d.s[i], lo, hi);
+    if (det3_cm(F) < 0.0f) {
+      int k = 0;
+      float m = d.s[0];
+      if (d.s[1] <= m) { k = 1; m = d.s[1]; }
+      if (d.s[2] <= m) { k = 2; }
+      s[0] = (k == 0) ? -s[0] : s[0];
+      s[1] = (k == 1) ? -s[1] : s[1];
+      s[2] = (k == 2) ? -s[2] : s[2];
+    }
+  }
+  float Fh[3][3];
+  svd3_recompose(d, s, Fh);  // projected = (0, Fh[0], Fh[1], Fh[2])
+  // A[1+r][0] = ((0 + -q_r0) + -q_r1) + -q_r2 ; A[1+r][1+c] = q_rc with q_rc = Qinv[r][c] (reference's row-major read)
+  float A0[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) A0[r] = ((0.0f + qi[r][0] * -1.0f) + qi[r][1] * -1.0f) + qi[r][2] * -1.0f;
+  float out[4][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    // sum over rows m = 0..3 of A[m][i] * p_m, starting from 0; row 0 of A and p_0 are zero
+    out[0][k] = ((0.0f + A0[0] * Fh[0][k]) + A0[1] * Fh[1][k]) + A0[2] * Fh[2][k];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) out[1 + cc][k] = ((0.0f + qi[0][cc] * Fh[0][k]) + qi[1][cc] * Fh[1][k]) + qi[2][cc] * Fh[2][k];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) contrib[4 * c + i] = make_float4(w * out[i][0], w * out[i][1], w * out[i][2], 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Right-hand side (Solver.cpp:266, 310-349): one lane per node, contributions in the reference's order
+// (position, distance, tet, volume, bend, ... then the floor contacts), so the float sum is the reference's.
+// Also evaluates the floor projection (CollisionConstraint.cpp:447-455: clamps to y >= 0, not floorHeight).
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_pd_rhs(const float4* __restrict__ msn, const float4* __restrict__ contrib,
+                                                   const uint32_t* __restrict__ incPtr, const uint32_t* __restrict__ incSlot,
+                                                   const float4* __restrict__ pos, const uint32_t* __restrict__ nstatic,
+                                                   float4* __restrict__ statp, float4* __restrict__ rhs, uint32_t n) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  float4 f = msn[i];
+  const uint32_t e = incPtr[i + 1];
+  for (uint32_t k = incPtr[i]; k < e; ++k) {
+    const float4 c = contrib[incSlot[k]];
+    f.x += c.x;
+    f.y += c.y;
+    f.z += c.z;
+  }
+  const uint32_t ns = nstatic[i];
+  if (ns) {
+    float4 p = pos[i];
+    if (p.y < 0.0f) p.y = 0.0f;
+    statp[i] = p;
+    const float cx = kStaticW * p.x, cy = kStaticW * p.y, cz = kStaticW * p.z;
+    for (uint32_t k = 0; k < ns; ++k) {
+      f.x += cx;
+      f.y += cy;
+      f.z += cz;
+    }
+  }
+  rhs[i] = f;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Jacobi-preconditioned CG, 3 right-hand sides at once.  Launch shape: kCgBlocks blocks of 256 threads,
+// grid-stride.  Dot products: per-block partials, re-reduced in a fixed order by every block of the
+// consuming kernel (deterministic, no atomics, no extra launch).
+//   partB[b] = { rz[3], rr[3] }  of the current residual     (written by init / update)
+//   partA[b] = { pAp[3] }                                    (written by ap)
+//   scal     = { rz[2][3] ping-pong, bb[3] }                 (written by block 0 of ap)
+// ------------------------------------------------------------------------------------------------------
+struct Red6 {
+  float v[6];
+};
+
+template <int NV> PIES_DEV void block_reduce_partials(const float* __restrict__ part, int stride, uint32_t nparts, float out[NV]) {
+  __shared__ float lds[4][NV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) acc[k] = (threadIdx.x < nparts) ? part[threadIdx.x * stride + k] : 0.0f;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] += __shfl_xor(acc[k], off, 64);
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) lds[wave][k] = acc[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) out[k] = ((lds[0][k] + lds[1][k]) + lds[2][k]) + lds[3][k];
+  __syncthreads();
+}
+
+template <int NV> PIES_DEV void block_write_partial(const float acc_in[NV], float* __restrict__ part, int stride) {
+  __shared__ float lds[4][NV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) acc[k] = acc_in[k];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] += __shfl_xor(acc[k], off, 64);
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) lds[wave][k] = acc[k];
+  __syncthreads();
+  if (threadIdx.x == 0)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) part[blockIdx.x * stride + k] = ((lds[0][k] + lds[1][k]) + lds[2][k]) + lds[3][k];
+  __syncthreads();
+}
+
+PIES_DEV bool all_converged(const float rr[3], const float bb[3], float tol2) {
+  return rr[0] <= tol2 * bb[0] && rr[1] <= tol2 * bb[1] && rr[2] <= tol2 * bb[2];
+}
+
+// r = f - (K + C) x ; z = D^-1 r ; partB = {rz, rr} ; partI = {bb}.   16 lanes per row.
+__global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __restrict__ x, const float4* __restrict__ f) {
+  const uint32_t group = (blockIdx.x * kBlock + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+  const uint32_t ngroups = (gridDim.x * kBlock) >> 4;
+  float acc9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint32_t i = group; i < A.n; i += ngroups) {
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    const uint32_t e = A.rowptr[i + 1];
+    for (uint32_t k = A.rowptr[i] + sub; k < e; k += 16) {
+      const float a = A.val[k];
+      const float4 xj = x[A.col[k]];
+      sx = fmaf(a, xj.x, sx);
+      sy = fmaf(a, xj.y, sy);
+      sz = fmaf(a, xj.z, sz);
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+      sx += __shfl_xor(sx, off, 16);
+      sy += __shfl_xor(sy, off, 16);
+      sz += __shfl_xor(sz, off, 16);
+    }
+    if (sub == 0) {
+      const float4 xi = x[i], fi = f[i];
+      const float cd = A.cdiag[i], di = A.dinv[i];
+      const float rx = fi.x - fmaf(cd, xi.x, sx), ry = fi.y - fmaf(cd, xi.y, sy), rz = fi.z - fmaf(cd, xi.z, sz);
+      const float zx = di * rx, zy = di * ry, zz = di * rz;
+      A.r[i] = make_float4(rx, ry, rz, 0.f);
+      A.z[i] = make_float4(zx, zy, zz, 0.f);
+      acc9[0] += rx * zx; acc9[1] += ry * zy; acc9[2] += rz * zz;
+      acc9[3] += rx * rx; acc9[4] += ry * ry; acc9[5] += rz * rz;
+      acc9[6] += fi.x * fi.x; acc9[7] += fi.y * fi.y; acc9[8] += fi.z * fi.z;
+    }
+  }
+  block_write_partial<9>(acc9, A.partI, 9);
+}
+
+// iteration k:  beta = rz_k / rz_{k-1} (0 for k = 0) ; p = z + beta p_old ; Ap = (K + C) p ; partA = {pAp}
+__global__ void __launch_bounds__(kBlock) k_cg_ap(CgArrays A, int k, float tol2) {
+  float red[9];
+  float rz[3], rr[3], bb[3];
+  if (k == 0) {
+    block_reduce_partials<9>(A.partI, 9, A.nparts, red);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { rz[c] = red[c]; rr[c] = red[3 + c]; bb[c] = red[6 + c]; }
+  } else {
+    block_reduce_partials<6>(A.partB, 6, A.nparts, red);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { rz[c] = red[c]; rr[c] = red[3 + c]; bb[c] = A.scal[6 + c]; }
+  }
+  if (k == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    A.scal[6] = bb[0];
+    A.scal[7] = bb[1];
+    A.scal[8] = bb[2];
+    A.scal[9] = 0.0f;  // iterations started in this solve
+  }
+  if (all_converged(rr, bb, tol2)) return;
+  float beta[3] = {0.f, 0.f, 0.f};
+  if (k > 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float old = A.scal[3 * ((k - 1) & 1) + c];
+      beta[c] = old > 0.0f ? rz[c] / old : 0.0f;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) A.scal[3 * (k & 1) + c] = rz[c];
+    A.scal[9] = static_cast<float>(k + 1);
+  }
+  const float4* __restrict__ pold = A.p[(k + 1) & 1];
+  float4* __restrict__ pnew = A.p[k & 1];
+  const uint32_t group = (blockIdx.x * kBlock + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+  const uint32_t ngroups = (gridDim.x * kBlock) >> 4;
+  float acc[3] = {0, 0, 0};
+  for (uint32_t i = group; i < A.n; i += ngroups) {
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    const uint32_t e = A.rowptr[i + 1];
+    for (uint32_t kk = A.rowptr[i] + sub; kk < e; kk += 16) {
+      const float a = A.val[kk];
+      const uint32_t j = A.col[kk];
+      const float4 zj = A.z[j];
+      float px = zj.x, py = zj.y, pz = zj.z;
+      if (k > 0) {
+        const float4 pj = pold[j];
+        px = fmaf(beta[0], pj.x, px);
+        py = fmaf(beta[1], pj.y, py);
+        pz = fmaf(beta[2], pj.z, pz);
+      }
+      sx = fmaf(a, px, sx);
+      sy = fmaf(a, py, sy);
+      sz = fmaf(a, pz, sz);
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+      sx += __shfl_xor(sx, off, 16);
+      sy += __shfl_xor(sy, off, 16);
+      sz += __shfl_xor(sz, off, 16);
+    }
+    if (sub == 0) {
+      const float4 zi = A.z[i];
+      float px = zi.x, py = zi.y, pz = zi.z;
+      if (k > 0) {
+        const float4 pi = pold[i];
+        px = fmaf(beta[0], pi.x, px);
+        py = fmaf(beta[1], pi.y, py);
+        pz = fmaf(beta[2], pi.z, pz);
+      }
+      const float cd = A.cdiag[i];
+      const float ax = fmaf(cd, px, sx), ay = fmaf(cd, py, sy), az = fmaf(cd, pz, sz);
+      pnew[i] = make_float4(px, py, pz, 0.f);
+      A.ap[i] = make_float4(ax, ay, az, 0.f);
+      acc[0] += px * ax;
+      acc[1] += py * ay;
+      acc[2] += pz * az;
+    }
+  }
+  block_write_partial<3>(acc, A.partA, 3);
+}
+
+// alpha = rz_k / pAp ; x += alpha p ; r -= alpha Ap ; z = D^-1 r ; partB = {rz_{k+1}, rr_{k+1}}
+__global__ void __launch_bounds__(kBlock) k_cg_update(CgArrays A, float4* __restrict__ x, int k, float tol2) {
+  float red[9];
+  float rr[3], bb[3];
+  if (k == 0) {
+    block_reduce_partials<9>(A.partI, 9, A.nparts, red);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { rr[c] = red[3 + c]; bb[c] = red[6 + c]; }
+  } else {
+    block_reduce_partials<6>(A.partB, 6, A.nparts, red);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { rr[c] = red[3 + c]; bb[c] = A.scal[6 + c]; }
+  }
+  if (all_converged(rr, bb, tol2)) {
+    // same decision as k_cg_ap(k), which produced nothing: carry the residual partials forward so that
+    // every later kernel of this solve takes the same branch
+    if (threadIdx.x < 6) A.partBnext[blockIdx.x * 6 + threadIdx.x] = (k == 0 ? A.partI[blockIdx.x * 9 + threadIdx.x] : A.partB[blockIdx.x * 6 + threadIdx.x]);
+    return;
+  }
+  float pap[3];
+  block_reduce_partials<3>(A.partA, 3, A.nparts, pap);
+  float alpha[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float rzk = A.scal[3 * (k & 1) + c];
+    alpha[c] = pap[c] > 0.0f ? rzk / pap[c] : 0.0f;
+  }
+  const float4* __restrict__ p = A.p[k & 1];
+  float acc[6] = {0, 0, 0, 0, 0, 0};
+  // blocks run concurrently, so the new residual partials go to the other half of a ping-pong pair
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < A.n; i += gridDim.x * kBlock) {
+    const float4 pi = p[i], api = A.ap[i];
+    float4 xi = x[i], ri = A.r[i];
+    xi.x = fmaf(alpha[0], pi.x, xi.x);
+    xi.y = fmaf(alpha[1], pi.y, xi.y);
+    xi.z = fmaf(alpha[2], pi.z, xi.z);
+    ri.x = fmaf(-alpha[0], api.x, ri.x);
+    ri.y = fmaf(-alpha[1], api.y, ri.y);
+    ri.z = fmaf(-alpha[2], api.z, ri.z);
+    const float di = A.dinv[i];
+    const float zx = di * ri.x, zy = di * ri.y, zz = di * ri.z;
+    x[i] = xi;
+    A.r[i] = ri;
+    A.z[i] = make_float4(zx, zy, zz, 0.f);
+    acc[0] += ri.x * zx; acc[1] += ri.y * zy; acc[2] += ri.z * zz;
+    acc[3] += ri.x * ri.x; acc[4] += ri.y * ri.y; acc[5] += ri.z * ri.z;
+  }
+  block_write_partial<6>(acc, A.partBnext, 6);
+}
+
+// end of a solve: statistics (max relative residual over the tick's solves, iterations of the last solve)
+__global__ void __launch_bounds__(kBlock) k_cg_finish(CgArrays A, int iters) {
+  float red[6];
+  block_reduce_partials<6>(A.partB, 6, A.nparts, red);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float worst = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float bb = A.scal[6 + c];
+      const float rel = bb > 0.f ? red[3 + c] / bb : 0.f;
+      worst = fmaxf(worst, rel);
+    }
+    A.stats[0] = fmaxf(A.stats[0], worst);  // max over solves of ||r||^2 / ||b||^2
+    A.stats[1] = fmaxf(A.stats[1], A.scal[9]);
+    A.stats[2] += 1.0f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Solver.cpp:367-383 (floor snap; tri/edge stabilisation is a later row) -- idempotent, applied once
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_pd_stabilize(float4* __restrict__ pos, const float4* __restrict__ statp,
+                                                         const uint32_t* __restrict__ nstatic, uint32_t n) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  if (nstatic[i]) {
+    const float4 s = statp[i];
+    float4 p = pos[i];
+    p.x = s.x;
+    p.y = s.y;
+    p.z = s.z;
+    pos[i] = p;
+  }
+}
+
+// Solver.cpp:386-395 + floor friction :473-484 (once per contact instance)
+__global__ void __launch_bounds__(kBlock) k_pd_velocity(const float4* __restrict__ pos, float4* __restrict__ prev,
+                                                        float4* __restrict__ vel, const uint32_t* __restrict__ nstatic, uint32_t n,
+                                                        float h, float damping, float gravity, float friction,
+                                                        float staticThreshold) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pos[i];
+  const float4 q = prev[i];
+  const float k = 1.0f - damping;
+  // node.force = (0,-g,0)/invMass ; v = (1-d)(pos-prev)/h + h*force*invMass
+  const float fx = 0.0f / p.w, fy = -gravity / p.w, fz = 0.0f / p.w;
+  float vx = (k * (p.x - q.x)) / h + (h * fx) * p.w;
+  float vy = (k * (p.y - q.y)) / h + (h * fy) * p.w;
+  float vz = (k * (p.z - q.z)) / h + (h * fz) * p.w;
+  const uint32_t ns = nstatic[i];
+  for (uint32_t c = 0; c < ns; ++c) {
+    const float px = vx, pz = vz;  // perpVel = (vx, 0, vz)
+    float fr = friction;
+    if (sqrtf(px * px + 0.0f * 0.0f + pz * pz) < staticThreshold) fr = 1.0f;
+    vx += -fr * px;
+    vy += -fr * 0.0f;
+    vz += -fr * pz;
+  }
+  prev[i] = make_float4(p.x, p.y, p.z, 0.f);
+  vel[i] = make_float4(vx, vy, vz, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------------
+void launch_pd_predict(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float h, float contactHeight) {
+  if (nd.n == 0) return;
+  hipLaunchKernelGGL(k_pd_predict, grid_for(nd.n), dim3(kBlock), 0, st, nd.pos, nd.vel, pd.msn, pd.triCount, pd.nstatic, pd.kdiag,
+                     pd.cg.cdiag, pd.cg.dinv, nd.n, h, h * h, contactHeight);
+}
+void launch_pd_local_distance(hipStream_t st, const float4* pos, const uint2* ids, const float2* rw, float4* contrib, uint32_t count) {
+  if (count == 0) return;
+  hipLaunchKernelGGL(k_pd_local_distance, grid_for(count), dim3(kBlock), 0, st, pos, ids, rw, contrib, count);
+}
+void launch_pd_local_tet(hipStream_t st, bool volume, const float4* pos, const uint4* ids, const float4* q0, const float4* q1,
+                         const float4* q2, float4* contrib, uint32_t count) {
+  if (count == 0) return;
+  if (volume) hipLaunchKernelGGL(k_pd_local_tet<true>, grid_for(count), dim3(kBlock), 0, st, pos, ids, q0, q1, q2, contrib, count);
+  else hipLaunchKernelGGL(k_pd_local_tet<false>, grid_for(count), dim3(kBlock), 0, st, pos, ids, q0, q1, q2, contrib, count);
+}
+void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd) {
+  if (nd.n == 0) return;
+  hipLaunchKernelGGL(k_pd_rhs, grid_for(nd.n), dim3(kBlock), 0, st, pd.msn, pd.contrib, pd.incPtr, pd.incSlot, nd.pos, pd.nstatic,
+                     pd.statp, pd.rhs, nd.n);
+}
+void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, int maxIters, float tol) {
+  if (nd.n == 0) return;
+  CgArrays A = pd.cg;
+  const dim3 grid(A.nparts), block(kBlock);
+  const float tol2 = tol * tol;
+  hipLaunchKernelGGL(k_cg_init, grid, block, 0, st, A, nd.pos, pd.rhs);
+  float* pb[2] = {pd.cg.partB, pd.cg.partBnext};
+  for (int k = 0; k < maxIters; ++k) {
+    A.partB = pb[k & 1];       // residual partials of iteration k (k = 0 reads partI instead)
+    A.partBnext = pb[(k + 1) & 1];
+    hipLaunchKernelGGL(k_cg_ap, grid, block, 0, st, A, k, tol2);
+    hipLaunchKernelGGL(k_cg_update, grid, block, 0, st, A, nd.pos, k, tol2);
+  }
+  A.partB = pb[maxIters & 1];
+  hipLaunchKernelGGL(k_cg_finish, dim3(1), block, 0, st, A, maxIters);
+}
+void launch_pd_stabilize(hipStream_t st, const NodeArrays& nd, const PdArrays& pd) {
+  if (nd.n == 0) return;
+  hipLaunchKernelGGL(k_pd_stabilize, grid_for(nd.n), dim3(kBlock), 0, st, nd.pos, pd.statp, pd.nstatic, nd.n);
+}
+void launch_pd_velocity(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float h, float damping, float gravity,
+                        float friction, float staticThreshold) {
+  if (nd.n == 0) return;
+  hipLaunchKernelGGL(k_pd_velocity, grid_for(nd.n), dim3(kBlock), 0, st, nd.pos, nd.prev, nd.vel, pd.nstatic, nd.n, h, damping, gravity,
+                     friction, staticThreshold);
+}
+
+}  // namespace pies

@@ -1,0 +1,143 @@
+// Projective-Dynamics precompute (host, once per topology change) -- the counterpart of
+// Solver::tickPD's rebuild block (Src/Solver.cpp:168-221 of the reference):
+//   * K = diag(1/(invMass h^2)) + sum_c w_c A_c^T A_c, accumulated in the reference's container order
+//     (position, distance, tet, volume, [shape, goal,] bend) with float `+=`, stored as CSR;
+//   * per node, the list of (constraint, local index) contribution slots in the order the reference adds
+//     them to the force vector (Solver.cpp:310-349), so the device right-hand side sums in that order;
+//   * per node, the number of surface-triangle incidences (one floor contact each, Solver.cpp:829-834).
+// The factorisation itself is replaced by CG on the device (pd_kernels.hip).
+#include <algorithm>
+#include <cstring>
+
+#include "device_util.h"
+
+namespace pies {
+
+namespace {
+struct Entry {
+  uint32_t col;
+  float val;
+};
+}  // namespace
+
+int pd_build(pies_solver* s) {
+  const uint32_t n = s->nodeCount();
+  if (!s->h_bend.empty())
+    return fail(s, PIES_ERR_UNSUPPORTED, "PD with bend constraints: not available in this build yet");
+  const float h = s->opt.fixedTimestepSize / s->opt.timeSubsteps;
+  const float h2 = h * h;
+
+  // ---- K, row by row, entries appended in the reference's accumulation order -------------------------
+  std::vector<std::vector<Entry>> rows(n);
+  for (uint32_t i = 0; i < n; ++i) rows[i].push_back({i, 1.0f / (s->h_invMass[i] * h2)});  // Solver.cpp:179-182
+  for (const HostPosition& c : s->h_position) rows[c.id].push_back({c.id, c.w * 1.0f});    // A = B = 1
+  for (const HostDistance& c : s->h_distance) {                                            // A^T A = [[.5,-.5],[-.5,.5]]
+    const float AtA[2][2] = {{0.5f * 0.5f + -0.5f * -0.5f, 0.5f * -0.5f + -0.5f * 0.5f},
+                             {-0.5f * 0.5f + 0.5f * -0.5f, -0.5f * -0.5f + 0.5f * 0.5f}};
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j) rows[c.ids[i]].push_back({c.ids[j], c.w * AtA[i][j]});
+  }
+  for (const std::vector<HostTet>* list : {&s->h_tet, &s->h_volume})
+    for (const HostTet& c : *list)
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) rows[c.ids[i]].push_back({c.ids[j], c.w * c.AtA[4 * i + j]});
+
+  std::vector<uint32_t> rowptr(n + 1, 0), col;
+  std::vector<float> val, kdiag(n, 0.f);
+  col.reserve(static_cast<size_t>(n) * 16);
+  val.reserve(static_cast<size_t>(n) * 16);
+  for (uint32_t i = 0; i < n; ++i) {
+    std::vector<Entry>& r = rows[i];
+    std::stable_sort(r.begin(), r.end(), [](const Entry& a, const Entry& b) { return a.col < b.col; });
+    for (size_t k = 0; k < r.size();) {
+      float acc = r[k].val;  // coeffRef(i,j) starts at 0: 0 + v == v
+      size_t m = k + 1;
+      for (; m < r.size() && r[m].col == r[k].col; ++m) acc += r[m].val;
+      col.push_back(r[k].col);
+      val.push_back(acc);
+      if (r[k].col == i) kdiag[i] = acc;
+      k = m;
+    }
+    rowptr[i + 1] = static_cast<uint32_t>(col.size());
+    std::vector<Entry>().swap(r);
+  }
+  s->pd_nnz = static_cast<uint32_t>(col.size());
+
+  // ---- contribution slots and per-node incidence lists -------------------------------------------------
+  const uint32_t cnt[5] = {(uint32_t)s->h_position.size(), (uint32_t)s->h_distance.size(), (uint32_t)s->h_tet.size(),
+                           (uint32_t)s->h_volume.size(), 0u};
+  const uint32_t arity[5] = {1, 2, 4, 4, 4};
+  uint32_t total = 0;
+  for (int t = 0; t < 5; ++t) {
+    s->slotBase[t] = total;
+    total += cnt[t] * arity[t];
+  }
+  std::vector<uint32_t> incPtr(n + 1, 0);
+  auto for_each_incidence = [&](auto&& fn) {
+    // reference order of setupGlobalForceVector calls: position, distance, tet, volume, bend (Solver.cpp:310-327)
+    for (uint32_t c = 0; c < cnt[0]; ++c) fn(s->h_position[c].id, s->slotBase[0] + c);
+    for (uint32_t c = 0; c < cnt[1]; ++c)
+      for (uint32_t i = 0; i < 2; ++i) fn(s->h_distance[c].ids[i], s->slotBase[1] + 2 * c + i);
+    for (uint32_t c = 0; c < cnt[2]; ++c)
+      for (uint32_t i = 0; i < 4; ++i) fn(s->h_tet[c].ids[i], s->slotBase[2] + 4 * c + i);
+    for (uint32_t c = 0; c < cnt[3]; ++c)
+      for (uint32_t i = 0; i < 4; ++i) fn(s->h_volume[c].ids[i], s->slotBase[3] + 4 * c + i);
+  };
+  for_each_incidence([&](uint32_t node, uint32_t) { ++incPtr[node + 1]; });
+  for (uint32_t i = 0; i < n; ++i) incPtr[i + 1] += incPtr[i];
+  std::vector<uint32_t> incSlot(incPtr[n]), cur(incPtr.begin(), incPtr.end() - 1);
+  for_each_incidence([&](uint32_t node, uint32_t slot) { incSlot[cur[node]++] = slot; });
+
+  std::vector<uint32_t> triCount(n, 0);
+  for (uint32_t id : s->h_triangles) ++triCount[id];
+
+  // position constraints project to a constant: w * (A^T B p) = w * (0 + 1*target)
+  std::vector<float4> contrib0(cnt[0]);
+  for (uint32_t c = 0; c < cnt[0]; ++c) {
+    const HostPosition& p = s->h_position[c];
+    contrib0[c] = make_float4(p.w * (0.0f + 1.0f * p.target[0]), p.w * (0.0f + 1.0f * p.target[1]),
+                              p.w * (0.0f + 1.0f * p.target[2]), 0.f);
+  }
+
+  // ---- HBM ---------------------------------------------------------------------------------------------
+  PdArrays& pd = s->pd;
+  CgArrays& cg = pd.cg;
+  cg.n = n;
+  cg.nparts = std::max(1u, std::min(kCgBlocks, (n + 15) / 16));
+  uint32_t *d_rowptr, *d_col, *d_incPtr, *d_incSlot, *d_tri;
+  float *d_val, *d_kdiag;
+  if (int rc = upload(s, rowptr, &d_rowptr)) return rc;
+  if (int rc = upload(s, col, &d_col)) return rc;
+  if (int rc = upload(s, val, &d_val)) return rc;
+  if (int rc = upload(s, kdiag, &d_kdiag)) return rc;
+  if (int rc = upload(s, incPtr, &d_incPtr)) return rc;
+  if (int rc = upload(s, incSlot, &d_incSlot)) return rc;
+  if (int rc = upload(s, triCount, &d_tri)) return rc;
+  cg.rowptr = d_rowptr; cg.col = d_col; cg.val = d_val;
+  pd.kdiag = d_kdiag; pd.incPtr = d_incPtr; pd.incSlot = d_incSlot; pd.triCount = d_tri;
+  if (int rc = dev_alloc(s, n, &pd.msn)) return rc;
+  if (int rc = dev_alloc(s, n, &pd.rhs)) return rc;
+  if (int rc = dev_alloc(s, n, &pd.statp, true)) return rc;
+  if (int rc = dev_alloc(s, n, &pd.nstatic, true)) return rc;
+  if (int rc = dev_alloc(s, std::max<size_t>(total, 1), &pd.contrib, true)) return rc;
+  if (int rc = dev_alloc(s, n, &cg.cdiag, true)) return rc;
+  if (int rc = dev_alloc(s, n, &cg.dinv, true)) return rc;
+  if (int rc = dev_alloc(s, n, &cg.r)) return rc;
+  if (int rc = dev_alloc(s, n, &cg.z)) return rc;
+  if (int rc = dev_alloc(s, n, &cg.p[0], true)) return rc;
+  if (int rc = dev_alloc(s, n, &cg.p[1], true)) return rc;
+  if (int rc = dev_alloc(s, n, &cg.ap)) return rc;
+  if (int rc = dev_alloc(s, kCgBlocks * 9, &cg.partI, true)) return rc;
+  if (int rc = dev_alloc(s, kCgBlocks * 3, &cg.partA, true)) return rc;
+  if (int rc = dev_alloc(s, kCgBlocks * 6, &cg.partB, true)) return rc;
+  if (int rc = dev_alloc(s, kCgBlocks * 6, &cg.partBnext, true)) return rc;
+  if (int rc = dev_alloc(s, 16, &cg.scal, true)) return rc;
+  if (int rc = dev_alloc(s, 4, &cg.stats, true)) return rc;
+  if (!contrib0.empty())
+    HIP_TRY(s, hipMemcpyAsync(pd.contrib + s->slotBase[0], contrib0.data(), contrib0.size() * sizeof(float4),
+                              hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  return PIES_OK;
+}
+
+}  // namespace pies

@@ -87,6 +87,10 @@ void build_plan(const OpView& ops, uint32_t nodeCount, int schedule, Plan& out) 
   if (ops.count == 0) return;
   std::vector<uint32_t> key(ops.count, 0);
   uint32_t nkeys = 0;
+  if (schedule < 0) {  // order-independent use (PD local step): one batch, host order
+    plan_from_keys(key, 1, out);
+    return;
+  }
   if (schedule == PIES_SCHEDULE_COLOURED && colours(ops, nodeCount, key, nkeys)) {
     plan_from_keys(key, nkeys, out);
     return;

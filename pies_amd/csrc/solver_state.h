@@ -9,6 +9,7 @@
 
 #include "../../include/pies_hip.h"
 #include "kernels.h"
+#include "pd_kernels.h"
 
 namespace pies {
 
@@ -92,6 +93,15 @@ struct pies_solver {
   float4 *d_tc_q0 = nullptr, *d_tc_q1 = nullptr, *d_tc_q2 = nullptr;
   uint4* d_bc_ids = nullptr;
   float2* d_bc_aw = nullptr;
+  uint4* d_vc_ids = nullptr;  // volume constraints (PD only), host order
+  float4 *d_vc_q0 = nullptr, *d_vc_q1 = nullptr, *d_vc_q2 = nullptr;
+
+  // ---- Projective Dynamics ----
+  pies::PdArrays pd{};
+  uint32_t slotBase[5] = {0, 0, 0, 0, 0};  // first contribution slot of each container
+  uint32_t pd_nnz = 0;
+  float pcgTol = 3.0e-7f;     // relative residual ||r|| / ||b|| per coordinate column
+  uint32_t pcgMaxIters = 12;  // CG iterations captured per global step
   std::vector<void*> allocations;
   float4* h_stage = nullptr;  // pinned staging for the per-tick position read-back
   size_t h_stage_n = 0;
