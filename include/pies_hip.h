@@ -146,7 +146,9 @@ int pies_tick(pies_solver_t* s);
 int pies_tick_async(pies_solver_t* s);
 int pies_synchronize(pies_solver_t* s);
 /* _simFailed latch (Solver.cpp:26-28,853-856) */
-int pies_failed(const pies_solver_t* s, int* failed);
+int pies_failed(pies_solver_t* s, int* failed);
+/* Node-node pairs resolved by the PBD collision pass since the last call (statistics). */
+int pies_collision_pairs(pies_solver_t* s, uint64_t* pairs);
 
 /* ---- state access --------------------------------------------------------------------------- */
 int pies_count(const pies_solver_t* s, int what, uint32_t* out);
@@ -167,7 +169,8 @@ int pies_get_batches(pies_solver_t* s, int type, uint32_t* batch_offsets, uint32
  * the solver's stream.  Returns the number of timed launches, their summed device time and the number
  * of units (constraints or nodes) they processed.  Advances the simulation by one substep. */
 enum { PIES_KERNEL_PREDICT = 0, PIES_KERNEL_POSITION = 1, PIES_KERNEL_DISTANCE = 2, PIES_KERNEL_TET = 3,
-       PIES_KERNEL_BEND = 4, PIES_KERNEL_FLOOR = 5, PIES_KERNEL_VELOCITY = 6, PIES_KERNEL_COUNT = 7 };
+       PIES_KERNEL_BEND = 4, PIES_KERNEL_FLOOR = 5, PIES_KERNEL_VELOCITY = 6, PIES_KERNEL_HASH = 7,
+       PIES_KERNEL_COLLIDE = 8, PIES_KERNEL_COUNT = 9 };
 int pies_profile_substep(pies_solver_t* s, int kernel, uint32_t* launches, double* total_ms, uint64_t* units);
 /* launches per substep of the captured graph, per kernel class (PIES_KERNEL_COUNT entries) */
 int pies_launch_counts(pies_solver_t* s, uint32_t* out);

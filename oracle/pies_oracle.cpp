@@ -447,6 +447,14 @@ struct NodeHash {
             map[CellId{r.minX + dx, r.minY + dy, r.minZ + dz}].push_back(i);
     }
   }
+  void findCollisions(const CellRange& r, std::vector<const std::vector<uint32_t>*>& out) const {
+    for (uint32_t dx = 0; dx < r.lengthX; ++dx)
+      for (uint32_t dy = 0; dy < r.lengthY; ++dy)
+        for (uint32_t dz = 0; dz < r.lengthZ; ++dz) {
+          auto it = map.find(CellId{r.minX + dx, r.minY + dy, r.minZ + dz});
+          if (it != map.end()) out.push_back(&it->second);
+        }
+  }
   // SpatialHash.h:101-127
   void findCollisions(const Node& node, float scale, std::vector<const std::vector<uint32_t>*>& out) const {
     CellRange r = nodeCompRange(node, scale);
@@ -581,6 +589,11 @@ struct ora_solver {
 
   // optional replay of a device collision visiting order (empty = reference order 0..N-1)
   std::vector<uint32_t> collisionOrder;
+  // collisionRule 0: the reference's loop (ascending node index, query range from the node's current
+  // position).  1: the device's documented rule (DESIGN.md "Node-node collisions"): nodes are visited
+  // pass by pass, pass = (min cell mod 3) per axis at hash-build time, then by min cell, then ascending
+  // index, and a node queries the cell range it was *inserted* with.  Same per-pair arithmetic.
+  int collisionRule = 0;
 
   NodeHash hashNodes;
   std::vector<StaticCollision> staticCollisions;
@@ -636,9 +649,29 @@ void ora_solver::tickPBD() {
         hashNodes.bulkInsert(nodes, opt.gridSpacing);      // :82
         std::vector<const std::vector<uint32_t>*> scratch;
         const size_t n = nodes.size();
+        std::vector<CellRange> inserted;
+        if (collisionRule == 1) {
+          inserted.resize(n);
+          for (size_t k = 0; k < n; ++k) inserted[k] = nodeCompRange(nodes[k], opt.gridSpacing);
+          auto mod3 = [](int64_t v) { return static_cast<int>(((v % 3) + 3) % 3); };
+          auto colour = [&](const CellRange& r) { return mod3(r.minX) + 3 * mod3(r.minY) + 9 * mod3(r.minZ); };
+          collisionOrder.resize(n);
+          std::iota(collisionOrder.begin(), collisionOrder.end(), 0u);
+          std::stable_sort(collisionOrder.begin(), collisionOrder.end(), [&](uint32_t a, uint32_t b) {
+            const CellRange &ra = inserted[a], &rb = inserted[b];
+            int ca = colour(ra), cb = colour(rb);
+            if (ca != cb) return ca < cb;
+            if (ra.minX != rb.minX) return ra.minX < rb.minX;
+            if (ra.minY != rb.minY) return ra.minY < rb.minY;
+            if (ra.minZ != rb.minZ) return ra.minZ < rb.minZ;
+            return a < b;
+          });
+        }
         for (size_t oi = 0; oi < n; ++oi) {                // :86-130
-          Node& node = nodes[collisionOrder.empty() ? oi : collisionOrder[oi]];
-          hashNodes.findCollisions(node, opt.gridSpacing, scratch);
+          const uint32_t ni = collisionOrder.empty() ? static_cast<uint32_t>(oi) : collisionOrder[oi];
+          Node& node = nodes[ni];
+          if (collisionRule == 1) hashNodes.findCollisions(inserted[ni], scratch);
+          else hashNodes.findCollisions(node, opt.gridSpacing, scratch);
           for (const std::vector<uint32_t>* bucket : scratch) {
             for (uint32_t otherId : *bucket) {
               Node* other = &nodes[otherId];
@@ -944,10 +977,11 @@ ora_solver* ora_create(const void* options) {
 void ora_destroy(ora_solver* s) { delete s; }
 uint32_t ora_options_size() { return sizeof(Options); }
 
-// flag: 0 = releaseHinge, 1 = nodeCollisions (extension)
+// flag: 0 = releaseHinge, 1 = nodeCollisions (extension), 2 = collision visiting rule (0 reference, 1 device)
 void ora_set_flag(ora_solver* s, int flag, int value) {
   if (flag == 0) s->releaseHinge = value != 0;
   if (flag == 1) s->nodeCollisions = value != 0;
+  if (flag == 2) { s->collisionRule = value; s->collisionOrder.clear(); }
 }
 int ora_failed(ora_solver* s) { return s->simFailed ? 1 : 0; }
 

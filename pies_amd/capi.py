@@ -17,9 +17,9 @@ POSITION, DISTANCE, TET, VOLUME, BEND, SHAPE, GOAL, TRIANGLES, LINES, NODES = ra
 SCHEDULE_EXACT, SCHEDULE_COLOURED = 0, 1
 FLAG_RELEASE_HINGE, FLAG_NODE_COLLISIONS = 0, 1
 NODE_POSITION, NODE_PREV_POSITION, NODE_VELOCITY, NODE_RADIUS, NODE_INV_MASS = range(5)
-KERNEL_NAMES = ["predict", "position", "distance", "tet", "bend", "floor", "velocity"]
+KERNEL_NAMES = ["predict", "position", "distance", "tet", "bend", "floor", "velocity", "hash", "collide"]
 KERNEL_PREDICT, KERNEL_POSITION, KERNEL_DISTANCE, KERNEL_TET, KERNEL_BEND, KERNEL_FLOOR, KERNEL_VELOCITY = range(7)
-KERNEL_COUNT = 7
+KERNEL_COUNT = 9
 
 # every symbol include/pies_hip.h declares (checked by tests/test_capi_symbols.py against the header)
 SYMBOLS = [
@@ -30,7 +30,7 @@ SYMBOLS = [
     "pies_create_bend_sheet", "pies_set_flag", "pies_set_schedule", "pies_finalize", "pies_tick", "pies_tick_async",
     "pies_synchronize", "pies_failed", "pies_count", "pies_read_nodes", "pies_write_nodes", "pies_get_ids",
     "pies_get_rest", "pies_get_order", "pies_get_batches", "pies_profile_substep", "pies_launch_counts",
-    "pies_set_pcg", "pies_get_pcg_stats",
+    "pies_set_pcg", "pies_get_pcg_stats", "pies_collision_pairs",
 ]
 
 
@@ -99,6 +99,7 @@ def load():
         "pies_launch_counts": [vp, pu],
         "pies_set_pcg": [vp, f32, u32],
         "pies_get_pcg_stats": [vp, pf, pu, pu],
+        "pies_collision_pairs": [vp, C.POINTER(C.c_uint64)],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -260,6 +261,12 @@ class Solver:
         f = C.c_int()
         self._ck(self._L.pies_failed(self._h, C.byref(f)))
         return bool(f.value)
+
+    @property
+    def collision_pairs(self):
+        n = C.c_uint64()
+        self._ck(self._L.pies_collision_pairs(self._h, C.byref(n)))
+        return n.value
 
     # -- state ---------------------------------------------------------------------------------
     def count(self, what):

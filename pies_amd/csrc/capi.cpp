@@ -32,6 +32,7 @@ static void free_device(pies_solver* s) {
   s->d_bc_ids = nullptr; s->d_bc_aw = nullptr;
   s->d_vc_ids = nullptr; s->d_vc_q0 = s->d_vc_q1 = s->d_vc_q2 = nullptr;
   s->pd = PdArrays{};
+  s->hash = HashArrays{};
 }
 
 static int upload_nodes(pies_solver* s) {
@@ -107,6 +108,11 @@ static void enqueue_pbd_substep(pies_solver* s, int timedKernel, LaunchTimer* ti
       launch_bend(st, s->nd.pos, s->d_bc_ids, s->d_bc_aw, b.start, b.count, T(PIES_KERNEL_BEND));
       C(PIES_KERNEL_BEND);
     }
+    if (s->nodeCollisions) {  // Solver.cpp:81-130
+      const uint32_t nb = launch_hash_build(st, s->hash, s->nd, s->opt.gridSpacing);
+      const uint32_t nc = launch_collide(st, s->hash, s->nd, s->opt.friction, s->opt.staticFrictionThreshold);
+      if (counts) { counts[PIES_KERNEL_HASH] += nb; counts[PIES_KERNEL_COLLIDE] += nc; }
+    }
     launch_floor(st, s->nd, s->opt.floorHeight, T(PIES_KERNEL_FLOOR));
     C(PIES_KERNEL_FLOOR);
   }
@@ -158,6 +164,19 @@ static int capture_graph(pies_solver* s) {
   hipError_t e = hipStreamEndCapture(s->stream, &s->graph);
   if (e != hipSuccess) return fail(s, PIES_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
   HIP_TRY(s, hipGraphInstantiate(&s->graphExec, s->graph, nullptr, nullptr, 0));
+  return PIES_OK;
+}
+
+static int poll_failure(pies_solver* s) {
+  if (s->simFailed || !s->hash.counters) return PIES_OK;
+  uint32_t flag = 0;
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipMemcpyAsync(&flag, s->hash.counters + 3, sizeof(flag), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  if (flag) {  // like the reference's latch (Solver.cpp:741-755, 853-856): tick becomes a no-op
+    s->simFailed = true;
+    s->error = flag & 2 ? "collision grid overflow" : "a node left the supported cell range (non-finite position or range > 2 cells)";
+  }
   return PIES_OK;
 }
 
@@ -297,8 +316,15 @@ int pies_finalize(pies_solver_t* s) {
     return PIES_OK;
   }
   const bool isPD = s->opt.solver == PIES_SOLVER_PD;
-  if (s->nodeCollisions && !isPD)
-    return fail(s, PIES_ERR_UNSUPPORTED, "PBD node-node collisions: not available in this build yet; clear PIES_FLAG_NODE_COLLISIONS");
+  const bool collide = s->nodeCollisions && !isPD;
+  if (collide && !s->h_radius.empty()) {
+    // NodeCompRange (Solver.cpp:877-901) spans ceil(fract + 2R) cells per axis with R = (r + 0.5)/gridSpacing;
+    // the device passes assume at most 2, i.e. 2R <= 1 (true for the reference defaults r = 0.5, spacing 2).
+    const float rmax = *std::max_element(s->h_radius.begin(), s->h_radius.end());
+    if (!(2.0f * ((rmax + 0.5f) / s->opt.gridSpacing) <= 1.0f))
+      return fail(s, PIES_ERR_UNSUPPORTED,
+                  "node-node collisions need gridSpacing >= 2*(max radius + 0.5) in this build (a node may span at most 2 cells per axis)");
+  }
   if (int rc = download_nodes(s)) return rc;
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   free_device(s);
@@ -395,6 +421,32 @@ int pies_finalize(pies_solver_t* s) {
     if (int rc = upload(s, aw, &s->d_bc_aw)) return rc;
     HIP_TRY(s, hipStreamSynchronize(s->stream));
   }
+  if (collide && n) {
+    HashArrays& H = s->hash;
+    H.n = n;
+    uint32_t cap = 1024;
+    while (cap < 16ull * n && cap < (1u << 30)) cap <<= 1;  // distinct cells <= 8n: load factor <= 0.5
+    H.capacity = cap;
+    H.mask = cap - 1;
+    if (int rc = dev_alloc(s, cap, &H.keys)) return rc;
+    HIP_TRY(s, hipMemsetAsync(H.keys, 0xFF, static_cast<size_t>(cap) * sizeof(uint64_t), s->stream));
+    if (int rc = dev_alloc(s, cap, &H.cnt, true)) return rc;
+    if (int rc = dev_alloc(s, cap, &H.start, true)) return rc;
+    if (int rc = dev_alloc(s, cap, &H.fill, true)) return rc;
+    if (int rc = dev_alloc(s, cap, &H.gcnt, true)) return rc;
+    if (int rc = dev_alloc(s, cap, &H.gstart, true)) return rc;
+    if (int rc = dev_alloc(s, cap, &H.gfill, true)) return rc;
+    if (int rc = dev_alloc(s, 8ull * n, &H.used, true)) return rc;
+    if (int rc = dev_alloc(s, 32, &H.counters, true)) return rc;
+    if (int rc = dev_alloc(s, 27ull * n, &H.passList, true)) return rc;
+    if (int rc = dev_alloc(s, 8ull * n, &H.nodeSlot, true)) return rc;
+    if (int rc = dev_alloc(s, n, &H.rng, true)) return rc;
+    if (int rc = dev_alloc(s, 8ull * n, &H.bucket, true)) return rc;
+    if (int rc = dev_alloc(s, 8ull * n, &H.bucketSorted, true)) return rc;
+    if (int rc = dev_alloc(s, n, &H.group, true)) return rc;
+    if (int rc = dev_alloc(s, n, &H.groupSorted, true)) return rc;
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+  }
   if (isPD) {
     std::vector<uint4> id(s->h_volume.size());
     std::vector<float4> q0(id.size()), q1(id.size()), q2(id.size());
@@ -448,6 +500,7 @@ int pies_tick(pies_solver_t* s) {
   // Solver.cpp:157 : _vertices[i].position = position -- one D2H copy per tick
   HIP_TRY(s, hipMemcpyAsync(s->h_stage, s->nd.pos, n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
+  if (int rc = poll_failure(s)) return rc;
   for (uint32_t i = 0; i < n; ++i) {
     s->h_pos[3 * i] = s->h_stage[i].x;
     s->h_pos[3 * i + 1] = s->h_stage[i].y;
@@ -456,9 +509,23 @@ int pies_tick(pies_solver_t* s) {
   return PIES_OK;
 }
 
-int pies_failed(const pies_solver_t* s, int* failed) {
+int pies_failed(pies_solver_t* s, int* failed) {
   if (!s || !failed) return PIES_ERR_INVALID;
+  if (int rc = poll_failure(s)) return rc;
   *failed = s->simFailed ? 1 : 0;
+  return PIES_OK;
+}
+
+int pies_collision_pairs(pies_solver_t* s, uint64_t* pairs) {
+  if (!s || !pairs) return PIES_ERR_INVALID;
+  *pairs = 0;
+  if (!s->hash.counters) return PIES_OK;
+  uint32_t v = 0;
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipMemcpyAsync(&v, s->hash.counters + 31, sizeof(v), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  HIP_TRY(s, hipMemsetAsync(s->hash.counters + 31, 0, sizeof(v), s->stream));
+  *pairs = v;
   return PIES_OK;
 }
 

@@ -10,6 +10,7 @@
 #include "../../include/pies_hip.h"
 #include "kernels.h"
 #include "pd_kernels.h"
+#include "hash_kernels.h"
 
 namespace pies {
 
@@ -96,6 +97,9 @@ struct pies_solver {
   uint4* d_vc_ids = nullptr;  // volume constraints (PD only), host order
   float4 *d_vc_q0 = nullptr, *d_vc_q1 = nullptr, *d_vc_q2 = nullptr;
 
+  // ---- node-node collisions (PBD) ----
+  pies::HashArrays hash{};
+
   // ---- Projective Dynamics ----
   pies::PdArrays pd{};
   uint32_t slotBase[5] = {0, 0, 0, 0, 0};  // first contribution slot of each container
@@ -108,7 +112,7 @@ struct pies_solver {
 
   hipGraph_t graph = nullptr;
   hipGraphExec_t graphExec = nullptr;
-  uint32_t launchCounts[PIES_KERNEL_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+  uint32_t launchCounts[PIES_KERNEL_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
   uint32_t nodeCount() const { return static_cast<uint32_t>(h_radius.size()); }
 };
