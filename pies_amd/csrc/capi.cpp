@@ -175,7 +175,9 @@ static int poll_failure(pies_solver* s) {
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   if (flag) {  // like the reference's latch (Solver.cpp:741-755, 853-856): tick becomes a no-op
     s->simFailed = true;
-    s->error = flag & 2 ? "collision grid overflow" : "a node left the supported cell range (non-finite position or range > 2 cells)";
+    s->error = flag & 2   ? "collision grid overflow"
+               : flag & 4 ? "more than 2048 nodes overlap one grid cell (runaway pile-up)"
+                          : "a node left the supported cell range (non-finite position or range > 2 cells)";
   }
   return PIES_OK;
 }

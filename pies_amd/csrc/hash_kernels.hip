@@ -31,6 +31,7 @@ namespace pies {
 constexpr int kBlock = 256;
 constexpr uint64_t kEmpty = ~0ull;
 constexpr int kCoordBias = 1 << 20;  // cell coordinates are packed as 21-bit biased integers
+constexpr uint32_t kMaxBucket = 2048;  // nodes overlapping one cell before the simulation is declared failed
 
 static inline dim3 grid_for(uint32_t n) { return dim3((n + kBlock - 1) / kBlock); }
 
@@ -124,6 +125,7 @@ __global__ void __launch_bounds__(kBlock) k_hash_alloc(HashArrays H) {
   const uint32_t used = H.counters[0];
   for (uint32_t u = blockIdx.x * kBlock + threadIdx.x; u < used; u += gridDim.x * kBlock) {
     const uint32_t s = H.used[u];
+    if (H.cnt[s] > kMaxBucket) atomicOr(&H.counters[3], 4u);  // runaway pile-up: latch, like Solver.cpp:741-755
     H.start[s] = atomicAdd(&H.counters[1], H.cnt[s]);
     H.fill[s] = 0;
     const uint32_t gc = H.gcnt[s];
@@ -164,6 +166,7 @@ PIES_DEV void rank_sort(const uint32_t* __restrict__ in, uint32_t* __restrict__ 
   }
 }
 __global__ void __launch_bounds__(kBlock) k_hash_sort(HashArrays H) {
+  if (H.counters[3]) return;  // failed: the host latches _simFailed
   const uint32_t used = H.counters[0];
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
@@ -188,7 +191,9 @@ __global__ void __launch_bounds__(kBlock) k_collide(HashArrays H, float4* pos4, 
   float* vel = reinterpret_cast<float*>(vel4);
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
+  if (H.counters[3]) return;  // failed: the host latches _simFailed
   const uint32_t ngroups = H.counters[4 + pass];
+  uint32_t resolved = 0;  // statistics, one atomic per wave at the end (a per-pair atomic on one word serialises the chip)
   for (uint32_t g = wave; g < ngroups; g += nwaves) {
     const uint32_t gslot = H.passList[static_cast<size_t>(pass) * H.n + g];
     const uint32_t gs = H.gstart[gslot], gc = H.gcnt[gslot];
@@ -209,9 +214,10 @@ __global__ void __launch_bounds__(kBlock) k_collide(HashArrays H, float4* pos4, 
             for (uint32_t base = 0; base < bc; base += 64) {
               const bool valid = base + lane < bc;
               const uint32_t j = valid ? H.bucketSorted[bs + base + lane] : 0xffffffffu;
-              float pjx = 0.f, pjy = 0.f, pjz = 0.f, imj = 1.f, rj = 0.f;
-              if (valid) {
+              float pjx = 0.f, pjy = 0.f, pjz = 0.f, imj = 1.f, rj = 0.f, wjx = 0.f, wjy = 0.f, wjz = 0.f;
+              if (valid) {  // candidate state up front: a resolve then needs no further loads
                 pjx = ld(pos + 4 * j); pjy = ld(pos + 4 * j + 1); pjz = ld(pos + 4 * j + 2); imj = ld(pos + 4 * j + 3);
+                wjx = ld(vel + 4 * j); wjy = ld(vel + 4 * j + 1); wjz = ld(vel + 4 * j + 2);
                 rj = radius[j];
               }
               int cursor = 0;
@@ -238,9 +244,8 @@ __global__ void __launch_bounds__(kBlock) k_collide(HashArrays H, float4* pos4, 
                 float ojx = (hj == i) ? pix : bcast(pjx, l), ojy = (hj == i) ? piy : bcast(pjy, l), ojz = (hj == i) ? piz : bcast(pjz, l);
                 ojx += ((sb * ux) * himj) / wSum; ojy += ((sb * uy) * himj) / wSum; ojz += ((sb * uz) * himj) / wSum;
                 // friction on the velocities
-                float vjx, vjy, vjz;
+                float vjx = bcast(wjx, l), vjy = bcast(wjy, l), vjz = bcast(wjz, l);
                 if (hj == i) { vjx = vix; vjy = viy; vjz = viz; }
-                else { vjx = ld(vel + 4 * hj); vjy = ld(vel + 4 * hj + 1); vjz = ld(vel + 4 * hj + 2); }
                 const float rx = vjx - vix, ry = vjy - viy, rz = vjz - viz;
                 const float rd = rx * ux + ry * uy + rz * uz;
                 const float qx = rx - rd * ux, qy = ry - rd * uy, qz = rz - rd * uz;
@@ -257,7 +262,7 @@ __global__ void __launch_bounds__(kBlock) k_collide(HashArrays H, float4* pos4, 
                     st(vel + 4 * hj, vjx); st(vel + 4 * hj + 1, vjy); st(vel + 4 * hj + 2, vjz);
                   }
                 }
-                if (lane == 0) atomicAdd(&H.counters[31], 1u);  // statistics: resolved pairs
+                ++resolved;
                 cursor = l + 1;
               }
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores are in L2 before its next loads
@@ -270,6 +275,7 @@ __global__ void __launch_bounds__(kBlock) k_collide(HashArrays H, float4* pos4, 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   }
+  if (lane == 0 && resolved) atomicAdd(&H.counters[31], resolved);
 }
 
 // ----------------------------------------------------------------------------------------------------
