@@ -1,0 +1,238 @@
+// Pies::Solver -- drop-in for the reference's public class (Include/Pies/Solver.h:21-116), implemented on
+// the MI355X through the C ABI in pies_hip.h (link libpies_hip.so).  Same names, signatures, defaults and
+// ownership rules; hosts (PiesForAlthea / PiesForMaya) recompile against this header.
+//
+//   Pies::SolverOptions opt; opt.solver = Pies::SolverName::PBD;
+//   Pies::Solver solver(opt);
+//   solver.createTetBox({0, 5, 0}, 1.0f, {0, 0, 0}, 0.05f, 1.0f, false);
+//   solver.tick(dt);                       // positions are current in getVertices() when this returns
+//
+// Differences from the reference, all documented in DESIGN.md: tick() runs on the GPU; getters return
+// host mirrors refreshed once per tick (Solver.cpp:157,393 refresh per substep, which nothing can observe);
+// addTriMeshVolume needs tetgen, which is not part of this build (use addTetMeshVolume with a
+// pre-tetrahedralised mesh); errors surface as std::runtime_error carrying pies_last_error().
+#pragma once
+
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../pies_hip.h"
+#include "Node.h"
+#include "Tetrahedron.h"
+#include "Triangle.h"
+#include "glm_compat.h"
+
+namespace Pies {
+enum class SolverName { PBD, PD };  // Solver.h:21
+
+struct SolverOptions {  // Solver.h:23-38, field for field
+  float fixedTimestepSize = 0.012f;
+  uint32_t timeSubsteps = 1;
+  uint32_t iterations = 4;
+  uint32_t collisionStabilizationIterations = 4;
+  float collisionThresholdDistance = 0.1f;
+  float collisionThickness = 0.05f;
+  float gravity = 10.0f;
+  float damping = 0.006f;
+  float friction = 0.01f;
+  float staticFrictionThreshold = 0.f;
+  float floorHeight = 0.0f;
+  float gridSpacing = 2.0f;
+  uint32_t threadCount = 8;
+  SolverName solver = SolverName::PD;
+};
+static_assert(sizeof(SolverOptions) == sizeof(pies_options_t), "SolverOptions must mirror pies_options_t");
+
+class Solver {
+public:
+  struct Vertex {  // Solver.h:42-49: consumed directly as a vertex/instance stream by the renderers
+    glm::vec3 position{};
+    float radius{};
+    glm::vec3 baseColor{};
+    float roughness{};
+    float metallic{};
+  };
+
+  bool renderStateDirty = true;
+  bool releaseHinge = false;
+  // extensions (not in the reference): which device schedule maps the Gauss-Seidel sweeps, and whether the
+  // PBD node-node pass runs (the reference always runs it)
+  int schedule = PIES_SCHEDULE_EXACT;
+  bool nodeCollisions = true;
+
+  Solver() : Solver(SolverOptions{}) {}
+  explicit Solver(const SolverOptions& options, int device = 0) : _options(options) {
+    pies_options_t o;
+    static_assert(sizeof(o) == sizeof(options), "layout");
+    std::memcpy(&o, &options, sizeof(o));
+    if (pies_create(&o, device, &_h) != PIES_OK) throw std::runtime_error("Pies::Solver: no gfx950 HIP device (there is no CPU fallback)");
+  }
+  Solver(Solver&& rhs) noexcept { *this = std::move(rhs); }
+  Solver& operator=(Solver&& rhs) noexcept {
+    if (this != &rhs) {
+      if (_h) pies_destroy(_h);
+      _h = rhs._h;
+      rhs._h = nullptr;
+      _options = rhs._options;
+      _vertices = std::move(rhs._vertices);
+      _lines = std::move(rhs._lines);
+      _triangles = std::move(rhs._triangles);
+      renderStateDirty = rhs.renderStateDirty;
+      releaseHinge = rhs.releaseHinge;
+      schedule = rhs.schedule;
+      nodeCollisions = rhs.nodeCollisions;
+    }
+    return *this;
+  }
+  Solver(const Solver&) = delete;
+  Solver& operator=(const Solver&) = delete;
+  ~Solver() {
+    if (_h) pies_destroy(_h);
+  }
+
+  // Solver.cpp:25-38.  The argument is ignored like in the reference (the step is fixedTimestepSize).
+  void tick(float /*deltaTime*/) {
+    _ck(pies_set_flag(_h, PIES_FLAG_RELEASE_HINGE, releaseHinge ? 1 : 0));
+    _ck(pies_set_flag(_h, PIES_FLAG_NODE_COLLISIONS, nodeCollisions ? 1 : 0));
+    _ck(pies_set_schedule(_h, schedule));
+    _ck(pies_tick(_h));
+    _refreshPositions();
+  }
+  void tickPBD(float dt) { tick(dt); }  // the solver kind is fixed by SolverOptions::solver
+  void tickPD(float dt) { tick(dt); }
+
+  const std::vector<Vertex>& getVertices() const { return _vertices; }
+  const std::vector<uint32_t>& getLines() const { return _lines; }
+  const std::vector<Triangle>& getTriangles() const { return _triangles; }
+  const SolverOptions& getOptions() const { return _options; }
+
+  void clear() {
+    _ck(pies_clear(_h));
+    _vertices.clear();
+    _lines.clear();
+    _triangles.clear();
+    renderStateDirty = true;
+  }
+
+  // ---- importing meshes (PrimitiveUtilities.cpp:42-328) ----
+  void addNodes(const std::vector<glm::vec3>& vertices) {
+    std::vector<float> p = _flatten(vertices);
+    _ck(pies_add_nodes(_h, static_cast<uint32_t>(vertices.size()), p.data(), nullptr));
+    _syncRenderState();
+  }
+  void addTriMeshVolume(const std::vector<glm::vec3>&, const std::vector<uint32_t>&, const glm::vec3&, float, float, float, float,
+                        float, float, float) {
+    throw std::runtime_error("Pies::Solver::addTriMeshVolume needs tetgen (not part of this build): tetrahedralise offline and "
+                             "call addTetMeshVolume");
+  }
+  // Pre-tetrahedralised replacement for addTriMeshVolume: vertices, 4 indices per tet, 3 per boundary face.
+  void addTetMeshVolume(const std::vector<glm::vec3>& vertices, const std::vector<uint32_t>& tetIndices,
+                        const std::vector<uint32_t>& surfaceTriIndices, const glm::vec3& initialVelocity, float density,
+                        float strainStiffness, float minStrain, float maxStrain, float volumeStiffness, float compression,
+                        float stretching) {
+    const uint32_t n = static_cast<uint32_t>(vertices.size());
+    std::vector<float> p = _flatten(vertices), v(3 * n), r(n, 0.5f), im(n, 1.0f / density);
+    for (uint32_t i = 0; i < n; ++i) { v[3 * i] = initialVelocity[0]; v[3 * i + 1] = initialVelocity[1]; v[3 * i + 2] = initialVelocity[2]; }
+    uint32_t first = 0;
+    _ck(pies_add_nodes_ex(_h, n, p.data(), v.data(), r.data(), im.data(), &first));
+    std::vector<uint32_t> t(tetIndices), f(surfaceTriIndices);
+    for (uint32_t& id : t) id += first;
+    for (uint32_t& id : f) id += first;
+    const uint32_t nt = static_cast<uint32_t>(t.size() / 4);
+    if (strainStiffness != 0.0f) _ck(pies_add_tet_constraints(_h, nt, t.data(), strainStiffness, minStrain, maxStrain));
+    if (volumeStiffness != 0.0f) _ck(pies_add_volume_constraints(_h, nt, t.data(), volumeStiffness, compression, stretching));
+    _ck(pies_add_triangles(_h, static_cast<uint32_t>(f.size() / 3), f.data()));
+    _syncRenderState();
+  }
+  void addFixedRegions(const std::vector<glm::mat4>&, float) { throw std::runtime_error("Pies::Solver::addFixedRegions: goal matching is not in this build yet"); }
+  void updateFixedRegions(const std::vector<glm::mat4>&) { throw std::runtime_error("Pies::Solver::updateFixedRegions: goal matching is not in this build yet"); }
+  void addLinkedRegions(const std::vector<glm::mat4>&, float) { throw std::runtime_error("Pies::Solver::addLinkedRegions: shape matching is not in this build yet"); }
+
+  // ---- primitives (PrimitiveUtilities.cpp:330-1289), reference grid sizes ----
+  void createBox(const glm::vec3& translation, float scale, float w) {
+    const float t[3] = {translation[0], translation[1], translation[2]};
+    _ck(pies_create_box(_h, 5, 5, 5, t, scale, w, 0, 0, 2u));
+    _syncRenderState();
+  }
+  void createTetBox(const glm::vec3& translation, float scale, const glm::vec3& initialVelocity, float w, float mass, bool hinged) {
+    const float t[3] = {translation[0], translation[1], translation[2]}, v[3] = {initialVelocity[0], initialVelocity[1], initialVelocity[2]};
+    if (hinged) _ck(pies_create_tet_box(_h, 10, 2, 10, t, scale, v, w, mass, 3u));
+    else _ck(pies_create_tet_box(_h, 3, 3, 3, t, scale, v, w, mass, 3u));
+    _syncRenderState();
+  }
+  void createSheet(const glm::vec3& translation, float scale, float mass, float k) {
+    const float t[3] = {translation[0], translation[1], translation[2]};
+    _ck(pies_create_sheet(_h, 20, 20, t, scale, mass, k));
+    _syncRenderState();
+  }
+  void createShapeMatchingBox(const glm::vec3&, uint32_t, uint32_t, uint32_t, float, const glm::vec3&, float) {
+    throw std::runtime_error("Pies::Solver::createShapeMatchingBox: shape matching is not in this build yet");
+  }
+  void createShapeMatchingSheet(const glm::vec3&, float, const glm::vec3&, float) {
+    throw std::runtime_error("Pies::Solver::createShapeMatchingSheet: shape matching is not in this build yet");
+  }
+  void createBendSheet(const glm::vec3& translation, float scale, float w) {
+    const float t[3] = {translation[0], translation[1], translation[2]};
+    _ck(pies_create_bend_sheet(_h, 10, 10, t, scale, w));
+    _syncRenderState();
+  }
+
+  pies_solver_t* handle() const { return _h; }  // escape hatch to the C ABI (schedules, PCG settings, statistics)
+
+private:
+  static float _randf() { return static_cast<float>(double(std::rand()) / RAND_MAX); }  // cosmetics only (PrimitiveUtilities.cpp:10-12)
+  static std::vector<float> _flatten(const std::vector<glm::vec3>& v) {
+    std::vector<float> p(3 * v.size());
+    for (size_t i = 0; i < v.size(); ++i) { p[3 * i] = v[i][0]; p[3 * i + 1] = v[i][1]; p[3 * i + 2] = v[i][2]; }
+    return p;
+  }
+  void _ck(int rc) const {
+    if (rc != PIES_OK) throw std::runtime_error(std::string("Pies::Solver: ") + pies_last_error(_h));
+  }
+  // after an add*/create*: new vertices get one colour per primitive, lines/triangles are re-read
+  void _syncRenderState() {
+    uint32_t n = 0, nl = 0, nt = 0;
+    _ck(pies_count(_h, PIES_NODES, &n));
+    _ck(pies_count(_h, PIES_LINES, &nl));
+    _ck(pies_count(_h, PIES_TRIANGLES, &nt));
+    const size_t old = _vertices.size();
+    _vertices.resize(n);
+    std::vector<float> pos(3 * size_t(n)), rad(n);
+    if (n) {
+      _ck(pies_read_nodes(_h, PIES_NODE_POSITION, pos.data(), n));
+      _ck(pies_read_nodes(_h, PIES_NODE_RADIUS, rad.data(), n));
+    }
+    const glm::vec3 colour(_randf(), _randf(), _randf());
+    const float roughness = _randf(), metallic = static_cast<float>(std::rand() % 2);
+    for (size_t i = 0; i < n; ++i) {
+      _vertices[i].position = glm::vec3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+      _vertices[i].radius = rad[i];
+      if (i >= old) { _vertices[i].baseColor = colour; _vertices[i].roughness = roughness; _vertices[i].metallic = metallic; }
+    }
+    _lines.resize(nl);
+    if (nl) _ck(pies_get_ids(_h, PIES_LINES, _lines.data(), nl));
+    _triangles.resize(nt);
+    if (nt) _ck(pies_get_ids(_h, PIES_TRIANGLES, &_triangles[0].nodeIds[0], 3 * nt));
+    renderStateDirty = true;
+  }
+  void _refreshPositions() {
+    const uint32_t n = static_cast<uint32_t>(_vertices.size());
+    if (!n) return;
+    _scratch.resize(3 * size_t(n));
+    _ck(pies_read_nodes(_h, PIES_NODE_POSITION, _scratch.data(), n));
+    for (size_t i = 0; i < n; ++i) _vertices[i].position = glm::vec3(_scratch[3 * i], _scratch[3 * i + 1], _scratch[3 * i + 2]);
+  }
+
+  pies_solver_t* _h = nullptr;
+  SolverOptions _options;
+  std::vector<Vertex> _vertices;
+  std::vector<uint32_t> _lines;
+  std::vector<Triangle> _triangles;
+  std::vector<float> _scratch;
+};
+}  // namespace Pies

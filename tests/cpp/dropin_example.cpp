@@ -1,0 +1,31 @@
+// Compiles against the drop-in header exactly like a Pies host would (PiesForAlthea-style usage):
+// build a scene through the reference's public API, tick, read vertices.  Exit code 0 on success.
+#include <Pies/Solver.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+int main(int argc, char** argv) {
+  const bool pd = argc > 1 && std::strcmp(argv[1], "pd") == 0;
+  Pies::SolverOptions options;
+  options.solver = pd ? Pies::SolverName::PD : Pies::SolverName::PBD;
+  options.iterations = 6;
+  Pies::Solver solver(options);
+  solver.createTetBox(glm::vec3(0.0f, 4.0f, 0.0f), 1.0f, glm::vec3(0.0f), pd ? 1.0f : 0.002f, 1.0f, false);
+  solver.createBox(glm::vec3(8.0f, 3.0f, 0.0f), 1.0f, 0.5f);
+  solver.addNodes({glm::vec3(20.0f, 2.0f, 0.0f), glm::vec3(20.6f, 2.0f, 0.0f)});
+  const size_t n = solver.getVertices().size();
+  if (n != 27 + 125 + 2 || solver.getTriangles().empty() || solver.getLines().empty() || !solver.renderStateDirty) return 2;
+  solver.renderStateDirty = false;
+  const float y0 = solver.getVertices()[0].position[1];
+  for (int i = 0; i < 10; ++i) solver.tick(0.016f);
+  const Pies::Solver::Vertex& v = solver.getVertices()[0];
+  if (!(std::isfinite(v.position[0]) && v.position[1] < y0)) return 3;  // the box fell under gravity
+  std::printf("dropin ok: %zu vertices, %zu triangles, y %.4f -> %.4f (%s)\n", n, solver.getTriangles().size(), y0, v.position[1],
+              pd ? "PD" : "PBD");
+  Pies::Solver moved(std::move(solver));
+  moved.tick(0.0f);
+  moved.clear();
+  return moved.getVertices().empty() ? 0 : 4;
+}
