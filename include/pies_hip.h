@@ -86,6 +86,9 @@ enum {
 enum { PIES_NODE_POSITION = 0, PIES_NODE_PREV_POSITION = 1, PIES_NODE_VELOCITY = 2, PIES_NODE_RADIUS = 3, PIES_NODE_INV_MASS = 4 };
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
+/* device == PIES_DEVICE_NONE creates a host-only handle: scenes can be built and schedules inspected
+ * (pies_get_ids/_rest/_order/_batches), every call that would compute returns PIES_ERR_HIP. */
+#define PIES_DEVICE_NONE (-1)
 /* Solver::Solver(const SolverOptions&) (Solver.cpp:11-17).  options == NULL -> reference defaults. */
 int pies_create(const pies_options_t* options, int device, pies_solver_t** out);
 /* Solver::~Solver (Solver.cpp:19-23) */

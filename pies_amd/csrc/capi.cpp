@@ -76,6 +76,7 @@ static int download_nodes(pies_solver* s) {
 }
 
 int scene_sync_host(pies_solver* s) {
+  if (s->device == PIES_DEVICE_NONE) return PIES_OK;
   if (hipSetDevice(s->device) != hipSuccess) return fail(s, PIES_ERR_HIP, "hipSetDevice failed");
   return download_nodes(s);
 }
@@ -168,7 +169,7 @@ static int capture_graph(pies_solver* s) {
 }
 
 static int poll_failure(pies_solver* s) {
-  if (s->simFailed || !s->hash.counters) return PIES_OK;
+  if (s->simFailed || !s->hash.counters || s->device == PIES_DEVICE_NONE) return PIES_OK;
   uint32_t flag = 0;
   HIP_TRY(s, hipSetDevice(s->device));
   HIP_TRY(s, hipMemcpyAsync(&flag, s->hash.counters + 3, sizeof(flag), hipMemcpyDeviceToHost, s->stream));
@@ -209,6 +210,14 @@ void pies_default_options(pies_options_t* o) {
 int pies_create(const pies_options_t* options, int device, pies_solver_t** out) {
   if (!out) return PIES_ERR_INVALID;
   *out = nullptr;
+  if (device == PIES_DEVICE_NONE) {  // scene/plan inspection only: every call that would compute fails
+    pies_solver* s = new pies_solver();
+    if (options) s->opt = *options; else pies_default_options(&s->opt);
+    if (s->opt.timeSubsteps == 0) s->opt.timeSubsteps = 1;
+    s->device = PIES_DEVICE_NONE;
+    *out = s;
+    return PIES_OK;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return PIES_ERR_HIP;
   hipDeviceProp_t prop;
@@ -229,6 +238,7 @@ int pies_create(const pies_options_t* options, int device, pies_solver_t** out) 
 
 int pies_destroy(pies_solver_t* s) {
   if (!s) return PIES_OK;
+  if (s->device == PIES_DEVICE_NONE) { delete s; return PIES_OK; }
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   free_device(s);
@@ -240,9 +250,11 @@ int pies_destroy(pies_solver_t* s) {
 
 int pies_clear(pies_solver_t* s) {
   if (!s) return PIES_ERR_INVALID;
-  (void)hipSetDevice(s->device);
-  (void)hipStreamSynchronize(s->stream);
-  free_device(s);
+  if (s->device != PIES_DEVICE_NONE) {
+    (void)hipSetDevice(s->device);
+    (void)hipStreamSynchronize(s->stream);
+    free_device(s);
+  }
   s->h_pos.clear(); s->h_prev.clear(); s->h_vel.clear(); s->h_radius.clear(); s->h_invMass.clear();
   s->h_position.clear(); s->h_distance.clear(); s->h_tet.clear(); s->h_volume.clear(); s->h_bend.clear();
   s->h_triangles.clear(); s->h_lines.clear();
@@ -310,8 +322,32 @@ int pies_get_pcg_stats(pies_solver_t* s, float* max_rel_residual, uint32_t* max_
   return PIES_OK;
 }
 
+static int build_plans(pies_solver* s, int sched) {
+  const uint32_t n = s->nodeCount();
+  std::vector<uint32_t> ids;
+  ids.resize(s->h_position.size());
+  for (size_t i = 0; i < ids.size(); ++i) ids[i] = s->h_position[i].id;
+  build_plan({ids.data(), 1, (uint32_t)s->h_position.size(), 0x1}, n, sched, s->plan[PIES_POSITION]);
+  ids.resize(2 * s->h_distance.size());
+  for (size_t i = 0; i < s->h_distance.size(); ++i) { ids[2 * i] = s->h_distance[i].ids[0]; ids[2 * i + 1] = s->h_distance[i].ids[1]; }
+  // a distance projection moves node a only (Constraints.cpp:34-36); node b is read
+  build_plan({ids.data(), 2, (uint32_t)s->h_distance.size(), 0x1}, n, sched, s->plan[PIES_DISTANCE]);
+  ids.resize(4 * s->h_tet.size());
+  for (size_t i = 0; i < s->h_tet.size(); ++i) std::memcpy(&ids[4 * i], s->h_tet[i].ids, 16);
+  build_plan({ids.data(), 4, (uint32_t)s->h_tet.size(), 0xF}, n, sched, s->plan[PIES_TET]);
+  ids.resize(4 * s->h_bend.size());
+  for (size_t i = 0; i < s->h_bend.size(); ++i) std::memcpy(&ids[4 * i], s->h_bend[i].ids, 16);
+  build_plan({ids.data(), 4, (uint32_t)s->h_bend.size(), 0xF}, n, sched, s->plan[PIES_BEND]);
+  return PIES_OK;
+}
+
 int pies_finalize(pies_solver_t* s) {
   if (!s) return PIES_ERR_INVALID;
+  if (s->device == PIES_DEVICE_NONE) {  // host-only handle: plans can be inspected, nothing is uploaded
+    if (s->sceneDirty) build_plans(s, s->opt.solver == PIES_SOLVER_PD ? -1 : s->schedule);
+    s->sceneDirty = false;
+    return PIES_OK;
+  }
   HIP_TRY(s, hipSetDevice(s->device));
   if (!s->sceneDirty) {
     if (s->hostNodesDirty) return upload_nodes(s);
@@ -333,23 +369,7 @@ int pies_finalize(pies_solver_t* s) {
 
   const uint32_t n = s->nodeCount();
   // ---- plans (PD's local step is order independent: one batch per container, host order) ----
-  const int sched = isPD ? -1 : s->schedule;
-  {
-    std::vector<uint32_t> ids;
-    ids.resize(s->h_position.size());
-    for (size_t i = 0; i < ids.size(); ++i) ids[i] = s->h_position[i].id;
-    build_plan({ids.data(), 1, (uint32_t)s->h_position.size(), 0x1}, n, sched, s->plan[PIES_POSITION]);
-    ids.resize(2 * s->h_distance.size());
-    for (size_t i = 0; i < s->h_distance.size(); ++i) { ids[2 * i] = s->h_distance[i].ids[0]; ids[2 * i + 1] = s->h_distance[i].ids[1]; }
-    // a distance projection moves node a only (Constraints.cpp:34-36); node b is read
-    build_plan({ids.data(), 2, (uint32_t)s->h_distance.size(), 0x1}, n, sched, s->plan[PIES_DISTANCE]);
-    ids.resize(4 * s->h_tet.size());
-    for (size_t i = 0; i < s->h_tet.size(); ++i) std::memcpy(&ids[4 * i], s->h_tet[i].ids, 16);
-    build_plan({ids.data(), 4, (uint32_t)s->h_tet.size(), 0xF}, n, sched, s->plan[PIES_TET]);
-    ids.resize(4 * s->h_bend.size());
-    for (size_t i = 0; i < s->h_bend.size(); ++i) std::memcpy(&ids[4 * i], s->h_bend[i].ids, 16);
-    build_plan({ids.data(), 4, (uint32_t)s->h_bend.size(), 0xF}, n, sched, s->plan[PIES_BEND]);
-  }
+  build_plans(s, isPD ? -1 : s->schedule);
   // ---- node arrays ----
   if (n) {
     void* p;
@@ -472,6 +492,7 @@ int pies_finalize(pies_solver_t* s) {
 
 int pies_tick_async(pies_solver_t* s) {
   if (!s) return PIES_ERR_INVALID;
+  if (s->device == PIES_DEVICE_NONE) return fail(s, PIES_ERR_HIP, "host-only handle (PIES_DEVICE_NONE): there is no CPU solver");
   if (s->simFailed) return PIES_OK;  // Solver.cpp:26-28
   if (s->sceneDirty || s->hostNodesDirty)
     if (int rc = pies_finalize(s)) return rc;
@@ -488,6 +509,7 @@ int pies_tick_async(pies_solver_t* s) {
 
 int pies_synchronize(pies_solver_t* s) {
   if (!s) return PIES_ERR_INVALID;
+  if (s->device == PIES_DEVICE_NONE) return PIES_OK;
   HIP_TRY(s, hipSetDevice(s->device));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   return PIES_OK;
@@ -552,8 +574,7 @@ int pies_count(const pies_solver_t* s, int what, uint32_t* out) {
 int pies_read_nodes(pies_solver_t* s, int what, float* out, uint32_t n) {
   if (!s || (!out && n)) return PIES_ERR_INVALID;
   if (n != s->nodeCount()) return fail(s, PIES_ERR_INVALID, "pies_read_nodes: n does not match the node count");
-  HIP_TRY(s, hipSetDevice(s->device));
-  if (int rc = download_nodes(s)) return rc;
+  if (int rc = scene_sync_host(s)) return rc;
   const std::vector<float>* src = nullptr;
   switch (what) {
     case PIES_NODE_POSITION: src = &s->h_pos; break;
@@ -570,8 +591,7 @@ int pies_read_nodes(pies_solver_t* s, int what, float* out, uint32_t n) {
 int pies_write_nodes(pies_solver_t* s, int what, const float* in, uint32_t n) {
   if (!s || (!in && n)) return PIES_ERR_INVALID;
   if (n != s->nodeCount()) return fail(s, PIES_ERR_INVALID, "pies_write_nodes: n does not match the node count");
-  HIP_TRY(s, hipSetDevice(s->device));
-  if (int rc = download_nodes(s)) return rc;
+  if (int rc = scene_sync_host(s)) return rc;
   std::vector<float>* dst = nullptr;
   switch (what) {
     case PIES_NODE_POSITION: dst = &s->h_pos; break;
@@ -651,6 +671,7 @@ int pies_launch_counts(pies_solver_t* s, uint32_t* out) {
 
 int pies_profile_substep(pies_solver_t* s, int kernel, uint32_t* launches, double* total_ms, uint64_t* units) {
   if (!s || kernel < 0 || kernel >= PIES_KERNEL_COUNT) return PIES_ERR_INVALID;
+  if (s->device == PIES_DEVICE_NONE) return fail(s, PIES_ERR_HIP, "host-only handle");
   if (s->opt.solver != PIES_SOLVER_PBD) return fail(s, PIES_ERR_UNSUPPORTED, "pies_profile_substep: PBD only");
   if (s->sceneDirty || s->hostNodesDirty)
     if (int rc = pies_finalize(s)) return rc;

@@ -1,0 +1,52 @@
+"""The N>1 path of bench.py on CPU: world_size 2 over gloo.  Bodies are independent (one per rank, SURVEY
+8e "replicas only"): the only communication is the timing record -- max over ranks of the elapsed time and
+the sum of substeps -- which is what this test exercises; no solver runs here."""
+import os
+import socket
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert bench.dist_env() == (rank, rank, world)
+    elapsed, units = bench.aggregate(1.0 + 0.5 * rank, 100 * (rank + 1), dist)  # rank 1 is the slow one
+    q.put((rank, elapsed, units))
+    dist.destroy_process_group()
+
+
+def test_aggregate_is_max_time_and_summed_units_over_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, elapsed, units in res:
+        assert elapsed == pytest.approx(1.5) and units == pytest.approx(300.0)
+    # whole-job value = all ranks' substeps / slowest rank's time
+    assert res[0][2] / res[0][1] == pytest.approx(200.0)
+
+
+def test_single_process_aggregate_is_identity():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.aggregate(2.5, 40, None) == (2.5, 40)

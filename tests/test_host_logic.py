@@ -1,0 +1,100 @@
+"""CPU-only tests of the product's host logic through a host-only handle (PIES_DEVICE_NONE): scene
+construction against the oracle's own generators, and the Gauss-Seidel schedules (dependency levels /
+colouring).  No compute call is made; tick on such a handle must fail (there is no CPU solver)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle_api as O
+import scenes
+from pies_amd import capi
+
+
+def host_solver(**kw):
+    return capi.Solver(scenes.pbd_options(capi, 4, **kw), device=-1)
+
+
+def test_host_only_handle_cannot_compute():
+    g = host_solver()
+    g.addNodes([[0, 1, 0]])
+    with pytest.raises(capi.PiesError):
+        g.tick()
+
+
+def test_scene_generators_match_oracle():
+    g = host_solver()
+    o = O.OracleSolver(scenes.pbd_options(O, 4))
+    for s in (g, o):
+        scenes.build_beam(s, (4, 5, 6), volume=True, triangles=True)
+        s.create_sheet(5, 4, translation=(9, 2, 0), scale=0.5, mass=2.0, w=0.3)
+        s.create_bend_sheet(4, 5, translation=(20, 2, 0), scale=1.0, w=0.4)
+        s.addNodes([[30, 1, 2], [31, 1, 2]])
+    for t in (capi.POSITION, capi.DISTANCE, capi.TET, capi.VOLUME, capi.BEND, capi.TRIANGLES, capi.LINES):
+        assert np.array_equal(g.ids(t), o.ids(t)), t
+    for t in (capi.DISTANCE, capi.TET, capi.VOLUME, capi.BEND):
+        assert np.array_equal(g.rest(t), o.rest(t)), t
+    for name in ("positions", "prev_positions", "velocities", "radii", "inv_masses"):
+        assert np.array_equal(getattr(g, name), getattr(o, name)), name
+
+
+def _conflict_free(ids, order, offs, writes):
+    for b in range(len(offs) - 1):
+        sel = ids[order[offs[b]:offs[b + 1]]].reshape(offs[b + 1] - offs[b], -1)
+        written = sel[:, writes].ravel()
+        assert len(np.unique(written)) == len(written)
+        reads = np.setdiff1d(sel.ravel(), written)
+        assert len(np.intersect1d(reads, written)) == 0
+
+
+@pytest.mark.parametrize("schedule", [capi.SCHEDULE_EXACT, capi.SCHEDULE_COLOURED])
+def test_schedules_are_permutations_of_conflict_free_batches(schedule):
+    g = host_solver()
+    scenes.build_beam(g, (6, 5, 7))
+    g.create_bend_sheet(5, 5, translation=(10, 2, 0))
+    g.set_schedule(schedule)
+    for t, writes in ((capi.POSITION, [0]), (capi.DISTANCE, [0]), (capi.TET, [0, 1, 2, 3]), (capi.BEND, [0, 1, 2, 3])):
+        ids, order, offs = g.ids(t), g.order(t), g.batches(t)
+        assert sorted(order.tolist()) == list(range(len(ids)))
+        assert offs[0] == 0 and offs[-1] == len(ids) and (np.diff(offs.astype(np.int64)) > 0).all()
+        _conflict_free(ids, order, offs, writes)
+
+
+def test_exact_schedule_keeps_every_conflicting_pair_in_container_order():
+    """The property that makes EXACT bit-identical to the sequential sweep."""
+    rng = np.random.default_rng(2)
+    g = host_solver()
+    g.addNodes(rng.uniform(0, 5, (60, 3)))
+    tets = np.array([rng.choice(60, 4, replace=False) for _ in range(300)], dtype=np.uint32)
+    g.add_tet(tets, 0.1)
+    g.set_schedule(capi.SCHEDULE_EXACT)
+    order, offs = g.order(capi.TET), g.batches(capi.TET)
+    level = np.empty(len(tets), dtype=np.int64)
+    for b in range(len(offs) - 1):
+        level[order[offs[b]:offs[b + 1]]] = b
+    for a in range(len(tets)):
+        for b in range(a + 1, len(tets)):
+            if len(np.intersect1d(tets[a], tets[b])):
+                assert level[a] < level[b]
+    for b in range(len(offs) - 1):  # stable inside a level
+        assert (np.diff(order[offs[b]:offs[b + 1]].astype(np.int64)) > 0).all()
+
+
+def test_colour_counts_on_the_reference_lattices():
+    g = host_solver()
+    scenes.build_beam(g, scenes.L1K)
+    g.set_schedule(capi.SCHEDULE_COLOURED)
+    nd, nt = len(g.batches(capi.DISTANCE)) - 1, len(g.batches(capi.TET)) - 1
+    assert 8 <= nd <= 16 and 24 <= nt <= 32, (nd, nt)  # lower bounds: 7 writers + 1, 24 tets per node
+    assert g.count(capi.DISTANCE) == 5616 and g.count(capi.TET) == 4374  # SURVEY section 8 sizes
+
+
+def test_bad_arguments_are_rejected():
+    g = host_solver()
+    g.addNodes([[0, 0, 0], [1, 0, 0]])
+    with pytest.raises(capi.PiesError):
+        g.add_distance([[0, 7]], 0.5)  # node id out of range
+    with pytest.raises(capi.PiesError):
+        g.set_schedule(5)
+    L = capi.load()
+    assert L.pies_count(None, 0, None) == capi.ERR_INVALID
