@@ -76,18 +76,19 @@ def timed_ticks(solver, steps, warmup, barrier):
     return time.perf_counter() - t0
 
 
-def kernel_profile(solver, reps=3):
-    """Per kernel class: launches per substep, average dispatch duration (us), algorithmic GB/s."""
+def kernel_profile(solver):
+    """Per kernel class: launches per substep, average per-launch device time (us), algorithmic GB/s.
+    Each class is timed in isolation by replaying a graph of only its launches (pies_profile_substep)."""
     out = {}
+    lc = solver.launch_counts()
     for k, name in enumerate(capi.KERNEL_NAMES):
-        launches = ms = units = 0
-        for _ in range(reps):
-            n, m, u = solver.profile_substep(k)
-            launches, ms, units = launches + n, ms + m, units + u
+        if name not in BYTES or lc.get(name, 0) == 0:
+            continue
+        launches, ms, units = solver.profile_substep(k)
         if launches == 0:
             continue
         out[name] = {
-            "launches_per_substep": launches // reps,
+            "launches_per_substep": lc[name],
             "avg_us": 1e3 * ms / launches,
             "units_per_launch": units / launches,
             "algorithmic_GBs": BYTES[name] * units / (ms * 1e-3) / 1e9 if ms > 0 else None,
@@ -104,6 +105,40 @@ def pmc_traffic(kernel_name):
             return json.load(f).get(kernel_name, {}).get("hbm_bytes_per_launch")
     except OSError:
         return None
+
+
+def extra_configs(device):
+    """Short secondary measurements of the other single-GPU BASELINE configs (not the headline value)."""
+    out = {}
+    # configs[2]: 100k beam, Projective Dynamics, tets + volume (w = 1), 10 iterations, k = 0 end cap pinned
+    W, H, D = scenes.L100K
+    g = capi.Solver(capi.Options(solver=capi.PD, iterations=10), device=device)
+    g.create_tet_box(W, H, D, translation=(0.0, 2.0, 0.0), w=1.0, volume=True, triangles=True)
+    g.add_position(np.array([D * (j + H * i) for i in range(W) for j in range(H)], dtype=np.uint32), 2.0)
+    g.finalize()
+    el = timed_ticks(g, 30, 3, lambda: None)
+    res, iters, solves = g.pcg_stats()
+    out["pd_config3"] = {"value": 30 / el, "unit": "substeps/s", "workload": "20x20x250 beam, PD, 539334 tet + 539334 volume constraints, "
+                         "10 local/global iterations, floor contacts, Jacobi-PCG rel. tol 3e-7",
+                         "pcg_max_rel_residual": res, "pcg_max_iterations_used": iters,
+                         "projections_per_sec": 30 / el * 10 * (g.count(capi.TET) + g.count(capi.VOLUME) + g.count(capi.POSITION))}
+    g.close()
+    # configs[3]: 500k loose particles, node-node collisions + floor, PBD, 4 iterations
+    W, H, D = scenes.L500K
+    rng = np.random.default_rng(1234)
+    p = np.stack(np.meshgrid(np.arange(W), np.arange(H), np.arange(D), indexing="ij"), -1).reshape(-1, 3) * 0.9
+    p = p + rng.uniform(-0.05, 0.05, p.shape) + [0, 0.5, 0]
+    g = capi.Solver(scenes.pbd_options(capi, 4), device=device)
+    g.addNodes(p.astype(np.float32))
+    g.set_velocities(np.random.default_rng(4321).uniform(-1, 1, p.shape).astype(np.float32))
+    g.finalize()
+    el = timed_ticks(g, 10, 2, lambda: None)
+    pairs = g.collision_pairs
+    out["collisions_config4"] = {"value": 10 / el, "unit": "substeps/s", "workload": "50x100x100 loose particles (r 0.5, spacing 0.9, "
+                                 "jitter 0.05), PBD, 4 iterations, spatial-hash node-node collisions + floor",
+                                 "resolved_pairs_per_substep": pairs / 12, "failed": g.failed}
+    g.close()
+    return out
 
 
 def cpu_baseline(dims, ticks):
@@ -133,6 +168,7 @@ def main():
     ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-order measurement")
     ap.add_argument("--cpu-ticks", type=int, default=4)
     ap.add_argument("--no-kernel-profile", action="store_true", help="skip the per-dispatch timing pass (roofline = null)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short PD (config 3) and collision (config 4) measurements")
     args = ap.parse_args()
 
     rank, local_rank, world = dist_env()
@@ -206,6 +242,8 @@ def main():
                                      "launches_per_substep": sum(e.launch_counts().values()), "steps": steps,
                                      "note": "schedule EXACT: bit-identical to the reference's container-order sweep"}
             e.close()
+        if not args.no_extras:
+            result["other_configs"] = extra_configs(local_rank)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(dims, args.cpu_ticks)
     if rank == 0:

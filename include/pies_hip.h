@@ -168,9 +168,10 @@ int pies_get_order(pies_solver_t* s, int type, uint32_t* order, uint32_t capacit
 int pies_get_batches(pies_solver_t* s, int type, uint32_t* batch_offsets, uint32_t capacity, uint32_t* n_batches);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
-/* One un-graphed substep in which every launch of kernel class `kernel` is bracketed by two events on
- * the solver's stream.  Returns the number of timed launches, their summed device time and the number
- * of units (constraints or nodes) they processed.  Advances the simulation by one substep. */
+/* Times one kernel class in isolation: a graph holding only that class's launches of one substep is
+ * replayed a few times back to back and timed on the host clock (the launches form one dependent chain, so
+ * time / launches is the per-launch device time including the kernel boundary).  Returns the launches
+ * timed, the total milliseconds and the units (constraints or nodes) processed.  Perturbs the state. */
 enum { PIES_KERNEL_PREDICT = 0, PIES_KERNEL_POSITION = 1, PIES_KERNEL_DISTANCE = 2, PIES_KERNEL_TET = 3,
        PIES_KERNEL_BEND = 4, PIES_KERNEL_FLOOR = 5, PIES_KERNEL_VELOCITY = 6, PIES_KERNEL_HASH = 7,
        PIES_KERNEL_COLLIDE = 8, PIES_KERNEL_COUNT = 9 };

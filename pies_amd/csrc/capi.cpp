@@ -3,6 +3,7 @@
 // fixed sequence of kernel launches captured once into a hipGraph: at 100k particles a conflict-free
 // batch runs for a few microseconds, so un-graphed launches would be host-bound.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -14,9 +15,26 @@ using namespace pies;
 
 namespace pies {
 
+// PIES_PROFILER_SAFE=1 (set by the profiling scripts): rocprofv3 7.2 on this pool segfaults when tens of
+// thousands of graph kernel nodes are queued without a synchronisation, or when a graph is destroyed
+// while it traces.  In this mode every tick is followed by a stream synchronisation and graphs are only
+// released with the process.
+static bool under_profiler() {
+  static const bool v = [] { const char* e = std::getenv("PIES_PROFILER_SAFE"); return e && e[0] == '1'; }();
+  return v;
+}
+
 static void destroy_graph(pies_solver* s) {
-  if (s->graphExec) (void)hipGraphExecDestroy(s->graphExec);
-  if (s->graph) (void)hipGraphDestroy(s->graph);
+  // graphs are not destroyed while a profiler is attached (rocprofv3 7.2 crashes on graph destruction)
+  if (!under_profiler()) {
+    if (s->graphExec) (void)hipGraphExecDestroy(s->graphExec);
+    if (s->graph) (void)hipGraphDestroy(s->graph);
+    for (auto& ge : s->retiredGraphs) {
+      (void)hipGraphExecDestroy(ge.second);
+      (void)hipGraphDestroy(ge.first);
+    }
+    s->retiredGraphs.clear();
+  }
   s->graphExec = nullptr;
   s->graph = nullptr;
 }
@@ -83,41 +101,44 @@ int scene_sync_host(pies_solver* s) {
 
 // One PBD substep as a launch sequence (Solver.cpp:45-159).  `timer`/`timedKernel` select one kernel
 // class for per-dispatch timing (profile pass); counts (optional) tallies launches per class.
-static void enqueue_pbd_substep(pies_solver* s, int timedKernel, LaunchTimer* timer, uint32_t* counts) {
+static void enqueue_pbd_substep(pies_solver* s, int only, uint32_t* counts, uint64_t* units = nullptr) {
   hipStream_t st = s->stream;
   const float dt = s->opt.fixedTimestepSize / s->opt.timeSubsteps;
-  auto T = [&](int k) -> LaunchTimer* { return (timer && timedKernel == k) ? timer : nullptr; };
+  auto T = [&](int) -> LaunchTimer* { return nullptr; };
   auto C = [&](int k) { if (counts) ++counts[k]; };
+  auto ON = [&](int k) { return only < 0 || only == k; };  // profile pass: launch one kernel class only
+  auto U = [&](uint64_t u) { if (units) *units += u; };
 
-  launch_predict(st, s->nd, dt, s->opt.gravity, T(PIES_KERNEL_PREDICT));
+  if (ON(PIES_KERNEL_PREDICT)) { launch_predict(st, s->nd, dt, s->opt.gravity, T(PIES_KERNEL_PREDICT)); U(s->nd.n); }
   C(PIES_KERNEL_PREDICT);
   for (uint32_t it = 0; it < s->opt.iterations; ++it) {
     if (!s->releaseHinge)
       for (const Batch& b : s->plan[PIES_POSITION].batches) {
-        launch_position(st, s->nd.pos, s->d_pc_id, s->d_pc_tw, b.start, b.count, T(PIES_KERNEL_POSITION));
+        if (ON(PIES_KERNEL_POSITION)) { launch_position(st, s->nd.pos, s->d_pc_id, s->d_pc_tw, b.start, b.count, nullptr); U(b.count); }
         C(PIES_KERNEL_POSITION);
       }
     for (const Batch& b : s->plan[PIES_DISTANCE].batches) {
-      launch_distance(st, s->nd.pos, s->d_dc_ids, s->d_dc_rw, b.start, b.count, T(PIES_KERNEL_DISTANCE));
+      if (ON(PIES_KERNEL_DISTANCE)) { launch_distance(st, s->nd.pos, s->d_dc_ids, s->d_dc_rw, b.start, b.count, nullptr); U(b.count); }
       C(PIES_KERNEL_DISTANCE);
     }
     for (const Batch& b : s->plan[PIES_TET].batches) {
-      launch_tet(st, s->nd.pos, s->d_tc_ids, s->d_tc_q0, s->d_tc_q1, s->d_tc_q2, b.start, b.count, T(PIES_KERNEL_TET));
+      if (ON(PIES_KERNEL_TET)) { launch_tet(st, s->nd.pos, s->d_tc_ids, s->d_tc_q0, s->d_tc_q1, s->d_tc_q2, b.start, b.count, nullptr); U(b.count); }
       C(PIES_KERNEL_TET);
     }
     for (const Batch& b : s->plan[PIES_BEND].batches) {
-      launch_bend(st, s->nd.pos, s->d_bc_ids, s->d_bc_aw, b.start, b.count, T(PIES_KERNEL_BEND));
+      if (ON(PIES_KERNEL_BEND)) { launch_bend(st, s->nd.pos, s->d_bc_ids, s->d_bc_aw, b.start, b.count, nullptr); U(b.count); }
       C(PIES_KERNEL_BEND);
     }
     if (s->nodeCollisions) {  // Solver.cpp:81-130
-      const uint32_t nb = launch_hash_build(st, s->hash, s->nd, s->opt.gridSpacing);
-      const uint32_t nc = launch_collide(st, s->hash, s->nd, s->opt.friction, s->opt.staticFrictionThreshold);
+      uint32_t nb = 6, nc = 27;
+      if (ON(PIES_KERNEL_HASH)) { nb = launch_hash_build(st, s->hash, s->nd, s->opt.gridSpacing); U(s->nd.n); }
+      if (ON(PIES_KERNEL_COLLIDE)) { nc = launch_collide(st, s->hash, s->nd, s->opt.friction, s->opt.staticFrictionThreshold); U(s->nd.n); }
       if (counts) { counts[PIES_KERNEL_HASH] += nb; counts[PIES_KERNEL_COLLIDE] += nc; }
     }
-    launch_floor(st, s->nd, s->opt.floorHeight, T(PIES_KERNEL_FLOOR));
+    if (ON(PIES_KERNEL_FLOOR)) { launch_floor(st, s->nd, s->opt.floorHeight, nullptr); U(s->nd.n); }
     C(PIES_KERNEL_FLOOR);
   }
-  launch_velocity(st, s->nd, dt, s->opt.damping, s->opt.friction, s->opt.floorHeight, T(PIES_KERNEL_VELOCITY));
+  if (ON(PIES_KERNEL_VELOCITY)) { launch_velocity(st, s->nd, dt, s->opt.damping, s->opt.friction, s->opt.floorHeight, nullptr); U(s->nd.n); }
   C(PIES_KERNEL_VELOCITY);
 }
 
@@ -144,7 +165,7 @@ static void enqueue_pd_substep(pies_solver* s) {
 
 static void enqueue_substep(pies_solver* s, uint32_t* counts) {
   if (s->opt.solver == PIES_SOLVER_PD) enqueue_pd_substep(s);
-  else enqueue_pbd_substep(s, -1, nullptr, counts);
+  else enqueue_pbd_substep(s, -1, counts);
 }
 
 static int capture_graph(pies_solver* s) {
@@ -503,6 +524,7 @@ int pies_tick_async(pies_solver_t* s) {
     if (s->graphExec) HIP_TRY(s, hipGraphLaunch(s->graphExec, s->stream));
     else enqueue_substep(s, nullptr);  // PIES_NO_GRAPH=1: eager launches (debug / tracing)
   }
+  if (under_profiler()) HIP_TRY(s, hipStreamSynchronize(s->stream));
   s->deviceAhead = true;
   return PIES_OK;
 }
@@ -676,30 +698,45 @@ int pies_profile_substep(pies_solver_t* s, int kernel, uint32_t* launches, doubl
   if (s->sceneDirty || s->hostNodesDirty)
     if (int rc = pies_finalize(s)) return rc;
   HIP_TRY(s, hipSetDevice(s->device));
-  LaunchTimer timer;
-  const uint32_t want = std::min<uint32_t>(s->launchCounts[kernel], 8192);
-  timer.starts.resize(want);
-  timer.stops.resize(want);
-  for (uint32_t i = 0; i < want; ++i) {
-    HIP_TRY(s, hipEventCreate(&timer.starts[i]));
-    HIP_TRY(s, hipEventCreate(&timer.stops[i]));
-  }
-  enqueue_pbd_substep(s, kernel, &timer, nullptr);
-  s->deviceAhead = true;
-  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  if (launches) *launches = 0;
+  if (total_ms) *total_ms = 0.0;
+  if (units) *units = 0;
+  if (s->nd.n == 0 || s->launchCounts[kernel] == 0) return PIES_OK;
+  // a graph holding ONLY this class's launches of one substep, replayed back to back: the launches
+  // form one dependent chain, so wall time / launches is the per-launch device time incl. the kernel
+  // boundary (no events or extension launches: robust under rocprofv3)
+  uint64_t u = 0;
+  const int reps = 5;
   double ms = 0.0;
-  for (size_t i = 0; i < timer.used; ++i) {
-    float e = 0.f;
-    HIP_TRY(s, hipEventElapsedTime(&e, timer.starts[i], timer.stops[i]));
-    ms += e;
+  if (under_profiler()) {
+    // rocprofv3 7.2 segfaults on a second graph instantiation: launch eagerly (host-bound below ~3 us/launch)
+    enqueue_pbd_substep(s, kernel, nullptr, &u);
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    for (int r = 0; r < reps; ++r) enqueue_pbd_substep(s, kernel, nullptr, nullptr);
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+  } else {
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    HIP_TRY(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    enqueue_pbd_substep(s, kernel, nullptr, &u);
+    HIP_TRY(s, hipStreamEndCapture(s->stream, &g));
+    HIP_TRY(s, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    HIP_TRY(s, hipGraphLaunch(ge, s->stream));  // warm
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    for (int r = 0; r < reps; ++r) HIP_TRY(s, hipGraphLaunch(ge, s->stream));
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+    (void)hipGraphExecDestroy(ge);
+    (void)hipGraphDestroy(g);
   }
-  for (uint32_t i = 0; i < want; ++i) {
-    (void)hipEventDestroy(timer.starts[i]);
-    (void)hipEventDestroy(timer.stops[i]);
-  }
-  if (launches) *launches = (uint32_t)timer.used;
+  s->deviceAhead = true;
+  uint32_t n = s->launchCounts[kernel];
+  if (launches) *launches = n * reps;
   if (total_ms) *total_ms = ms;
-  if (units) *units = timer.units;
+  if (units) *units = u * reps;
   return PIES_OK;
 }
 

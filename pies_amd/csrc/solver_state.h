@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/pies_hip.h"
@@ -112,6 +113,7 @@ struct pies_solver {
 
   hipGraph_t graph = nullptr;
   hipGraphExec_t graphExec = nullptr;
+  std::vector<std::pair<hipGraph_t, hipGraphExec_t>> retiredGraphs;  // profile-pass graphs, freed with the handle
   uint32_t launchCounts[PIES_KERNEL_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
   uint32_t nodeCount() const { return static_cast<uint32_t>(h_radius.size()); }
