@@ -11,6 +11,7 @@
 // host mirrors refreshed once per tick (Solver.cpp:157,393 refresh per substep, which nothing can observe);
 // addTriMeshVolume needs tetgen, which is not part of this build (use addTetMeshVolume with a
 // pre-tetrahedralised mesh); errors surface as std::runtime_error carrying pies_last_error().
+// Shape/goal matching (regions, createShapeMatching*) are Projective-Dynamics constraints, as in the reference.
 #pragma once
 
 #include <cstdint>
@@ -149,9 +150,19 @@ public:
     _ck(pies_add_triangles(_h, static_cast<uint32_t>(f.size() / 3), f.data()));
     _syncRenderState();
   }
-  void addFixedRegions(const std::vector<glm::mat4>&, float) { throw std::runtime_error("Pies::Solver::addFixedRegions: goal matching is not in this build yet"); }
-  void updateFixedRegions(const std::vector<glm::mat4>&) { throw std::runtime_error("Pies::Solver::updateFixedRegions: goal matching is not in this build yet"); }
-  void addLinkedRegions(const std::vector<glm::mat4>&, float) { throw std::runtime_error("Pies::Solver::addLinkedRegions: shape matching is not in this build yet"); }
+  void addFixedRegions(const std::vector<glm::mat4>& regionMatrices, float w) {
+    std::vector<float> m = _flattenMats(regionMatrices);
+    _ck(pies_add_fixed_regions(_h, static_cast<uint32_t>(regionMatrices.size()), m.data(), w));
+  }
+  void updateFixedRegions(const std::vector<glm::mat4>& regionMatrices) {
+    std::vector<float> m = _flattenMats(regionMatrices);
+    // the reference asserts and returns on a size mismatch (PrimitiveUtilities.cpp:115-118); here it throws
+    _ck(pies_update_fixed_regions(_h, static_cast<uint32_t>(regionMatrices.size()), m.data()));
+  }
+  void addLinkedRegions(const std::vector<glm::mat4>& regionMatrices, float w) {
+    std::vector<float> m = _flattenMats(regionMatrices);
+    _ck(pies_add_linked_regions(_h, static_cast<uint32_t>(regionMatrices.size()), m.data(), w));
+  }
 
   // ---- primitives (PrimitiveUtilities.cpp:330-1289), reference grid sizes ----
   void createBox(const glm::vec3& translation, float scale, float w) {
@@ -170,11 +181,17 @@ public:
     _ck(pies_create_sheet(_h, 20, 20, t, scale, mass, k));
     _syncRenderState();
   }
-  void createShapeMatchingBox(const glm::vec3&, uint32_t, uint32_t, uint32_t, float, const glm::vec3&, float) {
-    throw std::runtime_error("Pies::Solver::createShapeMatchingBox: shape matching is not in this build yet");
+  // like the reference, `scale` and `initialVelocity` are accepted and ignored (PrimitiveUtilities.cpp:995,1015)
+  void createShapeMatchingBox(const glm::vec3& translation, uint32_t countX, uint32_t countY, uint32_t countZ, float /*scale*/,
+                              const glm::vec3& /*initialVelocity*/, float w) {
+    const float t[3] = {translation[0], translation[1], translation[2]};
+    _ck(pies_create_shape_matching_box(_h, t, countX, countY, countZ, w));
+    _syncRenderState();
   }
-  void createShapeMatchingSheet(const glm::vec3&, float, const glm::vec3&, float) {
-    throw std::runtime_error("Pies::Solver::createShapeMatchingSheet: shape matching is not in this build yet");
+  void createShapeMatchingSheet(const glm::vec3& translation, float scale, const glm::vec3& /*initialVelocity*/, float w) {
+    const float t[3] = {translation[0], translation[1], translation[2]};
+    _ck(pies_create_shape_matching_sheet(_h, 50, 50, t, scale, w));
+    _syncRenderState();
   }
   void createBendSheet(const glm::vec3& translation, float scale, float w) {
     const float t[3] = {translation[0], translation[1], translation[2]};
@@ -190,6 +207,13 @@ private:
     std::vector<float> p(3 * v.size());
     for (size_t i = 0; i < v.size(); ++i) { p[3 * i] = v[i][0]; p[3 * i + 1] = v[i][1]; p[3 * i + 2] = v[i][2]; }
     return p;
+  }
+  static std::vector<float> _flattenMats(const std::vector<glm::mat4>& v) {
+    std::vector<float> m(16 * v.size());
+    for (size_t k = 0; k < v.size(); ++k)
+      for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) m[16 * k + 4 * c + r] = v[k][c][r];
+    return m;
   }
   void _ck(int rc) const {
     if (rc != PIES_OK) throw std::runtime_error(std::string("Pies::Solver: ") + pies_last_error(_h));

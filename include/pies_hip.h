@@ -114,6 +114,22 @@ int pies_add_distance_constraints(pies_solver_t* s, uint32_t n, const uint32_t* 
 int pies_add_tet_constraints(pies_solver_t* s, uint32_t n, const uint32_t* ids, float w, float min_strain, float max_strain);
 int pies_add_volume_constraints(pies_solver_t* s, uint32_t n, const uint32_t* ids, float w, float compression, float stretching);
 int pies_add_bend_constraints(pies_solver_t* s, uint32_t n, const uint32_t* ids, float w);
+/* ShapeMatchingConstraint over the listed nodes (ShapeMatchingConstraint.cpp:6-48); material coordinates
+ * are the nodes' current positions, as createShapeMatching* / addLinkedRegions pass them.  PD only. */
+int pies_add_shape_constraint(pies_solver_t* s, uint32_t n, const uint32_t* ids, float w);
+/* GoalMatchingConstraint over the listed nodes (ShapeMatchingConstraint.cpp:124-137).  PD only. */
+int pies_add_goal_constraint(pies_solver_t* s, uint32_t n, const uint32_t* ids, float w, uint32_t* goal_index);
+/* GoalMatchingConstraint::setTransform (:175-177); m16 column-major like glm::mat4 */
+int pies_set_goal_transform(pies_solver_t* s, uint32_t goal, const float m16[16]);
+/* Solver::addFixedRegions / updateFixedRegions / addLinkedRegions (PrimitiveUtilities.cpp:77-162);
+ * mats16: n column-major 4x4 region-to-world matrices (the region is the unit box [-1,1]^3) */
+int pies_add_fixed_regions(pies_solver_t* s, uint32_t n, const float* mats16, float w);
+int pies_update_fixed_regions(pies_solver_t* s, uint32_t n, const float* mats16);
+int pies_add_linked_regions(pies_solver_t* s, uint32_t n, const float* mats16, float w);
+/* Solver::createShapeMatchingBox (:985-1048; spacing fixed to 0.5 and mass 10 like the reference) and
+ * Solver::createShapeMatchingSheet (:1050-1125; reference 50 x 50, 3x3 patches) */
+int pies_create_shape_matching_box(pies_solver_t* s, const float translation[3], uint32_t count_x, uint32_t count_y, uint32_t count_z, float w);
+int pies_create_shape_matching_sheet(pies_solver_t* s, uint32_t W, uint32_t H, const float translation[3], float scale, float w);
 /* Solver::_triangles entries (Solver.h:194); ids: n x 3 */
 int pies_add_triangles(pies_solver_t* s, uint32_t n, const uint32_t* ids);
 /* Solver::createTetBox (PrimitiveUtilities.cpp:330-618) on a W x H x D lattice (reference: 3x3x3, hinged
@@ -160,6 +176,8 @@ int pies_read_nodes(pies_solver_t* s, int what, float* out, uint32_t n);
 int pies_write_nodes(pies_solver_t* s, int what, const float* in, uint32_t n);
 /* node ids of a container, flattened, in the order the host added them */
 int pies_get_ids(const pies_solver_t* s, int type, uint32_t* out, uint32_t capacity);
+/* node ids of shape (PIES_SHAPE) or goal (PIES_GOAL) constraint `index`; ids may be NULL to query count */
+int pies_get_group(const pies_solver_t* s, int type, uint32_t index, uint32_t* ids, uint32_t capacity, uint32_t* count);
 /* rest data in host order: DISTANCE target (1), TET/VOLUME Qinv column-major (9), BEND angle (1) */
 int pies_get_rest(const pies_solver_t* s, int type, float* out, uint32_t capacity);
 /* Execution order of a container under the current schedule: order[slot] = index in host order.

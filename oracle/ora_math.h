@@ -100,6 +100,42 @@ inline mat3 transpose(const mat3& m) {
 struct mat4 {
   float m[16];  // m[4*col + row]
 };
+// glm::inverse(mat4): the published cofactor algorithm (glm/detail/func_matrix.inl, compute_inverse<4,4>).
+inline mat4 inverse(const mat4& A) {
+  auto m = [&](int c, int r) { return A.m[4 * c + r]; };
+  float C00 = m(2, 2) * m(3, 3) - m(3, 2) * m(2, 3), C02 = m(1, 2) * m(3, 3) - m(3, 2) * m(1, 3), C03 = m(1, 2) * m(2, 3) - m(2, 2) * m(1, 3);
+  float C04 = m(2, 1) * m(3, 3) - m(3, 1) * m(2, 3), C06 = m(1, 1) * m(3, 3) - m(3, 1) * m(1, 3), C07 = m(1, 1) * m(2, 3) - m(2, 1) * m(1, 3);
+  float C08 = m(2, 1) * m(3, 2) - m(3, 1) * m(2, 2), C10 = m(1, 1) * m(3, 2) - m(3, 1) * m(1, 2), C11 = m(1, 1) * m(2, 2) - m(2, 1) * m(1, 2);
+  float C12 = m(2, 0) * m(3, 3) - m(3, 0) * m(2, 3), C14 = m(1, 0) * m(3, 3) - m(3, 0) * m(1, 3), C15 = m(1, 0) * m(2, 3) - m(2, 0) * m(1, 3);
+  float C16 = m(2, 0) * m(3, 2) - m(3, 0) * m(2, 2), C18 = m(1, 0) * m(3, 2) - m(3, 0) * m(1, 2), C19 = m(1, 0) * m(2, 2) - m(2, 0) * m(1, 2);
+  float C20 = m(2, 0) * m(3, 1) - m(3, 0) * m(2, 1), C22 = m(1, 0) * m(3, 1) - m(3, 0) * m(1, 1), C23 = m(1, 0) * m(2, 1) - m(2, 0) * m(1, 1);
+  float F0[4] = {C00, C00, C02, C03}, F1[4] = {C04, C04, C06, C07}, F2[4] = {C08, C08, C10, C11};
+  float F3[4] = {C12, C12, C14, C15}, F4[4] = {C16, C16, C18, C19}, F5[4] = {C20, C20, C22, C23};
+  float V0[4] = {m(1, 0), m(0, 0), m(0, 0), m(0, 0)}, V1[4] = {m(1, 1), m(0, 1), m(0, 1), m(0, 1)};
+  float V2[4] = {m(1, 2), m(0, 2), m(0, 2), m(0, 2)}, V3[4] = {m(1, 3), m(0, 3), m(0, 3), m(0, 3)};
+  const float SA[4] = {+1, -1, +1, -1}, SB[4] = {-1, +1, -1, +1};
+  float I[4][4];
+  for (int r = 0; r < 4; ++r) {
+    I[0][r] = (V1[r] * F0[r] - V2[r] * F1[r] + V3[r] * F2[r]) * SA[r];
+    I[1][r] = (V0[r] * F0[r] - V2[r] * F3[r] + V3[r] * F4[r]) * SB[r];
+    I[2][r] = (V0[r] * F1[r] - V1[r] * F3[r] + V3[r] * F5[r]) * SA[r];
+    I[3][r] = (V0[r] * F2[r] - V1[r] * F4[r] + V2[r] * F5[r]) * SB[r];
+  }
+  float Dot1 = (m(0, 0) * I[0][0] + m(0, 1) * I[1][0]) + (m(0, 2) * I[2][0] + m(0, 3) * I[3][0]);
+  float ood = 1.0f / Dot1;
+  mat4 R;
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) R.m[4 * c + r] = I[c][r] * ood;
+  return R;
+}
+// glm operator*(mat4, mat4): per column, ((a0*b0 + a1*b1) + a2*b2) + a3*b3
+inline mat4 operator*(const mat4& a, const mat4& b) {
+  mat4 R;
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r)
+      R.m[4 * c + r] = ((a.m[r] * b.m[4 * c] + a.m[4 + r] * b.m[4 * c + 1]) + a.m[8 + r] * b.m[4 * c + 2]) + a.m[12 + r] * b.m[4 * c + 3];
+  return R;
+}
 // glm operator*(mat4, vec4) sums as (m0*x + m1*y) + (m2*z + m3*w); here w = 1.
 inline void mul_point(const mat4& M, const vec3& p, float out[4]) {
   for (int r = 0; r < 4; ++r)

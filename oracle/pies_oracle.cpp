@@ -587,6 +587,9 @@ struct ora_solver {
   std::vector<uint32_t> lines;
   std::vector<std::array<uint32_t, 4>> tets;
 
+  struct FixedRegion { mat4 invInitialTransform; uint32_t goal; };  // Solver.h:147-151
+  std::vector<FixedRegion> fixedRegions;
+
   // optional replay of a device collision visiting order (empty = reference order 0..N-1)
   std::vector<uint32_t> collisionOrder;
   // collisionRule 0: the reference's loop (ascending node index, query range from the node's current
@@ -1053,6 +1056,120 @@ void ora_add_goal(ora_solver* s, uint32_t n, const uint32_t* ids, float w) {
 }
 void ora_set_goal_transform(ora_solver* s, uint32_t goal, const float* m16) {
   std::memcpy(s->goalCons[goal].transform.m, m16, 16 * sizeof(float));
+}
+
+static bool inside_unit_box(const mat4& worldToRegion, const vec3& p) {
+  float l[4];
+  mul_point(worldToRegion, p, l);
+  return -1.0f <= l[0] && l[0] <= 1.0f && -1.0f <= l[1] && l[1] <= 1.0f && -1.0f <= l[2] && l[2] <= 1.0f;
+}
+// Solver::addFixedRegions (PrimitiveUtilities.cpp:77-112)
+void ora_add_fixed_regions(ora_solver* s, uint32_t n, const float* mats16, float w) {
+  for (uint32_t k = 0; k < n; ++k) {
+    mat4 regionToWorld;
+    std::memcpy(regionToWorld.m, mats16 + 16 * k, 16 * sizeof(float));
+    ora_solver::FixedRegion region;
+    region.invInitialTransform = inverse(regionToWorld);
+    region.goal = static_cast<uint32_t>(s->goalCons.size());
+    std::vector<uint32_t> constrained;
+    for (const Node& node : s->nodes)
+      if (inside_unit_box(region.invInitialTransform, node.position)) constrained.push_back(node.id);
+    GoalCon c;
+    c.init(s->nodes, constrained, w);
+    s->goalCons.push_back(std::move(c));
+    s->fixedRegions.push_back(region);
+  }
+  s->pdDirty = true;
+}
+// Solver::updateFixedRegions (PrimitiveUtilities.cpp:114-128)
+void ora_update_fixed_regions(ora_solver* s, uint32_t n, const float* mats16) {
+  if (n != s->fixedRegions.size()) return;
+  for (uint32_t i = 0; i < n; ++i) {
+    mat4 cur;
+    std::memcpy(cur.m, mats16 + 16 * i, 16 * sizeof(float));
+    s->goalCons[s->fixedRegions[i].goal].transform = cur * s->fixedRegions[i].invInitialTransform;
+  }
+}
+// Solver::addLinkedRegions (PrimitiveUtilities.cpp:130-162)
+void ora_add_linked_regions(ora_solver* s, uint32_t n, const float* mats16, float w) {
+  for (uint32_t k = 0; k < n; ++k) {
+    mat4 region;
+    std::memcpy(region.m, mats16 + 16 * k, 16 * sizeof(float));
+    mat4 worldToRegion = inverse(region);
+    std::vector<vec3> mc;
+    std::vector<uint32_t> idx;
+    for (const Node& node : s->nodes)
+      if (inside_unit_box(worldToRegion, node.position)) { mc.push_back(node.position); idx.push_back(node.id); }
+    if (mc.size() >= 3) {
+      ShapeCon c;
+      c.init(s->nodes, idx, mc, w);
+      s->shapeCons.push_back(std::move(c));
+    }
+  }
+  s->pdDirty = true;
+}
+// Solver::createShapeMatchingBox (PrimitiveUtilities.cpp:985-1048); scale is overridden to 0.5 (:995)
+void ora_create_shape_matching_box(ora_solver* s, const float* tr, uint32_t cx, uint32_t cy, uint32_t cz, float w) {
+  const float scale = 0.5f;
+  size_t off = s->nodes.size();
+  vec3 t(tr[0], tr[1], tr[2]);
+  for (uint32_t i = 0; i < cx; ++i)
+    for (uint32_t j = 0; j < cy; ++j)
+      for (uint32_t k = 0; k < cz; ++k) {
+        Node node;
+        node.id = gid(cy, cz, off, i, j, k);
+        node.position = scale * vec3(float(i), float(j), float(k)) + t;
+        node.prevPosition = node.position;
+        node.velocity = vec3(0.0f);
+        node.radius = 0.5f * scale;
+        node.invMass = 1.0f / 10.0f;
+        s->nodes.push_back(node);
+      }
+  std::vector<uint32_t> idx(cx * cy * cz);
+  std::vector<vec3> mc(idx.size());
+  for (uint32_t i = 0; i < idx.size(); ++i) { idx[i] = static_cast<uint32_t>(off) + i; mc[i] = s->nodes[idx[i]].position; }
+  ShapeCon c;
+  c.init(s->nodes, idx, mc, w);
+  s->shapeCons.push_back(std::move(c));
+  s->pdDirty = true;
+}
+// Solver::createShapeMatchingSheet (PrimitiveUtilities.cpp:1050-1125), generalised to W x H (reference 50 x 50)
+void ora_create_shape_matching_sheet(ora_solver* s, uint32_t W, uint32_t H, const float* tr, float scale, float w) {
+  const uint32_t pw = 3, ph = 3;
+  struct Patch { std::vector<vec3> mc; std::vector<uint32_t> idx; };
+  std::vector<Patch> patches((W / pw) * (H / ph));
+  size_t off = s->nodes.size();
+  vec3 t(tr[0], tr[1], tr[2]);
+  auto add = [&](uint32_t p, uint32_t id, const vec3& pos) { if (p < patches.size()) { patches[p].mc.push_back(pos); patches[p].idx.push_back(id); } };
+  for (uint32_t i = 0; i < W; ++i)
+    for (uint32_t j = 0; j < H; ++j) {
+      Node node;
+      node.id = gid(H, 1, off, i, j, 0);
+      node.position = scale * vec3(float(i), float(j), 0.0f) + t;
+      node.prevPosition = node.position;
+      node.velocity = vec3(0.0f);
+      node.radius = 0.5f * scale;
+      node.invMass = 1.0f;
+      s->nodes.push_back(node);
+      add(i / pw * ph + j / ph, node.id, node.position);
+      if ((i % pw) == (pw - 1) && i < (W - 1)) add((1 + i / pw) * ph + j / ph, node.id, node.position);
+      if ((j % ph) == (ph - 1) && j < (H - 1)) add(i / pw * ph + j / ph + 1, node.id, node.position);
+    }
+  for (const Patch& p : patches) {
+    if (p.idx.empty()) continue;  // the reference also builds constraints for empty patches; they touch no node
+    ShapeCon c;
+    c.init(s->nodes, p.idx, p.mc, w);
+    s->shapeCons.push_back(std::move(c));
+  }
+  s->pdDirty = true;
+}
+// node ids of shape (5) / goal (6) constraint k
+uint32_t ora_group_size(ora_solver* s, int type, uint32_t k) {
+  return type == 5 ? (uint32_t)s->shapeCons[k].ids.size() : (uint32_t)s->goalCons[k].ids.size();
+}
+void ora_group_ids(ora_solver* s, int type, uint32_t k, uint32_t* out) {
+  const auto& ids = type == 5 ? s->shapeCons[k].ids : s->goalCons[k].ids;
+  std::copy(ids.begin(), ids.end(), out);
 }
 void ora_add_triangles(ora_solver* s, uint32_t n, const uint32_t* ids) {
   for (uint32_t i = 0; i < n; ++i) s->triangles.push_back({ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]});

@@ -30,7 +30,9 @@ SYMBOLS = [
     "pies_create_bend_sheet", "pies_set_flag", "pies_set_schedule", "pies_finalize", "pies_tick", "pies_tick_async",
     "pies_synchronize", "pies_failed", "pies_count", "pies_read_nodes", "pies_write_nodes", "pies_get_ids",
     "pies_get_rest", "pies_get_order", "pies_get_batches", "pies_profile_substep", "pies_launch_counts",
-    "pies_set_pcg", "pies_get_pcg_stats", "pies_collision_pairs",
+    "pies_set_pcg", "pies_get_pcg_stats", "pies_collision_pairs", "pies_add_shape_constraint",
+    "pies_add_goal_constraint", "pies_set_goal_transform", "pies_add_fixed_regions", "pies_update_fixed_regions",
+    "pies_add_linked_regions", "pies_create_shape_matching_box", "pies_create_shape_matching_sheet", "pies_get_group",
 ]
 
 
@@ -100,6 +102,15 @@ def load():
         "pies_set_pcg": [vp, f32, u32],
         "pies_get_pcg_stats": [vp, pf, pu, pu],
         "pies_collision_pairs": [vp, C.POINTER(C.c_uint64)],
+        "pies_add_shape_constraint": [vp, u32, pu, f32],
+        "pies_add_goal_constraint": [vp, u32, pu, f32, pu],
+        "pies_set_goal_transform": [vp, u32, pf],
+        "pies_add_fixed_regions": [vp, u32, pf, f32],
+        "pies_update_fixed_regions": [vp, u32, pf],
+        "pies_add_linked_regions": [vp, u32, pf, f32],
+        "pies_create_shape_matching_box": [vp, pf, u32, u32, u32, f32],
+        "pies_create_shape_matching_sheet": [vp, u32, u32, pf, f32, f32],
+        "pies_get_group": [vp, i32, u32, pu, u32, pu],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -202,6 +213,47 @@ class Solver:
     def add_triangles(self, ids):
         ids = _u32(ids).reshape(-1, 3)
         self._ck(self._L.pies_add_triangles(self._h, len(ids), _pu(ids)))
+
+    def add_shape(self, ids, w):
+        ids = _u32(ids).reshape(-1)
+        self._ck(self._L.pies_add_shape_constraint(self._h, len(ids), _pu(ids), w))
+
+    def add_goal(self, ids, w):
+        ids = _u32(ids).reshape(-1)
+        k = C.c_uint32()
+        self._ck(self._L.pies_add_goal_constraint(self._h, len(ids), _pu(ids), w, C.byref(k)))
+        return k.value
+
+    def set_goal_transform(self, goal, m16):
+        m = _f32(m16).reshape(16)
+        self._ck(self._L.pies_set_goal_transform(self._h, goal, _pf(m)))
+
+    def add_fixed_regions(self, mats, w):
+        m = _f32(mats).reshape(-1, 16)
+        self._ck(self._L.pies_add_fixed_regions(self._h, len(m), _pf(m), w))
+
+    def update_fixed_regions(self, mats):
+        m = _f32(mats).reshape(-1, 16)
+        self._ck(self._L.pies_update_fixed_regions(self._h, len(m), _pf(m)))
+
+    def add_linked_regions(self, mats, w):
+        m = _f32(mats).reshape(-1, 16)
+        self._ck(self._L.pies_add_linked_regions(self._h, len(m), _pf(m), w))
+
+    def create_shape_matching_box(self, translation, cx, cy, cz, w):
+        t = _f32(translation)
+        self._ck(self._L.pies_create_shape_matching_box(self._h, _pf(t), cx, cy, cz, w))
+
+    def create_shape_matching_sheet(self, W, H, translation=(0, 0, 0), scale=1.0, w=1.0):
+        t = _f32(translation)
+        self._ck(self._L.pies_create_shape_matching_sheet(self._h, W, H, _pf(t), scale, w))
+
+    def group_ids(self, ctype, k):
+        n = C.c_uint32()
+        self._ck(self._L.pies_get_group(self._h, ctype, k, None, 0, C.byref(n)))
+        out = np.empty(n.value, dtype=np.uint32)
+        self._ck(self._L.pies_get_group(self._h, ctype, k, _pu(out), out.size, C.byref(n)))
+        return out
 
     def create_tet_box(self, W, H, D, translation=(0, 0, 0), scale=1.0, velocity=(0, 0, 0), w=1.0, mass=1.0,
                        volume=True, triangles=True):

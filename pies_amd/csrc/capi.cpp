@@ -156,6 +156,8 @@ static void enqueue_pd_substep(pies_solver* s) {
                         (uint32_t)s->h_tet.size());
     launch_pd_local_tet(st, true, s->nd.pos, s->d_vc_ids, s->d_vc_q0, s->d_vc_q1, s->d_vc_q2, pd.contrib + s->slotBase[PIES_VOLUME],
                         (uint32_t)s->h_volume.size());
+    launch_pd_local_bend(st, s->nd.pos, s->d_bc_ids, s->d_bc_aw, pd.contrib + s->slotBase[PIES_BEND], (uint32_t)s->h_bend.size());
+    launch_pd_local_shape(st, s->nd.pos, pd);                        // goal targets are constants between transform updates
     launch_pd_rhs(st, s->nd, pd);                                    // Solver.cpp:266, 310-349
     launch_pd_solve(st, s->nd, pd, (int)s->pcgMaxIters, s->pcgTol);  // Solver.cpp:356-364
   }
@@ -279,6 +281,7 @@ int pies_clear(pies_solver_t* s) {
   s->h_pos.clear(); s->h_prev.clear(); s->h_vel.clear(); s->h_radius.clear(); s->h_invMass.clear();
   s->h_position.clear(); s->h_distance.clear(); s->h_tet.clear(); s->h_volume.clear(); s->h_bend.clear();
   s->h_triangles.clear(); s->h_lines.clear();
+  s->h_shape.clear(); s->h_goal.clear();  // like the reference, the fixed-region list survives clear() (Solver.cpp:488-507)
   for (Plan& p : s->plan) { p.order.clear(); p.batches.clear(); }
   s->constraintId = 0;
   s->sceneDirty = true;
@@ -519,7 +522,11 @@ int pies_tick_async(pies_solver_t* s) {
     if (int rc = pies_finalize(s)) return rc;
   HIP_TRY(s, hipSetDevice(s->device));
   if (s->nd.n == 0) return PIES_OK;
-  if (s->opt.solver == PIES_SOLVER_PD) HIP_TRY(s, hipMemsetAsync(s->pd.cg.stats, 0, 4 * sizeof(float), s->stream));
+  if (s->opt.solver == PIES_SOLVER_PD) {
+    if (s->goalDirty)
+      if (int rc = pd_upload_goals(s)) return rc;
+    HIP_TRY(s, hipMemsetAsync(s->pd.cg.stats, 0, 4 * sizeof(float), s->stream));
+  }
   for (uint32_t sub = 0; sub < s->opt.timeSubsteps; ++sub) {
     if (s->graphExec) HIP_TRY(s, hipGraphLaunch(s->graphExec, s->stream));
     else enqueue_substep(s, nullptr);  // PIES_NO_GRAPH=1: eager launches (debug / tracing)
@@ -583,8 +590,8 @@ int pies_count(const pies_solver_t* s, int what, uint32_t* out) {
     case PIES_TET: *out = (uint32_t)s->h_tet.size(); break;
     case PIES_VOLUME: *out = (uint32_t)s->h_volume.size(); break;
     case PIES_BEND: *out = (uint32_t)s->h_bend.size(); break;
-    case PIES_SHAPE: *out = 0; break;
-    case PIES_GOAL: *out = 0; break;
+    case PIES_SHAPE: *out = (uint32_t)s->h_shape.size(); break;
+    case PIES_GOAL: *out = (uint32_t)s->h_goal.size(); break;
     case PIES_TRIANGLES: *out = (uint32_t)(s->h_triangles.size() / 3); break;
     case PIES_LINES: *out = (uint32_t)s->h_lines.size(); break;
     case PIES_NODES: *out = s->nodeCount(); break;
@@ -643,6 +650,20 @@ int pies_get_ids(const pies_solver_t* s, int type, uint32_t* out, uint32_t capac
     default: return PIES_ERR_INVALID;
   }
   return k <= capacity ? PIES_OK : PIES_ERR_INVALID;
+}
+
+int pies_get_group(const pies_solver_t* s, int type, uint32_t index, uint32_t* ids, uint32_t capacity, uint32_t* count) {
+  if (!s || !count || (type != PIES_SHAPE && type != PIES_GOAL)) return PIES_ERR_INVALID;
+  const std::vector<uint32_t>* v = nullptr;
+  if (type == PIES_SHAPE && index < s->h_shape.size()) v = &s->h_shape[index].ids;
+  if (type == PIES_GOAL && index < s->h_goal.size()) v = &s->h_goal[index].ids;
+  if (!v) return PIES_ERR_INVALID;
+  *count = static_cast<uint32_t>(v->size());
+  if (ids) {
+    if (v->size() > capacity) return PIES_ERR_INVALID;
+    std::copy(v->begin(), v->end(), ids);
+  }
+  return PIES_OK;
 }
 
 int pies_get_rest(const pies_solver_t* s, int type, float* out, uint32_t capacity) {

@@ -36,6 +36,7 @@ template <class T> int upload(pies_solver* s, const std::vector<T>& h, T** d) {
   return PIES_OK;
 }
 
-int pd_build(pies_solver* s);  // pd_setup.cpp
+int pd_build(pies_solver* s);         // pd_setup.cpp
+int pd_upload_goals(pies_solver* s);  // pd_setup.cpp
 
 }  // namespace pies

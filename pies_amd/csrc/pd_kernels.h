@@ -23,7 +23,23 @@ struct CgArrays {
   float* stats;  // max relative residual^2 over the tick's solves, max iterations, number of solves
 };
 
+// ShapeMatchingConstraint data (fp64 like the reference) and the fp64 contribution slots of shape and
+// goal matching (the reference adds float w * double projection to the float force vector)
+struct ShapeArrays {
+  uint32_t count;          // shape constraints
+  const uint32_t* off;     // count+1 entry offsets
+  const uint32_t* node;    // per entry
+  const double* mat;       // 3 per entry, centred material coordinates
+  const double* qinv;      // 9 per constraint, row-major
+  double* quat;            // 4 per constraint (w,x,y,z), warm-started across iterations and ticks
+  const float* w;          // per constraint
+};
+
 struct PdArrays {
+  ShapeArrays shape;
+  double4* contribD;        // shape entries, then goal entries: (x, y, z, w)
+  const uint32_t* incPtrD;  // per node: fp64 slots in reference order (shape constraints, then goal)
+  const uint32_t* incSlotD;
   float4* msn;
   float4* rhs;
   float4* statp;
@@ -40,6 +56,8 @@ void launch_pd_predict(hipStream_t st, const NodeArrays& nd, const PdArrays& pd,
 void launch_pd_local_distance(hipStream_t st, const float4* pos, const uint2* ids, const float2* rw, float4* contrib, uint32_t count);
 void launch_pd_local_tet(hipStream_t st, bool volume, const float4* pos, const uint4* ids, const float4* q0, const float4* q1,
                          const float4* q2, float4* contrib, uint32_t count);
+void launch_pd_local_bend(hipStream_t st, const float4* pos, const uint4* ids, const float2* angle_w, float4* contrib, uint32_t count);
+void launch_pd_local_shape(hipStream_t st, const float4* pos, const PdArrays& pd);
 void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd);
 void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, int maxIters, float tol);
 void launch_pd_stabilize(hipStream_t st, const NodeArrays& nd, const PdArrays& pd);

@@ -157,6 +157,153 @@ __global__ void __launch_bounds__(kBlock) k_pd_local_tet(const float4* __restric
   for (int i = 0; i < 4; ++i) contrib[4 * c + i] = make_float4(w * out[i][0], w * out[i][1], w * out[i][2], 0.0f);
 }
 
+// BendConstraint in PD (Constraints.cpp:312-366): A = B = I, contribution = w * projected_i.
+struct V3 {
+  float x, y, z;
+};
+PIES_DEV V3 sub4(const float4& a, const float4& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+PIES_DEV V3 crossv(const V3& a, const V3& b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+PIES_DEV float dotv(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PIES_DEV V3 addv(const V3& a, const V3& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+PIES_DEV V3 subv(const V3& a, const V3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+PIES_DEV V3 mulv(const V3& a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+PIES_DEV V3 divv(const V3& a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+PIES_DEV V3 negv(const V3& a) { return {-a.x, -a.y, -a.z}; }
+
+__global__ void __launch_bounds__(kBlock) k_pd_local_bend(const float4* __restrict__ pos, const uint4* __restrict__ ids,
+                                                          const float2* __restrict__ angle_w, float4* __restrict__ contrib,
+                                                          uint32_t count) {
+  const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= count) return;
+  const uint4 id = ids[c];
+  const float2 aw = angle_w[c];
+  const float4 x1 = pos[id.x], x2 = pos[id.y], x3 = pos[id.z], x4 = pos[id.w];
+  const V3 p2 = sub4(x2, x1), p3 = sub4(x3, x1), p4 = sub4(x4, x1);
+  const V3 c23 = crossv(p2, p3), c24 = crossv(p2, p4);
+  const float l23 = sqrtf(dotv(c23, c23)), l24 = sqrtf(dotv(c24, c24));
+  const V3 n1 = divv(c23, l23), n2 = divv(c24, l24);
+  const float d = dotv(n1, n2);
+  const float C = static_cast<float>(acos(static_cast<double>(d))) - aw.x;
+  const V3 q3 = divv(addv(crossv(p2, n2), mulv(crossv(n1, p2), d)), l23);
+  const V3 q4 = divv(addv(crossv(p2, n1), mulv(crossv(n2, p2), d)), l24);
+  const V3 q2 = subv(negv(divv(addv(crossv(p3, n2), mulv(crossv(n1, p3), d)), l23)), divv(addv(crossv(p4, n1), mulv(crossv(n2, p4), d)), l24));
+  const V3 q1 = subv(subv(negv(q2), q3), q4);
+  const float wSum = x1.w + x2.w + x3.w + x4.w;
+  const float qSq = dotv(q1, q1) + dotv(q2, q2) + dotv(q3, q3) + dotv(q4, q4);
+  const float num = sqrtf(fmaxf(1.0f - d * d, 0.0f)) * C;
+  V3 pr[4] = {{x1.x, x1.y, x1.z}, {x2.x, x2.y, x2.z}, {x3.x, x3.y, x3.z}, {x4.x, x4.y, x4.z}};
+  if (!(qSq < 0.00001f)) {
+    pr[0] = addv(pr[0], divv(mulv(mulv(negv(q1), 4 * x1.w / wSum), num), qSq));
+    pr[1] = addv(pr[1], divv(mulv(mulv(negv(q2), 4 * x2.w / wSum), num), qSq));
+    pr[2] = addv(pr[2], divv(mulv(mulv(negv(q3), 4 * x3.w / wSum), num), qSq));
+    pr[3] = addv(pr[3], divv(mulv(mulv(negv(q4), 4 * x4.w / wSum), num), qSq));
+  }
+  const float w = aw.y;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) contrib[4 * c + i] = make_float4(w * pr[i].x, w * pr[i].y, w * pr[i].z, 0.0f);
+}
+
+// ShapeMatchingConstraint::projectToAuxiliaryVariable (ShapeMatchingConstraint.cpp:96-122), one workgroup
+// per constraint: float centroid, P = sum (x - c) r^T / invMass in fp64, F = P Qinv, warm-started
+// rotation extraction (:75-94; the 1e-9 is added to the reciprocal, as in the reference), projected = R r + c.
+// The centroid and P are block reductions, so their rounding differs from the reference's sequential sums
+// at the 1e-7 / 1e-16 level (PD parity is a tolerance anyway).
+__global__ void __launch_bounds__(kBlock) k_pd_local_shape(const float4* __restrict__ pos, ShapeArrays S, double4* __restrict__ contribD) {
+  __shared__ double red[kBlock / 64][12];
+  __shared__ double sh[16];  // centroid (3), R (9)
+  const uint32_t k = blockIdx.x;
+  const uint32_t e0 = S.off[k], n = S.off[k + 1] - e0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // centroid: weight * position accumulated in float per lane, then reduced
+  const float weight = 1.0f / static_cast<float>(n);
+  float cx = 0.f, cy = 0.f, cz = 0.f;
+  for (uint32_t e = threadIdx.x; e < n; e += kBlock) {
+    const float4 p = pos[S.node[e0 + e]];
+    cx += weight * p.x; cy += weight * p.y; cz += weight * p.z;
+  }
+  double acc[12] = {cx, cy, cz, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc[q] += __shfl_xor(acc[q], off, 64);
+  if (lane == 0) { red[wave][0] = acc[0]; red[wave][1] = acc[1]; red[wave][2] = acc[2]; }
+  __syncthreads();
+  if (threadIdx.x < 3) sh[threadIdx.x] = static_cast<double>(static_cast<float>(((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]));
+  __syncthreads();
+  const float comx = static_cast<float>(sh[0]), comy = static_cast<float>(sh[1]), comz = static_cast<float>(sh[2]);
+  // P
+  double P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint32_t e = threadIdx.x; e < n; e += kBlock) {
+    const float4 p = pos[S.node[e0 + e]];
+    const double l[3] = {static_cast<double>(p.x - comx), static_cast<double>(p.y - comy), static_cast<double>(p.z - comz)};
+    const double im = static_cast<double>(p.w);
+    const double* m = S.mat + 3 * static_cast<size_t>(e0 + e);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) P[3 * r + c] += l[r] * m[c] / im;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+    for (int q = 0; q < 9; ++q) P[q] += __shfl_xor(P[q], off, 64);
+  __syncthreads();
+  if (lane == 0)
+#pragma unroll
+    for (int q = 0; q < 9; ++q) red[wave][q] = P[q];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double Pm[9], F[9];
+    for (int q = 0; q < 9; ++q) Pm[q] = ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q];
+    const double* Qi = S.qinv + 9 * static_cast<size_t>(k);
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) F[3 * r + c] = Pm[3 * r] * Qi[c] + Pm[3 * r + 1] * Qi[3 + c] + Pm[3 * r + 2] * Qi[6 + c];
+    double* qp = S.quat + 4 * static_cast<size_t>(k);
+    double qw = qp[0], qx = qp[1], qy = qp[2], qz = qp[3];
+    double R[9];
+    auto qmat = [&]() {
+      const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+      const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+      R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+      R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+      R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+    };
+    for (int iter = 0; iter < 100; ++iter) {
+      qmat();
+      double om[3] = {0, 0, 0}, dsum = 0;
+      for (int c = 0; c < 3; ++c) {
+        const double r0 = R[c], r1 = R[3 + c], r2 = R[6 + c], a0 = F[c], a1 = F[3 + c], a2 = F[6 + c];
+        om[0] += r1 * a2 - r2 * a1;
+        om[1] += r2 * a0 - r0 * a2;
+        om[2] += r0 * a1 - r1 * a0;
+        dsum += r0 * a0 + r1 * a1 + r2 * a2;
+      }
+      const double f = 1.0 / fabs(dsum) + 1.0e-9;
+      om[0] *= f; om[1] *= f; om[2] *= f;
+      const double wn = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+      if (wn < 1.0e-9) break;
+      const double ha = 0.5 * wn, shf = sin(ha), ch = cos(ha);
+      const double ax = (1.0 / wn) * om[0], ay = (1.0 / wn) * om[1], az = (1.0 / wn) * om[2];
+      const double dw = ch, dx = shf * ax, dy = shf * ay, dz = shf * az;
+      const double nw = dw * qw - dx * qx - dy * qy - dz * qz, nx = dw * qx + dx * qw + dy * qz - dz * qy;
+      const double ny = dw * qy + dy * qw + dz * qx - dx * qz, nz = dw * qz + dz * qw + dx * qy - dy * qx;
+      const double nn = sqrt(nw * nw + nx * nx + ny * ny + nz * nz);
+      qw = nw / nn; qx = nx / nn; qy = ny / nn; qz = nz / nn;
+    }
+    qp[0] = qw; qp[1] = qx; qp[2] = qy; qp[3] = qz;
+    qmat();
+    for (int q = 0; q < 9; ++q) sh[3 + q] = R[q];
+  }
+  __syncthreads();
+  const double wk = static_cast<double>(S.w[k]);
+  const double T0 = static_cast<double>(comx), T1 = static_cast<double>(comy), T2 = static_cast<double>(comz);
+  for (uint32_t e = threadIdx.x; e < n; e += kBlock) {
+    const double* m = S.mat + 3 * static_cast<size_t>(e0 + e);
+    contribD[e0 + e] = make_double4((sh[3] * m[0] + sh[4] * m[1] + sh[5] * m[2]) + T0, (sh[6] * m[0] + sh[7] * m[1] + sh[8] * m[2]) + T1,
+                                    (sh[9] * m[0] + sh[10] * m[1] + sh[11] * m[2]) + T2, wk);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Right-hand side (Solver.cpp:266, 310-349): one lane per node, contributions in the reference's order
 // (position, distance, tet, volume, bend, ... then the floor contacts), so the float sum is the reference's.
@@ -164,8 +311,10 @@ __global__ void __launch_bounds__(kBlock) k_pd_local_tet(const float4* __restric
 // ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_pd_rhs(const float4* __restrict__ msn, const float4* __restrict__ contrib,
                                                    const uint32_t* __restrict__ incPtr, const uint32_t* __restrict__ incSlot,
-                                                   const float4* __restrict__ pos, const uint32_t* __restrict__ nstatic,
-                                                   float4* __restrict__ statp, float4* __restrict__ rhs, uint32_t n) {
+                                                   const double4* __restrict__ contribD, const uint32_t* __restrict__ incPtrD,
+                                                   const uint32_t* __restrict__ incSlotD, const float4* __restrict__ pos,
+                                                   const uint32_t* __restrict__ nstatic, float4* __restrict__ statp,
+                                                   float4* __restrict__ rhs, uint32_t n) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   float4 f = msn[i];
@@ -175,6 +324,15 @@ __global__ void __launch_bounds__(kBlock) k_pd_rhs(const float4* __restrict__ ms
     f.x += c.x;
     f.y += c.y;
     f.z += c.z;
+  }
+  if (incPtrD) {  // shape then goal matching: force += float w * double projection (ShapeMatchingConstraint.cpp:58-72,147-161)
+    const uint32_t ed = incPtrD[i + 1];
+    for (uint32_t k = incPtrD[i]; k < ed; ++k) {
+      const double4 c = contribD[incSlotD[k]];
+      f.x = static_cast<float>(static_cast<double>(f.x) + c.w * c.x);
+      f.y = static_cast<float>(static_cast<double>(f.y) + c.w * c.y);
+      f.z = static_cast<float>(static_cast<double>(f.z) + c.w * c.z);
+    }
   }
   const uint32_t ns = nstatic[i];
   if (ns) {
@@ -496,8 +654,16 @@ void launch_pd_local_tet(hipStream_t st, bool volume, const float4* pos, const u
 }
 void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd) {
   if (nd.n == 0) return;
-  hipLaunchKernelGGL(k_pd_rhs, grid_for(nd.n), dim3(kBlock), 0, st, pd.msn, pd.contrib, pd.incPtr, pd.incSlot, nd.pos, pd.nstatic,
-                     pd.statp, pd.rhs, nd.n);
+  hipLaunchKernelGGL(k_pd_rhs, grid_for(nd.n), dim3(kBlock), 0, st, pd.msn, pd.contrib, pd.incPtr, pd.incSlot, pd.contribD, pd.incPtrD,
+                     pd.incSlotD, nd.pos, pd.nstatic, pd.statp, pd.rhs, nd.n);
+}
+void launch_pd_local_bend(hipStream_t st, const float4* pos, const uint4* ids, const float2* angle_w, float4* contrib, uint32_t count) {
+  if (count == 0) return;
+  hipLaunchKernelGGL(k_pd_local_bend, grid_for(count), dim3(kBlock), 0, st, pos, ids, angle_w, contrib, count);
+}
+void launch_pd_local_shape(hipStream_t st, const float4* pos, const PdArrays& pd) {
+  if (pd.shape.count == 0) return;
+  hipLaunchKernelGGL(k_pd_local_shape, dim3(pd.shape.count), dim3(kBlock), 0, st, pos, pd.shape, pd.contribD);
 }
 void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, int maxIters, float tol) {
   if (nd.n == 0) return;

@@ -22,8 +22,6 @@ struct Entry {
 
 int pd_build(pies_solver* s) {
   const uint32_t n = s->nodeCount();
-  if (!s->h_bend.empty())
-    return fail(s, PIES_ERR_UNSUPPORTED, "PD with bend constraints: not available in this build yet");
   const float h = s->opt.fixedTimestepSize / s->opt.timeSubsteps;
   const float h2 = h * h;
 
@@ -41,6 +39,12 @@ int pd_build(pies_solver* s) {
     for (const HostTet& c : *list)
       for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) rows[c.ids[i]].push_back({c.ids[j], c.w * c.AtA[4 * i + j]});
+  for (const HostShape& c : s->h_shape)  // ShapeMatchingConstraint.cpp:50-56
+    for (uint32_t id : c.ids) rows[id].push_back({id, c.w});
+  for (const HostGoal& c : s->h_goal)  // :139-145
+    for (uint32_t id : c.ids) rows[id].push_back({id, c.w});
+  for (const HostBend& c : s->h_bend)  // A = I: w on the diagonal (the off-diagonal terms are w*0)
+    for (uint32_t id : c.ids) rows[id].push_back({id, c.w * 1.0f});
 
   std::vector<uint32_t> rowptr(n + 1, 0), col;
   std::vector<float> val, kdiag(n, 0.f);
@@ -65,7 +69,7 @@ int pd_build(pies_solver* s) {
 
   // ---- contribution slots and per-node incidence lists -------------------------------------------------
   const uint32_t cnt[5] = {(uint32_t)s->h_position.size(), (uint32_t)s->h_distance.size(), (uint32_t)s->h_tet.size(),
-                           (uint32_t)s->h_volume.size(), 0u};
+                           (uint32_t)s->h_volume.size(), (uint32_t)s->h_bend.size()};
   const uint32_t arity[5] = {1, 2, 4, 4, 4};
   uint32_t total = 0;
   for (int t = 0; t < 5; ++t) {
@@ -82,11 +86,41 @@ int pd_build(pies_solver* s) {
       for (uint32_t i = 0; i < 4; ++i) fn(s->h_tet[c].ids[i], s->slotBase[2] + 4 * c + i);
     for (uint32_t c = 0; c < cnt[3]; ++c)
       for (uint32_t i = 0; i < 4; ++i) fn(s->h_volume[c].ids[i], s->slotBase[3] + 4 * c + i);
+    for (uint32_t c = 0; c < cnt[4]; ++c)
+      for (uint32_t i = 0; i < 4; ++i) fn(s->h_bend[c].ids[i], s->slotBase[4] + 4 * c + i);
   };
   for_each_incidence([&](uint32_t node, uint32_t) { ++incPtr[node + 1]; });
   for (uint32_t i = 0; i < n; ++i) incPtr[i + 1] += incPtr[i];
   std::vector<uint32_t> incSlot(incPtr[n]), cur(incPtr.begin(), incPtr.end() - 1);
   for_each_incidence([&](uint32_t node, uint32_t slot) { incSlot[cur[node]++] = slot; });
+
+  // fp64 slots: shape entries, then goal entries (reference order :329-335)
+  std::vector<uint32_t> shOff(1, 0), shNode;
+  std::vector<double> shMat, shQinv, shQuat;
+  std::vector<float> shW;
+  for (const HostShape& c : s->h_shape) {
+    shNode.insert(shNode.end(), c.ids.begin(), c.ids.end());
+    shMat.insert(shMat.end(), c.mat.begin(), c.mat.end());
+    shQinv.insert(shQinv.end(), c.Qinv, c.Qinv + 9);
+    shQuat.insert(shQuat.end(), {1.0, 0.0, 0.0, 0.0});  // _currentRotation = identity (ShapeMatchingConstraint.cpp:14)
+    shW.push_back(c.w);
+    shOff.push_back(static_cast<uint32_t>(shNode.size()));
+  }
+  s->goalSlotBase = static_cast<uint32_t>(shNode.size());
+  uint32_t dtotal = s->goalSlotBase;
+  for (const HostGoal& c : s->h_goal) dtotal += static_cast<uint32_t>(c.ids.size());
+  std::vector<uint32_t> incPtrD(n + 1, 0);
+  auto for_each_d = [&](auto&& fn) {
+    uint32_t slot = 0;
+    for (const HostShape& c : s->h_shape)
+      for (uint32_t id : c.ids) fn(id, slot++);
+    for (const HostGoal& c : s->h_goal)
+      for (uint32_t id : c.ids) fn(id, slot++);
+  };
+  for_each_d([&](uint32_t node, uint32_t) { ++incPtrD[node + 1]; });
+  for (uint32_t i = 0; i < n; ++i) incPtrD[i + 1] += incPtrD[i];
+  std::vector<uint32_t> incSlotD(incPtrD[n]), curD(incPtrD.begin(), incPtrD.end() - 1);
+  for_each_d([&](uint32_t node, uint32_t slot) { incSlotD[curD[node]++] = slot; });
 
   std::vector<uint32_t> triCount(n, 0);
   for (uint32_t id : s->h_triangles) ++triCount[id];
@@ -115,6 +149,27 @@ int pd_build(pies_solver* s) {
   if (int rc = upload(s, triCount, &d_tri)) return rc;
   cg.rowptr = d_rowptr; cg.col = d_col; cg.val = d_val;
   pd.kdiag = d_kdiag; pd.incPtr = d_incPtr; pd.incSlot = d_incSlot; pd.triCount = d_tri;
+  pd.contribD = nullptr; pd.incPtrD = nullptr; pd.incSlotD = nullptr;
+  pd.shape = ShapeArrays{};
+  if (dtotal) {
+    uint32_t *d_ipd, *d_isd, *d_off, *d_node;
+    double *d_mat, *d_qinv, *d_quat;
+    float* d_w;
+    if (int rc = upload(s, incPtrD, &d_ipd)) return rc;
+    if (int rc = upload(s, incSlotD, &d_isd)) return rc;
+    if (int rc = dev_alloc(s, dtotal, &pd.contribD, true)) return rc;
+    pd.incPtrD = d_ipd; pd.incSlotD = d_isd;
+    if (!s->h_shape.empty()) {
+      if (int rc = upload(s, shOff, &d_off)) return rc;
+      if (int rc = upload(s, shNode, &d_node)) return rc;
+      if (int rc = upload(s, shMat, &d_mat)) return rc;
+      if (int rc = upload(s, shQinv, &d_qinv)) return rc;
+      if (int rc = upload(s, shQuat, &d_quat)) return rc;
+      if (int rc = upload(s, shW, &d_w)) return rc;
+      pd.shape = ShapeArrays{(uint32_t)s->h_shape.size(), d_off, d_node, d_mat, d_qinv, d_quat, d_w};
+    }
+    s->goalDirty = true;
+  }
   if (int rc = dev_alloc(s, n, &pd.msn)) return rc;
   if (int rc = dev_alloc(s, n, &pd.rhs)) return rc;
   if (int rc = dev_alloc(s, n, &pd.statp, true)) return rc;
@@ -137,6 +192,28 @@ int pd_build(pies_solver* s) {
     HIP_TRY(s, hipMemcpyAsync(pd.contrib + s->slotBase[0], contrib0.data(), contrib0.size() * sizeof(float4),
                               hipMemcpyHostToDevice, s->stream));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
+  return pd_upload_goals(s);
+}
+
+// GoalMatchingConstraint::projectToAuxiliaryVariable (ShapeMatchingConstraint.cpp:163-173): projected =
+// transform * (material, 1) in float (glm mat4*vec4), stored as double.  The targets only change when a
+// transform does, so they are evaluated on the host and copied into the fp64 contribution slots.
+int pd_upload_goals(pies_solver* s) {
+  if (!s->goalDirty || !s->pd.contribD) { s->goalDirty = false; return PIES_OK; }
+  std::vector<double4> out;
+  for (const HostGoal& c : s->h_goal)
+    for (size_t i = 0; i < c.ids.size(); ++i) {
+      const float x = c.mat[3 * i], y = c.mat[3 * i + 1], z = c.mat[3 * i + 2];
+      const float* m = c.transform;
+      float o[3];
+      for (int r = 0; r < 3; ++r) o[r] = (m[r] * x + m[4 + r] * y) + (m[8 + r] * z + m[12 + r] * 1.0f);
+      out.push_back(make_double4(o[0], o[1], o[2], c.w));
+    }
+  if (!out.empty()) {
+    HIP_TRY(s, hipMemcpyAsync(s->pd.contribD + s->goalSlotBase, out.data(), out.size() * sizeof(double4), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+  }
+  s->goalDirty = false;
   return PIES_OK;
 }
 

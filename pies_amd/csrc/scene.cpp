@@ -126,6 +126,91 @@ uint32_t push_node(pies_solver* s, P3 p, P3 v, float radius, float invMass) {
   return id;
 }
 
+// glm::inverse(mat4) (cofactor expansion), column-major m[4*col+row]; setup time only.
+void inverse_mat4(const float m[16], float out[16]) {
+  auto M = [&](int c, int r) { return m[4 * c + r]; };
+  const float c00 = M(2, 2) * M(3, 3) - M(3, 2) * M(2, 3), c02 = M(1, 2) * M(3, 3) - M(3, 2) * M(1, 3), c03 = M(1, 2) * M(2, 3) - M(2, 2) * M(1, 3);
+  const float c04 = M(2, 1) * M(3, 3) - M(3, 1) * M(2, 3), c06 = M(1, 1) * M(3, 3) - M(3, 1) * M(1, 3), c07 = M(1, 1) * M(2, 3) - M(2, 1) * M(1, 3);
+  const float c08 = M(2, 1) * M(3, 2) - M(3, 1) * M(2, 2), c10 = M(1, 1) * M(3, 2) - M(3, 1) * M(1, 2), c11 = M(1, 1) * M(2, 2) - M(2, 1) * M(1, 2);
+  const float c12 = M(2, 0) * M(3, 3) - M(3, 0) * M(2, 3), c14 = M(1, 0) * M(3, 3) - M(3, 0) * M(1, 3), c15 = M(1, 0) * M(2, 3) - M(2, 0) * M(1, 3);
+  const float c16 = M(2, 0) * M(3, 2) - M(3, 0) * M(2, 2), c18 = M(1, 0) * M(3, 2) - M(3, 0) * M(1, 2), c19 = M(1, 0) * M(2, 2) - M(2, 0) * M(1, 2);
+  const float c20 = M(2, 0) * M(3, 1) - M(3, 0) * M(2, 1), c22 = M(1, 0) * M(3, 1) - M(3, 0) * M(1, 1), c23 = M(1, 0) * M(2, 1) - M(2, 0) * M(1, 1);
+  const float f0[4] = {c00, c00, c02, c03}, f1[4] = {c04, c04, c06, c07}, f2[4] = {c08, c08, c10, c11};
+  const float f3[4] = {c12, c12, c14, c15}, f4[4] = {c16, c16, c18, c19}, f5[4] = {c20, c20, c22, c23};
+  const float v0[4] = {M(1, 0), M(0, 0), M(0, 0), M(0, 0)}, v1[4] = {M(1, 1), M(0, 1), M(0, 1), M(0, 1)};
+  const float v2[4] = {M(1, 2), M(0, 2), M(0, 2), M(0, 2)}, v3[4] = {M(1, 3), M(0, 3), M(0, 3), M(0, 3)};
+  const float sa[4] = {+1, -1, +1, -1}, sb[4] = {-1, +1, -1, +1};
+  float inv[4][4];  // inv[col][row]
+  for (int r = 0; r < 4; ++r) {
+    inv[0][r] = (v1[r] * f0[r] - v2[r] * f1[r] + v3[r] * f2[r]) * sa[r];
+    inv[1][r] = (v0[r] * f0[r] - v2[r] * f3[r] + v3[r] * f4[r]) * sb[r];
+    inv[2][r] = (v0[r] * f1[r] - v1[r] * f3[r] + v3[r] * f5[r]) * sa[r];
+    inv[3][r] = (v0[r] * f2[r] - v1[r] * f4[r] + v2[r] * f5[r]) * sb[r];
+  }
+  const float dot1 = (M(0, 0) * inv[0][0] + M(0, 1) * inv[1][0]) + (M(0, 2) * inv[2][0] + M(0, 3) * inv[3][0]);
+  const float ood = 1.0f / dot1;
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) out[4 * c + r] = inv[c][r] * ood;
+}
+
+// glm mat4 * vec4(p, 1): (m0*x + m1*y) + (m2*z + m3*1)
+inline void mul_point(const float m[16], P3 p, float out[4]) {
+  for (int r = 0; r < 4; ++r) out[r] = (m[r] * p.x + m[4 + r] * p.y) + (m[8 + r] * p.z + m[12 + r] * 1.0f);
+}
+inline void mul_mat4(const float a[16], const float b[16], float out[16]) {  // glm a*b, column by column
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r)
+      out[4 * c + r] = ((a[r] * b[4 * c] + a[4 + r] * b[4 * c + 1]) + a[8 + r] * b[4 * c + 2]) + a[12 + r] * b[4 * c + 3];
+}
+
+bool inside_unit_box(const float worldToRegion[16], P3 p) {
+  float l[4];
+  mul_point(worldToRegion, p, l);
+  return -1.0f <= l[0] && l[0] <= 1.0f && -1.0f <= l[1] && l[1] <= 1.0f && -1.0f <= l[2] && l[2] <= 1.0f;
+}
+
+void inverse3d(const double m[3][3], double o[9]) {
+  const double c00 = m[1][1] * m[2][2] - m[1][2] * m[2][1], c01 = m[1][2] * m[2][0] - m[1][0] * m[2][2], c02 = m[1][0] * m[2][1] - m[1][1] * m[2][0];
+  const double id = 1.0 / (m[0][0] * c00 + m[0][1] * c01 + m[0][2] * c02);
+  o[0] = c00 * id; o[1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) * id; o[2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) * id;
+  o[3] = c01 * id; o[4] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) * id; o[5] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) * id;
+  o[6] = c02 * id; o[7] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) * id; o[8] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) * id;
+}
+
+// ShapeMatchingConstraint constructor (ShapeMatchingConstraint.cpp:6-48): unweighted float centroid of the
+// material coordinates, Q = sum (r r^T)/invMass (products in float, sum in double), Qinv in double.
+void push_shape(pies_solver* s, const std::vector<uint32_t>& ids, const std::vector<P3>& material, float w) {
+  HostShape c;
+  c.ids = ids;
+  c.w = w;
+  const size_t n = material.size();
+  c.mat.assign(3 * n, 0.0);
+  P3 com{0.f, 0.f, 0.f};
+  const float weight = 1.0f / static_cast<float>(n);
+  for (const P3& m : material) { com.x += weight * m.x; com.y += weight * m.y; com.z += weight * m.z; }
+  double Q[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (size_t i = 0; i < n; ++i) {
+    const float mc[3] = {material[i].x - com.x, material[i].y - com.y, material[i].z - com.z};
+    for (int k = 0; k < 3; ++k) c.mat[3 * i + k] = mc[k];
+    const float im = s->h_invMass[ids[i]];
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < 3; ++cc) Q[r][cc] += (mc[r] * mc[cc]) / im;
+  }
+  inverse3d(Q, c.Qinv);
+  s->h_shape.push_back(std::move(c));
+}
+
+void push_goal(pies_solver* s, const std::vector<uint32_t>& ids, float w) {
+  HostGoal c;
+  c.ids = ids;
+  c.w = w;
+  c.mat.resize(3 * ids.size());
+  for (size_t i = 0; i < ids.size(); ++i)
+    for (int k = 0; k < 3; ++k) c.mat[3 * i + k] = s->h_pos[3 * ids[i] + k];
+  for (int i = 0; i < 16; ++i) c.transform[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+  s->h_goal.push_back(std::move(c));
+}
+
 // Grid::gridIdToNodeId (PrimitiveUtilities.cpp:35-38)
 inline uint32_t lattice_id(uint32_t H, uint32_t D, uint32_t first, uint32_t x, uint32_t y, uint32_t z) {
   return z + D * (y + H * x) + first;
@@ -381,6 +466,125 @@ int pies_create_bend_sheet(pies_solver_t* s, uint32_t W, uint32_t H, const float
       s->h_triangles.insert(s->h_triangles.end(), {G(i, j), G(i, j + 1), G(i + 1, j + 1)});
     }
   lines_from_distances(s, firstDistance);
+  return PIES_OK;
+}
+
+// ShapeMatchingConstraint over explicit nodes: material coordinates = the nodes' current positions
+// (what createShapeMatching* and addLinkedRegions pass, PrimitiveUtilities.cpp:149-156,1027-1036)
+int pies_add_shape_constraint(pies_solver_t* s, uint32_t n, const uint32_t* ids, float w) {
+  PIES_BEGIN_EDIT(s);
+  if (n == 0 || !ids || !ids_ok(s, ids, n)) return fail(s, PIES_ERR_INVALID, "shape constraint: bad node id");
+  std::vector<uint32_t> v(ids, ids + n);
+  std::vector<P3> mc(n);
+  for (uint32_t i = 0; i < n; ++i) mc[i] = node_pos(s, ids[i]);
+  push_shape(s, v, mc, w);
+  return PIES_OK;
+}
+
+int pies_add_goal_constraint(pies_solver_t* s, uint32_t n, const uint32_t* ids, float w, uint32_t* goal_index) {
+  PIES_BEGIN_EDIT(s);
+  if (n && (!ids || !ids_ok(s, ids, n))) return fail(s, PIES_ERR_INVALID, "goal constraint: bad node id");
+  if (goal_index) *goal_index = static_cast<uint32_t>(s->h_goal.size());
+  push_goal(s, std::vector<uint32_t>(ids, ids + n), w);
+  return PIES_OK;
+}
+
+// GoalMatchingConstraint::setTransform (ShapeMatchingConstraint.cpp:175-177); no re-capture needed
+int pies_set_goal_transform(pies_solver_t* s, uint32_t goal, const float m16[16]) {
+  PIES_CHECK_HANDLE(s);
+  if (!m16 || goal >= s->h_goal.size()) return fail(s, PIES_ERR_INVALID, "pies_set_goal_transform: bad goal index");
+  std::memcpy(s->h_goal[goal].transform, m16, 16 * sizeof(float));
+  s->goalDirty = true;
+  return PIES_OK;
+}
+
+// Solver::addFixedRegions (PrimitiveUtilities.cpp:77-112): one goal constraint per region over the nodes
+// inside its unit box.
+int pies_add_fixed_regions(pies_solver_t* s, uint32_t n, const float* mats16, float w) {
+  PIES_BEGIN_EDIT(s);
+  if (n && !mats16) return fail(s, PIES_ERR_INVALID, "pies_add_fixed_regions: NULL matrices");
+  for (uint32_t k = 0; k < n; ++k) {
+    HostFixedRegion region;
+    inverse_mat4(mats16 + 16 * k, region.invInitialTransform);
+    region.goal = static_cast<uint32_t>(s->h_goal.size());
+    std::vector<uint32_t> inside;
+    for (uint32_t i = 0; i < s->nodeCount(); ++i)
+      if (inside_unit_box(region.invInitialTransform, node_pos(s, i))) inside.push_back(i);
+    push_goal(s, inside, w);
+    s->h_fixedRegions.push_back(region);
+  }
+  return PIES_OK;
+}
+
+// Solver::updateFixedRegions (PrimitiveUtilities.cpp:114-128): transform = current * inverse(initial)
+int pies_update_fixed_regions(pies_solver_t* s, uint32_t n, const float* mats16) {
+  PIES_CHECK_HANDLE(s);
+  if (n != s->h_fixedRegions.size() || (n && !mats16)) return fail(s, PIES_ERR_INVALID, "pies_update_fixed_regions: region count mismatch");
+  for (uint32_t k = 0; k < n; ++k) {
+    float t[16];
+    mul_mat4(mats16 + 16 * k, s->h_fixedRegions[k].invInitialTransform, t);
+    std::memcpy(s->h_goal[s->h_fixedRegions[k].goal].transform, t, sizeof(t));
+  }
+  s->goalDirty = true;
+  return PIES_OK;
+}
+
+// Solver::addLinkedRegions (PrimitiveUtilities.cpp:130-162): one shape-matching constraint per region with >= 3 nodes
+int pies_add_linked_regions(pies_solver_t* s, uint32_t n, const float* mats16, float w) {
+  PIES_BEGIN_EDIT(s);
+  if (n && !mats16) return fail(s, PIES_ERR_INVALID, "pies_add_linked_regions: NULL matrices");
+  for (uint32_t k = 0; k < n; ++k) {
+    float inv[16];
+    inverse_mat4(mats16 + 16 * k, inv);
+    std::vector<uint32_t> ids;
+    std::vector<P3> mc;
+    for (uint32_t i = 0; i < s->nodeCount(); ++i)
+      if (inside_unit_box(inv, node_pos(s, i))) { ids.push_back(i); mc.push_back(node_pos(s, i)); }
+    if (mc.size() >= 3) push_shape(s, ids, mc, w);
+  }
+  return PIES_OK;
+}
+
+// Solver::createShapeMatchingBox (PrimitiveUtilities.cpp:985-1048): the scale argument is overridden to 0.5,
+// invMass 1/10, zero velocity (the reference ignores initialVelocity), one constraint over the whole lattice.
+int pies_create_shape_matching_box(pies_solver_t* s, const float tr[3], uint32_t countX, uint32_t countY, uint32_t countZ, float w) {
+  PIES_BEGIN_EDIT(s);
+  if (!tr || countX == 0 || countY == 0 || countZ == 0) return fail(s, PIES_ERR_INVALID, "pies_create_shape_matching_box: bad argument");
+  const float scale = 0.5f;
+  const uint32_t first = s->nodeCount();
+  for (uint32_t i = 0; i < countX; ++i)
+    for (uint32_t j = 0; j < countY; ++j)
+      for (uint32_t k = 0; k < countZ; ++k)
+        push_node(s, {scale * float(i) + tr[0], scale * float(j) + tr[1], scale * float(k) + tr[2]}, {0.f, 0.f, 0.f}, 0.5f * scale, 1.0f / 10.0f);
+  const uint32_t n = countX * countY * countZ;
+  std::vector<uint32_t> ids(n);
+  std::vector<P3> mc(n);
+  for (uint32_t i = 0; i < n; ++i) { ids[i] = first + i; mc[i] = node_pos(s, first + i); }
+  push_shape(s, ids, mc, w);
+  return PIES_OK;
+}
+
+// Solver::createShapeMatchingSheet (PrimitiveUtilities.cpp:1050-1125): W x H x 1 lattice in the xy plane,
+// overlapping 3x3 patches, one shape-matching constraint per patch (reference: 50 x 50).
+int pies_create_shape_matching_sheet(pies_solver_t* s, uint32_t W, uint32_t H, const float tr[3], float scale, float w) {
+  PIES_BEGIN_EDIT(s);
+  if (!tr || W < 3 || H < 3) return fail(s, PIES_ERR_INVALID, "pies_create_shape_matching_sheet: bad argument");
+  constexpr uint32_t pw = 3, ph = 3;
+  struct Patch { std::vector<uint32_t> ids; std::vector<P3> mc; };
+  std::vector<Patch> patches((W / pw) * (H / ph));
+  auto add = [&](uint32_t patch, uint32_t id, P3 p) {
+    if (patch < patches.size()) { patches[patch].ids.push_back(id); patches[patch].mc.push_back(p); }
+  };
+  for (uint32_t i = 0; i < W; ++i)
+    for (uint32_t j = 0; j < H; ++j) {
+      const P3 p{scale * float(i) + tr[0], scale * float(j) + tr[1], scale * 0.0f + tr[2]};
+      const uint32_t id = push_node(s, p, {0.f, 0.f, 0.f}, 0.5f * scale, 1.0f);
+      add(i / pw * ph + j / ph, id, p);
+      if ((i % pw) == (pw - 1) && i < (W - 1)) add((1 + i / pw) * ph + j / ph, id, p);
+      if ((j % ph) == (ph - 1) && j < (H - 1)) add(i / pw * ph + j / ph + 1, id, p);
+    }
+  for (const Patch& pt : patches)
+    if (!pt.ids.empty()) push_shape(s, pt.ids, pt.mc, w);
   return PIES_OK;
 }
 

@@ -39,6 +39,23 @@ struct HostBend {
   float w;
 };
 
+struct HostShape {  // ShapeMatchingConstraint (Src/ShapeMatchingConstraint.cpp:6-48)
+  std::vector<uint32_t> ids;
+  std::vector<double> mat;  // 3 x n material coordinates, centred (column i at mat[3i..])
+  double Qinv[9];           // row-major
+  float w;
+};
+struct HostGoal {  // GoalMatchingConstraint (Src/ShapeMatchingConstraint.cpp:124-137)
+  std::vector<uint32_t> ids;
+  std::vector<float> mat;  // 3 x n world positions at creation
+  float transform[16];     // column-major mat4
+  float w;
+};
+struct HostFixedRegion {  // Solver::FixedRegion (Include/Pies/Solver.h:147-151)
+  float invInitialTransform[16];
+  uint32_t goal;
+};
+
 struct Batch {
   uint32_t start, count;
 };
@@ -74,6 +91,10 @@ struct pies_solver {
   std::vector<pies::HostDistance> h_distance;
   std::vector<pies::HostTet> h_tet, h_volume;
   std::vector<pies::HostBend> h_bend;
+  std::vector<pies::HostShape> h_shape;
+  std::vector<pies::HostGoal> h_goal;
+  std::vector<pies::HostFixedRegion> h_fixedRegions;
+  bool goalDirty = false;  // a goal transform changed: refresh its projected positions in HBM
   std::vector<uint32_t> h_triangles;  // 3 per triangle
   std::vector<uint32_t> h_lines;
   uint32_t constraintId = 0;
@@ -105,6 +126,7 @@ struct pies_solver {
   pies::PdArrays pd{};
   uint32_t slotBase[5] = {0, 0, 0, 0, 0};  // first contribution slot of each container
   uint32_t pd_nnz = 0;
+  uint32_t goalSlotBase = 0;  // first fp64 contribution slot of the goal constraints
   float pcgTol = 3.0e-7f;     // relative residual ||r|| / ||b|| per coordinate column
   uint32_t pcgMaxIters = 12;  // CG iterations captured per global step
   std::vector<void*> allocations;

@@ -68,6 +68,14 @@ def lib():
         L.ora_add_goal.argtypes = [vp, u32, pu, f32]
         L.ora_set_goal_transform.argtypes = [vp, u32, pf]
         L.ora_add_triangles.argtypes = [vp, u32, pu]
+        L.ora_add_fixed_regions.argtypes = [vp, u32, pf, f32]
+        L.ora_update_fixed_regions.argtypes = [vp, u32, pf]
+        L.ora_add_linked_regions.argtypes = [vp, u32, pf, f32]
+        L.ora_create_shape_matching_box.argtypes = [vp, pf, u32, u32, u32, f32]
+        L.ora_create_shape_matching_sheet.argtypes = [vp, u32, u32, pf, f32, f32]
+        L.ora_group_size.restype = u32
+        L.ora_group_size.argtypes = [vp, i32, u32]
+        L.ora_group_ids.argtypes = [vp, i32, u32, pu]
         L.ora_create_tet_box.argtypes = [vp, u32, u32, u32, pf, f32, pf, f32, f32, u32]
         L.ora_create_box.argtypes = [vp, u32, u32, u32, pf, f32, f32, i32, u32, u32]
         L.ora_create_sheet.argtypes = [vp, u32, u32, pf, f32, f32, f32]
@@ -177,6 +185,31 @@ class OracleSolver:
     def add_triangles(self, ids):
         ids = _u32(ids).reshape(-1, 3)
         lib().ora_add_triangles(self._h, len(ids), _pu(ids))
+
+    def add_fixed_regions(self, mats, w):
+        m = _f32(mats).reshape(-1, 16)
+        lib().ora_add_fixed_regions(self._h, len(m), _pf(m), w)
+
+    def update_fixed_regions(self, mats):
+        m = _f32(mats).reshape(-1, 16)
+        lib().ora_update_fixed_regions(self._h, len(m), _pf(m))
+
+    def add_linked_regions(self, mats, w):
+        m = _f32(mats).reshape(-1, 16)
+        lib().ora_add_linked_regions(self._h, len(m), _pf(m), w)
+
+    def create_shape_matching_box(self, translation, cx, cy, cz, w):
+        t = _f32(translation)
+        lib().ora_create_shape_matching_box(self._h, _pf(t), cx, cy, cz, w)
+
+    def create_shape_matching_sheet(self, W, H, translation=(0, 0, 0), scale=1.0, w=1.0):
+        t = _f32(translation)
+        lib().ora_create_shape_matching_sheet(self._h, W, H, _pf(t), scale, w)
+
+    def group_ids(self, ctype, k):
+        out = np.empty(lib().ora_group_size(self._h, ctype, k), dtype=np.uint32)
+        lib().ora_group_ids(self._h, ctype, k, _pu(out))
+        return out
 
     def create_tet_box(self, W, H, D, translation=(0, 0, 0), scale=1.0, velocity=(0, 0, 0), w=1.0, mass=1.0,
                        volume=True, triangles=True):

@@ -121,3 +121,64 @@ def test_config3_l100k_pd_properties(pies):
     cap = np.array([0 + D * (j + H * i) for i in range(W) for j in range(H)])
     assert np.abs(p[cap] - p0[cap]).max() < 0.02          # pinned end cap barely moves
     assert p[:, 1].mean() < p0[:, 1].mean()               # the free part sags under gravity
+
+
+def _region(center, half):
+    m = np.zeros((4, 4), np.float32)  # column-major: m[col][row]
+    m[0, 0], m[1, 1], m[2, 2], m[3, 3] = half[0], half[1], half[2], 1.0
+    m[3, :3] = center
+    return m.reshape(16)
+
+
+def test_pd_bend_sheet(pies, oracle):
+    g = pies.Solver(pd_options(pies, 5))
+    o = oracle.OracleSolver(pd_options(oracle, 5))
+    for s in (g, o):
+        s.create_bend_sheet(7, 6, translation=(0, 3, 0), scale=1.0, w=0.8)
+        scenes.perturb(s, 6, 0.05)
+        s.set_prev_positions(s.positions)
+        s.tick(4)
+    assert np.abs(g.positions - o.positions).max() <= tol_for(o.positions)
+
+
+def test_pd_shape_matching_box_and_sheet(pies, oracle):
+    """C6: createShapeMatchingBox (one constraint over 4x3x5 nodes) and a 9x9 sheet of overlapping patches."""
+    g = pies.Solver(pd_options(pies, 5))
+    o = oracle.OracleSolver(pd_options(oracle, 5))
+    for s in (g, o):
+        s.create_shape_matching_box((0, 1.0, 0), 4, 3, 5, 30.0)
+        s.create_shape_matching_sheet(9, 9, translation=(6, 2, 0), scale=0.5, w=20.0)
+        s.add_triangles([[0, 1, 5], [60, 61, 70]])  # lets the box and the sheet feel the floor
+        scenes.perturb(s, 8, 0.05)
+        s.set_prev_positions(s.positions)
+    assert g.count(pies.SHAPE) == o.count(oracle.SHAPE) > 1
+    for k in range(g.count(pies.SHAPE)):
+        assert np.array_equal(g.group_ids(pies.SHAPE, k), o.group_ids(oracle.SHAPE, k))
+    for t in range(5):
+        g.tick(); o.tick()
+        assert np.abs(g.positions - o.positions).max() <= tol_for(o.positions), t
+    assert np.abs(g.velocities - o.velocities).max() <= tol_for(o.positions) / 0.012
+
+
+def test_pd_fixed_and_linked_regions(pies, oracle):
+    """C7 + region API: pin one end of a beam with a fixed region, move it, link a block with shape matching."""
+    g = pies.Solver(pd_options(pies, 6))
+    o = oracle.OracleSolver(pd_options(oracle, 6))
+    fixed = _region((1.5, 2.5, 0.0), (2.0, 2.0, 0.6))
+    linked = _region((1.5, 2.5, 6.0), (2.5, 2.5, 1.2))
+    for s in (g, o):
+        s.create_tet_box(4, 4, 9, translation=(0, 1.0, 0), w=1.0, volume=True, triangles=True)
+        s.add_fixed_regions(fixed, 50.0)
+        s.add_linked_regions(linked, 10.0)
+    assert g.count(pies.GOAL) == 1 and g.count(pies.SHAPE) == 1
+    assert np.array_equal(g.group_ids(pies.GOAL, 0), o.group_ids(oracle.GOAL, 0)) and len(g.group_ids(pies.GOAL, 0)) == 16
+    assert np.array_equal(g.group_ids(pies.SHAPE, 0), o.group_ids(oracle.SHAPE, 0))
+    for s in (g, o):
+        s.tick(2)
+    moved = _region((1.5 + 0.3, 2.5 + 0.2, 0.1), (2.0, 2.0, 0.6))  # drag the clamped end
+    for s in (g, o):
+        s.update_fixed_regions(moved)
+        s.tick(3)
+    assert np.abs(g.positions - o.positions).max() <= tol_for(o.positions)
+    cap = g.group_ids(pies.GOAL, 0)
+    assert np.abs(g.positions[cap, 0].mean() - (1.5 + 0.3)) < 0.05  # the goal nodes followed the region
