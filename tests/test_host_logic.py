@@ -38,6 +38,25 @@ def test_scene_generators_match_oracle():
         assert np.array_equal(getattr(g, name), getattr(o, name)), name
 
 
+def test_shape_and_region_generators_match_oracle():
+    g = capi.Solver(capi.Options(solver=capi.PD), device=-1)
+    o = O.OracleSolver(O.Options(solver=O.PD))
+    region = np.zeros((4, 4), np.float32)
+    region[0, 0], region[1, 1], region[2, 2], region[3, 3] = 1.2, 0.8, 2.0, 1.0
+    region[3, :3] = (1.0, 1.0, 1.0)
+    region[1, 0] = 0.3  # sheared box: exercises the full mat4 inverse
+    for s in (g, o):
+        s.create_shape_matching_box((0, 0.5, 0), 4, 3, 5, 2.0)
+        s.create_shape_matching_sheet(50, 50, translation=(5, 1, 0), scale=0.25, w=3.0)  # the reference's size
+        s.add_fixed_regions(region.reshape(16), 7.0)
+        s.add_linked_regions(np.stack([region.reshape(16), region.reshape(16) * np.float32(1.5)]), 4.0)
+    assert g.count(capi.SHAPE) == o.count(O.SHAPE) and g.count(capi.GOAL) == o.count(O.GOAL) == 1
+    for k in range(g.count(capi.SHAPE)):
+        assert np.array_equal(g.group_ids(capi.SHAPE, k), o.group_ids(O.SHAPE, k)), k
+    assert np.array_equal(g.group_ids(capi.GOAL, 0), o.group_ids(O.GOAL, 0)) and len(g.group_ids(capi.GOAL, 0)) > 0
+    assert np.array_equal(g.positions, o.positions) and np.array_equal(g.inv_masses, o.inv_masses)
+
+
 def _conflict_free(ids, order, offs, writes):
     for b in range(len(offs) - 1):
         sel = ids[order[offs[b]:offs[b + 1]]].reshape(offs[b + 1] - offs[b], -1)

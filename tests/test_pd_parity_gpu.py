@@ -142,16 +142,19 @@ def test_pd_bend_sheet(pies, oracle):
 
 
 def test_pd_shape_matching_box_and_sheet(pies, oracle):
-    """C6: createShapeMatchingBox (one constraint over 4x3x5 nodes) and a 9x9 sheet of overlapping patches."""
+    """C6: createShapeMatchingBox (one constraint over 4x3x5 nodes) plus a second, overlapping cluster.
+    (createShapeMatchingSheet builds planar patches whose Q = sum r r^T is singular, so the reference's own
+    Qinv is non-finite there; the sheet is therefore only compared structurally, in test_host_logic.)"""
     g = pies.Solver(pd_options(pies, 5))
     o = oracle.OracleSolver(pd_options(oracle, 5))
     for s in (g, o):
         s.create_shape_matching_box((0, 1.0, 0), 4, 3, 5, 30.0)
-        s.create_shape_matching_sheet(9, 9, translation=(6, 2, 0), scale=0.5, w=20.0)
-        s.add_triangles([[0, 1, 5], [60, 61, 70]])  # lets the box and the sheet feel the floor
+        s.create_shape_matching_box((4, 0.4, 0), 6, 6, 6, 5.0)
+        s.add_shape(np.arange(40, 100, dtype=np.uint32), 3.0)  # overlaps both boxes' node ranges
+        s.add_triangles([[0, 1, 5], [60, 61, 70], [100, 130, 170]])  # lets the bodies feel the floor
         scenes.perturb(s, 8, 0.05)
         s.set_prev_positions(s.positions)
-    assert g.count(pies.SHAPE) == o.count(oracle.SHAPE) > 1
+    assert g.count(pies.SHAPE) == o.count(oracle.SHAPE) == 3
     for k in range(g.count(pies.SHAPE)):
         assert np.array_equal(g.group_ids(pies.SHAPE, k), o.group_ids(oracle.SHAPE, k))
     for t in range(5):
@@ -181,4 +184,5 @@ def test_pd_fixed_and_linked_regions(pies, oracle):
         s.tick(3)
     assert np.abs(g.positions - o.positions).max() <= tol_for(o.positions)
     cap = g.group_ids(pies.GOAL, 0)
-    assert np.abs(g.positions[cap, 0].mean() - (1.5 + 0.3)) < 0.05  # the goal nodes followed the region
+    # w = 50 against m/h^2 ~ 7e3: the goal nodes are pulled towards the moved region, a little per tick
+    assert 0.005 < g.positions[cap, 0].mean() - 1.5 < 0.3
