@@ -10,6 +10,7 @@
 //              colour => bit-identical to a sequential sweep over the container re-ordered by colour
 //              (stable), which is the order pies_get_order reports.
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 
 #include "solver_state.h"
@@ -53,11 +54,13 @@ static uint32_t levels(const OpView& ops, uint32_t nodeCount, std::vector<uint32
   return maxLevel;
 }
 
-static bool colours(const OpView& ops, uint32_t nodeCount, std::vector<uint32_t>& key, uint32_t& ncolours) {
+// First-fit colouring of the ops visited in the order `visit` (nullptr = host order).
+static bool colours(const OpView& ops, uint32_t nodeCount, const uint32_t* visit, std::vector<uint32_t>& key, uint32_t& ncolours) {
   constexpr int kWords = 4;  // up to 256 colours
   std::vector<uint64_t> usedW(static_cast<size_t>(nodeCount) * kWords, 0), usedR(static_cast<size_t>(nodeCount) * kWords, 0);
   ncolours = 0;
-  for (uint32_t c = 0; c < ops.count; ++c) {
+  for (uint32_t v = 0; v < ops.count; ++v) {
+    const uint32_t c = visit ? visit[v] : v;
     const uint32_t* id = ops.ids + static_cast<size_t>(c) * ops.stride;
     uint64_t forbid[kWords] = {0, 0, 0, 0};
     for (uint32_t k = 0; k < ops.stride; ++k) {
@@ -81,6 +84,37 @@ static bool colours(const OpView& ops, uint32_t nodeCount, std::vector<uint32_t>
   return true;
 }
 
+// Iterated greedy (Culberson): re-running first-fit with the ops grouped by their current colour class can
+// never use more colours, and visiting the classes in a different order (largest first / reversed) lets
+// small classes dissolve into earlier ones.  Fewer colours = fewer dependent launches per sweep.
+static bool colours_iterated(const OpView& ops, uint32_t nodeCount, std::vector<uint32_t>& key, uint32_t& ncolours) {
+  if (!colours(ops, nodeCount, nullptr, key, ncolours)) return false;
+  int rounds = 12;
+  if (const char* e = std::getenv("PIES_COLOUR_ROUNDS")) rounds = std::atoi(e);
+  std::vector<uint32_t> visit(ops.count), best = key, trial(ops.count);
+  uint32_t bestN = ncolours;
+  for (int r = 0; r < rounds; ++r) {
+    // class sizes of the best colouring so far
+    std::vector<uint32_t> size(bestN, 0), classOrder(bestN);
+    for (uint32_t c = 0; c < ops.count; ++c) ++size[best[c]];
+    std::iota(classOrder.begin(), classOrder.end(), 0u);
+    if (r % 3 == 0) std::reverse(classOrder.begin(), classOrder.end());
+    else if (r % 3 == 1) std::stable_sort(classOrder.begin(), classOrder.end(), [&](uint32_t a, uint32_t b) { return size[a] > size[b]; });
+    else std::stable_sort(classOrder.begin(), classOrder.end(), [&](uint32_t a, uint32_t b) { return size[a] < size[b]; });
+    std::vector<uint32_t> rank(bestN), offs(bestN + 1, 0);
+    for (uint32_t k = 0; k < bestN; ++k) rank[classOrder[k]] = k;
+    for (uint32_t c = 0; c < ops.count; ++c) ++offs[rank[best[c]] + 1];
+    for (uint32_t k = 0; k < bestN; ++k) offs[k + 1] += offs[k];
+    for (uint32_t c = 0; c < ops.count; ++c) visit[offs[rank[best[c]]]++] = c;  // stable inside a class
+    uint32_t n = 0;
+    if (!colours(ops, nodeCount, visit.data(), trial, n)) break;
+    if (n <= bestN) { best.swap(trial); bestN = n; }
+  }
+  key.swap(best);
+  ncolours = bestN;
+  return true;
+}
+
 void build_plan(const OpView& ops, uint32_t nodeCount, int schedule, Plan& out) {
   out.order.clear();
   out.batches.clear();
@@ -91,7 +125,7 @@ void build_plan(const OpView& ops, uint32_t nodeCount, int schedule, Plan& out) 
     plan_from_keys(key, 1, out);
     return;
   }
-  if (schedule == PIES_SCHEDULE_COLOURED && colours(ops, nodeCount, key, nkeys)) {
+  if (schedule == PIES_SCHEDULE_COLOURED && colours_iterated(ops, nodeCount, key, nkeys)) {
     plan_from_keys(key, nkeys, out);
     return;
   }
