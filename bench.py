@@ -116,10 +116,12 @@ def extra_configs(device):
     g.create_tet_box(W, H, D, translation=(0.0, 2.0, 0.0), w=1.0, volume=True, triangles=True)
     g.add_position(np.array([D * (j + H * i) for i in range(W) for j in range(H)], dtype=np.uint32), 2.0)
     g.finalize()
+    g.tick_async(2)
+    g.synchronize()  # lets the captured CG iteration budget settle to what the solves use
     el = timed_ticks(g, 30, 3, lambda: None)
     res, iters, solves = g.pcg_stats()
     out["pd_config3"] = {"value": 30 / el, "unit": "substeps/s", "workload": "20x20x250 beam, PD, 539334 tet + 539334 volume constraints, "
-                         "10 local/global iterations, floor contacts, Jacobi-PCG rel. tol 3e-7",
+                         "10 local/global iterations, floor contacts, Jacobi-PCG rel. tol 3e-7 (iteration budget adapts)",
                          "pcg_max_rel_residual": res, "pcg_max_iterations_used": iters,
                          "projections_per_sec": 30 / el * 10 * (g.count(capi.TET) + g.count(capi.VOLUME) + g.count(capi.POSITION))}
     g.close()

@@ -159,7 +159,7 @@ static void enqueue_pd_substep(pies_solver* s) {
     launch_pd_local_bend(st, s->nd.pos, s->d_bc_ids, s->d_bc_aw, pd.contrib + s->slotBase[PIES_BEND], (uint32_t)s->h_bend.size());
     launch_pd_local_shape(st, s->nd.pos, pd);                        // goal targets are constants between transform updates
     launch_pd_rhs(st, s->nd, pd);                                    // Solver.cpp:266, 310-349
-    launch_pd_solve(st, s->nd, pd, (int)s->pcgMaxIters, s->pcgTol);  // Solver.cpp:356-364
+    launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, s->pcgTol);    // Solver.cpp:356-364
   }
   if (s->opt.collisionStabilizationIterations > 0) launch_pd_stabilize(st, s->nd, pd);  // :367-383
   launch_pd_velocity(st, s->nd, pd, h, s->opt.damping, s->opt.gravity, s->opt.friction, s->opt.staticFrictionThreshold);
@@ -188,6 +188,32 @@ static int capture_graph(pies_solver* s) {
   hipError_t e = hipStreamEndCapture(s->stream, &s->graph);
   if (e != hipSuccess) return fail(s, PIES_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
   HIP_TRY(s, hipGraphInstantiate(&s->graphExec, s->graph, nullptr, nullptr, 0));
+  return PIES_OK;
+}
+
+// The graph holds a fixed number of CG iterations per solve (converged solves early-exit the rest).  At
+// every host synchronisation the budget follows what the solves needed: it starts at pcgMaxIters, shrinks
+// to (iterations used + 2), and doubles (up to pcgMaxIters) when a solve ran out of iterations above the
+// tolerance.
+static int adapt_pcg_budget(pies_solver* s) {
+  if (s->opt.solver != PIES_SOLVER_PD || !s->pd.cg.stats || !s->graphExec || s->sceneDirty || under_profiler()) return PIES_OK;
+  float st[4] = {0, 0, 0, 0};
+  HIP_TRY(s, hipMemcpyAsync(st, s->pd.cg.stats, sizeof(st), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  if (st[2] == 0.0f) return PIES_OK;  // no solve since the statistics were reset
+  const uint32_t used = static_cast<uint32_t>(st[1]);
+  const bool converged = st[0] <= s->pcgTol * s->pcgTol;
+  uint32_t budget = s->pcgBudget;
+  if (!converged && budget < s->pcgMaxIters) {
+    budget = std::min(s->pcgMaxIters, budget * 2);
+    s->pcgSlack = 0;
+  } else if (converged && used + 2 < budget) {
+    budget = used + 2;  // keep two iterations of head-room
+  }
+  if (budget != s->pcgBudget) {
+    s->pcgBudget = budget;
+    return capture_graph(s);
+  }
   return PIES_OK;
 }
 
@@ -327,6 +353,7 @@ int pies_set_pcg(pies_solver_t* s, float rel_tol, uint32_t max_iters) {
     if (int rc = scene_sync_host(s)) return rc;
     s->pcgTol = rel_tol;
     s->pcgMaxIters = max_iters;
+    s->pcgBudget = max_iters;
     s->sceneDirty = true;  // the captured launch sequence changes
   }
   return PIES_OK;
@@ -541,7 +568,7 @@ int pies_synchronize(pies_solver_t* s) {
   if (s->device == PIES_DEVICE_NONE) return PIES_OK;
   HIP_TRY(s, hipSetDevice(s->device));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
-  return PIES_OK;
+  return adapt_pcg_budget(s);
 }
 
 int pies_tick(pies_solver_t* s) {
@@ -554,6 +581,7 @@ int pies_tick(pies_solver_t* s) {
   HIP_TRY(s, hipMemcpyAsync(s->h_stage, s->nd.pos, n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   if (int rc = poll_failure(s)) return rc;
+  if (int rc = adapt_pcg_budget(s)) return rc;
   for (uint32_t i = 0; i < n; ++i) {
     s->h_pos[3 * i] = s->h_stage[i].x;
     s->h_pos[3 * i + 1] = s->h_stage[i].y;

@@ -7,7 +7,7 @@
 
 namespace pies {
 
-constexpr uint32_t kCgBlocks = 256;  // CG launch shape: <= 256 blocks x 256 threads, grid-stride
+constexpr uint32_t kCgBlocks = 1024;  // CG launch shape: <= 1024 blocks x 256 threads (4 per CU), grid-stride
 
 struct CgArrays {
   uint32_t n;

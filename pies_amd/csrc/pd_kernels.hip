@@ -315,16 +315,34 @@ __global__ void __launch_bounds__(kBlock) k_pd_rhs(const float4* __restrict__ ms
                                                    const uint32_t* __restrict__ incSlotD, const float4* __restrict__ pos,
                                                    const uint32_t* __restrict__ nstatic, float4* __restrict__ statp,
                                                    float4* __restrict__ rhs, uint32_t n) {
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  float4 f = msn[i];
-  const uint32_t e = incPtr[i + 1];
-  for (uint32_t k = incPtr[i]; k < e; ++k) {
-    const float4 c = contrib[incSlot[k]];
-    f.x += c.x;
-    f.y += c.y;
-    f.z += c.z;
+  // 16 lanes per node: the slot indices and the contribution records of 16 slots are fetched in parallel,
+  // transposed through LDS and added one after the other in slot order by the group's first lane (the
+  // reference's float summation order).  (Measured: 1 lane/node 60 us, 16 lanes + shuffles 39 us, this
+  // 24 us at 100k nodes; visiting nodes in Morton order was slower than index order.)
+  const uint32_t i = (blockIdx.x * kBlock + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+  const bool live = i < n;
+  float4 f = live ? msn[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const uint32_t b = live ? incPtr[i] : 0u, e = live ? incPtr[i + 1] : 0u;
+  __shared__ float4 stage[kBlock];  // one 16-record strip per group, transposed through LDS
+  float4* strip = stage + (threadIdx.x & ~15u);
+  for (uint32_t k0 = b; k0 < e; k0 += 16) {
+    const uint32_t k = k0 + sub;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < e) c = contrib[incSlot[k]];
+    strip[sub] = c;
+    __builtin_amdgcn_wave_barrier();  // a group lives inside one wave; its LDS accesses execute in order
+    if (sub == 0) {
+      const uint32_t m = min(16u, e - k0);
+      for (uint32_t j = 0; j < m; ++j) {
+        const float4 v = strip[j];
+        f.x += v.x;
+        f.y += v.y;
+        f.z += v.z;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
+  if (!live || sub != 0) return;
   if (incPtrD) {  // shape then goal matching: force += float w * double projection (ShapeMatchingConstraint.cpp:58-72,147-161)
     const uint32_t ed = incPtrD[i + 1];
     for (uint32_t k = incPtrD[i]; k < ed; ++k) {
@@ -366,7 +384,10 @@ template <int NV> PIES_DEV void block_reduce_partials(const float* __restrict__ 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float acc[NV];
 #pragma unroll
-  for (int k = 0; k < NV; ++k) acc[k] = (threadIdx.x < nparts) ? part[threadIdx.x * stride + k] : 0.0f;
+  for (int k = 0; k < NV; ++k) acc[k] = 0.0f;
+  for (uint32_t t = threadIdx.x; t < nparts; t += kBlock)  // fixed order: the same sum in every block
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] += part[t * stride + k];
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1)
 #pragma unroll
@@ -654,7 +675,7 @@ void launch_pd_local_tet(hipStream_t st, bool volume, const float4* pos, const u
 }
 void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd) {
   if (nd.n == 0) return;
-  hipLaunchKernelGGL(k_pd_rhs, grid_for(nd.n), dim3(kBlock), 0, st, pd.msn, pd.contrib, pd.incPtr, pd.incSlot, pd.contribD, pd.incPtrD,
+  hipLaunchKernelGGL(k_pd_rhs, dim3((nd.n + 15) / 16), dim3(kBlock), 0, st, pd.msn, pd.contrib, pd.incPtr, pd.incSlot, pd.contribD, pd.incPtrD,
                      pd.incSlotD, nd.pos, pd.nstatic, pd.statp, pd.rhs, nd.n);
 }
 void launch_pd_local_bend(hipStream_t st, const float4* pos, const uint4* ids, const float2* angle_w, float4* contrib, uint32_t count) {

@@ -7,7 +7,9 @@
 //   * per node, the number of surface-triangle incidences (one floor contact each, Solver.cpp:829-834).
 // The factorisation itself is replaced by CG on the device (pd_kernels.hip).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <numeric>
 
 #include "device_util.h"
 
@@ -147,6 +149,7 @@ int pd_build(pies_solver* s) {
   if (int rc = upload(s, incPtr, &d_incPtr)) return rc;
   if (int rc = upload(s, incSlot, &d_incSlot)) return rc;
   if (int rc = upload(s, triCount, &d_tri)) return rc;
+
   cg.rowptr = d_rowptr; cg.col = d_col; cg.val = d_val;
   pd.kdiag = d_kdiag; pd.incPtr = d_incPtr; pd.incSlot = d_incSlot; pd.triCount = d_tri;
   pd.contribD = nullptr; pd.incPtrD = nullptr; pd.incSlotD = nullptr;

@@ -128,7 +128,8 @@ struct pies_solver {
   uint32_t pd_nnz = 0;
   uint32_t goalSlotBase = 0;  // first fp64 contribution slot of the goal constraints
   float pcgTol = 3.0e-7f;     // relative residual ||r|| / ||b|| per coordinate column
-  uint32_t pcgMaxIters = 12;  // CG iterations captured per global step
+  uint32_t pcgMaxIters = 32;  // upper bound of CG iterations per global step
+  uint32_t pcgBudget = 32;    // iterations currently captured in the graph (adapted to what the solves use)
   std::vector<void*> allocations;
   float4* h_stage = nullptr;  // pinned staging for the per-tick position read-back
   size_t h_stage_n = 0;
