@@ -178,20 +178,28 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        sync_t = torch.zeros(1, device="cuda")
+        backend = os.environ.get("PIES_BENCH_BACKEND", "nccl")  # "gloo": test hook for boxes with fewer GPUs than ranks
+        ndev = torch.cuda.device_count()
+        device_index = local_rank % max(1, ndev)
+        torch.cuda.set_device(device_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
+        sync_t = torch.zeros(1, device="cuda" if backend == "nccl" else "cpu")
 
         def barrier():
             dist.all_reduce(sync_t)  # RCCL over xGMI: 4-byte all-reduce as the barrier
             torch.cuda.synchronize()
     else:
+        device_index = local_rank
+
         def barrier():
             pass
 
     dims = tuple(args.dims)
     sched = capi.SCHEDULE_COLOURED if args.schedule == "coloured" else capi.SCHEDULE_EXACT
-    g = build_scene(capi, dims, 1234 + rank, schedule=sched, device=local_rank)
+    g = build_scene(capi, dims, 1234 + rank, schedule=sched, device=device_index)
     g.finalize()
     substeps_per_tick = g.options.timeSubsteps
     proj = scenes.projections_per_substep(g, capi, ITERATIONS)
@@ -236,7 +244,7 @@ def main():
 
     if rank == 0 and world == 1:
         if not args.no_exact and args.schedule == "coloured":
-            e = build_scene(capi, dims, 1234, schedule=capi.SCHEDULE_EXACT, device=local_rank)
+            e = build_scene(capi, dims, 1234, schedule=capi.SCHEDULE_EXACT, device=device_index)
             e.finalize()
             steps = max(2, min(args.steps, 10))
             el = timed_ticks(e, steps, 1, lambda: None)
@@ -245,7 +253,7 @@ def main():
                                      "note": "schedule EXACT: bit-identical to the reference's container-order sweep"}
             e.close()
         if not args.no_extras:
-            result["other_configs"] = extra_configs(local_rank)
+            result["other_configs"] = extra_configs(device_index)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(dims, args.cpu_ticks)
     if rank == 0:

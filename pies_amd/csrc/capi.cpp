@@ -104,29 +104,28 @@ int scene_sync_host(pies_solver* s) {
 static void enqueue_pbd_substep(pies_solver* s, int only, uint32_t* counts, uint64_t* units = nullptr) {
   hipStream_t st = s->stream;
   const float dt = s->opt.fixedTimestepSize / s->opt.timeSubsteps;
-  auto T = [&](int) -> LaunchTimer* { return nullptr; };
   auto C = [&](int k) { if (counts) ++counts[k]; };
   auto ON = [&](int k) { return only < 0 || only == k; };  // profile pass: launch one kernel class only
   auto U = [&](uint64_t u) { if (units) *units += u; };
 
-  if (ON(PIES_KERNEL_PREDICT)) { launch_predict(st, s->nd, dt, s->opt.gravity, T(PIES_KERNEL_PREDICT)); U(s->nd.n); }
+  if (ON(PIES_KERNEL_PREDICT)) { launch_predict(st, s->nd, dt, s->opt.gravity); U(s->nd.n); }
   C(PIES_KERNEL_PREDICT);
   for (uint32_t it = 0; it < s->opt.iterations; ++it) {
     if (!s->releaseHinge)
       for (const Batch& b : s->plan[PIES_POSITION].batches) {
-        if (ON(PIES_KERNEL_POSITION)) { launch_position(st, s->nd.pos, s->d_pc_id, s->d_pc_tw, b.start, b.count, nullptr); U(b.count); }
+        if (ON(PIES_KERNEL_POSITION)) { launch_position(st, s->nd.pos, s->d_pc_id, s->d_pc_tw, b.start, b.count); U(b.count); }
         C(PIES_KERNEL_POSITION);
       }
     for (const Batch& b : s->plan[PIES_DISTANCE].batches) {
-      if (ON(PIES_KERNEL_DISTANCE)) { launch_distance(st, s->nd.pos, s->d_dc_ids, s->d_dc_rw, b.start, b.count, nullptr); U(b.count); }
+      if (ON(PIES_KERNEL_DISTANCE)) { launch_distance(st, s->nd.pos, s->d_dc_ids, s->d_dc_rw, b.start, b.count); U(b.count); }
       C(PIES_KERNEL_DISTANCE);
     }
     for (const Batch& b : s->plan[PIES_TET].batches) {
-      if (ON(PIES_KERNEL_TET)) { launch_tet(st, s->nd.pos, s->d_tc_ids, s->d_tc_q0, s->d_tc_q1, s->d_tc_q2, b.start, b.count, nullptr); U(b.count); }
+      if (ON(PIES_KERNEL_TET)) { launch_tet(st, s->nd.pos, s->d_tc_ids, s->d_tc_q0, s->d_tc_q1, s->d_tc_q2, b.start, b.count); U(b.count); }
       C(PIES_KERNEL_TET);
     }
     for (const Batch& b : s->plan[PIES_BEND].batches) {
-      if (ON(PIES_KERNEL_BEND)) { launch_bend(st, s->nd.pos, s->d_bc_ids, s->d_bc_aw, b.start, b.count, nullptr); U(b.count); }
+      if (ON(PIES_KERNEL_BEND)) { launch_bend(st, s->nd.pos, s->d_bc_ids, s->d_bc_aw, b.start, b.count); U(b.count); }
       C(PIES_KERNEL_BEND);
     }
     if (s->nodeCollisions) {  // Solver.cpp:81-130
@@ -135,10 +134,10 @@ static void enqueue_pbd_substep(pies_solver* s, int only, uint32_t* counts, uint
       if (ON(PIES_KERNEL_COLLIDE)) { nc = launch_collide(st, s->hash, s->nd, s->opt.friction, s->opt.staticFrictionThreshold); U(s->nd.n); }
       if (counts) { counts[PIES_KERNEL_HASH] += nb; counts[PIES_KERNEL_COLLIDE] += nc; }
     }
-    if (ON(PIES_KERNEL_FLOOR)) { launch_floor(st, s->nd, s->opt.floorHeight, nullptr); U(s->nd.n); }
+    if (ON(PIES_KERNEL_FLOOR)) { launch_floor(st, s->nd, s->opt.floorHeight); U(s->nd.n); }
     C(PIES_KERNEL_FLOOR);
   }
-  if (ON(PIES_KERNEL_VELOCITY)) { launch_velocity(st, s->nd, dt, s->opt.damping, s->opt.friction, s->opt.floorHeight, nullptr); U(s->nd.n); }
+  if (ON(PIES_KERNEL_VELOCITY)) { launch_velocity(st, s->nd, dt, s->opt.damping, s->opt.friction, s->opt.floorHeight); U(s->nd.n); }
   C(PIES_KERNEL_VELOCITY);
 }
 
@@ -206,7 +205,6 @@ static int adapt_pcg_budget(pies_solver* s) {
   uint32_t budget = s->pcgBudget;
   if (!converged && budget < s->pcgMaxIters) {
     budget = std::min(s->pcgMaxIters, budget * 2);
-    s->pcgSlack = 0;
   } else if (converged && used + 2 < budget) {
     budget = used + 2;  // keep two iterations of head-room
   }

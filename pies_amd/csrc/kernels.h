@@ -3,28 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
-#include <vector>
 
 namespace pies {
-
-// Optional per-launch device timing: when `timer` is non-null the launch is bracketed by two events
-// recorded on the launch stream.  The kernels of a substep form one dependent chain, so the interval
-// between the two markers is the launch's share of the stream's busy time (dispatch + execution), which
-// is what rocprofv3 --kernel-trace reports as the dispatch duration to within a few percent.
-// (hipExtLaunchKernelGGL's start/stop events crash rocprofv3 7.2's tracer on this pool, so plain
-// in-stream events are used.)
-struct LaunchTimer {
-  std::vector<hipEvent_t> starts, stops;
-  size_t used = 0;
-  uint64_t units = 0;  // constraints / nodes processed by the timed launches
-  bool next(hipEvent_t* a, hipEvent_t* b) {
-    if (used >= starts.size()) return false;
-    *a = starts[used];
-    *b = stops[used];
-    ++used;
-    return true;
-  }
-};
 
 struct NodeArrays {
   float4* pos;    // x, y, z, invMass
@@ -35,25 +15,22 @@ struct NodeArrays {
 };
 
 // Solver.cpp:47-52
-void launch_predict(hipStream_t st, const NodeArrays& nd, float dt, float gravity, LaunchTimer* t);
+void launch_predict(hipStream_t st, const NodeArrays& nd, float dt, float gravity);
 // Solver.cpp:132-136
-void launch_floor(hipStream_t st, const NodeArrays& nd, float floorHeight, LaunchTimer* t);
+void launch_floor(hipStream_t st, const NodeArrays& nd, float floorHeight);
 // Solver.cpp:140-158
-void launch_velocity(hipStream_t st, const NodeArrays& nd, float dt, float damping, float friction, float floorHeight,
-                     LaunchTimer* t);
+void launch_velocity(hipStream_t st, const NodeArrays& nd, float dt, float damping, float friction, float floorHeight);
 
 // One conflict-free batch [start, start+count) of a constraint container.
 // PositionConstraint: Constraints.h:121-129 + Constraints.cpp:58-63
 void launch_position(hipStream_t st, float4* pos, const uint32_t* ids, const float4* target_w, uint32_t start,
-                     uint32_t count, LaunchTimer* t);
+                     uint32_t count);
 // DistanceConstraint: Constraints.h:121-129 + Constraints.cpp:11-37
-void launch_distance(hipStream_t st, float4* pos, const uint2* ids, const float2* rest_w, uint32_t start, uint32_t count,
-                     LaunchTimer* t);
+void launch_distance(hipStream_t st, float4* pos, const uint2* ids, const float2* rest_w, uint32_t start, uint32_t count);
 // TetrahedralConstraint: Constraints.h:121-129 + Constraints.cpp:76-128
 void launch_tet(hipStream_t st, float4* pos, const uint4* ids, const float4* q0, const float4* q1, const float4* q2,
-                uint32_t start, uint32_t count, LaunchTimer* t);
+                uint32_t start, uint32_t count);
 // BendConstraint: Constraints.h:121-129 + Constraints.cpp:312-366
-void launch_bend(hipStream_t st, float4* pos, const uint4* ids, const float2* angle_w, uint32_t start, uint32_t count,
-                 LaunchTimer* t);
+void launch_bend(hipStream_t st, float4* pos, const uint4* ids, const float2* angle_w, uint32_t start, uint32_t count);
 
 }  // namespace pies

@@ -24,17 +24,8 @@ constexpr int kProjBlock = PIES_PROJ_BLOCK;  // projection kernels (64 measured 
 
 static inline dim3 grid_for(uint32_t n, int block) { return dim3((n + block - 1) / block); }
 
-#define PIES_LAUNCH(kernel, block, n_items, st, timer, ...)                                             \
-  do {                                                                                                  \
-    hipEvent_t ev_a__ = nullptr, ev_b__ = nullptr;                                                      \
-    const bool timed__ = (timer) != nullptr && (timer)->next(&ev_a__, &ev_b__);                         \
-    if (timed__) {                                                                                      \
-      (timer)->units += (n_items);                                                                      \
-      (void)hipEventRecord(ev_a__, st);                                                                 \
-    }                                                                                                   \
-    hipLaunchKernelGGL(kernel, grid_for(n_items, block), dim3(block), 0, st, __VA_ARGS__);              \
-    if (timed__) (void)hipEventRecord(ev_b__, st);                                                      \
-  } while (0)
+#define PIES_LAUNCH(kernel, block, n_items, st, ...) \
+  hipLaunchKernelGGL(kernel, grid_for(n_items, block), dim3(block), 0, st, __VA_ARGS__)
 
 // ----------------------------------------------------------------------------------------------
 // Solver.cpp:47-52   prev = pos;  pos += v*dt + (0,-g,0)*dt*dt
@@ -259,40 +250,37 @@ __global__ void __launch_bounds__(kProjBlock) k_bend(float4* __restrict__ pos, c
 }
 
 // ----------------------------------------------------------------------------------------------
-void launch_predict(hipStream_t st, const NodeArrays& nd, float dt, float gravity, LaunchTimer* t) {
+void launch_predict(hipStream_t st, const NodeArrays& nd, float dt, float gravity) {
   if (nd.n == 0) return;
-  PIES_LAUNCH(k_predict, kBlock, nd.n, st, t, nd.pos, nd.prev, nd.vel, nd.n, dt, gravity);
+  PIES_LAUNCH(k_predict, kBlock, nd.n, st, nd.pos, nd.prev, nd.vel, nd.n, dt, gravity);
 }
-void launch_floor(hipStream_t st, const NodeArrays& nd, float floorHeight, LaunchTimer* t) {
+void launch_floor(hipStream_t st, const NodeArrays& nd, float floorHeight) {
   if (nd.n == 0) return;
-  PIES_LAUNCH(k_floor, kBlock, nd.n, st, t, nd.pos, nd.radius, nd.n, floorHeight);
+  PIES_LAUNCH(k_floor, kBlock, nd.n, st, nd.pos, nd.radius, nd.n, floorHeight);
 }
-void launch_velocity(hipStream_t st, const NodeArrays& nd, float dt, float damping, float friction, float floorHeight,
-                     LaunchTimer* t) {
+void launch_velocity(hipStream_t st, const NodeArrays& nd, float dt, float damping, float friction, float floorHeight) {
   if (nd.n == 0) return;
-  PIES_LAUNCH(k_velocity, kBlock, nd.n, st, t, nd.pos, nd.prev, nd.vel, nd.radius, nd.n, dt, damping, friction, floorHeight);
+  PIES_LAUNCH(k_velocity, kBlock, nd.n, st, nd.pos, nd.prev, nd.vel, nd.radius, nd.n, dt, damping, friction, floorHeight);
 }
 void launch_position(hipStream_t st, float4* pos, const uint32_t* ids, const float4* target_w, uint32_t start,
-                     uint32_t count, LaunchTimer* t) {
+                     uint32_t count) {
   if (count == 0) return;
-  PIES_LAUNCH(k_position, kProjBlock, count, st, t, pos, ids, target_w, start, count);
+  PIES_LAUNCH(k_position, kProjBlock, count, st, pos, ids, target_w, start, count);
 }
-void launch_distance(hipStream_t st, float4* pos, const uint2* ids, const float2* rest_w, uint32_t start, uint32_t count,
-                     LaunchTimer* t) {
+void launch_distance(hipStream_t st, float4* pos, const uint2* ids, const float2* rest_w, uint32_t start, uint32_t count) {
   if (count == 0) return;
-  PIES_LAUNCH(k_distance, kProjBlock, count, st, t, pos, ids, rest_w, start, count);
+  PIES_LAUNCH(k_distance, kProjBlock, count, st, pos, ids, rest_w, start, count);
 }
 void launch_tet(hipStream_t st, float4* pos, const uint4* ids, const float4* q0, const float4* q1, const float4* q2,
-                uint32_t start, uint32_t count, LaunchTimer* t) {
+                uint32_t start, uint32_t count) {
   if (count == 0) return;
   static const int variant = [] { const char* e = getenv("PIES_EXP_TET"); return e ? atoi(e) : 0; }();
-  if (variant == 1) { PIES_LAUNCH(k_tet<1>, kProjBlock, count, st, t, pos, ids, q0, q1, q2, start, count); return; }
-  PIES_LAUNCH(k_tet<0>, kProjBlock, count, st, t, pos, ids, q0, q1, q2, start, count);
+  if (variant == 1) { PIES_LAUNCH(k_tet<1>, kProjBlock, count, st, pos, ids, q0, q1, q2, start, count); return; }
+  PIES_LAUNCH(k_tet<0>, kProjBlock, count, st, pos, ids, q0, q1, q2, start, count);
 }
-void launch_bend(hipStream_t st, float4* pos, const uint4* ids, const float2* angle_w, uint32_t start, uint32_t count,
-                 LaunchTimer* t) {
+void launch_bend(hipStream_t st, float4* pos, const uint4* ids, const float2* angle_w, uint32_t start, uint32_t count) {
   if (count == 0) return;
-  PIES_LAUNCH(k_bend, kProjBlock, count, st, t, pos, ids, angle_w, start, count);
+  PIES_LAUNCH(k_bend, kProjBlock, count, st, pos, ids, angle_w, start, count);
 }
 
 }  // namespace pies

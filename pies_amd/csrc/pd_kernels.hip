@@ -50,7 +50,8 @@ __global__ void __launch_bounds__(kBlock) k_pd_predict(float4* __restrict__ pos,
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Local steps.  contrib[slotBase + N*c + i] = w * (A^T B p)_i   (Constraints.h:89-105)
+// Local steps.  contrib[slotBase + i*count + c] = w * (A^T B p)_i   (Constraints.h:89-105); one plane of
+// `count` records per local node index i, so that every store instruction writes 16 contiguous bytes per lane
 // ------------------------------------------------------------------------------------------------------
 // DistanceConstraint: A = B = [[.5,-.5],[-.5,.5]]  =>  A^T B = [[.5,-.5],[-.5,.5]] exactly.
 __global__ void __launch_bounds__(kBlock) k_pd_local_distance(const float4* __restrict__ pos, const uint2* __restrict__ ids,
@@ -74,9 +75,9 @@ __global__ void __launch_bounds__(kBlock) k_pd_local_distance(const float4* __re
   const float p0x = a.x + nd * ux, p0y = a.y + nd * uy, p0z = a.z + nd * uz;  // projected[0]; projected[1] = b
   const float w = rw.y;
   // (AtB p)_0 = .5 p0 + (-.5) p1 ; (AtB p)_1 = (-.5) p0 + .5 p1 ; accumulated from 0 like the reference's product
-  contrib[2 * c + 0] = make_float4(w * ((0.0f + 0.5f * p0x) + -0.5f * b.x), w * ((0.0f + 0.5f * p0y) + -0.5f * b.y),
-                                   w * ((0.0f + 0.5f * p0z) + -0.5f * b.z), 0.0f);
-  contrib[2 * c + 1] = make_float4(w * ((0.0f + -0.5f * p0x) + 0.5f * b.x), w * ((0.0f + -0.5f * p0y) + 0.5f * b.y),
+  contrib[c] = make_float4(w * ((0.0f + 0.5f * p0x) + -0.5f * b.x), w * ((0.0f + 0.5f * p0y) + -0.5f * b.y),
+                           w * ((0.0f + 0.5f * p0z) + -0.5f * b.z), 0.0f);
+  contrib[count + c] = make_float4(w * ((0.0f + -0.5f * p0x) + 0.5f * b.x), w * ((0.0f + -0.5f * p0y) + 0.5f * b.y),
                                    w * ((0.0f + -0.5f * p0z) + 0.5f * b.z), 0.0f);
 }
 
@@ -154,7 +155,7 @@ __global__ void __launch_bounds__(kBlock) k_pd_local_tet(const float4* __restric
     for (int cc = 0; cc < 3; ++cc) out[1 + cc][k] = ((0.0f + qi[0][cc] * Fh[0][k]) + qi[1][cc] * Fh[1][k]) + qi[2][cc] * Fh[2][k];
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) contrib[4 * c + i] = make_float4(w * out[i][0], w * out[i][1], w * out[i][2], 0.0f);
+  for (int i = 0; i < 4; ++i) contrib[i * count + c] = make_float4(w * out[i][0], w * out[i][1], w * out[i][2], 0.0f);
 }
 
 // BendConstraint in PD (Constraints.cpp:312-366): A = B = I, contribution = w * projected_i.
@@ -200,7 +201,7 @@ __global__ void __launch_bounds__(kBlock) k_pd_local_bend(const float4* __restri
   }
   const float w = aw.y;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) contrib[4 * c + i] = make_float4(w * pr[i].x, w * pr[i].y, w * pr[i].z, 0.0f);
+  for (int i = 0; i < 4; ++i) contrib[i * count + c] = make_float4(w * pr[i].x, w * pr[i].y, w * pr[i].z, 0.0f);
 }
 
 // ShapeMatchingConstraint::projectToAuxiliaryVariable (ShapeMatchingConstraint.cpp:96-122), one workgroup

@@ -83,13 +83,13 @@ int pd_build(pies_solver* s) {
     // reference order of setupGlobalForceVector calls: position, distance, tet, volume, bend (Solver.cpp:310-327)
     for (uint32_t c = 0; c < cnt[0]; ++c) fn(s->h_position[c].id, s->slotBase[0] + c);
     for (uint32_t c = 0; c < cnt[1]; ++c)
-      for (uint32_t i = 0; i < 2; ++i) fn(s->h_distance[c].ids[i], s->slotBase[1] + 2 * c + i);
+      for (uint32_t i = 0; i < 2; ++i) fn(s->h_distance[c].ids[i], s->slotBase[1] + i * cnt[1] + c);
     for (uint32_t c = 0; c < cnt[2]; ++c)
-      for (uint32_t i = 0; i < 4; ++i) fn(s->h_tet[c].ids[i], s->slotBase[2] + 4 * c + i);
+      for (uint32_t i = 0; i < 4; ++i) fn(s->h_tet[c].ids[i], s->slotBase[2] + i * cnt[2] + c);
     for (uint32_t c = 0; c < cnt[3]; ++c)
-      for (uint32_t i = 0; i < 4; ++i) fn(s->h_volume[c].ids[i], s->slotBase[3] + 4 * c + i);
+      for (uint32_t i = 0; i < 4; ++i) fn(s->h_volume[c].ids[i], s->slotBase[3] + i * cnt[3] + c);
     for (uint32_t c = 0; c < cnt[4]; ++c)
-      for (uint32_t i = 0; i < 4; ++i) fn(s->h_bend[c].ids[i], s->slotBase[4] + 4 * c + i);
+      for (uint32_t i = 0; i < 4; ++i) fn(s->h_bend[c].ids[i], s->slotBase[4] + i * cnt[4] + c);
   };
   for_each_incidence([&](uint32_t node, uint32_t) { ++incPtr[node + 1]; });
   for (uint32_t i = 0; i < n; ++i) incPtr[i + 1] += incPtr[i];
