@@ -79,7 +79,8 @@ enum { PIES_SCHEDULE_EXACT = 0, PIES_SCHEDULE_COLOURED = 1 };
 
 enum {
   PIES_FLAG_RELEASE_HINGE = 0,  /* Solver::releaseHinge (Solver.h:52, Solver.cpp:59) */
-  PIES_FLAG_NODE_COLLISIONS = 1 /* extension, default 1: 0 skips the PBD node-node pass (Solver.cpp:81-130) */
+  PIES_FLAG_NODE_COLLISIONS = 1,    /* extension, default 1: 0 skips the PBD node-node pass (Solver.cpp:81-130) */
+  PIES_FLAG_TRIANGLE_COLLISIONS = 2 /* extension, default 1: 0 skips the PD point-triangle contacts (Solver.cpp:693-797) */
 };
 
 /* node state selectors for pies_read_nodes / pies_write_nodes */
@@ -166,6 +167,9 @@ int pies_tick_async(pies_solver_t* s);
 int pies_synchronize(pies_solver_t* s);
 /* _simFailed latch (Solver.cpp:26-28,853-856) */
 int pies_failed(pies_solver_t* s, int* failed);
+/* Point-triangle contacts of the last PD substep (Solver::_triCollisions, Solver.h:187), in list order:
+ * 4 node ids each (point a, triangle b c d).  ids may be NULL to query the count. */
+int pies_get_tri_contacts(pies_solver_t* s, uint32_t* ids, uint32_t capacity, uint32_t* count);
 /* Node-node pairs resolved by the PBD collision pass since the last call (statistics). */
 int pies_collision_pairs(pies_solver_t* s, uint64_t* pairs);
 

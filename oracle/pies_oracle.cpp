@@ -468,6 +468,146 @@ struct NodeHash {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Src/CollisionDetection.cpp:14-302 -- point-triangle continuous collision detection.
+// ---------------------------------------------------------------------------------------------
+struct CubicExpression {
+  float cubicCoeff = 0.f, quadCoeff = 0.f, linearCoeff = 0.f, constCoeff = 0.f;
+  float eval(float t) const {  // CollisionDetection.cpp:20-23
+    float t2 = t * t;
+    return cubicCoeff * t2 * t + quadCoeff * t2 + linearCoeff * t + constCoeff;
+  }
+};
+
+// CollisionDetection.cpp:209-221
+static inline void expandTerm(float a0, float b0, float c0, float ad, float bd, float cd, CubicExpression& e) {
+  e.cubicCoeff += ad * bd * cd;
+  e.quadCoeff += ad * bd * c0 + a0 * bd * cd + ad * b0 * cd;
+  e.linearCoeff += ad * b0 * c0 + a0 * bd * c0 + a0 * b0 * cd;
+  e.constCoeff += a0 * b0 * c0;
+}
+
+// Smallest real root of a genuine cubic in [0,1].  The reference asks Eigen::PolynomialSolver<float,3>
+// (companion-matrix eigenvalues, CollisionDetection.cpp:189-204; Eigen is absent) for all roots and keeps
+// the smallest real one in [0,1].  Restated from the definition: [0,1] is split at the critical points of
+// the cubic into monotone pieces, and the first piece whose end values differ in sign (or vanish) is
+// bisected a fixed 32 times.  (A double root that only touches zero is invisible to both approaches up to
+// rounding.)
+static bool cubic_smallest_root01(const CubicExpression& c, float& root) {
+  float cuts[4];
+  int nc = 0;
+  cuts[nc++] = 0.0f;
+  const float a = 3.0f * c.cubicCoeff, b = 2.0f * c.quadCoeff, cc = c.linearCoeff;
+  const float disc = b * b - 4.0f * a * cc;
+  if (disc > 0.0f) {
+    const float sq = std::sqrt(disc);
+    float t0 = (-b - sq) / (2.0f * a), t1 = (-b + sq) / (2.0f * a);
+    if (t0 > t1) { float tmp = t0; t0 = t1; t1 = tmp; }
+    if (t0 > 0.0f && t0 < 1.0f) cuts[nc++] = t0;
+    if (t1 > 0.0f && t1 < 1.0f) cuts[nc++] = t1;
+  }
+  cuts[nc++] = 1.0f;
+  for (int k = 0; k + 1 < nc; ++k) {
+    float lo = cuts[k], hi = cuts[k + 1];
+    float flo = c.eval(lo), fhi = c.eval(hi);
+    if (flo == 0.0f) { root = lo; return true; }
+    if (flo * fhi > 0.0f) continue;
+    if (fhi == 0.0f && k + 2 == nc) { /* root at the right end */ }
+    for (int it = 0; it < 32; ++it) {
+      const float mid = 0.5f * (lo + hi);
+      const float fm = c.eval(mid);
+      if ((flo < 0.0f) == (fm < 0.0f) && fm != 0.0f) { lo = mid; flo = fm; } else { hi = mid; fhi = fm; }
+    }
+    root = hi;
+    return true;
+  }
+  return false;
+}
+
+// CollisionDetection.cpp:143-205
+static bool findRootInInterval(const CubicExpression& c, float& t) {
+  if (c.cubicCoeff == 0.0f) {
+    if (c.quadCoeff == 0.0f) {
+      if (c.linearCoeff == 0.0f) {
+        if (c.constCoeff == 0.0f) { t = 0.0f; return true; }
+        return false;
+      }
+      t = -c.constCoeff / c.linearCoeff;
+      return t >= 0.0f && t <= 1.0f;
+    }
+    float disc = c.linearCoeff * c.linearCoeff - 4.0f * c.quadCoeff * c.constCoeff;
+    if (disc < 0.0f) return false;
+    float sq = std::sqrt(disc);
+    t = (-c.linearCoeff - sq) / (2.0f * c.quadCoeff);
+    if (t > 1.0f) return false;
+    if (t < 0.0f) t = (-c.linearCoeff + sq) / (2.0f * c.quadCoeff);
+    return t >= 0.0f && t <= 1.0f;
+  }
+  return cubic_smallest_root01(c, t);
+}
+
+static inline bool bary_outside(const vec3& b) {  // CollisionDetection.cpp:251-253, 295-297
+  return (0.0 > b.x) || (b.x > 1.0) || (0.0 > b.y) || (b.y > 1.0) || (b.x + b.y > 1.0);
+}
+
+// CollisionDetection.cpp:227-302.  Returns true and t when a contact is reported.
+static bool pointTriangleCCD(const vec3& ap0, const vec3& ab0, const vec3& ac0, const vec3& ap1, const vec3& ab1,
+                             const vec3& ac1, float thresholdDistance, float& tOut) {
+  vec3 n0 = normalize(cross(ab0, ac0));
+  vec3 n1 = normalize(cross(ab1, ac1));
+  float nDotP0 = dot(n0, ap0);
+  float nDotP1 = dot(n1, ap1);
+  if (nDotP0 * nDotP1 >= 0.0f) {
+    if (nDotP1 >= 0.0f && nDotP1 < thresholdDistance) {
+      vec3 bc = inverse(mat3(ab1, ac1, n1)) * ap1;
+      if (bary_outside(bc)) return false;
+      tOut = 0.0f;
+      return true;
+    }
+    return false;
+  }
+  vec3 apd = ap1 - ap0, abd = ab1 - ab0, acd = ac1 - ac0;
+  CubicExpression e;
+  expandTerm(ap0.x, ab0.y, ac0.z, apd.x, abd.y, acd.z, e);
+  expandTerm(-ap0.x, ac0.y, ab0.z, -apd.x, acd.y, abd.z, e);
+  expandTerm(-ab0.x, ap0.y, ac0.z, -abd.x, apd.y, acd.z, e);
+  expandTerm(ab0.x, ac0.y, ap0.z, abd.x, acd.y, apd.z, e);
+  expandTerm(ac0.x, ap0.y, ab0.z, acd.x, apd.y, abd.z, e);
+  expandTerm(-ac0.x, ab0.y, ap0.z, -acd.x, abd.y, apd.z, e);
+  float t;
+  if (!findRootInInterval(e, t)) return false;
+  vec3 apt = ap0 + t * apd, abt = ab0 + t * abd, act = ac0 + t * acd;
+  vec3 n = normalize(cross(abt, act));
+  vec3 bc = inverse(mat3(abt, act, n)) * apt;
+  if (bary_outside(bc)) return false;
+  tOut = t;
+  return true;
+}
+
+// Src/Solver.cpp:639-677 (cap 20) and :942-979 (cap 50): AABB over position and prevPosition of the three
+// nodes, in WORLD units (the computed grid-scaled x1..x3 are unused in the reference).
+static CellRange triRange(const std::vector<Node>& nodes, const std::array<uint32_t, 3>& tri, uint32_t cap) {
+  vec3 mx = nodes[tri[0]].position, mn = nodes[tri[0]].position;
+  for (uint32_t i = 0; i < 3; ++i) {
+    const Node& node = nodes[tri[i]];
+    for (int k = 0; k < 3; ++k) {
+      mx[k] = std::fmax(node.position[k], mx[k]);
+      mx[k] = std::fmax(node.prevPosition[k], mx[k]);
+      mn[k] = std::fmin(node.position[k], mn[k]);
+      mn[k] = std::fmin(node.prevPosition[k], mn[k]);
+    }
+  }
+  CellRange r{};
+  r.minX = static_cast<int64_t>(std::floor(mn.x));
+  r.minY = static_cast<int64_t>(std::floor(mn.y));
+  r.minZ = static_cast<int64_t>(std::floor(mn.z));
+  r.lengthX = static_cast<uint32_t>(std::ceil(mx.x) - r.minX);
+  r.lengthY = static_cast<uint32_t>(std::ceil(mx.y) - r.minY);
+  r.lengthZ = static_cast<uint32_t>(std::ceil(mx.z) - r.minZ);
+  if (r.lengthX > cap || r.lengthY > cap || r.lengthZ > cap) return {};
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
 // fp32 banded Cholesky on a reverse-Cuthill-McKee ordering.  Stands in for
 // Eigen::SimplicialLLT<SparseMatrix<float>> (Src/Solver.cpp:213-215, 258-262, 356): same exact
 // factor-and-solve semantics in fp32; fill-reducing ordering and elimination order differ (Eigen
@@ -573,6 +713,7 @@ struct ora_solver {
   uint32_t constraintId = 0;
   bool releaseHinge = false;
   bool nodeCollisions = true;  // extension: false skips Solver.cpp:81-130 (not a reference option)
+  bool triangleCollisions = true;  // extension: false skips the point-triangle CCD of Solver.cpp:693-797
   bool simFailed = false;
 
   std::vector<Node> nodes;
@@ -607,6 +748,7 @@ struct ora_solver {
   uint32_t previousNodeCount = 0;
   SparseSym stiffness;
   BandedLLT llt;
+  bool orderedWithContacts = false;
   std::vector<float> state, force, msn;  // N x 3, column-major like Eigen::MatrixXf
   uint64_t stat_collision_pairs = 0;
 
@@ -739,22 +881,104 @@ template <class C, int N> static void addForce(const C& c, float* f, size_t n) {
   }
 }
 
-// Src/Solver.cpp:680-875, floor part (:829-834) + merge (:852-874).  Point-triangle CCD candidates
-// (:714-797) are a later row; triCollisions stays empty until then.
+// Src/Solver.cpp:680-875: triangle hash, swept-range candidate search, three point-triangle CCD tests per
+// candidate pair, floor contacts, per-thread lists merged thread by thread.
 void ora_solver::detectPD() {
   staticCollisions.clear();
   triCollisions.clear();
   const uint32_t T = std::max(1u, opt.threadCount);
-  for (uint32_t t = 0; t < T; ++t)
-    for (size_t triId = t; triId < triangles.size(); triId += T)
-      for (uint32_t i = 0; i < 3; ++i) {
-        const Node& node = nodes[triangles[triId][i]];
+  std::unordered_map<CellId, std::vector<uint32_t>, CellHash> triHash;
+  if (triangleCollisions) {  // :693, SpatialHash.h:129-189 with TriCompRange
+    for (uint32_t ti = 0; ti < triangles.size(); ++ti) {
+      CellRange r = triRange(nodes, triangles[ti], 50);
+      for (uint32_t dx = 0; dx < r.lengthX; ++dx)
+        for (uint32_t dy = 0; dy < r.lengthY; ++dy)
+          for (uint32_t dz = 0; dz < r.lengthZ; ++dz) triHash[CellId{r.minX + dx, r.minY + dy, r.minZ + dz}].push_back(ti);
+    }
+  }
+  for (uint32_t t = 0; t < T; ++t) {  // thread t, then the merge keeps this order (:852-874)
+    std::vector<TriCollision> mine;
+    std::vector<StaticCollision> mineStatic;
+    bool failed = false;
+    std::vector<const std::vector<uint32_t>*> buckets;
+    for (size_t triId = t; triId < triangles.size() && !failed; triId += T) {
+      const auto& tri = triangles[triId];
+      if (triangleCollisions) {
+        CellRange range = triRange(nodes, tri, 20);  // sweptTriRange
+        for (uint32_t dx = 0; dx < range.lengthX; ++dx)
+          for (uint32_t dy = 0; dy < range.lengthY; ++dy)
+            for (uint32_t dz = 0; dz < range.lengthZ; ++dz) {
+              auto it = triHash.find(CellId{range.minX + dx, range.minY + dy, range.minZ + dz});
+              if (it != triHash.end()) buckets.push_back(&it->second);
+            }
+        if (buckets.size() > 1000) { failed = true; break; }  // :741-745
+        for (const std::vector<uint32_t>* bucket : buckets) {
+          for (uint32_t other : *bucket) {
+            if (bucket->size() > 1000) { failed = true; break; }  // :751-755
+            const auto& ot = triangles[other];
+            bool common = false;
+            for (uint32_t i = 0; i < 3; ++i)
+              for (uint32_t j = 0; j < 3; ++j)
+                if (tri[i] == ot[j]) common = true;
+            if (common) continue;
+            const Node& nodeB = nodes[ot[0]];
+            const Node& nodeC = nodes[ot[1]];
+            const Node& nodeD = nodes[ot[2]];
+            for (uint32_t i = 0; i < 3; ++i) {
+              const Node& nodeA = nodes[tri[i]];
+              float tt;
+              if (!pointTriangleCCD(nodeA.prevPosition - nodeB.prevPosition, nodeC.prevPosition - nodeB.prevPosition,
+                                    nodeD.prevPosition - nodeB.prevPosition, nodeA.position - nodeB.position,
+                                    nodeC.position - nodeB.position, nodeD.position - nodeB.position,
+                                    opt.collisionThresholdDistance, tt))
+                continue;
+              TriCollision c;  // CollisionConstraint.cpp:67-84
+              c.nodeIds[0] = nodeA.id; c.nodeIds[1] = nodeB.id; c.nodeIds[2] = nodeC.id; c.nodeIds[3] = nodeD.id;
+              c.thickness = opt.collisionThickness;
+              const float A[4][4] = {{0, 0, 0, 0}, {-1, 1, 0, 0}, {-1, 0, 1, 0}, {-1, 0, 0, 1}};
+              for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b) {
+                  float acc = 0.f;
+                  for (int k = 0; k < 4; ++k) acc += A[k][a] * A[k][b];
+                  c.AtA[a][b] = acc;
+                }
+              mine.push_back(c);
+            }
+          }
+          if (failed) break;
+        }
+        buckets.clear();
+        if (failed) break;
+      }
+      for (uint32_t i = 0; i < 3; ++i) {  // :829-834
+        const Node& node = nodes[tri[i]];
         if (node.position.y < opt.floorHeight + opt.collisionThickness) {
           StaticCollision sc;
           sc.nodeId = node.id;
-          staticCollisions.push_back(sc);
+          mineStatic.push_back(sc);
         }
       }
+    }
+    if (failed) { simFailed = true; return; }  // :853-856
+    triCollisions.insert(triCollisions.end(), mine.begin(), mine.end());
+    staticCollisions.insert(staticCollisions.end(), mineStatic.begin(), mineStatic.end());
+  }
+}
+
+// CollisionConstraint.cpp:86-124 (project) / :126-162 (stabilize): normal of triangle b,c,d; push node a out
+static inline bool tri_contact_normal(const std::vector<Node>& nodes, const TriCollision& c, vec3& disp) {
+  const Node& A = nodes[c.nodeIds[0]];
+  const Node& B = nodes[c.nodeIds[1]];
+  const Node& C = nodes[c.nodeIds[2]];
+  const Node& D = nodes[c.nodeIds[3]];
+  vec3 p = A.position - B.position;
+  vec3 n = normalize(cross(C.position - B.position, D.position - B.position));
+  float nDotP = dot(n, p);
+  if (nDotP < c.thickness) {
+    disp = (c.thickness - nDotP) * n;
+    return true;
+  }
+  return false;
 }
 
 // Src/Solver.cpp:162-486
@@ -796,19 +1020,22 @@ void ora_solver::tickPD() {
 
     detectPD();  // :240
 
-    // :242-262  K + C, re-factor
-    SparseSym sys = stiffness;
-    for (const TriCollision& c : triCollisions)
+    // :242-262  C = sum of the collision blocks (tri, edge, static), then K + C, re-factor
+    SparseSym col;
+    col.resize(n);
+    for (const TriCollision& c : triCollisions)  // CollisionConstraint.cpp:164-174
       for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) sys.ref(c.nodeIds[i], c.nodeIds[j]) += c.w * c.AtA[i][j];
-    {
-      // Eigen sums C first, then K + C (:254-259): accumulate collision diagonal separately.
-      std::vector<float> cdiag(n, 0.f);
-      std::vector<char> touched(n, 0);
-      for (const StaticCollision& c : staticCollisions) { cdiag[c.nodeId] += c.w; touched[c.nodeId] = 1; }
-      for (uint32_t i = 0; i < nodeCount; ++i)
-        if (touched[i]) sys.ref(i, i) = stiffness.rows[i].at(i) + cdiag[i];
-    }
+        for (int j = 0; j < 4; ++j) col.ref(c.nodeIds[i], c.nodeIds[j]) += c.w * c.AtA[i][j];
+    for (const StaticCollision& c : staticCollisions) col.ref(c.nodeId, c.nodeId) += c.w;  // :441-445
+    SparseSym sys = stiffness;
+    for (uint32_t i = 0; i < nodeCount; ++i)
+      for (const auto& kv : col.rows[i]) {
+        auto it = stiffness.rows[i].find(kv.first);
+        sys.ref(i, kv.first) = (it != stiffness.rows[i].end() ? it->second : 0.0f) + kv.second;
+      }
+    if (!triCollisions.empty()) llt.order(sys);  // contact blocks fall outside K's band
+    else if (llt.bw == 0 || orderedWithContacts) llt.order(stiffness);
+    orderedWithContacts = !triCollisions.empty();
     if (!llt.factor(sys)) { simFailed = true; return; }
 
     for (uint32_t iter = 0; iter < opt.iterations; ++iter) {
@@ -821,6 +1048,12 @@ void ora_solver::tickPD() {
       for (auto& c : volumeCons) c.project(nodes, c.projected);
       for (auto& c : shapeCons) c.project(nodes);
       for (auto& c : goalCons) c.project();
+      for (auto& c : triCollisions) {  // CollisionConstraint.cpp:86-124
+        for (int k = 0; k < 4; ++k) c.projectedPositions[k] = nodes[c.nodeIds[k]].position;
+        vec3 disp;
+        c.colliding = tri_contact_normal(nodes, c, disp);
+        if (c.colliding) c.projectedPositions[0] += disp;
+      }
       for (auto& c : staticCollisions) {  // CollisionConstraint.cpp:447-455
         const Node& node = nodes[c.nodeId];
         c.projectedPosition = node.position;
@@ -847,6 +1080,19 @@ void ora_solver::tickPD() {
           f[n + id] += c.w * c.proj[3 * i + 1];
           f[2 * n + id] += c.w * c.proj[3 * i + 2];
         }
+      for (auto& c : triCollisions)  // CollisionConstraint.cpp:176-194: A == B, so AtB p = AtA p
+        for (int i = 0; i < 4; ++i) {
+          float ax = 0.f, ay = 0.f, az = 0.f;
+          for (int k = 0; k < 4; ++k) {
+            ax += c.AtA[i][k] * c.projectedPositions[k].x;
+            ay += c.AtA[i][k] * c.projectedPositions[k].y;
+            az += c.AtA[i][k] * c.projectedPositions[k].z;
+          }
+          uint32_t id = c.nodeIds[i];
+          f[id] += c.w * ax;
+          f[n + id] += c.w * ay;
+          f[2 * n + id] += c.w * az;
+        }
       for (auto& c : staticCollisions) {  // CollisionConstraint.cpp:457-463
         f[c.nodeId] += c.w * c.projectedPosition.x;
         f[n + c.nodeId] += c.w * c.projectedPosition.y;
@@ -857,13 +1103,53 @@ void ora_solver::tickPD() {
       for (uint32_t i = 0; i < nodeCount; ++i) nodes[i].position = vec3(state[i], state[n + i], state[2 * n + i]);
     }
 
-    for (uint32_t ci = 0; ci < opt.collisionStabilizationIterations; ++ci)  // :367-383
+    for (uint32_t ci = 0; ci < opt.collisionStabilizationIterations; ++ci) {  // :367-383
+      for (auto& c : triCollisions) {  // CollisionConstraint.cpp:126-162
+        vec3 disp;
+        if (!tri_contact_normal(nodes, c, disp)) continue;
+        Node& A = nodes[c.nodeIds[0]];
+        Node& B = nodes[c.nodeIds[1]];
+        Node& C = nodes[c.nodeIds[2]];
+        Node& D = nodes[c.nodeIds[3]];
+        float wTriSum = B.invMass + C.invMass + D.invMass;
+        float wSum = A.invMass + wTriSum;
+        A.position += disp * A.invMass / wSum;
+        B.position -= disp * wTriSum / wSum;
+        C.position -= disp * wTriSum / wSum;
+        D.position -= disp * wTriSum / wSum;
+        A.prevPosition += disp * A.invMass / wSum;
+        B.prevPosition -= disp * wTriSum / wSum;
+        C.prevPosition -= disp * wTriSum / wSum;
+        D.prevPosition -= disp * wTriSum / wSum;
+      }
       for (auto& c : staticCollisions) nodes[c.nodeId].position = c.projectedPosition;
+    }
 
     for (uint32_t i = 0; i < nodeCount; ++i) {  // :386-395
       Node& node = nodes[i];
       node.velocity = (1.0f - opt.damping) * (node.position - node.prevPosition) / h + h * node.force * node.invMass;
       node.prevPosition = node.position;
+    }
+    for (const TriCollision& col : triCollisions) {  // :431-471
+      Node& a = nodes[col.nodeIds[0]];
+      Node& b = nodes[col.nodeIds[1]];
+      Node& c = nodes[col.nodeIds[2]];
+      Node& d = nodes[col.nodeIds[3]];
+      vec3 avgTriVelocity = (b.velocity + c.velocity + d.velocity) / 3.0f;
+      vec3 nn = normalize(cross(c.position - b.position, d.position - b.position));
+      vec3 relativeVelocity = a.velocity - avgTriVelocity;
+      float vDotN = dot(relativeVelocity, nn);
+      vec3 normVel = vDotN * nn;
+      vec3 perpVel = relativeVelocity - normVel;
+      float friction = opt.friction;
+      if (length(perpVel) < opt.staticFrictionThreshold) friction = 1.0f;
+      float triWSum = b.invMass + c.invMass + d.invMass;
+      float wSum = a.invMass + triWSum;
+      vec3 dv = -friction * perpVel - 1.1f * std::fmin(vDotN, 0.0f) * nn;
+      a.velocity += dv * a.invMass / wSum;
+      b.velocity += -dv * triWSum / wSum;
+      c.velocity += -dv * triWSum / wSum;
+      d.velocity += -dv * triWSum / wSum;
     }
     for (const StaticCollision& c : staticCollisions) {  // :473-484
       Node& node = nodes[c.nodeId];
@@ -985,6 +1271,7 @@ void ora_set_flag(ora_solver* s, int flag, int value) {
   if (flag == 0) s->releaseHinge = value != 0;
   if (flag == 1) s->nodeCollisions = value != 0;
   if (flag == 2) { s->collisionRule = value; s->collisionOrder.clear(); }
+  if (flag == 3) s->triangleCollisions = value != 0;
 }
 int ora_failed(ora_solver* s) { return s->simFailed ? 1 : 0; }
 
@@ -1388,6 +1675,7 @@ uint32_t ora_count(ora_solver* s, int what) {
     case 8: return (uint32_t)s->lines.size();
     case 9: return (uint32_t)s->nodes.size();
     case 10: return (uint32_t)s->staticCollisions.size();
+    case 11: return (uint32_t)s->triCollisions.size();
   }
   return 0;
 }
@@ -1509,6 +1797,19 @@ void ora_tet_rest(const float* x, float* qinv, float* AtA) {
   TetCon c = makeTet(0, 1.0f, n[0], n[1], n[2], n[3], 0.8f, 1.0f);
   for (int col = 0; col < 3; ++col) for (int r = 0; r < 3; ++r) qinv[3 * col + r] = c.Qinv[col][r];
   for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) AtA[4 * i + j] = c.AtA[i][j];
+}
+// CollisionDetection.cpp:227-302; v: ap0, ab0, ac0, ap1, ab1, ac1 (18 floats); returns 1 and *t on contact
+int ora_point_triangle_ccd(const float* v, float threshold, float* t) {
+  auto V = [&](int k) { return vec3(v[3 * k], v[3 * k + 1], v[3 * k + 2]); };
+  float tt = -1.0f;
+  bool hit = pointTriangleCCD(V(0), V(1), V(2), V(3), V(4), V(5), threshold, tt);
+  *t = tt;
+  return hit ? 1 : 0;
+}
+// contacts of the last detection: n x 4 node ids (a, b, c, d)
+void ora_get_tri_collisions(ora_solver* s, uint32_t* out) {
+  size_t k = 0;
+  for (const TriCollision& c : s->triCollisions) for (uint32_t id : c.nodeIds) out[k++] = id;
 }
 // Src/Solver.cpp:877-901 : out = {minX,minY,minZ,lenX,lenY,lenZ}
 void ora_node_range(const float* pos, float radius, float scale, int64_t* out) {

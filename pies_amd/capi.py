@@ -15,7 +15,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(5)
 PBD, PD = 0, 1
 POSITION, DISTANCE, TET, VOLUME, BEND, SHAPE, GOAL, TRIANGLES, LINES, NODES = range(10)
 SCHEDULE_EXACT, SCHEDULE_COLOURED = 0, 1
-FLAG_RELEASE_HINGE, FLAG_NODE_COLLISIONS = 0, 1
+FLAG_RELEASE_HINGE, FLAG_NODE_COLLISIONS, FLAG_TRIANGLE_COLLISIONS = 0, 1, 2
 NODE_POSITION, NODE_PREV_POSITION, NODE_VELOCITY, NODE_RADIUS, NODE_INV_MASS = range(5)
 KERNEL_NAMES = ["predict", "position", "distance", "tet", "bend", "floor", "velocity", "hash", "collide"]
 KERNEL_PREDICT, KERNEL_POSITION, KERNEL_DISTANCE, KERNEL_TET, KERNEL_BEND, KERNEL_FLOOR, KERNEL_VELOCITY = range(7)
@@ -33,6 +33,7 @@ SYMBOLS = [
     "pies_set_pcg", "pies_get_pcg_stats", "pies_collision_pairs", "pies_add_shape_constraint",
     "pies_add_goal_constraint", "pies_set_goal_transform", "pies_add_fixed_regions", "pies_update_fixed_regions",
     "pies_add_linked_regions", "pies_create_shape_matching_box", "pies_create_shape_matching_sheet", "pies_get_group",
+    "pies_get_tri_contacts",
 ]
 
 
@@ -111,6 +112,7 @@ def load():
         "pies_create_shape_matching_box": [vp, pf, u32, u32, u32, f32],
         "pies_create_shape_matching_sheet": [vp, u32, u32, pf, f32, f32],
         "pies_get_group": [vp, i32, u32, pu, u32, pu],
+        "pies_get_tri_contacts": [vp, pu, u32, pu],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -313,6 +315,15 @@ class Solver:
         f = C.c_int()
         self._ck(self._L.pies_failed(self._h, C.byref(f)))
         return bool(f.value)
+
+    @property
+    def tri_collisions(self):
+        n = C.c_uint32()
+        self._ck(self._L.pies_get_tri_contacts(self._h, None, 0, C.byref(n)))
+        out = np.empty((n.value, 4), dtype=np.uint32)
+        if n.value:
+            self._ck(self._L.pies_get_tri_contacts(self._h, _pu(out), n.value, C.byref(n)))
+        return out
 
     @property
     def collision_pairs(self):

@@ -147,6 +147,9 @@ static void enqueue_pd_substep(pies_solver* s) {
   const float h = s->opt.fixedTimestepSize / s->opt.timeSubsteps;
   const PdArrays& pd = s->pd;
   launch_pd_predict(st, s->nd, pd, h, s->opt.floorHeight + s->opt.collisionThickness);
+  const bool tri = pd.tri.nt != 0;
+  if (tri)  // Solver.cpp:240, 245-248: detection, contact list, their blocks of the system matrix
+    launch_tri_detect(st, pd.tri, s->nd, pd.kdiag, pd.cg.cdiag, pd.cg.dinv, s->opt.collisionThresholdDistance, s->opt.collisionThickness);
   for (uint32_t it = 0; it < s->opt.iterations; ++it) {
     // local step (Solver.cpp:270-308): position constraints project to a constant, uploaded once
     launch_pd_local_distance(st, s->nd.pos, s->d_dc_ids, s->d_dc_rw, pd.contrib + s->slotBase[PIES_DISTANCE],
@@ -157,11 +160,22 @@ static void enqueue_pd_substep(pies_solver* s) {
                         (uint32_t)s->h_volume.size());
     launch_pd_local_bend(st, s->nd.pos, s->d_bc_ids, s->d_bc_aw, pd.contrib + s->slotBase[PIES_BEND], (uint32_t)s->h_bend.size());
     launch_pd_local_shape(st, s->nd.pos, pd);                        // goal targets are constants between transform updates
+    if (tri) launch_pd_local_tri(st, pd.tri, s->nd.pos, s->opt.collisionThickness);  // Solver.cpp:298-300
     launch_pd_rhs(st, s->nd, pd);                                    // Solver.cpp:266, 310-349
     launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, s->pcgTol);    // Solver.cpp:356-364
   }
-  if (s->opt.collisionStabilizationIterations > 0) launch_pd_stabilize(st, s->nd, pd);  // :367-383
-  launch_pd_velocity(st, s->nd, pd, h, s->opt.damping, s->opt.gravity, s->opt.friction, s->opt.staticFrictionThreshold);
+  if (tri) {  // :367-383: every stabilisation iteration is a sequential pass over the contacts, then the floor snap
+    for (uint32_t ci = 0; ci < s->opt.collisionStabilizationIterations; ++ci) {
+      launch_tri_stabilize(st, pd.tri, s->nd, s->opt.collisionThickness);
+      launch_pd_stabilize(st, s->nd, pd);
+    }
+    launch_pd_velocity(st, s->nd, pd, h, s->opt.damping, s->opt.gravity, s->opt.friction, s->opt.staticFrictionThreshold, false);
+    launch_tri_friction(st, pd.tri, s->nd, s->opt.friction, s->opt.staticFrictionThreshold);               // :431-471
+    launch_pd_static_friction(st, s->nd, pd, s->opt.friction, s->opt.staticFrictionThreshold);             // :473-484
+  } else {
+    if (s->opt.collisionStabilizationIterations > 0) launch_pd_stabilize(st, s->nd, pd);  // the floor snap is idempotent
+    launch_pd_velocity(st, s->nd, pd, h, s->opt.damping, s->opt.gravity, s->opt.friction, s->opt.staticFrictionThreshold, true);
+  }
 }
 
 static void enqueue_substep(pies_solver* s, uint32_t* counts) {
@@ -216,15 +230,19 @@ static int adapt_pcg_budget(pies_solver* s) {
 }
 
 static int poll_failure(pies_solver* s) {
-  if (s->simFailed || !s->hash.counters || s->device == PIES_DEVICE_NONE) return PIES_OK;
+  uint32_t* flagWord = s->hash.counters ? s->hash.counters + 3 : s->pd.tri.counters ? s->pd.tri.counters + 3 : nullptr;
+  if (s->simFailed || !flagWord || s->device == PIES_DEVICE_NONE) return PIES_OK;
   uint32_t flag = 0;
   HIP_TRY(s, hipSetDevice(s->device));
-  HIP_TRY(s, hipMemcpyAsync(&flag, s->hash.counters + 3, sizeof(flag), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipMemcpyAsync(&flag, flagWord, sizeof(flag), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   if (flag) {  // like the reference's latch (Solver.cpp:741-755, 853-856): tick becomes a no-op
     s->simFailed = true;
-    s->error = flag & 2   ? "collision grid overflow"
-               : flag & 4 ? "more than 2048 nodes overlap one grid cell (runaway pile-up)"
+    s->error = flag & 2    ? "collision grid overflow"
+               : flag & 4  ? "more than 2048 nodes overlap one grid cell (runaway pile-up)"
+               : flag & 16 ? "more than 1000 triangles in one grid cell (the reference's safety latch, Solver.cpp:751-755)"
+               : flag & 32 ? "a triangle's swept bounding box is non-finite or spans more than 4 grid cells per axis"
+               : flag & 64 ? "point-triangle contact list overflow"
                           : "a node left the supported cell range (non-finite position or range > 2 cells)";
   }
   return PIES_OK;
@@ -324,7 +342,10 @@ int pies_get_options(const pies_solver_t* s, pies_options_t* out) {
 
 int pies_set_flag(pies_solver_t* s, int flag, int value) {
   if (!s) return PIES_ERR_INVALID;
-  bool* target = flag == PIES_FLAG_RELEASE_HINGE ? &s->releaseHinge : flag == PIES_FLAG_NODE_COLLISIONS ? &s->nodeCollisions : nullptr;
+  bool* target = flag == PIES_FLAG_RELEASE_HINGE       ? &s->releaseHinge
+                 : flag == PIES_FLAG_NODE_COLLISIONS   ? &s->nodeCollisions
+                 : flag == PIES_FLAG_TRIANGLE_COLLISIONS ? &s->triangleCollisions
+                                                         : nullptr;
   if (!target) return fail(s, PIES_ERR_INVALID, "pies_set_flag: unknown flag");
   if (*target != (value != 0)) {
     *target = value != 0;
@@ -592,6 +613,23 @@ int pies_failed(pies_solver_t* s, int* failed) {
   if (!s || !failed) return PIES_ERR_INVALID;
   if (int rc = poll_failure(s)) return rc;
   *failed = s->simFailed ? 1 : 0;
+  return PIES_OK;
+}
+
+int pies_get_tri_contacts(pies_solver_t* s, uint32_t* ids, uint32_t capacity, uint32_t* count) {
+  if (!s || !count) return PIES_ERR_INVALID;
+  *count = 0;
+  if (s->device == PIES_DEVICE_NONE || !s->pd.tri.counters) return PIES_OK;
+  HIP_TRY(s, hipSetDevice(s->device));
+  uint32_t m = 0;
+  HIP_TRY(s, hipMemcpyAsync(&m, s->pd.tri.counters + 2, sizeof(m), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  *count = m;
+  if (ids && m) {
+    if (m > capacity) return fail(s, PIES_ERR_INVALID, "pies_get_tri_contacts: capacity too small");
+    HIP_TRY(s, hipMemcpyAsync(ids, s->pd.tri.ids, static_cast<size_t>(m) * sizeof(uint4), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+  }
   return PIES_OK;
 }
 

@@ -22,42 +22,15 @@
 // node has moved.  The per-pair arithmetic is the reference's, operation for operation.
 #include <cstdint>
 
+#include "cell_table.h"
 #include "hash_kernels.h"
 
 namespace pies {
 
-#define PIES_DEV __device__ __forceinline__
-
 constexpr int kBlock = 256;
-constexpr uint64_t kEmpty = ~0ull;
-constexpr int kCoordBias = 1 << 20;  // cell coordinates are packed as 21-bit biased integers
 constexpr uint32_t kMaxBucket = 2048;  // nodes overlapping one cell before the simulation is declared failed
 
 static inline dim3 grid_for(uint32_t n) { return dim3((n + kBlock - 1) / kBlock); }
-
-PIES_DEV uint64_t pack_cell(int x, int y, int z) {
-  return (static_cast<uint64_t>(static_cast<uint32_t>(x + kCoordBias)) << 42) |
-         (static_cast<uint64_t>(static_cast<uint32_t>(y + kCoordBias)) << 21) | static_cast<uint64_t>(static_cast<uint32_t>(z + kCoordBias));
-}
-PIES_DEV uint32_t hash_cell(uint64_t k, uint32_t mask) {
-  k ^= k >> 30; k *= 0xbf58476d1ce4e5b9ull;
-  k ^= k >> 27; k *= 0x94d049bb133111ebull;
-  k ^= k >> 31;
-  return static_cast<uint32_t>(k) & mask;
-}
-PIES_DEV int mod3(int v) { int m = v % 3; return m < 0 ? m + 3 : m; }
-
-// read-only lookup (table is static while it is used)
-PIES_DEV uint32_t find_cell(const HashArrays& H, uint64_t key) {
-  uint32_t h = hash_cell(key, H.mask);
-  for (int probe = 0; probe < 4096; ++probe) {
-    const uint64_t k = H.keys[h];
-    if (k == key) return h;
-    if (k == kEmpty) return 0xffffffffu;
-    h = (h + 1) & H.mask;
-  }
-  return 0xffffffffu;
-}
 
 // ---- reset: only the slots the previous build used ------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_hash_reset(HashArrays H) {
@@ -157,14 +130,6 @@ __global__ void __launch_bounds__(kBlock) k_hash_fill(HashArrays H, uint32_t n) 
 }
 
 // ---- sort: ascending node index inside every bucket and every group (rank sort, one wave per cell) ---
-PIES_DEV void rank_sort(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t start, uint32_t c, int lane) {
-  for (uint32_t e = lane; e < c; e += 64) {
-    const uint32_t v = in[start + e];
-    uint32_t rank = 0;
-    for (uint32_t f = 0; f < c; ++f) rank += (in[start + f] < v) ? 1u : 0u;
-    out[start + rank] = v;
-  }
-}
 __global__ void __launch_bounds__(kBlock) k_hash_sort(HashArrays H) {
   if (H.counters[3]) return;  // failed: the host latches _simFailed
   const uint32_t used = H.counters[0];
@@ -208,7 +173,7 @@ __global__ void __launch_bounds__(kBlock) k_collide(HashArrays H, float4* pos4, 
       for (uint32_t dx = 0; dx < lx; ++dx)
         for (uint32_t dy = 0; dy < ly; ++dy)
           for (uint32_t dz = 0; dz < lz; ++dz) {
-            const uint32_t cs = find_cell(H, pack_cell(rg.x + (int)dx, rg.y + (int)dy, rg.z + (int)dz));
+            const uint32_t cs = find_cell(H.keys, H.mask, pack_cell(rg.x + (int)dx, rg.y + (int)dy, rg.z + (int)dz));
             if (cs == 0xffffffffu) continue;
             const uint32_t bs = H.start[cs], bc = H.cnt[cs];
             for (uint32_t base = 0; base < bc; base += 64) {

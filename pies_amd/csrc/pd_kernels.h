@@ -4,6 +4,7 @@
 #include <cstdint>
 
 #include "kernels.h"
+#include "tri_kernels.h"
 
 namespace pies {
 
@@ -19,6 +20,9 @@ struct CgArrays {
   float* dinv;   // 1 / diag(K + C)
   float4 *r, *z, *p[2], *ap;
   float *partI, *partA, *partB, *partBnext;
+  // point-triangle contacts of the substep (null when the pipeline is off): per node, ascending (contact<<2 | local)
+  const uint32_t *tIncCnt, *tIncStart, *tInc;
+  const uint4* tIds;
   float* scal;   // rz[2][3], bb[3], iterations
   float* stats;  // max relative residual^2 over the tick's solves, max iterations, number of solves
 };
@@ -46,6 +50,8 @@ struct PdArrays {
   float4* contrib;
   const uint32_t* incPtr;
   const uint32_t* incSlot;
+  const float4* tContrib;  // 4 per contact: w * (AtA p)_i
+  TriArrays tri;
   const uint32_t* triCount;
   uint32_t* nstatic;
   const float* kdiag;
@@ -61,7 +67,10 @@ void launch_pd_local_shape(hipStream_t st, const float4* pos, const PdArrays& pd
 void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd);
 void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, int maxIters, float tol);
 void launch_pd_stabilize(hipStream_t st, const NodeArrays& nd, const PdArrays& pd);
+// staticFriction = false leaves the floor friction (Solver.cpp:473-484) to launch_pd_static_friction, which the
+// reference runs after the point-triangle friction
 void launch_pd_velocity(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float h, float damping, float gravity,
-                        float friction, float staticThreshold);
+                        float friction, float staticThreshold, bool staticFriction);
+void launch_pd_static_friction(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float friction, float staticThreshold);
 
 }  // namespace pies

@@ -315,7 +315,9 @@ __global__ void __launch_bounds__(kBlock) k_pd_rhs(const float4* __restrict__ ms
                                                    const double4* __restrict__ contribD, const uint32_t* __restrict__ incPtrD,
                                                    const uint32_t* __restrict__ incSlotD, const float4* __restrict__ pos,
                                                    const uint32_t* __restrict__ nstatic, float4* __restrict__ statp,
-                                                   float4* __restrict__ rhs, uint32_t n) {
+                                                   float4* __restrict__ rhs, const uint32_t* __restrict__ tIncCnt,
+                                                   const uint32_t* __restrict__ tIncStart, const uint32_t* __restrict__ tInc,
+                                                   const float4* __restrict__ tContrib, uint32_t n) {
   // 16 lanes per node: the slot indices and the contribution records of 16 slots are fetched in parallel,
   // transposed through LDS and added one after the other in slot order by the group's first lane (the
   // reference's float summation order).  (Measured: 1 lane/node 60 us, 16 lanes + shuffles 39 us, this
@@ -351,6 +353,19 @@ __global__ void __launch_bounds__(kBlock) k_pd_rhs(const float4* __restrict__ ms
       f.x = static_cast<float>(static_cast<double>(f.x) + c.w * c.x);
       f.y = static_cast<float>(static_cast<double>(f.y) + c.w * c.y);
       f.z = static_cast<float>(static_cast<double>(f.z) + c.w * c.z);
+    }
+  }
+  if (tIncCnt) {  // point-triangle contacts, in contact-list order (Solver.cpp:337-340)
+    const uint32_t tc = tIncCnt[i];
+    if (tc) {
+      const uint32_t ts = tIncStart[i];
+      for (uint32_t k = 0; k < tc; ++k) {
+        const uint32_t v = tInc[ts + k];
+        const float4 c = tContrib[4 * (v >> 2) + (v & 3u)];
+        f.x += c.x;
+        f.y += c.y;
+        f.z += c.z;
+      }
     }
   }
   const uint32_t ns = nstatic[i];
@@ -426,6 +441,32 @@ PIES_DEV bool all_converged(const float rr[3], const float bb[3], float tol2) {
   return rr[0] <= tol2 * bb[0] && rr[1] <= tol2 * bb[1] && rr[2] <= tol2 * bb[2];
 }
 
+// Off-diagonal part of the contact blocks w*AtA for row i (the diagonal 3w / w is in cdiag): the point couples
+// to the three triangle nodes with -w, each triangle node to the point with -w.  FETCH(j) returns the vector at j.
+template <class Fetch> PIES_DEV void contact_row(const CgArrays& A, uint32_t i, Fetch fetch, float& sx, float& sy, float& sz) {
+  if (!A.tIncCnt) return;
+  const uint32_t tc = A.tIncCnt[i];
+  if (!tc) return;
+  const uint32_t ts = A.tIncStart[i];
+  for (uint32_t k = 0; k < tc; ++k) {
+    const uint32_t v = A.tInc[ts + k];
+    const uint4 id = A.tIds[v >> 2];
+    if ((v & 3u) == 0u) {
+      const uint32_t nb[3] = {id.y, id.z, id.w};
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        float px, py, pz;
+        fetch(nb[q], px, py, pz);
+        sx = fmaf(-kTriContactW, px, sx); sy = fmaf(-kTriContactW, py, sy); sz = fmaf(-kTriContactW, pz, sz);
+      }
+    } else {
+      float px, py, pz;
+      fetch(id.x, px, py, pz);
+      sx = fmaf(-kTriContactW, px, sx); sy = fmaf(-kTriContactW, py, sy); sz = fmaf(-kTriContactW, pz, sz);
+    }
+  }
+}
+
 // r = f - (K + C) x ; z = D^-1 r ; partB = {rz, rr} ; partI = {bb}.   16 lanes per row.
 __global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __restrict__ x, const float4* __restrict__ f) {
   const uint32_t group = (blockIdx.x * kBlock + threadIdx.x) >> 4, sub = threadIdx.x & 15;
@@ -448,6 +489,7 @@ __global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __
       sz += __shfl_xor(sz, off, 16);
     }
     if (sub == 0) {
+      contact_row(A, i, [&](uint32_t j, float& px, float& py, float& pz) { const float4 v = x[j]; px = v.x; py = v.y; pz = v.z; }, sx, sy, sz);
       const float4 xi = x[i], fi = f[i];
       const float cd = A.cdiag[i], di = A.dinv[i];
       const float rx = fi.x - fmaf(cd, xi.x, sx), ry = fi.y - fmaf(cd, xi.y, sy), rz = fi.z - fmaf(cd, xi.z, sz);
@@ -525,6 +567,14 @@ __global__ void __launch_bounds__(kBlock) k_cg_ap(CgArrays A, int k, float tol2)
       sz += __shfl_xor(sz, off, 16);
     }
     if (sub == 0) {
+      contact_row(A, i, [&](uint32_t j, float& qx, float& qy, float& qz) {
+        const float4 zj = A.z[j];
+        qx = zj.x; qy = zj.y; qz = zj.z;
+        if (k > 0) {
+          const float4 pj = pold[j];
+          qx = fmaf(beta[0], pj.x, qx); qy = fmaf(beta[1], pj.y, qy); qz = fmaf(beta[2], pj.z, qz);
+        }
+      }, sx, sy, sz);
       const float4 zi = A.z[i];
       float px = zi.x, py = zi.y, pz = zi.z;
       if (k > 0) {
@@ -634,7 +684,7 @@ __global__ void __launch_bounds__(kBlock) k_pd_stabilize(float4* __restrict__ po
 __global__ void __launch_bounds__(kBlock) k_pd_velocity(const float4* __restrict__ pos, float4* __restrict__ prev,
                                                         float4* __restrict__ vel, const uint32_t* __restrict__ nstatic, uint32_t n,
                                                         float h, float damping, float gravity, float friction,
-                                                        float staticThreshold) {
+                                                        float staticThreshold, bool staticFriction) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const float4 p = pos[i];
@@ -645,7 +695,7 @@ __global__ void __launch_bounds__(kBlock) k_pd_velocity(const float4* __restrict
   float vx = (k * (p.x - q.x)) / h + (h * fx) * p.w;
   float vy = (k * (p.y - q.y)) / h + (h * fy) * p.w;
   float vz = (k * (p.z - q.z)) / h + (h * fz) * p.w;
-  const uint32_t ns = nstatic[i];
+  const uint32_t ns = staticFriction ? nstatic[i] : 0u;
   for (uint32_t c = 0; c < ns; ++c) {
     const float px = vx, pz = vz;  // perpVel = (vx, 0, vz)
     float fr = friction;
@@ -656,6 +706,25 @@ __global__ void __launch_bounds__(kBlock) k_pd_velocity(const float4* __restrict
   }
   prev[i] = make_float4(p.x, p.y, p.z, 0.f);
   vel[i] = make_float4(vx, vy, vz, 0.f);
+}
+
+// Solver.cpp:473-484 on its own (runs after the point-triangle friction when that pipeline is on)
+__global__ void __launch_bounds__(kBlock) k_pd_static_friction(float4* __restrict__ vel, const uint32_t* __restrict__ nstatic, uint32_t n,
+                                                               float friction, float staticThreshold) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t ns = nstatic[i];
+  if (!ns) return;
+  float4 v = vel[i];
+  for (uint32_t c = 0; c < ns; ++c) {
+    const float px = v.x, pz = v.z;
+    float fr = friction;
+    if (sqrtf(px * px + 0.0f * 0.0f + pz * pz) < staticThreshold) fr = 1.0f;
+    v.x += -fr * px;
+    v.y += -fr * 0.0f;
+    v.z += -fr * pz;
+  }
+  vel[i] = v;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -677,7 +746,7 @@ void launch_pd_local_tet(hipStream_t st, bool volume, const float4* pos, const u
 void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd) {
   if (nd.n == 0) return;
   hipLaunchKernelGGL(k_pd_rhs, dim3((nd.n + 15) / 16), dim3(kBlock), 0, st, pd.msn, pd.contrib, pd.incPtr, pd.incSlot, pd.contribD, pd.incPtrD,
-                     pd.incSlotD, nd.pos, pd.nstatic, pd.statp, pd.rhs, nd.n);
+                     pd.incSlotD, nd.pos, pd.nstatic, pd.statp, pd.rhs, pd.cg.tIncCnt, pd.cg.tIncStart, pd.cg.tInc, pd.tContrib, nd.n);
 }
 void launch_pd_local_bend(hipStream_t st, const float4* pos, const uint4* ids, const float2* angle_w, float4* contrib, uint32_t count) {
   if (count == 0) return;
@@ -708,10 +777,14 @@ void launch_pd_stabilize(hipStream_t st, const NodeArrays& nd, const PdArrays& p
   hipLaunchKernelGGL(k_pd_stabilize, grid_for(nd.n), dim3(kBlock), 0, st, nd.pos, pd.statp, pd.nstatic, nd.n);
 }
 void launch_pd_velocity(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float h, float damping, float gravity,
-                        float friction, float staticThreshold) {
+                        float friction, float staticThreshold, bool staticFriction) {
   if (nd.n == 0) return;
   hipLaunchKernelGGL(k_pd_velocity, grid_for(nd.n), dim3(kBlock), 0, st, nd.pos, nd.prev, nd.vel, pd.nstatic, nd.n, h, damping, gravity,
-                     friction, staticThreshold);
+                     friction, staticThreshold, staticFriction);
+}
+void launch_pd_static_friction(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float friction, float staticThreshold) {
+  if (nd.n == 0) return;
+  hipLaunchKernelGGL(k_pd_static_friction, grid_for(nd.n), dim3(kBlock), 0, st, nd.vel, pd.nstatic, nd.n, friction, staticThreshold);
 }
 
 }  // namespace pies

@@ -191,6 +191,54 @@ int pd_build(pies_solver* s) {
   if (int rc = dev_alloc(s, kCgBlocks * 6, &cg.partBnext, true)) return rc;
   if (int rc = dev_alloc(s, 16, &cg.scal, true)) return rc;
   if (int rc = dev_alloc(s, 4, &cg.stats, true)) return rc;
+  // ---- point-triangle contact pipeline (Solver.cpp:680-875) ------------------------------------------------
+  pd.tri = TriArrays{};
+  cg.tIncCnt = cg.tIncStart = cg.tInc = nullptr;
+  cg.tIds = nullptr;
+  pd.tContrib = nullptr;
+  const uint32_t nt = static_cast<uint32_t>(s->h_triangles.size() / 3);
+  if (s->triangleCollisions && nt) {
+    TriArrays& T = pd.tri;
+    T.nt = nt;
+    T.threadCount = std::max(1u, s->opt.threadCount);
+    std::vector<uint32_t> order;  // the reference's merge order: thread t takes triangles t, t+T, ... (Solver.cpp:714,852)
+    order.reserve(nt);
+    for (uint32_t t = 0; t < T.threadCount; ++t)
+      for (uint32_t tri = t; tri < nt; tri += T.threadCount) order.push_back(tri);
+    uint32_t *d_tris, *d_order;
+    if (int rc = upload(s, s->h_triangles, &d_tris)) return rc;
+    if (int rc = upload(s, order, &d_order)) return rc;
+    T.tris = d_tris;
+    T.triOrder = d_order;
+    uint32_t cap = 1024;
+    while (cap < 2ull * kTriMaxEntries * nt && cap < (1u << 28)) cap <<= 1;
+    T.capacity = cap;
+    T.mask = cap - 1;
+    T.maxContacts = 16 * nt + 1024;
+    if (int rc = dev_alloc(s, cap, &T.keys)) return rc;
+    HIP_TRY(s, hipMemsetAsync(T.keys, 0xFF, static_cast<size_t>(cap) * sizeof(uint64_t), s->stream));
+    if (int rc = dev_alloc(s, cap, &T.cnt, true)) return rc;
+    if (int rc = dev_alloc(s, cap, &T.start, true)) return rc;
+    if (int rc = dev_alloc(s, cap, &T.fill, true)) return rc;
+    if (int rc = dev_alloc(s, static_cast<size_t>(kTriMaxEntries) * nt, &T.used, true)) return rc;
+    if (int rc = dev_alloc(s, 8, &T.counters, true)) return rc;
+    if (int rc = dev_alloc(s, static_cast<size_t>(kTriMaxEntries) * nt, &T.triSlot, true)) return rc;
+    if (int rc = dev_alloc(s, nt, &T.rng, true)) return rc;
+    if (int rc = dev_alloc(s, static_cast<size_t>(kTriMaxEntries) * nt, &T.bucket, true)) return rc;
+    if (int rc = dev_alloc(s, static_cast<size_t>(kTriMaxEntries) * nt, &T.bucketSorted, true)) return rc;
+    if (int rc = dev_alloc(s, nt, &T.cntTri, true)) return rc;
+    if (int rc = dev_alloc(s, nt, &T.offTri, true)) return rc;
+    if (int rc = dev_alloc(s, T.maxContacts, &T.ids, true)) return rc;
+    if (int rc = dev_alloc(s, 4ull * T.maxContacts, &T.contrib, true)) return rc;
+    if (int rc = dev_alloc(s, n, &T.incCnt, true)) return rc;
+    if (int rc = dev_alloc(s, n, &T.incStart, true)) return rc;
+    if (int rc = dev_alloc(s, n, &T.incFill, true)) return rc;
+    if (int rc = dev_alloc(s, n, &T.usedNodes, true)) return rc;
+    if (int rc = dev_alloc(s, 4ull * T.maxContacts, &T.inc, true)) return rc;
+    if (int rc = dev_alloc(s, 4ull * T.maxContacts, &T.incSorted, true)) return rc;
+    cg.tIncCnt = T.incCnt; cg.tIncStart = T.incStart; cg.tInc = T.incSorted; cg.tIds = T.ids;
+    pd.tContrib = T.contrib;
+  }
   if (!contrib0.empty())
     HIP_TRY(s, hipMemcpyAsync(pd.contrib + s->slotBase[0], contrib0.data(), contrib0.size() * sizeof(float4),
                               hipMemcpyHostToDevice, s->stream));

@@ -81,6 +81,7 @@ struct pies_solver {
 
   bool releaseHinge = false;
   bool nodeCollisions = true;
+  bool triangleCollisions = true;  // PD point-triangle CCD contacts (Solver.cpp:693-797); extension flag to switch off
   bool simFailed = false;
   int schedule = PIES_SCHEDULE_EXACT;
 

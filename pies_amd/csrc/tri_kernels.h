@@ -1,0 +1,46 @@
+// Point-triangle collision pipeline of the PD substep (reference: Src/Solver.cpp:680-875 detection,
+// Src/CollisionDetection.cpp:227-302 CCD, Src/CollisionConstraint.cpp:67-194 constraint) -- launch wrappers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "kernels.h"
+
+namespace pies {
+
+constexpr uint32_t kTriMaxCellsPerAxis = 4;                     // a triangle's swept AABB may span 4^3 world-unit cells
+constexpr uint32_t kTriMaxEntries = kTriMaxCellsPerAxis * kTriMaxCellsPerAxis * kTriMaxCellsPerAxis;
+constexpr float kTriContactW = 10000.0f;                        // PointTriangleCollisionConstraint::w (CollisionConstraint.h:32)
+
+struct TriArrays {
+  uint32_t nt;           // surface triangles (0 = pipeline disabled)
+  uint32_t threadCount;  // SolverOptions::threadCount: contacts are listed thread by thread (Solver.cpp:714,852)
+  const uint32_t* tris;      // 3 node ids per triangle
+  const uint32_t* triOrder;  // triangles in the order the reference's merge visits them
+  // triangle grid (exact-key cell table, world-unit cells)
+  uint32_t capacity, mask;
+  uint64_t* keys;
+  uint32_t *cnt, *start, *fill, *used;
+  uint32_t* counters;  // [0] used cells [1] bucket entries [2] contacts [3] failure flag [4] nodes with contacts [5] incidences
+  uint32_t* triSlot;   // nt x kTriMaxEntries
+  int4* rng;           // per triangle: min cell, packed lengths
+  uint32_t *bucket, *bucketSorted;
+  // contacts of the current substep, in the reference's list order
+  uint32_t maxContacts;
+  uint32_t *cntTri, *offTri;
+  uint4* ids;        // a, b, c, d
+  float4* contrib;   // 4 per contact: w * (AtA p)_i
+  // per node: the contacts it takes part in, ascending (contact << 2 | local index)
+  uint32_t *incCnt, *incStart, *incFill, *usedNodes, *inc, *incSorted;
+};
+
+struct PdArrays;
+
+// after the predict kernel: grid build, detection (count, scan, fill), per-node incidence + diagonal; returns launches
+uint32_t launch_tri_detect(hipStream_t st, const TriArrays& T, const NodeArrays& nd, const float* kdiag, float* cdiag, float* dinv,
+                           float threshold, float thickness);
+void launch_pd_local_tri(hipStream_t st, const TriArrays& T, const float4* pos, float thickness);
+void launch_tri_stabilize(hipStream_t st, const TriArrays& T, const NodeArrays& nd, float thickness);
+void launch_tri_friction(hipStream_t st, const TriArrays& T, const NodeArrays& nd, float friction, float staticThreshold);
+
+}  // namespace pies

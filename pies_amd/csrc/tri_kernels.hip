@@ -1,0 +1,485 @@
+// Point-triangle collisions of the Projective-Dynamics substep.
+//
+//   detection  Src/Solver.cpp:680-875: every surface triangle is inserted into a world-unit cell grid over the
+//              AABB of its nodes' current and previous positions (TriCompRange :942-979, sweptTriRange :639-677);
+//              for every triangle, every triangle without a common node found in the cells of its swept range
+//              is tested with three point-triangle CCDs (CollisionDetection.cpp:227-302).  Contacts are listed
+//              in the reference's order: thread by thread (triangle id modulo threadCount), triangle by
+//              triangle, cell by cell (dx,dy,dz), bucket entry by entry (ascending triangle id), point by
+//              point -- including the duplicates a pair produces when it shares several cells.
+//   constraint CollisionConstraint.cpp:67-194: differential coordinates w.r.t. the point (A = B), projection
+//              along the triangle normal, w = 1e4; its 4x4 block is added to the system matrix through a
+//              per-node list of contacts (diagonal into cdiag, off-diagonals applied inside the SpMV).
+//   sequential parts (stabilisation :367-383 via CollisionConstraint.cpp:126-162, friction Solver.cpp:431-471)
+//              are order dependent Gauss-Seidel passes over the contact list.  They run in ONE wavefront that
+//              takes 64 contacts at a time, finds the dependency levels inside the window (two contacts
+//              conflict when they share a node) and executes level after level -- the sequential result.
+#include <cstdint>
+
+#include "cell_table.h"
+#include "tri_kernels.h"
+
+namespace pies {
+
+constexpr int kBlock = 256;
+static inline dim3 grid_for(uint32_t n) { return dim3((n + kBlock - 1) / kBlock); }
+
+struct F3 {
+  float x, y, z;
+};
+PIES_DEV F3 f3(float x, float y, float z) { return {x, y, z}; }
+PIES_DEV F3 operator+(F3 a, F3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+PIES_DEV F3 operator-(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+PIES_DEV F3 operator*(F3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+PIES_DEV F3 operator*(float s, F3 a) { return {s * a.x, s * a.y, s * a.z}; }
+PIES_DEV F3 operator/(F3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+PIES_DEV F3 neg(F3 a) { return {-a.x, -a.y, -a.z}; }
+PIES_DEV float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PIES_DEV F3 cross(F3 a, F3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+PIES_DEV F3 normalize(F3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+PIES_DEV F3 xyz(const float4& v) { return {v.x, v.y, v.z}; }
+
+// inverse(mat3(c0, c1, c2)) * v with glm's cofactor formula (columns c0, c1, c2)
+PIES_DEV F3 solve_columns(F3 c0, F3 c1, F3 c2, F3 v) {
+  const float m00 = c0.x, m01 = c0.y, m02 = c0.z, m10 = c1.x, m11 = c1.y, m12 = c1.z, m20 = c2.x, m21 = c2.y, m22 = c2.z;
+  const float det = +m00 * (m11 * m22 - m21 * m12) - m10 * (m01 * m22 - m21 * m02) + m20 * (m01 * m12 - m11 * m02);
+  const float ood = 1.0f / det;
+  const float i00 = +(m11 * m22 - m21 * m12) * ood, i10 = -(m10 * m22 - m20 * m12) * ood, i20 = +(m10 * m21 - m20 * m11) * ood;
+  const float i01 = -(m01 * m22 - m21 * m02) * ood, i11 = +(m00 * m22 - m20 * m02) * ood, i21 = -(m00 * m21 - m20 * m01) * ood;
+  const float i02 = +(m01 * m12 - m11 * m02) * ood, i12 = -(m00 * m12 - m10 * m02) * ood, i22 = +(m00 * m11 - m10 * m01) * ood;
+  return {i00 * v.x + i10 * v.y + i20 * v.z, i01 * v.x + i11 * v.y + i21 * v.z, i02 * v.x + i12 * v.y + i22 * v.z};
+}
+PIES_DEV bool bary_outside(F3 b) { return (0.0f > b.x) || (b.x > 1.0f) || (0.0f > b.y) || (b.y > 1.0f) || (b.x + b.y > 1.0f); }
+
+struct Cubic {
+  float c3, c2, c1, c0;
+};
+PIES_DEV float eval(const Cubic& c, float t) {
+  const float t2 = t * t;
+  return c.c3 * t2 * t + c.c2 * t2 + c.c1 * t + c.c0;
+}
+PIES_DEV void expand_term(float a0, float b0, float c0, float ad, float bd, float cd, Cubic& e) {  // CollisionDetection.cpp:209-221
+  e.c3 += ad * bd * cd;
+  e.c2 += ad * bd * c0 + a0 * bd * cd + ad * b0 * cd;
+  e.c1 += ad * b0 * c0 + a0 * bd * c0 + a0 * b0 * cd;
+  e.c0 += a0 * b0 * c0;
+}
+// smallest real root of a genuine cubic in [0,1]: monotone pieces between the critical points, first sign
+// change bisected 32 times (stands in for the companion-matrix eigenvalues of CollisionDetection.cpp:189-204)
+PIES_DEV bool cubic_smallest_root01(const Cubic& c, float& root) {
+  float cuts[4];
+  int nc = 0;
+  cuts[nc++] = 0.0f;
+  const float a = 3.0f * c.c3, b = 2.0f * c.c2, cc = c.c1;
+  const float disc = b * b - 4.0f * a * cc;
+  if (disc > 0.0f) {
+    const float sq = sqrtf(disc);
+    float t0 = (-b - sq) / (2.0f * a), t1 = (-b + sq) / (2.0f * a);
+    if (t0 > t1) { const float tmp = t0; t0 = t1; t1 = tmp; }
+    if (t0 > 0.0f && t0 < 1.0f) cuts[nc++] = t0;
+    if (t1 > 0.0f && t1 < 1.0f) cuts[nc++] = t1;
+  }
+  cuts[nc++] = 1.0f;
+  for (int k = 0; k + 1 < nc; ++k) {
+    float lo = cuts[k], hi = cuts[k + 1];
+    float flo = eval(c, lo), fhi = eval(c, hi);
+    if (flo == 0.0f) { root = lo; return true; }
+    if (flo * fhi > 0.0f) continue;
+    for (int it = 0; it < 32; ++it) {
+      const float mid = 0.5f * (lo + hi);
+      const float fm = eval(c, mid);
+      if ((flo < 0.0f) == (fm < 0.0f) && fm != 0.0f) { lo = mid; flo = fm; } else { hi = mid; fhi = fm; }
+    }
+    root = hi;
+    return true;
+  }
+  return false;
+}
+PIES_DEV bool find_root(const Cubic& c, float& t) {  // CollisionDetection.cpp:143-205
+  if (c.c3 == 0.0f) {
+    if (c.c2 == 0.0f) {
+      if (c.c1 == 0.0f) {
+        if (c.c0 == 0.0f) { t = 0.0f; return true; }
+        return false;
+      }
+      t = -c.c0 / c.c1;
+      return t >= 0.0f && t <= 1.0f;
+    }
+    const float disc = c.c1 * c.c1 - 4.0f * c.c2 * c.c0;
+    if (disc < 0.0f) return false;
+    const float sq = sqrtf(disc);
+    t = (-c.c1 - sq) / (2.0f * c.c2);
+    if (t > 1.0f) return false;
+    if (t < 0.0f) t = (-c.c1 + sq) / (2.0f * c.c2);
+    return t >= 0.0f && t <= 1.0f;
+  }
+  return cubic_smallest_root01(c, t);
+}
+// CollisionDetection.cpp:227-302
+PIES_DEV bool point_triangle_ccd(F3 ap0, F3 ab0, F3 ac0, F3 ap1, F3 ab1, F3 ac1, float threshold) {
+  const F3 n0 = normalize(cross(ab0, ac0)), n1 = normalize(cross(ab1, ac1));
+  const float d0 = dot(n0, ap0), d1 = dot(n1, ap1);
+  if (d0 * d1 >= 0.0f) {
+    if (d1 >= 0.0f && d1 < threshold) return !bary_outside(solve_columns(ab1, ac1, n1, ap1));
+    return false;
+  }
+  const F3 apd = ap1 - ap0, abd = ab1 - ab0, acd = ac1 - ac0;
+  Cubic e{0.f, 0.f, 0.f, 0.f};
+  expand_term(ap0.x, ab0.y, ac0.z, apd.x, abd.y, acd.z, e);
+  expand_term(-ap0.x, ac0.y, ab0.z, -apd.x, acd.y, abd.z, e);
+  expand_term(-ab0.x, ap0.y, ac0.z, -abd.x, apd.y, acd.z, e);
+  expand_term(ab0.x, ac0.y, ap0.z, abd.x, acd.y, apd.z, e);
+  expand_term(ac0.x, ap0.y, ab0.z, acd.x, apd.y, abd.z, e);
+  expand_term(-ac0.x, ab0.y, ap0.z, -acd.x, abd.y, apd.z, e);
+  float t;
+  if (!find_root(e, t)) return false;
+  const F3 apt = ap0 + t * apd, abt = ab0 + t * abd, act = ac0 + t * acd;
+  const F3 n = normalize(cross(abt, act));
+  return !bary_outside(solve_columns(abt, act, n, apt));
+}
+
+// ---- triangle grid -------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_tri_reset(TriArrays T) {
+  const uint32_t used = T.counters[0], usedNodes = T.counters[4];
+  for (uint32_t u = blockIdx.x * kBlock + threadIdx.x; u < used; u += gridDim.x * kBlock) {
+    const uint32_t s = T.used[u];
+    T.keys[s] = kEmpty;
+    T.cnt[s] = 0;
+  }
+  for (uint32_t u = blockIdx.x * kBlock + threadIdx.x; u < usedNodes; u += gridDim.x * kBlock) T.incCnt[T.usedNodes[u]] = 0;
+}
+__global__ void k_tri_zero(TriArrays T) {
+  const uint32_t t = threadIdx.x;
+  if (t < 6 && t != 3) T.counters[t] = 0;  // [3] is the sticky failure flag
+}
+
+// TriCompRange / sweptTriRange: floor(min), ceil(max) - floor(min) over position and prevPosition, world units
+__global__ void __launch_bounds__(kBlock) k_tri_count(TriArrays T, const float4* __restrict__ pos, const float4* __restrict__ prev) {
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= T.nt) return;
+  float mn[3], mx[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const uint32_t id = T.tris[3 * t + i];
+    const float4 p = pos[id], q = prev[id];
+    const float pv[3] = {p.x, p.y, p.z}, qv[3] = {q.x, q.y, q.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (i == 0) { mx[k] = pv[k]; mn[k] = pv[k]; }
+      mx[k] = fmaxf(pv[k], mx[k]); mx[k] = fmaxf(qv[k], mx[k]);
+      mn[k] = fminf(pv[k], mn[k]); mn[k] = fminf(qv[k], mn[k]);
+    }
+  }
+  int m[3];
+  uint32_t len[3];
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float f = floorf(mn[k]);
+    ok = ok && (fabsf(f) < 1.0e6f) && (fabsf(mx[k]) < 1.0e6f);
+    m[k] = ok ? static_cast<int>(f) : 0;
+    len[k] = ok ? static_cast<uint32_t>(ceilf(mx[k]) - static_cast<float>(static_cast<long long>(f))) : 0u;
+  }
+  if (!ok || len[0] > kTriMaxCellsPerAxis || len[1] > kTriMaxCellsPerAxis || len[2] > kTriMaxCellsPerAxis) {
+    atomicOr(&T.counters[3], 32u);  // non-finite, or wider than this build's 4 cells per axis (the reference allows 20 / 50)
+    len[0] = len[1] = len[2] = 0;
+  }
+  T.rng[t] = make_int4(m[0], m[1], m[2], static_cast<int>(len[0] | (len[1] << 8) | (len[2] << 16)));
+  uint32_t e = 0;
+  for (uint32_t dx = 0; dx < len[0]; ++dx)
+    for (uint32_t dy = 0; dy < len[1]; ++dy)
+      for (uint32_t dz = 0; dz < len[2]; ++dz, ++e) {
+        bool created;
+        const uint32_t s = insert_cell(T.keys, T.mask, pack_cell(m[0] + (int)dx, m[1] + (int)dy, m[2] + (int)dz), created);
+        T.triSlot[t * kTriMaxEntries + e] = s;
+        if (s == 0xffffffffu) { atomicOr(&T.counters[3], 2u); continue; }
+        if (created) T.used[atomicAdd(&T.counters[0], 1u)] = s;
+        atomicAdd(&T.cnt[s], 1u);
+      }
+}
+__global__ void __launch_bounds__(kBlock) k_tri_alloc(TriArrays T) {
+  const uint32_t used = T.counters[0];
+  for (uint32_t u = blockIdx.x * kBlock + threadIdx.x; u < used; u += gridDim.x * kBlock) {
+    const uint32_t s = T.used[u];
+    if (T.cnt[s] > 1000u) atomicOr(&T.counters[3], 16u);  // Solver.cpp:751-755: a bucket of more than 1000 triangles fails the sim
+    T.start[s] = atomicAdd(&T.counters[1], T.cnt[s]);
+    T.fill[s] = 0;
+  }
+}
+__global__ void __launch_bounds__(kBlock) k_tri_fill(TriArrays T) {
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= T.nt) return;
+  const int4 rg = T.rng[t];
+  const uint32_t ne = (rg.w & 0xff) * ((rg.w >> 8) & 0xff) * ((rg.w >> 16) & 0xff);
+  for (uint32_t e = 0; e < ne; ++e) {
+    const uint32_t s = T.triSlot[t * kTriMaxEntries + e];
+    if (s != 0xffffffffu) T.bucket[T.start[s] + atomicAdd(&T.fill[s], 1u)] = t;
+  }
+}
+__global__ void __launch_bounds__(kBlock) k_tri_sort(TriArrays T) {
+  if (T.counters[3]) return;
+  const uint32_t used = T.counters[0];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
+  for (uint32_t u = wave; u < used; u += nwaves) {
+    const uint32_t s = T.used[u];
+    rank_sort(T.bucket, T.bucketSorted, T.start[s], T.cnt[s], lane);
+  }
+}
+
+// ---- detection: one lane = one triangle (Solver.cpp:714-797); FILL = false counts, true writes -------------
+template <bool FILL>
+__global__ void __launch_bounds__(kBlock) k_tri_detect(TriArrays T, const float4* __restrict__ pos, const float4* __restrict__ prev,
+                                                       float threshold) {
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= T.nt || T.counters[3]) return;
+  const uint32_t ia[3] = {T.tris[3 * t], T.tris[3 * t + 1], T.tris[3 * t + 2]};
+  F3 a1[3], a0[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { a1[i] = xyz(pos[ia[i]]); a0[i] = xyz(prev[ia[i]]); }
+  const int4 rg = T.rng[t];
+  const uint32_t lx = rg.w & 0xff, ly = (rg.w >> 8) & 0xff, lz = (rg.w >> 16) & 0xff;
+  uint32_t count = 0;
+  const uint32_t base = FILL ? T.offTri[t] : 0u;
+  for (uint32_t dx = 0; dx < lx; ++dx)
+    for (uint32_t dy = 0; dy < ly; ++dy)
+      for (uint32_t dz = 0; dz < lz; ++dz) {
+        const uint32_t s = find_cell(T.keys, T.mask, pack_cell(rg.x + (int)dx, rg.y + (int)dy, rg.z + (int)dz));
+        if (s == 0xffffffffu) continue;
+        const uint32_t bs = T.start[s], bc = T.cnt[s];
+        for (uint32_t k = 0; k < bc; ++k) {
+          const uint32_t o = T.bucketSorted[bs + k];
+          const uint32_t ib = T.tris[3 * o], ic = T.tris[3 * o + 1], idd = T.tris[3 * o + 2];
+          bool common = false;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) common = common || ia[i] == ib || ia[i] == ic || ia[i] == idd;
+          if (common) continue;
+          const F3 b1 = xyz(pos[ib]), c1 = xyz(pos[ic]), d1 = xyz(pos[idd]);
+          const F3 b0 = xyz(prev[ib]), c0 = xyz(prev[ic]), d0 = xyz(prev[idd]);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            if (!point_triangle_ccd(a0[i] - b0, c0 - b0, d0 - b0, a1[i] - b1, c1 - b1, d1 - b1, threshold)) continue;
+            if (FILL) {
+              const uint32_t c = base + count;
+              if (c < T.maxContacts) T.ids[c] = make_uint4(ia[i], ib, ic, idd);
+            }
+            ++count;
+          }
+        }
+      }
+  if (!FILL) T.cntTri[t] = count;
+}
+
+// exclusive scan of the per-triangle counts in the reference's merge order (one block)
+__global__ void __launch_bounds__(1024) k_tri_scan(TriArrays T) {
+  __shared__ uint32_t part[1024];
+  const uint32_t tid = threadIdx.x, nt = T.nt;
+  const uint32_t chunk = (nt + 1023) / 1024;
+  const uint32_t lo = tid * chunk, hi = min(nt, lo + chunk);
+  uint32_t sum = 0;
+  for (uint32_t r = lo; r < hi; ++r) sum += T.cntTri[T.triOrder[r]];
+  part[tid] = sum;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    const uint32_t v = tid >= off ? part[tid - off] : 0u;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = tid ? part[tid - 1] : 0u;
+  for (uint32_t r = lo; r < hi; ++r) {
+    const uint32_t t = T.triOrder[r];
+    T.offTri[t] = run;
+    run += T.cntTri[t];
+  }
+  if (tid == 1023) {
+    const uint32_t total = part[1023];
+    if (total > T.maxContacts) atomicOr(&T.counters[3], 64u);  // contact list overflow: latch
+    T.counters[2] = min(total, T.maxContacts);
+  }
+}
+
+// ---- per-node incidence of the contacts + their diagonal blocks ---------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_inc_count(TriArrays T, float* __restrict__ cdiag) {
+  const uint32_t M = T.counters[2];
+  for (uint32_t c = blockIdx.x * kBlock + threadIdx.x; c < M; c += gridDim.x * kBlock) {
+    const uint4 id = T.ids[c];
+    const uint32_t n[4] = {id.x, id.y, id.z, id.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (atomicAdd(&T.incCnt[n[i]], 1u) == 0u) T.usedNodes[atomicAdd(&T.counters[4], 1u)] = n[i];
+      // diag(w A^T A) = w * (3, 1, 1, 1); multiples of 1e4 add exactly in float, so the order is irrelevant
+      atomicAdd(&cdiag[n[i]], kTriContactW * (i == 0 ? 3.0f : 1.0f));
+    }
+  }
+}
+__global__ void __launch_bounds__(kBlock) k_inc_alloc(TriArrays T, const float* __restrict__ kdiag, const float* __restrict__ cdiag,
+                                                      float* __restrict__ dinv) {
+  const uint32_t used = T.counters[4];
+  for (uint32_t u = blockIdx.x * kBlock + threadIdx.x; u < used; u += gridDim.x * kBlock) {
+    const uint32_t n = T.usedNodes[u];
+    T.incStart[n] = atomicAdd(&T.counters[5], T.incCnt[n]);
+    T.incFill[n] = 0;
+    dinv[n] = 1.0f / (kdiag[n] + cdiag[n]);
+  }
+}
+__global__ void __launch_bounds__(kBlock) k_inc_fill(TriArrays T) {
+  const uint32_t M = T.counters[2];
+  for (uint32_t c = blockIdx.x * kBlock + threadIdx.x; c < M; c += gridDim.x * kBlock) {
+    const uint4 id = T.ids[c];
+    const uint32_t n[4] = {id.x, id.y, id.z, id.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) T.inc[T.incStart[n[i]] + atomicAdd(&T.incFill[n[i]], 1u)] = (c << 2) | static_cast<uint32_t>(i);
+  }
+}
+__global__ void __launch_bounds__(kBlock) k_inc_sort(TriArrays T) {
+  const uint32_t used = T.counters[4];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
+  for (uint32_t u = wave; u < used; u += nwaves) {
+    const uint32_t n = T.usedNodes[u];
+    rank_sort(T.inc, T.incSorted, T.incStart[n], T.incCnt[n], lane);
+  }
+}
+
+// ---- local step (CollisionConstraint.cpp:86-124) and w * (AtA p)_i (:176-194) ------------------------------
+__global__ void __launch_bounds__(kBlock) k_pd_local_tri(TriArrays T, const float4* __restrict__ pos, float thickness) {
+  const uint32_t M = T.counters[2];
+  for (uint32_t c = blockIdx.x * kBlock + threadIdx.x; c < M; c += gridDim.x * kBlock) {
+    const uint4 id = T.ids[c];
+    F3 p[4] = {xyz(pos[id.x]), xyz(pos[id.y]), xyz(pos[id.z]), xyz(pos[id.w])};
+    const F3 rel = p[0] - p[1];
+    const F3 n = normalize(cross(p[2] - p[1], p[3] - p[1]));
+    const float nDotP = dot(n, rel);
+    if (nDotP < thickness) p[0] = p[0] + (thickness - nDotP) * n;
+    // AtA = [[3,-1,-1,-1],[-1,1,0,0],[-1,0,1,0],[-1,0,0,1]], products accumulated from 0 in column order
+    const float AtA[4][4] = {{3.f, -1.f, -1.f, -1.f}, {-1.f, 1.f, 0.f, 0.f}, {-1.f, 0.f, 1.f, 0.f}, {-1.f, 0.f, 0.f, 1.f}};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ax += AtA[i][k] * p[k].x;
+        ay += AtA[i][k] * p[k].y;
+        az += AtA[i][k] * p[k].z;
+      }
+      T.contrib[4 * c + i] = make_float4(kTriContactW * ax, kTriContactW * ay, kTriContactW * az, 0.f);
+    }
+  }
+}
+
+// ---- sequential passes over the contact list, one wavefront ------------------------------------------------
+PIES_DEV float ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+PIES_DEV void st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+PIES_DEV F3 ld3(const float* base, uint32_t node) { return {ld(base + 4 * node), ld(base + 4 * node + 1), ld(base + 4 * node + 2)}; }
+PIES_DEV void st3(float* base, uint32_t node, F3 v) { st(base + 4 * node, v.x); st(base + 4 * node + 1, v.y); st(base + 4 * node + 2, v.z); }
+
+// dependency level of every contact of a 64-contact window (contacts that share a node keep their list order)
+PIES_DEV int window_levels(bool valid, const uint4& id, int lane, int& maxLevel) {
+  int level = 0;
+  for (int m = 0; m < 63; ++m) {
+    const int lm = __builtin_amdgcn_readlane(level, m);
+    const uint32_t mx = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(id.x), m));
+    const uint32_t my = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(id.y), m));
+    const uint32_t mz = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(id.z), m));
+    const uint32_t mw = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(id.w), m));
+    const uint32_t mine[4] = {id.x, id.y, id.z, id.w};
+    bool share = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) share = share || mine[k] == mx || mine[k] == my || mine[k] == mz || mine[k] == mw;
+    if (valid && lane > m && share && mx != 0xffffffffu) level = max(level, lm + 1);
+  }
+  int mxl = valid ? level : 0;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mxl = max(mxl, __shfl_xor(mxl, off, 64));
+  maxLevel = mxl;
+  return level;
+}
+
+// MODE 0: PointTriangleCollisionConstraint::stabilizeCollisions (CollisionConstraint.cpp:126-162)
+// MODE 1: point-triangle friction (Solver.cpp:431-471)
+template <int MODE>
+__global__ void __launch_bounds__(64) k_tri_sequential(TriArrays T, float4* pos4, float4* prev4, float4* vel4, float thickness,
+                                                       float friction, float staticThreshold) {
+  float* pos = reinterpret_cast<float*>(pos4);
+  float* prev = reinterpret_cast<float*>(prev4);
+  float* vel = reinterpret_cast<float*>(vel4);
+  const int lane = threadIdx.x;
+  const uint32_t M = T.counters[2];
+  for (uint32_t base = 0; base < M; base += 64) {
+    const bool valid = base + lane < M;
+    const uint4 id = valid ? T.ids[base + lane] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    int maxLevel;
+    const int level = window_levels(valid, id, lane, maxLevel);
+    for (int lv = 0; lv <= maxLevel; ++lv) {
+      if (valid && level == lv) {
+        const float imA = ld(pos + 4 * id.x + 3), imB = ld(pos + 4 * id.y + 3), imC = ld(pos + 4 * id.z + 3), imD = ld(pos + 4 * id.w + 3);
+        const F3 pa = ld3(pos, id.x), pb = ld3(pos, id.y), pc = ld3(pos, id.z), pd = ld3(pos, id.w);
+        const F3 n = normalize(cross(pc - pb, pd - pb));
+        const float wTri = imB + imC + imD, wSum = imA + wTri;
+        if (MODE == 0) {
+          const float nDotP = dot(n, pa - pb);
+          if (nDotP < thickness) {
+            const F3 disp = (thickness - nDotP) * n;
+            const F3 da = disp * imA / wSum, dt = disp * wTri / wSum;
+            st3(pos, id.x, pa + da); st3(pos, id.y, pb - dt); st3(pos, id.z, pc - dt); st3(pos, id.w, pd - dt);
+            st3(prev, id.x, ld3(prev, id.x) + da); st3(prev, id.y, ld3(prev, id.y) - dt);
+            st3(prev, id.z, ld3(prev, id.z) - dt); st3(prev, id.w, ld3(prev, id.w) - dt);
+          }
+        } else {
+          const F3 va = ld3(vel, id.x), vb = ld3(vel, id.y), vc = ld3(vel, id.z), vd = ld3(vel, id.w);
+          const F3 avg = (vb + vc + vd) / 3.0f;
+          const F3 rel = va - avg;
+          const float vDotN = dot(rel, n);
+          const F3 perp = rel - vDotN * n;
+          float fr = friction;
+          if (sqrtf(dot(perp, perp)) < staticThreshold) fr = 1.0f;
+          const F3 dv = (-fr) * perp - (1.1f * fminf(vDotN, 0.0f)) * n;
+          const F3 ndv = neg(dv);
+          st3(vel, id.x, va + dv * imA / wSum);
+          st3(vel, id.y, vb + ndv * wTri / wSum);
+          st3(vel, id.z, vc + ndv * wTri / wSum);
+          st3(vel, id.w, vd + ndv * wTri / wSum);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+uint32_t launch_tri_detect(hipStream_t st_, const TriArrays& T, const NodeArrays& nd, const float* kdiag, float* cdiag, float* dinv,
+                           float threshold, float /*thickness*/) {
+  if (T.nt == 0) return 0;
+  const dim3 wide(std::min<uint32_t>(1024u, (T.nt * 8 + kBlock - 1) / kBlock)), blk(kBlock);
+  hipLaunchKernelGGL(k_tri_reset, wide, blk, 0, st_, T);
+  hipLaunchKernelGGL(k_tri_zero, dim3(1), dim3(64), 0, st_, T);
+  hipLaunchKernelGGL(k_tri_count, grid_for(T.nt), blk, 0, st_, T, nd.pos, nd.prev);
+  hipLaunchKernelGGL(k_tri_alloc, wide, blk, 0, st_, T);
+  hipLaunchKernelGGL(k_tri_fill, grid_for(T.nt), blk, 0, st_, T);
+  hipLaunchKernelGGL(k_tri_sort, wide, blk, 0, st_, T);
+  hipLaunchKernelGGL(k_tri_detect<false>, grid_for(T.nt), blk, 0, st_, T, nd.pos, nd.prev, threshold);
+  hipLaunchKernelGGL(k_tri_scan, dim3(1), dim3(1024), 0, st_, T);
+  hipLaunchKernelGGL(k_tri_detect<true>, grid_for(T.nt), blk, 0, st_, T, nd.pos, nd.prev, threshold);
+  const dim3 cgrid(std::min<uint32_t>(256u, (T.maxContacts + kBlock - 1) / kBlock));
+  hipLaunchKernelGGL(k_inc_count, cgrid, blk, 0, st_, T, cdiag);
+  hipLaunchKernelGGL(k_inc_alloc, cgrid, blk, 0, st_, T, kdiag, cdiag, dinv);
+  hipLaunchKernelGGL(k_inc_fill, cgrid, blk, 0, st_, T);
+  hipLaunchKernelGGL(k_inc_sort, cgrid, blk, 0, st_, T);
+  return 13;
+}
+void launch_pd_local_tri(hipStream_t st_, const TriArrays& T, const float4* pos, float thickness) {
+  if (T.nt == 0) return;
+  const dim3 cgrid(std::min<uint32_t>(256u, (T.maxContacts + kBlock - 1) / kBlock));
+  hipLaunchKernelGGL(k_pd_local_tri, cgrid, dim3(kBlock), 0, st_, T, pos, thickness);
+}
+void launch_tri_stabilize(hipStream_t st_, const TriArrays& T, const NodeArrays& nd, float thickness) {
+  if (T.nt == 0) return;
+  hipLaunchKernelGGL(k_tri_sequential<0>, dim3(1), dim3(64), 0, st_, T, nd.pos, nd.prev, nd.vel, thickness, 0.0f, 0.0f);
+}
+void launch_tri_friction(hipStream_t st_, const TriArrays& T, const NodeArrays& nd, float friction, float staticThreshold) {
+  if (T.nt == 0) return;
+  hipLaunchKernelGGL(k_tri_sequential<1>, dim3(1), dim3(64), 0, st_, T, nd.pos, nd.prev, nd.vel, 0.0f, friction, staticThreshold);
+}
+
+}  // namespace pies

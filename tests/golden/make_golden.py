@@ -414,7 +414,76 @@ def make_loops():
              w_pin=np.float32(2.0), expected=np.array(traj))
 
 
+
+
+# ---------------------------------------------------------------------------------------------------
+# point-triangle CCD (CollisionDetection.cpp:227-302), float64 with numpy.roots for the cubic
+# ---------------------------------------------------------------------------------------------------
+def ccd_fp64(ap0, ab0, ac0, ap1, ab1, ac1, thr):
+    ap0, ab0, ac0, ap1, ab1, ac1 = (np.asarray(v, np.float64) for v in (ap0, ab0, ac0, ap1, ab1, ac1))
+    n0 = np.cross(ab0, ac0); n0 /= np.linalg.norm(n0)
+    n1 = np.cross(ab1, ac1); n1 /= np.linalg.norm(n1)
+    d0, d1 = n0 @ ap0, n1 @ ap1
+
+    def inside(ab, ac, n, ap):
+        b = np.linalg.solve(np.stack([ab, ac, n], axis=1), ap)
+        return not (b[0] < 0 or b[0] > 1 or b[1] < 0 or b[1] > 1 or b[0] + b[1] > 1), b
+
+    if d0 * d1 >= 0:
+        if 0 <= d1 < thr:
+            ok, b = inside(ab1, ac1, n1, ap1)
+            return (ok, 0.0, min(b[0], b[1], 1 - b[0] - b[1]))
+        return (False, -1.0, 1.0)
+    # det[ap(t), ab(t), ac(t)] as a cubic in t
+    import numpy.polynomial.polynomial as P
+    def lin(a, b):
+        return [np.array([a[k], b[k] - a[k]]) for k in range(3)]
+    p, q, r = lin(ap0, ap1), lin(ab0, ab1), lin(ac0, ac1)
+    det = (P.polymul(p[0], P.polysub(P.polymul(q[1], r[2]), P.polymul(q[2], r[1])))
+           - P.polymul(p[1], P.polysub(P.polymul(q[0], r[2]), P.polymul(q[2], r[0])))
+           + P.polymul(p[2], P.polysub(P.polymul(q[0], r[1]), P.polymul(q[1], r[0]))))
+    roots = np.roots(det[::-1])
+    real = sorted(x.real for x in roots if abs(x.imag) < 1e-9 and 0 <= x.real <= 1)
+    if not real:
+        return (False, -1.0, 1.0)
+    t = real[0]
+    ok, b = inside(ab0 + t * (ab1 - ab0), ac0 + t * (ac1 - ac0), None if False else
+                   np.cross(ab0 + t * (ab1 - ab0), ac0 + t * (ac1 - ac0)) / np.linalg.norm(np.cross(ab0 + t * (ab1 - ab0), ac0 + t * (ac1 - ac0))),
+                   ap0 + t * (ap1 - ap0))
+    return (ok, t, min(b[0], b[1], 1 - b[0] - b[1]))
+
+
+def make_ccd():
+    rng = np.random.default_rng(777)  # own stream: independent of the fixtures generated above
+    cases, exp = [], []
+    while len(cases) < 400:
+        b0, c0, d0 = rng.normal(size=(3, 3))
+        vel = rng.normal(size=(4, 3)) * 0.3
+        kind = len(cases) % 4
+        n = np.cross(c0 - b0, d0 - b0); n /= np.linalg.norm(n)
+        u, v = rng.uniform(0.05, 0.6), rng.uniform(0.05, 0.3)
+        foot = b0 + u * (c0 - b0) + v * (d0 - b0)
+        if kind == 0:    # crosses the plane inside the triangle
+            a0 = foot + 0.2 * n; vel[0] = -0.5 * n + 0.05 * rng.normal(size=3)
+        elif kind == 1:  # resting within the threshold
+            a0 = foot + 0.05 * n; vel *= 0.01
+        elif kind == 2:  # crosses the plane outside the triangle
+            a0 = b0 - 1.5 * (c0 - b0) + 0.2 * n; vel[0] = -0.5 * n
+        else:            # far away
+            a0 = foot + 2.0 * n
+        p0 = np.stack([a0, b0, c0, d0]).astype(np.float32).astype(np.float64)
+        p1 = (p0 + vel).astype(np.float32).astype(np.float64)
+        args = [p0[0] - p0[1], p0[2] - p0[1], p0[3] - p0[1], p1[0] - p1[1], p1[2] - p1[1], p1[3] - p1[1]]
+        hit, t, margin = ccd_fp64(*args, 0.1)
+        if abs(margin) < 1e-3:
+            continue  # skip decisions that sit on a triangle edge: fp32 and fp64 may legitimately differ
+        cases.append(np.array(args, dtype=np.float32))
+        exp.append((float(hit), t))
+    np.savez(os.path.join(HERE, "point_triangle_ccd.npz"), args=np.array(cases), threshold=np.float32(0.1), expected=np.array(exp))
+
+
 if __name__ == "__main__":
     make_projections()
     make_loops()
+    make_ccd()
     print("golden vectors written to", HERE)

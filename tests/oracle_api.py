@@ -9,8 +9,8 @@ import numpy as np
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _SO = os.path.join(_ROOT, "oracle", "_build", "libpies_oracle.so")
 
-POSITION, DISTANCE, TET, VOLUME, BEND, SHAPE, GOAL, TRIANGLES, LINES, NODES, STATICS = range(11)
-FLAG_RELEASE_HINGE, FLAG_NODE_COLLISIONS, FLAG_COLLISION_RULE = 0, 1, 2
+POSITION, DISTANCE, TET, VOLUME, BEND, SHAPE, GOAL, TRIANGLES, LINES, NODES, STATICS, TRI_CONTACTS = range(12)
+FLAG_RELEASE_HINGE, FLAG_NODE_COLLISIONS, FLAG_COLLISION_RULE, FLAG_TRIANGLE_COLLISIONS = 0, 1, 2, 3
 PBD, PD = 0, 1
 
 
@@ -98,6 +98,9 @@ def lib():
         L.ora_project_bend.argtypes = [pf, pf, f32, pf]
         L.ora_tet_rest.argtypes = [pf, pf, pf]
         L.ora_node_range.argtypes = [pf, f32, f32, C.POINTER(C.c_int64)]
+        L.ora_point_triangle_ccd.argtypes = [pf, f32, pf]
+        L.ora_point_triangle_ccd.restype = C.c_int
+        L.ora_get_tri_collisions.argtypes = [vp, pu]
         assert L.ora_options_size() == C.sizeof(Options)
         _lib = L
     return _lib
@@ -295,6 +298,12 @@ class OracleSolver:
             lib().ora_tick(self._h)
 
     @property
+    def tri_collisions(self):
+        out = np.empty((self.count(TRI_CONTACTS), 4), dtype=np.uint32)
+        lib().ora_get_tri_collisions(self._h, _pu(out))
+        return out
+
+    @property
     def failed(self):
         return bool(lib().ora_failed(self._h))
 
@@ -337,6 +346,13 @@ def project_bend(x, invMass, angle):
     out = np.empty((4, 3), np.float32)
     lib().ora_project_bend(_pf(x), _pf(im), angle, _pf(out))
     return out
+
+
+def point_triangle_ccd(ap0, ab0, ac0, ap1, ab1, ac1, threshold):
+    v = _f32(np.stack([ap0, ab0, ac0, ap1, ab1, ac1])).reshape(18)
+    t = C.c_float()
+    hit = lib().ora_point_triangle_ccd(_pf(v), threshold, C.byref(t))
+    return bool(hit), t.value
 
 
 def tet_rest(x):

@@ -182,3 +182,57 @@ def test_two_overlapping_spheres_are_pushed_apart():
     p = o.positions
     assert p[1, 0] - p[0, 0] > 0.8 and abs((p[0, 0] + p[1, 0]) - 0.8) < 1e-6
     assert o.collision_pairs >= 2
+
+
+# ---- point-triangle CCD (D1) ----------------------------------------------------------------------
+def test_point_triangle_ccd_against_fp64():
+    d = load("point_triangle_ccd.npz")
+    hits = 0
+    for a, (hit, t) in zip(d["args"], d["expected"]):
+        got, tt = O.point_triangle_ccd(*a, float(d["threshold"]))
+        assert got == bool(hit), (a, hit, t, tt)
+        if hit:
+            hits += 1
+            assert abs(tt - t) <= 2e-4  # bisection to float resolution vs numpy.roots
+    assert 100 < hits < 300
+
+
+def test_ccd_known_answers():
+    b, c, dd = np.float32([0, 0, 0]), np.float32([1, 0, 0]), np.float32([0, 0, -1])  # normal (0, 1, 0)
+    tri = lambda a0, a1: O.point_triangle_ccd(a0 - b, c - b, dd - b, a1 - b, c - b, dd - b, 0.1)
+    hit, t = tri(np.float32([0.2, 1.0, -0.2]), np.float32([0.2, -1.0, -0.2]))  # straight through at t = 0.5
+    assert hit and abs(t - 0.5) < 1e-6
+    hit, t = tri(np.float32([0.2, 0.05, -0.2]), np.float32([0.2, 0.04, -0.2]))  # resting inside the threshold
+    assert hit and t == 0.0
+    assert not tri(np.float32([0.2, 0.5, -0.2]), np.float32([0.2, 0.3, -0.2]))[0]   # approaches, too far
+    assert not tri(np.float32([2.0, 1.0, -0.2]), np.float32([2.0, -1.0, -0.2]))[0]  # crosses the plane outside
+    assert not tri(np.float32([0.2, -0.05, -0.2]), np.float32([0.2, -0.04, -0.2]))[0]  # behind the triangle
+
+
+def _two_boxes(o):
+    o.create_tet_box(3, 3, 3, translation=(0, 0.02, 0), w=1.0)        # sits on the floor
+    o.create_tet_box(3, 3, 3, translation=(0.4, 2.06, 0.3), w=1.0)   # just above it, offset, falling
+    v = o.velocities
+    v[27:, 1] = -2.0
+    o.set_velocities(v)
+    o.set_prev_positions(o.positions)
+
+
+def test_pd_two_boxes_collide_through_triangle_ccd():
+    """K3/H3/D1 in the oracle: a box dropped on another is caught by point-triangle contacts."""
+    res = {}
+    for tri in (1, 0):
+        o = O.OracleSolver(solver=O.PD, iterations=6)
+        _two_boxes(o)
+        o.set_flag(O.FLAG_TRIANGLE_COLLISIONS, tri)
+        contacts = 0
+        for _ in range(12):
+            o.tick()
+            contacts += o.count(O.TRI_CONTACTS)
+        res[tri] = (o.positions, contacts)
+        assert not o.failed and np.isfinite(o.positions).all()
+    assert res[0][1] == 0 and res[1][1] > 0
+    # node 36 (bottom face of the upper box, over the lower box): held up by its contacts, free-falls without
+    # (w = 1 against m/h^2 ~ 7e3 makes the boxes very soft, so only the contacting nodes are compared)
+    assert res[1][0][36, 1] > res[0][0][36, 1] + 0.15
+    assert res[1][0][36, 1] > res[1][0][:27, 1].max() - 0.1  # it rides on the lower box's top face

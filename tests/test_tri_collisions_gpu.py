@@ -1,0 +1,95 @@
+"""GPU parity of the PD point-triangle collision pipeline (K3 / H3 / D1): triangle grid + swept-range
+candidate search (Src/Solver.cpp:680-875), CCD (Src/CollisionDetection.cpp:227-302), contact constraint,
+stabilisation and friction (Src/CollisionConstraint.cpp:67-194, Src/Solver.cpp:367-383, 431-471).
+
+Detection decisions are taken with the same fp32 arithmetic on both sides, so while the trajectories agree
+the contact LISTS must be identical (same contacts, same order, duplicates included); positions carry the
+PD tolerance (CG vs direct solve): 1e-5 x bounding-box diagonal."""
+import numpy as np
+import pytest
+
+import scenes
+from test_pd_parity_gpu import pd_options, tol_for
+
+pytestmark = pytest.mark.gpu
+
+
+def two_boxes(s, gap=0.04, vy=-2.0, offset=(0.4, 0.3)):
+    s.create_tet_box(3, 3, 3, translation=(0, 0.02, 0), w=1.0)                       # sits on the floor
+    s.create_tet_box(3, 3, 3, translation=(offset[0], 2.02 + gap, offset[1]), w=1.0)  # just above it, falling
+    v = s.velocities
+    v[27:, 1] = vy
+    s.set_velocities(v)
+    s.set_prev_positions(s.positions)
+
+
+def test_two_boxes_contact_lists_and_positions(pies, oracle):
+    g = pies.Solver(pd_options(pies, 6))
+    o = oracle.OracleSolver(pd_options(oracle, 6))
+    for s in (g, o):
+        two_boxes(s)
+    tol = tol_for(o.positions)
+    seen = 0
+    for t in range(12):
+        g.tick(); o.tick()
+        cg_, co = g.tri_collisions, o.tri_collisions
+        assert np.array_equal(cg_, co), (t, len(cg_), len(co))
+        seen += len(co)
+        assert np.abs(g.positions - o.positions).max() <= tol, t
+        assert np.abs(g.prev_positions - o.prev_positions).max() <= tol, t
+        assert np.abs(g.velocities - o.velocities).max() <= tol / 0.012, t
+    assert seen > 100 and not g.failed
+    # the contacting node rides on the lower box instead of falling through it (see the oracle test)
+    assert g.positions[36, 1] > g.positions[:27, 1].max() - 0.1
+
+
+def test_switching_the_pipeline_off_matches_oracle_too(pies, oracle):
+    g = pies.Solver(pd_options(pies, 4))
+    o = oracle.OracleSolver(pd_options(oracle, 4))
+    for s in (g, o):
+        two_boxes(s)
+    g.set_flag(pies.FLAG_TRIANGLE_COLLISIONS, 0)
+    o.set_flag(oracle.FLAG_TRIANGLE_COLLISIONS, 0)
+    g.tick(8); o.tick(8)
+    assert len(g.tri_collisions) == 0
+    assert np.abs(g.positions - o.positions).max() <= tol_for(o.positions)
+
+
+def test_friction_and_static_threshold(pies, oracle):
+    """sliding contact: lateral velocity, non-default friction and static threshold"""
+    kw = dict(friction=0.3, staticFrictionThreshold=0.4, collisionStabilizationIterations=3)
+    g = pies.Solver(pd_options(pies, 5, **kw))
+    o = oracle.OracleSolver(pd_options(oracle, 5, **kw))
+    for s in (g, o):
+        two_boxes(s, gap=0.03, vy=-1.0, offset=(0.2, 0.1))
+        v = s.velocities
+        v[27:, 0] = 1.5
+        s.set_velocities(v)
+    tol = tol_for(o.positions)
+    for t in range(10):
+        g.tick(); o.tick()
+        assert np.array_equal(g.tri_collisions, o.tri_collisions), t
+        assert np.abs(g.positions - o.positions).max() <= tol, t
+        assert np.abs(g.velocities - o.velocities).max() <= tol / 0.012, t
+
+
+def test_many_contacts_spanning_several_windows(pies, oracle):
+    """a 6x6 plate pressed onto a 6x6 plate: several hundred contacts per tick (> 64: multiple windows of the
+    sequential stabilisation / friction passes, with conflicts inside and across windows)"""
+    g = pies.Solver(pd_options(pies, 4))
+    o = oracle.OracleSolver(pd_options(oracle, 4))
+    for s in (g, o):
+        s.create_tet_box(6, 2, 6, translation=(0, 0.02, 0), w=1.0)
+        s.create_tet_box(6, 2, 6, translation=(0.37, 1.05, 0.41), w=1.0)
+        v = s.velocities
+        v[72:, 1] = -1.5
+        s.set_velocities(v)
+        s.set_prev_positions(s.positions)
+    tol = tol_for(o.positions)
+    most = 0
+    for t in range(6):
+        g.tick(); o.tick()
+        assert np.array_equal(g.tri_collisions, o.tri_collisions), t
+        most = max(most, len(o.tri_collisions))
+        assert np.abs(g.positions - o.positions).max() <= tol, t
+    assert most > 128
