@@ -64,7 +64,8 @@ public:
   // extensions (not in the reference): which device schedule maps the Gauss-Seidel sweeps, and whether the
   // PBD node-node pass runs (the reference always runs it)
   int schedule = PIES_SCHEDULE_EXACT;
-  bool nodeCollisions = true;
+  bool nodeCollisions = true;       // PBD node-node pass (Solver.cpp:81-130)
+  bool triangleCollisions = true;   // PD point-triangle contacts (Solver.cpp:693-797)
 
   Solver() : Solver(SolverOptions{}) {}
   explicit Solver(const SolverOptions& options, int device = 0) : _options(options) {
@@ -87,6 +88,7 @@ public:
       releaseHinge = rhs.releaseHinge;
       schedule = rhs.schedule;
       nodeCollisions = rhs.nodeCollisions;
+      triangleCollisions = rhs.triangleCollisions;
     }
     return *this;
   }
@@ -100,6 +102,7 @@ public:
   void tick(float /*deltaTime*/) {
     _ck(pies_set_flag(_h, PIES_FLAG_RELEASE_HINGE, releaseHinge ? 1 : 0));
     _ck(pies_set_flag(_h, PIES_FLAG_NODE_COLLISIONS, nodeCollisions ? 1 : 0));
+    _ck(pies_set_flag(_h, PIES_FLAG_TRIANGLE_COLLISIONS, triangleCollisions ? 1 : 0));
     _ck(pies_set_schedule(_h, schedule));
     _ck(pies_tick(_h));
     _refreshPositions();
