@@ -401,10 +401,14 @@ static int build_plans(pies_solver* s, int sched) {
   ids.resize(2 * s->h_distance.size());
   for (size_t i = 0; i < s->h_distance.size(); ++i) { ids[2 * i] = s->h_distance[i].ids[0]; ids[2 * i + 1] = s->h_distance[i].ids[1]; }
   // a distance projection moves node a only (Constraints.cpp:34-36); node b is read
-  build_plan({ids.data(), 2, (uint32_t)s->h_distance.size(), 0x1}, n, sched, s->plan[PIES_DISTANCE]);
+  std::vector<uint16_t> hint(s->h_distance.size());
+  for (size_t i = 0; i < hint.size(); ++i) hint[i] = s->h_distance[i].hint;
+  build_plan({ids.data(), 2, (uint32_t)s->h_distance.size(), 0x1, hint.data()}, n, sched, s->plan[PIES_DISTANCE]);
   ids.resize(4 * s->h_tet.size());
   for (size_t i = 0; i < s->h_tet.size(); ++i) std::memcpy(&ids[4 * i], s->h_tet[i].ids, 16);
-  build_plan({ids.data(), 4, (uint32_t)s->h_tet.size(), 0xF}, n, sched, s->plan[PIES_TET]);
+  hint.resize(s->h_tet.size());
+  for (size_t i = 0; i < hint.size(); ++i) hint[i] = s->h_tet[i].hint;
+  build_plan({ids.data(), 4, (uint32_t)s->h_tet.size(), 0xF, hint.data()}, n, sched, s->plan[PIES_TET]);
   ids.resize(4 * s->h_bend.size());
   for (size_t i = 0; i < s->h_bend.size(); ++i) std::memcpy(&ids[4 * i], s->h_bend[i].ids, 16);
   build_plan({ids.data(), 4, (uint32_t)s->h_bend.size(), 0xF}, n, sched, s->plan[PIES_BEND]);

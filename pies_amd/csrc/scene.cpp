@@ -62,6 +62,7 @@ bool ids_ok(const pies_solver* s, const uint32_t* ids, size_t count) {
 // reading of the column-major inverse (diffToBary_(r,k) = diffToBary[r][k]);  B = I.
 HostTet make_tet(const pies_solver* s, const uint32_t ids[4], float w, float lo, float hi) {
   HostTet t{};
+  t.hint = kNoColourHint;
   std::memcpy(t.ids, ids, sizeof(t.ids));
   const P3 x1 = node_pos(s, ids[0]);
   inverse_columns(node_pos(s, ids[1]) - x1, node_pos(s, ids[2]) - x1, node_pos(s, ids[3]) - x1, t.qinv);
@@ -85,8 +86,9 @@ HostTet make_tet(const pies_solver* s, const uint32_t ids[4], float w, float lo,
   return t;
 }
 
-void push_distance(pies_solver* s, uint32_t a, uint32_t b, float w) {
+void push_distance(pies_solver* s, uint32_t a, uint32_t b, float w, uint16_t hint = kNoColourHint) {
   HostDistance d;
+  d.hint = hint;
   d.ids[0] = a;
   d.ids[1] = b;
   const P3 diff = node_pos(s, b) - node_pos(s, a);
@@ -353,8 +355,13 @@ int pies_create_tet_box(pies_solver_t* s, uint32_t W, uint32_t H, uint32_t D, co
         // the six tetrahedra of the cell, all sharing the 000-111 diagonal (PrimitiveUtilities.cpp:401-514)
         const uint32_t q[6][4] = {{n000, n001, n011, n111}, {n000, n010, n011, n111}, {n000, n001, n101, n111},
                                   {n000, n100, n101, n111}, {n000, n010, n110, n111}, {n000, n100, n110, n111}};
+        // Proposed colouring: tetrahedron e of a cell runs 000 -> e_a -> e_a+e_b -> 111, so two tetrahedra of
+        // the same kind share a node only when their cells differ by e_a, e_b, e_c, e_a+e_b, e_b+e_c or 111,
+        // none of which has i+j+k = 0 mod 4: 6 x 4 = 24 colours, the number of tetrahedra at an inner node.
+        const uint16_t cellColour = static_cast<uint16_t>((i + j + k) & 3u);
         for (int e = 0; e < 6; ++e) {
           s->h_tet.push_back(make_tet(s, q[e], w, 0.8f, 1.0f));
+          s->h_tet.back().hint = static_cast<uint16_t>(4 * e + cellColour);
           if (flags & 1u) s->h_volume.push_back(make_tet(s, q[e], w, 1.0f, 1.0f));
           s->constraintId += 2;
         }
@@ -384,14 +391,21 @@ int pies_create_box(pies_solver_t* s, uint32_t W, uint32_t H, uint32_t D, const 
   for (uint32_t i = 0; i < W; ++i)
     for (uint32_t j = 0; j < H; ++j)
       for (uint32_t k = 0; k < D; ++k) {
-        if (i + 1 < W) push_distance(s, G(i, j, k), G(i + 1, j, k), w);
-        if (j + 1 < H) push_distance(s, G(i, j, k), G(i, j + 1, k), w);
-        if (k + 1 < D) push_distance(s, G(i, j, k), G(i, j, k + 1), w);
+        // Proposed colouring (9 colours; a node is moved by 7 of these constraints and read by 7 more):
+        // colour = (x + 2y + 4z of the moved node + g[kind]) mod 9, found by exhaustive search over linear
+        // forms so that neither two constraints moving one node nor a mover and a reader of it coincide.
+        auto col = [&](uint32_t x, uint32_t y, uint32_t z, uint32_t kind) {
+          static const uint32_t g[7] = {0, 1, 3, 5, 4, 2, 6};
+          return static_cast<uint16_t>((x + 2u * y + 4u * z + g[kind]) % 9u);
+        };
+        if (i + 1 < W) push_distance(s, G(i, j, k), G(i + 1, j, k), w, col(i, j, k, 0));
+        if (j + 1 < H) push_distance(s, G(i, j, k), G(i, j + 1, k), w, col(i, j, k, 1));
+        if (k + 1 < D) push_distance(s, G(i, j, k), G(i, j, k + 1), w, col(i, j, k, 2));
         if (i + 1 < W && j + 1 < H && k + 1 < D) {  // the four body diagonals of the cell
-          push_distance(s, G(i, j, k), G(i + 1, j + 1, k + 1), w);
-          push_distance(s, G(i + 1, j, k), G(i, j + 1, k + 1), w);
-          push_distance(s, G(i, j + 1, k), G(i + 1, j, k + 1), w);
-          push_distance(s, G(i, j, k + 1), G(i + 1, j + 1, k), w);
+          push_distance(s, G(i, j, k), G(i + 1, j + 1, k + 1), w, col(i, j, k, 3));
+          push_distance(s, G(i + 1, j, k), G(i, j + 1, k + 1), w, col(i + 1, j, k, 4));
+          push_distance(s, G(i, j + 1, k), G(i + 1, j, k + 1), w, col(i, j + 1, k, 5));
+          push_distance(s, G(i, j, k + 1), G(i + 1, j + 1, k), w, col(i, j, k + 1, 6));
         }
       }
   if (flags & 2u) lattice_surface(s, W, H, D, first);

@@ -84,11 +84,113 @@ static bool colours(const OpView& ops, uint32_t nodeCount, const uint32_t* visit
   return true;
 }
 
+// A colouring proposed by the lattice factories (scene.cpp) is taken only after it has been checked here, op by
+// op, against the same conflict rule first-fit uses; any unhinted op or clash rejects the whole proposal.
+static bool colours_from_hint(const OpView& ops, uint32_t nodeCount, std::vector<uint32_t>& key, uint32_t& ncolours) {
+  if (!ops.hint) return false;
+  constexpr int kWords = 4;
+  std::vector<uint64_t> usedW(static_cast<size_t>(nodeCount) * kWords, 0), usedR(static_cast<size_t>(nodeCount) * kWords, 0);
+  ncolours = 0;
+  for (uint32_t c = 0; c < ops.count; ++c) {
+    const uint32_t col = ops.hint[c];
+    if (col >= kWords * 64) return false;
+    const uint64_t bit = 1ull << (col & 63);
+    const uint32_t* id = ops.ids + static_cast<size_t>(c) * ops.stride;
+    for (uint32_t k = 0; k < ops.stride; ++k) {
+      const size_t n = static_cast<size_t>(id[k]) * kWords + (col >> 6);
+      const bool wr = ops.writeMask & (1u << k);
+      if ((usedW[n] & bit) || (wr && (usedR[n] & bit))) return false;
+    }
+    for (uint32_t k = 0; k < ops.stride; ++k) {
+      const size_t n = static_cast<size_t>(id[k]) * kWords + (col >> 6);
+      if (ops.writeMask & (1u << k)) usedW[n] |= bit;
+      else usedR[n] |= bit;
+    }
+    key[c] = col;
+    ncolours = std::max(ncolours, col + 1);
+  }
+  return true;
+}
+
+// DSATUR (Brelaz): always colour the op whose neighbours already use the most distinct colours (ties: most
+// conflicting neighbours, then host order), with the smallest free colour.  On regular meshes the saturation
+// front sweeps through the lattice and finds the periodic optimum first-fit misses (24 colours for the
+// six-tetrahedra-per-cell box, the maximum number of tetrahedra at a node, where first-fit needs 30).
+static bool colours_dsatur(const OpView& ops, uint32_t nodeCount, std::vector<uint32_t>& key, uint32_t& ncolours) {
+  constexpr int kWords = 4;
+  const uint32_t n = ops.count, st = ops.stride;
+  // node -> incident (op, slot) lists
+  std::vector<uint32_t> start(nodeCount + 1, 0);
+  for (size_t e = 0; e < static_cast<size_t>(n) * st; ++e) ++start[ops.ids[e] + 1];
+  for (uint32_t v = 0; v < nodeCount; ++v) start[v + 1] += start[v];
+  std::vector<uint32_t> inc(static_cast<size_t>(n) * st);
+  {
+    std::vector<uint32_t> cur(start.begin(), start.end() - 1);
+    for (uint32_t c = 0; c < n; ++c)
+      for (uint32_t k = 0; k < st; ++k) inc[cur[ops.ids[static_cast<size_t>(c) * st + k]]++] = c * st + k;
+  }
+  auto writes = [&](uint32_t slot) { return (ops.writeMask >> slot) & 1u; };
+  std::vector<uint64_t> forbid(static_cast<size_t>(n) * kWords, 0);
+  std::vector<uint32_t> sat(n, 0), deg(n, 0);
+  for (uint32_t c = 0; c < n; ++c)
+    for (uint32_t k = 0; k < st; ++k) {
+      const uint32_t v = ops.ids[static_cast<size_t>(c) * st + k];
+      deg[c] += start[v + 1] - start[v] - 1;  // upper bound (read-read pairs included): tie-break only
+    }
+  // bucket queue on saturation with lazy deletion; inside a bucket a heap on (degree desc, index asc)
+  using Item = std::pair<uint32_t, uint32_t>;  // (degree, ~index) max-heap
+  std::vector<std::vector<Item>> bucket(kWords * 64 + 1);
+  for (uint32_t c = 0; c < n; ++c) bucket[0].push_back({deg[c], ~c});
+  std::make_heap(bucket[0].begin(), bucket[0].end());
+  std::vector<uint8_t> done(n, 0);
+  int top = 0;
+  ncolours = 0;
+  for (uint32_t coloured = 0; coloured < n;) {
+    while (top >= 0 && bucket[top].empty()) --top;
+    if (top < 0) return false;
+    std::pop_heap(bucket[top].begin(), bucket[top].end());
+    const uint32_t c = ~bucket[top].back().second;
+    bucket[top].pop_back();
+    if (done[c] || sat[c] != static_cast<uint32_t>(top)) continue;  // stale entry
+    const uint64_t* f = &forbid[static_cast<size_t>(c) * kWords];
+    int col = -1;
+    for (int w = 0; w < kWords && col < 0; ++w)
+      if (~f[w]) col = w * 64 + __builtin_ctzll(~f[w]);
+    if (col < 0) return false;
+    done[c] = 1;
+    ++coloured;
+    key[c] = static_cast<uint32_t>(col);
+    ncolours = std::max(ncolours, static_cast<uint32_t>(col) + 1);
+    const uint64_t bit = 1ull << (col & 63);
+    for (uint32_t k = 0; k < st; ++k) {
+      const uint32_t v = ops.ids[static_cast<size_t>(c) * st + k];
+      const bool wr = writes(k);
+      for (uint32_t e = start[v]; e < start[v + 1]; ++e) {
+        const uint32_t d = inc[e] / st;
+        if (done[d] || !(wr || writes(inc[e] % st))) continue;
+        uint64_t& word = forbid[static_cast<size_t>(d) * kWords + (col >> 6)];
+        if (word & bit) continue;
+        word |= bit;
+        const uint32_t sd = ++sat[d];
+        bucket[sd].push_back({deg[d], ~d});
+        std::push_heap(bucket[sd].begin(), bucket[sd].end());
+        if (static_cast<int>(sd) > top) top = static_cast<int>(sd);
+      }
+    }
+  }
+  return true;
+}
+
 // Iterated greedy (Culberson): re-running first-fit with the ops grouped by their current colour class can
 // never use more colours, and visiting the classes in a different order (largest first / reversed) lets
 // small classes dissolve into earlier ones.  Fewer colours = fewer dependent launches per sweep.
 static bool colours_iterated(const OpView& ops, uint32_t nodeCount, std::vector<uint32_t>& key, uint32_t& ncolours) {
   if (!colours(ops, nodeCount, nullptr, key, ncolours)) return false;
+  if (const char* e = std::getenv("PIES_COLOUR_DSATUR"); e && std::atoi(e)) {
+    std::vector<uint32_t> k2(ops.count);
+    uint32_t n2 = 0;
+    if (colours_dsatur(ops, nodeCount, k2, n2) && n2 <= ncolours) { key.swap(k2); ncolours = n2; }
+  }
   int rounds = 12;
   if (const char* e = std::getenv("PIES_COLOUR_ROUNDS")) rounds = std::atoi(e);
   std::vector<uint32_t> visit(ops.count), best = key, trial(ops.count);
@@ -112,6 +214,11 @@ static bool colours_iterated(const OpView& ops, uint32_t nodeCount, std::vector<
   }
   key.swap(best);
   ncolours = bestN;
+  const char* noHint = std::getenv("PIES_NO_COLOUR_HINT");
+  if (!(noHint && std::atoi(noHint))) {
+    uint32_t n = 0;
+    if (colours_from_hint(ops, nodeCount, trial, n) && n < ncolours) { key.swap(trial); ncolours = n; }
+  }
   return true;
 }
 

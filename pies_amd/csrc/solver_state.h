@@ -20,10 +20,12 @@ struct HostPosition {
   float target[3];
   float w;
 };
+constexpr uint16_t kNoColourHint = 0xFFFFu;
 struct HostDistance {
   uint32_t ids[2];
   float target;
   float w;
+  uint16_t hint;  // colour proposed by a lattice factory (schedule.cpp verifies it), kNoColourHint otherwise
 };
 struct HostTet {  // TetrahedralConstraint and VolumeConstraint share the rest data
   uint32_t ids[4];
@@ -32,6 +34,7 @@ struct HostTet {  // TetrahedralConstraint and VolumeConstraint share the rest d
   float w;
   float AtA[16];  // row-major 4x4, A^T A (B = I so AtB = A^T)
   float A[16];    // row-major 4x4
+  uint16_t hint;  // see HostDistance
 };
 struct HostBend {
   uint32_t ids[4];
@@ -152,6 +155,7 @@ struct OpView {
   uint32_t stride;      // node ids per op
   uint32_t count;
   uint8_t writeMask;    // same for every op of a container
+  const uint16_t* hint = nullptr;  // optional proposed colouring (count entries)
 };
 void build_plan(const OpView& ops, uint32_t nodeCount, int schedule, Plan& out);
 }  // namespace pies
