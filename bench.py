@@ -76,11 +76,30 @@ def timed_ticks(solver, steps, warmup, barrier):
     return time.perf_counter() - t0
 
 
-def kernel_profile(solver):
+def pd_bytes(solver):
+    """Algorithmic bytes per unit of the PD kernels; units are constraints for the local
+    steps and rows (nodes) for the rest."""
+    n = solver.count(capi.NODES)
+    nnz = solver.count(capi.SYSTEM_NNZ)
+    inc = (4 * (solver.count(capi.TET) + solver.count(capi.VOLUME) + solver.count(capi.BEND)) + 2 * solver.count(capi.DISTANCE)
+           + solver.count(capi.POSITION))
+    return {
+        "pd_predict": 52, "pd_local_distance": 64, "pd_local_tet": 148, "pd_local_volume": 148,
+        # gather formulation: one 16-byte contribution + its 4-byte slot index per (constraint, node) incidence,
+        # inertia term in, right-hand side out (the survey's scatter formulation would be 148 B per tetrahedron)
+        "pd_rhs": (20.0 * inc + 32.0 * n) / n,
+        "pd_spmv": (8.0 * nnz + 28.0 * n) / n,   # col + val per stored entry; rowptr, x, y per row; 3 right-hand sides fused
+        "pd_cg_update": 120,                     # the PCG iteration's 10 three-component vector passes
+        "pd_velocity": 60,
+    }
+
+
+def kernel_profile(solver, bytes_per_unit=None):
     """Per kernel class: launches per substep, average per-launch device time (us), algorithmic GB/s.
     Each class is timed in isolation by replaying a graph of only its launches (pies_profile_substep)."""
     out = {}
     lc = solver.launch_counts()
+    BYTES = bytes_per_unit or globals()["BYTES"]
     for k, name in enumerate(capi.KERNEL_NAMES):
         if name not in BYTES or lc.get(name, 0) == 0:
             continue
@@ -93,6 +112,37 @@ def kernel_profile(solver):
             "units_per_launch": units / launches,
             "algorithmic_GBs": BYTES[name] * units / (ms * 1e-3) / 1e9 if ms > 0 else None,
         }
+        out[name]["hbm_frac"] = out[name]["algorithmic_GBs"] / HBM_PEAK_GBS if ms > 0 else None
+    return out
+
+
+def pd_beam(dims, device):
+    """BASELINE configs[2] pattern: lattice beam, Projective Dynamics, tets + volume (w = 1), 10 iterations,
+    the k = 0 end cap pinned."""
+    W, H, D = dims
+    g = capi.Solver(capi.Options(solver=capi.PD, iterations=10), device=device)
+    g.create_tet_box(W, H, D, translation=(0.0, 2.0, 0.0), w=1.0, volume=True, triangles=True)
+    g.add_position(np.array([D * (j + H * i) for i in range(W) for j in range(H)], dtype=np.uint32), 2.0)
+    g.finalize()
+    g.tick_async(2)
+    g.synchronize()  # lets the captured CG iteration budget settle to what the solves use
+    return g
+
+
+def scale_profiles(device):
+    """Per-kernel algorithmic bandwidth of the projection and SpMV kernels at 1M particles (100x100x100), where
+    a launch is long enough for HBM rather than the kernel boundary to bound it."""
+    out = {}
+    g = build_scene(capi, scenes.L1M, 99, schedule=capi.SCHEDULE_COLOURED, device=device)
+    g.finalize()
+    el = timed_ticks(g, 3, 1, lambda: None)
+    out["pbd_1m"] = {"substeps_per_sec": 3 / el, "projections_per_sec": 3 / el * scenes.projections_per_substep(g, capi, ITERATIONS),
+                     "launches_per_substep": sum(g.launch_counts().values()), "kernels": kernel_profile(g)}
+    g.close()
+    g = pd_beam(scenes.L1M, device)
+    el = timed_ticks(g, 3, 1, lambda: None)
+    out["pd_1m"] = {"substeps_per_sec": 3 / el, "pcg_stats": g.pcg_stats(), "kernels": kernel_profile(g, pd_bytes(g))}
+    g.close()
     return out
 
 
@@ -111,19 +161,16 @@ def extra_configs(device):
     """Short secondary measurements of the other single-GPU BASELINE configs (not the headline value)."""
     out = {}
     # configs[2]: 100k beam, Projective Dynamics, tets + volume (w = 1), 10 iterations, k = 0 end cap pinned
-    W, H, D = scenes.L100K
-    g = capi.Solver(capi.Options(solver=capi.PD, iterations=10), device=device)
-    g.create_tet_box(W, H, D, translation=(0.0, 2.0, 0.0), w=1.0, volume=True, triangles=True)
-    g.add_position(np.array([D * (j + H * i) for i in range(W) for j in range(H)], dtype=np.uint32), 2.0)
-    g.finalize()
-    g.tick_async(2)
-    g.synchronize()  # lets the captured CG iteration budget settle to what the solves use
+    g = pd_beam(scenes.L100K, device)
     el = timed_ticks(g, 30, 3, lambda: None)
     res, iters, solves = g.pcg_stats()
     out["pd_config3"] = {"value": 30 / el, "unit": "substeps/s", "workload": "20x20x250 beam, PD, 539334 tet + 539334 volume constraints, "
                          "10 local/global iterations, floor contacts, Jacobi-PCG rel. tol 3e-7 (iteration budget adapts)",
                          "pcg_max_rel_residual": res, "pcg_max_iterations_used": iters,
                          "projections_per_sec": 30 / el * 10 * (g.count(capi.TET) + g.count(capi.VOLUME) + g.count(capi.POSITION))}
+    g.set_flag(capi.FLAG_TRIANGLE_COLLISIONS, 0)  # the profile pass times the tetrahedral pipeline's kernels
+    g.finalize()
+    out["pd_config3"]["kernels"] = kernel_profile(g, pd_bytes(g))
     g.close()
     # configs[3]: 500k loose particles, node-node collisions + floor, PBD, 4 iterations
     W, H, D = scenes.L500K
@@ -171,6 +218,7 @@ def main():
     ap.add_argument("--cpu-ticks", type=int, default=4)
     ap.add_argument("--no-kernel-profile", action="store_true", help="skip the per-dispatch timing pass (roofline = null)")
     ap.add_argument("--no-extras", action="store_true", help="skip the short PD (config 3) and collision (config 4) measurements")
+    ap.add_argument("--no-scale", action="store_true", help="skip the 1M-particle per-kernel bandwidth measurements")
     args = ap.parse_args()
 
     rank, local_rank, world = dist_env()
@@ -254,6 +302,8 @@ def main():
             e.close()
         if not args.no_extras:
             result["other_configs"] = extra_configs(device_index)
+        if not args.no_scale:
+            result["scale_1m"] = scale_profiles(device_index)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(dims, args.cpu_ticks)
     if rank == 0:

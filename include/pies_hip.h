@@ -67,7 +67,8 @@ enum {
   PIES_GOAL = 6,     /* GoalMatchingConstraint  ShapeMatchingConstraint.cpp:124-177 (PD only) */
   PIES_TRIANGLES = 7,
   PIES_LINES = 8,
-  PIES_NODES = 9
+  PIES_NODES = 9,
+  PIES_SYSTEM_NNZ = 10  /* pies_count only: stored entries of the PD system matrix (after pies_finalize) */
 };
 
 /* How the sequential Gauss-Seidel sweeps of tickPBD (Solver.cpp:58-75) are mapped to the device.
@@ -196,7 +197,11 @@ int pies_get_batches(pies_solver_t* s, int type, uint32_t* batch_offsets, uint32
  * timed, the total milliseconds and the units (constraints or nodes) processed.  Perturbs the state. */
 enum { PIES_KERNEL_PREDICT = 0, PIES_KERNEL_POSITION = 1, PIES_KERNEL_DISTANCE = 2, PIES_KERNEL_TET = 3,
        PIES_KERNEL_BEND = 4, PIES_KERNEL_FLOOR = 5, PIES_KERNEL_VELOCITY = 6, PIES_KERNEL_HASH = 7,
-       PIES_KERNEL_COLLIDE = 8, PIES_KERNEL_COUNT = 9 };
+       PIES_KERNEL_COLLIDE = 8,
+       /* projective dynamics (Solver.cpp:228-485) */
+       PIES_KERNEL_PD_PREDICT = 9, PIES_KERNEL_PD_LOCAL_DISTANCE = 10, PIES_KERNEL_PD_LOCAL_TET = 11,
+       PIES_KERNEL_PD_LOCAL_VOLUME = 12, PIES_KERNEL_PD_RHS = 13, PIES_KERNEL_PD_SPMV = 14,
+       PIES_KERNEL_PD_CG_UPDATE = 15, PIES_KERNEL_PD_VELOCITY = 16, PIES_KERNEL_COUNT = 17 };
 int pies_profile_substep(pies_solver_t* s, int kernel, uint32_t* launches, double* total_ms, uint64_t* units);
 /* launches per substep of the captured graph, per kernel class (PIES_KERNEL_COUNT entries) */
 int pies_launch_counts(pies_solver_t* s, uint32_t* out);

@@ -141,30 +141,52 @@ static void enqueue_pbd_substep(pies_solver* s, int only, uint32_t* counts, uint
   C(PIES_KERNEL_VELOCITY);
 }
 
-// One PD substep as a launch sequence (Solver.cpp:228-485; point-triangle CCD contacts are a later row).
-static void enqueue_pd_substep(pies_solver* s) {
+// One PD substep as a launch sequence (Solver.cpp:228-485).  `only` >= 0 (profile pass) launches one kernel
+// class of the tetrahedral pipeline; units tallies the work items of the launches made.
+static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts = nullptr, uint64_t* units = nullptr) {
   hipStream_t st = s->stream;
   const float h = s->opt.fixedTimestepSize / s->opt.timeSubsteps;
   const PdArrays& pd = s->pd;
-  launch_pd_predict(st, s->nd, pd, h, s->opt.floorHeight + s->opt.collisionThickness);
+  auto ON = [&](int k) { return only < 0 || only == k; };
+  auto C = [&](int k, uint32_t n = 1) { if (counts) counts[k] += n; };
+  auto U = [&](uint64_t u) { if (units && only >= 0) *units += u; };
+  const uint32_t nDist = (uint32_t)s->h_distance.size(), nTet = (uint32_t)s->h_tet.size(), nVol = (uint32_t)s->h_volume.size();
+  if (ON(PIES_KERNEL_PD_PREDICT)) { launch_pd_predict(st, s->nd, pd, h, s->opt.floorHeight + s->opt.collisionThickness); U(s->nd.n); }
+  C(PIES_KERNEL_PD_PREDICT);
   const bool tri = pd.tri.nt != 0;
-  if (tri)  // Solver.cpp:240, 245-248: detection, contact list, their blocks of the system matrix
+  if (tri && only < 0)  // Solver.cpp:240, 245-248: detection, contact list, their blocks of the system matrix
     launch_tri_detect(st, pd.tri, s->nd, pd.kdiag, pd.cg.cdiag, pd.cg.dinv, s->opt.collisionThresholdDistance, s->opt.collisionThickness);
   for (uint32_t it = 0; it < s->opt.iterations; ++it) {
     // local step (Solver.cpp:270-308): position constraints project to a constant, uploaded once
-    launch_pd_local_distance(st, s->nd.pos, s->d_dc_ids, s->d_dc_rw, pd.contrib + s->slotBase[PIES_DISTANCE],
-                             (uint32_t)s->h_distance.size());
-    launch_pd_local_tet(st, false, s->nd.pos, s->d_tc_ids, s->d_tc_q0, s->d_tc_q1, s->d_tc_q2, pd.contrib + s->slotBase[PIES_TET],
-                        (uint32_t)s->h_tet.size());
-    launch_pd_local_tet(st, true, s->nd.pos, s->d_vc_ids, s->d_vc_q0, s->d_vc_q1, s->d_vc_q2, pd.contrib + s->slotBase[PIES_VOLUME],
-                        (uint32_t)s->h_volume.size());
-    launch_pd_local_bend(st, s->nd.pos, s->d_bc_ids, s->d_bc_aw, pd.contrib + s->slotBase[PIES_BEND], (uint32_t)s->h_bend.size());
-    launch_pd_local_shape(st, s->nd.pos, pd);                        // goal targets are constants between transform updates
-    if (tri) launch_pd_local_tri(st, pd.tri, s->nd.pos, s->opt.collisionThickness);  // Solver.cpp:298-300
-    launch_pd_rhs(st, s->nd, pd);                                    // Solver.cpp:266, 310-349
-    launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, s->pcgTol);    // Solver.cpp:356-364
+    if (ON(PIES_KERNEL_PD_LOCAL_DISTANCE) && nDist) {
+      launch_pd_local_distance(st, s->nd.pos, s->d_dc_ids, s->d_dc_rw, pd.contrib + s->slotBase[PIES_DISTANCE], nDist);
+      U(nDist);
+    }
+    if (nDist) C(PIES_KERNEL_PD_LOCAL_DISTANCE);
+    if (ON(PIES_KERNEL_PD_LOCAL_TET) && nTet) {
+      launch_pd_local_tet(st, false, s->nd.pos, s->d_tc_ids, s->d_tc_q0, s->d_tc_q1, s->d_tc_q2, pd.contrib + s->slotBase[PIES_TET], nTet);
+      U(nTet);
+    }
+    if (nTet) C(PIES_KERNEL_PD_LOCAL_TET);
+    if (ON(PIES_KERNEL_PD_LOCAL_VOLUME) && nVol) {
+      launch_pd_local_tet(st, true, s->nd.pos, s->d_vc_ids, s->d_vc_q0, s->d_vc_q1, s->d_vc_q2, pd.contrib + s->slotBase[PIES_VOLUME], nVol);
+      U(nVol);
+    }
+    if (nVol) C(PIES_KERNEL_PD_LOCAL_VOLUME);
+    if (only < 0) {
+      launch_pd_local_bend(st, s->nd.pos, s->d_bc_ids, s->d_bc_aw, pd.contrib + s->slotBase[PIES_BEND], (uint32_t)s->h_bend.size());
+      launch_pd_local_shape(st, s->nd.pos, pd);                        // goal targets are constants between transform updates
+      if (tri) launch_pd_local_tri(st, pd.tri, s->nd.pos, s->opt.collisionThickness);  // Solver.cpp:298-300
+    }
+    if (ON(PIES_KERNEL_PD_RHS)) { launch_pd_rhs(st, s->nd, pd); U(s->nd.n); }    // Solver.cpp:266, 310-349
+    C(PIES_KERNEL_PD_RHS);
+    if (only < 0) launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, s->pcgTol);  // Solver.cpp:356-364
+    else if (only == PIES_KERNEL_PD_SPMV) { launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, 0.f, 1); U((uint64_t)s->nd.n * s->pcgBudget); }
+    else if (only == PIES_KERNEL_PD_CG_UPDATE) { launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, 0.f, 0); U((uint64_t)s->nd.n * s->pcgBudget); }
+    C(PIES_KERNEL_PD_SPMV, s->pcgBudget);
+    C(PIES_KERNEL_PD_CG_UPDATE, s->pcgBudget);
   }
-  if (tri) {  // :367-383: every stabilisation iteration is a sequential pass over the contacts, then the floor snap
+  if (tri && only < 0) {  // :367-383: every stabilisation iteration is a sequential pass over the contacts, then the floor snap
     for (uint32_t ci = 0; ci < s->opt.collisionStabilizationIterations; ++ci) {
       launch_tri_stabilize(st, pd.tri, s->nd, s->opt.collisionThickness);
       launch_pd_stabilize(st, s->nd, pd);
@@ -173,13 +195,17 @@ static void enqueue_pd_substep(pies_solver* s) {
     launch_tri_friction(st, pd.tri, s->nd, s->opt.friction, s->opt.staticFrictionThreshold);               // :431-471
     launch_pd_static_friction(st, s->nd, pd, s->opt.friction, s->opt.staticFrictionThreshold);             // :473-484
   } else {
-    if (s->opt.collisionStabilizationIterations > 0) launch_pd_stabilize(st, s->nd, pd);  // the floor snap is idempotent
-    launch_pd_velocity(st, s->nd, pd, h, s->opt.damping, s->opt.gravity, s->opt.friction, s->opt.staticFrictionThreshold, true);
+    if (only < 0 && s->opt.collisionStabilizationIterations > 0) launch_pd_stabilize(st, s->nd, pd);  // the floor snap is idempotent
+    if (ON(PIES_KERNEL_PD_VELOCITY)) {
+      launch_pd_velocity(st, s->nd, pd, h, s->opt.damping, s->opt.gravity, s->opt.friction, s->opt.staticFrictionThreshold, true);
+      U(s->nd.n);
+    }
   }
+  C(PIES_KERNEL_PD_VELOCITY);
 }
 
 static void enqueue_substep(pies_solver* s, uint32_t* counts) {
-  if (s->opt.solver == PIES_SOLVER_PD) enqueue_pd_substep(s);
+  if (s->opt.solver == PIES_SOLVER_PD) enqueue_pd_substep(s, -1, counts);
   else enqueue_pbd_substep(s, -1, counts);
 }
 
@@ -663,6 +689,7 @@ int pies_count(const pies_solver_t* s, int what, uint32_t* out) {
     case PIES_TRIANGLES: *out = (uint32_t)(s->h_triangles.size() / 3); break;
     case PIES_LINES: *out = (uint32_t)s->h_lines.size(); break;
     case PIES_NODES: *out = s->nodeCount(); break;
+    case PIES_SYSTEM_NNZ: *out = s->pd_nnz; break;
     default: return PIES_ERR_INVALID;
   }
   return PIES_OK;
@@ -783,7 +810,8 @@ int pies_launch_counts(pies_solver_t* s, uint32_t* out) {
 int pies_profile_substep(pies_solver_t* s, int kernel, uint32_t* launches, double* total_ms, uint64_t* units) {
   if (!s || kernel < 0 || kernel >= PIES_KERNEL_COUNT) return PIES_ERR_INVALID;
   if (s->device == PIES_DEVICE_NONE) return fail(s, PIES_ERR_HIP, "host-only handle");
-  if (s->opt.solver != PIES_SOLVER_PBD) return fail(s, PIES_ERR_UNSUPPORTED, "pies_profile_substep: PBD only");
+  const bool isPD = s->opt.solver == PIES_SOLVER_PD;
+  if (isPD != (kernel >= PIES_KERNEL_PD_PREDICT)) return fail(s, PIES_ERR_INVALID, "pies_profile_substep: kernel class of the other solver");
   if (s->sceneDirty || s->hostNodesDirty)
     if (int rc = pies_finalize(s)) return rc;
   HIP_TRY(s, hipSetDevice(s->device));
@@ -797,19 +825,23 @@ int pies_profile_substep(pies_solver_t* s, int kernel, uint32_t* launches, doubl
   uint64_t u = 0;
   const int reps = 5;
   double ms = 0.0;
+  auto enqueue_one = [&](uint64_t* units_) {
+    if (isPD) enqueue_pd_substep(s, kernel, nullptr, units_);
+    else enqueue_pbd_substep(s, kernel, nullptr, units_);
+  };
   if (under_profiler()) {
     // rocprofv3 7.2 segfaults on a second graph instantiation: launch eagerly (host-bound below ~3 us/launch)
-    enqueue_pbd_substep(s, kernel, nullptr, &u);
+    enqueue_one(&u);
     HIP_TRY(s, hipStreamSynchronize(s->stream));
     const auto t0 = std::chrono::high_resolution_clock::now();
-    for (int r = 0; r < reps; ++r) enqueue_pbd_substep(s, kernel, nullptr, nullptr);
+    for (int r = 0; r < reps; ++r) enqueue_one(nullptr);
     HIP_TRY(s, hipStreamSynchronize(s->stream));
     ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
   } else {
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
     HIP_TRY(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-    enqueue_pbd_substep(s, kernel, nullptr, &u);
+    enqueue_one(&u);
     HIP_TRY(s, hipStreamEndCapture(s->stream, &g));
     HIP_TRY(s, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     HIP_TRY(s, hipGraphLaunch(ge, s->stream));  // warm

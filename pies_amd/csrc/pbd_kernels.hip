@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(kBlock) k_velocity(const float4* __restrict__ 
 // ----------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kProjBlock) k_position(float4* __restrict__ pos, const uint32_t* __restrict__ ids,
                                                      const float4* __restrict__ target_w, uint32_t start, uint32_t count) {
-  const uint32_t t = blockIdx.x * kProjBlock + threadIdx.x;
+  const uint32_t t = xcd_block(blockIdx.x, gridDim.x) * kProjBlock + threadIdx.x;
   if (t >= count) return;
   const uint32_t c = start + t;
   const uint32_t id = ids[c];
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(kProjBlock) k_position(float4* __restrict__ po
 // ----------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kProjBlock) k_distance(float4* __restrict__ pos, const uint2* __restrict__ ids,
                                                      const float2* __restrict__ rest_w, uint32_t start, uint32_t count) {
-  const uint32_t t = blockIdx.x * kProjBlock + threadIdx.x;
+  const uint32_t t = xcd_block(blockIdx.x, gridDim.x) * kProjBlock + threadIdx.x;
   if (t >= count) return;
   const uint32_t c = start + t;
   const uint2 id = ids[c];
@@ -138,7 +138,7 @@ template <int VARIANT>
 __global__ void __launch_bounds__(kProjBlock) k_tet(float4* __restrict__ pos, const uint4* __restrict__ ids,
                                                 const float4* __restrict__ q0, const float4* __restrict__ q1,
                                                 const float4* __restrict__ q2, uint32_t start, uint32_t count) {
-  const uint32_t t = blockIdx.x * kProjBlock + threadIdx.x;
+  const uint32_t t = xcd_block(blockIdx.x, gridDim.x) * kProjBlock + threadIdx.x;
   if (t >= count) return;
   const uint32_t c = start + t;
   const uint4 id = ids[c];
@@ -211,7 +211,7 @@ PIES_DEV V3 negv(const V3& a) { return {-a.x, -a.y, -a.z}; }
 
 __global__ void __launch_bounds__(kProjBlock) k_bend(float4* __restrict__ pos, const uint4* __restrict__ ids,
                                                  const float2* __restrict__ angle_w, uint32_t start, uint32_t count) {
-  const uint32_t t = blockIdx.x * kProjBlock + threadIdx.x;
+  const uint32_t t = xcd_block(blockIdx.x, gridDim.x) * kProjBlock + threadIdx.x;
   if (t >= count) return;
   const uint32_t c = start + t;
   const uint4 id = ids[c];

@@ -65,7 +65,8 @@ void launch_pd_local_tet(hipStream_t st, bool volume, const float4* pos, const u
 void launch_pd_local_bend(hipStream_t st, const float4* pos, const uint4* ids, const float2* angle_w, float4* contrib, uint32_t count);
 void launch_pd_local_shape(hipStream_t st, const float4* pos, const PdArrays& pd);
 void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd);
-void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, int maxIters, float tol);
+// part: -1 = the solve; profile passes: 1 = the SpMV (+ direction update) kernels only, 0 = the vector-update kernels only
+void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, int maxIters, float tol, int part = -1);
 void launch_pd_stabilize(hipStream_t st, const NodeArrays& nd, const PdArrays& pd);
 // staticFriction = false leaves the floor friction (Solver.cpp:473-484) to launch_pd_static_friction, which the
 // reference runs after the point-triangle friction

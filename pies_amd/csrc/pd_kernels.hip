@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(kBlock) k_pd_predict(float4* __restrict__ pos,
 __global__ void __launch_bounds__(kBlock) k_pd_local_distance(const float4* __restrict__ pos, const uint2* __restrict__ ids,
                                                               const float2* __restrict__ rest_w, float4* __restrict__ contrib,
                                                               uint32_t count) {
-  const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t c = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
   if (c >= count) return;
   const uint2 id = ids[c];
   const float2 rw = rest_w[c];
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(kBlock) k_pd_local_tet(const float4* __restric
                                                          const float4* __restrict__ q0, const float4* __restrict__ q1,
                                                          const float4* __restrict__ q2, float4* __restrict__ contrib,
                                                          uint32_t count) {
-  const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t c = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
   if (c >= count) return;
   const uint4 id = ids[c];
   const float4 a0 = q0[c], a1 = q1[c], a2 = q2[c];
@@ -174,7 +174,7 @@ PIES_DEV V3 negv(const V3& a) { return {-a.x, -a.y, -a.z}; }
 __global__ void __launch_bounds__(kBlock) k_pd_local_bend(const float4* __restrict__ pos, const uint4* __restrict__ ids,
                                                           const float2* __restrict__ angle_w, float4* __restrict__ contrib,
                                                           uint32_t count) {
-  const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t c = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
   if (c >= count) return;
   const uint4 id = ids[c];
   const float2 aw = angle_w[c];
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(kBlock) k_pd_rhs(const float4* __restrict__ ms
   // transposed through LDS and added one after the other in slot order by the group's first lane (the
   // reference's float summation order).  (Measured: 1 lane/node 60 us, 16 lanes + shuffles 39 us, this
   // 24 us at 100k nodes; visiting nodes in Morton order was slower than index order.)
-  const uint32_t i = (blockIdx.x * kBlock + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+  const uint32_t i = (xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x) >> 4, sub = threadIdx.x & 15;
   const bool live = i < n;
   float4 f = live ? msn[i] : make_float4(0.f, 0.f, 0.f, 0.f);
   const uint32_t b = live ? incPtr[i] : 0u, e = live ? incPtr[i + 1] : 0u;
@@ -756,10 +756,17 @@ void launch_pd_local_shape(hipStream_t st, const float4* pos, const PdArrays& pd
   if (pd.shape.count == 0) return;
   hipLaunchKernelGGL(k_pd_local_shape, dim3(pd.shape.count), dim3(kBlock), 0, st, pos, pd.shape, pd.contribD);
 }
-void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, int maxIters, float tol) {
+void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, int maxIters, float tol, int part) {
   if (nd.n == 0) return;
   CgArrays A = pd.cg;
   const dim3 grid(A.nparts), block(kBlock);
+  if (part >= 0) {  // profile pass: one kind of kernel only, never taking the converged early exit
+    for (int k = 0; k < maxIters; ++k) {
+      if (part == 1) hipLaunchKernelGGL(k_cg_ap, grid, block, 0, st, A, k, -1.0f);
+      else hipLaunchKernelGGL(k_cg_update, grid, block, 0, st, A, nd.pos, k, -1.0f);
+    }
+    return;
+  }
   const float tol2 = tol * tol;
   hipLaunchKernelGGL(k_cg_init, grid, block, 0, st, A, nd.pos, pd.rhs);
   float* pb[2] = {pd.cg.partB, pd.cg.partBnext};

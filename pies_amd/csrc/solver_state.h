@@ -141,7 +141,7 @@ struct pies_solver {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graphExec = nullptr;
   std::vector<std::pair<hipGraph_t, hipGraphExec_t>> retiredGraphs;  // profile-pass graphs, freed with the handle
-  uint32_t launchCounts[PIES_KERNEL_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t launchCounts[PIES_KERNEL_COUNT] = {};
 
   uint32_t nodeCount() const { return static_cast<uint32_t>(h_radius.size()); }
 };
