@@ -13,7 +13,10 @@ constexpr uint32_t kCgBlocks = 1024;  // CG launch shape: <= 1024 blocks x 256 t
 struct CgArrays {
   uint32_t n;
   uint32_t nparts;  // blocks per CG launch (<= kCgBlocks)
-  const uint32_t* rowptr;
+  // K in sliced ELL form (SELL-64): slice s holds rows 64s..64s+63, one row per lane; entry k of the slice's
+  // rows sits at sliceOff[s] + 64k + lane, so a wavefront's loads of col/val are contiguous.  Rows are padded to
+  // the slice's longest row with (col = the row itself, val = 0).
+  const uint32_t* sliceOff;  // ceil(n/64) + 1 offsets (in entries)
   const uint32_t* col;
   const float* val;
   float* cdiag;  // diagonal of the collision matrix (floor contacts)

@@ -467,28 +467,40 @@ template <class Fetch> PIES_DEV void contact_row(const CgArrays& A, uint32_t i, 
   }
 }
 
-// r = f - (K + C) x ; z = D^-1 r ; partB = {rz, rr} ; partI = {bb}.   16 lanes per row.
+// The slices a wavefront sweeps: blocks that share an XCD (equal blockIdx % 8, see xcd_block) take one contiguous
+// part of the matrix, so the rows a slice gathers from were fetched into that XCD's L2 by its neighbours.
+struct SliceSweep {
+  uint32_t begin, end, step;
+};
+PIES_DEV SliceSweep slice_sweep(uint32_t n) {
+  const uint32_t nslices = (n + 63u) >> 6;
+  const uint32_t labels = gridDim.x < 8u ? gridDim.x : 8u;
+  const uint32_t x = blockIdx.x % labels, xb = blockIdx.x / labels;
+  const uint32_t nbx = (gridDim.x - x + labels - 1u) / labels;  // blocks carrying this label
+  const uint32_t segBeg = static_cast<uint32_t>((static_cast<uint64_t>(nslices) * x) / labels);
+  const uint32_t segEnd = static_cast<uint32_t>((static_cast<uint64_t>(nslices) * (x + 1u)) / labels);
+  return {segBeg + xb * (kBlock / 64u) + (threadIdx.x >> 6), segEnd, nbx * (kBlock / 64u)};
+}
+
+// r = f - (K + C) x ; z = D^-1 r ; partB = {rz, rr} ; partI = {bb}.   One row per lane (SELL-64).
 __global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __restrict__ x, const float4* __restrict__ f) {
-  const uint32_t group = (blockIdx.x * kBlock + threadIdx.x) >> 4, sub = threadIdx.x & 15;
-  const uint32_t ngroups = (gridDim.x * kBlock) >> 4;
+  const uint32_t lane = threadIdx.x & 63u;
+  const SliceSweep sw = slice_sweep(A.n);
   float acc9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (uint32_t i = group; i < A.n; i += ngroups) {
+  for (uint32_t sl = sw.begin; sl < sw.end; sl += sw.step) {
+    const uint32_t i = (sl << 6) + lane;
+    const uint32_t off = A.sliceOff[sl], width = (A.sliceOff[sl + 1] - off) >> 6;
     float sx = 0.f, sy = 0.f, sz = 0.f;
-    const uint32_t e = A.rowptr[i + 1];
-    for (uint32_t k = A.rowptr[i] + sub; k < e; k += 16) {
-      const float a = A.val[k];
-      const float4 xj = x[A.col[k]];
+#pragma unroll 4
+    for (uint32_t k = 0; k < width; ++k) {
+      const uint32_t at = off + (k << 6) + lane;
+      const float a = A.val[at];
+      const float4 xj = x[A.col[at]];
       sx = fmaf(a, xj.x, sx);
       sy = fmaf(a, xj.y, sy);
       sz = fmaf(a, xj.z, sz);
     }
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) {
-      sx += __shfl_xor(sx, off, 16);
-      sy += __shfl_xor(sy, off, 16);
-      sz += __shfl_xor(sz, off, 16);
-    }
-    if (sub == 0) {
+    if (i < A.n) {
       contact_row(A, i, [&](uint32_t j, float& px, float& py, float& pz) { const float4 v = x[j]; px = v.x; py = v.y; pz = v.z; }, sx, sy, sz);
       const float4 xi = x[i], fi = f[i];
       const float cd = A.cdiag[i], di = A.dinv[i];
@@ -539,34 +551,36 @@ __global__ void __launch_bounds__(kBlock) k_cg_ap(CgArrays A, int k, float tol2)
   }
   const float4* __restrict__ pold = A.p[(k + 1) & 1];
   float4* __restrict__ pnew = A.p[k & 1];
-  const uint32_t group = (blockIdx.x * kBlock + threadIdx.x) >> 4, sub = threadIdx.x & 15;
-  const uint32_t ngroups = (gridDim.x * kBlock) >> 4;
+  const uint32_t lane = threadIdx.x & 63u;
+  const SliceSweep sw = slice_sweep(A.n);
   float acc[3] = {0, 0, 0};
-  for (uint32_t i = group; i < A.n; i += ngroups) {
+  for (uint32_t sl = sw.begin; sl < sw.end; sl += sw.step) {
+    const uint32_t i = (sl << 6) + lane;
+    const uint32_t off = A.sliceOff[sl], width = (A.sliceOff[sl + 1] - off) >> 6;
     float sx = 0.f, sy = 0.f, sz = 0.f;
-    const uint32_t e = A.rowptr[i + 1];
-    for (uint32_t kk = A.rowptr[i] + sub; kk < e; kk += 16) {
-      const float a = A.val[kk];
-      const uint32_t j = A.col[kk];
-      const float4 zj = A.z[j];
-      float px = zj.x, py = zj.y, pz = zj.z;
-      if (k > 0) {
-        const float4 pj = pold[j];
-        px = fmaf(beta[0], pj.x, px);
-        py = fmaf(beta[1], pj.y, py);
-        pz = fmaf(beta[2], pj.z, pz);
+    if (k > 0) {
+#pragma unroll 4
+      for (uint32_t kk = 0; kk < width; ++kk) {
+        const uint32_t at = off + (kk << 6) + lane;
+        const float a = A.val[at];
+        const uint32_t j = A.col[at];
+        const float4 zj = A.z[j], pj = pold[j];
+        sx = fmaf(a, fmaf(beta[0], pj.x, zj.x), sx);
+        sy = fmaf(a, fmaf(beta[1], pj.y, zj.y), sy);
+        sz = fmaf(a, fmaf(beta[2], pj.z, zj.z), sz);
       }
-      sx = fmaf(a, px, sx);
-      sy = fmaf(a, py, sy);
-      sz = fmaf(a, pz, sz);
+    } else {
+#pragma unroll 4
+      for (uint32_t kk = 0; kk < width; ++kk) {
+        const uint32_t at = off + (kk << 6) + lane;
+        const float a = A.val[at];
+        const float4 zj = A.z[A.col[at]];
+        sx = fmaf(a, zj.x, sx);
+        sy = fmaf(a, zj.y, sy);
+        sz = fmaf(a, zj.z, sz);
+      }
     }
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) {
-      sx += __shfl_xor(sx, off, 16);
-      sy += __shfl_xor(sy, off, 16);
-      sz += __shfl_xor(sz, off, 16);
-    }
-    if (sub == 0) {
+    if (i < A.n) {
       contact_row(A, i, [&](uint32_t j, float& qx, float& qy, float& qz) {
         const float4 zj = A.z[j];
         qx = zj.x; qy = zj.y; qz = zj.z;

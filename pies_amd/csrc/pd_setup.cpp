@@ -68,6 +68,29 @@ int pd_build(pies_solver* s) {
     std::vector<Entry>().swap(r);
   }
   s->pd_nnz = static_cast<uint32_t>(col.size());
+  // CSR -> SELL-64 (see CgArrays): the order of a row's entries (ascending column) is kept
+  const uint32_t nslices = (n + 63u) / 64u;
+  std::vector<uint32_t> sliceOff(nslices + 1, 0), sellCol;
+  std::vector<float> sellVal;
+  for (uint32_t sl = 0; sl < nslices; ++sl) {
+    uint32_t width = 0;
+    for (uint32_t i = 64u * sl; i < std::min(n, 64u * sl + 64u); ++i) width = std::max(width, rowptr[i + 1] - rowptr[i]);
+    sliceOff[sl + 1] = sliceOff[sl] + 64u * width;
+  }
+  sellCol.resize(sliceOff[nslices]);
+  sellVal.assign(sliceOff[nslices], 0.0f);
+  for (uint32_t sl = 0; sl < nslices; ++sl) {
+    const uint32_t width = (sliceOff[sl + 1] - sliceOff[sl]) / 64u;
+    for (uint32_t lane = 0; lane < 64u; ++lane) {
+      const uint32_t i = 64u * sl + lane, self = std::min(i, n - 1u);
+      const uint32_t b = i < n ? rowptr[i] : 0u, len = i < n ? rowptr[i + 1] - rowptr[i] : 0u;
+      for (uint32_t k = 0; k < width; ++k) {
+        const size_t at = static_cast<size_t>(sliceOff[sl]) + 64u * k + lane;
+        sellCol[at] = k < len ? col[b + k] : self;
+        if (k < len) sellVal[at] = val[b + k];
+      }
+    }
+  }
 
   // ---- contribution slots and per-node incidence lists -------------------------------------------------
   const uint32_t cnt[5] = {(uint32_t)s->h_position.size(), (uint32_t)s->h_distance.size(), (uint32_t)s->h_tet.size(),
@@ -139,18 +162,18 @@ int pd_build(pies_solver* s) {
   PdArrays& pd = s->pd;
   CgArrays& cg = pd.cg;
   cg.n = n;
-  cg.nparts = std::max(1u, std::min(kCgBlocks, (n + 15) / 16));
+  cg.nparts = std::max(1u, std::min(kCgBlocks, (n + 255u) / 256u));  // 4 wavefronts (= 4 slices in flight) per block
   uint32_t *d_rowptr, *d_col, *d_incPtr, *d_incSlot, *d_tri;
   float *d_val, *d_kdiag;
-  if (int rc = upload(s, rowptr, &d_rowptr)) return rc;
-  if (int rc = upload(s, col, &d_col)) return rc;
-  if (int rc = upload(s, val, &d_val)) return rc;
+  if (int rc = upload(s, sliceOff, &d_rowptr)) return rc;
+  if (int rc = upload(s, sellCol, &d_col)) return rc;
+  if (int rc = upload(s, sellVal, &d_val)) return rc;
   if (int rc = upload(s, kdiag, &d_kdiag)) return rc;
   if (int rc = upload(s, incPtr, &d_incPtr)) return rc;
   if (int rc = upload(s, incSlot, &d_incSlot)) return rc;
   if (int rc = upload(s, triCount, &d_tri)) return rc;
 
-  cg.rowptr = d_rowptr; cg.col = d_col; cg.val = d_val;
+  cg.sliceOff = d_rowptr; cg.col = d_col; cg.val = d_val;
   pd.kdiag = d_kdiag; pd.incPtr = d_incPtr; pd.incSlot = d_incSlot; pd.triCount = d_tri;
   pd.contribD = nullptr; pd.incPtrD = nullptr; pd.incSlotD = nullptr;
   pd.shape = ShapeArrays{};
