@@ -83,8 +83,11 @@ def pd_bytes(solver):
     nnz = solver.count(capi.SYSTEM_NNZ)
     inc = (4 * (solver.count(capi.TET) + solver.count(capi.VOLUME) + solver.count(capi.BEND)) + 2 * solver.count(capi.DISTANCE)
            + solver.count(capi.POSITION))
+    # strain + volume constraints over the same elements run fused (no separate volume launches): ids 16 + Qinv 36 +
+    # 2 x (min, max, w) 24 + four positions 48 + 2 x 36 projected gradients
+    paired = solver.count(capi.VOLUME) > 0 and solver.launch_counts().get("pd_local_volume", 0) == 0
     return {
-        "pd_predict": 52, "pd_local_distance": 64, "pd_local_tet": 148, "pd_local_volume": 148,
+        "pd_predict": 52, "pd_local_distance": 64, "pd_local_tet": 196 if paired else 148, "pd_local_volume": 148,
         # gather formulation: one 16-byte contribution + its 4-byte slot index per (constraint, node) incidence,
         # inertia term in, right-hand side out (the survey's scatter formulation would be 148 B per tetrahedron)
         "pd_rhs": (20.0 * inc + 32.0 * n) / n,

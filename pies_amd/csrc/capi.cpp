@@ -163,6 +163,14 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
       U(nDist);
     }
     if (nDist) C(PIES_KERNEL_PD_LOCAL_DISTANCE);
+    if (s->tetVolumePaired) {  // both projections in one launch, accounted to the strain class
+      if (ON(PIES_KERNEL_PD_LOCAL_TET)) {
+        launch_pd_local_tet_pair(st, s->nd.pos, s->d_tc_ids, s->d_tc_q0, s->d_tc_q1, s->d_tc_q2, s->d_vc_q2,
+                                 pd.contrib + s->slotBase[PIES_TET], pd.contrib + s->slotBase[PIES_VOLUME], nTet);
+        U(nTet);
+      }
+      C(PIES_KERNEL_PD_LOCAL_TET);
+    } else {
     if (ON(PIES_KERNEL_PD_LOCAL_TET) && nTet) {
       launch_pd_local_tet(st, false, s->nd.pos, s->d_tc_ids, s->d_tc_q0, s->d_tc_q1, s->d_tc_q2, pd.contrib + s->slotBase[PIES_TET], nTet);
       U(nTet);
@@ -173,6 +181,7 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
       U(nVol);
     }
     if (nVol) C(PIES_KERNEL_PD_LOCAL_VOLUME);
+    }
     if (only < 0) {
       launch_pd_local_bend(st, s->nd.pos, s->d_bc_ids, s->d_bc_aw, pd.contrib + s->slotBase[PIES_BEND], (uint32_t)s->h_bend.size());
       launch_pd_local_shape(st, s->nd.pos, pd);                        // goal targets are constants between transform updates
@@ -583,6 +592,13 @@ int pies_finalize(pies_solver_t* s) {
     if (int rc = upload(s, q0, &s->d_vc_q0)) return rc;
     if (int rc = upload(s, q1, &s->d_vc_q1)) return rc;
     if (int rc = upload(s, q2, &s->d_vc_q2)) return rc;
+    // strain and volume constraints added pairwise over the same elements share one gather and one SVD
+    s->tetVolumePaired = !s->h_tet.empty() && s->h_tet.size() == s->h_volume.size();
+    for (size_t k = 0; s->tetVolumePaired && k < s->h_tet.size(); ++k) {
+      const HostTet &a = s->h_tet[s->plan[PIES_TET].order[k]], &b = s->h_volume[k];
+      s->tetVolumePaired = std::memcmp(a.ids, b.ids, sizeof(a.ids)) == 0 && std::memcmp(a.qinv, b.qinv, sizeof(a.qinv)) == 0;
+    }
+    if (const char* e = std::getenv("PIES_NO_TET_PAIRS"); e && e[0] == '1') s->tetVolumePaired = false;
     if (int rc = pd_build(s)) return rc;
   }
   if (int rc = capture_graph(s)) return rc;

@@ -65,6 +65,9 @@ void launch_pd_predict(hipStream_t st, const NodeArrays& nd, const PdArrays& pd,
 void launch_pd_local_distance(hipStream_t st, const float4* pos, const uint2* ids, const float2* rw, float4* contrib, uint32_t count);
 void launch_pd_local_tet(hipStream_t st, bool volume, const float4* pos, const uint4* ids, const float4* q0, const float4* q1,
                          const float4* q2, float4* contrib, uint32_t count);
+// strain + volume constraints over identical elements (same ids, same Qinv), fused
+void launch_pd_local_tet_pair(hipStream_t st, const float4* pos, const uint4* ids, const float4* q0, const float4* q1, const float4* q2,
+                              const float4* vq2, float4* contribTet, float4* contribVol, uint32_t count);
 void launch_pd_local_bend(hipStream_t st, const float4* pos, const uint4* ids, const float2* angle_w, float4* contrib, uint32_t count);
 void launch_pd_local_shape(hipStream_t st, const float4* pos, const PdArrays& pd);
 void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd);

@@ -101,6 +101,66 @@ PIES_DEV void compute_d(const float s[3], float omegaMin, float omegaMax, float 
 // TetrahedralConstraint (VOLUME = false, Constraints.cpp:76-128) and VolumeConstraint (VOLUME = true,
 // :205-255).  B = I and A = [0 ; Qinv_(r,k) D] (Constraints.cpp:141-175), so
 // (A^T p)_0 = -(q_r0+q_r1+q_r2) weighted sum, (A^T p)_{1+c} = sum_r Qinv[r][c] p_{1+r}; p_0 = 0.
+struct TetFrame {
+  float qi[3][3];  // Qinv, [col][row]
+  float F[3][3];
+  Svd3 d;
+};
+PIES_DEV void tet_frame(const float4* __restrict__ pos, const uint4 id, const float4 a0, const float4 a1, const float4 a2, TetFrame& t) {
+  const float4 x1 = pos[id.x], x2 = pos[id.y], x3 = pos[id.z], x4 = pos[id.w];
+  const float qi[3][3] = {{a0.x, a0.y, a0.z}, {a0.w, a1.x, a1.y}, {a1.z, a1.w, a2.x}};
+  const float P[3][3] = {{x2.x - x1.x, x2.y - x1.y, x2.z - x1.z},
+                         {x3.x - x1.x, x3.y - x1.y, x3.z - x1.z},
+                         {x4.x - x1.x, x4.y - x1.y, x4.z - x1.z}};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) t.qi[i][j] = qi[i][j];
+  mat3_mul_cm(P, t.qi, t.F);
+  svd3(t.F, t.d);
+}
+// singular values of the projection: VolumeConstraint (:205-255) or TetrahedralConstraint (:76-128)
+template <bool VOLUME> PIES_DEV void tet_project(const TetFrame& t, float lo, float hi, float s[3]) {
+  if (VOLUME) {
+    float D[3];
+    compute_d(t.d.s, lo, hi, D);
+    s[0] = t.d.s[0] + D[0];
+    s[1] = t.d.s[1] + D[1];
+    s[2] = t.d.s[2] + D[2];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s[i] = clampf(t.d.s[i], lo, hi);
+    if (det3_cm(t.F) < 0.0f) {
+      int k = 0;
+      float m = t.d.s[0];
+      if (t.d.s[1] <= m) { k = 1; m = t.d.s[1]; }
+      if (t.d.s[2] <= m) { k = 2; }
+      s[0] = (k == 0) ? -s[0] : s[0];
+      s[1] = (k == 1) ? -s[1] : s[1];
+      s[2] = (k == 2) ? -s[2] : s[2];
+    }
+  }
+}
+// contribution_i = w * (A^T p)_i with p = (0, Fh[0], Fh[1], Fh[2]), Fh = U diag(s) V^T
+PIES_DEV void tet_emit(const TetFrame& t, const float s[3], float w, float4* __restrict__ contrib, uint32_t count, uint32_t c) {
+  float Fh[3][3];
+  svd3_recompose(t.d, s, Fh);
+  // A[1+r][0] = ((0 + -q_r0) + -q_r1) + -q_r2 ; A[1+r][1+c] = q_rc with q_rc = Qinv[r][c] (reference's row-major read)
+  float A0[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) A0[r] = ((0.0f + t.qi[r][0] * -1.0f) + t.qi[r][1] * -1.0f) + t.qi[r][2] * -1.0f;
+  float out[4][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    // sum over rows m = 0..3 of A[m][i] * p_m, starting from 0; row 0 of A and p_0 are zero
+    out[0][k] = ((0.0f + A0[0] * Fh[0][k]) + A0[1] * Fh[1][k]) + A0[2] * Fh[2][k];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) out[1 + cc][k] = ((0.0f + t.qi[0][cc] * Fh[0][k]) + t.qi[1][cc] * Fh[1][k]) + t.qi[2][cc] * Fh[2][k];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) contrib[i * count + c] = make_float4(w * out[i][0], w * out[i][1], w * out[i][2], 0.0f);
+}
+
 template <bool VOLUME>
 __global__ void __launch_bounds__(kBlock) k_pd_local_tet(const float4* __restrict__ pos, const uint4* __restrict__ ids,
                                                          const float4* __restrict__ q0, const float4* __restrict__ q1,
@@ -108,54 +168,32 @@ __global__ void __launch_bounds__(kBlock) k_pd_local_tet(const float4* __restric
                                                          uint32_t count) {
   const uint32_t c = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
   if (c >= count) return;
-  const uint4 id = ids[c];
-  const float4 a0 = q0[c], a1 = q1[c], a2 = q2[c];
-  const float4 x1 = pos[id.x], x2 = pos[id.y], x3 = pos[id.z], x4 = pos[id.w];
-  const float qi[3][3] = {{a0.x, a0.y, a0.z}, {a0.w, a1.x, a1.y}, {a1.z, a1.w, a2.x}};  // [col][row]
-  const float lo = a2.y, hi = a2.z, w = a2.w;
-  const float P[3][3] = {{x2.x - x1.x, x2.y - x1.y, x2.z - x1.z},
-                         {x3.x - x1.x, x3.y - x1.y, x3.z - x1.z},
-                         {x4.x - x1.x, x4.y - x1.y, x4.z - x1.z}};
-  float F[3][3];
-  mat3_mul_cm(P, qi, F);
-  Svd3 d;
-  svd3(F, d);
+  const float4 a2 = q2[c];
+  TetFrame t;
+  tet_frame(pos, ids[c], q0[c], q1[c], a2, t);
   float s[3];
-  if (VOLUME) {
-    float D[3];
-    compute_d(d.s, lo, hi, D);
-    s[0] = d.s[0] + D[0];
-    s[1] = d.s[1] + D[1];
-    s[2] = d.s[2] + D[2];
-  } else {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) s[i] = clampf(d.s[i], lo, hi);
-    if (det3_cm(F) < 0.0f) {
-      int k = 0;
-      float m = d.s[0];
-      if (d.s[1] <= m) { k = 1; m = d.s[1]; }
-      if (d.s[2] <= m) { k = 2; }
-      s[0] = (k == 0) ? -s[0] : s[0];
-      s[1] = (k == 1) ? -s[1] : s[1];
-      s[2] = (k == 2) ? -s[2] : s[2];
-    }
-  }
-  float Fh[3][3];
-  svd3_recompose(d, s, Fh);  // projected = (0, Fh[0], Fh[1], Fh[2])
-  // A[1+r][0] = ((0 + -q_r0) + -q_r1) + -q_r2 ; A[1+r][1+c] = q_rc with q_rc = Qinv[r][c] (reference's row-major read)
-  float A0[3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) A0[r] = ((0.0f + qi[r][0] * -1.0f) + qi[r][1] * -1.0f) + qi[r][2] * -1.0f;
-  float out[4][3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    // sum over rows m = 0..3 of A[m][i] * p_m, starting from 0; row 0 of A and p_0 are zero
-    out[0][k] = ((0.0f + A0[0] * Fh[0][k]) + A0[1] * Fh[1][k]) + A0[2] * Fh[2][k];
-#pragma unroll
-    for (int cc = 0; cc < 3; ++cc) out[1 + cc][k] = ((0.0f + qi[0][cc] * Fh[0][k]) + qi[1][cc] * Fh[1][k]) + qi[2][cc] * Fh[2][k];
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) contrib[i * count + c] = make_float4(w * out[i][0], w * out[i][1], w * out[i][2], 0.0f);
+  tet_project<VOLUME>(t, a2.y, a2.z, s);
+  tet_emit(t, s, a2.w, contrib, count, c);
+}
+
+// A tetrahedral-strain and a volume constraint over the same element (createTetBox adds them in pairs,
+// PrimitiveUtilities.cpp:401-514; pd_setup.cpp checks ids and Qinv are identical): one gather, one SVD, both
+// projections - the arithmetic of each is exactly that of its own kernel above.
+__global__ void __launch_bounds__(kBlock) k_pd_local_tet_pair(const float4* __restrict__ pos, const uint4* __restrict__ ids,
+                                                              const float4* __restrict__ q0, const float4* __restrict__ q1,
+                                                              const float4* __restrict__ q2, const float4* __restrict__ vq2,
+                                                              float4* __restrict__ contribTet, float4* __restrict__ contribVol,
+                                                              uint32_t count) {
+  const uint32_t c = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
+  if (c >= count) return;
+  const float4 a2 = q2[c], v2 = vq2[c];
+  TetFrame t;
+  tet_frame(pos, ids[c], q0[c], q1[c], a2, t);
+  float s[3];
+  tet_project<false>(t, a2.y, a2.z, s);
+  tet_emit(t, s, a2.w, contribTet, count, c);
+  tet_project<true>(t, v2.y, v2.z, s);
+  tet_emit(t, s, v2.w, contribVol, count, c);
 }
 
 // BendConstraint in PD (Constraints.cpp:312-366): A = B = I, contribution = w * projected_i.
@@ -761,6 +799,11 @@ void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd) {
   if (nd.n == 0) return;
   hipLaunchKernelGGL(k_pd_rhs, dim3((nd.n + 15) / 16), dim3(kBlock), 0, st, pd.msn, pd.contrib, pd.incPtr, pd.incSlot, pd.contribD, pd.incPtrD,
                      pd.incSlotD, nd.pos, pd.nstatic, pd.statp, pd.rhs, pd.cg.tIncCnt, pd.cg.tIncStart, pd.cg.tInc, pd.tContrib, nd.n);
+}
+void launch_pd_local_tet_pair(hipStream_t st, const float4* pos, const uint4* ids, const float4* q0, const float4* q1, const float4* q2,
+                              const float4* vq2, float4* contribTet, float4* contribVol, uint32_t count) {
+  if (count == 0) return;
+  hipLaunchKernelGGL(k_pd_local_tet_pair, grid_for(count), dim3(kBlock), 0, st, pos, ids, q0, q1, q2, vq2, contribTet, contribVol, count);
 }
 void launch_pd_local_bend(hipStream_t st, const float4* pos, const uint4* ids, const float2* angle_w, float4* contrib, uint32_t count) {
   if (count == 0) return;

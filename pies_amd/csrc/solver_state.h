@@ -84,6 +84,7 @@ struct pies_solver {
 
   bool releaseHinge = false;
   bool nodeCollisions = true;
+  bool tetVolumePaired = false;    // PD: h_volume[k] and h_tet[k] are the same element for every k (fused local step)
   bool triangleCollisions = true;  // PD point-triangle CCD contacts (Solver.cpp:693-797); extension flag to switch off
   bool simFailed = false;
   int schedule = PIES_SCHEDULE_EXACT;
