@@ -88,9 +88,9 @@ def pd_bytes(solver):
     paired = solver.count(capi.VOLUME) > 0 and solver.launch_counts().get("pd_local_volume", 0) == 0
     return {
         "pd_predict": 52, "pd_local_distance": 64, "pd_local_tet": 196 if paired else 148, "pd_local_volume": 148,
-        # gather formulation: one 16-byte contribution + its 4-byte slot index per (constraint, node) incidence,
+        # gather formulation: one 12-byte contribution + its 4-byte slot index per (constraint, node) incidence,
         # inertia term in, right-hand side out (the survey's scatter formulation would be 148 B per tetrahedron)
-        "pd_rhs": (20.0 * inc + 32.0 * n) / n,
+        "pd_rhs": (16.0 * inc + 32.0 * n) / n,
         "pd_spmv": (8.0 * nnz + 28.0 * n) / n,   # col + val per stored entry; rowptr, x, y per row; 3 right-hand sides fused
         "pd_cg_update": 120,                     # the PCG iteration's 10 three-component vector passes
         "pd_velocity": 60,

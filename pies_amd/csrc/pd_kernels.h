@@ -10,6 +10,11 @@ namespace pies {
 
 constexpr uint32_t kCgBlocks = 1024;  // CG launch shape: <= 1024 blocks x 256 threads (4 per CU), grid-stride
 
+// One contribution record: w * (A^T B p)_i, packed to 12 bytes (global_load/store_dwordx3).
+struct Vec3f {
+  float x, y, z;
+};
+
 struct CgArrays {
   uint32_t n;
   uint32_t nparts;  // blocks per CG launch (<= kCgBlocks)
@@ -50,7 +55,7 @@ struct PdArrays {
   float4* msn;
   float4* rhs;
   float4* statp;
-  float4* contrib;
+  Vec3f* contrib;
   const uint32_t* incPtr;
   const uint32_t* incSlot;
   const float4* tContrib;  // 4 per contact: w * (AtA p)_i
@@ -62,13 +67,13 @@ struct PdArrays {
 };
 
 void launch_pd_predict(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float h, float contactHeight);
-void launch_pd_local_distance(hipStream_t st, const float4* pos, const uint2* ids, const float2* rw, float4* contrib, uint32_t count);
+void launch_pd_local_distance(hipStream_t st, const float4* pos, const uint2* ids, const float2* rw, Vec3f* contrib, uint32_t count);
 void launch_pd_local_tet(hipStream_t st, bool volume, const float4* pos, const uint4* ids, const float4* q0, const float4* q1,
-                         const float4* q2, float4* contrib, uint32_t count);
+                         const float4* q2, Vec3f* contrib, uint32_t count);
 // strain + volume constraints over identical elements (same ids, same Qinv), fused
 void launch_pd_local_tet_pair(hipStream_t st, const float4* pos, const uint4* ids, const float4* q0, const float4* q1, const float4* q2,
-                              const float4* vq2, float4* contribTet, float4* contribVol, uint32_t count);
-void launch_pd_local_bend(hipStream_t st, const float4* pos, const uint4* ids, const float2* angle_w, float4* contrib, uint32_t count);
+                              const float4* vq2, Vec3f* contribTet, Vec3f* contribVol, uint32_t count);
+void launch_pd_local_bend(hipStream_t st, const float4* pos, const uint4* ids, const float2* angle_w, Vec3f* contrib, uint32_t count);
 void launch_pd_local_shape(hipStream_t st, const float4* pos, const PdArrays& pd);
 void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd);
 // part: -1 = the solve; profile passes: 1 = the SpMV (+ direction update) kernels only, 0 = the vector-update kernels only

@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(kBlock) k_pd_predict(float4* __restrict__ pos,
 // ------------------------------------------------------------------------------------------------------
 // DistanceConstraint: A = B = [[.5,-.5],[-.5,.5]]  =>  A^T B = [[.5,-.5],[-.5,.5]] exactly.
 __global__ void __launch_bounds__(kBlock) k_pd_local_distance(const float4* __restrict__ pos, const uint2* __restrict__ ids,
-                                                              const float2* __restrict__ rest_w, float4* __restrict__ contrib,
+                                                              const float2* __restrict__ rest_w, Vec3f* __restrict__ contrib,
                                                               uint32_t count) {
   const uint32_t c = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
   if (c >= count) return;
@@ -75,10 +75,10 @@ __global__ void __launch_bounds__(kBlock) k_pd_local_distance(const float4* __re
   const float p0x = a.x + nd * ux, p0y = a.y + nd * uy, p0z = a.z + nd * uz;  // projected[0]; projected[1] = b
   const float w = rw.y;
   // (AtB p)_0 = .5 p0 + (-.5) p1 ; (AtB p)_1 = (-.5) p0 + .5 p1 ; accumulated from 0 like the reference's product
-  contrib[c] = make_float4(w * ((0.0f + 0.5f * p0x) + -0.5f * b.x), w * ((0.0f + 0.5f * p0y) + -0.5f * b.y),
-                           w * ((0.0f + 0.5f * p0z) + -0.5f * b.z), 0.0f);
-  contrib[count + c] = make_float4(w * ((0.0f + -0.5f * p0x) + 0.5f * b.x), w * ((0.0f + -0.5f * p0y) + 0.5f * b.y),
-                                   w * ((0.0f + -0.5f * p0z) + 0.5f * b.z), 0.0f);
+  contrib[c] = Vec3f{w * ((0.0f + 0.5f * p0x) + -0.5f * b.x), w * ((0.0f + 0.5f * p0y) + -0.5f * b.y),
+                     w * ((0.0f + 0.5f * p0z) + -0.5f * b.z)};
+  contrib[count + c] = Vec3f{w * ((0.0f + -0.5f * p0x) + 0.5f * b.x), w * ((0.0f + -0.5f * p0y) + 0.5f * b.y),
+                             w * ((0.0f + -0.5f * p0z) + 0.5f * b.z)};
 }
 
 // Constraints.cpp:186-203
@@ -142,7 +142,7 @@ template <bool VOLUME> PIES_DEV void tet_project(const TetFrame& t, float lo, fl
   }
 }
 // contribution_i = w * (A^T p)_i with p = (0, Fh[0], Fh[1], Fh[2]), Fh = U diag(s) V^T
-PIES_DEV void tet_emit(const TetFrame& t, const float s[3], float w, float4* __restrict__ contrib, uint32_t count, uint32_t c) {
+PIES_DEV void tet_emit(const TetFrame& t, const float s[3], float w, Vec3f* __restrict__ contrib, uint32_t count, uint32_t c) {
   float Fh[3][3];
   svd3_recompose(t.d, s, Fh);
   // A[1+r][0] = ((0 + -q_r0) + -q_r1) + -q_r2 ; A[1+r][1+c] = q_rc with q_rc = Qinv[r][c] (reference's row-major read)
@@ -158,13 +158,13 @@ PIES_DEV void tet_emit(const TetFrame& t, const float s[3], float w, float4* __r
     for (int cc = 0; cc < 3; ++cc) out[1 + cc][k] = ((0.0f + t.qi[0][cc] * Fh[0][k]) + t.qi[1][cc] * Fh[1][k]) + t.qi[2][cc] * Fh[2][k];
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) contrib[i * count + c] = make_float4(w * out[i][0], w * out[i][1], w * out[i][2], 0.0f);
+  for (int i = 0; i < 4; ++i) contrib[i * count + c] = Vec3f{w * out[i][0], w * out[i][1], w * out[i][2]};
 }
 
 template <bool VOLUME>
 __global__ void __launch_bounds__(kBlock) k_pd_local_tet(const float4* __restrict__ pos, const uint4* __restrict__ ids,
                                                          const float4* __restrict__ q0, const float4* __restrict__ q1,
-                                                         const float4* __restrict__ q2, float4* __restrict__ contrib,
+                                                         const float4* __restrict__ q2, Vec3f* __restrict__ contrib,
                                                          uint32_t count) {
   const uint32_t c = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
   if (c >= count) return;
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(kBlock) k_pd_local_tet(const float4* __restric
 __global__ void __launch_bounds__(kBlock) k_pd_local_tet_pair(const float4* __restrict__ pos, const uint4* __restrict__ ids,
                                                               const float4* __restrict__ q0, const float4* __restrict__ q1,
                                                               const float4* __restrict__ q2, const float4* __restrict__ vq2,
-                                                              float4* __restrict__ contribTet, float4* __restrict__ contribVol,
+                                                              Vec3f* __restrict__ contribTet, Vec3f* __restrict__ contribVol,
                                                               uint32_t count) {
   const uint32_t c = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
   if (c >= count) return;
@@ -210,7 +210,7 @@ PIES_DEV V3 divv(const V3& a, float s) { return {a.x / s, a.y / s, a.z / s}; }
 PIES_DEV V3 negv(const V3& a) { return {-a.x, -a.y, -a.z}; }
 
 __global__ void __launch_bounds__(kBlock) k_pd_local_bend(const float4* __restrict__ pos, const uint4* __restrict__ ids,
-                                                          const float2* __restrict__ angle_w, float4* __restrict__ contrib,
+                                                          const float2* __restrict__ angle_w, Vec3f* __restrict__ contrib,
                                                           uint32_t count) {
   const uint32_t c = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
   if (c >= count) return;
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(kBlock) k_pd_local_bend(const float4* __restri
   }
   const float w = aw.y;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) contrib[i * count + c] = make_float4(w * pr[i].x, w * pr[i].y, w * pr[i].z, 0.0f);
+  for (int i = 0; i < 4; ++i) contrib[i * count + c] = Vec3f{w * pr[i].x, w * pr[i].y, w * pr[i].z};
 }
 
 // ShapeMatchingConstraint::projectToAuxiliaryVariable (ShapeMatchingConstraint.cpp:96-122), one workgroup
@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(kBlock) k_pd_local_shape(const float4* __restr
 // (position, distance, tet, volume, bend, ... then the floor contacts), so the float sum is the reference's.
 // Also evaluates the floor projection (CollisionConstraint.cpp:447-455: clamps to y >= 0, not floorHeight).
 // ------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_pd_rhs(const float4* __restrict__ msn, const float4* __restrict__ contrib,
+__global__ void __launch_bounds__(kBlock) k_pd_rhs(const float4* __restrict__ msn, const Vec3f* __restrict__ contrib,
                                                    const uint32_t* __restrict__ incPtr, const uint32_t* __restrict__ incSlot,
                                                    const double4* __restrict__ contribD, const uint32_t* __restrict__ incPtrD,
                                                    const uint32_t* __restrict__ incSlotD, const float4* __restrict__ pos,
@@ -356,33 +356,31 @@ __global__ void __launch_bounds__(kBlock) k_pd_rhs(const float4* __restrict__ ms
                                                    float4* __restrict__ rhs, const uint32_t* __restrict__ tIncCnt,
                                                    const uint32_t* __restrict__ tIncStart, const uint32_t* __restrict__ tInc,
                                                    const float4* __restrict__ tContrib, uint32_t n) {
-  // 16 lanes per node: the slot indices and the contribution records of 16 slots are fetched in parallel,
-  // transposed through LDS and added one after the other in slot order by the group's first lane (the
-  // reference's float summation order).  (Measured: 1 lane/node 60 us, 16 lanes + shuffles 39 us, this
-  // 24 us at 100k nodes; visiting nodes in Morton order was slower than index order.)
+  // 16 lanes per node: lane `sub` adds up the records sub, sub + 16, ... of the node's slot list (slot indices and
+  // records of 16 slots are in flight at once), then the 16 partial sums are combined pairwise.  The reference adds
+  // the same terms one after the other; the difference is fp32 rounding of a ~50-term sum (PD parity is by
+  // tolerance).  (Measured at 100k nodes: 1 lane/node 60 us; 16 lanes with the terms added in
+  // list order by one lane 24 us; visiting nodes in Morton order was slower than index order.)
   const uint32_t i = (xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x) >> 4, sub = threadIdx.x & 15;
   const bool live = i < n;
   float4 f = live ? msn[i] : make_float4(0.f, 0.f, 0.f, 0.f);
   const uint32_t b = live ? incPtr[i] : 0u, e = live ? incPtr[i + 1] : 0u;
-  __shared__ float4 stage[kBlock];  // one 16-record strip per group, transposed through LDS
-  float4* strip = stage + (threadIdx.x & ~15u);
-  for (uint32_t k0 = b; k0 < e; k0 += 16) {
-    const uint32_t k = k0 + sub;
-    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k < e) c = contrib[incSlot[k]];
-    strip[sub] = c;
-    __builtin_amdgcn_wave_barrier();  // a group lives inside one wave; its LDS accesses execute in order
-    if (sub == 0) {
-      const uint32_t m = min(16u, e - k0);
-      for (uint32_t j = 0; j < m; ++j) {
-        const float4 v = strip[j];
-        f.x += v.x;
-        f.y += v.y;
-        f.z += v.z;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  for (uint32_t k = b + sub; k < e; k += 16) {
+    const Vec3f c = contrib[incSlot[k]];
+    ax += c.x;
+    ay += c.y;
+    az += c.z;
   }
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) {
+    ax += __shfl_xor(ax, off, 16);
+    ay += __shfl_xor(ay, off, 16);
+    az += __shfl_xor(az, off, 16);
+  }
+  f.x += ax;
+  f.y += ay;
+  f.z += az;
   if (!live || sub != 0) return;
   if (incPtrD) {  // shape then goal matching: force += float w * double projection (ShapeMatchingConstraint.cpp:58-72,147-161)
     const uint32_t ed = incPtrD[i + 1];
@@ -785,12 +783,12 @@ void launch_pd_predict(hipStream_t st, const NodeArrays& nd, const PdArrays& pd,
   hipLaunchKernelGGL(k_pd_predict, grid_for(nd.n), dim3(kBlock), 0, st, nd.pos, nd.vel, pd.msn, pd.triCount, pd.nstatic, pd.kdiag,
                      pd.cg.cdiag, pd.cg.dinv, nd.n, h, h * h, contactHeight);
 }
-void launch_pd_local_distance(hipStream_t st, const float4* pos, const uint2* ids, const float2* rw, float4* contrib, uint32_t count) {
+void launch_pd_local_distance(hipStream_t st, const float4* pos, const uint2* ids, const float2* rw, Vec3f* contrib, uint32_t count) {
   if (count == 0) return;
   hipLaunchKernelGGL(k_pd_local_distance, grid_for(count), dim3(kBlock), 0, st, pos, ids, rw, contrib, count);
 }
 void launch_pd_local_tet(hipStream_t st, bool volume, const float4* pos, const uint4* ids, const float4* q0, const float4* q1,
-                         const float4* q2, float4* contrib, uint32_t count) {
+                         const float4* q2, Vec3f* contrib, uint32_t count) {
   if (count == 0) return;
   if (volume) hipLaunchKernelGGL(k_pd_local_tet<true>, grid_for(count), dim3(kBlock), 0, st, pos, ids, q0, q1, q2, contrib, count);
   else hipLaunchKernelGGL(k_pd_local_tet<false>, grid_for(count), dim3(kBlock), 0, st, pos, ids, q0, q1, q2, contrib, count);
@@ -801,11 +799,11 @@ void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd) {
                      pd.incSlotD, nd.pos, pd.nstatic, pd.statp, pd.rhs, pd.cg.tIncCnt, pd.cg.tIncStart, pd.cg.tInc, pd.tContrib, nd.n);
 }
 void launch_pd_local_tet_pair(hipStream_t st, const float4* pos, const uint4* ids, const float4* q0, const float4* q1, const float4* q2,
-                              const float4* vq2, float4* contribTet, float4* contribVol, uint32_t count) {
+                              const float4* vq2, Vec3f* contribTet, Vec3f* contribVol, uint32_t count) {
   if (count == 0) return;
   hipLaunchKernelGGL(k_pd_local_tet_pair, grid_for(count), dim3(kBlock), 0, st, pos, ids, q0, q1, q2, vq2, contribTet, contribVol, count);
 }
-void launch_pd_local_bend(hipStream_t st, const float4* pos, const uint4* ids, const float2* angle_w, float4* contrib, uint32_t count) {
+void launch_pd_local_bend(hipStream_t st, const float4* pos, const uint4* ids, const float2* angle_w, Vec3f* contrib, uint32_t count) {
   if (count == 0) return;
   hipLaunchKernelGGL(k_pd_local_bend, grid_for(count), dim3(kBlock), 0, st, pos, ids, angle_w, contrib, count);
 }

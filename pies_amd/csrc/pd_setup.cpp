@@ -151,11 +151,10 @@ int pd_build(pies_solver* s) {
   for (uint32_t id : s->h_triangles) ++triCount[id];
 
   // position constraints project to a constant: w * (A^T B p) = w * (0 + 1*target)
-  std::vector<float4> contrib0(cnt[0]);
+  std::vector<Vec3f> contrib0(cnt[0]);
   for (uint32_t c = 0; c < cnt[0]; ++c) {
     const HostPosition& p = s->h_position[c];
-    contrib0[c] = make_float4(p.w * (0.0f + 1.0f * p.target[0]), p.w * (0.0f + 1.0f * p.target[1]),
-                              p.w * (0.0f + 1.0f * p.target[2]), 0.f);
+    contrib0[c] = Vec3f{p.w * (0.0f + 1.0f * p.target[0]), p.w * (0.0f + 1.0f * p.target[1]), p.w * (0.0f + 1.0f * p.target[2])};
   }
 
   // ---- HBM ---------------------------------------------------------------------------------------------
@@ -263,7 +262,7 @@ int pd_build(pies_solver* s) {
     pd.tContrib = T.contrib;
   }
   if (!contrib0.empty())
-    HIP_TRY(s, hipMemcpyAsync(pd.contrib + s->slotBase[0], contrib0.data(), contrib0.size() * sizeof(float4),
+    HIP_TRY(s, hipMemcpyAsync(pd.contrib + s->slotBase[0], contrib0.data(), contrib0.size() * sizeof(Vec3f),
                               hipMemcpyHostToDevice, s->stream));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   return pd_upload_goals(s);
