@@ -4,7 +4,7 @@
 # command uses --steps 12 --warmup 2; PIES_PROFILER_SAFE=1 keeps the library from creating a second graph.
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/${1:-r01}; mkdir -p $OUT
-B="--no-cpu-baseline --no-exact --no-extras"
+B="--no-cpu-baseline --no-exact --no-extras --no-scale"
 echo "== plain"; timeout 300 python bench.py --steps 200 --warmup 20 $B > $OUT/bench_plain.json 2> $OUT/bench_plain.err; tail -c 600 $OUT/bench_plain.json; echo
 export PIES_PROFILER_SAFE=1
 echo "== kernel trace"; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 12 --warmup 2 $B > $OUT/bench_traced.json 2> $OUT/trace.err; echo rc=$?
