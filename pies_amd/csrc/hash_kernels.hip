@@ -21,6 +21,7 @@
 // in lane (= bucket) order, re-testing the remaining candidates after each resolve because the visiting
 // node has moved.  The per-pair arithmetic is the reference's, operation for operation.
 #include <cstdint>
+#include <cstdlib>
 
 #include "cell_table.h"
 #include "hash_kernels.h"
@@ -150,94 +151,253 @@ PIES_DEV float ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED
 PIES_DEV void st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 PIES_DEV float bcast(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 
-__global__ void __launch_bounds__(kBlock) k_collide(HashArrays H, float4* pos4, float4* vel4, const float* __restrict__ radius,
-                                                    uint32_t pass, float friction, float staticThreshold) {
+// One resolved pair (Solver.cpp:92-125), wave uniform.  (pi, vi) is the visiting node, (pj, wj) the other node's
+// state before the pair; `self` marks the node meeting itself (quirk Q3).  On return (oj, vj) is the other node's
+// new state (for a self pair it has already been folded into pi, vi).
+struct PairState {
+  float pix, piy, piz, vix, viy, viz;
+};
+PIES_DEV void resolve_pair(PairState& a, float imi, bool self, float hdx, float hdy, float hdz, float hdist, float hdisp, float himj,
+                           float pjx, float pjy, float pjz, float wjx, float wjy, float wjz, float friction, float staticThreshold,
+                           float& ojx, float& ojy, float& ojz, float& vjx, float& vjy, float& vjz) {
+  float ux = 1.0f, uy = 0.0f, uz = 0.0f;
+  if (hdist > 0.00001f) { ux = hdx / hdist; uy = hdy / hdist; uz = hdz / hdist; }
+  const float wSum = imi + himj;
+  const float sa = 0.85f * -hdisp, sb = 0.85f * hdisp;
+  // node.position += 0.85f * -disp * dir * node.invMass / wSum
+  a.pix += ((sa * ux) * imi) / wSum; a.piy += ((sa * uy) * imi) / wSum; a.piz += ((sa * uz) * imi) / wSum;
+  // other.position += 0.85f * disp * dir * other.invMass / wSum   (other may be the node itself)
+  ojx = self ? a.pix : pjx; ojy = self ? a.piy : pjy; ojz = self ? a.piz : pjz;
+  ojx += ((sb * ux) * himj) / wSum; ojy += ((sb * uy) * himj) / wSum; ojz += ((sb * uz) * himj) / wSum;
+  // friction on the velocities
+  vjx = self ? a.vix : wjx; vjy = self ? a.viy : wjy; vjz = self ? a.viz : wjz;
+  const float rx = vjx - a.vix, ry = vjy - a.viy, rz = vjz - a.viz;
+  const float rd = rx * ux + ry * uy + rz * uz;
+  const float qx = rx - rd * ux, qy = ry - rd * uy, qz = rz - rd * uz;
+  float fr = friction;
+  if (sqrtf(qx * qx + qy * qy + qz * qz) < staticThreshold) fr = 1.0f;
+  a.vix += ((-fr * qx) * imi) / wSum; a.viy += ((-fr * qy) * imi) / wSum; a.viz += ((-fr * qz) * imi) / wSum;
+  if (self) {
+    a.pix = ojx; a.piy = ojy; a.piz = ojz;
+    a.vix += ((fr * qx) * himj) / wSum; a.viy += ((fr * qy) * himj) / wSum; a.viz += ((fr * qz) * himj) / wSum;
+  } else {
+    vjx += ((fr * qx) * himj) / wSum; vjy += ((fr * qy) * himj) / wSum; vjz += ((fr * qz) * himj) / wSum;
+  }
+}
+
+// Resolve of one group straight from global memory: every candidate's state is fetched again for every visiting
+// node.  Only used for groups whose neighbourhood does not fit the LDS staging of k_collide (dense pile-ups).
+PIES_DEV uint32_t collide_group_global(const HashArrays& H, float* pos, float* vel, const float* __restrict__ radius, uint32_t gslot,
+                                       int lane, float friction, float staticThreshold) {
+  uint32_t resolved = 0;
+  const uint32_t gs = H.gstart[gslot], gc = H.gcnt[gslot];
+  for (uint32_t k = 0; k < gc; ++k) {
+    const uint32_t i = H.groupSorted[gs + k];
+    PairState a = {ld(pos + 4 * i), ld(pos + 4 * i + 1), ld(pos + 4 * i + 2), ld(vel + 4 * i), ld(vel + 4 * i + 1), ld(vel + 4 * i + 2)};
+    const float imi = ld(pos + 4 * i + 3);
+    const float ri = radius[i];
+    const int4 rg = H.rng[i];
+    const uint32_t lx = rg.w & 0xff, ly = (rg.w >> 8) & 0xff, lz = (rg.w >> 16) & 0xff;
+    for (uint32_t dx = 0; dx < lx; ++dx)
+      for (uint32_t dy = 0; dy < ly; ++dy)
+        for (uint32_t dz = 0; dz < lz; ++dz) {
+          const uint32_t cs = find_cell(H.keys, H.mask, pack_cell(rg.x + (int)dx, rg.y + (int)dy, rg.z + (int)dz));
+          if (cs == 0xffffffffu) continue;
+          const uint32_t bs = H.start[cs], bc = H.cnt[cs];
+          for (uint32_t base = 0; base < bc; base += 64) {
+            const bool valid = base + lane < bc;
+            const uint32_t j = valid ? H.bucketSorted[bs + base + lane] : 0xffffffffu;
+            float pjx = 0.f, pjy = 0.f, pjz = 0.f, imj = 1.f, rj = 0.f, wjx = 0.f, wjy = 0.f, wjz = 0.f;
+            if (valid) {  // candidate state up front: a resolve then needs no further loads
+              pjx = ld(pos + 4 * j); pjy = ld(pos + 4 * j + 1); pjz = ld(pos + 4 * j + 2); imj = ld(pos + 4 * j + 3);
+              wjx = ld(vel + 4 * j); wjy = ld(vel + 4 * j + 1); wjz = ld(vel + 4 * j + 2);
+              rj = radius[j];
+            }
+            int cursor = 0;
+            for (;;) {
+              if (valid && j == i) { pjx = a.pix; pjy = a.piy; pjz = a.piz; }  // the self pair sees the node's current position
+              const float ddx = pjx - a.pix, ddy = pjy - a.piy, ddz = pjz - a.piz;
+              const float dist = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+              const float disp = ri + rj - dist;
+              const bool hit = valid && lane >= cursor && disp > 0.0f;
+              const unsigned long long m = __ballot(hit);
+              if (m == 0ull) break;
+              const int l = __builtin_ctzll(m);
+              const uint32_t hj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(j), l));
+              float ojx, ojy, ojz, vjx, vjy, vjz;
+              resolve_pair(a, imi, hj == i, bcast(ddx, l), bcast(ddy, l), bcast(ddz, l), bcast(dist, l), bcast(disp, l), bcast(imj, l),
+                           bcast(pjx, l), bcast(pjy, l), bcast(pjz, l), bcast(wjx, l), bcast(wjy, l), bcast(wjz, l), friction,
+                           staticThreshold, ojx, ojy, ojz, vjx, vjy, vjz);
+              if (hj != i && lane == l) {
+                st(pos + 4 * hj, ojx); st(pos + 4 * hj + 1, ojy); st(pos + 4 * hj + 2, ojz);
+                st(vel + 4 * hj, vjx); st(vel + 4 * hj + 1, vjy); st(vel + 4 * hj + 2, vjz);
+              }
+              ++resolved;
+              cursor = l + 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores are in L2 before its next loads
+          }
+        }
+    if (lane == 0) {
+      st(pos + 4 * i, a.pix); st(pos + 4 * i + 1, a.piy); st(pos + 4 * i + 2, a.piz);
+      st(vel + 4 * i, a.vix); st(vel + 4 * i + 1, a.viy); st(vel + 4 * i + 2, a.viz);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  return resolved;
+}
+
+// LDS staging of one group's neighbourhood.  All nodes of a group share their minimum cell, so everything they can
+// touch lies in the 2x2x2 cells above it: the distinct nodes of those buckets (typically ~100) are fetched ONCE
+// into a wave-private LDS table (open addressing on the node index), the visiting order of collide_group_global is
+// replayed on the LDS copies, and the touched nodes are written back at the end.  Same arithmetic, same order.
+constexpr int kColBlock = 128;            // two wavefronts, each with its own table
+constexpr uint32_t kColSlots = 512;       // table capacity per wavefront
+constexpr uint32_t kColMaxUnique = 256;   // live entries allowed (load factor 1/2)
+constexpr uint32_t kColMaxEntries = 1024; // bucket entries of the 8 cells
+constexpr uint32_t kColEmpty = 0xffffffffu, kColDirty = 0x80000000u;
+struct ColTable {
+  uint32_t key[kColSlots];  // node index | kColDirty
+  float px[kColSlots], py[kColSlots], pz[kColSlots], im[kColSlots], vx[kColSlots], vy[kColSlots], vz[kColSlots], r[kColSlots];
+  uint16_t ent[kColMaxEntries];  // table slot of every bucket entry, cell after cell
+};
+PIES_DEV uint32_t col_hash(uint32_t j) { return (j * 2654435761u) >> 23; }
+PIES_DEV uint32_t col_find(const uint32_t* key, uint32_t j) {  // j is present
+  uint32_t h = col_hash(j);
+  while ((key[h] & ~kColDirty) != j) h = (h + 1) & (kColSlots - 1);
+  return h;
+}
+
+__global__ void __launch_bounds__(kColBlock) k_collide(HashArrays H, float4* pos4, float4* vel4, const float* __restrict__ radius,
+                                                       uint32_t pass, float friction, float staticThreshold, int forceGlobal) {
+  __shared__ ColTable tables[kColBlock / 64];
+  ColTable& T = tables[threadIdx.x >> 6];
   float* pos = reinterpret_cast<float*>(pos4);
   float* vel = reinterpret_cast<float*>(vel4);
   const int lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
+  const uint32_t wave = (blockIdx.x * kColBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kColBlock) >> 6;
   if (H.counters[3]) return;  // failed: the host latches _simFailed
   const uint32_t ngroups = H.counters[4 + pass];
   uint32_t resolved = 0;  // statistics, one atomic per wave at the end (a per-pair atomic on one word serialises the chip)
   for (uint32_t g = wave; g < ngroups; g += nwaves) {
     const uint32_t gslot = H.passList[static_cast<size_t>(pass) * H.n + g];
     const uint32_t gs = H.gstart[gslot], gc = H.gcnt[gslot];
+    if (gc == 0) continue;
+    // ---- the 2x2x2 cells above the group's cell: lanes 0..7 look one up each ------------------------------
+    const int4 rg0 = H.rng[H.groupSorted[gs]];
+    uint32_t myStart = 0, myCnt = 0;
+    if (lane < 8) {
+      const uint32_t cs = find_cell(H.keys, H.mask, pack_cell(rg0.x + ((lane >> 2) & 1), rg0.y + ((lane >> 1) & 1), rg0.z + (lane & 1)));
+      if (cs != 0xffffffffu) { myStart = H.start[cs]; myCnt = H.cnt[cs]; }
+    }
+    uint32_t cStart[8], cCnt[8], cOff[9];
+    cOff[0] = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      cStart[c] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(myStart), c));
+      cCnt[c] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(myCnt), c));
+      cOff[c + 1] = cOff[c] + cCnt[c];
+    }
+    bool staged = !forceGlobal && cOff[8] <= kColMaxEntries;
+    if (staged) {
+      for (uint32_t t = lane; t < kColSlots; t += 64) T.key[t] = kColEmpty;
+      uint32_t unique = 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        for (uint32_t base = 0; base < cCnt[c] && staged; base += 64) {
+          bool fresh = false;
+          if (base + lane < cCnt[c]) {
+            const uint32_t j = H.bucketSorted[cStart[c] + base + lane];
+            uint32_t h = col_hash(j);
+            for (;;) {  // at most kColMaxUnique + 64 live entries: the probe ends
+              const uint32_t old = atomicCAS(&T.key[h], kColEmpty, j);
+              if (old == kColEmpty) { fresh = true; break; }
+              if (old == j) break;
+              h = (h + 1) & (kColSlots - 1);
+            }
+            T.ent[cOff[c] + base + lane] = static_cast<uint16_t>(h);
+          }
+          unique += static_cast<uint32_t>(__popcll(__ballot(fresh)));
+          if (unique > kColMaxUnique) staged = false;
+        }
+      }
+    }
+    if (!staged) {
+      resolved += collide_group_global(H, pos, vel, radius, gslot, lane, friction, staticThreshold);
+      continue;
+    }
+    for (uint32_t t = lane; t < kColSlots; t += 64) {
+      const uint32_t j = T.key[t];
+      if (j == kColEmpty) continue;
+      const float4 p = pos4[j], v = vel4[j];
+      T.px[t] = p.x; T.py[t] = p.y; T.pz[t] = p.z; T.im[t] = p.w;
+      T.vx[t] = v.x; T.vy[t] = v.y; T.vz[t] = v.z;
+      T.r[t] = radius[j];
+    }
+    // ---- the visiting order of collide_group_global on the staged copies -----------------------------------
     for (uint32_t k = 0; k < gc; ++k) {
       const uint32_t i = H.groupSorted[gs + k];
-      float pix = ld(pos + 4 * i), piy = ld(pos + 4 * i + 1), piz = ld(pos + 4 * i + 2);
-      const float imi = ld(pos + 4 * i + 3);
-      float vix = ld(vel + 4 * i), viy = ld(vel + 4 * i + 1), viz = ld(vel + 4 * i + 2);
-      const float ri = radius[i];
-      const int4 rg = H.rng[i];
-      const uint32_t lx = rg.w & 0xff, ly = (rg.w >> 8) & 0xff, lz = (rg.w >> 16) & 0xff;
+      const uint32_t si = col_find(T.key, i);
+      PairState a = {T.px[si], T.py[si], T.pz[si], T.vx[si], T.vy[si], T.vz[si]};
+      const float imi = T.im[si], ri = T.r[si];
+      const uint32_t rw = static_cast<uint32_t>(H.rng[i].w);
+      const uint32_t lx = rw & 0xff, ly = (rw >> 8) & 0xff, lz = (rw >> 16) & 0xff;
       for (uint32_t dx = 0; dx < lx; ++dx)
         for (uint32_t dy = 0; dy < ly; ++dy)
           for (uint32_t dz = 0; dz < lz; ++dz) {
-            const uint32_t cs = find_cell(H.keys, H.mask, pack_cell(rg.x + (int)dx, rg.y + (int)dy, rg.z + (int)dz));
-            if (cs == 0xffffffffu) continue;
-            const uint32_t bs = H.start[cs], bc = H.cnt[cs];
+            const uint32_t c = dx * 4 + dy * 2 + dz;
+            uint32_t off = 0, bc = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+              if (c == static_cast<uint32_t>(q)) { off = cOff[q]; bc = cCnt[q]; }
             for (uint32_t base = 0; base < bc; base += 64) {
               const bool valid = base + lane < bc;
-              const uint32_t j = valid ? H.bucketSorted[bs + base + lane] : 0xffffffffu;
+              const uint32_t sj = valid ? T.ent[off + base + lane] : 0u;
+              const uint32_t j = valid ? (T.key[sj] & ~kColDirty) : 0xffffffffu;
               float pjx = 0.f, pjy = 0.f, pjz = 0.f, imj = 1.f, rj = 0.f, wjx = 0.f, wjy = 0.f, wjz = 0.f;
-              if (valid) {  // candidate state up front: a resolve then needs no further loads
-                pjx = ld(pos + 4 * j); pjy = ld(pos + 4 * j + 1); pjz = ld(pos + 4 * j + 2); imj = ld(pos + 4 * j + 3);
-                wjx = ld(vel + 4 * j); wjy = ld(vel + 4 * j + 1); wjz = ld(vel + 4 * j + 2);
-                rj = radius[j];
+              if (valid) {
+                pjx = T.px[sj]; pjy = T.py[sj]; pjz = T.pz[sj]; imj = T.im[sj];
+                wjx = T.vx[sj]; wjy = T.vy[sj]; wjz = T.vz[sj];
+                rj = T.r[sj];
               }
               int cursor = 0;
               for (;;) {
-                if (valid && j == i) { pjx = pix; pjy = piy; pjz = piz; }  // the self pair sees the node's current position
-                const float ddx = pjx - pix, ddy = pjy - piy, ddz = pjz - piz;
+                if (valid && j == i) { pjx = a.pix; pjy = a.piy; pjz = a.piz; }  // the self pair sees the node's current position
+                const float ddx = pjx - a.pix, ddy = pjy - a.piy, ddz = pjz - a.piz;
                 const float dist = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
                 const float disp = ri + rj - dist;
                 const bool hit = valid && lane >= cursor && disp > 0.0f;
                 const unsigned long long m = __ballot(hit);
                 if (m == 0ull) break;
                 const int l = __builtin_ctzll(m);
-                // the hit pair, made wave uniform (Solver.cpp:92-125)
-                const float hdx = bcast(ddx, l), hdy = bcast(ddy, l), hdz = bcast(ddz, l);
-                const float hdist = bcast(dist, l), hdisp = bcast(disp, l), himj = bcast(imj, l);
                 const uint32_t hj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(j), l));
-                float ux = 1.0f, uy = 0.0f, uz = 0.0f;
-                if (hdist > 0.00001f) { ux = hdx / hdist; uy = hdy / hdist; uz = hdz / hdist; }
-                const float wSum = imi + himj;
-                const float sa = 0.85f * -hdisp, sb = 0.85f * hdisp;
-                // node.position += 0.85f * -disp * dir * node.invMass / wSum
-                pix += ((sa * ux) * imi) / wSum; piy += ((sa * uy) * imi) / wSum; piz += ((sa * uz) * imi) / wSum;
-                // other.position += 0.85f * disp * dir * other.invMass / wSum   (other may be the node itself)
-                float ojx = (hj == i) ? pix : bcast(pjx, l), ojy = (hj == i) ? piy : bcast(pjy, l), ojz = (hj == i) ? piz : bcast(pjz, l);
-                ojx += ((sb * ux) * himj) / wSum; ojy += ((sb * uy) * himj) / wSum; ojz += ((sb * uz) * himj) / wSum;
-                // friction on the velocities
-                float vjx = bcast(wjx, l), vjy = bcast(wjy, l), vjz = bcast(wjz, l);
-                if (hj == i) { vjx = vix; vjy = viy; vjz = viz; }
-                const float rx = vjx - vix, ry = vjy - viy, rz = vjz - viz;
-                const float rd = rx * ux + ry * uy + rz * uz;
-                const float qx = rx - rd * ux, qy = ry - rd * uy, qz = rz - rd * uz;
-                float fr = friction;
-                if (sqrtf(qx * qx + qy * qy + qz * qz) < staticThreshold) fr = 1.0f;
-                vix += ((-fr * qx) * imi) / wSum; viy += ((-fr * qy) * imi) / wSum; viz += ((-fr * qz) * imi) / wSum;
-                if (hj == i) {
-                  pix = ojx; piy = ojy; piz = ojz;
-                  vix += ((fr * qx) * himj) / wSum; viy += ((fr * qy) * himj) / wSum; viz += ((fr * qz) * himj) / wSum;
-                } else {
-                  vjx += ((fr * qx) * himj) / wSum; vjy += ((fr * qy) * himj) / wSum; vjz += ((fr * qz) * himj) / wSum;
-                  if (lane == l) {
-                    st(pos + 4 * hj, ojx); st(pos + 4 * hj + 1, ojy); st(pos + 4 * hj + 2, ojz);
-                    st(vel + 4 * hj, vjx); st(vel + 4 * hj + 1, vjy); st(vel + 4 * hj + 2, vjz);
-                  }
+                float ojx, ojy, ojz, vjx, vjy, vjz;
+                resolve_pair(a, imi, hj == i, bcast(ddx, l), bcast(ddy, l), bcast(ddz, l), bcast(dist, l), bcast(disp, l), bcast(imj, l),
+                             bcast(pjx, l), bcast(pjy, l), bcast(pjz, l), bcast(wjx, l), bcast(wjy, l), bcast(wjz, l), friction,
+                             staticThreshold, ojx, ojy, ojz, vjx, vjy, vjz);
+                if (hj != i && lane == l) {
+                  T.px[sj] = ojx; T.py[sj] = ojy; T.pz[sj] = ojz;
+                  T.vx[sj] = vjx; T.vy[sj] = vjy; T.vz[sj] = vjz;
+                  T.key[sj] = j | kColDirty;
                 }
                 ++resolved;
                 cursor = l + 1;
               }
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores are in L2 before its next loads
             }
           }
       if (lane == 0) {
-        st(pos + 4 * i, pix); st(pos + 4 * i + 1, piy); st(pos + 4 * i + 2, piz);
-        st(vel + 4 * i, vix); st(vel + 4 * i + 1, viy); st(vel + 4 * i + 2, viz);
+        T.px[si] = a.pix; T.py[si] = a.piy; T.pz[si] = a.piz;
+        T.vx[si] = a.vix; T.vy[si] = a.viy; T.vz[si] = a.viz;
+        T.key[si] = i | kColDirty;
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // ---- write the touched nodes back --------------------------------------------------------------------
+    for (uint32_t t = lane; t < kColSlots; t += 64) {
+      const uint32_t kj = T.key[t];
+      if (kj == kColEmpty || !(kj & kColDirty)) continue;
+      const uint32_t j = kj & ~kColDirty;
+      pos4[j] = make_float4(T.px[t], T.py[t], T.pz[t], T.im[t]);
+      vel[4 * j] = T.vx[t]; vel[4 * j + 1] = T.vy[t]; vel[4 * j + 2] = T.vz[t];
     }
   }
   if (lane == 0 && resolved) atomicAdd(&H.counters[31], resolved);
@@ -258,9 +418,10 @@ uint32_t launch_hash_build(hipStream_t st_, const HashArrays& H, const NodeArray
 
 uint32_t launch_collide(hipStream_t st_, const HashArrays& H, const NodeArrays& nd, float friction, float staticThreshold) {
   if (nd.n == 0) return 0;
-  const dim3 grid(std::max<uint32_t>(1u, std::min<uint32_t>(1024u, (nd.n / 8 + 3) / 4)));
+  const dim3 grid(std::max<uint32_t>(1u, std::min<uint32_t>(2048u, (nd.n / 8 + 1) / 2)));
+  static const int forceGlobal = [] { const char* e = std::getenv("PIES_COLLIDE_GLOBAL"); return e && e[0] == '1' ? 1 : 0; }();
   for (uint32_t pass = 0; pass < 27; ++pass)
-    hipLaunchKernelGGL(k_collide, grid, dim3(kBlock), 0, st_, H, nd.pos, nd.vel, nd.radius, pass, friction, staticThreshold);
+    hipLaunchKernelGGL(k_collide, grid, dim3(kColBlock), 0, st_, H, nd.pos, nd.vel, nd.radius, pass, friction, staticThreshold, forceGlobal);
   return 27;
 }
 

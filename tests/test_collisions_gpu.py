@@ -135,3 +135,20 @@ def test_config4_l500k_one_tick(pies, oracle):
     g, o = pair(pies, oracle, build, 4, 1)
     check(g, o)
     assert g.collision_pairs == o.collision_pairs > 1_000_000
+
+
+def test_dense_cells_take_the_unstaged_path(pies, oracle):
+    """More distinct nodes around one cell than the resolve kernel stages in LDS (256): those groups are resolved
+    straight from global memory, the others from LDS, inside the same passes; both must replay the same order."""
+    rng = np.random.default_rng(7)
+    dense = rng.uniform(0.05, 3.95, (700, 3)) + [0, 1.0, 0]       # ~90 nodes per 2^3 cell, ~700 around the middle ones
+    loose, _ = particles((5, 5, 5), y0=1.0)
+    p = np.concatenate([dense, loose + [8.0, 0, 0]]).astype(np.float32)
+    r = np.concatenate([np.full(len(dense), 0.12), np.full(len(loose), 0.5)]).astype(np.float32)
+    v = rng.uniform(-1, 1, p.shape).astype(np.float32)
+
+    def build(s):
+        s.add_nodes_raw(p, vel=v, radius=r, invMass=np.ones(len(p), np.float32))
+    g, o = pair(pies, oracle, build, 3, 2)
+    check(g, o)
+    assert g.collision_pairs == o.collision_pairs > 700
