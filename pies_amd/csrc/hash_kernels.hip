@@ -151,44 +151,60 @@ PIES_DEV float ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED
 PIES_DEV void st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 PIES_DEV float bcast(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 
-// One resolved pair (Solver.cpp:92-125), wave uniform.  (pi, vi) is the visiting node, (pj, wj) the other node's
-// state before the pair; `self` marks the node meeting itself (quirk Q3).  On return (oj, vj) is the other node's
-// new state (for a self pair it has already been folded into pi, vi).
+// One resolved pair (Solver.cpp:92-125).  Every argument is wave uniform: (pi, vi) is the visiting node, (pj, wj)
+// the other node's state before the pair; `self` marks the node meeting itself (quirk Q3).  On return (oj, vj) is
+// the other node's new state (for a self pair it has already been folded into pi, vi).
+// The pair needs 15 IEEE divisions; instead of every lane computing all of them, lane t computes one (the three
+// components of dir on lanes 0-2, then the twelve corrections `(coef * vec_k) * mass / wSum` on lanes 0-11) and the
+// quotients are broadcast: the same operations on the same operands, so the same bits.
 struct PairState {
   float pix, piy, piz, vix, viy, viz;
 };
+struct LaneRole {
+  int k3;    // component this lane divides
+  int kind;  // 0: node position, 1: other position, 2: node velocity, 3: other velocity
+};
+PIES_DEV float sel3(int k, float x, float y, float z) { return k == 0 ? x : (k == 1 ? y : z); }
 PIES_DEV void resolve_pair(PairState& a, float imi, bool self, float hdx, float hdy, float hdz, float hdist, float hdisp, float himj,
                            float pjx, float pjy, float pjz, float wjx, float wjy, float wjz, float friction, float staticThreshold,
-                           float& ojx, float& ojy, float& ojz, float& vjx, float& vjy, float& vjz) {
+                           const LaneRole role, float& ojx, float& ojy, float& ojz, float& vjx, float& vjy, float& vjz) {
   float ux = 1.0f, uy = 0.0f, uz = 0.0f;
-  if (hdist > 0.00001f) { ux = hdx / hdist; uy = hdy / hdist; uz = hdz / hdist; }
+  if (hdist > 0.00001f) {
+    const float quot = sel3(role.k3, hdx, hdy, hdz) / hdist;
+    ux = bcast(quot, 0); uy = bcast(quot, 1); uz = bcast(quot, 2);
+  }
   const float wSum = imi + himj;
   const float sa = 0.85f * -hdisp, sb = 0.85f * hdisp;
-  // node.position += 0.85f * -disp * dir * node.invMass / wSum
-  a.pix += ((sa * ux) * imi) / wSum; a.piy += ((sa * uy) * imi) / wSum; a.piz += ((sa * uz) * imi) / wSum;
-  // other.position += 0.85f * disp * dir * other.invMass / wSum   (other may be the node itself)
-  ojx = self ? a.pix : pjx; ojy = self ? a.piy : pjy; ojz = self ? a.piz : pjz;
-  ojx += ((sb * ux) * himj) / wSum; ojy += ((sb * uy) * himj) / wSum; ojz += ((sb * uz) * himj) / wSum;
-  // friction on the velocities
+  // friction works on the velocities as they are before the pair
   vjx = self ? a.vix : wjx; vjy = self ? a.viy : wjy; vjz = self ? a.viz : wjz;
   const float rx = vjx - a.vix, ry = vjy - a.viy, rz = vjz - a.viz;
   const float rd = rx * ux + ry * uy + rz * uz;
   const float qx = rx - rd * ux, qy = ry - rd * uy, qz = rz - rd * uz;
   float fr = friction;
-  if (sqrtf(qx * qx + qy * qy + qz * qz) < staticThreshold) fr = 1.0f;
-  a.vix += ((-fr * qx) * imi) / wSum; a.viy += ((-fr * qy) * imi) / wSum; a.viz += ((-fr * qz) * imi) / wSum;
+  if (staticThreshold > 0.0f)  // sqrt(x) < t is false for every t <= 0
+    if (sqrtf(qx * qx + qy * qy + qz * qz) < staticThreshold) fr = 1.0f;
+  const float vec = role.kind < 2 ? sel3(role.k3, ux, uy, uz) : sel3(role.k3, qx, qy, qz);
+  const float coef = role.kind == 0 ? sa : (role.kind == 1 ? sb : (role.kind == 2 ? -fr : fr));
+  const float mass = (role.kind & 1) ? himj : imi;
+  const float corr = ((coef * vec) * mass) / wSum;
+  // node.position += 0.85f * -disp * dir * node.invMass / wSum
+  a.pix += bcast(corr, 0); a.piy += bcast(corr, 1); a.piz += bcast(corr, 2);
+  // other.position += 0.85f * disp * dir * other.invMass / wSum   (other may be the node itself)
+  ojx = self ? a.pix : pjx; ojy = self ? a.piy : pjy; ojz = self ? a.piz : pjz;
+  ojx += bcast(corr, 3); ojy += bcast(corr, 4); ojz += bcast(corr, 5);
+  a.vix += bcast(corr, 6); a.viy += bcast(corr, 7); a.viz += bcast(corr, 8);
   if (self) {
     a.pix = ojx; a.piy = ojy; a.piz = ojz;
-    a.vix += ((fr * qx) * himj) / wSum; a.viy += ((fr * qy) * himj) / wSum; a.viz += ((fr * qz) * himj) / wSum;
+    a.vix += bcast(corr, 9); a.viy += bcast(corr, 10); a.viz += bcast(corr, 11);
   } else {
-    vjx += ((fr * qx) * himj) / wSum; vjy += ((fr * qy) * himj) / wSum; vjz += ((fr * qz) * himj) / wSum;
+    vjx += bcast(corr, 9); vjy += bcast(corr, 10); vjz += bcast(corr, 11);
   }
 }
 
 // Resolve of one group straight from global memory: every candidate's state is fetched again for every visiting
 // node.  Only used for groups whose neighbourhood does not fit the LDS staging of k_collide (dense pile-ups).
 PIES_DEV uint32_t collide_group_global(const HashArrays& H, float* pos, float* vel, const float* __restrict__ radius, uint32_t gslot,
-                                       int lane, float friction, float staticThreshold) {
+                                       int lane, const LaneRole role, float friction, float staticThreshold) {
   uint32_t resolved = 0;
   const uint32_t gs = H.gstart[gslot], gc = H.gcnt[gslot];
   for (uint32_t k = 0; k < gc; ++k) {
@@ -227,7 +243,7 @@ PIES_DEV uint32_t collide_group_global(const HashArrays& H, float* pos, float* v
               float ojx, ojy, ojz, vjx, vjy, vjz;
               resolve_pair(a, imi, hj == i, bcast(ddx, l), bcast(ddy, l), bcast(ddz, l), bcast(dist, l), bcast(disp, l), bcast(imj, l),
                            bcast(pjx, l), bcast(pjy, l), bcast(pjz, l), bcast(wjx, l), bcast(wjy, l), bcast(wjz, l), friction,
-                           staticThreshold, ojx, ojy, ojz, vjx, vjy, vjz);
+                           staticThreshold, role, ojx, ojy, ojz, vjx, vjy, vjz);
               if (hj != i && lane == l) {
                 st(pos + 4 * hj, ojx); st(pos + 4 * hj + 1, ojy); st(pos + 4 * hj + 2, ojz);
                 st(vel + 4 * hj, vjx); st(vel + 4 * hj + 1, vjy); st(vel + 4 * hj + 2, vjz);
@@ -275,6 +291,7 @@ __global__ void __launch_bounds__(kColBlock) k_collide(HashArrays H, float4* pos
   float* pos = reinterpret_cast<float*>(pos4);
   float* vel = reinterpret_cast<float*>(vel4);
   const int lane = threadIdx.x & 63;
+  const LaneRole role = {lane % 3, lane / 3};
   const uint32_t wave = (blockIdx.x * kColBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kColBlock) >> 6;
   if (H.counters[3]) return;  // failed: the host latches _simFailed
   const uint32_t ngroups = H.counters[4 + pass];
@@ -323,7 +340,7 @@ __global__ void __launch_bounds__(kColBlock) k_collide(HashArrays H, float4* pos
       }
     }
     if (!staged) {
-      resolved += collide_group_global(H, pos, vel, radius, gslot, lane, friction, staticThreshold);
+      resolved += collide_group_global(H, pos, vel, radius, gslot, lane, role, friction, staticThreshold);
       continue;
     }
     for (uint32_t t = lane; t < kColSlots; t += 64) {
@@ -374,7 +391,7 @@ __global__ void __launch_bounds__(kColBlock) k_collide(HashArrays H, float4* pos
                 float ojx, ojy, ojz, vjx, vjy, vjz;
                 resolve_pair(a, imi, hj == i, bcast(ddx, l), bcast(ddy, l), bcast(ddz, l), bcast(dist, l), bcast(disp, l), bcast(imj, l),
                              bcast(pjx, l), bcast(pjy, l), bcast(pjz, l), bcast(wjx, l), bcast(wjy, l), bcast(wjz, l), friction,
-                             staticThreshold, ojx, ojy, ojz, vjx, vjy, vjz);
+                             staticThreshold, role, ojx, ojy, ojz, vjx, vjy, vjz);
                 if (hj != i && lane == l) {
                   T.px[sj] = ojx; T.py[sj] = ojy; T.pz[sj] = ojz;
                   T.vx[sj] = vjx; T.vy[sj] = vjy; T.vz[sj] = vjz;
