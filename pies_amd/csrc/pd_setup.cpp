@@ -223,15 +223,9 @@ int pd_build(pies_solver* s) {
     TriArrays& T = pd.tri;
     T.nt = nt;
     T.threadCount = std::max(1u, s->opt.threadCount);
-    std::vector<uint32_t> order;  // the reference's merge order: thread t takes triangles t, t+T, ... (Solver.cpp:714,852)
-    order.reserve(nt);
-    for (uint32_t t = 0; t < T.threadCount; ++t)
-      for (uint32_t tri = t; tri < nt; tri += T.threadCount) order.push_back(tri);
-    uint32_t *d_tris, *d_order;
+    uint32_t* d_tris;
     if (int rc = upload(s, s->h_triangles, &d_tris)) return rc;
-    if (int rc = upload(s, order, &d_order)) return rc;
     T.tris = d_tris;
-    T.triOrder = d_order;
     uint32_t cap = 1024;
     while (cap < 2ull * kTriMaxEntries * nt && cap < (1u << 28)) cap <<= 1;
     T.capacity = cap;

@@ -16,7 +16,6 @@ struct TriArrays {
   uint32_t nt;           // surface triangles (0 = pipeline disabled)
   uint32_t threadCount;  // SolverOptions::threadCount: contacts are listed thread by thread (Solver.cpp:714,852)
   const uint32_t* tris;      // 3 node ids per triangle
-  const uint32_t* triOrder;  // triangles in the order the reference's merge visits them
   // triangle grid (exact-key cell table, world-unit cells)
   uint32_t capacity, mask;
   uint64_t* keys;
@@ -27,7 +26,7 @@ struct TriArrays {
   uint32_t *bucket, *bucketSorted;
   // contacts of the current substep, in the reference's list order
   uint32_t maxContacts;
-  uint32_t *cntTri, *offTri;
+  uint32_t *cntTri, *offTri;  // contacts per triangle and their list offsets, indexed by merge_rank(triangle)
   uint4* ids;        // a, b, c, d
   float4* contrib;   // 4 per contact: w * (AtA p)_i
   // per node: the contacts it takes part in, ascending (contact << 2 | local index)

@@ -227,12 +227,21 @@ __global__ void __launch_bounds__(kBlock) k_tri_sort(TriArrays T) {
   }
 }
 
+// Position of triangle t in the reference's merge order: thread (t mod T) owns triangles t, t + T, ... and the
+// per-thread lists are concatenated thread after thread (Solver.cpp:714, 852).  cntTri / offTri are indexed by it.
+PIES_DEV uint32_t merge_rank(uint32_t t, uint32_t nt, uint32_t threads) {
+  const uint32_t th = t % threads, q = nt / threads, rem = nt % threads;
+  return th * q + min(th, rem) + t / threads;
+}
+
 // ---- detection: one lane = one triangle (Solver.cpp:714-797); FILL = false counts, true writes -------------
 template <bool FILL>
 __global__ void __launch_bounds__(kBlock) k_tri_detect(TriArrays T, const float4* __restrict__ pos, const float4* __restrict__ prev,
                                                        float threshold) {
   const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= T.nt || T.counters[3]) return;
+  const uint32_t rank = merge_rank(t, T.nt, T.threadCount);
+  if (FILL && T.cntTri[rank] == 0u) return;  // nothing to write: the usual case
   const uint32_t ia[3] = {T.tris[3 * t], T.tris[3 * t + 1], T.tris[3 * t + 2]};
   F3 a1[3], a0[3];
 #pragma unroll
@@ -240,7 +249,7 @@ __global__ void __launch_bounds__(kBlock) k_tri_detect(TriArrays T, const float4
   const int4 rg = T.rng[t];
   const uint32_t lx = rg.w & 0xff, ly = (rg.w >> 8) & 0xff, lz = (rg.w >> 16) & 0xff;
   uint32_t count = 0;
-  const uint32_t base = FILL ? T.offTri[t] : 0u;
+  const uint32_t base = FILL ? T.offTri[rank] : 0u;
   for (uint32_t dx = 0; dx < lx; ++dx)
     for (uint32_t dy = 0; dy < ly; ++dy)
       for (uint32_t dz = 0; dz < lz; ++dz) {
@@ -267,7 +276,7 @@ __global__ void __launch_bounds__(kBlock) k_tri_detect(TriArrays T, const float4
           }
         }
       }
-  if (!FILL) T.cntTri[t] = count;
+  if (!FILL) T.cntTri[rank] = count;
 }
 
 // exclusive scan of the per-triangle counts in the reference's merge order (one block)
@@ -277,7 +286,8 @@ __global__ void __launch_bounds__(1024) k_tri_scan(TriArrays T) {
   const uint32_t chunk = (nt + 1023) / 1024;
   const uint32_t lo = tid * chunk, hi = min(nt, lo + chunk);
   uint32_t sum = 0;
-  for (uint32_t r = lo; r < hi; ++r) sum += T.cntTri[T.triOrder[r]];
+#pragma unroll 8
+  for (uint32_t r = lo; r < hi; ++r) sum += T.cntTri[r];
   part[tid] = sum;
   __syncthreads();
   for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
@@ -287,10 +297,12 @@ __global__ void __launch_bounds__(1024) k_tri_scan(TriArrays T) {
     __syncthreads();
   }
   uint32_t run = tid ? part[tid - 1] : 0u;
-  for (uint32_t r = lo; r < hi; ++r) {
-    const uint32_t t = T.triOrder[r];
-    T.offTri[t] = run;
-    run += T.cntTri[t];
+  if (sum == 0u) {  // no contacts in this chunk: offsets are never read (the fill pass skips empty triangles)
+  } else {
+    for (uint32_t r = lo; r < hi; ++r) {
+      T.offTri[r] = run;
+      run += T.cntTri[r];
+    }
   }
   if (tid == 1023) {
     const uint32_t total = part[1023];

@@ -2,9 +2,8 @@
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pd
 export PIES_PROFILER_SAFE=1
-timeout 200 python scratch/pd_bench.py 20 20 250 20 12
 timeout 200 python scratch/pd_bench.py 20 20 250 20 32
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pd/trace -- python scratch/pd_bench.py 20 20 250 6 3 > gpurun_out/pd/out.txt 2> gpurun_out/pd/err.txt; echo rc=$?
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pd/trace -- python scratch/pd_bench.py 20 20 250 6 32 > gpurun_out/pd/out.txt 2> gpurun_out/pd/err.txt; echo rc=$?
 find gpurun_out/pd -name "*kernel_trace.csv" -delete
 python - <<'PY'
 import csv, glob
