@@ -27,13 +27,14 @@ def main(rnd):
     src = os.path.join(ROOT, "gpurun_out", rnd)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
+    newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)  # gpurun merges runs into the same directory
+    stats = newest(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
     shutil.copy(stats, os.path.join(dst, "%s_kernel_stats.csv" % rnd))
     for f in ("bench_plain.json", "bench_traced.json"):
         shutil.copy(os.path.join(src, f), os.path.join(dst, "%s_%s" % (rnd, f)))
     counters = collections.defaultdict(lambda: collections.defaultdict(list))
     for kind in ("pmc_fetch", "pmc_write"):
-        for f in glob.glob(os.path.join(src, kind, "*", "*counter_collection.csv")):
+        for f in [newest(os.path.join(src, kind, "*", "*counter_collection.csv"))]:
             for r in csv.DictReader(open(f)):
                 counters[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     traffic = {}
