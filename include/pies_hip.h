@@ -201,7 +201,9 @@ enum { PIES_KERNEL_PREDICT = 0, PIES_KERNEL_POSITION = 1, PIES_KERNEL_DISTANCE =
        /* projective dynamics (Solver.cpp:228-485) */
        PIES_KERNEL_PD_PREDICT = 9, PIES_KERNEL_PD_LOCAL_DISTANCE = 10, PIES_KERNEL_PD_LOCAL_TET = 11,
        PIES_KERNEL_PD_LOCAL_VOLUME = 12, PIES_KERNEL_PD_RHS = 13, PIES_KERNEL_PD_SPMV = 14,
-       PIES_KERNEL_PD_CG_UPDATE = 15, PIES_KERNEL_PD_VELOCITY = 16, PIES_KERNEL_COUNT = 17 };
+       PIES_KERNEL_PD_CG_UPDATE = 15, PIES_KERNEL_PD_VELOCITY = 16,
+       /* schedule EXACT: one dependency level of the whole-substep DAG (all projection kinds + floor clamps) */
+       PIES_KERNEL_WAVE = 17, PIES_KERNEL_COUNT = 18 };
 int pies_profile_substep(pies_solver_t* s, int kernel, uint32_t* launches, double* total_ms, uint64_t* units);
 /* launches per substep of the captured graph, per kernel class (PIES_KERNEL_COUNT entries) */
 int pies_launch_counts(pies_solver_t* s, uint32_t* out);

@@ -110,7 +110,27 @@ static void enqueue_pbd_substep(pies_solver* s, int only, uint32_t* counts, uint
 
   if (ON(PIES_KERNEL_PREDICT)) { launch_predict(st, s->nd, dt, s->opt.gravity); U(s->nd.n); }
   C(PIES_KERNEL_PREDICT);
-  for (uint32_t it = 0; it < s->opt.iterations; ++it) {
+  if (s->wave.active) {  // schedule EXACT: the levels of the whole-substep DAG, cut by the collision passes
+    const WaveData W = {s->d_pc_id, s->d_pc_tw, s->d_dc_ids, s->d_dc_rw, s->d_tc_ids, s->d_tc_q0, s->d_tc_q1, s->d_tc_q2, s->d_bc_ids, s->d_bc_aw};
+    size_t barrier = 0;
+    auto collide = [&] {
+      uint32_t nb = 6, nc = 27;
+      if (ON(PIES_KERNEL_HASH)) { nb = launch_hash_build(st, s->hash, s->nd, s->opt.gridSpacing); U(s->nd.n); }
+      if (ON(PIES_KERNEL_COLLIDE)) { nc = launch_collide(st, s->hash, s->nd, s->opt.friction, s->opt.staticFrictionThreshold); U(s->nd.n); }
+      if (counts) { counts[PIES_KERNEL_HASH] += nb; counts[PIES_KERNEL_COLLIDE] += nc; }
+    };
+    for (size_t l = 0; l < s->wave.levels.size(); ++l) {
+      for (; barrier < s->wave.barrierAfter.size() && s->wave.barrierAfter[barrier] == l; ++barrier) collide();
+      const WaveLevel& L = s->wave.levels[l];
+      if (ON(PIES_KERNEL_WAVE)) {
+        launch_wave(st, s->nd, s->opt.floorHeight, s->d_waveIndex, L, W);
+        U((uint64_t)L.cnt[0] + L.cnt[1] + L.cnt[2] + L.cnt[3] + L.cnt[4]);
+      }
+      C(PIES_KERNEL_WAVE);
+    }
+    for (; barrier < s->wave.barrierAfter.size(); ++barrier) collide();
+  }
+  for (uint32_t it = 0; it < (s->wave.active ? 0u : s->opt.iterations); ++it) {  // one launch per batch, sweep after sweep
     if (!s->releaseHinge)
       for (const Batch& b : s->plan[PIES_POSITION].batches) {
         if (ON(PIES_KERNEL_POSITION)) { launch_position(st, s->nd.pos, s->d_pc_id, s->d_pc_tw, b.start, b.count); U(b.count); }
@@ -447,6 +467,9 @@ static int build_plans(pies_solver* s, int sched) {
   ids.resize(4 * s->h_bend.size());
   for (size_t i = 0; i < s->h_bend.size(); ++i) std::memcpy(&ids[4 * i], s->h_bend[i].ids, 16);
   build_plan({ids.data(), 4, (uint32_t)s->h_bend.size(), 0xF}, n, sched, s->plan[PIES_BEND]);
+  s->wave = WavePlan{};
+  const char* noWave = std::getenv("PIES_NO_WAVEFRONT");
+  if (sched == PIES_SCHEDULE_EXACT && !(noWave && noWave[0] == '1')) build_wave_plan(s, s->wave);
   return PIES_OK;
 }
 
@@ -551,6 +574,12 @@ int pies_finalize(pies_solver_t* s) {
     if (int rc = upload(s, id, &s->d_bc_ids)) return rc;
     if (int rc = upload(s, aw, &s->d_bc_aw)) return rc;
     HIP_TRY(s, hipStreamSynchronize(s->stream));
+  }
+  s->d_waveIndex = nullptr;
+  if (s->wave.active && !isPD) {
+    if (int rc = upload(s, s->wave.index, &s->d_waveIndex)) return rc;
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    std::vector<uint32_t>().swap(s->wave.index);  // the levels (offsets, counts) stay on the host; the items live in HBM
   }
   if (collide && n) {
     HashArrays& H = s->hash;

@@ -14,6 +14,25 @@ struct NodeArrays {
   uint32_t n;
 };
 
+// One dependency level of the whole-substep DAG of schedule EXACT (wavefront.cpp): items of kind k are
+// index[off[k] .. off[k] + cnt[k]), slots of the container arrays (node indices for the floor clamp).
+constexpr int kWaveKinds = 5;  // position, distance, tet, bend, floor clamp: the order tickPBD visits them
+struct WaveLevel {
+  uint32_t off[kWaveKinds];
+  uint32_t cnt[kWaveKinds];
+};
+struct WaveData {  // the containers' device arrays, in plan (slot) order
+  const uint32_t* pc_id;
+  const float4* pc_tw;
+  const uint2* dc_ids;
+  const float2* dc_rw;
+  const uint4* tc_ids;
+  const float4 *tc_q0, *tc_q1, *tc_q2;
+  const uint4* bc_ids;
+  const float2* bc_aw;
+};
+void launch_wave(hipStream_t st, const NodeArrays& nd, float floorHeight, const uint32_t* index, const WaveLevel& L, const WaveData& W);
+
 // Solver.cpp:47-52
 void launch_predict(hipStream_t st, const NodeArrays& nd, float dt, float gravity);
 // Solver.cpp:132-136

@@ -46,16 +46,19 @@ __global__ void __launch_bounds__(kBlock) k_predict(float4* __restrict__ pos, fl
 }
 
 // Solver.cpp:132-136
-__global__ void __launch_bounds__(kBlock) k_floor(float4* __restrict__ pos, const float* __restrict__ radius, uint32_t n,
-                                                  float floorHeight) {
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
+PIES_DEV void clamp_floor(float4* __restrict__ pos, const float* __restrict__ radius, uint32_t i, float floorHeight) {
   float4 p = pos[i];
   const float r = radius[i];
   if (p.y - r < floorHeight) {
     p.y = floorHeight + r;
     pos[i] = p;
   }
+}
+__global__ void __launch_bounds__(kBlock) k_floor(float4* __restrict__ pos, const float* __restrict__ radius, uint32_t n,
+                                                  float floorHeight) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  clamp_floor(pos, radius, i, floorHeight);
 }
 
 // Solver.cpp:140-158   v = (1-damping)*(pos-prev)/dt, floor friction with the hard-coded speed 5.0
@@ -86,11 +89,7 @@ __global__ void __launch_bounds__(kBlock) k_velocity(const float4* __restrict__ 
 // ----------------------------------------------------------------------------------------------
 // PositionConstraint (Constraints.cpp:58-63 through Constraints.h:121-129): pos += w*(fixed - pos)
 // ----------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kProjBlock) k_position(float4* __restrict__ pos, const uint32_t* __restrict__ ids,
-                                                     const float4* __restrict__ target_w, uint32_t start, uint32_t count) {
-  const uint32_t t = xcd_block(blockIdx.x, gridDim.x) * kProjBlock + threadIdx.x;
-  if (t >= count) return;
-  const uint32_t c = start + t;
+PIES_DEV void project_position(float4* __restrict__ pos, const uint32_t* __restrict__ ids, const float4* __restrict__ target_w, uint32_t c) {
   const uint32_t id = ids[c];
   const float4 tw = target_w[c];
   float4 p = pos[id];
@@ -99,16 +98,18 @@ __global__ void __launch_bounds__(kProjBlock) k_position(float4* __restrict__ po
   p.z += tw.w * (tw.z - p.z);
   pos[id] = p;
 }
+__global__ void __launch_bounds__(kProjBlock) k_position(float4* __restrict__ pos, const uint32_t* __restrict__ ids,
+                                                     const float4* __restrict__ target_w, uint32_t start, uint32_t count) {
+  const uint32_t t = xcd_block(blockIdx.x, gridDim.x) * kProjBlock + threadIdx.x;
+  if (t >= count) return;
+  project_position(pos, ids, target_w, start + t);
+}
 
 // ----------------------------------------------------------------------------------------------
 // DistanceConstraint (Constraints.cpp:11-37): only node a moves, by the full correction.
 // 52 algorithmic B/projection: ids 8 + rest,w 8 + two position reads 24 + one position write 12.
 // ----------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kProjBlock) k_distance(float4* __restrict__ pos, const uint2* __restrict__ ids,
-                                                     const float2* __restrict__ rest_w, uint32_t start, uint32_t count) {
-  const uint32_t t = xcd_block(blockIdx.x, gridDim.x) * kProjBlock + threadIdx.x;
-  if (t >= count) return;
-  const uint32_t c = start + t;
+PIES_DEV void project_distance(float4* __restrict__ pos, const uint2* __restrict__ ids, const float2* __restrict__ rest_w, uint32_t c) {
   const uint2 id = ids[c];
   const float2 rw = rest_w[c];
   float4 a = pos[id.x];
@@ -128,6 +129,12 @@ __global__ void __launch_bounds__(kProjBlock) k_distance(float4* __restrict__ po
   a.z += rw.y * (pz - a.z);
   pos[id.x] = a;
 }
+__global__ void __launch_bounds__(kProjBlock) k_distance(float4* __restrict__ pos, const uint2* __restrict__ ids,
+                                                     const float2* __restrict__ rest_w, uint32_t start, uint32_t count) {
+  const uint32_t t = xcd_block(blockIdx.x, gridDim.x) * kProjBlock + threadIdx.x;
+  if (t >= count) return;
+  project_distance(pos, ids, rest_w, start + t);
+}
 
 // ----------------------------------------------------------------------------------------------
 // TetrahedralConstraint (Constraints.cpp:76-128) applied as a PBD projection (Constraints.h:121-129).
@@ -135,12 +142,8 @@ __global__ void __launch_bounds__(kProjBlock) k_distance(float4* __restrict__ po
 // Record layout: q0 = Qinv col0 + Qinv[1][0], q1 = Qinv[1][1..2] + Qinv[2][0..1], q2 = Qinv[2][2], min, max, w.
 // ----------------------------------------------------------------------------------------------
 template <int VARIANT>
-__global__ void __launch_bounds__(kProjBlock) k_tet(float4* __restrict__ pos, const uint4* __restrict__ ids,
-                                                const float4* __restrict__ q0, const float4* __restrict__ q1,
-                                                const float4* __restrict__ q2, uint32_t start, uint32_t count) {
-  const uint32_t t = xcd_block(blockIdx.x, gridDim.x) * kProjBlock + threadIdx.x;
-  if (t >= count) return;
-  const uint32_t c = start + t;
+PIES_DEV void project_tet(float4* __restrict__ pos, const uint4* __restrict__ ids, const float4* __restrict__ q0,
+                          const float4* __restrict__ q1, const float4* __restrict__ q2, uint32_t c) {
   const uint4 id = ids[c];
   const float4 a0 = q0[c], a1 = q1[c], a2 = q2[c];
   float4 x1 = pos[id.x], x2 = pos[id.y], x3 = pos[id.z], x4 = pos[id.w];
@@ -192,6 +195,14 @@ __global__ void __launch_bounds__(kProjBlock) k_tet(float4* __restrict__ pos, co
   pos[id.z] = x3;
   pos[id.w] = x4;
 }
+template <int VARIANT>
+__global__ void __launch_bounds__(kProjBlock) k_tet(float4* __restrict__ pos, const uint4* __restrict__ ids,
+                                                const float4* __restrict__ q0, const float4* __restrict__ q1,
+                                                const float4* __restrict__ q2, uint32_t start, uint32_t count) {
+  const uint32_t t = xcd_block(blockIdx.x, gridDim.x) * kProjBlock + threadIdx.x;
+  if (t >= count) return;
+  project_tet<VARIANT>(pos, ids, q0, q1, q2, start + t);
+}
 
 // ----------------------------------------------------------------------------------------------
 // BendConstraint (Constraints.cpp:312-366): dihedral-angle projection, mass weighted.
@@ -209,11 +220,7 @@ PIES_DEV V3 mulv(const V3& a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 PIES_DEV V3 divv(const V3& a, float s) { return {a.x / s, a.y / s, a.z / s}; }
 PIES_DEV V3 negv(const V3& a) { return {-a.x, -a.y, -a.z}; }
 
-__global__ void __launch_bounds__(kProjBlock) k_bend(float4* __restrict__ pos, const uint4* __restrict__ ids,
-                                                 const float2* __restrict__ angle_w, uint32_t start, uint32_t count) {
-  const uint32_t t = xcd_block(blockIdx.x, gridDim.x) * kProjBlock + threadIdx.x;
-  if (t >= count) return;
-  const uint32_t c = start + t;
+PIES_DEV void project_bend(float4* __restrict__ pos, const uint4* __restrict__ ids, const float2* __restrict__ angle_w, uint32_t c) {
   const uint4 id = ids[c];
   const float2 aw = angle_w[c];
   float4 x1 = pos[id.x], x2 = pos[id.y], x3 = pos[id.z], x4 = pos[id.w];
@@ -248,8 +255,47 @@ __global__ void __launch_bounds__(kProjBlock) k_bend(float4* __restrict__ pos, c
   pos[id.z] = x3;
   pos[id.w] = x4;
 }
+__global__ void __launch_bounds__(kProjBlock) k_bend(float4* __restrict__ pos, const uint4* __restrict__ ids,
+                                                 const float2* __restrict__ angle_w, uint32_t start, uint32_t count) {
+  const uint32_t t = xcd_block(blockIdx.x, gridDim.x) * kProjBlock + threadIdx.x;
+  if (t >= count) return;
+  project_bend(pos, ids, angle_w, start + t);
+}
 
 // ----------------------------------------------------------------------------------------------
+// One dependency level of the whole-substep DAG (schedule EXACT, wavefront.cpp): the projections and floor clamps
+// whose predecessors in the reference's sequential order have all run, whatever their type or iteration.  Blocks
+// are homogeneous: the first ceil(cnt[0]/256) blocks run position projections, the next ones distance, ...
+// index[off[k] + t] is the slot of the t-th item of kind k (a node index for the floor clamp).
+// ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kProjBlock) k_wave(float4* __restrict__ pos, const float* __restrict__ radius, float floorHeight,
+                                                     const uint32_t* __restrict__ index, WaveLevel L, WaveData W) {
+  uint32_t b = blockIdx.x;
+#pragma unroll
+  for (int kind = 0; kind < kWaveKinds; ++kind) {
+    const uint32_t nb = (L.cnt[kind] + kProjBlock - 1) / kProjBlock;
+    if (b < nb) {
+      const uint32_t t = b * kProjBlock + threadIdx.x;
+      if (t >= L.cnt[kind]) return;
+      const uint32_t c = index[L.off[kind] + t];
+      if (kind == 0) project_position(pos, W.pc_id, W.pc_tw, c);
+      else if (kind == 1) project_distance(pos, W.dc_ids, W.dc_rw, c);
+      else if (kind == 2) project_tet<0>(pos, W.tc_ids, W.tc_q0, W.tc_q1, W.tc_q2, c);
+      else if (kind == 3) project_bend(pos, W.bc_ids, W.bc_aw, c);
+      else clamp_floor(pos, radius, c, floorHeight);
+      return;
+    }
+    b -= nb;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+void launch_wave(hipStream_t st, const NodeArrays& nd, float floorHeight, const uint32_t* index, const WaveLevel& L, const WaveData& W) {
+  uint32_t blocks = 0;
+  for (int kind = 0; kind < kWaveKinds; ++kind) blocks += (L.cnt[kind] + kProjBlock - 1) / kProjBlock;
+  if (blocks == 0) return;
+  hipLaunchKernelGGL(k_wave, dim3(blocks), dim3(kProjBlock), 0, st, nd.pos, nd.radius, floorHeight, index, L, W);
+}
 void launch_predict(hipStream_t st, const NodeArrays& nd, float dt, float gravity) {
   if (nd.n == 0) return;
   PIES_LAUNCH(k_predict, kBlock, nd.n, st, nd.pos, nd.prev, nd.vel, nd.n, dt, gravity);

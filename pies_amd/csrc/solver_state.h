@@ -69,6 +69,15 @@ struct Plan {
   std::vector<Batch> batches;
 };
 
+// Whole-substep dependency levels of schedule EXACT (wavefront.cpp)
+constexpr uint64_t kWaveMaxOps = 1ull << 27;  // 512 MB of level indices: beyond this the per-sweep levels are used
+struct WavePlan {
+  bool active = false;
+  std::vector<WaveLevel> levels;
+  std::vector<uint32_t> index;         // items of every level, kind after kind
+  std::vector<uint32_t> barrierAfter;  // with node-node collisions: the collision pass of iteration i runs after this many levels
+};
+
 template <class T> struct DevArray {
   T* p = nullptr;
   size_t n = 0;
@@ -110,6 +119,8 @@ struct pies_solver {
 
   // ---- plans ----
   pies::Plan plan[5];  // PIES_POSITION .. PIES_BEND
+  pies::WavePlan wave;  // schedule EXACT, PBD: levels of the whole-substep DAG
+  uint32_t* d_waveIndex = nullptr;
 
   // ---- HBM ----
   pies::NodeArrays nd{nullptr, nullptr, nullptr, nullptr, 0};
@@ -159,4 +170,5 @@ struct OpView {
   const uint16_t* hint = nullptr;  // optional proposed colouring (count entries)
 };
 void build_plan(const OpView& ops, uint32_t nodeCount, int schedule, Plan& out);
+bool build_wave_plan(const pies_solver* s, WavePlan& out);
 }  // namespace pies
