@@ -16,6 +16,15 @@ int main(int argc, char** argv) {
   uint32_t n, nd, nt; pies_count(s, PIES_NODES, &n); pies_count(s, PIES_DISTANCE, &nd); pies_count(s, PIES_TET, &nt);
   std::vector<uint32_t> di(2ull * nd), ti(4ull * nt);
   pies_get_ids(s, PIES_DISTANCE, di.data(), di.size()); pies_get_ids(s, PIES_TET, ti.data(), ti.size());
+  std::vector<uint32_t> od(nd), ot(nt);
+  if (argc > 4) {  // coloured order
+    pies_set_schedule(s, PIES_SCHEDULE_COLOURED);
+    pies_get_order(s, PIES_DISTANCE, od.data(), nd); pies_get_order(s, PIES_TET, ot.data(), nt);
+    std::vector<uint32_t> d2(di.size()), t2(ti.size());
+    for (uint32_t k = 0; k < nd; ++k) { d2[2*k] = di[2*od[k]]; d2[2*k+1] = di[2*od[k]+1]; }
+    for (uint32_t k = 0; k < nt; ++k) for (int j = 0; j < 4; ++j) t2[4*k+j] = ti[4*ot[k]+j];
+    di.swap(d2); ti.swap(t2);
+  }
   std::vector<uint32_t> lastW(n, 0), lastR(n, 0);
   uint32_t maxLevel = 0; uint64_t ops = 0;
   std::vector<uint32_t> hist;
