@@ -192,8 +192,8 @@ int pies_get_batches(pies_solver_t* s, int type, uint32_t* batch_offsets, uint32
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* Times one kernel class in isolation: a graph holding only that class's launches of one substep is
- * replayed a few times back to back and timed on the host clock (the launches form one dependent chain, so
- * time / launches is the per-launch device time including the kernel boundary).  Returns the launches
+ * replayed a few times back to back between two HIP events recorded on the solver's stream (the launches form
+ * one dependent chain, so time / launches is the per-launch device time including the kernel boundary).  Returns the launches
  * timed, the total milliseconds and the units (constraints or nodes) processed.  Perturbs the state. */
 enum { PIES_KERNEL_PREDICT = 0, PIES_KERNEL_POSITION = 1, PIES_KERNEL_DISTANCE = 2, PIES_KERNEL_TET = 3,
        PIES_KERNEL_BEND = 4, PIES_KERNEL_FLOOR = 5, PIES_KERNEL_VELOCITY = 6, PIES_KERNEL_HASH = 7,

@@ -874,30 +874,37 @@ int pies_profile_substep(pies_solver_t* s, int kernel, uint32_t* launches, doubl
     if (isPD) enqueue_pd_substep(s, kernel, nullptr, units_);
     else enqueue_pbd_substep(s, kernel, nullptr, units_);
   };
-  if (under_profiler()) {
-    // rocprofv3 7.2 segfaults on a second graph instantiation: launch eagerly (host-bound below ~3 us/launch)
+  // device time between two events recorded on the solver's stream, around the replays
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  HIP_TRY(s, hipEventCreate(&ev0));
+  HIP_TRY(s, hipEventCreate(&ev1));
+  hipGraph_t g = nullptr;
+  hipGraphExec_t ge = nullptr;
+  const bool eager = under_profiler();  // rocprofv3 7.2 segfaults on a second graph instantiation: launch eagerly there
+  if (eager) {
     enqueue_one(&u);
-    HIP_TRY(s, hipStreamSynchronize(s->stream));
-    const auto t0 = std::chrono::high_resolution_clock::now();
-    for (int r = 0; r < reps; ++r) enqueue_one(nullptr);
-    HIP_TRY(s, hipStreamSynchronize(s->stream));
-    ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
   } else {
-    hipGraph_t g = nullptr;
-    hipGraphExec_t ge = nullptr;
     HIP_TRY(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
     enqueue_one(&u);
     HIP_TRY(s, hipStreamEndCapture(s->stream, &g));
     HIP_TRY(s, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     HIP_TRY(s, hipGraphLaunch(ge, s->stream));  // warm
-    HIP_TRY(s, hipStreamSynchronize(s->stream));
-    const auto t0 = std::chrono::high_resolution_clock::now();
-    for (int r = 0; r < reps; ++r) HIP_TRY(s, hipGraphLaunch(ge, s->stream));
-    HIP_TRY(s, hipStreamSynchronize(s->stream));
-    ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
-    (void)hipGraphExecDestroy(ge);
-    (void)hipGraphDestroy(g);
   }
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  HIP_TRY(s, hipEventRecord(ev0, s->stream));
+  for (int r = 0; r < reps; ++r) {
+    if (eager) enqueue_one(nullptr);
+    else HIP_TRY(s, hipGraphLaunch(ge, s->stream));
+  }
+  HIP_TRY(s, hipEventRecord(ev1, s->stream));
+  HIP_TRY(s, hipEventSynchronize(ev1));
+  float evMs = 0.0f;
+  HIP_TRY(s, hipEventElapsedTime(&evMs, ev0, ev1));
+  ms = evMs;
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
+  if (ge) (void)hipGraphExecDestroy(ge);
+  if (g) (void)hipGraphDestroy(g);
   s->deviceAhead = true;
   uint32_t n = s->launchCounts[kernel];
   if (launches) *launches = n * reps;
