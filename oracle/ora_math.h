@@ -12,6 +12,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 
 namespace ora {
 
@@ -170,8 +171,26 @@ struct Svd3 {
   float b[3][3];  // b[i] = i-th column of A*V  (= s_i * u_i)
   float v[3][3];  // v[i] = i-th column of V
   float s[3];     // singular values (>= 0, unsorted)
+  float rs[3];    // 1 / s[i]
   int sweeps = 0;
 };
+
+// 1/sqrt(x) from an integer seed and three Newton steps (relative error ~1e-7).  Only *, fma and integer operations:
+// the same bits on any IEEE machine.  The SVD normalises with it instead of sqrt + division (the SVD is this
+// repository's own restatement of Eigen's JacobiSVD, see the header comment; nothing restated literally from the
+// reference uses it).
+inline float rsqrt_nr(float x) {
+  int32_t i;
+  std::memcpy(&i, &x, 4);
+  i = 0x5f3759df - (i >> 1);
+  float y;
+  std::memcpy(&y, &i, 4);
+  const float hx = 0.5f * x;
+  y = y * std::fmaf(-hx, y * y, 1.5f);
+  y = y * std::fmaf(-hx, y * y, 1.5f);
+  y = y * std::fmaf(-hx, y * y, 1.5f);
+  return y;
+}
 
 inline float dot3f(const float* x, const float* y) { return std::fmaf(x[2], y[2], std::fmaf(x[1], y[1], x[0] * y[0])); }
 
@@ -184,10 +203,11 @@ inline bool jacobi_pair(Svd3& d, int p, int q) {
   if (!(gamma * gamma > kSvdTol2 * (alpha * beta))) return false;
   const float delta = beta - alpha;
   const float g2 = gamma + gamma;
-  const float h = std::sqrt(std::fmaf(delta, delta, g2 * g2));
+  const float hw = std::fmaf(delta, delta, g2 * g2);
+  const float h = hw * rsqrt_nr(hw);
   const float c1 = h + std::fabs(delta);           // proportional to cos(theta)
   const float s1 = delta < 0.0f ? -g2 : g2;        // proportional to sin(theta)
-  const float inv = 1.0f / std::sqrt(std::fmaf(c1, c1, s1 * s1));
+  const float inv = rsqrt_nr(std::fmaf(c1, c1, s1 * s1));
   const float cs = c1 * inv, sn = s1 * inv;
   for (int k = 0; k < 3; ++k) {
     const float x = bp[k], y = bq[k];
@@ -214,7 +234,11 @@ inline Svd3 svd3(const float a[3][3]) {
     bool r12 = jacobi_pair(d, 1, 2);
     if (!(r01 || r02 || r12)) break;
   }
-  for (int i = 0; i < 3; ++i) d.s[i] = std::sqrt(dot3f(d.b[i], d.b[i]));
+  for (int i = 0; i < 3; ++i) {
+    const float n2 = dot3f(d.b[i], d.b[i]);
+    d.rs[i] = rsqrt_nr(n2);
+    d.s[i] = n2 * d.rs[i];
+  }
   return d;
 }
 
@@ -231,7 +255,7 @@ inline void svd3_recompose(const Svd3& d, const float snew[3], float out[3][3]) 
   for (int i = 0; i < 3; ++i) {
     ok[i] = d.s[i] > kSvdTiny;
     if (!ok[i]) ++nbad;
-    float g = ok[i] ? snew[i] / d.s[i] : 0.0f;
+    float g = ok[i] ? snew[i] * d.rs[i] : 0.0f;
     for (int k = 0; k < 3; ++k) t[i][k] = d.b[i][k] * g;
   }
   if (nbad == 1) {
