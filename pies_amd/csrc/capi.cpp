@@ -597,7 +597,8 @@ int pies_finalize(pies_solver_t* s) {
     if (int rc = dev_alloc(s, cap, &H.gstart, true)) return rc;
     if (int rc = dev_alloc(s, cap, &H.gfill, true)) return rc;
     if (int rc = dev_alloc(s, 8ull * n, &H.used, true)) return rc;
-    if (int rc = dev_alloc(s, 32, &H.counters, true)) return rc;
+    if (int rc = dev_alloc(s, kHashCounters, &H.counters, true)) return rc;
+    if (int rc = dev_alloc(s, cap, &H.done, true)) return rc;
     if (int rc = dev_alloc(s, 27ull * n, &H.passList, true)) return rc;
     if (int rc = dev_alloc(s, 8ull * n, &H.nodeSlot, true)) return rc;
     if (int rc = dev_alloc(s, n, &H.rng, true)) return rc;

@@ -47,6 +47,8 @@ __global__ void k_hash_zero(HashArrays H) {
   const uint32_t t = threadIdx.x;
   if (t < 3) H.counters[t] = 0;            // used, total entries, total grouped nodes
   if (t >= 4 && t < 4 + 27) H.counters[t] = 0;  // groups per pass      (counters[3] = sticky failure flag)
+  if (t == kCounterTicket) H.counters[t] = 0;   // k_collide_flow's work queue
+  if (t == kCounterEpoch) H.counters[t] += 1;   // completion stamps of earlier builds are stale by construction
 }
 
 // ---- count: NodeCompRange (Solver.cpp:877-901) + insertion into the cell table ---------------------
@@ -272,6 +274,7 @@ constexpr uint32_t kColSlots = 512;       // table capacity per wavefront
 constexpr uint32_t kColMaxUnique = 256;   // live entries allowed (load factor 1/2)
 constexpr uint32_t kColMaxEntries = 1024; // bucket entries of the 8 cells
 constexpr uint32_t kColEmpty = 0xffffffffu, kColDirty = 0x80000000u;
+constexpr uint32_t kColMaxSpins = 1u << 18;  // polls of one completion stamp before the wait is declared dead (~0.3 s)
 struct ColTable {
   uint32_t key[kColSlots];  // node index | kColDirty
   float px[kColSlots], py[kColSlots], pz[kColSlots], im[kColSlots], vx[kColSlots], vy[kColSlots], vz[kColSlots], r[kColSlots];
@@ -284,6 +287,133 @@ PIES_DEV uint32_t col_find(const uint32_t* key, uint32_t j) {  // j is present
   return h;
 }
 
+// One group on the staged path (or, for a dense neighbourhood, the unstaged one).  Node state is read and written
+// through agent-scope (sc1) loads and stores: in k_collide_flow the previous owner of a node may be a wavefront
+// of the same launch on another XCD.  Returns the number of resolved pairs.
+PIES_DEV uint32_t collide_group(const HashArrays& H, ColTable& T, float* pos, float* vel, const float* __restrict__ radius, uint32_t gslot,
+                                int lane, const LaneRole role, float friction, float staticThreshold, int forceGlobal) {
+  uint32_t resolved = 0;
+  const uint32_t gs = H.gstart[gslot], gc = H.gcnt[gslot];
+  if (gc == 0) return 0;
+  // ---- the 2x2x2 cells above the group's cell: lanes 0..7 look one up each ------------------------------
+  const int4 rg0 = H.rng[H.groupSorted[gs]];
+  uint32_t myStart = 0, myCnt = 0;
+  if (lane < 8) {
+    const uint32_t cs = find_cell(H.keys, H.mask, pack_cell(rg0.x + ((lane >> 2) & 1), rg0.y + ((lane >> 1) & 1), rg0.z + (lane & 1)));
+    if (cs != 0xffffffffu) { myStart = H.start[cs]; myCnt = H.cnt[cs]; }
+  }
+  uint32_t cStart[8], cCnt[8], cOff[9];
+  cOff[0] = 0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    cStart[c] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(myStart), c));
+    cCnt[c] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(myCnt), c));
+    cOff[c + 1] = cOff[c] + cCnt[c];
+  }
+  bool staged = !forceGlobal && cOff[8] <= kColMaxEntries;
+  if (staged) {
+    for (uint32_t t = lane; t < kColSlots; t += 64) T.key[t] = kColEmpty;
+    uint32_t unique = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      for (uint32_t base = 0; base < cCnt[c] && staged; base += 64) {
+        bool fresh = false;
+        if (base + lane < cCnt[c]) {
+          const uint32_t j = H.bucketSorted[cStart[c] + base + lane];
+          uint32_t h = col_hash(j);
+          for (;;) {  // at most kColMaxUnique + 64 live entries: the probe ends
+            const uint32_t old = atomicCAS(&T.key[h], kColEmpty, j);
+            if (old == kColEmpty) { fresh = true; break; }
+            if (old == j) break;
+            h = (h + 1) & (kColSlots - 1);
+          }
+          T.ent[cOff[c] + base + lane] = static_cast<uint16_t>(h);
+        }
+        unique += static_cast<uint32_t>(__popcll(__ballot(fresh)));
+        if (unique > kColMaxUnique) staged = false;
+      }
+    }
+  }
+  if (!staged) {
+    return collide_group_global(H, pos, vel, radius, gslot, lane, role, friction, staticThreshold);
+  }
+  for (uint32_t t = lane; t < kColSlots; t += 64) {
+    const uint32_t j = T.key[t];
+    if (j == kColEmpty) continue;
+    T.px[t] = ld(pos + 4 * j); T.py[t] = ld(pos + 4 * j + 1); T.pz[t] = ld(pos + 4 * j + 2); T.im[t] = ld(pos + 4 * j + 3);
+    T.vx[t] = ld(vel + 4 * j); T.vy[t] = ld(vel + 4 * j + 1); T.vz[t] = ld(vel + 4 * j + 2);
+    T.r[t] = radius[j];
+  }
+  // ---- the visiting order of collide_group_global on the staged copies -----------------------------------
+  for (uint32_t k = 0; k < gc; ++k) {
+    const uint32_t i = H.groupSorted[gs + k];
+    const uint32_t si = col_find(T.key, i);
+    PairState a = {T.px[si], T.py[si], T.pz[si], T.vx[si], T.vy[si], T.vz[si]};
+    const float imi = T.im[si], ri = T.r[si];
+    const uint32_t rw = static_cast<uint32_t>(H.rng[i].w);
+    const uint32_t lx = rw & 0xff, ly = (rw >> 8) & 0xff, lz = (rw >> 16) & 0xff;
+    for (uint32_t dx = 0; dx < lx; ++dx)
+      for (uint32_t dy = 0; dy < ly; ++dy)
+        for (uint32_t dz = 0; dz < lz; ++dz) {
+          const uint32_t c = dx * 4 + dy * 2 + dz;
+          uint32_t off = 0, bc = 0;
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (c == static_cast<uint32_t>(q)) { off = cOff[q]; bc = cCnt[q]; }
+          for (uint32_t base = 0; base < bc; base += 64) {
+            const bool valid = base + lane < bc;
+            const uint32_t sj = valid ? T.ent[off + base + lane] : 0u;
+            const uint32_t j = valid ? (T.key[sj] & ~kColDirty) : 0xffffffffu;
+            float pjx = 0.f, pjy = 0.f, pjz = 0.f, imj = 1.f, rj = 0.f, wjx = 0.f, wjy = 0.f, wjz = 0.f;
+            if (valid) {
+              pjx = T.px[sj]; pjy = T.py[sj]; pjz = T.pz[sj]; imj = T.im[sj];
+              wjx = T.vx[sj]; wjy = T.vy[sj]; wjz = T.vz[sj];
+              rj = T.r[sj];
+            }
+            int cursor = 0;
+            for (;;) {
+              if (valid && j == i) { pjx = a.pix; pjy = a.piy; pjz = a.piz; }  // the self pair sees the node's current position
+              const float ddx = pjx - a.pix, ddy = pjy - a.piy, ddz = pjz - a.piz;
+              const float dist = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+              const float disp = ri + rj - dist;
+              const bool hit = valid && lane >= cursor && disp > 0.0f;
+              const unsigned long long m = __ballot(hit);
+              if (m == 0ull) break;
+              const int l = __builtin_ctzll(m);
+              const uint32_t hj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(j), l));
+              float ojx, ojy, ojz, vjx, vjy, vjz;
+              resolve_pair(a, imi, hj == i, bcast(ddx, l), bcast(ddy, l), bcast(ddz, l), bcast(dist, l), bcast(disp, l), bcast(imj, l),
+                           bcast(pjx, l), bcast(pjy, l), bcast(pjz, l), bcast(wjx, l), bcast(wjy, l), bcast(wjz, l), friction,
+                           staticThreshold, role, ojx, ojy, ojz, vjx, vjy, vjz);
+              if (hj != i && lane == l) {
+                T.px[sj] = ojx; T.py[sj] = ojy; T.pz[sj] = ojz;
+                T.vx[sj] = vjx; T.vy[sj] = vjy; T.vz[sj] = vjz;
+                T.key[sj] = j | kColDirty;
+              }
+              ++resolved;
+              cursor = l + 1;
+            }
+          }
+        }
+    if (lane == 0) {
+      T.px[si] = a.pix; T.py[si] = a.piy; T.pz[si] = a.piz;
+      T.vx[si] = a.vix; T.vy[si] = a.viy; T.vz[si] = a.viz;
+      T.key[si] = i | kColDirty;
+    }
+  }
+  // ---- write the touched nodes back --------------------------------------------------------------------
+  for (uint32_t t = lane; t < kColSlots; t += 64) {
+    const uint32_t kj = T.key[t];
+    if (kj == kColEmpty || !(kj & kColDirty)) continue;
+    const uint32_t j = kj & ~kColDirty;
+    st(pos + 4 * j, T.px[t]); st(pos + 4 * j + 1, T.py[t]); st(pos + 4 * j + 2, T.pz[t]);
+    st(vel + 4 * j, T.vx[t]); st(vel + 4 * j + 1, T.vy[t]); st(vel + 4 * j + 2, T.vz[t]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the group's stores have left the wavefront
+  return resolved;
+}
+
+// The 27 residue classes as 27 launches: inside a launch no two groups share a node.
 __global__ void __launch_bounds__(kColBlock) k_collide(HashArrays H, float4* pos4, float4* vel4, const float* __restrict__ radius,
                                                        uint32_t pass, float friction, float staticThreshold, int forceGlobal) {
   __shared__ ColTable tables[kColBlock / 64];
@@ -296,126 +426,70 @@ __global__ void __launch_bounds__(kColBlock) k_collide(HashArrays H, float4* pos
   if (H.counters[3]) return;  // failed: the host latches _simFailed
   const uint32_t ngroups = H.counters[4 + pass];
   uint32_t resolved = 0;  // statistics, one atomic per wave at the end (a per-pair atomic on one word serialises the chip)
-  for (uint32_t g = wave; g < ngroups; g += nwaves) {
-    const uint32_t gslot = H.passList[static_cast<size_t>(pass) * H.n + g];
-    const uint32_t gs = H.gstart[gslot], gc = H.gcnt[gslot];
-    if (gc == 0) continue;
-    // ---- the 2x2x2 cells above the group's cell: lanes 0..7 look one up each ------------------------------
-    const int4 rg0 = H.rng[H.groupSorted[gs]];
-    uint32_t myStart = 0, myCnt = 0;
-    if (lane < 8) {
-      const uint32_t cs = find_cell(H.keys, H.mask, pack_cell(rg0.x + ((lane >> 2) & 1), rg0.y + ((lane >> 1) & 1), rg0.z + (lane & 1)));
-      if (cs != 0xffffffffu) { myStart = H.start[cs]; myCnt = H.cnt[cs]; }
-    }
-    uint32_t cStart[8], cCnt[8], cOff[9];
-    cOff[0] = 0;
+  for (uint32_t g = wave; g < ngroups; g += nwaves)
+    resolved += collide_group(H, T, pos, vel, radius, H.passList[static_cast<size_t>(pass) * H.n + g], lane, role, friction,
+                              staticThreshold, forceGlobal);
+  if (lane == 0 && resolved) atomicAdd(&H.counters[31], resolved);
+}
+
+// The same order of conflicting groups in ONE launch.  Groups are handed out through a ticket counter in pass-major
+// order; before a wavefront touches its group it waits until every group of an earlier pass within two cells (the
+// only ones that can share a node with it) has published its completion stamp.  A ticket's predecessors were all
+// taken earlier by wavefronts that are resident and running, so the wait always ends; it is bounded anyway and a
+// timeout latches the failure flag, which every wait loop polls.  Against the 27 launches this removes the barrier
+// after each pass (a pass lasted as long as its slowest group, with ~1.7 wavefronts per SIMD).
+PIES_DEV uint32_t ldu(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ void __launch_bounds__(kColBlock) k_collide_flow(HashArrays H, float4* pos4, float4* vel4, const float* __restrict__ radius,
+                                                            float friction, float staticThreshold, int forceGlobal) {
+  __shared__ ColTable tables[kColBlock / 64];
+  ColTable& T = tables[threadIdx.x >> 6];
+  float* pos = reinterpret_cast<float*>(pos4);
+  float* vel = reinterpret_cast<float*>(vel4);
+  const int lane = threadIdx.x & 63;
+  const LaneRole role = {lane % 3, lane / 3};
+  if (H.counters[3]) return;
+  const uint32_t epoch = H.counters[kCounterEpoch];
+  // inclusive prefix of the groups per pass, lane p holding pass p
+  uint32_t incl = lane < 27 ? H.counters[4 + lane] : 0u;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      cStart[c] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(myStart), c));
-      cCnt[c] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(myCnt), c));
-      cOff[c + 1] = cOff[c] + cCnt[c];
-    }
-    bool staged = !forceGlobal && cOff[8] <= kColMaxEntries;
-    if (staged) {
-      for (uint32_t t = lane; t < kColSlots; t += 64) T.key[t] = kColEmpty;
-      uint32_t unique = 0;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        for (uint32_t base = 0; base < cCnt[c] && staged; base += 64) {
-          bool fresh = false;
-          if (base + lane < cCnt[c]) {
-            const uint32_t j = H.bucketSorted[cStart[c] + base + lane];
-            uint32_t h = col_hash(j);
-            for (;;) {  // at most kColMaxUnique + 64 live entries: the probe ends
-              const uint32_t old = atomicCAS(&T.key[h], kColEmpty, j);
-              if (old == kColEmpty) { fresh = true; break; }
-              if (old == j) break;
-              h = (h + 1) & (kColSlots - 1);
-            }
-            T.ent[cOff[c] + base + lane] = static_cast<uint16_t>(h);
-          }
-          unique += static_cast<uint32_t>(__popcll(__ballot(fresh)));
-          if (unique > kColMaxUnique) staged = false;
-        }
+  for (int off = 1; off < 32; off <<= 1) {
+    const uint32_t v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  const uint32_t total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 26));
+  uint32_t resolved = 0;
+  for (;;) {
+    uint32_t ticket = 0;
+    if (lane == 0) ticket = atomicAdd(&H.counters[kCounterTicket], 1u);
+    ticket = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ticket)));
+    if (ticket >= total) break;
+    const uint32_t pass = static_cast<uint32_t>(__popcll(__ballot(lane < 27 && incl <= ticket)));
+    const uint32_t before = pass ? static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), pass - 1)) : 0u;
+    const uint32_t gslot = H.passList[static_cast<size_t>(pass) * H.n + (ticket - before)];
+    // ---- wait for the conflicting groups of earlier passes -------------------------------------------------
+    const uint64_t key = H.keys[gslot];
+    const int x = static_cast<int>((key >> 42) & 0x1fffff) - kCoordBias, y = static_cast<int>((key >> 21) & 0x1fffff) - kCoordBias,
+              z = static_cast<int>(key & 0x1fffff) - kCoordBias;
+    bool gaveUp = false;
+    for (int q = lane; q < 125; q += 64) {
+      const int dx = q % 5 - 2, dy = (q / 5) % 5 - 2, dz = q / 25 - 2;
+      if (dx == 0 && dy == 0 && dz == 0) continue;
+      const uint32_t other = static_cast<uint32_t>(mod3(x + dx) + 3 * mod3(y + dy) + 9 * mod3(z + dz));
+      if (other >= pass) continue;
+      const uint32_t os = find_cell(H.keys, H.mask, pack_cell(x + dx, y + dy, z + dz));
+      if (os == 0xffffffffu || H.gcnt[os] == 0u) continue;
+      uint32_t spins = 0;
+      while (ldu(H.done + os) != epoch) {
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 255u) == 0u && (spins > kColMaxSpins || ldu(H.counters + 3))) { gaveUp = true; break; }
       }
     }
-    if (!staged) {
-      resolved += collide_group_global(H, pos, vel, radius, gslot, lane, role, friction, staticThreshold);
-      continue;
+    if (__ballot(gaveUp)) {  // a predecessor never finished (or the simulation failed elsewhere): latch and leave
+      if (lane == 0) atomicOr(&H.counters[3], 8u);
+      break;
     }
-    for (uint32_t t = lane; t < kColSlots; t += 64) {
-      const uint32_t j = T.key[t];
-      if (j == kColEmpty) continue;
-      const float4 p = pos4[j], v = vel4[j];
-      T.px[t] = p.x; T.py[t] = p.y; T.pz[t] = p.z; T.im[t] = p.w;
-      T.vx[t] = v.x; T.vy[t] = v.y; T.vz[t] = v.z;
-      T.r[t] = radius[j];
-    }
-    // ---- the visiting order of collide_group_global on the staged copies -----------------------------------
-    for (uint32_t k = 0; k < gc; ++k) {
-      const uint32_t i = H.groupSorted[gs + k];
-      const uint32_t si = col_find(T.key, i);
-      PairState a = {T.px[si], T.py[si], T.pz[si], T.vx[si], T.vy[si], T.vz[si]};
-      const float imi = T.im[si], ri = T.r[si];
-      const uint32_t rw = static_cast<uint32_t>(H.rng[i].w);
-      const uint32_t lx = rw & 0xff, ly = (rw >> 8) & 0xff, lz = (rw >> 16) & 0xff;
-      for (uint32_t dx = 0; dx < lx; ++dx)
-        for (uint32_t dy = 0; dy < ly; ++dy)
-          for (uint32_t dz = 0; dz < lz; ++dz) {
-            const uint32_t c = dx * 4 + dy * 2 + dz;
-            uint32_t off = 0, bc = 0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-              if (c == static_cast<uint32_t>(q)) { off = cOff[q]; bc = cCnt[q]; }
-            for (uint32_t base = 0; base < bc; base += 64) {
-              const bool valid = base + lane < bc;
-              const uint32_t sj = valid ? T.ent[off + base + lane] : 0u;
-              const uint32_t j = valid ? (T.key[sj] & ~kColDirty) : 0xffffffffu;
-              float pjx = 0.f, pjy = 0.f, pjz = 0.f, imj = 1.f, rj = 0.f, wjx = 0.f, wjy = 0.f, wjz = 0.f;
-              if (valid) {
-                pjx = T.px[sj]; pjy = T.py[sj]; pjz = T.pz[sj]; imj = T.im[sj];
-                wjx = T.vx[sj]; wjy = T.vy[sj]; wjz = T.vz[sj];
-                rj = T.r[sj];
-              }
-              int cursor = 0;
-              for (;;) {
-                if (valid && j == i) { pjx = a.pix; pjy = a.piy; pjz = a.piz; }  // the self pair sees the node's current position
-                const float ddx = pjx - a.pix, ddy = pjy - a.piy, ddz = pjz - a.piz;
-                const float dist = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
-                const float disp = ri + rj - dist;
-                const bool hit = valid && lane >= cursor && disp > 0.0f;
-                const unsigned long long m = __ballot(hit);
-                if (m == 0ull) break;
-                const int l = __builtin_ctzll(m);
-                const uint32_t hj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(j), l));
-                float ojx, ojy, ojz, vjx, vjy, vjz;
-                resolve_pair(a, imi, hj == i, bcast(ddx, l), bcast(ddy, l), bcast(ddz, l), bcast(dist, l), bcast(disp, l), bcast(imj, l),
-                             bcast(pjx, l), bcast(pjy, l), bcast(pjz, l), bcast(wjx, l), bcast(wjy, l), bcast(wjz, l), friction,
-                             staticThreshold, role, ojx, ojy, ojz, vjx, vjy, vjz);
-                if (hj != i && lane == l) {
-                  T.px[sj] = ojx; T.py[sj] = ojy; T.pz[sj] = ojz;
-                  T.vx[sj] = vjx; T.vy[sj] = vjy; T.vz[sj] = vjz;
-                  T.key[sj] = j | kColDirty;
-                }
-                ++resolved;
-                cursor = l + 1;
-              }
-            }
-          }
-      if (lane == 0) {
-        T.px[si] = a.pix; T.py[si] = a.piy; T.pz[si] = a.piz;
-        T.vx[si] = a.vix; T.vy[si] = a.viy; T.vz[si] = a.viz;
-        T.key[si] = i | kColDirty;
-      }
-    }
-    // ---- write the touched nodes back --------------------------------------------------------------------
-    for (uint32_t t = lane; t < kColSlots; t += 64) {
-      const uint32_t kj = T.key[t];
-      if (kj == kColEmpty || !(kj & kColDirty)) continue;
-      const uint32_t j = kj & ~kColDirty;
-      pos4[j] = make_float4(T.px[t], T.py[t], T.pz[t], T.im[t]);
-      vel[4 * j] = T.vx[t]; vel[4 * j + 1] = T.vy[t]; vel[4 * j + 2] = T.vz[t];
-    }
+    resolved += collide_group(H, T, pos, vel, radius, gslot, lane, role, friction, staticThreshold, forceGlobal);
+    if (lane == 0) __hip_atomic_store(H.done + gslot, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (lane == 0 && resolved) atomicAdd(&H.counters[31], resolved);
 }
@@ -436,7 +510,13 @@ uint32_t launch_hash_build(hipStream_t st_, const HashArrays& H, const NodeArray
 uint32_t launch_collide(hipStream_t st_, const HashArrays& H, const NodeArrays& nd, float friction, float staticThreshold) {
   if (nd.n == 0) return 0;
   const dim3 grid(std::max<uint32_t>(1u, std::min<uint32_t>(2048u, (nd.n / 8 + 1) / 2)));
-  static const int forceGlobal = [] { const char* e = std::getenv("PIES_COLLIDE_GLOBAL"); return e && e[0] == '1' ? 1 : 0; }();
+  auto flag = [](const char* name) { const char* e = std::getenv(name); return e && e[0] == '1' ? 1 : 0; };
+  const int forceGlobal = flag("PIES_COLLIDE_GLOBAL");  // diagnostics, read when the substep is captured
+  const int passes = flag("PIES_COLLIDE_PASSES");
+  if (!passes) {
+    hipLaunchKernelGGL(k_collide_flow, grid, dim3(kColBlock), 0, st_, H, nd.pos, nd.vel, nd.radius, friction, staticThreshold, forceGlobal);
+    return 1;
+  }
   for (uint32_t pass = 0; pass < 27; ++pass)
     hipLaunchKernelGGL(k_collide, grid, dim3(kColBlock), 0, st_, H, nd.pos, nd.vel, nd.radius, pass, friction, staticThreshold, forceGlobal);
   return 27;

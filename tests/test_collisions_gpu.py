@@ -152,3 +152,25 @@ def test_dense_cells_take_the_unstaged_path(pies, oracle):
     g, o = pair(pies, oracle, build, 3, 2)
     check(g, o)
     assert g.collision_pairs == o.collision_pairs > 700
+
+
+def test_resolve_variants_agree(pies, monkeypatch):
+    """The product path resolves all 27 residue classes in one launch (tickets + completion stamps, LDS staging);
+    PIES_COLLIDE_PASSES=1 is the 27-launch form and PIES_COLLIDE_GLOBAL=1 the unstaged one.  The order of
+    conflicting groups is the same in all of them, so the results must be identical bit for bit."""
+    p, v = particles((9, 8, 10))
+
+    def run():
+        g = pies.Solver(scenes.pbd_options(pies, 3))
+        g.addNodes(p)
+        g.set_velocities(v)
+        g.tick(3)
+        return g.positions, g.velocities, g.collision_pairs, g.launch_counts()["collide"]
+    ref = run()
+    assert ref[3] == 3
+    for name in ("PIES_COLLIDE_PASSES", "PIES_COLLIDE_GLOBAL"):
+        monkeypatch.setenv(name, "1")
+        alt = run()
+        monkeypatch.delenv(name)
+        assert np.array_equal(ref[0], alt[0]) and np.array_equal(ref[1], alt[1]) and ref[2] == alt[2], name
+        assert alt[3] == (81 if name == "PIES_COLLIDE_PASSES" else 3)

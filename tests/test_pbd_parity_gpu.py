@@ -101,7 +101,7 @@ def test_exact_whole_substep_dag_equals_per_container_levels(pies, oracle, monke
     assert lc0["wave"] == 0 and lc1["wave"] > 0 and lc1["tet"] == 0
     # the collision passes cut the DAG once per iteration, so the saving is modest here (942 against 1536 launches)
     assert lc1["wave"] < lc0["distance"] + lc0["tet"] + lc0["bend"] + lc0["position"] + lc0["floor"]
-    assert lc1["collide"] == lc0["collide"] == 6 * 27
+    assert lc1["collide"] == lc0["collide"] == 6  # one resolve launch per iteration
 
 
 def test_coloured_batches_are_conflict_free(pies):
