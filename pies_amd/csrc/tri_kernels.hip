@@ -22,6 +22,7 @@
 namespace pies {
 
 constexpr int kBlock = 256;
+constexpr int kTriTeam = 16;  // lanes sharing one triangle's candidate list in the counting pass
 static inline dim3 grid_for(uint32_t n) { return dim3((n + kBlock - 1) / kBlock); }
 
 struct F3 {
@@ -234,12 +235,14 @@ PIES_DEV uint32_t merge_rank(uint32_t t, uint32_t nt, uint32_t threads) {
   return th * q + min(th, rem) + t / threads;
 }
 
-// ---- detection: one lane = one triangle (Solver.cpp:714-797); FILL = false counts, true writes -------------
-template <bool FILL>
+// ---- detection (Solver.cpp:714-797).  FILL = false counts a triangle's contacts with TEAM lanes sharing the bucket
+// entries (the count does not depend on the order); FILL = true writes them, one lane per triangle walking the
+// entries in the reference's order, and only for the few triangles that have any. ---------------------------------
+template <bool FILL, int TEAM>
 __global__ void __launch_bounds__(kBlock) k_tri_detect(TriArrays T, const float4* __restrict__ pos, const float4* __restrict__ prev,
                                                        float threshold) {
-  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= T.nt || T.counters[3]) return;
+  const uint32_t t = (blockIdx.x * kBlock + threadIdx.x) / TEAM, member = threadIdx.x % TEAM;
+  if (t >= T.nt || T.counters[3]) return;  // a team lies inside one wavefront and leaves as a whole
   const uint32_t rank = merge_rank(t, T.nt, T.threadCount);
   if (FILL && T.cntTri[rank] == 0u) return;  // nothing to write: the usual case
   const uint32_t ia[3] = {T.tris[3 * t], T.tris[3 * t + 1], T.tris[3 * t + 2]};
@@ -256,7 +259,7 @@ __global__ void __launch_bounds__(kBlock) k_tri_detect(TriArrays T, const float4
         const uint32_t s = find_cell(T.keys, T.mask, pack_cell(rg.x + (int)dx, rg.y + (int)dy, rg.z + (int)dz));
         if (s == 0xffffffffu) continue;
         const uint32_t bs = T.start[s], bc = T.cnt[s];
-        for (uint32_t k = 0; k < bc; ++k) {
+        for (uint32_t k = member; k < bc; k += TEAM) {
           const uint32_t o = T.bucketSorted[bs + k];
           const uint32_t ib = T.tris[3 * o], ic = T.tris[3 * o + 1], idd = T.tris[3 * o + 2];
           bool common = false;
@@ -265,8 +268,27 @@ __global__ void __launch_bounds__(kBlock) k_tri_detect(TriArrays T, const float4
           if (common) continue;
           const F3 b1 = xyz(pos[ib]), c1 = xyz(pos[ic]), d1 = xyz(pos[idd]);
           const F3 b0 = xyz(prev[ib]), c0 = xyz(prev[ic]), d0 = xyz(prev[idd]);
+          // Conservative reject before the CCD.  A hit puts the point, at some time in [0,1], within `threshold` of a
+          // point of the moving triangle (proximity branch: at t = 1; crossing branch: on it at the root), so the
+          // point's swept segment must meet the box of the triangle's six corner positions grown by the threshold;
+          // the margin adds 5 % and 1e-3 of the box on top of that, orders of magnitude above the rounding of the
+          // barycentric test.  A triangle with a vanishing normal (NaN inside the CCD, which then cannot say
+          // "outside") is never rejected here, nor is anything non-finite: every comparison below is false for NaN.
+          const F3 nn0 = cross(c0 - b0, d0 - b0), nn1 = cross(c1 - b1, d1 - b1);
+          const bool regular = dot(nn0, nn0) > 0.0f && dot(nn1, nn1) > 0.0f;
+          const F3 lo = {fminf(fminf(fminf(b0.x, c0.x), fminf(d0.x, b1.x)), fminf(c1.x, d1.x)),
+                         fminf(fminf(fminf(b0.y, c0.y), fminf(d0.y, b1.y)), fminf(c1.y, d1.y)),
+                         fminf(fminf(fminf(b0.z, c0.z), fminf(d0.z, b1.z)), fminf(c1.z, d1.z))};
+          const F3 hi = {fmaxf(fmaxf(fmaxf(b0.x, c0.x), fmaxf(d0.x, b1.x)), fmaxf(c1.x, d1.x)),
+                         fmaxf(fmaxf(fmaxf(b0.y, c0.y), fmaxf(d0.y, b1.y)), fmaxf(c1.y, d1.y)),
+                         fmaxf(fmaxf(fmaxf(b0.z, c0.z), fmaxf(d0.z, b1.z)), fmaxf(c1.z, d1.z))};
+          const float margin = 1.05f * threshold + 1.0e-3f * fmaxf(fmaxf(hi.x - lo.x, hi.y - lo.y), hi.z - lo.z);
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
+            const bool apart = (fmaxf(a0[i].x, a1[i].x) < lo.x - margin) || (fminf(a0[i].x, a1[i].x) > hi.x + margin) ||
+                               (fmaxf(a0[i].y, a1[i].y) < lo.y - margin) || (fminf(a0[i].y, a1[i].y) > hi.y + margin) ||
+                               (fmaxf(a0[i].z, a1[i].z) < lo.z - margin) || (fminf(a0[i].z, a1[i].z) > hi.z + margin);
+            if (regular && apart) continue;
             if (!point_triangle_ccd(a0[i] - b0, c0 - b0, d0 - b0, a1[i] - b1, c1 - b1, d1 - b1, threshold)) continue;
             if (FILL) {
               const uint32_t c = base + count;
@@ -276,7 +298,11 @@ __global__ void __launch_bounds__(kBlock) k_tri_detect(TriArrays T, const float4
           }
         }
       }
-  if (!FILL) T.cntTri[rank] = count;
+  if (!FILL) {
+#pragma unroll
+    for (int off = TEAM / 2; off >= 1; off >>= 1) count += __shfl_xor(count, off, TEAM);
+    if (member == 0) T.cntTri[rank] = count;
+  }
 }
 
 // exclusive scan of the per-triangle counts in the reference's merge order (one block)
@@ -470,9 +496,9 @@ uint32_t launch_tri_detect(hipStream_t st_, const TriArrays& T, const NodeArrays
   hipLaunchKernelGGL(k_tri_alloc, wide, blk, 0, st_, T);
   hipLaunchKernelGGL(k_tri_fill, grid_for(T.nt), blk, 0, st_, T);
   hipLaunchKernelGGL(k_tri_sort, wide, blk, 0, st_, T);
-  hipLaunchKernelGGL(k_tri_detect<false>, grid_for(T.nt), blk, 0, st_, T, nd.pos, nd.prev, threshold);
+  hipLaunchKernelGGL((k_tri_detect<false, kTriTeam>), grid_for(T.nt * kTriTeam), blk, 0, st_, T, nd.pos, nd.prev, threshold);
   hipLaunchKernelGGL(k_tri_scan, dim3(1), dim3(1024), 0, st_, T);
-  hipLaunchKernelGGL(k_tri_detect<true>, grid_for(T.nt), blk, 0, st_, T, nd.pos, nd.prev, threshold);
+  hipLaunchKernelGGL((k_tri_detect<true, 1>), grid_for(T.nt), blk, 0, st_, T, nd.pos, nd.prev, threshold);
   const dim3 cgrid(std::min<uint32_t>(256u, (T.maxContacts + kBlock - 1) / kBlock));
   hipLaunchKernelGGL(k_inc_count, cgrid, blk, 0, st_, T, cdiag);
   hipLaunchKernelGGL(k_inc_alloc, cgrid, blk, 0, st_, T, kdiag, cdiag, dinv);
