@@ -366,11 +366,19 @@ __global__ void __launch_bounds__(kBlock) k_pd_rhs(const float4* __restrict__ ms
   float4 f = live ? msn[i] : make_float4(0.f, 0.f, 0.f, 0.f);
   const uint32_t b = live ? incPtr[i] : 0u, e = live ? incPtr[i + 1] : 0u;
   float ax = 0.f, ay = 0.f, az = 0.f;
-  for (uint32_t k = b + sub; k < e; k += 16) {
-    const Vec3f c = contrib[incSlot[k]];
-    ax += c.x;
-    ay += c.y;
-    az += c.z;
+  for (uint32_t k = b + sub; k < e; k += 64) {  // four records per lane in flight: slot indices first, then the records
+    uint32_t slot[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) slot[u] = (k + 16u * u < e) ? incSlot[k + 16u * u] : 0xffffffffu;
+    Vec3f c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c[u] = (slot[u] != 0xffffffffu) ? contrib[slot[u]] : Vec3f{0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      ax += c[u].x;
+      ay += c[u].y;
+      az += c[u].z;
+    }
   }
 #pragma unroll
   for (int off = 8; off >= 1; off >>= 1) {
