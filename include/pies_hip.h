@@ -75,8 +75,13 @@ enum {
  *  EXACT    : dependency levels of the container order; bit-identical to processing the containers
  *             sequentially in the order the host added the constraints (the reference's semantics).
  *  COLOURED : greedy graph colouring; identical to a sequential sweep over the containers re-ordered
- *             colour by colour (pies_get_order returns that order).  Fewer, larger launches. */
-enum { PIES_SCHEDULE_EXACT = 0, PIES_SCHEDULE_COLOURED = 1 };
+ *             colour by colour (pies_get_order returns that order).  Fewer, larger launches.
+ *  LAYERED  : breadth-first levels of the constraint graph; the constraints between two adjacent levels are
+ *             swept colour by colour by one workgroup with the nodes resident in LDS (two launches per
+ *             iteration).  Identical to a sequential sweep in the order pies_get_order returns.  Falls back
+ *             to COLOURED when two adjacent levels do not fit in LDS (wide bodies) or node-node collisions
+ *             are on. */
+enum { PIES_SCHEDULE_EXACT = 0, PIES_SCHEDULE_COLOURED = 1, PIES_SCHEDULE_LAYERED = 2 };
 
 enum {
   PIES_FLAG_RELEASE_HINGE = 0,  /* Solver::releaseHinge (Solver.h:52, Solver.cpp:59) */
@@ -203,7 +208,10 @@ enum { PIES_KERNEL_PREDICT = 0, PIES_KERNEL_POSITION = 1, PIES_KERNEL_DISTANCE =
        PIES_KERNEL_PD_LOCAL_VOLUME = 12, PIES_KERNEL_PD_RHS = 13, PIES_KERNEL_PD_SPMV = 14,
        PIES_KERNEL_PD_CG_UPDATE = 15, PIES_KERNEL_PD_VELOCITY = 16,
        /* schedule EXACT: one dependency level of the whole-substep DAG (all projection kinds + floor clamps) */
-       PIES_KERNEL_WAVE = 17, PIES_KERNEL_COUNT = 18 };
+       PIES_KERNEL_WAVE = 17,
+       /* schedule LAYERED: the groups of one parity, LDS resident (units = algorithmic bytes of the projections and
+        * per-node steps the launches execute, SURVEY 8d figures) */
+       PIES_KERNEL_LAYER = 18, PIES_KERNEL_COUNT = 19 };
 int pies_profile_substep(pies_solver_t* s, int kernel, uint32_t* launches, double* total_ms, uint64_t* units);
 /* launches per substep of the captured graph, per kernel class (PIES_KERNEL_COUNT entries) */
 int pies_launch_counts(pies_solver_t* s, uint32_t* out);

@@ -14,14 +14,14 @@ LIB_PATH = os.path.join(HERE, "lib", "libpies_hip.so")
 OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(5)
 PBD, PD = 0, 1
 POSITION, DISTANCE, TET, VOLUME, BEND, SHAPE, GOAL, TRIANGLES, LINES, NODES = range(10)
-SCHEDULE_EXACT, SCHEDULE_COLOURED = 0, 1
+SCHEDULE_EXACT, SCHEDULE_COLOURED, SCHEDULE_LAYERED = 0, 1, 2
 FLAG_RELEASE_HINGE, FLAG_NODE_COLLISIONS, FLAG_TRIANGLE_COLLISIONS = 0, 1, 2
 NODE_POSITION, NODE_PREV_POSITION, NODE_VELOCITY, NODE_RADIUS, NODE_INV_MASS = range(5)
 KERNEL_NAMES = ["predict", "position", "distance", "tet", "bend", "floor", "velocity", "hash", "collide",
                 "pd_predict", "pd_local_distance", "pd_local_tet", "pd_local_volume", "pd_rhs", "pd_spmv", "pd_cg_update",
-                "pd_velocity", "wave"]
+                "pd_velocity", "wave", "layer"]
 KERNEL_PREDICT, KERNEL_POSITION, KERNEL_DISTANCE, KERNEL_TET, KERNEL_BEND, KERNEL_FLOOR, KERNEL_VELOCITY = range(7)
-KERNEL_COUNT = 18
+KERNEL_COUNT = 19
 SYSTEM_NNZ = 10
 
 # every symbol include/pies_hip.h declares (checked by tests/test_capi_symbols.py against the header)

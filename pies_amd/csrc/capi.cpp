@@ -51,6 +51,7 @@ static void free_device(pies_solver* s) {
   s->d_vc_ids = nullptr; s->d_vc_q0 = s->d_vc_q1 = s->d_vc_q2 = nullptr;
   s->pd = PdArrays{};
   s->hash = HashArrays{};
+  s->d_layer = LayerDevice{};
 }
 
 static int upload_nodes(pies_solver* s) {
@@ -66,6 +67,12 @@ static int upload_nodes(pies_solver* s) {
     HIP_TRY(s, hipMemcpyAsync(s->nd.prev, prev.data(), n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
     HIP_TRY(s, hipMemcpyAsync(s->nd.vel, vel.data(), n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
     HIP_TRY(s, hipMemcpyAsync(s->nd.radius, s->h_radius.data(), n * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    std::vector<float> lrad;
+    if (s->d_layer.lrad && s->layer.nodeList.size() == n) {  // schedule LAYERED keeps the radii in level order as well
+      lrad.resize(n);
+      for (uint32_t i = 0; i < n; ++i) lrad[i] = s->h_radius[s->layer.nodeList[i]];
+      HIP_TRY(s, hipMemcpyAsync(s->d_layer.lrad, lrad.data(), n * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    }
     HIP_TRY(s, hipStreamSynchronize(s->stream));  // the staging vectors die with this scope
   }
   s->hostNodesDirty = false;
@@ -99,6 +106,115 @@ int scene_sync_host(pies_solver* s) {
   return download_nodes(s);
 }
 
+// Schedule LAYERED: the substep as a list of layer launches (groups of one parity, LDS resident) and collision
+// passes.  Walks tickPBD's order (Solver.cpp:45-159) and packs consecutive steps that run on the same parity into
+// one launch: the distance container runs (even, odd), the tetrahedral one (odd, even), bend (even, odd), so an
+// iteration without bend constraints or collisions is two launches: [tet even of the previous iteration, floor
+// clamp, position, distance even] and [distance odd, tet odd].  Per-node steps run with whichever parity is current.
+struct LayerItem {
+  bool collide = false;
+  LayerLaunch launch{};
+  uint64_t bytes = 0;  // algorithmic bytes of the launch (SURVEY 8d per-unit figures)
+};
+static void build_layer_program(const pies_solver* s, std::vector<LayerItem>& prog) {
+  const LayerPlan& L = s->layer;
+  struct Step { uint32_t kind; int parity; int container; int phase; };
+  std::vector<Step> steps;
+  steps.push_back({LAYER_PREDICT, -1, -1, 0});
+  const bool collide = s->nodeCollisions;
+  for (uint32_t it = 0; it < s->opt.iterations; ++it) {
+    if (!s->releaseHinge && L.kind[PIES_POSITION].ncol[0]) steps.push_back({LAYER_POSITION, 0, PIES_POSITION, 0});
+    const int cont[3] = {PIES_DISTANCE, PIES_TET, PIES_BEND};
+    const uint32_t lk[3] = {LAYER_DISTANCE, LAYER_TET, LAYER_BEND};
+    for (int c = 0; c < 3; ++c)
+      for (int phase = 0; phase < 2; ++phase)
+        if (L.kind[cont[c]].ncol[phase]) steps.push_back({lk[c], (kLayerFirstParity[cont[c]] + phase) & 1, cont[c], phase});
+    if (collide) steps.push_back({0xFFFFFFFFu, -1, -1, 0});
+    steps.push_back({LAYER_FLOOR, -1, -1, 0});
+  }
+  steps.push_back({LAYER_VELOCITY, -1, -1, 0});
+
+  const uint64_t N = s->nd.n;
+  LayerItem cur;
+  bool open = false;
+  auto flush = [&] { if (open) prog.push_back(cur); open = false; cur = LayerItem{}; };
+  for (size_t i = 0; i < steps.size(); ++i) {
+    const Step& st = steps[i];
+    if (st.kind == 0xFFFFFFFFu) {
+      flush();
+      LayerItem c;
+      c.collide = true;
+      prog.push_back(c);
+      continue;
+    }
+    int q = st.parity;
+    if (open && (q < 0 || q == (int)cur.launch.parity) && cur.launch.nseg < (uint32_t)kLayerMaxSegs) {
+      q = cur.launch.parity;
+    } else {
+      flush();
+      if (q < 0) {  // a per-node step opens a launch: take the parity of the next container phase so that it can join
+        q = 0;
+        for (size_t j = i + 1; j < steps.size(); ++j) {
+          if (steps[j].kind == 0xFFFFFFFFu) break;
+          if (steps[j].parity >= 0) { q = steps[j].parity; break; }
+        }
+      }
+      open = true;
+      cur.launch.parity = (uint32_t)q;
+      cur.launch.groups = L.groups[q];
+      cur.launch.maxClass = 1;
+    }
+    LayerSeg& seg = cur.launch.seg[cur.launch.nseg++];
+    seg.kind = st.kind;
+    seg.ncol = 0;
+    seg.colOff = nullptr;
+    if (st.container >= 0) {
+      const LayerKind& K = L.kind[st.container];
+      seg.ncol = K.ncol[st.phase];
+      seg.colOff = s->d_layer.colOff[st.container][st.phase];
+      cur.launch.maxClass = std::max(cur.launch.maxClass, K.maxClass);
+      const uint64_t count = K.colOff[st.phase].back() - K.colOff[st.phase].front();
+      const uint64_t perUnit = st.container == PIES_POSITION ? 44 : st.container == PIES_DISTANCE ? 52 : st.container == PIES_TET ? 160 : 136;
+      cur.bytes += perUnit * count;
+    } else {
+      cur.bytes += (st.kind == LAYER_PREDICT ? 48u : st.kind == LAYER_FLOOR ? 20u : 40u) * N;
+    }
+  }
+  flush();
+  // the node array is the source of the first launch and of every launch after a collision pass, and the
+  // destination of the last launch and of every launch before a collision pass
+  for (size_t i = 0; i < prog.size(); ++i) {
+    if (prog[i].collide) continue;
+    prog[i].launch.loadGlobal = (i == 0 || prog[i - 1].collide) ? 1u : 0u;
+    prog[i].launch.storeGlobal = (i + 1 == prog.size() || prog[i + 1].collide) ? 1u : 0u;
+  }
+}
+
+static void enqueue_layered_substep(pies_solver* s, int only, uint32_t* counts, uint64_t* units) {
+  hipStream_t st = s->stream;
+  std::vector<LayerItem> prog;
+  build_layer_program(s, prog);
+  const LayerDevice& d = s->d_layer;
+  const LayerData D = {d.nodeList, {d.groupOff[0], d.groupOff[1]}, s->layer.maxGroupNodes, d.lpos, d.lrad, d.pc_lid, s->d_pc_tw, d.dc_lid, s->d_dc_rw,
+                       d.tc_lid, s->d_tc_q0, s->d_tc_q1, s->d_tc_q2, d.bc_lid, s->d_bc_aw};
+  const float dt = s->opt.fixedTimestepSize / s->opt.timeSubsteps;
+  const LayerParams P = {s->opt.floorHeight, dt, s->opt.gravity, s->opt.damping, s->opt.friction};
+  for (const LayerItem& item : prog) {
+    if (item.collide) {  // Solver.cpp:81-130
+      uint32_t nb = 6, nc = 27;
+      if (only < 0 || only == PIES_KERNEL_HASH) { nb = launch_hash_build(st, s->hash, s->nd, s->opt.gridSpacing); if (units) *units += s->nd.n; }
+      if (only < 0 || only == PIES_KERNEL_COLLIDE) { nc = launch_collide(st, s->hash, s->nd, s->opt.friction, s->opt.staticFrictionThreshold); if (units) *units += s->nd.n; }
+      if (counts) { counts[PIES_KERNEL_HASH] += nb; counts[PIES_KERNEL_COLLIDE] += nc; }
+      continue;
+    }
+    if (only < 0 || only == PIES_KERNEL_LAYER) {
+      launch_layer(st, s->nd, D, item.launch, P);
+      if (units) *units += item.bytes;
+    }
+    if (counts) ++counts[PIES_KERNEL_LAYER];
+  }
+}
+
 // One PBD substep as a launch sequence (Solver.cpp:45-159).  `timer`/`timedKernel` select one kernel
 // class for per-dispatch timing (profile pass); counts (optional) tallies launches per class.
 static void enqueue_pbd_substep(pies_solver* s, int only, uint32_t* counts, uint64_t* units = nullptr) {
@@ -108,6 +224,7 @@ static void enqueue_pbd_substep(pies_solver* s, int only, uint32_t* counts, uint
   auto ON = [&](int k) { return only < 0 || only == k; };  // profile pass: launch one kernel class only
   auto U = [&](uint64_t u) { if (units) *units += u; };
 
+  if (s->layer.active) { enqueue_layered_substep(s, only, counts, units); return; }
   if (ON(PIES_KERNEL_PREDICT)) { launch_predict(st, s->nd, dt, s->opt.gravity); U(s->nd.n); }
   C(PIES_KERNEL_PREDICT);
   if (s->wave.active) {  // schedule EXACT: the levels of the whole-substep DAG, cut by the collision passes
@@ -412,7 +529,7 @@ int pies_set_flag(pies_solver_t* s, int flag, int value) {
 
 int pies_set_schedule(pies_solver_t* s, int schedule) {
   if (!s) return PIES_ERR_INVALID;
-  if (schedule != PIES_SCHEDULE_EXACT && schedule != PIES_SCHEDULE_COLOURED) return fail(s, PIES_ERR_INVALID, "unknown schedule");
+  if (schedule != PIES_SCHEDULE_EXACT && schedule != PIES_SCHEDULE_COLOURED && schedule != PIES_SCHEDULE_LAYERED) return fail(s, PIES_ERR_INVALID, "unknown schedule");
   if (schedule != s->schedule) {
     if (int rc = scene_sync_host(s)) return rc;
     s->schedule = schedule;
@@ -449,6 +566,12 @@ int pies_get_pcg_stats(pies_solver_t* s, float* max_rel_residual, uint32_t* max_
 
 static int build_plans(pies_solver* s, int sched) {
   const uint32_t n = s->nodeCount();
+  s->layer = LayerPlan{};
+  s->wave = WavePlan{};
+  if (sched == PIES_SCHEDULE_LAYERED) {
+    if (build_layer_plan(s)) return PIES_OK;
+    sched = PIES_SCHEDULE_COLOURED;  // wide bodies (two levels do not fit in LDS), scenes without constraints
+  }
   std::vector<uint32_t> ids;
   ids.resize(s->h_position.size());
   for (size_t i = 0; i < ids.size(); ++i) ids[i] = s->h_position[i].id;
@@ -467,7 +590,6 @@ static int build_plans(pies_solver* s, int sched) {
   ids.resize(4 * s->h_bend.size());
   for (size_t i = 0; i < s->h_bend.size(); ++i) std::memcpy(&ids[4 * i], s->h_bend[i].ids, 16);
   build_plan({ids.data(), 4, (uint32_t)s->h_bend.size(), 0xF}, n, sched, s->plan[PIES_BEND]);
-  s->wave = WavePlan{};
   const char* noWave = std::getenv("PIES_NO_WAVEFRONT");
   if (sched == PIES_SCHEDULE_EXACT && !(noWave && noWave[0] == '1')) build_wave_plan(s, s->wave);
   return PIES_OK;
@@ -573,6 +695,41 @@ int pies_finalize(pies_solver_t* s) {
     }
     if (int rc = upload(s, id, &s->d_bc_ids)) return rc;
     if (int rc = upload(s, aw, &s->d_bc_aw)) return rc;
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+  }
+  if (s->layer.active && !isPD) {
+    const LayerPlan& L = s->layer;
+    LayerDevice& d = s->d_layer;
+    int maxLds = 0;
+    HIP_TRY(s, hipDeviceGetAttribute(&maxLds, hipDeviceAttributeMaxSharedMemoryPerBlock, s->device));
+    if (static_cast<size_t>(L.maxGroupNodes) * 20 + 4096 > static_cast<size_t>(maxLds))
+      return fail(s, PIES_ERR_UNSUPPORTED, "schedule LAYERED: the device's LDS is smaller than this build assumes");
+    HIP_TRY(s, layer_prepare(L.maxGroupNodes));
+    if (int rc = upload(s, L.nodeList, &d.nodeList)) return rc;
+    if (int rc = dev_alloc(s, L.nodeList.size(), &d.lpos, true)) return rc;
+    {
+      std::vector<float> lrad(L.nodeList.size());
+      for (size_t i = 0; i < lrad.size(); ++i) lrad[i] = s->h_radius[L.nodeList[i]];
+      if (int rc = upload(s, lrad, &d.lrad)) return rc;
+    }
+    for (int q = 0; q < 2; ++q)
+      if (int rc = upload(s, L.groupOff[q], &d.groupOff[q])) return rc;
+    for (int k = 0; k < 5; ++k)
+      for (int ph = 0; ph < 2; ++ph)
+        if (int rc = upload(s, L.kind[k].colOff[ph], &d.colOff[k][ph])) return rc;
+    if (int rc = upload(s, L.kind[PIES_POSITION].local, &d.pc_lid)) return rc;
+    {
+      const std::vector<uint32_t>& l = L.kind[PIES_DISTANCE].local;
+      std::vector<uint32_t> packed(l.size() / 2);
+      for (size_t k = 0; k < packed.size(); ++k) packed[k] = l[2 * k] | (l[2 * k + 1] << 16);
+      if (int rc = upload(s, packed, &d.dc_lid)) return rc;
+    }
+    for (int k : {PIES_TET, PIES_BEND}) {
+      const std::vector<uint32_t>& l = L.kind[k].local;
+      std::vector<uint2> packed(l.size() / 4);
+      for (size_t c = 0; c < packed.size(); ++c) packed[c] = make_uint2(l[4 * c] | (l[4 * c + 1] << 16), l[4 * c + 2] | (l[4 * c + 3] << 16));
+      if (int rc = upload(s, packed, k == PIES_TET ? &d.tc_lid : &d.bc_lid)) return rc;
+    }
     HIP_TRY(s, hipStreamSynchronize(s->stream));
   }
   s->d_waveIndex = nullptr;
@@ -857,7 +1014,8 @@ int pies_profile_substep(pies_solver_t* s, int kernel, uint32_t* launches, doubl
   if (!s || kernel < 0 || kernel >= PIES_KERNEL_COUNT) return PIES_ERR_INVALID;
   if (s->device == PIES_DEVICE_NONE) return fail(s, PIES_ERR_HIP, "host-only handle");
   const bool isPD = s->opt.solver == PIES_SOLVER_PD;
-  if (isPD != (kernel >= PIES_KERNEL_PD_PREDICT)) return fail(s, PIES_ERR_INVALID, "pies_profile_substep: kernel class of the other solver");
+  const bool pdClass = kernel >= PIES_KERNEL_PD_PREDICT && kernel <= PIES_KERNEL_PD_VELOCITY;
+  if (isPD != pdClass) return fail(s, PIES_ERR_INVALID, "pies_profile_substep: kernel class of the other solver");
   if (s->sceneDirty || s->hostNodesDirty)
     if (int rc = pies_finalize(s)) return rc;
   HIP_TRY(s, hipSetDevice(s->device));

@@ -33,6 +33,44 @@ struct WaveData {  // the containers' device arrays, in plan (slot) order
 };
 void launch_wave(hipStream_t st, const NodeArrays& nd, float floorHeight, const uint32_t* index, const WaveLevel& L, const WaveData& W);
 
+// Schedule LAYERED (layer_plan.cpp, layer_kernels.hip): one launch = the groups of one parity, one workgroup per
+// group with the group's node records in LDS, running a short list of segments (a container phase or a per-node
+// step) colour after colour.
+enum { LAYER_POSITION = 0, LAYER_DISTANCE = 1, LAYER_TET = 2, LAYER_BEND = 3, LAYER_FLOOR = 4, LAYER_PREDICT = 5, LAYER_VELOCITY = 6 };
+constexpr int kLayerMaxSegs = 6;
+constexpr int kLayerMaxCols = 128;  // colours of one segment inside a group (layer_plan.cpp gives up beyond)
+struct LayerSeg {
+  uint32_t kind;
+  uint32_t ncol;           // colours per group (0 for the per-node kinds)
+  const uint32_t* colOff;  // groups x (ncol+1) slot offsets
+};
+struct LayerLaunch {
+  uint32_t parity, groups, nseg, maxClass;
+  uint32_t loadGlobal, storeGlobal;  // node records from / to the node array instead of the layer-ordered copy
+  LayerSeg seg[kLayerMaxSegs];
+};
+struct LayerData {
+  const uint32_t* nodeList;
+  const uint32_t* groupOff[2];
+  uint32_t maxGroupNodes;
+  float4* lpos;       // node records in nodeList order: valid between the layer launches of a substep
+  const float* lrad;  // radii in nodeList order
+  const uint32_t* pc_lid;
+  const float4* pc_tw;
+  const uint32_t* dc_lid;
+  const float2* dc_rw;
+  const uint2* tc_lid;
+  const float4 *tc_q0, *tc_q1, *tc_q2;
+  const uint2* bc_lid;
+  const float2* bc_aw;
+};
+struct LayerParams {  // scalars of the per-node steps
+  float floorHeight, dt, gravity, damping, friction;
+};
+// Returns hipSuccess or the error of the attribute call that raises the kernel's LDS limit.
+hipError_t layer_prepare(uint32_t maxGroupNodes);
+void launch_layer(hipStream_t st, const NodeArrays& nd, const LayerData& D, const LayerLaunch& L, const LayerParams& P);
+
 // Solver.cpp:47-52
 void launch_predict(hipStream_t st, const NodeArrays& nd, float dt, float gravity);
 // Solver.cpp:132-136

@@ -78,6 +78,39 @@ struct WavePlan {
   std::vector<uint32_t> barrierAfter;  // with node-node collisions: the collision pass of iteration i runs after this many levels
 };
 
+// Schedule LAYERED (layer_plan.cpp): breadth-first levels of the constraint graph.  A constraint's nodes lie in
+// two adjacent levels, so the constraints whose lowest level is l ("group l") touch levels l and l+1 only and
+// groups of equal parity are independent: one workgroup sweeps one group with its nodes resident in LDS, colour
+// after colour (a colouring inside the group), and a container's sweep is two launches (even groups, odd groups).
+struct LayerKind {
+  uint32_t ncol[2] = {0, 0};         // colours per group in the container's first / second phase (padded to the max)
+  std::vector<uint32_t> colOff[2];   // per group of the phase's parity: ncol+1 absolute slot offsets
+  std::vector<uint32_t> local;       // stride x count group-local node indices (16 bit each), slot order
+  uint32_t maxClass = 0;             // largest colour class of any group
+};
+constexpr int kLayerFirstParity[5] = {0, 0, 1, 0, 0};  // parity of a container's first phase (POSITION, DISTANCE, TET, -, BEND)
+constexpr uint32_t kLayerMaxGroupNodes = 7936;         // 20 B per node (record + radius) + the colour offsets in the 160 KB LDS
+struct LayerPlan {
+  bool active = false;
+  uint32_t levels = 0;
+  uint32_t groups[2] = {0, 0};        // even groups cover levels (2g, 2g+1); odd groups (2g-1, 2g), group 0 = level 0 alone
+  uint32_t maxGroupNodes = 0;
+  std::vector<uint32_t> nodeList;     // node ids sorted by (level, id)
+  std::vector<uint32_t> groupOff[2];  // per parity: groups+1 offsets into nodeList
+  LayerKind kind[5];                  // indexed by PIES_POSITION .. PIES_BEND (PIES_VOLUME unused)
+};
+struct LayerDevice {
+  uint32_t* nodeList = nullptr;
+  float4* lpos = nullptr;
+  float* lrad = nullptr;
+  uint32_t* groupOff[2] = {nullptr, nullptr};
+  uint32_t* colOff[5][2] = {};
+  uint32_t* pc_lid = nullptr;  // 1 x 16 bit in a word
+  uint32_t* dc_lid = nullptr;  // a | b << 16
+  uint2* tc_lid = nullptr;     // (n1 | n2 << 16, n3 | n4 << 16)
+  uint2* bc_lid = nullptr;
+};
+
 template <class T> struct DevArray {
   T* p = nullptr;
   size_t n = 0;
@@ -121,6 +154,8 @@ struct pies_solver {
   pies::Plan plan[5];  // PIES_POSITION .. PIES_BEND
   pies::WavePlan wave;  // schedule EXACT, PBD: levels of the whole-substep DAG
   uint32_t* d_waveIndex = nullptr;
+  pies::LayerPlan layer;  // schedule LAYERED, PBD
+  pies::LayerDevice d_layer;
 
   // ---- HBM ----
   pies::NodeArrays nd{nullptr, nullptr, nullptr, nullptr, 0};
@@ -171,4 +206,6 @@ struct OpView {
 };
 void build_plan(const OpView& ops, uint32_t nodeCount, int schedule, Plan& out);
 bool build_wave_plan(const pies_solver* s, WavePlan& out);
+// layer_plan.cpp : fills s->layer and the four PBD plans; false (nothing changed) when the scene does not suit it
+bool build_layer_plan(pies_solver* s);
 }  // namespace pies

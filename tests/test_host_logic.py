@@ -66,7 +66,7 @@ def _conflict_free(ids, order, offs, writes):
         assert len(np.intersect1d(reads, written)) == 0
 
 
-@pytest.mark.parametrize("schedule", [capi.SCHEDULE_EXACT, capi.SCHEDULE_COLOURED])
+@pytest.mark.parametrize("schedule", [capi.SCHEDULE_EXACT, capi.SCHEDULE_COLOURED, capi.SCHEDULE_LAYERED])
 def test_schedules_are_permutations_of_conflict_free_batches(schedule):
     g = host_solver()
     scenes.build_beam(g, (6, 5, 7))

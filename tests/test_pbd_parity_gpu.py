@@ -22,7 +22,7 @@ def _pair(pies, oracle, dims, iterations, schedule, ticks, seed=7, amp=0.05, **b
         scenes.perturb(s, seed, amp)
         s.set_flag(1, 0)  # node-node collisions off (BASELINE configs 1-2)
     g.set_schedule(schedule)
-    if schedule == pies.SCHEDULE_COLOURED:
+    if schedule != pies.SCHEDULE_EXACT:  # the order the device plan is equivalent to
         for t in (pies.POSITION, pies.DISTANCE, pies.TET, pies.BEND):
             if g.count(t):
                 o.permute(t, g.order(t))
@@ -54,20 +54,20 @@ def test_scene_arrays_match_oracle(pies, oracle):
     assert np.array_equal(g.radii, o.radii) and np.array_equal(g.inv_masses, o.inv_masses)
 
 
-@pytest.mark.parametrize("schedule", [0, 1])
+@pytest.mark.parametrize("schedule", [0, 1, 2])
 def test_config1_l1k_pbd(pies, oracle, schedule):
     """BASELINE config 1: 10x10x10 lattice, distance + tet-strain, 10 iterations."""
     g, o = _pair(pies, oracle, scenes.L1K, 10, schedule, ticks=5)
     _check(g, o)
 
 
-@pytest.mark.parametrize("schedule", [0, 1])
+@pytest.mark.parametrize("schedule", [0, 1, 2])
 def test_distance_only(pies, oracle, schedule):
     g, o = _pair(pies, oracle, (6, 7, 5), 4, schedule, ticks=8, tets=False)
     _check(g, o)
 
 
-@pytest.mark.parametrize("schedule", [0, 1])
+@pytest.mark.parametrize("schedule", [0, 1, 2])
 def test_tets_only_with_inversion(pies, oracle, schedule):
     # large perturbation: inverted and strongly compressed elements exercise the sigma flip and clamps
     g, o = _pair(pies, oracle, (5, 4, 6), 6, schedule, ticks=4, amp=0.8, distance=False)
@@ -163,7 +163,7 @@ def test_random_graph_ragged(pies, oracle):
     dist = np.array([rng.choice(n, 2, replace=False) for _ in range(2003)], dtype=np.uint32)
     pins = np.array([3, 3, 10, 500, 3], dtype=np.uint32)
     im = rng.uniform(0.5, 2.0, size=n).astype(np.float32)
-    for schedule in (0, 1):
+    for schedule in (0, 1, 2):
         g = pies.Solver(scenes.pbd_options(pies, 3))
         o = oracle.OracleSolver(scenes.pbd_options(oracle, 3))
         for s in (g, o):
@@ -173,12 +173,77 @@ def test_random_graph_ragged(pies, oracle):
             s.add_tet(tets, 0.02)
             s.set_flag(1, 0)
         g.set_schedule(schedule)
-        if schedule == 1:
+        if schedule != 0:
             for t in (pies.POSITION, pies.DISTANCE, pies.TET):
                 o.permute(t, g.order(t))
         g.tick(3)
         o.tick(3)
         _check(g, o)
+
+
+def _layered_pair(pies, oracle, build, iterations, ticks, collisions=0, hinge=0):
+    g = pies.Solver(scenes.pbd_options(pies, iterations))
+    o = oracle.OracleSolver(scenes.pbd_options(oracle, iterations))
+    for s in (g, o):
+        build(s)
+        s.set_flag(1, collisions)
+        s.set_flag(0, hinge)
+    if collisions:
+        o.set_flag(oracle.FLAG_COLLISION_RULE, 1)  # the device's documented visiting order
+    g.set_schedule(pies.SCHEDULE_LAYERED)
+    g.finalize()
+    for t in (pies.POSITION, pies.DISTANCE, pies.TET, pies.BEND):
+        if g.count(t):
+            o.permute(t, g.order(t))
+    g.tick(ticks)
+    o.tick(ticks)
+    return g, o
+
+
+def test_layered_is_active_and_fuses_an_iteration_into_two_launches(pies, oracle):
+    """Schedule LAYERED on a beam: breadth-first levels are the cross-sections, one workgroup per pair of levels keeps
+    the node records in LDS; an iteration is two launches, predict and velocity ride along (2*iterations + 1)."""
+    def build(s):
+        scenes.build_beam(s, (6, 5, 40))
+        scenes.perturb(s, 3, 0.05)
+    g, o = _layered_pair(pies, oracle, build, 7, ticks=4)
+    lc = g.launch_counts()
+    assert lc["layer"] == 2 * 7 + 1 and lc["tet"] == 0 and lc["distance"] == 0 and lc["predict"] == 0 and lc["velocity"] == 0, lc
+    _check(g, o)
+
+
+def test_layered_with_bend_position_constraints_and_two_bodies(pies, oracle):
+    def build(s):
+        scenes.build_beam(s, (4, 5, 17), translation=(0.0, 0.3, 0.0))  # touches the floor
+        s.create_bend_sheet(7, 9, translation=(9.0, 3.0, 0.0))
+        s.create_sheet(9, 7, translation=(20, 3, 0), scale=0.5, mass=2.0, w=0.7)  # hinged: position constraints
+        scenes.perturb(s, 4, 0.05)
+    for hinge in (0, 1):
+        g, o = _layered_pair(pies, oracle, build, 5, ticks=4, hinge=hinge)
+        assert g.launch_counts()["layer"] > 0
+        _check(g, o, exact=False)  # bend: acos
+
+
+def test_layered_with_node_collisions(pies, oracle):
+    """The collision pass (global launches) cuts the layer launches once per iteration."""
+    def build(s):
+        scenes.build_beam(s, (4, 4, 12), translation=(0.0, 2.0, 0.0))
+        scenes.build_beam(s, (4, 4, 12), translation=(1.3, 5.2, 0.4))
+        scenes.perturb(s, 5, 0.05)
+    g, o = _layered_pair(pies, oracle, build, 4, ticks=3, collisions=1)
+    lc = g.launch_counts()
+    assert lc["layer"] > 0 and lc["collide"] > 0
+    _check(g, o)
+
+
+def test_layered_falls_back_when_levels_do_not_fit_in_lds(pies, oracle):
+    def build(s):
+        scenes.build_beam(s, (64, 64, 64))  # cross-sections of 4096 nodes: two levels exceed the LDS budget
+        scenes.perturb(s, 6, 0.05)
+    g, o = _layered_pair(pies, oracle, build, 2, ticks=1)
+    lc = g.launch_counts()
+    assert lc["layer"] == 0 and lc["tet"] > 0  # coloured batches instead
+    _check(g, o)
 
 
 def test_empty_and_unconstrained(pies, oracle):
@@ -205,6 +270,13 @@ def test_edit_after_tick_and_substeps(pies, oracle):
         scenes.build_beam(s, (3, 4, 3), translation=(6, 4, 0))  # second body appended after ticking
         s.tick(2)
     _check(g, o)
+
+
+def test_config2_l100k_one_tick_layered(pies, oracle):
+    """BASELINE config 2 at full size under schedule LAYERED (the one bench.py reports): exact equality."""
+    g, o = _pair(pies, oracle, scenes.L100K, 20, pies.SCHEDULE_LAYERED, ticks=1)
+    _check(g, o)
+    assert g.launch_counts()["layer"] == 41
 
 
 def test_config2_l100k_one_tick(pies, oracle):
