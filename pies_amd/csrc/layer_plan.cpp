@@ -29,6 +29,7 @@ struct Ops {  // one container: `stride` node ids per op; bit k of writeMask set
   std::vector<uint32_t> ids;
   uint32_t stride = 1, count = 0;
   uint8_t writeMask = 1;
+  std::vector<uint16_t> hints[3];  // optional proposed colourings (count entries each, kNoColourHint = none)
 };
 
 // First-fit colouring of the ops listed in `sel` (visited in the order `visit` of positions in sel) with node
@@ -60,6 +61,35 @@ uint32_t first_fit(const Ops& ops, const std::vector<uint32_t>& sel, const uint3
     }
     key[p] = static_cast<uint32_t>(col);
     ncol = std::max(ncol, static_cast<uint32_t>(col) + 1);
+  }
+  return ncol;
+}
+
+// A proposed colouring of the group is taken only when every op has a proposal and no two conflicting ops share a
+// colour (same rule as first_fit).  Returns the number of colours, 0 when the proposal is not usable.
+uint32_t from_hint(const Ops& ops, const std::vector<uint32_t>& sel, const std::vector<uint16_t>& hint, const uint32_t* localOf,
+                   uint32_t m, std::vector<uint32_t>& key) {
+  if (hint.size() != ops.count) return 0;
+  std::vector<uint64_t> usedW(static_cast<size_t>(m) * kWords, 0), usedR(static_cast<size_t>(m) * kWords, 0);
+  uint32_t ncol = 0;
+  key.assign(sel.size(), 0);
+  for (size_t p = 0; p < sel.size(); ++p) {
+    const uint32_t col = hint[sel[p]];
+    if (col >= kWords * 64) return 0;
+    const uint64_t bit = 1ull << (col & 63);
+    const uint32_t* id = &ops.ids[static_cast<size_t>(sel[p]) * ops.stride];
+    for (uint32_t k = 0; k < ops.stride; ++k) {
+      const size_t n = static_cast<size_t>(localOf[id[k]]) * kWords + (col >> 6);
+      const bool wr = ops.writeMask & (1u << k);
+      if ((usedW[n] & bit) || (wr && (usedR[n] & bit))) return 0;
+    }
+    for (uint32_t k = 0; k < ops.stride; ++k) {
+      const size_t n = static_cast<size_t>(localOf[id[k]]) * kWords + (col >> 6);
+      if (ops.writeMask & (1u << k)) usedW[n] |= bit;
+      else usedR[n] |= bit;
+    }
+    key[p] = col;
+    ncol = std::max(ncol, col + 1);
   }
   return ncol;
 }
@@ -101,7 +131,10 @@ bool build_layer_plan(pies_solver* s) {
   ops[PIES_DISTANCE].stride = 2; ops[PIES_DISTANCE].writeMask = 0x1;  // node a moves, node b is read (Constraints.cpp:34-36)
   for (const HostDistance& c : s->h_distance) { ops[PIES_DISTANCE].ids.push_back(c.ids[0]); ops[PIES_DISTANCE].ids.push_back(c.ids[1]); }
   ops[PIES_TET].stride = 4; ops[PIES_TET].writeMask = 0xF;
-  for (const HostTet& c : s->h_tet) ops[PIES_TET].ids.insert(ops[PIES_TET].ids.end(), c.ids, c.ids + 4);
+  for (const HostTet& c : s->h_tet) {
+    ops[PIES_TET].ids.insert(ops[PIES_TET].ids.end(), c.ids, c.ids + 4);
+    for (int a = 0; a < 3; ++a) ops[PIES_TET].hints[a].push_back(c.layerHint[a]);
+  }
   ops[PIES_BEND].stride = 4; ops[PIES_BEND].writeMask = 0xF;
   for (const HostBend& c : s->h_bend) ops[PIES_BEND].ids.insert(ops[PIES_BEND].ids.end(), c.ids, c.ids + 4);
   const int kinds[4] = {PIES_POSITION, PIES_DISTANCE, PIES_TET, PIES_BEND};
@@ -223,6 +256,7 @@ bool build_layer_plan(pies_solver* s) {
   // ---- per container: group, colour inside the group, order ----
   int rounds = 12;
   if (const char* e = std::getenv("PIES_COLOUR_ROUNDS")) rounds = std::atoi(e);
+  const char* noHint = std::getenv("PIES_NO_COLOUR_HINT");
   std::vector<uint32_t> localOf(N, 0);
   Plan plans[5];
   for (int k : kinds) {
@@ -257,8 +291,14 @@ bool build_layer_plan(pies_solver* s) {
         if (sel.empty()) continue;
         const uint32_t n0 = L.groupOff[q][g], m = L.groupOff[q][g + 1] - n0;
         for (uint32_t i = 0; i < m; ++i) localOf[L.nodeList[n0 + i]] = i;
-        const uint32_t nc = colour_group(O, sel, localOf.data(), m, rounds, keys[q][g]);
+        uint32_t nc = colour_group(O, sel, localOf.data(), m, rounds, keys[q][g]);
         if (nc == 0) return false;
+        if (!(noHint && std::atoi(noHint)))
+          for (int a = 0; a < 3; ++a) {
+            std::vector<uint32_t> proposed;
+            const uint32_t nh = from_hint(O, sel, O.hints[a], localOf.data(), m, proposed);
+            if (nh != 0 && nh < nc) { keys[q][g].swap(proposed); nc = nh; }
+          }
         ncol = std::max(ncol, nc);
       }
       K.ncol[phase] = ncol;

@@ -359,9 +359,19 @@ int pies_create_tet_box(pies_solver_t* s, uint32_t W, uint32_t H, uint32_t D, co
         // the same kind share a node only when their cells differ by e_a, e_b, e_c, e_a+e_b, e_b+e_c or 111,
         // none of which has i+j+k = 0 mod 4: 6 x 4 = 24 colours, the number of tetrahedra at an inner node.
         const uint16_t cellColour = static_cast<uint16_t>((i + j + k) & 3u);
+        // Schedule LAYERED colours one layer of cells at a time: 12 tetrahedra of a layer meet at a node and 12 colours
+        // suffice, periodic with period 2 in both in-layer directions (tables found by tools/layer_colour_tables.py).
+        // kLayerTetColour[axis][2 * (u & 1) + (v & 1)][e]: u, v = cell indices along the two in-layer axes (ascending)
+        static const uint8_t kLayerTetColour[3][4][6] = {
+            {{6, 5, 11, 4, 10, 8}, {0, 4, 7, 5, 1, 3}, {8, 9, 7, 2, 1, 6}, {3, 2, 11, 9, 10, 0}},
+            {{6, 5, 1, 4, 10, 0}, {8, 4, 7, 5, 11, 3}, {8, 9, 10, 2, 1, 3}, {6, 2, 11, 9, 7, 0}},
+            {{3, 6, 1, 10, 8, 0}, {0, 2, 7, 5, 9, 3}, {11, 2, 8, 5, 1, 4}, {4, 6, 9, 10, 7, 11}},
+        };
+        const uint32_t uv[3] = {2 * (j & 1u) + (k & 1u), 2 * (i & 1u) + (k & 1u), 2 * (i & 1u) + (j & 1u)};
         for (int e = 0; e < 6; ++e) {
           s->h_tet.push_back(make_tet(s, q[e], w, 0.8f, 1.0f));
           s->h_tet.back().hint = static_cast<uint16_t>(4 * e + cellColour);
+          for (int a = 0; a < 3; ++a) s->h_tet.back().layerHint[a] = kLayerTetColour[a][uv[a]][e];
           if (flags & 1u) s->h_volume.push_back(make_tet(s, q[e], w, 1.0f, 1.0f));
           s->constraintId += 2;
         }

@@ -35,6 +35,9 @@ struct HostTet {  // TetrahedralConstraint and VolumeConstraint share the rest d
   float AtA[16];  // row-major 4x4, A^T A (B = I so AtB = A^T)
   float A[16];    // row-major 4x4
   uint16_t hint;  // see HostDistance
+  // colours proposed for schedule LAYERED when the breadth-first levels are lattice layers perpendicular to x, y or z
+  // (layer_plan.cpp verifies a proposal group by group)
+  uint16_t layerHint[3] = {kNoColourHint, kNoColourHint, kNoColourHint};
 };
 struct HostBend {
   uint32_t ids[4];
