@@ -11,7 +11,7 @@ collisions off, synthetic perturbed rest state already resident in HBM.
 
 Rank 0 prints ONE JSON line.  `value` is whole-job substeps/s (N independent bodies, weak scaling; the
 only collective is the timing barrier / max-reduce).  `roofline` is measured live for the dominant kernel
-(tet-strain projection) from the dispatches' own start/stop timestamps; `cpu_baseline` is the CPU oracle
+(k_layer: the LDS-resident sweep of schedule LAYERED) between two HIP events on the solver's stream; `cpu_baseline` is the CPU oracle
 (a single-threaded restatement of the reference loop) timed on this host on a bounded sample.
 """
 import argparse
@@ -32,7 +32,8 @@ from pies_amd import capi  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec)
 # algorithmic bytes per unit (DESIGN.md "Kernels")
-BYTES = {"predict": 48, "position": 44, "distance": 52, "tet": 160, "bend": 136, "floor": 20, "velocity": 40}
+BYTES = {"predict": 48, "position": 44, "distance": 52, "tet": 160, "bend": 136, "floor": 20, "velocity": 40,
+         "layer": 1}  # a layer launch fuses several kinds: the library tallies its units in algorithmic bytes directly
 ITERATIONS = 20
 
 
@@ -215,7 +216,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--dims", type=int, nargs=3, default=list(scenes.L100K))
-    ap.add_argument("--schedule", choices=["coloured", "exact"], default="coloured")
+    ap.add_argument("--schedule", choices=["layered", "coloured", "exact"], default="layered")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-order measurement")
     ap.add_argument("--cpu-ticks", type=int, default=4)
@@ -249,7 +250,7 @@ def main():
             pass
 
     dims = tuple(args.dims)
-    sched = capi.SCHEDULE_COLOURED if args.schedule == "coloured" else capi.SCHEDULE_EXACT
+    sched = {"layered": capi.SCHEDULE_LAYERED, "coloured": capi.SCHEDULE_COLOURED, "exact": capi.SCHEDULE_EXACT}[args.schedule]
     g = build_scene(capi, dims, 1234 + rank, schedule=sched, device=device_index)
     g.finalize()
     substeps_per_tick = g.options.timeSubsteps
@@ -271,7 +272,7 @@ def main():
         wave_bytes = ITERATIONS * (BYTES["distance"] * g.count(capi.DISTANCE) + BYTES["tet"] * g.count(capi.TET) + BYTES["position"]
                                    * g.count(capi.POSITION) + BYTES["bend"] * g.count(capi.BEND) + BYTES["floor"] * g.count(capi.NODES)) / items
         prof = kernel_profile(g, dict(BYTES, wave=wave_bytes))  # schedule exact: a launch mixes the kinds of one dependency level
-        dom = "wave" if "wave" in prof else "tet" if "tet" in prof else max(prof, key=lambda k: prof[k]["avg_us"] * prof[k]["launches_per_substep"])
+        dom = "layer" if "layer" in prof else "wave" if "wave" in prof else "tet" if "tet" in prof else max(prof, key=lambda k: prof[k]["avg_us"] * prof[k]["launches_per_substep"])
         achieved = prof[dom]["algorithmic_GBs"]
         result = {
             "metric": "substeps/sec @100k particles (PBD distance+tet-strain, 20 iterations)",
@@ -298,7 +299,17 @@ def main():
     g.close()
 
     if rank == 0 and world == 1:
-        if not args.no_exact and args.schedule == "coloured":
+        if not args.no_exact and args.schedule == "layered":
+            c = build_scene(capi, dims, 1234, schedule=capi.SCHEDULE_COLOURED, device=device_index)
+            c.finalize()
+            steps = max(2, min(args.steps, 50))
+            el = timed_ticks(c, steps, 2, lambda: None)
+            result["coloured_schedule"] = {"value": steps * substeps_per_tick / el, "unit": "substeps/s",
+                                           "launches_per_substep": sum(c.launch_counts().values()), "steps": steps,
+                                           "kernels": kernel_profile(c),
+                                           "note": "schedule COLOURED: one launch per colour class (24 tet + 9 distance colours per iteration)"}
+            c.close()
+        if not args.no_exact and args.schedule != "exact":
             e = build_scene(capi, dims, 1234, schedule=capi.SCHEDULE_EXACT, device=device_index)
             e.finalize()
             steps = max(2, min(args.steps, 10))

@@ -23,7 +23,10 @@ PIES_DEV uint32_t xcd_block(uint32_t bid, uint32_t nwg) {
 // orthogonal to working precision, |b_p.b_q| <= kSvdTol |b_p||b_q|  (at most kSvdMaxSweeps sweeps; a
 // typical deformation gradient needs 2-3 rotating sweeps plus the final check sweep).  Per rotation:
 // two rsqrt_nr, everything else fused multiply-adds; no division or square-root instruction in the sweep.
-constexpr int kSvdMaxSweeps = 8;
+#ifndef PIES_SVD_MAX_SWEEPS
+#define PIES_SVD_MAX_SWEEPS 8
+#endif
+constexpr int kSvdMaxSweeps = PIES_SVD_MAX_SWEEPS;
 constexpr float kSvdTol = 4.76837158203125e-07f;  // 4 * 2^-23
 constexpr float kSvdTol2 = kSvdTol * kSvdTol;
 constexpr float kSvdTiny = 1.0e-18f;
