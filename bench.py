@@ -194,6 +194,27 @@ def extra_configs(device):
     return out
 
 
+def cpu_all_cores(dims, ticks, threads):
+    """The same oracle with every host core: the containers re-ordered into the conflict-free colour classes of a
+    coloured plan (built by a host-only handle: no GPU involved) and each class swept with OpenMP threads."""
+    import oracle_api as ora
+    plan = build_scene(capi, dims, 1234, schedule=capi.SCHEDULE_COLOURED, device=capi.DEVICE_NONE)
+    plan.finalize()
+    o = build_scene(ora, dims, 1234)
+    for t in (capi.DISTANCE, capi.TET):
+        o.permute(t, plan.order(t))
+        o.set_batches(t, plan.batches(t))
+    plan.close()
+    o.set_threads(threads)
+    o.tick(1)
+    t0 = time.perf_counter()
+    o.tick(ticks)
+    dt = time.perf_counter() - t0
+    return {"value": ticks / dt, "unit": "substeps/s", "cores": threads,
+            "sample": "%d ticks, colour classes swept with %d OpenMP threads (bit-identical to the sequential sweep in "
+                      "that order)" % (ticks, threads)}
+
+
 def cpu_baseline(dims, ticks):
     import oracle_api as ora
     o = build_scene(ora, dims, 1234)
@@ -201,7 +222,9 @@ def cpu_baseline(dims, ticks):
     t0 = time.perf_counter()
     o.tick(ticks)
     dt = time.perf_counter() - t0
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     return {
+        "all_cores": cpu_all_cores(dims, 3 * ticks, threads),
         "value": ticks / dt, "unit": "substeps/s", "cores": 1, "kind": "port",
         "sample": "%d ticks of the same %dx%dx%d workload (20 iterations, oracle/pies_oracle.cpp, g++ -O2, 1 thread; "
                   "the reference's projection loops are single-threaded, Src/Solver.cpp:58-75)" % ((ticks,) + tuple(dims)),

@@ -739,6 +739,12 @@ struct ora_solver {
   // index, and a node queries the cell range it was *inserted* with.  Same per-pair arithmetic.
   int collisionRule = 0;
 
+  // Optional multi-core replay for the all-cores CPU baseline (bench.py): conflict-free batches of each container
+  // (ora_set_batches, taken from a coloured device plan) are swept with `threads` OpenMP threads.  A batch touches every
+  // node at most once, so the result is bit-identical to the single-threaded sweep in the same order.
+  int threads = 1;
+  std::vector<uint32_t> batchOffs[5];
+
   NodeHash hashNodes;
   std::vector<StaticCollision> staticCollisions;
   std::vector<TriCollision> triCollisions;
@@ -774,20 +780,36 @@ void ora_solver::tick() {
   if (opt.solver == 0) tickPBD(); else tickPD();
 }
 
+// One Gauss-Seidel sweep over a container: sequential (the reference's loop), or batch by batch with OpenMP when
+// conflict-free batches were supplied and threads > 1 (same result: no two constraints of a batch share a written node).
+template <class C, int N> static void sweep(std::vector<C>& cons, std::vector<Node>& nodes, const std::vector<uint32_t>& offs, int threads) {
+  if (threads > 1 && offs.size() >= 2 && offs.back() == cons.size()) {
+    for (size_t b = 0; b + 1 < offs.size(); ++b) {
+      const int64_t lo = offs[b], hi = offs[b + 1];
+#pragma omp parallel for num_threads(threads) schedule(static)
+      for (int64_t k = lo; k < hi; ++k) projectNodePositions<C, N>(cons[static_cast<size_t>(k)], nodes);
+    }
+    return;
+  }
+  for (C& c : cons) projectNodePositions<C, N>(c, nodes);
+}
+
 // Src/Solver.cpp:40-160
 void ora_solver::tickPBD() {
   float deltaTime = opt.fixedTimestepSize / opt.timeSubsteps;
+  const int64_t nNodes = static_cast<int64_t>(nodes.size());
   for (uint32_t substep = 0; substep < opt.timeSubsteps; ++substep) {
-    for (Node& node : nodes) {  // :47-52
+#pragma omp parallel for num_threads(threads) schedule(static) if (threads > 1)
+    for (int64_t k = 0; k < nNodes; ++k) {  // :47-52
+      Node& node = nodes[static_cast<size_t>(k)];
       node.prevPosition = node.position;
       node.position += node.velocity * deltaTime + vec3(0.0f, -opt.gravity, 0.0f) * deltaTime * deltaTime;
     }
     for (uint32_t i = 0; i < opt.iterations; ++i) {
-      if (!releaseHinge)
-        for (PositionCon& c : positionCons) projectNodePositions<PositionCon, 1>(c, nodes);  // :59-63
-      for (DistanceCon& c : distanceCons) projectNodePositions<DistanceCon, 2>(c, nodes);     // :65-67
-      for (TetCon& c : tetCons) projectNodePositions<TetCon, 4>(c, nodes);                    // :69-71
-      for (BendCon& c : bendCons) projectNodePositions<BendCon, 4>(c, nodes);                 // :73-75
+      if (!releaseHinge) sweep<PositionCon, 1>(positionCons, nodes, batchOffs[0], threads);  // :59-63
+      sweep<DistanceCon, 2>(distanceCons, nodes, batchOffs[1], threads);                       // :65-67
+      sweep<TetCon, 4>(tetCons, nodes, batchOffs[2], threads);                                 // :69-71
+      sweep<BendCon, 4>(bendCons, nodes, batchOffs[4], threads);                               // :73-75
 
       if (nodeCollisions) {
         hashNodes.clear();                                 // :81
@@ -841,10 +863,15 @@ void ora_solver::tickPBD() {
           scratch.clear();
         }
       }
-      for (Node& node : nodes)  // :132-136
+#pragma omp parallel for num_threads(threads) schedule(static) if (threads > 1)
+      for (int64_t k = 0; k < nNodes; ++k) {  // :132-136
+        Node& node = nodes[static_cast<size_t>(k)];
         if (node.position.y - node.radius < opt.floorHeight) node.position.y = opt.floorHeight + node.radius;
+      }
     }
-    for (Node& node : nodes) {  // :140-158
+#pragma omp parallel for num_threads(threads) schedule(static) if (threads > 1)
+    for (int64_t k = 0; k < nNodes; ++k) {  // :140-158
+      Node& node = nodes[static_cast<size_t>(k)];
       node.velocity = (1.0f - opt.damping) * (node.position - node.prevPosition) / deltaTime;
       if (node.position.y - node.radius <= opt.floorHeight) {
         float l = std::sqrt(node.velocity.x * node.velocity.x + node.velocity.z * node.velocity.z);
@@ -1656,8 +1683,15 @@ void ora_permute(ora_solver* s, int type, const uint32_t* perm, uint32_t n) {
     case 3: apply(s->volumeCons); break;
     case 4: apply(s->bendCons); break;
   }
+  if (type >= 0 && type <= 4) s->batchOffs[type].clear();  // batches describe an order: gone with it
   s->pdDirty = true;
 }
+// Conflict-free batches of a container (after ora_permute): n_batches + 1 slot offsets.  Used only with ora_set_threads > 1.
+void ora_set_batches(ora_solver* s, int type, const uint32_t* offs, uint32_t n_batches) {
+  if (type < 0 || type > 4) return;
+  s->batchOffs[type].assign(offs, offs + (n_batches ? n_batches + 1 : 0));
+}
+void ora_set_threads(ora_solver* s, int threads) { s->threads = threads < 1 ? 1 : threads; }
 void ora_set_collision_order(ora_solver* s, const uint32_t* order, uint32_t n) {
   s->collisionOrder.assign(order, order + n);
 }

@@ -15,6 +15,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(5)
 PBD, PD = 0, 1
 POSITION, DISTANCE, TET, VOLUME, BEND, SHAPE, GOAL, TRIANGLES, LINES, NODES = range(10)
 SCHEDULE_EXACT, SCHEDULE_COLOURED, SCHEDULE_LAYERED = 0, 1, 2
+DEVICE_NONE = -1  # PIES_DEVICE_NONE: host-only handle (scenes and schedules, no compute)
 FLAG_RELEASE_HINGE, FLAG_NODE_COLLISIONS, FLAG_TRIANGLE_COLLISIONS = 0, 1, 2
 NODE_POSITION, NODE_PREV_POSITION, NODE_VELOCITY, NODE_RADIUS, NODE_INV_MASS = range(5)
 KERNEL_NAMES = ["predict", "position", "distance", "tet", "bend", "floor", "velocity", "hash", "collide",

@@ -82,6 +82,8 @@ def lib():
         L.ora_create_bend_sheet.argtypes = [vp, u32, u32, pf, f32, f32]
         L.ora_permute.argtypes = [vp, i32, pu, u32]
         L.ora_set_collision_order.argtypes = [vp, pu, u32]
+        L.ora_set_batches.argtypes = [vp, i32, pu, u32]
+        L.ora_set_threads.argtypes = [vp, i32]
         L.ora_count.restype = u32
         L.ora_count.argtypes = [vp, i32]
         L.ora_stat_collision_pairs.restype = C.c_uint64
@@ -235,6 +237,14 @@ class OracleSolver:
     def permute(self, ctype, perm):
         perm = _u32(perm)
         lib().ora_permute(self._h, ctype, _pu(perm), len(perm))
+
+    def set_batches(self, ctype, offsets):
+        """Conflict-free batches (n+1 slot offsets) of a container, for the multi-threaded sweep (set_threads > 1)."""
+        offsets = _u32(offsets)
+        lib().ora_set_batches(self._h, ctype, _pu(offsets), max(0, len(offsets) - 1))
+
+    def set_threads(self, n):
+        lib().ora_set_threads(self._h, int(n))
 
     def set_collision_order(self, order):
         order = _u32(order)

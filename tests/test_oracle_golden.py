@@ -236,3 +236,27 @@ def test_pd_two_boxes_collide_through_triangle_ccd():
     # (w = 1 against m/h^2 ~ 7e3 makes the boxes very soft, so only the contacting nodes are compared)
     assert res[1][0][36, 1] > res[0][0][36, 1] + 0.15
     assert res[1][0][36, 1] > res[1][0][:27, 1].max() - 0.1  # it rides on the lower box's top face
+
+
+def test_multithreaded_batch_sweep_equals_the_sequential_sweep():
+    """The all-cores CPU baseline of bench.py: conflict-free batches of a coloured device plan swept with OpenMP threads
+    give the bits of the single-threaded sweep in the same order."""
+    import scenes
+    from pies_amd import capi
+    g = capi.Solver(scenes.pbd_options(capi, 3), device=capi.DEVICE_NONE)
+    scenes.build_beam(g, (5, 6, 9))
+    g.set_schedule(capi.SCHEDULE_COLOURED)
+    g.finalize()
+    res = []
+    for threads in (1, 4):
+        o = O.OracleSolver(scenes.pbd_options(O, 3))
+        scenes.build_beam(o, (5, 6, 9))
+        scenes.perturb(o, 8, 0.05)
+        o.set_flag(1, 0)
+        for t in (capi.DISTANCE, capi.TET):
+            o.permute(t, g.order(t))
+            o.set_batches(t, g.batches(t))
+        o.set_threads(threads)
+        o.tick(3)
+        res.append((o.positions.copy(), o.velocities.copy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
