@@ -106,62 +106,83 @@ int scene_sync_host(pies_solver* s) {
   return download_nodes(s);
 }
 
-// Schedule LAYERED: the substep as a list of layer launches (groups of one parity, LDS resident) and collision
-// passes.  Walks tickPBD's order (Solver.cpp:45-159) and packs consecutive steps that run on the same parity into
-// one launch: the distance container runs (even, odd), the tetrahedral one (odd, even), bend (even, odd), so an
-// iteration without bend constraints or collisions is two launches: [tet even of the previous iteration, floor
-// clamp, position, distance even] and [distance odd, tet odd].  Per-node steps run with whichever parity is current.
+// Schedule LAYERED: the substep as a list of layer launches (tiles of one phase, LDS resident), collision passes and
+// - for bodies cut into strips - per-node launches over the level-ordered copy.  Walks tickPBD's order
+// (Solver.cpp:45-159) and packs consecutive steps that run on the same phase into one launch: the distance container
+// runs its phases in the order (0,1,2,3), the tetrahedral one (3,2,1,0), bend (0,1,2,3).  With one strip only phases
+// 0 (even levels) and 2 (odd levels) exist and both cover every node, so the per-node steps ride along and an
+// iteration without bend constraints or collisions is two launches: [tet even of the previous iteration, floor clamp,
+// position, distance even] and [distance odd, tet odd].
+enum { ITEM_LAYER = 0, ITEM_COLLIDE, ITEM_LPREDICT, ITEM_LVELOCITY, ITEM_LFLOOR, ITEM_LPOSITION, ITEM_TO_NODES, ITEM_FROM_NODES };
 struct LayerItem {
-  bool collide = false;
+  int type = ITEM_LAYER;
   LayerLaunch launch{};
   uint64_t bytes = 0;  // algorithmic bytes of the launch (SURVEY 8d per-unit figures)
+  Batch batch{0, 0};   // ITEM_LPOSITION
 };
 static void build_layer_program(const pies_solver* s, std::vector<LayerItem>& prog) {
   const LayerPlan& L = s->layer;
-  struct Step { uint32_t kind; int parity; int container; int phase; };
+  const bool oneStrip = L.strips == 1;
+  constexpr uint32_t kCollide = 0xFFFFFFFFu;
+  struct Step { uint32_t kind; int phase; int container; };  // phase -1: a per-node step
   std::vector<Step> steps;
-  steps.push_back({LAYER_PREDICT, -1, -1, 0});
-  const bool collide = s->nodeCollisions;
+  steps.push_back({LAYER_PREDICT, -1, -1});
   for (uint32_t it = 0; it < s->opt.iterations; ++it) {
-    if (!s->releaseHinge && L.kind[PIES_POSITION].ncol[0]) steps.push_back({LAYER_POSITION, 0, PIES_POSITION, 0});
+    if (!s->releaseHinge && !s->h_position.empty()) steps.push_back({LAYER_POSITION, oneStrip ? 0 : -1, PIES_POSITION});
     const int cont[3] = {PIES_DISTANCE, PIES_TET, PIES_BEND};
     const uint32_t lk[3] = {LAYER_DISTANCE, LAYER_TET, LAYER_BEND};
     for (int c = 0; c < 3; ++c)
-      for (int phase = 0; phase < 2; ++phase)
-        if (L.kind[cont[c]].ncol[phase]) steps.push_back({lk[c], (kLayerFirstParity[cont[c]] + phase) & 1, cont[c], phase});
-    if (collide) steps.push_back({0xFFFFFFFFu, -1, -1, 0});
-    steps.push_back({LAYER_FLOOR, -1, -1, 0});
+      for (int k = 0; k < 4; ++k) {
+        const int ph = kLayerPhaseOrder[cont[c]][k];
+        if (L.kind[cont[c]].ncol[ph]) steps.push_back({lk[c], ph, cont[c]});
+      }
+    if (s->nodeCollisions) steps.push_back({kCollide, -1, -1});
+    steps.push_back({LAYER_FLOOR, -1, -1});
   }
-  steps.push_back({LAYER_VELOCITY, -1, -1, 0});
+  steps.push_back({LAYER_VELOCITY, -1, -1});
 
   const uint64_t N = s->nd.n;
   LayerItem cur;
   bool open = false;
   auto flush = [&] { if (open) prog.push_back(cur); open = false; cur = LayerItem{}; };
+  auto plain = [&](int type) { LayerItem it; it.type = type; prog.push_back(it); };
   for (size_t i = 0; i < steps.size(); ++i) {
     const Step& st = steps[i];
-    if (st.kind == 0xFFFFFFFFu) {
+    if (st.kind == kCollide) {  // the collision pass works on the node array
       flush();
-      LayerItem c;
-      c.collide = true;
-      prog.push_back(c);
+      if (!oneStrip) plain(ITEM_TO_NODES);
+      plain(ITEM_COLLIDE);
+      if (!oneStrip) plain(ITEM_FROM_NODES);
       continue;
     }
-    int q = st.parity;
-    if (open && (q < 0 || q == (int)cur.launch.parity) && cur.launch.nseg < (uint32_t)kLayerMaxSegs) {
-      q = cur.launch.parity;
+    if (st.phase < 0 && !oneStrip) {  // strips: no phase's tiles cover every node exactly once
+      flush();
+      if (st.kind == LAYER_POSITION) {
+        for (const Batch& b : s->plan[PIES_POSITION].batches) { LayerItem it; it.type = ITEM_LPOSITION; it.batch = b; it.bytes = 44ull * b.count; prog.push_back(it); }
+      } else {
+        LayerItem it;
+        it.type = st.kind == LAYER_PREDICT ? ITEM_LPREDICT : st.kind == LAYER_FLOOR ? ITEM_LFLOOR : ITEM_LVELOCITY;
+        it.bytes = (st.kind == LAYER_PREDICT ? 48u : st.kind == LAYER_FLOOR ? 20u : 40u) * N;
+        prog.push_back(it);
+      }
+      continue;
+    }
+    int q = st.phase;
+    if (open && (q < 0 || q == (int)cur.launch.phase) && cur.launch.nseg < (uint32_t)kLayerMaxSegs) {
+      q = cur.launch.phase;
     } else {
       flush();
-      if (q < 0) {  // a per-node step opens a launch: take the parity of the next container phase so that it can join
+      if (q < 0) {  // a per-node step opens a launch: take the phase of the next container step so that it can join
         q = 0;
         for (size_t j = i + 1; j < steps.size(); ++j) {
-          if (steps[j].kind == 0xFFFFFFFFu) break;
-          if (steps[j].parity >= 0) { q = steps[j].parity; break; }
+          if (steps[j].kind == kCollide) break;
+          if (steps[j].phase >= 0) { q = steps[j].phase; break; }
         }
       }
       open = true;
-      cur.launch.parity = (uint32_t)q;
-      cur.launch.groups = L.groups[q];
+      cur.type = ITEM_LAYER;
+      cur.launch.phase = (uint32_t)q;
+      cur.launch.groups = (uint32_t)L.tiles[q].size();
       cur.launch.maxClass = 1;
     }
     LayerSeg& seg = cur.launch.seg[cur.launch.nseg++];
@@ -170,10 +191,10 @@ static void build_layer_program(const pies_solver* s, std::vector<LayerItem>& pr
     seg.colOff = nullptr;
     if (st.container >= 0) {
       const LayerKind& K = L.kind[st.container];
-      seg.ncol = K.ncol[st.phase];
-      seg.colOff = s->d_layer.colOff[st.container][st.phase];
+      seg.ncol = K.ncol[q];
+      seg.colOff = s->d_layer.colOff[st.container][q];
       cur.launch.maxClass = std::max(cur.launch.maxClass, K.maxClass);
-      const uint64_t count = K.colOff[st.phase].back() - K.colOff[st.phase].front();
+      const uint64_t count = K.colOff[q].empty() ? 0 : K.colOff[q].back() - K.colOff[q].front();
       const uint64_t perUnit = st.container == PIES_POSITION ? 44 : st.container == PIES_DISTANCE ? 52 : st.container == PIES_TET ? 160 : 136;
       cur.bytes += perUnit * count;
     } else {
@@ -181,12 +202,12 @@ static void build_layer_program(const pies_solver* s, std::vector<LayerItem>& pr
     }
   }
   flush();
-  // the node array is the source of the first launch and of every launch after a collision pass, and the
-  // destination of the last launch and of every launch before a collision pass
+  // One strip: the node array is the source of the first launch and of every launch after a collision pass, and the
+  // destination of the last launch and of every launch before a collision pass.  Strips: always the copy.
   for (size_t i = 0; i < prog.size(); ++i) {
-    if (prog[i].collide) continue;
-    prog[i].launch.loadGlobal = (i == 0 || prog[i - 1].collide) ? 1u : 0u;
-    prog[i].launch.storeGlobal = (i + 1 == prog.size() || prog[i + 1].collide) ? 1u : 0u;
+    if (prog[i].type != ITEM_LAYER) continue;
+    prog[i].launch.loadGlobal = oneStrip && (i == 0 || prog[i - 1].type == ITEM_COLLIDE) ? 1u : 0u;
+    prog[i].launch.storeGlobal = oneStrip && (i + 1 == prog.size() || prog[i + 1].type == ITEM_COLLIDE) ? 1u : 0u;
   }
 }
 
@@ -195,23 +216,53 @@ static void enqueue_layered_substep(pies_solver* s, int only, uint32_t* counts, 
   std::vector<LayerItem> prog;
   build_layer_program(s, prog);
   const LayerDevice& d = s->d_layer;
-  const LayerData D = {d.nodeList, {d.groupOff[0], d.groupOff[1]}, s->layer.maxGroupNodes, d.lpos, d.lrad, d.pc_lid, s->d_pc_tw, d.dc_lid, s->d_dc_rw,
-                       d.tc_lid, s->d_tc_q0, s->d_tc_q1, s->d_tc_q2, d.bc_lid, s->d_bc_aw};
+  LayerData D{};
+  D.nodeList = d.nodeList;
+  for (int ph = 0; ph < 4; ++ph) D.tiles[ph] = reinterpret_cast<const uint4*>(d.tiles[ph]);
+  D.maxGroupNodes = s->layer.maxGroupNodes;
+  D.lpos = d.lpos; D.lrad = d.lrad;
+  D.pc_lid = d.pc_lid; D.pc_tw = s->d_pc_tw;
+  D.dc_lid = d.dc_lid; D.dc_rw = s->d_dc_rw;
+  D.tc_lid = d.tc_lid; D.tc_q0 = s->d_tc_q0; D.tc_q1 = s->d_tc_q1; D.tc_q2 = s->d_tc_q2;
+  D.bc_lid = d.bc_lid; D.bc_aw = s->d_bc_aw;
   const float dt = s->opt.fixedTimestepSize / s->opt.timeSubsteps;
   const LayerParams P = {s->opt.floorHeight, dt, s->opt.gravity, s->opt.damping, s->opt.friction};
+  auto ON = [&](int k) { return only < 0 || only == k; };
+  auto C = [&](int k) { if (counts) ++counts[k]; };
   for (const LayerItem& item : prog) {
-    if (item.collide) {  // Solver.cpp:81-130
-      uint32_t nb = 6, nc = 27;
-      if (only < 0 || only == PIES_KERNEL_HASH) { nb = launch_hash_build(st, s->hash, s->nd, s->opt.gridSpacing); if (units) *units += s->nd.n; }
-      if (only < 0 || only == PIES_KERNEL_COLLIDE) { nc = launch_collide(st, s->hash, s->nd, s->opt.friction, s->opt.staticFrictionThreshold); if (units) *units += s->nd.n; }
-      if (counts) { counts[PIES_KERNEL_HASH] += nb; counts[PIES_KERNEL_COLLIDE] += nc; }
-      continue;
+    switch (item.type) {
+      case ITEM_COLLIDE: {  // Solver.cpp:81-130
+        uint32_t nb = 6, nc = 27;
+        if (ON(PIES_KERNEL_HASH)) { nb = launch_hash_build(st, s->hash, s->nd, s->opt.gridSpacing); if (units) *units += s->nd.n; }
+        if (ON(PIES_KERNEL_COLLIDE)) { nc = launch_collide(st, s->hash, s->nd, s->opt.friction, s->opt.staticFrictionThreshold); if (units) *units += s->nd.n; }
+        if (counts) { counts[PIES_KERNEL_HASH] += nb; counts[PIES_KERNEL_COLLIDE] += nc; }
+        break;
+      }
+      case ITEM_LAYER:
+        if (ON(PIES_KERNEL_LAYER)) { launch_layer(st, s->nd, D, item.launch, P); if (units) *units += item.bytes; }
+        C(PIES_KERNEL_LAYER);
+        break;
+      case ITEM_LPREDICT:
+        if (ON(PIES_KERNEL_PREDICT)) { launch_lpredict(st, s->nd, D, P); if (units) *units += s->nd.n; }
+        C(PIES_KERNEL_PREDICT);
+        break;
+      case ITEM_LVELOCITY:
+        if (ON(PIES_KERNEL_VELOCITY)) { launch_lvelocity(st, s->nd, D, P); if (units) *units += s->nd.n; }
+        C(PIES_KERNEL_VELOCITY);
+        break;
+      case ITEM_LFLOOR:
+        if (ON(PIES_KERNEL_FLOOR)) { launch_lfloor(st, s->nd, D, P); if (units) *units += s->nd.n; }
+        C(PIES_KERNEL_FLOOR);
+        break;
+      case ITEM_LPOSITION:
+        if (ON(PIES_KERNEL_POSITION)) { launch_lposition(st, D, item.batch.start, item.batch.count); if (units) *units += item.batch.count; }
+        C(PIES_KERNEL_POSITION);
+        break;
+      case ITEM_TO_NODES:
+      case ITEM_FROM_NODES:
+        if (only < 0) launch_lcopy(st, s->nd, D, item.type == ITEM_TO_NODES);
+        break;
     }
-    if (only < 0 || only == PIES_KERNEL_LAYER) {
-      launch_layer(st, s->nd, D, item.launch, P);
-      if (units) *units += item.bytes;
-    }
-    if (counts) ++counts[PIES_KERNEL_LAYER];
   }
 }
 
@@ -712,10 +763,10 @@ int pies_finalize(pies_solver_t* s) {
       for (size_t i = 0; i < lrad.size(); ++i) lrad[i] = s->h_radius[L.nodeList[i]];
       if (int rc = upload(s, lrad, &d.lrad)) return rc;
     }
-    for (int q = 0; q < 2; ++q)
-      if (int rc = upload(s, L.groupOff[q], &d.groupOff[q])) return rc;
+    for (int ph = 0; ph < 4; ++ph)
+      if (int rc = upload(s, L.tiles[ph], &d.tiles[ph])) return rc;
     for (int k = 0; k < 5; ++k)
-      for (int ph = 0; ph < 2; ++ph)
+      for (int ph = 0; ph < 4; ++ph)
         if (int rc = upload(s, L.kind[k].colOff[ph], &d.colOff[k][ph])) return rc;
     if (int rc = upload(s, L.kind[PIES_POSITION].local, &d.pc_lid)) return rc;
     {

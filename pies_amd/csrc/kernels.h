@@ -45,13 +45,13 @@ struct LayerSeg {
   const uint32_t* colOff;  // groups x (ncol+1) slot offsets
 };
 struct LayerLaunch {
-  uint32_t parity, groups, nseg, maxClass;
+  uint32_t phase, groups, nseg, maxClass;  // phase = 2 * (level parity) + (strip parity); groups = tiles of that phase
   uint32_t loadGlobal, storeGlobal;  // node records from / to the node array instead of the layer-ordered copy
   LayerSeg seg[kLayerMaxSegs];
 };
 struct LayerData {
   const uint32_t* nodeList;
-  const uint32_t* groupOff[2];
+  const uint4* tiles[4];  // per phase: (first0, count0, first1, count1) = two runs of the level-ordered node list
   uint32_t maxGroupNodes;
   float4* lpos;       // node records in nodeList order: valid between the layer launches of a substep
   const float* lrad;  // radii in nodeList order
@@ -70,6 +70,13 @@ struct LayerParams {  // scalars of the per-node steps
 // Returns hipSuccess or the error of the attribute call that raises the kernel's LDS limit.
 hipError_t layer_prepare(uint32_t maxGroupNodes);
 void launch_layer(hipStream_t st, const NodeArrays& nd, const LayerData& D, const LayerLaunch& L, const LayerParams& P);
+// Per-node steps on the level-ordered copy, for bodies whose levels are cut into strips (no tile partition covers every
+// node exactly once there): predict reads the node array and fills the copy, velocity writes the node array back.
+void launch_lpredict(hipStream_t st, const NodeArrays& nd, const LayerData& D, const LayerParams& P);
+void launch_lvelocity(hipStream_t st, const NodeArrays& nd, const LayerData& D, const LayerParams& P);
+void launch_lfloor(hipStream_t st, const NodeArrays& nd, const LayerData& D, const LayerParams& P);
+void launch_lposition(hipStream_t st, const LayerData& D, uint32_t start, uint32_t count);
+void launch_lcopy(hipStream_t st, const NodeArrays& nd, const LayerData& D, bool toNodeArray);
 
 // Solver.cpp:47-52
 void launch_predict(hipStream_t st, const NodeArrays& nd, float dt, float gravity);

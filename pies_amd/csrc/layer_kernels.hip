@@ -39,10 +39,11 @@ __global__ void __launch_bounds__(BLOCK) k_layer(NodeArrays nd, LayerData D, Lay
   uint32_t* __restrict__ soff = reinterpret_cast<uint32_t*>(srad + D.maxGroupNodes);  // colour offsets, per segment
   const uint32_t tid = threadIdx.x;
   const uint32_t g = xcd_block(blockIdx.x, gridDim.x);  // neighbouring groups (shared levels) meet in one XCD's L2
-  const uint32_t n0 = D.groupOff[L.parity][g];
-  const uint32_t m = D.groupOff[L.parity][g + 1] - n0;
-  const uint32_t* __restrict__ nodes = D.nodeList + n0;
-  if (m == 0) return;  // uniform: an empty group (odd group 0 of a one-level body)
+  const uint4 tile = D.tiles[L.phase][g];
+  const uint32_t m = tile.y + tile.w;
+  if (m == 0) return;  // uniform: an empty tile
+  // LDS index -> position in the level-ordered node list (two runs: the tile's part of its two levels)
+  auto lp = [&](uint32_t i) { return i < tile.y ? tile.x + i : tile.z + (i - tile.y); };
 
   bool needRadius = false;
   for (uint32_t s = 0; s < L.nseg; ++s) needRadius |= L.seg[s].kind == LAYER_FLOOR || L.seg[s].kind == LAYER_VELOCITY;
@@ -53,7 +54,7 @@ __global__ void __launch_bounds__(BLOCK) k_layer(NodeArrays nd, LayerData D, Lay
     for (uint32_t base = 0; base < m; base += kBatch * BLOCK) {
       uint32_t v[kBatch];
 #pragma unroll
-      for (int k = 0; k < kBatch; ++k) v[k] = nodes[min(base + k * BLOCK + tid, m - 1)];
+      for (int k = 0; k < kBatch; ++k) v[k] = D.nodeList[lp(min(base + k * BLOCK + tid, m - 1))];
       const float4 r0 = nd.pos[v[0]], r1 = nd.pos[v[1]], r2 = nd.pos[v[2]], r3 = nd.pos[v[3]];
       const uint32_t i = base + tid;
       if (i < m) sp[i] = r0;
@@ -62,11 +63,10 @@ __global__ void __launch_bounds__(BLOCK) k_layer(NodeArrays nd, LayerData D, Lay
       if (i + 3 * BLOCK < m) sp[i + 3 * BLOCK] = r3;
     }
   } else {
-    const float4* __restrict__ src = D.lpos + n0;
     for (uint32_t base = 0; base < m; base += kBatch * BLOCK) {
       const uint32_t i = base + tid;
-      const float4 r0 = src[min(i, m - 1)], r1 = src[min(i + BLOCK, m - 1)], r2 = src[min(i + 2 * BLOCK, m - 1)],
-                   r3 = src[min(i + 3 * BLOCK, m - 1)];
+      const float4 r0 = D.lpos[lp(min(i, m - 1))], r1 = D.lpos[lp(min(i + BLOCK, m - 1))], r2 = D.lpos[lp(min(i + 2 * BLOCK, m - 1))],
+                   r3 = D.lpos[lp(min(i + 3 * BLOCK, m - 1))];
       if (i < m) sp[i] = r0;
       if (i + BLOCK < m) sp[i + BLOCK] = r1;
       if (i + 2 * BLOCK < m) sp[i + 2 * BLOCK] = r2;
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(BLOCK) k_layer(NodeArrays nd, LayerData D, Lay
     }
   }
   if (needRadius)
-    for (uint32_t i = tid; i < m; i += BLOCK) srad[i] = D.lrad[n0 + i];
+    for (uint32_t i = tid; i < m; i += BLOCK) srad[i] = D.lrad[lp(i)];
   for (uint32_t s = 0; s < L.nseg; ++s) {
     const uint32_t nc = L.seg[s].ncol;
     if (nc == 0) continue;
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(BLOCK) k_layer(NodeArrays nd, LayerData D, Lay
         uint32_t v[kBatch];
         float4 vel[kBatch];
 #pragma unroll
-        for (int k = 0; k < kBatch; ++k) v[k] = nodes[min(base + k * BLOCK + tid, m - 1)];
+        for (int k = 0; k < kBatch; ++k) v[k] = D.nodeList[lp(min(base + k * BLOCK + tid, m - 1))];
 #pragma unroll
         for (int k = 0; k < kBatch; ++k) vel[k] = nd.vel[v[k]];
 #pragma unroll
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(BLOCK) k_layer(NodeArrays nd, LayerData D, Lay
         uint32_t v[kBatch];
         float4 prev[kBatch];
 #pragma unroll
-        for (int k = 0; k < kBatch; ++k) v[k] = nodes[min(base + k * BLOCK + tid, m - 1)];
+        for (int k = 0; k < kBatch; ++k) v[k] = D.nodeList[lp(min(base + k * BLOCK + tid, m - 1))];
 #pragma unroll
         for (int k = 0; k < kBatch; ++k) prev[k] = nd.prev[v[k]];
 #pragma unroll
@@ -224,14 +224,77 @@ __global__ void __launch_bounds__(BLOCK) k_layer(NodeArrays nd, LayerData D, Lay
     for (uint32_t base = 0; base < m; base += kBatch * BLOCK) {
       uint32_t v[kBatch];
 #pragma unroll
-      for (int k = 0; k < kBatch; ++k) v[k] = nodes[min(base + k * BLOCK + tid, m - 1)];
+      for (int k = 0; k < kBatch; ++k) v[k] = D.nodeList[lp(min(base + k * BLOCK + tid, m - 1))];
 #pragma unroll
       for (int k = 0; k < kBatch; ++k)
         if (base + k * BLOCK + tid < m) nd.pos[v[k]] = sp[base + k * BLOCK + tid];
     }
   } else {
-    for (uint32_t i = tid; i < m; i += BLOCK) D.lpos[n0 + i] = sp[i];
+    for (uint32_t i = tid; i < m; i += BLOCK) D.lpos[lp(i)] = sp[i];
   }
+}
+
+// ---- per-node steps over the level-ordered copy (bodies cut into strips) -----------------------------------------
+constexpr int kNodeBlock = 256;
+__global__ void __launch_bounds__(kNodeBlock) k_lpredict(NodeArrays nd, const uint32_t* __restrict__ nodeList, float4* __restrict__ lpos,
+                                                         float dt, float g) {
+  const uint32_t i = blockIdx.x * kNodeBlock + threadIdx.x;
+  if (i >= nd.n) return;
+  const uint32_t v = nodeList[i];
+  float4 p = nd.pos[v];
+  nd.prev[v] = make_float4(p.x, p.y, p.z, 0.0f);
+  predict_core(p, nd.vel[v], dt, g);
+  lpos[i] = p;
+}
+__global__ void __launch_bounds__(kNodeBlock) k_lvelocity(NodeArrays nd, const uint32_t* __restrict__ nodeList, const float4* __restrict__ lpos,
+                                                          const float* __restrict__ lrad, LayerParams P) {
+  const uint32_t i = blockIdx.x * kNodeBlock + threadIdx.x;
+  if (i >= nd.n) return;
+  const uint32_t v = nodeList[i];
+  const float4 p = lpos[i];
+  nd.vel[v] = velocity_core(p, nd.prev[v], lrad[i], P.dt, P.damping, P.friction, P.floorHeight);
+  nd.pos[v] = p;
+}
+__global__ void __launch_bounds__(kNodeBlock) k_lfloor(float4* __restrict__ lpos, const float* __restrict__ lrad, uint32_t n, float floorHeight) {
+  const uint32_t i = blockIdx.x * kNodeBlock + threadIdx.x;
+  if (i >= n) return;
+  float4 p = lpos[i];
+  if (floor_core(p, lrad[i], floorHeight)) lpos[i] = p;
+}
+__global__ void __launch_bounds__(kNodeBlock) k_lposition(float4* __restrict__ lpos, const uint32_t* __restrict__ lid,
+                                                          const float4* __restrict__ target_w, uint32_t start, uint32_t count) {
+  const uint32_t t = blockIdx.x * kNodeBlock + threadIdx.x;
+  if (t >= count) return;
+  const uint32_t i = lid[start + t];
+  float4 p = lpos[i];
+  position_core(p, target_w[start + t]);
+  lpos[i] = p;
+}
+template <bool TO_NODES>
+__global__ void __launch_bounds__(kNodeBlock) k_lcopy(float4* __restrict__ pos, const uint32_t* __restrict__ nodeList, float4* __restrict__ lpos,
+                                                      uint32_t n) {
+  const uint32_t i = blockIdx.x * kNodeBlock + threadIdx.x;
+  if (i >= n) return;
+  if (TO_NODES) pos[nodeList[i]] = lpos[i];
+  else lpos[i] = pos[nodeList[i]];
+}
+static dim3 node_grid(uint32_t n) { return dim3((n + kNodeBlock - 1) / kNodeBlock); }
+void launch_lpredict(hipStream_t st, const NodeArrays& nd, const LayerData& D, const LayerParams& P) {
+  if (nd.n) hipLaunchKernelGGL(k_lpredict, node_grid(nd.n), dim3(kNodeBlock), 0, st, nd, D.nodeList, D.lpos, P.dt, P.gravity);
+}
+void launch_lvelocity(hipStream_t st, const NodeArrays& nd, const LayerData& D, const LayerParams& P) {
+  if (nd.n) hipLaunchKernelGGL(k_lvelocity, node_grid(nd.n), dim3(kNodeBlock), 0, st, nd, D.nodeList, D.lpos, D.lrad, P);
+}
+void launch_lfloor(hipStream_t st, const NodeArrays& nd, const LayerData& D, const LayerParams& P) {
+  if (nd.n) hipLaunchKernelGGL(k_lfloor, node_grid(nd.n), dim3(kNodeBlock), 0, st, D.lpos, D.lrad, nd.n, P.floorHeight);
+}
+void launch_lposition(hipStream_t st, const LayerData& D, uint32_t start, uint32_t count) {
+  if (count) hipLaunchKernelGGL(k_lposition, node_grid(count), dim3(kNodeBlock), 0, st, D.lpos, D.pc_lid, D.pc_tw, start, count);
+}
+void launch_lcopy(hipStream_t st, const NodeArrays& nd, const LayerData& D, bool toNodeArray) {
+  if (nd.n == 0) return;
+  if (toNodeArray) hipLaunchKernelGGL(k_lcopy<true>, node_grid(nd.n), dim3(kNodeBlock), 0, st, nd.pos, D.nodeList, D.lpos, nd.n);
+  else hipLaunchKernelGGL(k_lcopy<false>, node_grid(nd.n), dim3(kNodeBlock), 0, st, nd.pos, D.nodeList, D.lpos, nd.n);
 }
 
 static size_t layer_lds_bytes(uint32_t maxGroupNodes) {

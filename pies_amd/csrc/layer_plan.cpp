@@ -168,16 +168,15 @@ bool build_layer_plan(pies_solver* s) {
     ids = &ops[k].ids[static_cast<size_t>(handle - base[k]) * stride];
   };
 
-  // ---- seeds: the end face of the body along its longest axis (levels become cross-sections) ----
+  // ---- bounding box, mean edge length ----
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (uint32_t v = 0; v < N; ++v)
     for (int a = 0; a < 3; ++a) {
       lo[a] = std::min(lo[a], s->h_pos[3 * v + a]);
       hi[a] = std::max(hi[a], s->h_pos[3 * v + a]);
     }
-  int axis = 0;
-  for (int a = 1; a < 3; ++a)
-    if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
+  int axes[3] = {0, 1, 2};  // by decreasing extent
+  std::stable_sort(axes, axes + 3, [&](int a, int b) { return hi[a] - lo[a] > hi[b] - lo[b]; });
   double edgeSum = 0.0;
   size_t edges = 0;
   for (int k : linking)
@@ -191,139 +190,230 @@ bool build_layer_plan(pies_solver* s) {
       if (std::isfinite(d2)) { edgeSum += std::sqrt(d2); ++edges; }
     }
   const float slack = edges ? static_cast<float>(0.45 * edgeSum / static_cast<double>(edges)) : 0.0f;
-  std::vector<uint32_t> byAxis;  // constrained nodes, ascending along the axis (ties: node index)
-  for (uint32_t v = 0; v < N; ++v)
-    if (start[v + 1] > start[v]) byAxis.push_back(v);
-  std::stable_sort(byAxis.begin(), byAxis.end(), [&](uint32_t a, uint32_t b) { return s->h_pos[3 * a + axis] < s->h_pos[3 * b + axis]; });
 
-  // ---- breadth-first levels, component after component ----
+  // ---- breadth-first levels from the end face along `axis` (levels become cross-sections), component after component;
+  //      nodes without constraints only take part in the per-node steps and are spread over the levels ----
   constexpr uint32_t kNone = 0xFFFFFFFFu;
-  std::vector<uint32_t> level(N, kNone);
-  std::vector<uint8_t> seen(totalOps, 0);
-  std::vector<uint32_t> frontier, next;
-  uint32_t nLevels = 0;
-  for (size_t cursor = 0; cursor < byAxis.size(); ++cursor) {
-    if (level[byAxis[cursor]] != kNone) continue;
-    const float c0 = s->h_pos[3 * byAxis[cursor] + axis];
-    frontier.clear();
-    for (size_t j = cursor; j < byAxis.size() && !(s->h_pos[3 * byAxis[j] + axis] > c0 + slack); ++j)
-      if (level[byAxis[j]] == kNone) { level[byAxis[j]] = nLevels; frontier.push_back(byAxis[j]); }
-    while (!frontier.empty()) {
-      next.clear();
-      for (uint32_t v : frontier)
-        for (uint32_t e = start[v]; e < start[v + 1]; ++e) {
-          if (seen[inc[e]]) continue;
-          seen[inc[e]] = 1;
-          const uint32_t* id;
-          uint32_t stride;
-          nodes_of(inc[e], id, stride);
-          for (uint32_t j = 0; j < stride; ++j)
-            if (level[id[j]] == kNone) { level[id[j]] = nLevels + 1; next.push_back(id[j]); }
-        }
-      ++nLevels;
-      frontier.swap(next);
+  auto bfs = [&](int axis, std::vector<uint32_t>& level) -> uint32_t {
+    std::vector<uint32_t> byAxis;  // constrained nodes, ascending along the axis (ties: node index)
+    for (uint32_t v = 0; v < N; ++v)
+      if (start[v + 1] > start[v]) byAxis.push_back(v);
+    std::stable_sort(byAxis.begin(), byAxis.end(), [&](uint32_t a, uint32_t b) { return s->h_pos[3 * a + axis] < s->h_pos[3 * b + axis]; });
+    level.assign(N, kNone);
+    std::vector<uint8_t> seen(totalOps, 0);
+    std::vector<uint32_t> frontier, next;
+    uint32_t nLevels = 0;
+    for (size_t cursor = 0; cursor < byAxis.size(); ++cursor) {
+      if (level[byAxis[cursor]] != kNone) continue;
+      const float c0 = s->h_pos[3 * byAxis[cursor] + axis];
+      frontier.clear();
+      for (size_t j = cursor; j < byAxis.size() && !(s->h_pos[3 * byAxis[j] + axis] > c0 + slack); ++j)
+        if (level[byAxis[j]] == kNone) { level[byAxis[j]] = nLevels; frontier.push_back(byAxis[j]); }
+      while (!frontier.empty()) {
+        next.clear();
+        for (uint32_t v : frontier)
+          for (uint32_t e = start[v]; e < start[v + 1]; ++e) {
+            if (seen[inc[e]]) continue;
+            seen[inc[e]] = 1;
+            const uint32_t* id;
+            uint32_t stride;
+            nodes_of(inc[e], id, stride);
+            for (uint32_t j = 0; j < stride; ++j)
+              if (level[id[j]] == kNone) { level[id[j]] = nLevels + 1; next.push_back(id[j]); }
+          }
+        ++nLevels;
+        frontier.swap(next);
+      }
     }
-  }
-  if (nLevels < 2) return false;
-  {  // nodes without constraints only take part in the per-node steps: spread them over the levels
+    if (nLevels == 0) return 0;
     uint32_t rr = 0;
     for (uint32_t v = 0; v < N; ++v)
       if (level[v] == kNone) level[v] = rr++ % nLevels;
-  }
-  L.levels = nLevels;
+    return nLevels;
+  };
+  std::vector<uint32_t> level1, level2;
+  const uint32_t L1 = bfs(axes[0], level1);
+  if (L1 < 2) return false;
+  L.levels = L1;
 
-  // ---- node list by (level, id), groups of both parities ----
-  std::vector<uint32_t> levelOff(nLevels + 1, 0);
-  for (uint32_t v = 0; v < N; ++v) ++levelOff[level[v] + 1];
-  for (uint32_t l = 0; l < nLevels; ++l) levelOff[l + 1] += levelOff[l];
+  // ---- one strip (a pair of levels fits a workgroup) or strips of a second levelling across the first ----
+  uint32_t maxPair = 0;
+  {
+    std::vector<uint32_t> cnt(L1 + 1, 0);
+    for (uint32_t v = 0; v < N; ++v) ++cnt[level1[v]];
+    for (uint32_t l = 0; l < L1; ++l) maxPair = std::max(maxPair, cnt[l] + cnt[l + 1]);
+  }
+  uint32_t oneStripMax = 2560, tileTarget = 1280;
+  if (const char* e = std::getenv("PIES_LAYER_ONE_STRIP_MAX")) oneStripMax = static_cast<uint32_t>(std::atoi(e));
+  if (const char* e = std::getenv("PIES_LAYER_TILE_NODES")) tileTarget = static_cast<uint32_t>(std::atoi(e));
+  tileTarget = std::min(tileTarget, kLayerMaxGroupNodes);
+  uint32_t L2 = 1, width = 1;
+  if (maxPair <= std::min(oneStripMax, kLayerMaxGroupNodes)) {
+    level2.assign(N, 0);
+  } else {
+    L2 = bfs(axes[1], level2);
+    if (L2 == 0) return false;
+    // nodes per (level1, level2) cell, prefix sums along level2
+    std::vector<uint32_t> pre(static_cast<size_t>(L1 + 1) * (L2 + 1), 0);
+    for (uint32_t v = 0; v < N; ++v) ++pre[static_cast<size_t>(level1[v]) * (L2 + 1) + level2[v] + 1];
+    for (uint32_t l = 0; l < L1; ++l)
+      for (uint32_t m = 0; m < L2; ++m) pre[static_cast<size_t>(l) * (L2 + 1) + m + 1] += pre[static_cast<size_t>(l) * (L2 + 1) + m];
+    auto tile_max = [&](uint32_t w) {
+      uint32_t worst = 0;
+      for (uint32_t l = 0; l < L1; ++l)
+        for (uint32_t t = 0; t * w < L2; ++t) {
+          const uint32_t m0 = t * w, m1 = std::min((t + 1) * w + 1, L2);  // the strip and the first level of the next one
+          uint32_t n = pre[static_cast<size_t>(l) * (L2 + 1) + m1] - pre[static_cast<size_t>(l) * (L2 + 1) + m0];
+          if (l + 1 < L1) n += pre[static_cast<size_t>(l + 1) * (L2 + 1) + m1] - pre[static_cast<size_t>(l + 1) * (L2 + 1) + m0];
+          worst = std::max(worst, n);
+        }
+      return worst;
+    };
+    width = 0;
+    for (uint32_t w = L2; w >= 1; --w)
+      if (tile_max(w) <= tileTarget) { width = w; break; }
+    if (width == 0) {
+      if (tile_max(1) > kLayerMaxGroupNodes) return false;  // even single cross-lines do not fit in LDS
+      width = 1;
+    }
+  }
+  const uint32_t S = (L2 + width - 1) / width;  // strips
+  L.strips = S;
+  L.width = width;
+
+  // ---- node list by (level1, level2, id) ----
+  std::vector<uint32_t> cellOff(static_cast<size_t>(L1) * L2 + 1, 0);
+  for (uint32_t v = 0; v < N; ++v) ++cellOff[static_cast<size_t>(level1[v]) * L2 + level2[v] + 1];
+  for (size_t c = 0; c < static_cast<size_t>(L1) * L2; ++c) cellOff[c + 1] += cellOff[c];
   L.nodeList.resize(N);
   std::vector<uint32_t> posInList(N);
   {
-    std::vector<uint32_t> cur(levelOff.begin(), levelOff.end() - 1);
-    for (uint32_t v = 0; v < N; ++v) { posInList[v] = cur[level[v]]; L.nodeList[cur[level[v]]++] = v; }
+    std::vector<uint32_t> cur(cellOff.begin(), cellOff.end() - 1);
+    for (uint32_t v = 0; v < N; ++v) {
+      uint32_t& c = cur[static_cast<size_t>(level1[v]) * L2 + level2[v]];
+      posInList[v] = c;
+      L.nodeList[c++] = v;
+    }
   }
-  L.groups[0] = (nLevels + 1) / 2;
-  L.groups[1] = nLevels / 2 + 1;
-  L.groupOff[0].resize(L.groups[0] + 1);
-  for (uint32_t g = 0; g <= L.groups[0]; ++g) L.groupOff[0][g] = levelOff[std::min(2 * g, nLevels)];
-  L.groupOff[1].resize(L.groups[1] + 1);
-  L.groupOff[1][0] = 0;
-  for (uint32_t g = 1; g <= L.groups[1]; ++g) L.groupOff[1][g] = levelOff[std::min(2 * g - 1, nLevels)];
-  for (int q = 0; q < 2; ++q)
-    for (uint32_t g = 0; g < L.groups[q]; ++g) L.maxGroupNodes = std::max(L.maxGroupNodes, L.groupOff[q][g + 1] - L.groupOff[q][g]);
-  if (L.maxGroupNodes > kLayerMaxGroupNodes) return false;  // a pair of levels does not fit in LDS
 
-  // ---- per container: group, colour inside the group, order ----
+  // ---- tiles: phase = 2 * (level parity) + (strip parity); odd level parity starts with the tile "level 0 alone"
+  //      (it only matters with one strip, where the per-node steps may run with either parity) ----
+  const uint32_t G[2] = {(L1 + 1) / 2, L1 / 2 + 1}, Sp[2] = {(S + 1) / 2, S / 2};
+  auto run_of = [&](int64_t l, uint32_t t, uint32_t& first, uint32_t& count) {
+    first = count = 0;
+    if (l < 0 || l >= static_cast<int64_t>(L1)) return;
+    const uint32_t m0 = t * width, m1 = std::min((t + 1) * width + 1, L2);
+    first = cellOff[static_cast<size_t>(l) * L2 + m0];
+    count = cellOff[static_cast<size_t>(l) * L2 + m1] - first;
+  };
+  for (int p1 = 0; p1 < 2; ++p1)
+    for (int p2 = 0; p2 < 2; ++p2) {
+      std::vector<LayerTile>& T = L.tiles[2 * p1 + p2];
+      T.resize(static_cast<size_t>(G[p1]) * Sp[p2]);
+      for (uint32_t gi = 0; gi < G[p1]; ++gi)
+        for (uint32_t ti = 0; ti < Sp[p2]; ++ti) {
+          const int64_t l = p1 == 0 ? 2 * static_cast<int64_t>(gi) : 2 * static_cast<int64_t>(gi) - 1;
+          LayerTile& tile = T[static_cast<size_t>(gi) * Sp[p2] + ti];
+          run_of(l, 2 * ti + p2, tile.first0, tile.count0);
+          run_of(l + 1, 2 * ti + p2, tile.first1, tile.count1);
+          if (tile.count0 == 0) { tile.first0 = tile.first1; tile.count0 = tile.count1; tile.first1 = tile.count1 = 0; }
+          L.maxGroupNodes = std::max(L.maxGroupNodes, tile.count0 + tile.count1);
+        }
+    }
+  if (L.maxGroupNodes > kLayerMaxGroupNodes) return false;
+
+  // ---- per container: tile of every op, colouring inside the tile, execution order ----
   int rounds = 12;
   if (const char* e = std::getenv("PIES_COLOUR_ROUNDS")) rounds = std::atoi(e);
   const char* noHint = std::getenv("PIES_NO_COLOUR_HINT");
   std::vector<uint32_t> localOf(N, 0);
+  auto local_index = [&](const LayerTile& tile, uint32_t v) {
+    const uint32_t p = posInList[v];
+    return p >= tile.first0 && p < tile.first0 + tile.count0 ? p - tile.first0 : tile.count0 + (p - tile.first1);
+  };
   Plan plans[5];
   for (int k : kinds) {
     const Ops& O = ops[k];
     LayerKind& K = L.kind[k];
     Plan& P = plans[k];
     if (O.count == 0) continue;
-    // group of an op: parity and index from its lowest level (position constraints run with the even groups)
-    std::vector<std::vector<uint32_t>> members[2];
-    members[0].resize(L.groups[0]);
-    members[1].resize(L.groups[1]);
+    if (k == PIES_POSITION && S > 1) {
+      // with strips the per-node steps are launches of their own over the level-ordered copy: the j-th constraint of a
+      // node goes to batch j (constraints of one node keep their order, constraints of different nodes commute)
+      std::vector<uint32_t> seenCount(N, 0), key(O.count);
+      uint32_t nb = 0;
+      for (uint32_t c = 0; c < O.count; ++c) { key[c] = seenCount[O.ids[c]]++; nb = std::max(nb, key[c] + 1); }
+      std::vector<uint32_t> offs(nb + 1, 0);
+      for (uint32_t c = 0; c < O.count; ++c) ++offs[key[c] + 1];
+      for (uint32_t b = 0; b < nb; ++b) offs[b + 1] += offs[b];
+      P.order.assign(O.count, 0);
+      std::vector<uint32_t> cur(offs.begin(), offs.end() - 1);
+      for (uint32_t c = 0; c < O.count; ++c) P.order[cur[key[c]]++] = c;
+      for (uint32_t b = 0; b < nb; ++b) P.batches.push_back({offs[b], offs[b + 1] - offs[b]});
+      for (uint32_t c : P.order) K.local.push_back(posInList[O.ids[c]]);  // index into the level-ordered copy
+      continue;
+    }
+    std::vector<std::vector<uint32_t>> members[4];
+    for (int ph = 0; ph < 4; ++ph) members[ph].resize(L.tiles[ph].size());
     for (uint32_t c = 0; c < O.count; ++c) {
-      uint32_t l = kNone, lmax = 0;
+      uint32_t l = kNone, lmax = 0, m = kNone, mmax = 0;
       for (uint32_t j = 0; j < O.stride; ++j) {
-        l = std::min(l, level[O.ids[static_cast<size_t>(c) * O.stride + j]]);
-        lmax = std::max(lmax, level[O.ids[static_cast<size_t>(c) * O.stride + j]]);
+        const uint32_t v = O.ids[static_cast<size_t>(c) * O.stride + j];
+        l = std::min(l, level1[v]); lmax = std::max(lmax, level1[v]);
+        m = std::min(m, level2[v]); mmax = std::max(mmax, level2[v]);
       }
-      if (lmax - l > 1) return false;  // cannot happen for a breadth-first levelling
-      if (k == PIES_POSITION) members[0][l / 2].push_back(c);
-      else if (l & 1u) members[1][(l + 1) / 2].push_back(c);
-      else members[0][l / 2].push_back(c);
+      if (lmax - l > 1 || mmax - m > 1) return false;  // cannot happen for breadth-first levellings
+      const uint32_t t = m / width;
+      if (k == PIES_POSITION) { members[0][static_cast<size_t>(l / 2) * Sp[0]].push_back(c); continue; }  // one strip: with the even tiles
+      const int p1 = l & 1u, p2 = t & 1u;
+      const uint32_t gi = p1 ? (l + 1) / 2 : l / 2;
+      members[2 * p1 + p2][static_cast<size_t>(gi) * Sp[p2] + t / 2].push_back(c);
     }
     P.order.reserve(O.count);
     K.local.reserve(static_cast<size_t>(O.count) * O.stride);
-    std::vector<std::vector<uint32_t>> keys[2];
-    for (int phase = 0; phase < 2; ++phase) {
-      const int q = (kLayerFirstParity[k] + phase) & 1;
-      keys[q].resize(L.groups[q]);
+    for (int step = 0; step < 4; ++step) {
+      const int ph = kLayerPhaseOrder[k][step];
+      const std::vector<LayerTile>& T = L.tiles[ph];
+      std::vector<std::vector<uint32_t>> keys(T.size());
       uint32_t ncol = 0;
-      for (uint32_t g = 0; g < L.groups[q]; ++g) {
-        const std::vector<uint32_t>& sel = members[q][g];
+      for (size_t g = 0; g < T.size(); ++g) {
+        const std::vector<uint32_t>& sel = members[ph][g];
         if (sel.empty()) continue;
-        const uint32_t n0 = L.groupOff[q][g], m = L.groupOff[q][g + 1] - n0;
-        for (uint32_t i = 0; i < m; ++i) localOf[L.nodeList[n0 + i]] = i;
-        uint32_t nc = colour_group(O, sel, localOf.data(), m, rounds, keys[q][g]);
+        const uint32_t m = T[g].count0 + T[g].count1;
+        for (uint32_t i = 0; i < T[g].count0; ++i) localOf[L.nodeList[T[g].first0 + i]] = i;
+        for (uint32_t i = 0; i < T[g].count1; ++i) localOf[L.nodeList[T[g].first1 + i]] = T[g].count0 + i;
+        uint32_t nc = colour_group(O, sel, localOf.data(), m, rounds, keys[g]);
         if (nc == 0) return false;
         if (!(noHint && std::atoi(noHint)))
           for (int a = 0; a < 3; ++a) {
             std::vector<uint32_t> proposed;
             const uint32_t nh = from_hint(O, sel, O.hints[a], localOf.data(), m, proposed);
-            if (nh != 0 && nh < nc) { keys[q][g].swap(proposed); nc = nh; }
+            if (nh != 0 && nh < nc) { keys[g].swap(proposed); nc = nh; }
           }
         ncol = std::max(ncol, nc);
       }
-      K.ncol[phase] = ncol;
-      K.colOff[phase].assign(static_cast<size_t>(L.groups[q]) * (ncol + 1), 0);
-      for (uint32_t g = 0; g < L.groups[q]; ++g) {
-        const std::vector<uint32_t>& sel = members[q][g];
-        const uint32_t n0 = L.groupOff[q][g];
+      K.ncol[ph] = ncol;
+      if (ncol == 0) continue;  // no constraint of this container in this phase
+      K.colOff[ph].assign(T.size() * (ncol + 1), 0);
+      for (size_t g = 0; g < T.size(); ++g) {
+        const std::vector<uint32_t>& sel = members[ph][g];
         std::vector<uint32_t> offs(ncol + 2, 0);
-        for (uint32_t key : keys[q][g]) ++offs[key + 1];
+        for (uint32_t key : keys[g]) ++offs[key + 1];
         for (uint32_t c = 0; c <= ncol; ++c) offs[c + 1] += offs[c];
         const uint32_t slot0 = static_cast<uint32_t>(P.order.size());
-        for (uint32_t c = 0; c <= ncol; ++c) K.colOff[phase][static_cast<size_t>(g) * (ncol + 1) + c] = slot0 + offs[c];
+        for (uint32_t c = 0; c <= ncol; ++c) K.colOff[ph][g * (ncol + 1) + c] = slot0 + offs[c];
         for (uint32_t c = 0; c < ncol; ++c)
           if (offs[c + 1] > offs[c]) {
             P.batches.push_back({slot0 + offs[c], offs[c + 1] - offs[c]});
             K.maxClass = std::max(K.maxClass, offs[c + 1] - offs[c]);
           }
         std::vector<uint32_t> sorted(sel.size()), cur(offs.begin(), offs.end() - 1);
-        for (size_t p = 0; p < sel.size(); ++p) sorted[cur[keys[q][g][p]]++] = sel[p];  // stable: host order in a class
+        for (size_t p = 0; p < sel.size(); ++p) sorted[cur[keys[g][p]]++] = sel[p];  // stable: host order in a class
         for (uint32_t c : sorted) {
           P.order.push_back(c);
-          for (uint32_t j = 0; j < O.stride; ++j) K.local.push_back(posInList[O.ids[static_cast<size_t>(c) * O.stride + j]] - n0);
+          for (uint32_t j = 0; j < O.stride; ++j) K.local.push_back(local_index(T[g], O.ids[static_cast<size_t>(c) * O.stride + j]));
         }
       }
-      if (k == PIES_POSITION) break;  // one phase only
     }
     if (P.order.size() != O.count) return false;
   }

@@ -85,29 +85,35 @@ struct WavePlan {
 // two adjacent levels, so the constraints whose lowest level is l ("group l") touch levels l and l+1 only and
 // groups of equal parity are independent: one workgroup sweeps one group with its nodes resident in LDS, colour
 // after colour (a colouring inside the group), and a container's sweep is two launches (even groups, odd groups).
-struct LayerKind {
-  uint32_t ncol[2] = {0, 0};         // colours per group in the container's first / second phase (padded to the max)
-  std::vector<uint32_t> colOff[2];   // per group of the phase's parity: ncol+1 absolute slot offsets
-  std::vector<uint32_t> local;       // stride x count group-local node indices (16 bit each), slot order
-  uint32_t maxClass = 0;             // largest colour class of any group
+struct LayerTile {  // the nodes a workgroup keeps in LDS: two runs of the level-ordered node list (one per level)
+  uint32_t first0, count0, first1, count1;
 };
-constexpr int kLayerFirstParity[5] = {0, 0, 1, 0, 0};  // parity of a container's first phase (POSITION, DISTANCE, TET, -, BEND)
-constexpr uint32_t kLayerMaxGroupNodes = 7936;         // 20 B per node (record + radius) + the colour offsets in the 160 KB LDS
+struct LayerKind {
+  uint32_t ncol[4] = {0, 0, 0, 0};   // colours per tile in each phase (padded to the phase's maximum; 0 = phase unused)
+  std::vector<uint32_t> colOff[4];   // per tile of the phase: ncol+1 absolute slot offsets
+  std::vector<uint32_t> local;       // stride x count tile-local node indices (16 bit each), slot order
+  uint32_t maxClass = 0;             // largest colour class of any tile
+};
+// A tile's phase = 2 * (parity of its lowest level) + (parity of its strip).  Order in which a container runs its phases:
+// the distance container ends where the tetrahedral one starts and vice versa, so those phases share a launch.
+constexpr int kLayerPhaseOrder[5][4] = {{0, 1, 2, 3}, {0, 1, 2, 3}, {3, 2, 1, 0}, {0, 1, 2, 3}, {0, 1, 2, 3}};
+constexpr uint32_t kLayerMaxGroupNodes = 7936;  // 20 B per node (record + radius) + the colour offsets in the 160 KB LDS
 struct LayerPlan {
   bool active = false;
-  uint32_t levels = 0;
-  uint32_t groups[2] = {0, 0};        // even groups cover levels (2g, 2g+1); odd groups (2g-1, 2g), group 0 = level 0 alone
-  uint32_t maxGroupNodes = 0;
-  std::vector<uint32_t> nodeList;     // node ids sorted by (level, id)
-  std::vector<uint32_t> groupOff[2];  // per parity: groups+1 offsets into nodeList
+  uint32_t levels = 0;         // breadth-first levels along the longest axis
+  uint32_t strips = 1;         // strips of `width` levels of the second levelling (1: a pair of levels is one tile)
+  uint32_t width = 1;
+  uint32_t maxGroupNodes = 0;  // nodes of the largest tile
+  std::vector<uint32_t> nodeList;     // node ids sorted by (level, second level, id)
+  std::vector<LayerTile> tiles[4];    // per phase
   LayerKind kind[5];                  // indexed by PIES_POSITION .. PIES_BEND (PIES_VOLUME unused)
 };
 struct LayerDevice {
   uint32_t* nodeList = nullptr;
   float4* lpos = nullptr;
   float* lrad = nullptr;
-  uint32_t* groupOff[2] = {nullptr, nullptr};
-  uint32_t* colOff[5][2] = {};
+  pies::LayerTile* tiles[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint32_t* colOff[5][4] = {};
   uint32_t* pc_lid = nullptr;  // 1 x 16 bit in a word
   uint32_t* dc_lid = nullptr;  // a | b << 16
   uint2* tc_lid = nullptr;     // (n1 | n2 << 16, n3 | n4 << 16)

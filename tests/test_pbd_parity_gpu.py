@@ -236,13 +236,55 @@ def test_layered_with_node_collisions(pies, oracle):
     _check(g, o)
 
 
-def test_layered_falls_back_when_levels_do_not_fit_in_lds(pies, oracle):
+def test_layered_wide_body_is_cut_into_strips(pies, oracle):
+    """Cross-sections of 4096 nodes: a pair of levels is cut into strips by a second levelling (four phases per
+    container instead of two; predict / floor / velocity run as launches of their own over the level-ordered copy)."""
     def build(s):
-        scenes.build_beam(s, (64, 64, 64))  # cross-sections of 4096 nodes: two levels exceed the LDS budget
+        scenes.build_beam(s, (64, 64, 64))
         scenes.perturb(s, 6, 0.05)
     g, o = _layered_pair(pies, oracle, build, 2, ticks=1)
     lc = g.launch_counts()
-    assert lc["layer"] == 0 and lc["tet"] > 0  # coloured batches instead
+    assert lc["layer"] == 2 * 7 and lc["tet"] == 0 and lc["predict"] == 1 and lc["floor"] == 2 and lc["velocity"] == 1, lc
+    _check(g, o)
+
+
+@pytest.mark.parametrize("collisions", [0, 1])
+def test_layered_strips_small_tiles_all_containers(pies, oracle, monkeypatch, collisions):
+    """The strip path forced onto small scenes (tiny tiles, ragged strips): beams, a bend sheet, a hinged sheet with
+    position constraints (two of them on one node), with and without the collision pass between the sweeps."""
+    monkeypatch.setenv("PIES_LAYER_ONE_STRIP_MAX", "40")
+    monkeypatch.setenv("PIES_LAYER_TILE_NODES", "90")
+    def build(s):
+        scenes.build_beam(s, (7, 6, 13), translation=(0.0, 0.3, 0.0))
+        scenes.build_beam(s, (5, 9, 4), translation=(1.3, 7.2, 0.4))
+        s.create_bend_sheet(7, 9, translation=(12.0, 3.0, 0.0))
+        s.create_sheet(9, 7, translation=(24, 3, 0), scale=0.5, mass=2.0, w=0.7)
+        s.add_position(np.array([3, 3, 40], dtype=np.uint32), 0.3)
+        scenes.perturb(s, 4, 0.05)
+    g, o = _layered_pair(pies, oracle, build, 4, ticks=3, collisions=collisions)
+    lc = g.launch_counts()
+    assert lc["layer"] > 0 and lc["floor"] == 4 and lc["position"] >= 4 and (lc["collide"] > 0) == bool(collisions), lc
+    _check(g, o, exact=False)  # bend: acos
+
+
+def test_layered_substeps_and_state_edits(pies, oracle):
+    """timeSubsteps > 1 (the captured substep is replayed) and node state written between ticks (the first launch of a
+    substep reads the node array, not the level-ordered copy)."""
+    g = pies.Solver(scenes.pbd_options(pies, 3, timeSubsteps=3))
+    o = oracle.OracleSolver(scenes.pbd_options(oracle, 3, timeSubsteps=3))
+    for s in (g, o):
+        scenes.build_beam(s, (4, 4, 15))
+        s.set_flag(1, 0)
+    g.set_schedule(pies.SCHEDULE_LAYERED)
+    g.finalize()
+    for t in (pies.DISTANCE, pies.TET):
+        o.permute(t, g.order(t))
+    for s in (g, o):
+        s.tick(2)
+        scenes.perturb(s, 9, 0.1)
+        s.set_radii(np.full(s.count(pies.NODES), 0.3, dtype=np.float32))
+        s.tick(2)
+    assert g.launch_counts()["layer"] == 7
     _check(g, o)
 
 
