@@ -25,6 +25,8 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # the CPU baseline's OpenMP threads sleep at barriers instead of spinning
+
 import numpy as np  # noqa: E402
 
 import scenes  # noqa: E402
@@ -35,6 +37,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec)
 BYTES = {"predict": 48, "position": 44, "distance": 52, "tet": 160, "bend": 136, "floor": 20, "velocity": 40,
          "layer": 1}  # a layer launch fuses several kinds: the library tallies its units in algorithmic bytes directly
 ITERATIONS = 20
+
+
+def log(msg):
+    """Progress on stderr (stdout carries the one JSON line)."""
+    print("[bench %6.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
+T_START = time.perf_counter()
 
 
 def dist_env():
@@ -137,12 +147,15 @@ def scale_profiles(device):
     """Per-kernel algorithmic bandwidth of the projection and SpMV kernels at 1M particles (100x100x100), where
     a launch is long enough for HBM rather than the kernel boundary to bound it."""
     out = {}
-    g = build_scene(capi, scenes.L1M, 99, schedule=capi.SCHEDULE_COLOURED, device=device)
-    g.finalize()
-    el = timed_ticks(g, 3, 1, lambda: None)
-    out["pbd_1m"] = {"substeps_per_sec": 3 / el, "projections_per_sec": 3 / el * scenes.projections_per_substep(g, capi, ITERATIONS),
+    for name, sched in (("pbd_1m", capi.SCHEDULE_LAYERED), ("pbd_1m_coloured", capi.SCHEDULE_COLOURED)):
+        log(name)
+        g = build_scene(capi, scenes.L1M, 99, schedule=sched, device=device)
+        g.finalize()
+        el = timed_ticks(g, 3, 1, lambda: None)
+        out[name] = {"substeps_per_sec": 3 / el, "projections_per_sec": 3 / el * scenes.projections_per_substep(g, capi, ITERATIONS),
                      "launches_per_substep": sum(g.launch_counts().values()), "kernels": kernel_profile(g)}
-    g.close()
+        g.close()
+    log("pd_1m")
     g = pd_beam(scenes.L1M, device)
     el = timed_ticks(g, 3, 1, lambda: None)
     out["pd_1m"] = {"substeps_per_sec": 3 / el, "pcg_stats": g.pcg_stats(), "kernels": kernel_profile(g, pd_bytes(g))}
@@ -194,6 +207,19 @@ def extra_configs(device):
     return out
 
 
+def host_cores():
+    """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands out a
+    share of a large host; OpenMP threads beyond the share only spin against each other)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_all_cores(dims, ticks, threads):
     """The same oracle with every host core: the containers re-ordered into the conflict-free colour classes of a
     coloured plan (built by a host-only handle: no GPU involved) and each class swept with OpenMP threads."""
@@ -206,7 +232,10 @@ def cpu_all_cores(dims, ticks, threads):
         o.set_batches(t, plan.batches(t))
     plan.close()
     o.set_threads(threads)
-    o.tick(1)
+    t0 = time.perf_counter()
+    o.tick(1)  # warm-up, and the yardstick that bounds the sample to about ten seconds
+    one = time.perf_counter() - t0
+    ticks = max(1, min(ticks, int(10.0 / max(one, 1e-3))))
     t0 = time.perf_counter()
     o.tick(ticks)
     dt = time.perf_counter() - t0
@@ -222,7 +251,7 @@ def cpu_baseline(dims, ticks):
     t0 = time.perf_counter()
     o.tick(ticks)
     dt = time.perf_counter() - t0
-    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = host_cores()
     return {
         "all_cores": cpu_all_cores(dims, 3 * ticks, threads),
         "value": ticks / dt, "unit": "substeps/s", "cores": 1, "kind": "port",
@@ -279,6 +308,7 @@ def main():
     substeps_per_tick = g.options.timeSubsteps
     proj = scenes.projections_per_substep(g, capi, ITERATIONS)
 
+    log("scene ready, timing %d steps" % args.steps)
     elapsed = timed_ticks(g, args.steps, args.warmup, barrier)
     elapsed, total_substeps = aggregate(elapsed, args.steps * substeps_per_tick, dist)
     assert np.isfinite(g.positions).all()
@@ -323,6 +353,7 @@ def main():
 
     if rank == 0 and world == 1:
         if not args.no_exact and args.schedule == "layered":
+            log("coloured schedule")
             c = build_scene(capi, dims, 1234, schedule=capi.SCHEDULE_COLOURED, device=device_index)
             c.finalize()
             steps = max(2, min(args.steps, 50))
@@ -333,6 +364,7 @@ def main():
                                            "note": "schedule COLOURED: one launch per colour class (24 tet + 9 distance colours per iteration)"}
             c.close()
         if not args.no_exact and args.schedule != "exact":
+            log("exact schedule")
             e = build_scene(capi, dims, 1234, schedule=capi.SCHEDULE_EXACT, device=device_index)
             e.finalize()
             steps = max(2, min(args.steps, 10))
@@ -343,11 +375,15 @@ def main():
                                              "the whole-substep dependency DAG"}
             e.close()
         if not args.no_extras:
+            log("configs 3 and 4")
             result["other_configs"] = extra_configs(device_index)
         if not args.no_scale:
+            log("1M-particle profiles")
             result["scale_1m"] = scale_profiles(device_index)
         if not args.no_cpu_baseline:
+            log("CPU baseline")
             result["cpu_baseline"] = cpu_baseline(dims, args.cpu_ticks)
+        log("done")
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
