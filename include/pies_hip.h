@@ -78,9 +78,9 @@ enum {
  *             colour by colour (pies_get_order returns that order).  Fewer, larger launches.
  *  LAYERED  : breadth-first levels of the constraint graph; the constraints between two adjacent levels are
  *             swept colour by colour by one workgroup with the nodes resident in LDS (two launches per
- *             iteration).  Identical to a sequential sweep in the order pies_get_order returns.  Falls back
- *             to COLOURED when two adjacent levels do not fit in LDS (wide bodies) or node-node collisions
- *             are on. */
+ *             iteration; wide bodies are cut into strips by a second levelling: four phases per container).
+ *             Identical to a sequential sweep in the order pies_get_order returns.  Falls back to COLOURED
+ *             for scenes without distance / tetrahedral / bend constraints. */
 enum { PIES_SCHEDULE_EXACT = 0, PIES_SCHEDULE_COLOURED = 1, PIES_SCHEDULE_LAYERED = 2 };
 
 enum {
