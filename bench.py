@@ -189,6 +189,16 @@ def extra_configs(device):
     g.finalize()
     out["pd_config3"]["kernels"] = kernel_profile(g, pd_bytes(g))
     g.close()
+    # configs[4], one GPU's share: a 250k-particle body (25x25x400), PD, point-triangle + floor contact pipeline on
+    log("config 5 share")
+    g = pd_beam(scenes.L250K, device)
+    el = timed_ticks(g, 20, 3, lambda: None)
+    res, iters, solves = g.pcg_stats()
+    out["pd_config5_per_gpu"] = {"value": 20 / el, "unit": "substeps/s", "workload": "25x25x400 beam (250000 particles), PD, tets + volume, 10 "
+                                 "iterations, point-triangle CCD + floor contacts on; configs[4] runs one such body per GPU",
+                                 "pcg_max_rel_residual": res, "pcg_max_iterations_used": iters,
+                                 "tri_contacts_last_substep": len(g.tri_collisions())}
+    g.close()
     # configs[3]: 500k loose particles, node-node collisions + floor, PBD, 4 iterations
     W, H, D = scenes.L500K
     rng = np.random.default_rng(1234)

@@ -310,8 +310,15 @@ hipError_t layer_prepare(uint32_t maxGroupNodes) {
   return e;
 }
 
-void launch_layer(hipStream_t st, const NodeArrays& nd, const LayerData& D, const LayerLaunch& L, const LayerParams& P) {
-  if (L.groups == 0 || L.nseg == 0) return;
+void launch_layer(hipStream_t st, const NodeArrays& nd, const LayerData& D, const LayerLaunch& L0, const LayerParams& P) {
+  if (L0.groups == 0 || L0.nseg == 0) return;
+  static const int skipMask = [] { const char* e = getenv("PIES_EXP_LAYER_SKIP"); return e ? atoi(e) : 0; }();  // timing experiments
+  LayerLaunch L = L0;
+  if (skipMask) {
+    L.nseg = 0;
+    for (uint32_t s = 0; s < L0.nseg; ++s)
+      if (!((skipMask >> L0.seg[s].kind) & 1)) L.seg[L.nseg++] = L0.seg[s];
+  }
   const size_t lds = layer_lds_bytes(D.maxGroupNodes);
   static const int variant = [] { const char* e = getenv("PIES_EXP_TET"); return e ? atoi(e) : 0; }();
   static const uint32_t forceBlock = [] { const char* e = getenv("PIES_LAYER_BLOCK"); return e ? (uint32_t)atoi(e) : 0u; }();
