@@ -189,6 +189,22 @@ def extra_configs(device):
     g.finalize()
     out["pd_config3"]["kernels"] = kernel_profile(g, pd_bytes(g))
     g.close()
+    # configs[1] on an unstructured mesh: Delaunay beam of the same size (the lattice stands in for tetgen in the headline)
+    log("unstructured beam")
+    mesh = scenes.delaunay_beam(scenes.L100K)
+    un = {"workload": "Delaunay triangulation of a jittered 20x20x250 lattice: %d particles, %d distance + %d tet-strain constraints, "
+                      "PBD, 20 iterations" % (len(mesh[0]), len(mesh[2]), len(mesh[1]))}
+    for name, sched in (("layered", capi.SCHEDULE_LAYERED), ("coloured", capi.SCHEDULE_COLOURED)):
+        g = capi.Solver(scenes.pbd_options(capi, ITERATIONS), device=device)
+        scenes.build_unstructured(g, mesh)
+        scenes.perturb(g, 1234, 0.03)
+        g.set_flag(1, 0)
+        g.set_schedule(sched)
+        g.finalize()
+        el = timed_ticks(g, 20, 2, lambda: None)
+        un[name] = {"value": 20 / el, "unit": "substeps/s", "launches_per_substep": sum(g.launch_counts().values())}
+        g.close()
+    out["unstructured_config2"] = un
     # configs[4], one GPU's share: a 250k-particle body (25x25x400), PD, point-triangle + floor contact pipeline on
     log("config 5 share")
     g = pd_beam(scenes.L250K, device)
@@ -197,7 +213,7 @@ def extra_configs(device):
     out["pd_config5_per_gpu"] = {"value": 20 / el, "unit": "substeps/s", "workload": "25x25x400 beam (250000 particles), PD, tets + volume, 10 "
                                  "iterations, point-triangle CCD + floor contacts on; configs[4] runs one such body per GPU",
                                  "pcg_max_rel_residual": res, "pcg_max_iterations_used": iters,
-                                 "tri_contacts_last_substep": len(g.tri_collisions())}
+                                 "tri_contacts_last_substep": len(g.tri_collisions)}
     g.close()
     # configs[3]: 500k loose particles, node-node collisions + floor, PBD, 4 iterations
     W, H, D = scenes.L500K

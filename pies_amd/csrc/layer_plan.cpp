@@ -16,6 +16,7 @@
 // likewise the last phase of one iteration and the first phase of the next.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -121,6 +122,12 @@ uint32_t colour_group(const Ops& ops, const std::vector<uint32_t>& sel, const ui
 
 }  // namespace
 
+// PIES_LAYER_DEBUG=1: say on stderr why a scene was handed back to the coloured schedule
+static bool layer_reject(const char* why) {
+  if (const char* e = std::getenv("PIES_LAYER_DEBUG"); e && e[0] == '1') std::fprintf(stderr, "[pies] schedule LAYERED not used: %s\n", why);
+  return false;
+}
+
 bool build_layer_plan(pies_solver* s) {
   const uint32_t N = s->nodeCount();
   LayerPlan L;
@@ -142,7 +149,7 @@ bool build_layer_plan(pies_solver* s) {
   const int linking[3] = {PIES_DISTANCE, PIES_TET, PIES_BEND};
   size_t incidences = 0;
   for (int k : linking) incidences += ops[k].ids.size();
-  if (N == 0 || incidences == 0) return false;
+  if (N == 0 || incidences == 0) return layer_reject("no distance / tetrahedral / bend constraints");
 
   // ---- node -> incident constraints (all linking containers in one list) ----
   std::vector<uint32_t> start(N + 1, 0);
@@ -233,7 +240,7 @@ bool build_layer_plan(pies_solver* s) {
   };
   std::vector<uint32_t> level1, level2;
   const uint32_t L1 = bfs(axes[0], level1);
-  if (L1 < 2) return false;
+  if (L1 < 2) return layer_reject("fewer than two levels");
   L.levels = L1;
 
   // ---- one strip (a pair of levels fits a workgroup) or strips of a second levelling across the first ----
@@ -252,7 +259,7 @@ bool build_layer_plan(pies_solver* s) {
     level2.assign(N, 0);
   } else {
     L2 = bfs(axes[1], level2);
-    if (L2 == 0) return false;
+    if (L2 == 0) return layer_reject("no second levelling");
     // nodes per (level1, level2) cell, prefix sums along level2
     std::vector<uint32_t> pre(static_cast<size_t>(L1 + 1) * (L2 + 1), 0);
     for (uint32_t v = 0; v < N; ++v) ++pre[static_cast<size_t>(level1[v]) * (L2 + 1) + level2[v] + 1];
@@ -273,7 +280,7 @@ bool build_layer_plan(pies_solver* s) {
     for (uint32_t w = L2; w >= 1; --w)
       if (tile_max(w) <= tileTarget) { width = w; break; }
     if (width == 0) {
-      if (tile_max(1) > kLayerMaxGroupNodes) return false;  // even single cross-lines do not fit in LDS
+      if (tile_max(1) > kLayerMaxGroupNodes) return layer_reject("a tile of width 1 does not fit in LDS");
       width = 1;
     }
   }
@@ -320,7 +327,7 @@ bool build_layer_plan(pies_solver* s) {
           L.maxGroupNodes = std::max(L.maxGroupNodes, tile.count0 + tile.count1);
         }
     }
-  if (L.maxGroupNodes > kLayerMaxGroupNodes) return false;
+  if (L.maxGroupNodes > kLayerMaxGroupNodes) return layer_reject("tile larger than the LDS budget");
 
   // ---- per container: tile of every op, colouring inside the tile, execution order ----
   int rounds = 12;
@@ -362,7 +369,7 @@ bool build_layer_plan(pies_solver* s) {
         l = std::min(l, level1[v]); lmax = std::max(lmax, level1[v]);
         m = std::min(m, level2[v]); mmax = std::max(mmax, level2[v]);
       }
-      if (lmax - l > 1 || mmax - m > 1) return false;  // cannot happen for breadth-first levellings
+      if (lmax - l > 1 || mmax - m > 1) return layer_reject("a constraint spans more than two levels");  // cannot happen for breadth-first levellings
       const uint32_t t = m / width;
       if (k == PIES_POSITION) { members[0][static_cast<size_t>(l / 2) * Sp[0]].push_back(c); continue; }  // one strip: with the even tiles
       const int p1 = l & 1u, p2 = t & 1u;
@@ -383,7 +390,7 @@ bool build_layer_plan(pies_solver* s) {
         for (uint32_t i = 0; i < T[g].count0; ++i) localOf[L.nodeList[T[g].first0 + i]] = i;
         for (uint32_t i = 0; i < T[g].count1; ++i) localOf[L.nodeList[T[g].first1 + i]] = T[g].count0 + i;
         uint32_t nc = colour_group(O, sel, localOf.data(), m, rounds, keys[g]);
-        if (nc == 0) return false;
+        if (nc == 0) return layer_reject("more than 128 colours inside a tile");
         if (!(noHint && std::atoi(noHint)))
           for (int a = 0; a < 3; ++a) {
             std::vector<uint32_t> proposed;
@@ -415,7 +422,7 @@ bool build_layer_plan(pies_solver* s) {
         }
       }
     }
-    if (P.order.size() != O.count) return false;
+    if (P.order.size() != O.count) return layer_reject("internal: incomplete order");
   }
   for (int k : kinds) s->plan[k] = std::move(plans[k]);
   L.active = true;

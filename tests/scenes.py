@@ -44,3 +44,34 @@ def perturb(solver, seed, amplitude):
 def projections_per_substep(solver, mod, iterations):
     n = sum(solver.count(t) for t in (mod.POSITION, mod.DISTANCE, mod.TET, mod.BEND))
     return n * iterations
+
+
+def delaunay_beam(dims, seed=5, jitter=0.3, min_volume=0.02, max_edge=2.6):
+    """An unstructured tetrahedral beam (the BASELINE configs call for a tetgen beam; tetgen is not available, scipy's
+    Delaunay triangulation of a jittered lattice stands in): returns (positions n x 3 float32, tets m x 4 uint32,
+    edges k x 2 uint32).  Slivers below `min_volume` and the long flat tetrahedra Delaunay puts on the convex hull
+    (an edge longer than `max_edge`; tetgen's quality bound would not produce them) are dropped; edges are the unique
+    tetrahedron edges."""
+    from scipy.spatial import Delaunay
+    W, H, D = dims
+    rng = np.random.default_rng(seed)
+    p = np.stack(np.meshgrid(np.arange(W), np.arange(H), np.arange(D), indexing="ij"), -1).reshape(-1, 3).astype(np.float64)
+    p += rng.uniform(-jitter, jitter, p.shape)
+    tets = Delaunay(p).simplices.astype(np.uint32)
+    a, b, c = p[tets[:, 1]] - p[tets[:, 0]], p[tets[:, 2]] - p[tets[:, 0]], p[tets[:, 3]] - p[tets[:, 0]]
+    tets = tets[np.abs(np.einsum("ij,ij->i", np.cross(a, b), c)) / 6.0 > min_volume]
+    longest = np.zeros(len(tets))
+    for i, j in ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)):
+        longest = np.maximum(longest, np.linalg.norm(p[tets[:, i]] - p[tets[:, j]], axis=1))
+    tets = tets[longest <= max_edge]
+    e = np.concatenate([tets[:, [0, 1]], tets[:, [0, 2]], tets[:, [0, 3]], tets[:, [1, 2]], tets[:, [1, 3]], tets[:, [2, 3]]])
+    e.sort(axis=1)
+    e = np.unique(e, axis=0).astype(np.uint32)
+    return (p + [0.0, 5.0, 0.0]).astype(np.float32), tets, e
+
+
+def build_unstructured(solver, mesh, w_tet=0.05, w_dist=0.5, radius=0.3):
+    pos, tets, edges = mesh
+    solver.add_nodes_raw(pos, radius=radius)
+    solver.add_distance(edges, w_dist)
+    solver.add_tet(tets, w_tet)

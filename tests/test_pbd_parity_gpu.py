@@ -288,6 +288,29 @@ def test_layered_substeps_and_state_edits(pies, oracle):
     _check(g, o)
 
 
+@pytest.mark.parametrize("schedule", [0, 1, 2])
+def test_unstructured_delaunay_beam(pies, oracle, schedule):
+    """A tetgen-like unstructured beam (Delaunay triangulation of a jittered lattice: ~25 tetrahedra per node, irregular
+    valence, no lattice colouring proposals): every schedule reproduces the oracle bit for bit."""
+    mesh = scenes.delaunay_beam((7, 6, 40))
+    g = pies.Solver(scenes.pbd_options(pies, 5))
+    o = oracle.OracleSolver(scenes.pbd_options(oracle, 5))
+    for s in (g, o):
+        scenes.build_unstructured(s, mesh)
+        scenes.perturb(s, 12, 0.03)
+        s.set_flag(1, 0)
+    g.set_schedule(schedule)
+    g.finalize()
+    if schedule != 0:
+        for t in (pies.DISTANCE, pies.TET):
+            o.permute(t, g.order(t))
+    g.tick(3)
+    o.tick(3)
+    if schedule == 2:
+        assert g.launch_counts()["layer"] == 2 * 5 + 1
+    _check(g, o)
+
+
 def test_empty_and_unconstrained(pies, oracle):
     g = pies.Solver(scenes.pbd_options(pies, 2))
     g.set_flag(1, 0)
