@@ -96,6 +96,7 @@ uint32_t from_hint(const Ops& ops, const std::vector<uint32_t>& sel, const std::
 }
 
 // First fit, then rounds of iterated greedy (Culberson): re-colouring class by class never needs more colours.
+// (DSATUR per tile was tried: never fewer colours than this on the lattice or the Delaunay beam, four times the time.)
 uint32_t colour_group(const Ops& ops, const std::vector<uint32_t>& sel, const uint32_t* localOf, uint32_t m, int rounds,
                       std::vector<uint32_t>& key) {
   std::vector<uint64_t> usedW, usedR;
@@ -423,6 +424,12 @@ bool build_layer_plan(pies_solver* s) {
       }
     }
     if (P.order.size() != O.count) return layer_reject("internal: incomplete order");
+  }
+  if (const char* e = std::getenv("PIES_LAYER_DEBUG"); e && e[0] == '1') {
+    std::fprintf(stderr, "[pies] schedule LAYERED: %u levels, %u strip(s) of width %u, largest tile %u nodes\n", L.levels, L.strips, L.width, L.maxGroupNodes);
+    for (int k : kinds)
+      std::fprintf(stderr, "[pies]   container %d: colours per phase %u %u %u %u, largest class %u\n", k, L.kind[k].ncol[0], L.kind[k].ncol[1],
+                   L.kind[k].ncol[2], L.kind[k].ncol[3], L.kind[k].maxClass);
   }
   for (int k : kinds) s->plan[k] = std::move(plans[k]);
   L.active = true;
