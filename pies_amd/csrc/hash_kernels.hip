@@ -269,9 +269,18 @@ PIES_DEV uint32_t collide_group_global(const HashArrays& H, float* pos, float* v
 // touch lies in the 2x2x2 cells above it: the distinct nodes of those buckets (typically ~100) are fetched ONCE
 // into a wave-private LDS table (open addressing on the node index), the visiting order of collide_group_global is
 // replayed on the LDS copies, and the touched nodes are written back at the end.  Same arithmetic, same order.
-constexpr int kColBlock = 128;            // two wavefronts, each with its own table
-constexpr uint32_t kColSlots = 512;       // table capacity per wavefront
-constexpr uint32_t kColMaxUnique = 256;   // live entries allowed (load factor 1/2)
+#ifndef PIES_COL_BLOCK
+#define PIES_COL_BLOCK 128
+#endif
+constexpr int kColBlock = PIES_COL_BLOCK;            // wavefronts of a block, each with its own table
+#ifndef PIES_COL_SLOTS
+#define PIES_COL_SLOTS 512
+#endif
+constexpr uint32_t kColSlots = PIES_COL_SLOTS;       // table capacity per wavefront (power of two)
+#ifndef PIES_COL_MAX_UNIQUE
+#define PIES_COL_MAX_UNIQUE 384
+#endif
+constexpr uint32_t kColMaxUnique = PIES_COL_MAX_UNIQUE;   // live entries allowed: an interior group of BASELINE config 4 (spacing 0.9, cells of 2.0) sees 216-343 distinct nodes
 constexpr uint32_t kColMaxEntries = 1024; // bucket entries of the 8 cells
 constexpr uint32_t kColEmpty = 0xffffffffu, kColDirty = 0x80000000u;
 constexpr uint32_t kColMaxSpins = 1u << 18;  // polls of one completion stamp before the wait is declared dead (~0.3 s)
@@ -280,7 +289,9 @@ struct ColTable {
   float px[kColSlots], py[kColSlots], pz[kColSlots], im[kColSlots], vx[kColSlots], vy[kColSlots], vz[kColSlots], r[kColSlots];
   uint16_t ent[kColMaxEntries];  // table slot of every bucket entry, cell after cell
 };
-PIES_DEV uint32_t col_hash(uint32_t j) { return (j * 2654435761u) >> 23; }
+constexpr int kColSlotBits = kColSlots == 256 ? 8 : kColSlots == 512 ? 9 : kColSlots == 1024 ? 10 : 11;
+static_assert((1u << kColSlotBits) == kColSlots, "kColSlots must be 256, 512, 1024 or 2048");
+PIES_DEV uint32_t col_hash(uint32_t j) { return (j * 2654435761u) >> (32 - kColSlotBits); }
 PIES_DEV uint32_t col_find(const uint32_t* key, uint32_t j) {  // j is present
   uint32_t h = col_hash(j);
   while ((key[h] & ~kColDirty) != j) h = (h + 1) & (kColSlots - 1);
