@@ -217,6 +217,7 @@ def test_layered_with_bend_position_constraints_and_two_bodies(pies, oracle):
         scenes.build_beam(s, (4, 5, 17), translation=(0.0, 0.3, 0.0))  # touches the floor
         s.create_bend_sheet(7, 9, translation=(9.0, 3.0, 0.0))
         s.create_sheet(9, 7, translation=(20, 3, 0), scale=0.5, mass=2.0, w=0.7)  # hinged: position constraints
+        s.addNodes(np.float32([[40, 0.4, 0], [41, 6, 1], [42, 0.2, 2]]))  # loose nodes ride along in some tile
         scenes.perturb(s, 4, 0.05)
     for hinge in (0, 1):
         g, o = _layered_pair(pies, oracle, build, 5, ticks=4, hinge=hinge)
@@ -260,6 +261,7 @@ def test_layered_strips_small_tiles_all_containers(pies, oracle, monkeypatch, co
         s.create_bend_sheet(7, 9, translation=(12.0, 3.0, 0.0))
         s.create_sheet(9, 7, translation=(24, 3, 0), scale=0.5, mass=2.0, w=0.7)
         s.add_position(np.array([3, 3, 40], dtype=np.uint32), 0.3)
+        s.addNodes(np.float32([[40, 0.4, 0], [41, 6, 1], [42, 0.2, 2], [43, 3, 3], [44, 0.1, 4]]))  # loose: per-node steps only
         scenes.perturb(s, 4, 0.05)
     g, o = _layered_pair(pies, oracle, build, 4, ticks=3, collisions=collisions)
     lc = g.launch_counts()
