@@ -80,7 +80,8 @@ enum {
  *             swept colour by colour by one workgroup with the nodes resident in LDS (two launches per
  *             iteration; wide bodies are cut into strips by a second levelling: four phases per container).
  *             Identical to a sequential sweep in the order pies_get_order returns.  Falls back to COLOURED
- *             for scenes without distance / tetrahedral / bend constraints. */
+ *             for scenes without distance / tetrahedral / bend constraints and for squat bodies of fewer than
+ *             300k nodes whose cross-sections do not fit one workgroup (measured slower there). */
 enum { PIES_SCHEDULE_EXACT = 0, PIES_SCHEDULE_COLOURED = 1, PIES_SCHEDULE_LAYERED = 2 };
 
 enum {

@@ -251,14 +251,20 @@ bool build_layer_plan(pies_solver* s) {
     for (uint32_t v = 0; v < N; ++v) ++cnt[level1[v]];
     for (uint32_t l = 0; l < L1; ++l) maxPair = std::max(maxPair, cnt[l] + cnt[l + 1]);
   }
-  uint32_t oneStripMax = 2560, tileTarget = 1280;
+  // Measured on the box (substeps/s, one strip / strips / coloured): 20x20x250 680 / - / 333; 50x50x40 290 / 229 / 347;
+  // 60x60x100 183 / 235 / 227; 100^3 - / 156 / 116.  One strip pays while a pair of levels is a few waves per colour
+  // (long bodies); strips pay once the body is large enough to fill the chip four phases at a time; squat bodies in
+  // between are left to the coloured schedule.
+  uint32_t oneStripMax = 2560, tileTarget = 1280, stripsMinNodes = 300000;
   if (const char* e = std::getenv("PIES_LAYER_ONE_STRIP_MAX")) oneStripMax = static_cast<uint32_t>(std::atoi(e));
   if (const char* e = std::getenv("PIES_LAYER_TILE_NODES")) tileTarget = static_cast<uint32_t>(std::atoi(e));
+  if (const char* e = std::getenv("PIES_LAYER_STRIPS_MIN_NODES")) stripsMinNodes = static_cast<uint32_t>(std::atoi(e));
   tileTarget = std::min(tileTarget, kLayerMaxGroupNodes);
   uint32_t L2 = 1, width = 1;
   if (maxPair <= std::min(oneStripMax, kLayerMaxGroupNodes)) {
     level2.assign(N, 0);
   } else {
+    if (N < stripsMinNodes) return layer_reject("a pair of levels is too wide for one workgroup and the body too small for strips");
     L2 = bfs(axes[1], level2);
     if (L2 == 0) return layer_reject("no second levelling");
     // nodes per (level1, level2) cell, prefix sums along level2

@@ -238,10 +238,18 @@ def test_layered_with_node_collisions(pies, oracle):
 
 
 def test_layered_wide_body_is_cut_into_strips(pies, oracle):
-    """Cross-sections of 4096 nodes: a pair of levels is cut into strips by a second levelling (four phases per
-    container instead of two; predict / floor / velocity run as launches of their own over the level-ordered copy)."""
+    """Cross-sections of 4900 nodes, 343k particles: a pair of levels is cut into strips by a second levelling (four
+    phases per container instead of two; predict / floor / velocity run as launches of their own over the level-ordered
+    copy).  A squat body below 300k particles is left to the coloured schedule."""
+    def small(s):
+        scenes.build_beam(s, (40, 40, 40))  # 3200 nodes in a pair of levels, 64k particles
+        scenes.perturb(s, 6, 0.05)
+    g, o = _layered_pair(pies, oracle, small, 2, ticks=1)
+    assert g.launch_counts()["layer"] == 0 and g.launch_counts()["tet"] > 0
+    _check(g, o)
+
     def build(s):
-        scenes.build_beam(s, (64, 64, 64))
+        scenes.build_beam(s, (70, 70, 70))
         scenes.perturb(s, 6, 0.05)
     g, o = _layered_pair(pies, oracle, build, 2, ticks=1)
     lc = g.launch_counts()
@@ -255,6 +263,7 @@ def test_layered_strips_small_tiles_all_containers(pies, oracle, monkeypatch, co
     position constraints (two of them on one node), with and without the collision pass between the sweeps."""
     monkeypatch.setenv("PIES_LAYER_ONE_STRIP_MAX", "40")
     monkeypatch.setenv("PIES_LAYER_TILE_NODES", "90")
+    monkeypatch.setenv("PIES_LAYER_STRIPS_MIN_NODES", "0")
     def build(s):
         scenes.build_beam(s, (7, 6, 13), translation=(0.0, 0.3, 0.0))
         scenes.build_beam(s, (5, 9, 4), translation=(1.3, 7.2, 0.4))
