@@ -1,10 +1,10 @@
-// Schedule LAYERED on gfx950: one workgroup sweeps one group of constraints (layer_plan.cpp) with the group's
-// node records resident in LDS.
+// Schedule LAYERED on gfx950: one workgroup sweeps one tile of constraints (layer_plan.cpp) with the tile's node
+// records resident in LDS.
 //
-// A launch covers the groups of one parity (they share no node).  The workgroup copies its two levels of node
-// records (16 B each) from HBM into LDS once, runs the launch's segments - phases of the distance / tetrahedral /
-// bend / position containers colour after colour, and the per-node steps of the substep (predict, floor clamp,
-// velocity) - and writes the records back once.  Between two colours stands a workgroup barrier (~0.1 us) where
+// A launch covers the tiles of one phase (they share no node).  The workgroup copies its node records (16 B each;
+// two runs of the level-ordered copy, one per level) from HBM into LDS once, runs the launch's segments - phases of
+// the distance / tetrahedral / bend / position containers colour after colour and, when a level is one tile, the
+// per-node steps of the substep (predict, floor clamp, velocity) - and writes the records back once.  Between two colours stands a workgroup barrier (~0.1 us) where
 // the batch-per-launch schedules pay a kernel boundary plus two dependent HBM round trips (~3.8 us); constraint
 // records (local ids 4-8 B, rest data) stream from HBM and the next colour's are requested before the current
 // colour is computed, so their latency hides behind the arithmetic.
@@ -25,8 +25,8 @@ constexpr uint32_t kOffStride = kLayerMaxCols + 2;  // colour offsets of one seg
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also drains the global loads in flight
 // (s_waitcnt vmcnt(0)), i.e. the constraint records requested ahead for the next colours.
 PIES_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-constexpr int kDistPreload = 12;
-constexpr int kBatch = 4;  // node records a lane requests before it consumes the first (the load phase is written out for 4)  // colours of a distance segment whose records a lane requests up front
+constexpr int kDistPreload = 12;  // colours of a distance segment whose records a lane requests up front
+constexpr int kBatch = 4;         // node records a lane requests before it consumes the first (the load phase is written out for 4)
 
 PIES_DEV uint32_t lo16(uint32_t v) { return v & 0xFFFFu; }
 PIES_DEV uint32_t hi16(uint32_t v) { return v >> 16; }
@@ -47,8 +47,8 @@ __global__ void __launch_bounds__(BLOCK) k_layer(NodeArrays nd, LayerData D, Lay
 
   bool needRadius = false;
   for (uint32_t s = 0; s < L.nseg; ++s) needRadius |= L.seg[s].kind == LAYER_FLOOR || L.seg[s].kind == LAYER_VELOCITY;
-  // Node records in: from the layer-ordered copy (the group's range is contiguous: coalesced) or, in the first launch
-  // of a substep / after a collision pass, gathered from the node array.  Four requests per lane are in flight before
+  // Node records in: from the level-ordered copy (the tile's two runs are contiguous: coalesced) or, with one strip, in
+  // the first launch of a substep / after a collision pass, gathered from the node array.  Four requests per lane are in flight before
   // the first is consumed (clamped indices keep the loads unconditional, so nothing waits at a branch join).
   if (L.loadGlobal) {
     for (uint32_t base = 0; base < m; base += kBatch * BLOCK) {

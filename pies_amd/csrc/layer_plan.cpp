@@ -7,7 +7,9 @@
 // concurrently, then all odd groups.  Inside a group the constraints are coloured (same conflict rule as
 // schedule.cpp) and run colour after colour by one workgroup that keeps the group's two levels of node records
 // in LDS, so the sweep costs two launches per container instead of one per colour, and a step between two
-// colours is a workgroup barrier instead of a kernel boundary.
+// colours is a workgroup barrier instead of a kernel boundary.  Large bodies whose levels are too wide for one
+// workgroup get a second levelling across the first: a level is cut into strips, a group into tiles, and the
+// tiles of equal (level parity, strip parity) form one of four phases.
 //
 // The result is that of a sequential sweep over the container in the order [phase 0: group after group, colour
 // after colour][phase 1: ...] - the order pies_get_order reports and the oracle replays, bit for bit.  The
