@@ -377,7 +377,7 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
     }
     if (ON(PIES_KERNEL_PD_RHS)) { launch_pd_rhs(st, s->nd, pd); U(s->nd.n); }    // Solver.cpp:266, 310-349
     C(PIES_KERNEL_PD_RHS);
-    if (only < 0) launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, s->pcgTol);  // Solver.cpp:356-364
+    if (only < 0) launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, s->pcgTol, -1, it == 0, it + 1 == s->opt.iterations);  // Solver.cpp:356-364
     else if (only == PIES_KERNEL_PD_SPMV) { launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, 0.f, 1); U((uint64_t)s->nd.n * s->pcgBudget); }
     else if (only == PIES_KERNEL_PD_CG_UPDATE) { launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, 0.f, 0); U((uint64_t)s->nd.n * s->pcgBudget); }
     C(PIES_KERNEL_PD_SPMV, s->pcgBudget);
@@ -442,8 +442,16 @@ static int adapt_pcg_budget(pies_solver* s) {
   uint32_t budget = s->pcgBudget;
   if (!converged && budget < s->pcgMaxIters) {
     budget = std::min(s->pcgMaxIters, budget * 2);
+    s->pcgCalm = 0;
   } else if (converged && used + 2 < budget) {
-    budget = used + 2;  // keep two iterations of head-room
+    budget = used + 2;  // two iterations of head-room at once ...
+    s->pcgCalm = 0;
+  } else if (converged && used + 1 < budget) {
+    // ... and one once the solves have stayed that short for a while (every spare iteration is two launches per
+    // local/global iteration that exit at once); a solve that then runs out doubles the budget again
+    if (++s->pcgCalm >= 8) { budget = used + 1; s->pcgCalm = 0; }
+  } else {
+    s->pcgCalm = 0;
   }
   if (budget != s->pcgBudget) {
     s->pcgBudget = budget;

@@ -77,7 +77,10 @@ void launch_pd_local_bend(hipStream_t st, const float4* pos, const uint4* ids, c
 void launch_pd_local_shape(hipStream_t st, const float4* pos, const PdArrays& pd);
 void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd);
 // part: -1 = the solve; profile passes: 1 = the SpMV (+ direction update) kernels only, 0 = the vector-update kernels only
-void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, int maxIters, float tol, int part = -1);
+// first / last: the first and the last solve of a substep (a solve's statistics are closed by the next solve's first
+// kernel, the last one's by a launch of its own)
+void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, int maxIters, float tol, int part = -1, bool first = true,
+                     bool last = true);
 void launch_pd_stabilize(hipStream_t st, const NodeArrays& nd, const PdArrays& pd);
 // staticFriction = false leaves the floor friction (Solver.cpp:473-484) to launch_pd_static_friction, which the
 // reference runs after the point-triangle friction

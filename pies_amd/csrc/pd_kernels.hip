@@ -526,8 +526,32 @@ PIES_DEV SliceSweep slice_sweep(uint32_t n) {
   return {segBeg + xb * (kBlock / 64u) + (threadIdx.x >> 6), segEnd, nbx * (kBlock / 64u)};
 }
 
+// Statistics at the end of a solve (max relative residual over the tick's solves, iterations of the solve): run by one
+// block, either of k_cg_finish or - for every solve but the last of a substep - of the next solve's k_cg_init, which
+// saves a launch per local/global iteration.  prevPartB holds the finished solve's final residual partials.
+PIES_DEV void solve_statistics(const CgArrays& A, const float* __restrict__ prevPartB) {
+  float red[6];
+  block_reduce_partials<6>(prevPartB, 6, A.nparts, red);
+  if (threadIdx.x == 0) {
+    float worst = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float bb = A.scal[6 + c];
+      const float rel = bb > 0.f ? red[3 + c] / bb : 0.f;
+      worst = fmaxf(worst, rel);
+    }
+    A.stats[0] = fmaxf(A.stats[0], worst);  // max over solves of ||r||^2 / ||b||^2
+    A.stats[1] = fmaxf(A.stats[1], A.scal[9]);
+    A.stats[2] += 1.0f;
+  }
+}
+
 // r = f - (K + C) x ; z = D^-1 r ; partB = {rz, rr} ; partI = {bb}.   One row per lane (SELL-64).
-__global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __restrict__ x, const float4* __restrict__ f) {
+// prevPartB != nullptr: block 0 first closes the previous solve's statistics (its scal[] entries are still intact:
+// this solve's k_cg_ap(0) is the first kernel to overwrite them).
+__global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __restrict__ x, const float4* __restrict__ f,
+                                                    const float* __restrict__ prevPartB) {
+  if (prevPartB && blockIdx.x == 0) solve_statistics(A, prevPartB);
   const uint32_t lane = threadIdx.x & 63u;
   const SliceSweep sw = slice_sweep(A.n);
   float acc9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -703,23 +727,8 @@ __global__ void __launch_bounds__(kBlock) k_cg_update(CgArrays A, float4* __rest
   block_write_partial<6>(acc, A.partBnext, 6);
 }
 
-// end of a solve: statistics (max relative residual over the tick's solves, iterations of the last solve)
-__global__ void __launch_bounds__(kBlock) k_cg_finish(CgArrays A, int iters) {
-  float red[6];
-  block_reduce_partials<6>(A.partB, 6, A.nparts, red);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    float worst = 0.f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float bb = A.scal[6 + c];
-      const float rel = bb > 0.f ? red[3 + c] / bb : 0.f;
-      worst = fmaxf(worst, rel);
-    }
-    A.stats[0] = fmaxf(A.stats[0], worst);  // max over solves of ||r||^2 / ||b||^2
-    A.stats[1] = fmaxf(A.stats[1], A.scal[9]);
-    A.stats[2] += 1.0f;
-  }
-}
+// end of the last solve of a substep: its statistics
+__global__ void __launch_bounds__(kBlock) k_cg_finish(CgArrays A) { solve_statistics(A, A.partB); }
 
 // ------------------------------------------------------------------------------------------------------
 // Solver.cpp:367-383 (floor snap; tri/edge stabilisation is a later row) -- idempotent, applied once
@@ -819,7 +828,7 @@ void launch_pd_local_shape(hipStream_t st, const float4* pos, const PdArrays& pd
   if (pd.shape.count == 0) return;
   hipLaunchKernelGGL(k_pd_local_shape, dim3(pd.shape.count), dim3(kBlock), 0, st, pos, pd.shape, pd.contribD);
 }
-void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, int maxIters, float tol, int part) {
+void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, int maxIters, float tol, int part, bool first, bool last) {
   if (nd.n == 0) return;
   CgArrays A = pd.cg;
   const dim3 grid(A.nparts), block(kBlock);
@@ -831,16 +840,18 @@ void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, i
     return;
   }
   const float tol2 = tol * tol;
-  hipLaunchKernelGGL(k_cg_init, grid, block, 0, st, A, nd.pos, pd.rhs);
   float* pb[2] = {pd.cg.partB, pd.cg.partBnext};
+  // every solve of a substep runs the same number of iterations, so the previous solve left its final partials here
+  hipLaunchKernelGGL(k_cg_init, grid, block, 0, st, A, nd.pos, pd.rhs, first ? nullptr : pb[maxIters & 1]);
   for (int k = 0; k < maxIters; ++k) {
     A.partB = pb[k & 1];       // residual partials of iteration k (k = 0 reads partI instead)
     A.partBnext = pb[(k + 1) & 1];
     hipLaunchKernelGGL(k_cg_ap, grid, block, 0, st, A, k, tol2);
     hipLaunchKernelGGL(k_cg_update, grid, block, 0, st, A, nd.pos, k, tol2);
   }
+  if (!last) return;
   A.partB = pb[maxIters & 1];
-  hipLaunchKernelGGL(k_cg_finish, dim3(1), block, 0, st, A, maxIters);
+  hipLaunchKernelGGL(k_cg_finish, dim3(1), block, 0, st, A);
 }
 void launch_pd_stabilize(hipStream_t st, const NodeArrays& nd, const PdArrays& pd) {
   if (nd.n == 0) return;

@@ -190,6 +190,7 @@ struct pies_solver {
   float pcgTol = 3.0e-7f;     // relative residual ||r|| / ||b|| per coordinate column
   uint32_t pcgMaxIters = 32;  // upper bound of CG iterations per global step
   uint32_t pcgBudget = 32;    // iterations currently captured in the graph (adapted to what the solves use)
+  uint32_t pcgCalm = 0;       // consecutive synchronisations at which one iteration of head-room would have been enough
   std::vector<void*> allocations;
   float4* h_stage = nullptr;  // pinned staging for the per-tick position read-back
   size_t h_stage_n = 0;
