@@ -138,8 +138,8 @@ def pd_beam(dims, device):
     g.create_tet_box(W, H, D, translation=(0.0, 2.0, 0.0), w=1.0, volume=True, triangles=True)
     g.add_position(np.array([D * (j + H * i) for i in range(W) for j in range(H)], dtype=np.uint32), 2.0)
     g.finalize()
-    for _ in range(12):  # a host ticks and synchronises once per frame: the captured CG iteration budget settles to what
-        g.tick_async(1)  # the solves use (two spare iterations at once, one after eight calm frames)
+    for _ in range(34):  # a host ticks and synchronises once per frame: the captured CG iteration budget settles to what
+        g.tick_async(1)  # the solves use (two spare iterations after 8 calm frames, one after 24 more)
         g.synchronize()
     return g
 

@@ -429,8 +429,8 @@ static int capture_graph(pies_solver* s) {
 
 // The graph holds a fixed number of CG iterations per solve (converged solves early-exit the rest).  At
 // every host synchronisation the budget follows what the solves needed: it starts at pcgMaxIters, shrinks
-// to (iterations used + 2), and doubles (up to pcgMaxIters) when a solve ran out of iterations above the
-// tolerance.
+// to (most iterations used over the last 8+ synchronisations) + 2, to + 1 after 24, and returns to pcgMaxIters at
+// once when a solve ran out of iterations above the tolerance.
 static int adapt_pcg_budget(pies_solver* s) {
   if (s->opt.solver != PIES_SOLVER_PD || !s->pd.cg.stats || !s->graphExec || s->sceneDirty || under_profiler()) return PIES_OK;
   float st[4] = {0, 0, 0, 0};
@@ -441,18 +441,30 @@ static int adapt_pcg_budget(pies_solver* s) {
   const bool converged = st[0] <= s->pcgTol * s->pcgTol;
   uint32_t budget = s->pcgBudget;
   if (!converged && budget < s->pcgMaxIters) {
-    budget = std::min(s->pcgMaxIters, budget * 2);
+    // a solve ran out of iterations above the tolerance (new contacts stiffen the system at once): back to the full
+    // budget now - the reference's solve is a direct one - and no shrinking for the next 60 synchronisations
+    budget = s->pcgMaxIters;
     s->pcgCalm = 0;
-  } else if (converged && used + 2 < budget) {
-    budget = used + 2;  // two iterations of head-room at once ...
-    s->pcgCalm = 0;
-  } else if (converged && used + 1 < budget) {
-    // ... and one once the solves have stayed that short for a while (every spare iteration is two launches per
-    // local/global iteration that exit at once); a solve that then runs out doubles the budget again
-    if (++s->pcgCalm >= 8) { budget = used + 1; s->pcgCalm = 0; }
-  } else {
-    s->pcgCalm = 0;
+    s->pcgWindowMax = 0;
+    s->pcgCooldown = 60;
+  } else if (s->pcgCooldown > 0) {
+    --s->pcgCooldown;
+  } else if (converged) {
+    // the most iterations any solve used over the window of synchronisations since the last change
+    s->pcgWindowMax = std::max(s->pcgWindowMax, used);
+    ++s->pcgCalm;
+    bool restart = false;
+    if (s->pcgCalm >= 8 && s->pcgWindowMax + 2 < budget) { budget = s->pcgWindowMax + 2; restart = true; }  // two spare iterations ...
+    else if (s->pcgCalm >= 24) {                                                                          // ... one after a long calm
+      if (s->pcgWindowMax + 1 < budget) budget = s->pcgWindowMax + 1;
+      restart = true;  // the window never looks back further than 24 synchronisations
+    }
+    if (restart) { s->pcgCalm = 0; s->pcgWindowMax = 0; }
+    // (every spare iteration is two launches per local/global iteration that exit at once)
   }
+  if (const char* e = std::getenv("PIES_PCG_DEBUG"); e && e[0] == '1')
+    std::fprintf(stderr, "[pies] pcg: residual^2 %.3g (%s) iterations %u budget %u -> %u calm %u cooldown %u\n", st[0], converged ? "ok" : "short", used,
+                 s->pcgBudget, budget, s->pcgCalm, s->pcgCooldown);
   if (budget != s->pcgBudget) {
     s->pcgBudget = budget;
     return capture_graph(s);

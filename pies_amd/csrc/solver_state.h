@@ -190,7 +190,9 @@ struct pies_solver {
   float pcgTol = 3.0e-7f;     // relative residual ||r|| / ||b|| per coordinate column
   uint32_t pcgMaxIters = 32;  // upper bound of CG iterations per global step
   uint32_t pcgBudget = 32;    // iterations currently captured in the graph (adapted to what the solves use)
-  uint32_t pcgCalm = 0;       // consecutive synchronisations at which one iteration of head-room would have been enough
+  uint32_t pcgCalm = 0;       // synchronisations in the current observation window (all solves converged)
+  uint32_t pcgWindowMax = 0;  // most CG iterations any solve used in that window
+  uint32_t pcgCooldown = 0;   // synchronisations left before the budget may shrink again after a solve ran out
   std::vector<void*> allocations;
   float4* h_stage = nullptr;  // pinned staging for the per-tick position read-back
   size_t h_stage_n = 0;

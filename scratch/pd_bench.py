@@ -11,6 +11,6 @@ g = capi.Solver(capi.Options(solver=capi.PD, iterations=10)); g.set_pcg(3e-7, cg
 g.create_tet_box(W,H,D, translation=(0,2.0,0), w=w, volume=True, triangles=True)
 g.add_position(np.array([D*(j+H*i) for i in range(W) for j in range(H)], dtype=np.uint32), 2.0 * w)
 g.set_flag(capi.FLAG_TRIANGLE_COLLISIONS, int(os.environ.get('TRI','1'))); g.finalize()
-for _ in range(12): g.tick_async(1); g.synchronize()
+for _ in range(34): g.tick_async(1); g.synchronize()
 t0=time.perf_counter(); g.tick_async(steps); g.synchronize(); dt=(time.perf_counter()-t0)/steps
 print("PD %s: %.3f ms/substep %.1f substeps/s pcg %s" % (dims, dt*1e3, 1/dt, g.pcg_stats()))
