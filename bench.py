@@ -212,9 +212,30 @@ def extra_configs(device):
     el = timed_ticks(g, 20, 3, lambda: None)
     res, iters, solves = g.pcg_stats()
     out["pd_config5_per_gpu"] = {"value": 20 / el, "unit": "substeps/s", "workload": "25x25x400 beam (250000 particles), PD, tets + volume, 10 "
-                                 "iterations, point-triangle CCD + floor contacts on; configs[4] runs one such body per GPU",
+                                 "iterations, point-triangle CCD + floor contact pipeline on (no contact binds in this window: see pd_contacts); "
+                                 "configs[4] runs one such body per GPU",
                                  "pcg_max_rel_residual": res, "pcg_max_iterations_used": iters,
                                  "tri_contacts_last_substep": len(g.tri_collisions)}
+    g.close()
+    # PD with contacts that actually bind: a short beam resting on a long one that lies on the floor
+    log("PD contact scene")
+    g = capi.Solver(capi.Options(solver=capi.PD, iterations=10), device=device)
+    g.create_tet_box(25, 25, 160, translation=(0.0, 0.04, 0.0), w=1.0, volume=True, triangles=True)
+    g.create_tet_box(25, 25, 40, translation=(0.3, 0.04 + 24 + 0.07, 10.3), w=1.0, volume=True, triangles=True)
+    g.finalize()
+    for _ in range(10):  # frame loop: the upper beam lands, the CG budget follows the contacts
+        g.tick_async(1)
+        g.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        g.tick_async(1)
+        g.synchronize()
+    el = time.perf_counter() - t0
+    res, iters, solves = g.pcg_stats()
+    out["pd_contacts"] = {"value": 10 / el, "unit": "substeps/s", "workload": "125000 particles: a 25x25x40 beam resting on a 25x25x160 beam on the "
+                          "floor, PD, 10 iterations, floor + point-triangle contacts binding (w = 1e4 on the diagonal)",
+                          "tri_contacts_last_substep": len(g.tri_collisions), "pcg_max_rel_residual": res, "pcg_max_iterations_used": iters,
+                          "failed": g.failed}
     g.close()
     # configs[3]: 500k loose particles, node-node collisions + floor, PBD, 4 iterations
     W, H, D = scenes.L500K

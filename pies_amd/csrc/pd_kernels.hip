@@ -487,26 +487,41 @@ PIES_DEV bool all_converged(const float rr[3], const float bb[3], float tol2) {
 
 // Off-diagonal part of the contact blocks w*AtA for row i (the diagonal 3w / w is in cdiag): the point couples
 // to the three triangle nodes with -w, each triangle node to the point with -w.  FETCH(j) returns the vector at j.
+// The terms are added in contact-list order; the loads of four contacts are requested together (index, ids, then
+// the vectors - three dependent trips per batch instead of per contact: a node of a contact patch sits in tens of
+// contacts, and one lane walking them one by one made the SpMV ten times slower than without contacts).
 template <class Fetch> PIES_DEV void contact_row(const CgArrays& A, uint32_t i, Fetch fetch, float& sx, float& sy, float& sz) {
   if (!A.tIncCnt) return;
   const uint32_t tc = A.tIncCnt[i];
   if (!tc) return;
   const uint32_t ts = A.tIncStart[i];
-  for (uint32_t k = 0; k < tc; ++k) {
-    const uint32_t v = A.tInc[ts + k];
-    const uint4 id = A.tIds[v >> 2];
-    if ((v & 3u) == 0u) {
-      const uint32_t nb[3] = {id.y, id.z, id.w};
+  constexpr int kAhead = 4;
+  for (uint32_t k0 = 0; k0 < tc; k0 += kAhead) {
+    uint32_t v[kAhead];
+    uint4 id[kAhead];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        float px, py, pz;
-        fetch(nb[q], px, py, pz);
-        sx = fmaf(-kTriContactW, px, sx); sy = fmaf(-kTriContactW, py, sy); sz = fmaf(-kTriContactW, pz, sz);
-      }
-    } else {
-      float px, py, pz;
-      fetch(id.x, px, py, pz);
-      sx = fmaf(-kTriContactW, px, sx); sy = fmaf(-kTriContactW, py, sy); sz = fmaf(-kTriContactW, pz, sz);
+    for (int u = 0; u < kAhead; ++u) v[u] = A.tInc[ts + min(k0 + u, tc - 1)];  // clamped: unconditional loads
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) id[u] = A.tIds[v[u] >> 2];
+    float q[kAhead][3][3];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      const bool point = (v[u] & 3u) == 0u;  // the point's row couples to the three triangle nodes, their rows to the point
+      fetch(point ? id[u].y : id[u].x, q[u][0][0], q[u][0][1], q[u][0][2]);
+      fetch(id[u].z, q[u][1][0], q[u][1][1], q[u][1][2]);
+      fetch(id[u].w, q[u][2][0], q[u][2][1], q[u][2][2]);
+    }
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      if (k0 + u >= tc) break;
+      const int terms = (v[u] & 3u) == 0u ? 3 : 1;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        if (t < terms) {
+          sx = fmaf(-kTriContactW, q[u][t][0], sx);
+          sy = fmaf(-kTriContactW, q[u][t][1], sy);
+          sz = fmaf(-kTriContactW, q[u][t][2], sz);
+        }
     }
   }
 }

@@ -21,6 +21,7 @@ struct TriArrays {
   uint64_t* keys;
   uint32_t *cnt, *start, *fill, *used;
   uint32_t* counters;  // [0] used cells [1] bucket entries [2] contacts [3] failure flag [4] nodes with contacts [5] incidences
+                       // [6] dependency levels of the contact list [7] 1: more than kTriMaxLevels levels
   uint32_t* triSlot;   // nt x kTriMaxEntries
   int4* rng;           // per triangle: min cell, packed lengths
   uint32_t *bucket, *bucketSorted;
@@ -31,7 +32,13 @@ struct TriArrays {
   float4* contrib;   // 4 per contact: w * (AtA p)_i
   // per node: the contacts it takes part in, ascending (contact << 2 | local index)
   uint32_t *incCnt, *incStart, *incFill, *usedNodes, *inc, *incSorted;
+  // dependency levels of the contact list (k_tri_levels): the sequential passes run level by level
+  int* lastLevel;      // per node: level of the last contact seen that touches it (-1 between substeps)
+  uint32_t* lvl;       // per contact
+  uint32_t* lvOrder;   // contacts bucketed by level
+  uint32_t* lvStart;   // kTriMaxLevels + 1 offsets into lvOrder
 };
+constexpr uint32_t kTriMaxLevels = 2048;  // longer chains (one node in thousands of contacts) take the single-wavefront path
 
 struct PdArrays;
 

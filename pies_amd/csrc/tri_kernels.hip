@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(kBlock) k_tri_reset(TriArrays T) {
 }
 __global__ void k_tri_zero(TriArrays T) {
   const uint32_t t = threadIdx.x;
-  if (t < 6 && t != 3) T.counters[t] = 0;  // [3] is the sticky failure flag
+  if (t < 8 && t != 3) T.counters[t] = 0;  // [3] is the sticky failure flag
 }
 
 // TriCompRange / sweptTriRange: floor(min), ceil(max) - floor(min) over position and prevPosition, world units
@@ -413,8 +413,8 @@ PIES_DEV F3 ld3(const float* base, uint32_t node) { return {ld(base + 4 * node),
 PIES_DEV void st3(float* base, uint32_t node, F3 v) { st(base + 4 * node, v.x); st(base + 4 * node + 1, v.y); st(base + 4 * node + 2, v.z); }
 
 // dependency level of every contact of a 64-contact window (contacts that share a node keep their list order)
-PIES_DEV int window_levels(bool valid, const uint4& id, int lane, int& maxLevel) {
-  int level = 0;
+PIES_DEV int window_levels(bool valid, const uint4& id, int lane, int& maxLevel, int base = 0) {
+  int level = base;
   for (int m = 0; m < 63; ++m) {
     const int lm = __builtin_amdgcn_readlane(level, m);
     const uint32_t mx = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(id.x), m));
@@ -434,54 +434,140 @@ PIES_DEV int window_levels(bool valid, const uint4& id, int lane, int& maxLevel)
   return level;
 }
 
-// MODE 0: PointTriangleCollisionConstraint::stabilizeCollisions (CollisionConstraint.cpp:126-162)
-// MODE 1: point-triangle friction (Solver.cpp:431-471)
+// One contact of a sequential pass.  MODE 0: PointTriangleCollisionConstraint::stabilizeCollisions
+// (CollisionConstraint.cpp:126-162); MODE 1: point-triangle friction (Solver.cpp:431-471)
 template <int MODE>
-__global__ void __launch_bounds__(64) k_tri_sequential(TriArrays T, float4* pos4, float4* prev4, float4* vel4, float thickness,
-                                                       float friction, float staticThreshold) {
+PIES_DEV void tri_contact_step(const uint4 id, float* pos, float* prev, float* vel, float thickness, float friction, float staticThreshold) {
+  const float imA = ld(pos + 4 * id.x + 3), imB = ld(pos + 4 * id.y + 3), imC = ld(pos + 4 * id.z + 3), imD = ld(pos + 4 * id.w + 3);
+  const F3 pa = ld3(pos, id.x), pb = ld3(pos, id.y), pc = ld3(pos, id.z), pd = ld3(pos, id.w);
+  const F3 n = normalize(cross(pc - pb, pd - pb));
+  const float wTri = imB + imC + imD, wSum = imA + wTri;
+  if (MODE == 0) {
+    const float nDotP = dot(n, pa - pb);
+    if (nDotP < thickness) {
+      const F3 disp = (thickness - nDotP) * n;
+      const F3 da = disp * imA / wSum, dt = disp * wTri / wSum;
+      st3(pos, id.x, pa + da); st3(pos, id.y, pb - dt); st3(pos, id.z, pc - dt); st3(pos, id.w, pd - dt);
+      st3(prev, id.x, ld3(prev, id.x) + da); st3(prev, id.y, ld3(prev, id.y) - dt);
+      st3(prev, id.z, ld3(prev, id.z) - dt); st3(prev, id.w, ld3(prev, id.w) - dt);
+    }
+  } else {
+    const F3 va = ld3(vel, id.x), vb = ld3(vel, id.y), vc = ld3(vel, id.z), vd = ld3(vel, id.w);
+    const F3 avg = (vb + vc + vd) / 3.0f;
+    const F3 rel = va - avg;
+    const float vDotN = dot(rel, n);
+    const F3 perp = rel - vDotN * n;
+    float fr = friction;
+    if (sqrtf(dot(perp, perp)) < staticThreshold) fr = 1.0f;
+    const F3 dv = (-fr) * perp - (1.1f * fminf(vDotN, 0.0f)) * n;
+    const F3 ndv = neg(dv);
+    st3(vel, id.x, va + dv * imA / wSum);
+    st3(vel, id.y, vb + ndv * wTri / wSum);
+    st3(vel, id.z, vc + ndv * wTri / wSum);
+    st3(vel, id.w, vd + ndv * wTri / wSum);
+  }
+}
+
+// Dependency levels of the whole contact list, once per substep: level(c) = 1 + the highest level among the earlier
+// contacts that share a node with c, so that running the list level by level, in any order inside a level, is the
+// reference's sequential pass.  The list is walked in order by one wavefront, 64 contacts at a time: levels inside the
+// window as before, starting from the per-node level of the last earlier contact (lastLevel, reset to -1 behind us).
+// The other 15 wavefronts of the block then bucket the contacts by level.  More than kTriMaxLevels levels (thousands
+// of contacts on one node) raise counters[7] and the passes fall back to the single-wavefront walk.
+constexpr int kSeqBlock = 1024;
+__global__ void __launch_bounds__(kSeqBlock) k_tri_levels(TriArrays T) {
+  __shared__ uint32_t hist[kTriMaxLevels + 1];
+  __shared__ int sMaxLevel;
+  const uint32_t M = T.counters[2];
+  const int tid = threadIdx.x;
+  for (int b = tid; b <= static_cast<int>(kTriMaxLevels); b += kSeqBlock) hist[b] = 0;
+  if (tid == 0) sMaxLevel = -1;
+  __syncthreads();
+  if (M == 0) {
+    if (tid == 0) { T.counters[6] = 0; T.counters[7] = 0; }
+    return;
+  }
+  if (tid < 64) {
+    int top = -1;
+    for (uint32_t base = 0; base < M; base += 64) {
+      const bool valid = base + tid < M;
+      const uint4 id = valid ? T.ids[base + tid] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+      int bl = 0;
+      if (valid) {
+        const int a = __hip_atomic_load(T.lastLevel + id.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int b = __hip_atomic_load(T.lastLevel + id.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int c = __hip_atomic_load(T.lastLevel + id.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int d = __hip_atomic_load(T.lastLevel + id.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bl = max(max(a, b), max(c, d)) + 1;
+      }
+      int maxLevel;
+      const int level = window_levels(valid, id, tid, maxLevel, bl);
+      if (valid) {
+        T.lvl[base + tid] = static_cast<uint32_t>(level);
+        atomicMax(T.lastLevel + id.x, level); atomicMax(T.lastLevel + id.y, level);
+        atomicMax(T.lastLevel + id.z, level); atomicMax(T.lastLevel + id.w, level);
+      }
+      top = max(top, maxLevel);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the window's levels are in L2 before the next window reads them
+    }
+    if (tid == 0) sMaxLevel = top;
+  }
+  __syncthreads();
+  const int levels = sMaxLevel + 1;
+  for (uint32_t c = tid; c < M; c += kSeqBlock) {  // behind us: the per-node levels go back to -1 for the next substep
+    const uint4 id = T.ids[c];
+    T.lastLevel[id.x] = -1; T.lastLevel[id.y] = -1; T.lastLevel[id.z] = -1; T.lastLevel[id.w] = -1;
+  }
+  if (levels > static_cast<int>(kTriMaxLevels)) {
+    if (tid == 0) { T.counters[6] = static_cast<uint32_t>(levels); T.counters[7] = 1; }
+    return;
+  }
+  for (uint32_t c = tid; c < M; c += kSeqBlock) atomicAdd(&hist[T.lvl[c] + 1], 1u);
+  __syncthreads();
+  if (tid == 0) {
+    for (int b = 0; b < levels; ++b) hist[b + 1] += hist[b];  // hist[b] = first slot of level b
+    T.counters[6] = static_cast<uint32_t>(levels);
+    T.counters[7] = 0;
+  }
+  __syncthreads();
+  for (int b = tid; b <= levels; b += kSeqBlock) T.lvStart[b] = hist[b];
+  __syncthreads();
+  for (uint32_t c = tid; c < M; c += kSeqBlock) T.lvOrder[atomicAdd(&hist[T.lvl[c]], 1u)] = c;  // any order inside a level
+}
+
+// A sequential pass over the contact list (stabilisation or friction), level by level with the whole workgroup: the
+// contacts of a level share no node.  Node state goes through agent-scope (L2) loads and stores, a level ends with
+// the stores drained and a workgroup barrier.
+template <int MODE>
+__global__ void __launch_bounds__(kSeqBlock) k_tri_sequential(TriArrays T, float4* pos4, float4* prev4, float4* vel4, float thickness,
+                                                              float friction, float staticThreshold) {
   float* pos = reinterpret_cast<float*>(pos4);
   float* prev = reinterpret_cast<float*>(prev4);
   float* vel = reinterpret_cast<float*>(vel4);
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
   const uint32_t M = T.counters[2];
-  for (uint32_t base = 0; base < M; base += 64) {
-    const bool valid = base + lane < M;
-    const uint4 id = valid ? T.ids[base + lane] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-    int maxLevel;
-    const int level = window_levels(valid, id, lane, maxLevel);
-    for (int lv = 0; lv <= maxLevel; ++lv) {
-      if (valid && level == lv) {
-        const float imA = ld(pos + 4 * id.x + 3), imB = ld(pos + 4 * id.y + 3), imC = ld(pos + 4 * id.z + 3), imD = ld(pos + 4 * id.w + 3);
-        const F3 pa = ld3(pos, id.x), pb = ld3(pos, id.y), pc = ld3(pos, id.z), pd = ld3(pos, id.w);
-        const F3 n = normalize(cross(pc - pb, pd - pb));
-        const float wTri = imB + imC + imD, wSum = imA + wTri;
-        if (MODE == 0) {
-          const float nDotP = dot(n, pa - pb);
-          if (nDotP < thickness) {
-            const F3 disp = (thickness - nDotP) * n;
-            const F3 da = disp * imA / wSum, dt = disp * wTri / wSum;
-            st3(pos, id.x, pa + da); st3(pos, id.y, pb - dt); st3(pos, id.z, pc - dt); st3(pos, id.w, pd - dt);
-            st3(prev, id.x, ld3(prev, id.x) + da); st3(prev, id.y, ld3(prev, id.y) - dt);
-            st3(prev, id.z, ld3(prev, id.z) - dt); st3(prev, id.w, ld3(prev, id.w) - dt);
-          }
-        } else {
-          const F3 va = ld3(vel, id.x), vb = ld3(vel, id.y), vc = ld3(vel, id.z), vd = ld3(vel, id.w);
-          const F3 avg = (vb + vc + vd) / 3.0f;
-          const F3 rel = va - avg;
-          const float vDotN = dot(rel, n);
-          const F3 perp = rel - vDotN * n;
-          float fr = friction;
-          if (sqrtf(dot(perp, perp)) < staticThreshold) fr = 1.0f;
-          const F3 dv = (-fr) * perp - (1.1f * fminf(vDotN, 0.0f)) * n;
-          const F3 ndv = neg(dv);
-          st3(vel, id.x, va + dv * imA / wSum);
-          st3(vel, id.y, vb + ndv * wTri / wSum);
-          st3(vel, id.z, vc + ndv * wTri / wSum);
-          st3(vel, id.w, vd + ndv * wTri / wSum);
-        }
+  if (M == 0) return;
+  if (T.counters[7]) {  // too many levels: one wavefront walks the list window by window
+    if (tid >= 64) return;
+    for (uint32_t base = 0; base < M; base += 64) {
+      const bool valid = base + tid < M;
+      const uint4 id = valid ? T.ids[base + tid] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+      int maxLevel;
+      const int level = window_levels(valid, id, tid, maxLevel);
+      for (int lv = 0; lv <= maxLevel; ++lv) {
+        if (valid && level == lv) tri_contact_step<MODE>(id, pos, prev, vel, thickness, friction, staticThreshold);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    return;
+  }
+  const uint32_t levels = T.counters[6];
+  for (uint32_t lv = 0; lv < levels; ++lv) {
+    const uint32_t lo = T.lvStart[lv], hi = T.lvStart[lv + 1];
+    for (uint32_t k = lo + tid; k < hi; k += kSeqBlock)
+      tri_contact_step<MODE>(T.ids[T.lvOrder[k]], pos, prev, vel, thickness, friction, staticThreshold);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   }
 }
 
@@ -504,7 +590,8 @@ uint32_t launch_tri_detect(hipStream_t st_, const TriArrays& T, const NodeArrays
   hipLaunchKernelGGL(k_inc_alloc, cgrid, blk, 0, st_, T, kdiag, cdiag, dinv);
   hipLaunchKernelGGL(k_inc_fill, cgrid, blk, 0, st_, T);
   hipLaunchKernelGGL(k_inc_sort, cgrid, blk, 0, st_, T);
-  return 13;
+  hipLaunchKernelGGL(k_tri_levels, dim3(1), dim3(kSeqBlock), 0, st_, T);
+  return 14;
 }
 void launch_pd_local_tri(hipStream_t st_, const TriArrays& T, const float4* pos, float thickness) {
   if (T.nt == 0) return;
@@ -513,11 +600,11 @@ void launch_pd_local_tri(hipStream_t st_, const TriArrays& T, const float4* pos,
 }
 void launch_tri_stabilize(hipStream_t st_, const TriArrays& T, const NodeArrays& nd, float thickness) {
   if (T.nt == 0) return;
-  hipLaunchKernelGGL(k_tri_sequential<0>, dim3(1), dim3(64), 0, st_, T, nd.pos, nd.prev, nd.vel, thickness, 0.0f, 0.0f);
+  hipLaunchKernelGGL(k_tri_sequential<0>, dim3(1), dim3(kSeqBlock), 0, st_, T, nd.pos, nd.prev, nd.vel, thickness, 0.0f, 0.0f);
 }
 void launch_tri_friction(hipStream_t st_, const TriArrays& T, const NodeArrays& nd, float friction, float staticThreshold) {
   if (T.nt == 0) return;
-  hipLaunchKernelGGL(k_tri_sequential<1>, dim3(1), dim3(64), 0, st_, T, nd.pos, nd.prev, nd.vel, 0.0f, friction, staticThreshold);
+  hipLaunchKernelGGL(k_tri_sequential<1>, dim3(1), dim3(kSeqBlock), 0, st_, T, nd.pos, nd.prev, nd.vel, 0.0f, friction, staticThreshold);
 }
 
 }  // namespace pies

@@ -10,11 +10,12 @@ g.create_tet_box(W,H,D, translation=(0,0.04,0), w=1.0, volume=True, triangles=Tr
 g.create_tet_box(W,H,D2, translation=(0.3, 0.04 + (H-1) + 0.07, 10.3), w=1.0, volume=True, triangles=True)
 g.finalize()
 t0=time.perf_counter()
-for k in range(16):
+WARM, TIMED = (6, 4) if os.environ.get("PROF") else (16, 20)
+for k in range(WARM):
     g.tick_async(1); g.synchronize()
     print(k, "contacts", len(g.tri_collisions), "failed", g.failed, "pcg", g.pcg_stats(), flush=True)
 t0=time.perf_counter()
-for k in range(20): g.tick_async(1); g.synchronize()  # a host's frame loop: the CG budget follows the contacts
-dt=(time.perf_counter()-t0)/20
+for k in range(TIMED): g.tick_async(1); g.synchronize()  # a host's frame loop: the CG budget follows the contacts
+dt=(time.perf_counter()-t0)/TIMED
 print("PD contacts %s: %.3f ms/substep %.1f substeps/s contacts %d failed %s pcg %s" % ((W,H,D), dt*1e3, 1/dt, len(g.tri_collisions), g.failed, g.pcg_stats()))
 assert np.isfinite(g.positions).all()
