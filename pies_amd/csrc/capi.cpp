@@ -462,11 +462,27 @@ static int adapt_pcg_budget(pies_solver* s) {
     if (restart) { s->pcgCalm = 0; s->pcgWindowMax = 0; }
     // (every spare iteration is two launches per local/global iteration that exit at once)
   }
+  // Graph variant for contact-heavy substeps: the contact rows of the SpMV get a pass of their own (k_contact_rows, one
+  // wavefront per node).  Either variant is correct with any number of contacts; the switch only follows what the last
+  // substep saw (on at 512 contacts, off after 120 synchronisations without any).
+  bool fastRows = s->triFastRows;
+  if (s->pd.tri.nt && s->pd.tri.counters) {
+    static const int force = [] { const char* e = std::getenv("PIES_TRI_FAST_ROWS"); return e ? std::atoi(e) : -1; }();
+    uint32_t contacts = 0;
+    HIP_TRY(s, hipMemcpyAsync(&contacts, s->pd.tri.counters + 2, sizeof(contacts), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    if (contacts >= 512) { fastRows = true; s->triQuiet = 0; }
+    else if (contacts == 0 && fastRows && ++s->triQuiet >= 120) { fastRows = false; s->triQuiet = 0; }
+    else if (contacts != 0) s->triQuiet = 0;
+    if (force >= 0) fastRows = force != 0;
+  }
   if (const char* e = std::getenv("PIES_PCG_DEBUG"); e && e[0] == '1')
-    std::fprintf(stderr, "[pies] pcg: residual^2 %.3g (%s) iterations %u budget %u -> %u calm %u cooldown %u\n", st[0], converged ? "ok" : "short", used,
-                 s->pcgBudget, budget, s->pcgCalm, s->pcgCooldown);
-  if (budget != s->pcgBudget) {
+    std::fprintf(stderr, "[pies] pcg: residual^2 %.3g (%s) iterations %u budget %u -> %u calm %u cooldown %u contact rows %s\n", st[0],
+                 converged ? "ok" : "short", used, s->pcgBudget, budget, s->pcgCalm, s->pcgCooldown, fastRows ? "pass" : "inline");
+  if (budget != s->pcgBudget || fastRows != s->triFastRows) {
     s->pcgBudget = budget;
+    s->triFastRows = fastRows;
+    s->pd.cg.useCAp = fastRows ? 1 : 0;
     return capture_graph(s);
   }
   return PIES_OK;

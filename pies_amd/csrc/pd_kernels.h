@@ -31,6 +31,12 @@ struct CgArrays {
   // point-triangle contacts of the substep (null when the pipeline is off): per node, ascending (contact<<2 | local)
   const uint32_t *tIncCnt, *tIncStart, *tInc;
   const uint4* tIds;
+  // contact-heavy substeps (the host switches the graph variant, capi.cpp): the contact part of a row is summed by a
+  // whole wavefront in a pass of its own (k_contact_rows) into cAp instead of by the row's lane inside the SpMV
+  const uint32_t* tUsed;       // nodes that take part in contacts
+  const uint32_t* tUsedCount;  // how many (device counter)
+  float4* cAp;
+  int useCAp;
   float* scal;   // rz[2][3], bb[3], iterations
   float* stats;  // max relative residual^2 over the tick's solves, max iterations, number of solves
 };

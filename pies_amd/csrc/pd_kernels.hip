@@ -561,6 +561,77 @@ PIES_DEV void solve_statistics(const CgArrays& A, const float* __restrict__ prev
   }
 }
 
+// Contact part of (K + C) v for the nodes that take part in contacts, one wavefront per node: lane t takes the node's
+// incidences t, t + 64, ... (list order inside a lane), the 64 partial sums are combined pairwise.  MODE 0: v = x
+// (before k_cg_init); MODE 1: v = p = z + beta p_old of CG iteration k (before k_cg_ap(k), same beta, same early exit).
+// Used by the contact-heavy graph variant only (CgArrays::useCAp): a node of a contact patch sits in tens to hundreds
+// of contacts, and the row's single lane walking them inside the SpMV made one CG iteration ~10x longer.
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_contact_rows(CgArrays A, const float4* __restrict__ x, int k, float tol2) {
+  float beta[3] = {0.f, 0.f, 0.f};
+  if (MODE == 1) {
+    float red[9], rz[3], rr[3], bb[3];
+    if (k == 0) {
+      block_reduce_partials<9>(A.partI, 9, A.nparts, red);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { rz[c] = red[c]; rr[c] = red[3 + c]; bb[c] = red[6 + c]; }
+    } else {
+      block_reduce_partials<6>(A.partB, 6, A.nparts, red);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { rz[c] = red[c]; rr[c] = red[3 + c]; bb[c] = A.scal[6 + c]; }
+    }
+    if (all_converged(rr, bb, tol2)) return;
+    if (k > 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float old = A.scal[3 * ((k - 1) & 1) + c];
+        beta[c] = old > 0.0f ? rz[c] / old : 0.0f;
+      }
+    }
+  }
+  const float4* __restrict__ pold = A.p[(k + 1) & 1];
+  auto fetch = [&](uint32_t j, float& qx, float& qy, float& qz) {
+    if (MODE == 0) {
+      const float4 v = x[j];
+      qx = v.x; qy = v.y; qz = v.z;
+    } else {
+      const float4 zj = A.z[j];
+      qx = zj.x; qy = zj.y; qz = zj.z;
+      if (k > 0) {
+        const float4 pj = pold[j];
+        qx = fmaf(beta[0], pj.x, qx); qy = fmaf(beta[1], pj.y, qy); qz = fmaf(beta[2], pj.z, qz);
+      }
+    }
+  };
+  const uint32_t used = *A.tUsedCount, lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
+  for (uint32_t u = wave; u < used; u += nwaves) {
+    const uint32_t node = A.tUsed[u];
+    const uint32_t tc = A.tIncCnt[node], ts = A.tIncStart[node];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (uint32_t t = lane; t < tc; t += 64) {
+      const uint32_t v = A.tInc[ts + t];
+      const uint4 id = A.tIds[v >> 2];
+      const bool point = (v & 3u) == 0u;
+      float q0[3], q1[3] = {0.f, 0.f, 0.f}, q2[3] = {0.f, 0.f, 0.f};
+      fetch(point ? id.y : id.x, q0[0], q0[1], q0[2]);
+      if (point) { fetch(id.z, q1[0], q1[1], q1[2]); fetch(id.w, q2[0], q2[1], q2[2]); }
+      sx = fmaf(-kTriContactW, q0[0], sx); sy = fmaf(-kTriContactW, q0[1], sy); sz = fmaf(-kTriContactW, q0[2], sz);
+      if (point) {
+        sx = fmaf(-kTriContactW, q1[0], sx); sy = fmaf(-kTriContactW, q1[1], sy); sz = fmaf(-kTriContactW, q1[2], sz);
+        sx = fmaf(-kTriContactW, q2[0], sx); sy = fmaf(-kTriContactW, q2[1], sy); sz = fmaf(-kTriContactW, q2[2], sz);
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      sx += __shfl_xor(sx, off, 64);
+      sy += __shfl_xor(sy, off, 64);
+      sz += __shfl_xor(sz, off, 64);
+    }
+    if (lane == 0) A.cAp[node] = make_float4(sx, sy, sz, 0.f);
+  }
+}
+
 // r = f - (K + C) x ; z = D^-1 r ; partB = {rz, rr} ; partI = {bb}.   One row per lane (SELL-64).
 // prevPartB != nullptr: block 0 first closes the previous solve's statistics (its scal[] entries are still intact:
 // this solve's k_cg_ap(0) is the first kernel to overwrite them).
@@ -584,7 +655,13 @@ __global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __
       sz = fmaf(a, xj.z, sz);
     }
     if (i < A.n) {
-      contact_row(A, i, [&](uint32_t j, float& px, float& py, float& pz) { const float4 v = x[j]; px = v.x; py = v.y; pz = v.z; }, sx, sy, sz);
+      if (A.useCAp) {
+        if (A.tIncCnt[i]) {
+          const float4 c = A.cAp[i]; sx += c.x; sy += c.y; sz += c.z;
+        }
+      } else {
+        contact_row(A, i, [&](uint32_t j, float& px, float& py, float& pz) { const float4 v = x[j]; px = v.x; py = v.y; pz = v.z; }, sx, sy, sz);
+      }
       const float4 xi = x[i], fi = f[i];
       const float cd = A.cdiag[i], di = A.dinv[i];
       const float rx = fi.x - fmaf(cd, xi.x, sx), ry = fi.y - fmaf(cd, xi.y, sy), rz = fi.z - fmaf(cd, xi.z, sz);
@@ -664,14 +741,20 @@ __global__ void __launch_bounds__(kBlock) k_cg_ap(CgArrays A, int k, float tol2)
       }
     }
     if (i < A.n) {
-      contact_row(A, i, [&](uint32_t j, float& qx, float& qy, float& qz) {
-        const float4 zj = A.z[j];
-        qx = zj.x; qy = zj.y; qz = zj.z;
-        if (k > 0) {
-          const float4 pj = pold[j];
-          qx = fmaf(beta[0], pj.x, qx); qy = fmaf(beta[1], pj.y, qy); qz = fmaf(beta[2], pj.z, qz);
+      if (A.useCAp) {
+        if (A.tIncCnt[i]) {
+          const float4 c = A.cAp[i]; sx += c.x; sy += c.y; sz += c.z;
         }
-      }, sx, sy, sz);
+      } else {
+        contact_row(A, i, [&](uint32_t j, float& qx, float& qy, float& qz) {
+          const float4 zj = A.z[j];
+          qx = zj.x; qy = zj.y; qz = zj.z;
+          if (k > 0) {
+            const float4 pj = pold[j];
+            qx = fmaf(beta[0], pj.x, qx); qy = fmaf(beta[1], pj.y, qy); qz = fmaf(beta[2], pj.z, qz);
+          }
+        }, sx, sy, sz);
+      }
       const float4 zi = A.z[i];
       float px = zi.x, py = zi.y, pz = zi.z;
       if (k > 0) {
@@ -857,10 +940,14 @@ void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, i
   const float tol2 = tol * tol;
   float* pb[2] = {pd.cg.partB, pd.cg.partBnext};
   // every solve of a substep runs the same number of iterations, so the previous solve left its final partials here
+  const bool rows = A.useCAp && A.tIncCnt;
+  const dim3 rgrid(256);
+  if (rows) hipLaunchKernelGGL(k_contact_rows<0>, rgrid, block, 0, st, A, nd.pos, 0, 0.0f);
   hipLaunchKernelGGL(k_cg_init, grid, block, 0, st, A, nd.pos, pd.rhs, first ? nullptr : pb[maxIters & 1]);
   for (int k = 0; k < maxIters; ++k) {
     A.partB = pb[k & 1];       // residual partials of iteration k (k = 0 reads partI instead)
     A.partBnext = pb[(k + 1) & 1];
+    if (rows) hipLaunchKernelGGL(k_contact_rows<1>, rgrid, block, 0, st, A, nd.pos, k, tol2);
     hipLaunchKernelGGL(k_cg_ap, grid, block, 0, st, A, k, tol2);
     hipLaunchKernelGGL(k_cg_update, grid, block, 0, st, A, nd.pos, k, tol2);
   }

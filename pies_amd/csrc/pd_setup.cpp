@@ -217,6 +217,9 @@ int pd_build(pies_solver* s) {
   pd.tri = TriArrays{};
   cg.tIncCnt = cg.tIncStart = cg.tInc = nullptr;
   cg.tIds = nullptr;
+  cg.tUsed = cg.tUsedCount = nullptr;
+  cg.cAp = nullptr;
+  cg.useCAp = 0;
   pd.tContrib = nullptr;
   const uint32_t nt = static_cast<uint32_t>(s->h_triangles.size() / 3);
   if (s->triangleCollisions && nt) {
@@ -258,6 +261,10 @@ int pd_build(pies_solver* s) {
     if (int rc = dev_alloc(s, T.maxContacts, &T.lvOrder, true)) return rc;
     if (int rc = dev_alloc(s, kTriMaxLevels + 1, &T.lvStart, true)) return rc;
     cg.tIncCnt = T.incCnt; cg.tIncStart = T.incStart; cg.tInc = T.incSorted; cg.tIds = T.ids;
+    cg.tUsed = T.usedNodes; cg.tUsedCount = T.counters + 4;
+    if (int rc = dev_alloc(s, n, &cg.cAp, true)) return rc;
+    if (const char* e = std::getenv("PIES_TRI_FAST_ROWS")) s->triFastRows = std::atoi(e) != 0;  // tests: force a variant from the first tick
+    cg.useCAp = s->triFastRows ? 1 : 0;
     pd.tContrib = T.contrib;
   }
   if (!contrib0.empty())

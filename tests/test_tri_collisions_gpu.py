@@ -31,7 +31,11 @@ def two_boxes(s, gap=0.04, vy=-2.0, offset=(0.4, 0.3)):
     s.set_prev_positions(s.positions)
 
 
-def test_two_boxes_contact_lists_and_positions(pies, oracle):
+@pytest.mark.parametrize("contact_rows", ["inline", "pass"])
+def test_two_boxes_contact_lists_and_positions(pies, oracle, monkeypatch, contact_rows):
+    """Both graph variants of the global step: contact rows summed by the row's lane inside the SpMV (few contacts) or
+    by a wavefront per node in a pass of their own (the variant the host switches to at 512 contacts)."""
+    monkeypatch.setenv("PIES_TRI_FAST_ROWS", "1" if contact_rows == "pass" else "0")
     g = pies.Solver(pd_options(pies, 6))
     o = oracle.OracleSolver(pd_options(oracle, 6))
     for s in (g, o):
