@@ -52,12 +52,15 @@ PIES_DEV uint32_t insert_cell(uint64_t* keys, uint32_t mask, uint64_t key, bool&
 }
 
 // ascending rank sort of c values (one wave; c is small: a bucket or a per-node list)
-PIES_DEV void rank_sort(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t start, uint32_t c, int lane) {
+// rankOfValue (optional): rankOfValue[v] = position of value v in its sorted list (the values are distinct indices)
+PIES_DEV void rank_sort(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t start, uint32_t c, int lane,
+                        uint32_t* __restrict__ rankOfValue = nullptr) {
   for (uint32_t e = lane; e < c; e += 64) {
     const uint32_t v = in[start + e];
     uint32_t rank = 0;
     for (uint32_t f = 0; f < c; ++f) rank += (in[start + f] < v) ? 1u : 0u;
     out[start + rank] = v;
+    if (rankOfValue) rankOfValue[v] = rank;
   }
 }
 

@@ -255,6 +255,7 @@ int pd_build(pies_solver* s) {
     if (int rc = dev_alloc(s, n, &T.usedNodes, true)) return rc;
     if (int rc = dev_alloc(s, 4ull * T.maxContacts, &T.inc, true)) return rc;
     if (int rc = dev_alloc(s, 4ull * T.maxContacts, &T.incSorted, true)) return rc;
+    if (int rc = dev_alloc(s, 4ull * T.maxContacts, &T.incPos, true)) return rc;
     if (int rc = dev_alloc(s, n, &T.lastLevel)) return rc;
     HIP_TRY(s, hipMemsetAsync(T.lastLevel, 0xFF, static_cast<size_t>(n) * sizeof(int), s->stream));  // -1
     if (int rc = dev_alloc(s, T.maxContacts, &T.lvl, true)) return rc;

@@ -32,6 +32,7 @@ struct TriArrays {
   float4* contrib;   // 4 per contact: w * (AtA p)_i
   // per node: the contacts it takes part in, ascending (contact << 2 | local index)
   uint32_t *incCnt, *incStart, *incFill, *usedNodes, *inc, *incSorted;
+  uint32_t* incPos;    // per (contact << 2 | local): its position in the node's sorted list
   // dependency levels of the contact list (k_tri_levels): the sequential passes run level by level
   int* lastLevel;      // per node: level of the last contact seen that touches it (-1 between substeps)
   uint32_t* lvl;       // per contact

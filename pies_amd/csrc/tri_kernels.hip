@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(kBlock) k_inc_sort(TriArrays T) {
   const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
   for (uint32_t u = wave; u < used; u += nwaves) {
     const uint32_t n = T.usedNodes[u];
-    rank_sort(T.inc, T.incSorted, T.incStart[n], T.incCnt[n], lane);
+    rank_sort(T.inc, T.incSorted, T.incStart[n], T.incCnt[n], lane, T.incPos);
   }
 }
 
@@ -470,13 +470,20 @@ PIES_DEV void tri_contact_step(const uint4 id, float* pos, float* prev, float* v
 
 // Dependency levels of the whole contact list, once per substep: level(c) = 1 + the highest level among the earlier
 // contacts that share a node with c, so that running the list level by level, in any order inside a level, is the
-// reference's sequential pass.  The list is walked in order by one wavefront, 64 contacts at a time: levels inside the
-// window as before, starting from the per-node level of the last earlier contact (lastLevel, reset to -1 behind us).
-// The other 15 wavefronts of the block then bucket the contacts by level.  More than kTriMaxLevels levels (thousands
-// of contacts on one node) raise counters[7] and the passes fall back to the single-wavefront walk.
+// reference's sequential pass.  A node's contacts are already listed in ascending order (incSorted) with every
+// incidence's position in that list (incPos), so the earlier contact that matters for node n is the list entry before
+// c: at most four predecessors per contact, all with smaller indices.  The list is relaxed 1024 contacts at a time,
+// in order: predecessors in earlier chunks are final, those inside the chunk are iterated to the fixed point
+// (as many rounds as the longest chain inside the chunk; levels live in LDS, 16 bit).  Lists longer than
+// kLevelsLdsCap take the older walk: one wavefront, 64 contacts at a time, levels inside the window with 63
+// cross-lane broadcasts on top of a per-node "level of the last earlier contact" array.  Then the contacts are
+// bucketed by level.  More than kTriMaxLevels levels (thousands of contacts on one node) raise counters[7] and the
+// passes fall back to the single-wavefront walk.
 constexpr int kSeqBlock = 1024;
+constexpr uint32_t kLevelsLdsCap = 49152;  // contacts whose 16-bit levels fit next to the histogram in LDS
 __global__ void __launch_bounds__(kSeqBlock) k_tri_levels(TriArrays T) {
   __shared__ uint32_t hist[kTriMaxLevels + 1];
+  __shared__ uint16_t slv[kLevelsLdsCap];
   __shared__ int sMaxLevel;
   const uint32_t M = T.counters[2];
   const int tid = threadIdx.x;
@@ -487,42 +494,83 @@ __global__ void __launch_bounds__(kSeqBlock) k_tri_levels(TriArrays T) {
     if (tid == 0) { T.counters[6] = 0; T.counters[7] = 0; }
     return;
   }
-  if (tid < 64) {
+  const bool inLds = M <= kLevelsLdsCap;
+  if (inLds) {
     int top = -1;
-    for (uint32_t base = 0; base < M; base += 64) {
-      const bool valid = base + tid < M;
-      const uint4 id = valid ? T.ids[base + tid] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-      int bl = 0;
+    bool overflow = false;
+    for (uint32_t base = 0; base < M; base += kSeqBlock) {
+      const uint32_t c = base + tid;
+      const bool valid = c < M;
+      uint32_t pred[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
       if (valid) {
-        const int a = __hip_atomic_load(T.lastLevel + id.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int b = __hip_atomic_load(T.lastLevel + id.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int c = __hip_atomic_load(T.lastLevel + id.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int d = __hip_atomic_load(T.lastLevel + id.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bl = max(max(a, b), max(c, d)) + 1;
+        const uint4 id = T.ids[c];
+        const uint32_t node[4] = {id.x, id.y, id.z, id.w};
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+          const uint32_t rank = T.incPos[4 * c + l];
+          if (rank) pred[l] = T.incSorted[T.incStart[node[l]] + rank - 1] >> 2;
+        }
+        slv[c] = 0;
       }
-      int maxLevel;
-      const int level = window_levels(valid, id, tid, maxLevel, bl);
-      if (valid) {
-        T.lvl[base + tid] = static_cast<uint32_t>(level);
-        atomicMax(T.lastLevel + id.x, level); atomicMax(T.lastLevel + id.y, level);
-        atomicMax(T.lastLevel + id.z, level); atomicMax(T.lastLevel + id.w, level);
+      __syncthreads();
+      int cur = 0;
+      for (;;) {
+        int lv = 0;
+        if (valid) {
+#pragma unroll
+          for (int l = 0; l < 4; ++l)
+            if (pred[l] != 0xffffffffu) lv = max(lv, static_cast<int>(slv[pred[l]]) + 1);
+        }
+        const bool changed = valid && lv != cur;
+        if (changed) { cur = lv; slv[c] = static_cast<uint16_t>(min(lv, 65535)); }
+        if (!__syncthreads_or(changed ? 1 : 0)) break;
       }
-      top = max(top, maxLevel);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the window's levels are in L2 before the next window reads them
+      if (valid) { top = max(top, cur); overflow = overflow || cur >= 65535; }
     }
-    if (tid == 0) sMaxLevel = top;
+    // block maximum of the levels
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) top = max(top, __shfl_xor(top, off, 64));
+    if ((tid & 63) == 0) atomicMax(&sMaxLevel, overflow ? 1 << 20 : top);
+    __syncthreads();
+  } else {
+    if (tid < 64) {
+      int top = -1;
+      for (uint32_t base = 0; base < M; base += 64) {
+        const bool valid = base + tid < M;
+        const uint4 id = valid ? T.ids[base + tid] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+        int bl = 0;
+        if (valid) {
+          const int a = __hip_atomic_load(T.lastLevel + id.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int b = __hip_atomic_load(T.lastLevel + id.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int c = __hip_atomic_load(T.lastLevel + id.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int d = __hip_atomic_load(T.lastLevel + id.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bl = max(max(a, b), max(c, d)) + 1;
+        }
+        int maxLevel;
+        const int level = window_levels(valid, id, tid, maxLevel, bl);
+        if (valid) {
+          T.lvl[base + tid] = static_cast<uint32_t>(level);
+          atomicMax(T.lastLevel + id.x, level); atomicMax(T.lastLevel + id.y, level);
+          atomicMax(T.lastLevel + id.z, level); atomicMax(T.lastLevel + id.w, level);
+        }
+        top = max(top, maxLevel);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the window's levels are in L2 before the next window reads them
+      }
+      if (tid == 0) sMaxLevel = top;
+    }
+    __syncthreads();
+    for (uint32_t c = tid; c < M; c += kSeqBlock) {  // behind us: the per-node levels go back to -1 for the next substep
+      const uint4 id = T.ids[c];
+      T.lastLevel[id.x] = -1; T.lastLevel[id.y] = -1; T.lastLevel[id.z] = -1; T.lastLevel[id.w] = -1;
+    }
   }
-  __syncthreads();
   const int levels = sMaxLevel + 1;
-  for (uint32_t c = tid; c < M; c += kSeqBlock) {  // behind us: the per-node levels go back to -1 for the next substep
-    const uint4 id = T.ids[c];
-    T.lastLevel[id.x] = -1; T.lastLevel[id.y] = -1; T.lastLevel[id.z] = -1; T.lastLevel[id.w] = -1;
-  }
   if (levels > static_cast<int>(kTriMaxLevels)) {
-    if (tid == 0) { T.counters[6] = static_cast<uint32_t>(levels); T.counters[7] = 1; }
+    if (tid == 0) { T.counters[6] = static_cast<uint32_t>(min(levels, 1 << 20)); T.counters[7] = 1; }
     return;
   }
-  for (uint32_t c = tid; c < M; c += kSeqBlock) atomicAdd(&hist[T.lvl[c] + 1], 1u);
+  auto level_of = [&](uint32_t c) { return inLds ? static_cast<uint32_t>(slv[c]) : T.lvl[c]; };
+  for (uint32_t c = tid; c < M; c += kSeqBlock) atomicAdd(&hist[level_of(c) + 1], 1u);
   __syncthreads();
   if (tid == 0) {
     for (int b = 0; b < levels; ++b) hist[b + 1] += hist[b];  // hist[b] = first slot of level b
@@ -532,7 +580,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_tri_levels(TriArrays T) {
   __syncthreads();
   for (int b = tid; b <= levels; b += kSeqBlock) T.lvStart[b] = hist[b];
   __syncthreads();
-  for (uint32_t c = tid; c < M; c += kSeqBlock) T.lvOrder[atomicAdd(&hist[T.lvl[c]], 1u)] = c;  // any order inside a level
+  for (uint32_t c = tid; c < M; c += kSeqBlock) T.lvOrder[atomicAdd(&hist[level_of(c)], 1u)] = c;  // any order inside a level
 }
 
 // A sequential pass over the contact list (stabilisation or friction), level by level with the whole workgroup: the
