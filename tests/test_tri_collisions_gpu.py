@@ -108,3 +108,34 @@ def test_many_contacts_spanning_several_windows(pies, oracle):
         most = max(most, len(o.tri_collisions))
         assert np.abs(g.positions - o.positions).max() <= tol, t
     assert most > 128
+
+
+@pytest.mark.parametrize("contact_rows", ["inline", "pass"])
+def test_thousands_of_contacts_level_schedule(pies, oracle, monkeypatch, contact_rows):
+    """A plate resting on a larger one: 2000+ contacts per tick, chains of tens of contacts through one node.  Exercises
+    the dependency levels of the whole contact list (chunked relaxation, more than one 1024-contact chunk), the
+    level-by-level stabilisation / friction passes and both variants of the contact rows in the global step."""
+    monkeypatch.setenv("PIES_TRI_FAST_ROWS", "1" if contact_rows == "pass" else "0")
+    g = pies.Solver(pd_options(pies, 3))
+    g.set_pcg(3e-7, 256)  # thousands of w = 1e4 contacts: the default cap of 32 CG iterations stops above the tolerance
+    o = oracle.OracleSolver(pd_options(oracle, 3))
+    for s in (g, o):
+        s.create_tet_box(14, 2, 20, translation=(0, 0.02, 0), w=1.0)
+        s.create_tet_box(12, 2, 18, translation=(0.37, 1.05, 0.41), w=1.0)
+        v = s.velocities
+        v[14 * 2 * 20:, 1] = -1.5
+        s.set_velocities(v)
+        s.set_prev_positions(s.positions)
+    # 5 000+ contacts of weight 1e4 against elastic terms of order 1: the fp32 solution of that system (direct in the
+    # oracle, CG here) is only good to a few 1e-5 of the body size, so twice the usual PD tolerance (measured: 1.3x with
+    # the contact rows summed lane by lane, 0.5x with the pairwise sums of the wavefront pass)
+    tol = 2.0 * tol_for(o.positions)
+    most = 0
+    for t in range(3):
+        sync_state(g, o)
+        g.tick(); o.tick()
+        assert np.array_equal(g.tri_collisions, o.tri_collisions), t
+        most = max(most, len(o.tri_collisions))
+        assert np.abs(g.positions - o.positions).max() <= tol, t
+        assert np.abs(g.velocities - o.velocities).max() <= tol / 0.012, t
+    assert most > 1024 and not g.failed
