@@ -157,7 +157,8 @@ int pies_set_flag(pies_solver_t* s, int flag, int value);
 int pies_set_schedule(pies_solver_t* s, int schedule);
 /* PD global step: the reference solves (K + C) x = rhs with a sparse Cholesky factorisation rebuilt every
  * substep (Solver.cpp:258-262,356); here it is a Jacobi-preconditioned CG.  rel_tol bounds ||r||/||rhs|| per
- * coordinate column, max_iters is the number of CG iterations captured per solve (defaults 3e-7, 12). */
+ * coordinate column, max_iters the upper bound of CG iterations per solve (defaults 3e-7, 128; the captured graph
+ * holds as many as the recent solves needed plus one or two). */
 int pies_set_pcg(pies_solver_t* s, float rel_tol, uint32_t max_iters);
 /* Over the last tick: largest ||r||/||rhs|| left by any solve, most CG iterations any solve used, solves run. */
 int pies_get_pcg_stats(pies_solver_t* s, float* max_rel_residual, uint32_t* max_iters_used, uint32_t* solves);

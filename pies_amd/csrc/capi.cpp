@@ -428,9 +428,9 @@ static int capture_graph(pies_solver* s) {
 }
 
 // The graph holds a fixed number of CG iterations per solve (converged solves early-exit the rest).  At
-// every host synchronisation the budget follows what the solves needed: it starts at pcgMaxIters, shrinks
-// to (most iterations used over the last 8+ synchronisations) + 2, to + 1 after 24, and returns to pcgMaxIters at
-// once when a solve ran out of iterations above the tolerance.
+// every host synchronisation the budget follows what the solves needed: it starts at 32, shrinks to (most
+// iterations used over the last 8+ synchronisations) + 2, to + 1 after 24, and quadruples (at least 32, at most
+// pcgMaxIters = 128 by default) when a solve ran out of iterations above the tolerance.
 static int adapt_pcg_budget(pies_solver* s) {
   if (s->opt.solver != PIES_SOLVER_PD || !s->pd.cg.stats || !s->graphExec || s->sceneDirty || under_profiler()) return PIES_OK;
   float st[4] = {0, 0, 0, 0};
@@ -443,7 +443,7 @@ static int adapt_pcg_budget(pies_solver* s) {
   if (!converged && budget < s->pcgMaxIters) {
     // a solve ran out of iterations above the tolerance (new contacts stiffen the system at once): back to the full
     // budget now - the reference's solve is a direct one - and no shrinking for the next 60 synchronisations
-    budget = s->pcgMaxIters;
+    budget = std::min(s->pcgMaxIters, std::max(32u, 4u * budget));  // 2..8 -> 32 -> 128: at most two short substeps
     s->pcgCalm = 0;
     s->pcgWindowMax = 0;
     s->pcgCooldown = 60;
@@ -631,7 +631,7 @@ int pies_set_pcg(pies_solver_t* s, float rel_tol, uint32_t max_iters) {
     if (int rc = scene_sync_host(s)) return rc;
     s->pcgTol = rel_tol;
     s->pcgMaxIters = max_iters;
-    s->pcgBudget = max_iters;
+    s->pcgBudget = std::min(max_iters, 32u);
     s->sceneDirty = true;  // the captured launch sequence changes
   }
   return PIES_OK;

@@ -188,7 +188,7 @@ struct pies_solver {
   uint32_t pd_nnz = 0;
   uint32_t goalSlotBase = 0;  // first fp64 contribution slot of the goal constraints
   float pcgTol = 3.0e-7f;     // relative residual ||r|| / ||b|| per coordinate column
-  uint32_t pcgMaxIters = 32;  // upper bound of CG iterations per global step
+  uint32_t pcgMaxIters = 128; // upper bound of CG iterations per global step (thousands of w = 1e4 contacts need 40+)
   uint32_t pcgBudget = 32;    // iterations currently captured in the graph (adapted to what the solves use)
   uint32_t pcgCalm = 0;       // synchronisations in the current observation window (all solves converged)
   uint32_t pcgWindowMax = 0;  // most CG iterations any solve used in that window
