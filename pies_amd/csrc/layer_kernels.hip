@@ -312,7 +312,8 @@ hipError_t layer_prepare(uint32_t maxGroupNodes) {
 
 void launch_layer(hipStream_t st, const NodeArrays& nd, const LayerData& D, const LayerLaunch& L0, const LayerParams& P) {
   if (L0.groups == 0 || L0.nseg == 0) return;
-  static const int skipMask = [] { const char* e = getenv("PIES_EXP_LAYER_SKIP"); return e ? atoi(e) : 0; }();  // timing experiments
+  // timing experiments / tests: read at every capture (a launch is recorded into the substep graph once)
+  const int skipMask = [] { const char* e = getenv("PIES_EXP_LAYER_SKIP"); return e ? atoi(e) : 0; }();
   LayerLaunch L = L0;
   if (skipMask) {
     L.nseg = 0;
@@ -320,8 +321,8 @@ void launch_layer(hipStream_t st, const NodeArrays& nd, const LayerData& D, cons
       if (!((skipMask >> L0.seg[s].kind) & 1)) L.seg[L.nseg++] = L0.seg[s];
   }
   const size_t lds = layer_lds_bytes(D.maxGroupNodes);
-  static const int variant = [] { const char* e = getenv("PIES_EXP_TET"); return e ? atoi(e) : 0; }();
-  static const uint32_t forceBlock = [] { const char* e = getenv("PIES_LAYER_BLOCK"); return e ? (uint32_t)atoi(e) : 0u; }();
+  const int variant = [] { const char* e = getenv("PIES_EXP_TET"); return e ? atoi(e) : 0; }();
+  const uint32_t forceBlock = [] { const char* e = getenv("PIES_LAYER_BLOCK"); return e ? (uint32_t)atoi(e) : 0u; }();
   const uint32_t want = forceBlock ? forceBlock : L.maxClass;
   if (variant == 1) { hipLaunchKernelGGL((k_layer<256, 1>), dim3(L.groups), dim3(256), lds, st, nd, D, L, P); return; }  // experiment: no SVD
   if (want <= 256) hipLaunchKernelGGL((k_layer<256, 0>), dim3(L.groups), dim3(256), lds, st, nd, D, L, P);

@@ -212,6 +212,19 @@ def test_layered_is_active_and_fuses_an_iteration_into_two_launches(pies, oracle
     _check(g, o)
 
 
+def test_layered_colour_classes_larger_than_the_workgroup(pies, oracle, monkeypatch):
+    """Cross-sections of 576 nodes give colour classes of ~270 tetrahedra and ~500 distance constraints; with the
+    workgroup forced to 256 lanes every class takes two or three passes of the in-kernel loops."""
+    monkeypatch.setenv("PIES_LAYER_BLOCK", "256")
+    def build(s):
+        scenes.build_beam(s, (24, 24, 26))
+        scenes.perturb(s, 3, 0.05)
+    g, o = _layered_pair(pies, oracle, build, 3, ticks=2)
+    assert g.launch_counts()["layer"] == 2 * 3 + 1
+    assert np.diff(g.batches(pies.TET).astype(np.int64)).max() > 256
+    _check(g, o)
+
+
 def test_layered_with_bend_position_constraints_and_two_bodies(pies, oracle):
     def build(s):
         scenes.build_beam(s, (4, 5, 17), translation=(0.0, 0.3, 0.0))  # touches the floor
