@@ -166,6 +166,8 @@ constexpr int kSvdMaxSweeps = ORA_SVD_MAX_SWEEPS;
 #define ORA_SVD_TOL 4.76837158203125e-07f /* 4 * 2^-23 */
 #endif
 constexpr float kSvdTol2 = ORA_SVD_TOL * ORA_SVD_TOL;
+constexpr float kSvdTiny = 1.0e-18f;   // a singular value below this is a collapsed direction
+constexpr float kSvdTiny2 = 1.0e-36f;  // squared norms (or their products) below this: numerically zero columns
 
 struct Svd3 {
   float b[3][3];  // b[i] = i-th column of A*V  (= s_i * u_i)
@@ -200,7 +202,9 @@ inline bool jacobi_pair(Svd3& d, int p, int q) {
   const float alpha = dot3f(bp, bp);
   const float beta = dot3f(bq, bq);
   const float gamma = dot3f(bp, bq);
-  if (!(gamma * gamma > kSvdTol2 * (alpha * beta))) return false;
+  // + kSvdTiny2: numerically zero columns (collapsed element) are never rotated against; for every other pair the fused
+  // sum rounds to kSvdTol2 * (alpha * beta) itself
+  if (!(gamma * gamma > std::fmaf(kSvdTol2, alpha * beta, kSvdTiny2))) return false;
   const float delta = beta - alpha;
   const float g2 = gamma + gamma;
   const float hw = std::fmaf(delta, delta, g2 * g2);
@@ -236,13 +240,12 @@ inline Svd3 svd3(const float a[3][3]) {
   }
   for (int i = 0; i < 3; ++i) {
     const float n2 = dot3f(d.b[i], d.b[i]);
-    d.rs[i] = rsqrt_nr(n2);
+    d.rs[i] = n2 > kSvdTiny2 ? rsqrt_nr(n2) : 0.0f;
     d.s[i] = n2 * d.rs[i];
   }
   return d;
 }
 
-constexpr float kSvdTiny = 1.0e-18f;
 
 // out[r][c] = sum_i u_i[r] * snew[i] * v_i[c], with u_i = b_i / s_i, evaluated as
 // sum_i (b_i[r] * (snew[i]/s_i)) * v_i[c].  A direction whose singular value underflows (collapsed

@@ -30,6 +30,7 @@ constexpr int kSvdMaxSweeps = PIES_SVD_MAX_SWEEPS;
 constexpr float kSvdTol = 4.76837158203125e-07f;  // 4 * 2^-23
 constexpr float kSvdTol2 = kSvdTol * kSvdTol;
 constexpr float kSvdTiny = 1.0e-18f;
+constexpr float kSvdTiny2 = 1.0e-36f;
 
 struct Svd3 {
   float b[3][3];  // b[i] = column i of A*V (= s_i u_i)
@@ -56,7 +57,10 @@ template <int P, int Q> PIES_DEV bool jacobi_pair(Svd3& d) {
   const float alpha = dot3f(d.b[P], d.b[P]);
   const float beta = dot3f(d.b[Q], d.b[Q]);
   const float gamma = dot3f(d.b[P], d.b[Q]);
-  if (!(gamma * gamma > kSvdTol2 * (alpha * beta))) return false;
+  // + kSvdTiny2: a column whose squared norm has fallen to ~1e-36 is numerically zero (a collapsed element); since
+  // gamma^2 <= alpha*beta the pair is then skipped instead of sending rsqrt_nr out of its range.  For every other
+  // pair the fused sum rounds to kSvdTol2 * (alpha * beta) itself.
+  if (!(gamma * gamma > fmaf(kSvdTol2, alpha * beta, kSvdTiny2))) return false;
   const float delta = beta - alpha;
   const float g2 = gamma + gamma;
   const float hw = fmaf(delta, delta, g2 * g2);
@@ -95,7 +99,7 @@ PIES_DEV void svd3(const float a[3][3], Svd3& d) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const float n2 = dot3f(d.b[i], d.b[i]);
-    d.rs[i] = rsqrt_nr(n2);
+    d.rs[i] = n2 > kSvdTiny2 ? rsqrt_nr(n2) : 0.0f;  // a collapsed direction: s = 0, handled by svd3_recompose
     d.s[i] = n2 * d.rs[i];
   }
 }
