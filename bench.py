@@ -92,11 +92,12 @@ def pd_bytes(solver):
     steps and rows (nodes) for the rest."""
     n = solver.count(capi.NODES)
     nnz = solver.count(capi.SYSTEM_NNZ)
-    inc = (4 * (solver.count(capi.TET) + solver.count(capi.VOLUME) + solver.count(capi.BEND)) + 2 * solver.count(capi.DISTANCE)
-           + solver.count(capi.POSITION))
+    paired = solver.count(capi.VOLUME) > 0 and solver.launch_counts().get("pd_local_volume", 0) == 0
+    # the fused strain + volume local step leaves one record per corner of the element pair
+    inc = (4 * (solver.count(capi.TET) + (0 if paired else solver.count(capi.VOLUME)) + solver.count(capi.BEND))
+           + 2 * solver.count(capi.DISTANCE) + solver.count(capi.POSITION))
     # strain + volume constraints over the same elements run fused (no separate volume launches): ids 16 + Qinv 36 +
     # 2 x (min, max, w) 24 + four positions 48 + 2 x 36 projected gradients
-    paired = solver.count(capi.VOLUME) > 0 and solver.launch_counts().get("pd_local_volume", 0) == 0
     return {
         "pd_predict": 52, "pd_local_distance": 64, "pd_local_tet": 196 if paired else 148, "pd_local_volume": 148,
         # gather formulation: one 12-byte contribution + its 4-byte slot index per (constraint, node) incidence,

@@ -142,7 +142,7 @@ template <bool VOLUME> PIES_DEV void tet_project(const TetFrame& t, float lo, fl
   }
 }
 // contribution_i = w * (A^T p)_i with p = (0, Fh[0], Fh[1], Fh[2]), Fh = U diag(s) V^T
-PIES_DEV void tet_emit(const TetFrame& t, const float s[3], float w, Vec3f* __restrict__ contrib, uint32_t count, uint32_t c) {
+PIES_DEV void tet_records(const TetFrame& t, const float s[3], float w, float rec[4][3]) {
   float Fh[3][3];
   svd3_recompose(t.d, s, Fh);
   // A[1+r][0] = ((0 + -q_r0) + -q_r1) + -q_r2 ; A[1+r][1+c] = q_rc with q_rc = Qinv[r][c] (reference's row-major read)
@@ -158,7 +158,15 @@ PIES_DEV void tet_emit(const TetFrame& t, const float s[3], float w, Vec3f* __re
     for (int cc = 0; cc < 3; ++cc) out[1 + cc][k] = ((0.0f + t.qi[0][cc] * Fh[0][k]) + t.qi[1][cc] * Fh[1][k]) + t.qi[2][cc] * Fh[2][k];
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) contrib[i * count + c] = Vec3f{w * out[i][0], w * out[i][1], w * out[i][2]};
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rec[i][k] = w * out[i][k];
+}
+PIES_DEV void tet_emit(const TetFrame& t, const float s[3], float w, Vec3f* __restrict__ contrib, uint32_t count, uint32_t c) {
+  float rec[4][3];
+  tet_records(t, s, w, rec);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) contrib[i * count + c] = Vec3f{rec[i][0], rec[i][1], rec[i][2]};
 }
 
 template <bool VOLUME>
@@ -190,10 +198,16 @@ __global__ void __launch_bounds__(kBlock) k_pd_local_tet_pair(const float4* __re
   TetFrame t;
   tet_frame(pos, ids[c], q0[c], q1[c], a2, t);
   float s[3];
+  // one record per corner: the strain and the volume contribution of the element added up here (the right-hand side
+  // then gathers 4 records per element pair instead of 8; contribVol stays unused)
+  float ra[4][3], rb[4][3];
   tet_project<false>(t, a2.y, a2.z, s);
-  tet_emit(t, s, a2.w, contribTet, count, c);
+  tet_records(t, s, a2.w, ra);
   tet_project<true>(t, v2.y, v2.z, s);
-  tet_emit(t, s, v2.w, contribVol, count, c);
+  tet_records(t, s, v2.w, rb);
+  (void)contribVol;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) contribTet[i * count + c] = Vec3f{ra[i][0] + rb[i][0], ra[i][1] + rb[i][1], ra[i][2] + rb[i][2]};
 }
 
 // BendConstraint in PD (Constraints.cpp:312-366): A = B = I, contribution = w * projected_i.

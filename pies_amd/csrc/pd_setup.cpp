@@ -109,7 +109,9 @@ int pd_build(pies_solver* s) {
       for (uint32_t i = 0; i < 2; ++i) fn(s->h_distance[c].ids[i], s->slotBase[1] + i * cnt[1] + c);
     for (uint32_t c = 0; c < cnt[2]; ++c)
       for (uint32_t i = 0; i < 4; ++i) fn(s->h_tet[c].ids[i], s->slotBase[2] + i * cnt[2] + c);
-    for (uint32_t c = 0; c < cnt[3]; ++c)
+    // strain + volume constraints over identical elements (tetVolumePaired): the fused local step adds the volume
+    // contribution into the strain constraint's record, so the volume slots are not gathered
+    for (uint32_t c = 0; c < (s->tetVolumePaired ? 0u : cnt[3]); ++c)
       for (uint32_t i = 0; i < 4; ++i) fn(s->h_volume[c].ids[i], s->slotBase[3] + i * cnt[3] + c);
     for (uint32_t c = 0; c < cnt[4]; ++c)
       for (uint32_t i = 0; i < 4; ++i) fn(s->h_bend[c].ids[i], s->slotBase[4] + i * cnt[4] + c);
