@@ -362,6 +362,12 @@ __global__ void __launch_bounds__(kBlock) k_pd_local_shape(const float4* __restr
 // (position, distance, tet, volume, bend, ... then the floor contacts), so the float sum is the reference's.
 // Also evaluates the floor projection (CollisionConstraint.cpp:447-455: clamps to y >= 0, not floorHeight).
 // ------------------------------------------------------------------------------------------------------
+#ifndef PIES_RHS_LANES
+#define PIES_RHS_LANES 4
+#endif
+// lanes that share a node's gather (each with four records in flight).  Measured per launch at 100k / 1M nodes with ~24
+// records per node: 16 lanes 13.1 / 136 us, 8 lanes 10.2 / 95, 4 lanes 9.3 / 88, 2 lanes 10.6 / 105.
+constexpr uint32_t kRhsLanes = PIES_RHS_LANES;
 __global__ void __launch_bounds__(kBlock) k_pd_rhs(const float4* __restrict__ msn, const Vec3f* __restrict__ contrib,
                                                    const uint32_t* __restrict__ incPtr, const uint32_t* __restrict__ incSlot,
                                                    const double4* __restrict__ contribD, const uint32_t* __restrict__ incPtrD,
@@ -370,20 +376,20 @@ __global__ void __launch_bounds__(kBlock) k_pd_rhs(const float4* __restrict__ ms
                                                    float4* __restrict__ rhs, const uint32_t* __restrict__ tIncCnt,
                                                    const uint32_t* __restrict__ tIncStart, const uint32_t* __restrict__ tInc,
                                                    const float4* __restrict__ tContrib, uint32_t n) {
-  // 16 lanes per node: lane `sub` adds up the records sub, sub + 16, ... of the node's slot list (slot indices and
-  // records of 16 slots are in flight at once), then the 16 partial sums are combined pairwise.  The reference adds
+  // kRhsLanes lanes per node: lane `sub` adds up the records sub, sub + kRhsLanes, ... of the node's slot list (four
+  // slot indices and records per lane in flight at once), then the partial sums are combined pairwise.  The reference adds
   // the same terms one after the other; the difference is fp32 rounding of a ~50-term sum (PD parity is by
   // tolerance).  (Measured at 100k nodes: 1 lane/node 60 us; 16 lanes with the terms added in
   // list order by one lane 24 us; visiting nodes in Morton order was slower than index order.)
-  const uint32_t i = (xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+  const uint32_t i = (xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x) / kRhsLanes, sub = threadIdx.x & (kRhsLanes - 1);
   const bool live = i < n;
   float4 f = live ? msn[i] : make_float4(0.f, 0.f, 0.f, 0.f);
   const uint32_t b = live ? incPtr[i] : 0u, e = live ? incPtr[i + 1] : 0u;
   float ax = 0.f, ay = 0.f, az = 0.f;
-  for (uint32_t k = b + sub; k < e; k += 64) {  // four records per lane in flight: slot indices first, then the records
+  for (uint32_t k = b + sub; k < e; k += 4 * kRhsLanes) {  // four records per lane in flight: slot indices first, then the records
     uint32_t slot[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) slot[u] = (k + 16u * u < e) ? incSlot[k + 16u * u] : 0xffffffffu;
+    for (int u = 0; u < 4; ++u) slot[u] = (k + kRhsLanes * u < e) ? incSlot[k + kRhsLanes * u] : 0xffffffffu;
     Vec3f c[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) c[u] = (slot[u] != 0xffffffffu) ? contrib[slot[u]] : Vec3f{0.f, 0.f, 0.f};
@@ -395,10 +401,10 @@ __global__ void __launch_bounds__(kBlock) k_pd_rhs(const float4* __restrict__ ms
     }
   }
 #pragma unroll
-  for (int off = 8; off >= 1; off >>= 1) {
-    ax += __shfl_xor(ax, off, 16);
-    ay += __shfl_xor(ay, off, 16);
-    az += __shfl_xor(az, off, 16);
+  for (int off = kRhsLanes / 2; off >= 1; off >>= 1) {
+    ax += __shfl_xor(ax, off, kRhsLanes);
+    ay += __shfl_xor(ay, off, kRhsLanes);
+    az += __shfl_xor(az, off, kRhsLanes);
   }
   f.x += ax;
   f.y += ay;
@@ -924,7 +930,7 @@ void launch_pd_local_tet(hipStream_t st, bool volume, const float4* pos, const u
 }
 void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd) {
   if (nd.n == 0) return;
-  hipLaunchKernelGGL(k_pd_rhs, dim3((nd.n + 15) / 16), dim3(kBlock), 0, st, pd.msn, pd.contrib, pd.incPtr, pd.incSlot, pd.contribD, pd.incPtrD,
+  hipLaunchKernelGGL(k_pd_rhs, dim3((nd.n + kBlock / kRhsLanes - 1) / (kBlock / kRhsLanes)), dim3(kBlock), 0, st, pd.msn, pd.contrib, pd.incPtr, pd.incSlot, pd.contribD, pd.incPtrD,
                      pd.incSlotD, nd.pos, pd.nstatic, pd.statp, pd.rhs, pd.cg.tIncCnt, pd.cg.tIncStart, pd.cg.tInc, pd.tContrib, nd.n);
 }
 void launch_pd_local_tet_pair(hipStream_t st, const float4* pos, const uint4* ids, const float4* q0, const float4* q1, const float4* q2,
