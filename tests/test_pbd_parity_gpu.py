@@ -361,6 +361,15 @@ def test_edit_after_tick_and_substeps(pies, oracle):
     _check(g, o)
 
 
+def test_scale_1m_layered_strips(pies, oracle):
+    """The 1M-particle lattice of bench.py's scale measurements (100^3: 5.8M tetrahedra, 6.9M distance constraints) under
+    schedule LAYERED with strips, two iterations, one tick: exact equality with the oracle replaying the exported order."""
+    g, o = _pair(pies, oracle, scenes.L1M, 2, pies.SCHEDULE_LAYERED, ticks=1)
+    lc = g.launch_counts()
+    assert lc["layer"] == 2 * 7 and lc["tet"] == 0, lc
+    _check(g, o)
+
+
 def test_config2_l100k_one_tick_layered(pies, oracle):
     """BASELINE config 2 at full size under schedule LAYERED (the one bench.py reports): exact equality."""
     g, o = _pair(pies, oracle, scenes.L100K, 20, pies.SCHEDULE_LAYERED, ticks=1)
