@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-#define PIES_ABI_VERSION 1
+/* 2: PIES_SCHEDULE_LAYERED, PIES_KERNEL_LAYER (pies_launch_counts now fills PIES_KERNEL_COUNT = 19 entries) */
+#define PIES_ABI_VERSION 2
 
 typedef struct pies_solver pies_solver_t;
 
