@@ -62,8 +62,11 @@ public:
   bool renderStateDirty = true;
   bool releaseHinge = false;
   // extensions (not in the reference): which device schedule maps the Gauss-Seidel sweeps, and whether the
-  // PBD node-node pass runs (the reference always runs it)
-  int schedule = PIES_SCHEDULE_EXACT;
+  // PBD node-node pass runs (the reference always runs it).  PIES_SCHEDULE_EXACT sweeps the containers in the order
+  // the constraints were added and the colliding nodes in ascending index - the reference's order, bit for bit the
+  // sequential loop; the default (PIES_SCHEDULE_DEFAULT = LAYERED) is the fast one bench.py reports, a sweep over the
+  // same constraints in another order (pies_hip.h; DESIGN.md section 3 states how far apart the results are).
+  int schedule = PIES_SCHEDULE_DEFAULT;
   bool nodeCollisions = true;       // PBD node-node pass (Solver.cpp:81-130)
   bool triangleCollisions = true;   // PD point-triangle contacts (Solver.cpp:693-797)
 
@@ -84,6 +87,8 @@ public:
       _vertices = std::move(rhs._vertices);
       _lines = std::move(rhs._lines);
       _triangles = std::move(rhs._triangles);
+      _frames[0] = rhs._frames[0];
+      _frames[1] = rhs._frames[1];
       renderStateDirty = rhs.renderStateDirty;
       releaseHinge = rhs.releaseHinge;
       schedule = rhs.schedule;
@@ -106,6 +111,30 @@ public:
     _ck(pies_set_schedule(_h, schedule));
     _ck(pies_tick(_h));
     _refreshPositions();
+  }
+  // tick() in two halves, so that a host can do its own work (or begin the next tick) while this one's positions travel:
+  // beginTick queues the substeps and the asynchronous copy of their result, endTick waits for that copy and refreshes
+  // getVertices().  At most two ticks may be begun before the first is ended (pies_tick_begin in pies_hip.h).
+  void beginTick() {
+    _ck(pies_set_flag(_h, PIES_FLAG_RELEASE_HINGE, releaseHinge ? 1 : 0));
+    _ck(pies_set_flag(_h, PIES_FLAG_NODE_COLLISIONS, nodeCollisions ? 1 : 0));
+    _ck(pies_set_flag(_h, PIES_FLAG_TRIANGLE_COLLISIONS, triangleCollisions ? 1 : 0));
+    _ck(pies_set_schedule(_h, schedule));
+    uint64_t f = 0;
+    _ck(pies_tick_begin(_h, &f));
+    if (_frames[0] == 0) _frames[0] = f; else _frames[1] = f;
+  }
+  void endTick() {
+    if (_frames[0] == 0) return;
+    const uint64_t f = _frames[0];
+    _frames[0] = _frames[1];
+    _frames[1] = 0;
+    const float* p = nullptr;
+    uint32_t n = 0;
+    _ck(pies_export_acquire(_h, f, &p, &n));
+    const size_t m = n < _vertices.size() ? n : _vertices.size();
+    for (size_t i = 0; i < m; ++i) _vertices[i].position = glm::vec3(p[4 * i], p[4 * i + 1], p[4 * i + 2]);
+    _ck(pies_export_release(_h, f));
   }
   void tickPBD(float dt) { tick(dt); }  // the solver kind is fixed by SolverOptions::solver
   void tickPD(float dt) { tick(dt); }
@@ -247,12 +276,12 @@ private:
     if (nt) _ck(pies_get_ids(_h, PIES_TRIANGLES, &_triangles[0].nodeIds[0], 3 * nt));
     renderStateDirty = true;
   }
+  // Solver.cpp:157,393: _vertices[i].position = node.position.  pies_tick has already brought the positions to the
+  // host (one pinned D2H copy per tick); this writes them straight into the vertex stream.
   void _refreshPositions() {
     const uint32_t n = static_cast<uint32_t>(_vertices.size());
     if (!n) return;
-    _scratch.resize(3 * size_t(n));
-    _ck(pies_read_nodes(_h, PIES_NODE_POSITION, _scratch.data(), n));
-    for (size_t i = 0; i < n; ++i) _vertices[i].position = glm::vec3(_scratch[3 * i], _scratch[3 * i + 1], _scratch[3 * i + 2]);
+    _ck(pies_read_positions_strided(_h, &_vertices[0].position, sizeof(Vertex), n));
   }
 
   pies_solver_t* _h = nullptr;
@@ -260,6 +289,6 @@ private:
   std::vector<Vertex> _vertices;
   std::vector<uint32_t> _lines;
   std::vector<Triangle> _triangles;
-  std::vector<float> _scratch;
+  uint64_t _frames[2] = {0, 0};  // ticks begun and not yet ended (beginTick / endTick)
 };
 }  // namespace Pies

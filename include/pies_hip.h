@@ -24,8 +24,10 @@
 extern "C" {
 #endif
 
-/* 2: PIES_SCHEDULE_LAYERED, PIES_KERNEL_LAYER (pies_launch_counts now fills PIES_KERNEL_COUNT = 19 entries) */
-#define PIES_ABI_VERSION 2
+/* 2: PIES_SCHEDULE_LAYERED, PIES_KERNEL_LAYER (pies_launch_counts now fills PIES_KERNEL_COUNT = 19 entries)
+ * 3: pies_tick_begin / pies_export_acquire / pies_export_release, pies_read_positions_strided, pies_get_pcg_health,
+ *    pies_set_pcg_retry, PIES_FLAG_REFERENCE_COLLISION_ORDER, pies_profile_in_situ; PIES_SCHEDULE_DEFAULT */
+#define PIES_ABI_VERSION 3
 
 typedef struct pies_solver pies_solver_t;
 
@@ -84,11 +86,24 @@ enum {
  *             for scenes without distance / tetrahedral / bend constraints and for squat bodies of fewer than
  *             300k nodes whose cross-sections do not fit one workgroup (measured slower there). */
 enum { PIES_SCHEDULE_EXACT = 0, PIES_SCHEDULE_COLOURED = 1, PIES_SCHEDULE_LAYERED = 2 };
+/* What pies_create and Pies::Solver start with: the schedule bench.py's headline figure is measured on.  Every schedule
+ * is a Gauss-Seidel sweep over the same constraints with the same per-constraint arithmetic; LAYERED and COLOURED
+ * visit them in another order than the host added them, EXACT in exactly that order (and then also runs the node-node
+ * pass in the reference's order, see PIES_FLAG_REFERENCE_COLLISION_ORDER).  bench.py reports how far the orders are
+ * apart (`order_deviation`) and the EXACT throughput beside the headline.  The environment variable
+ * PIES_SCHEDULE=exact|coloured|layered overrides the default at pies_create (not an explicit pies_set_schedule). */
+#define PIES_SCHEDULE_DEFAULT PIES_SCHEDULE_LAYERED
 
 enum {
   PIES_FLAG_RELEASE_HINGE = 0,  /* Solver::releaseHinge (Solver.h:52, Solver.cpp:59) */
   PIES_FLAG_NODE_COLLISIONS = 1,    /* extension, default 1: 0 skips the PBD node-node pass (Solver.cpp:81-130) */
-  PIES_FLAG_TRIANGLE_COLLISIONS = 2 /* extension, default 1: 0 skips the PD point-triangle contacts (Solver.cpp:693-797) */
+  PIES_FLAG_TRIANGLE_COLLISIONS = 2, /* extension, default 1: 0 skips the PD point-triangle contacts (Solver.cpp:693-797) */
+  /* PBD node-node pass (Solver.cpp:85-130).  1: the reference's loop -- nodes in ascending index, each querying the cell
+   * range of its *current* position, every overlapping pair resolved at once -- executed as one sequential chain on
+   * the device (bit-identical to the loop, slow).  0: the parallel visiting rule of DESIGN.md section 6 (same contact
+   * set and per-pair arithmetic, different order).  Default: 1 under PIES_SCHEDULE_EXACT, 0 otherwise; setting the
+   * flag overrides that until the schedule changes. */
+  PIES_FLAG_REFERENCE_COLLISION_ORDER = 3
 };
 
 /* node state selectors for pies_read_nodes / pies_write_nodes */
@@ -163,6 +178,16 @@ int pies_set_schedule(pies_solver_t* s, int schedule);
 int pies_set_pcg(pies_solver_t* s, float rel_tol, uint32_t max_iters);
 /* Over the last tick: largest ||r||/||rhs|| left by any solve, most CG iterations any solve used, solves run. */
 int pies_get_pcg_stats(pies_solver_t* s, float* max_rel_residual, uint32_t* max_iters_used, uint32_t* solves);
+/* The reference's global step is exact (Solver.cpp:356).  pies_tick therefore does not keep a substep in which a solve
+ * ended above rel_tol: the substep's input is restored and it runs again with four times the captured CG budget, up to
+ * max_iters (default on; 0 switches the re-run off).  pies_tick_async cannot look at a substep before the next one is
+ * queued; both paths count what was left above the tolerance:
+ *   short_solves      solves of kept substeps that ended above rel_tol since pies_finalize (0 = every solve met it),
+ *   solves_total      solves of kept substeps,
+ *   substeps_retried  substeps pies_tick ran again,
+ *   budget            CG iterations per solve in the captured graph right now. */
+int pies_set_pcg_retry(pies_solver_t* s, int enabled);
+int pies_get_pcg_health(pies_solver_t* s, uint64_t* short_solves, uint64_t* solves_total, uint32_t* substeps_retried, uint32_t* budget);
 /* Builds schedules, uploads to HBM and captures the substep graph.  Called implicitly by pies_tick
  * when the scene changed. */
 int pies_finalize(pies_solver_t* s);
@@ -173,7 +198,17 @@ int pies_finalize(pies_solver_t* s);
 int pies_tick(pies_solver_t* s);
 /* Same work, but neither the host copy-back nor a stream synchronisation: state stays in HBM. */
 int pies_tick_async(pies_solver_t* s);
+/* Waits for the queued ticks, then latches a device-side failure (pies_failed) and adapts the CG budget. */
 int pies_synchronize(pies_solver_t* s);
+/* Render-state export without a stall (Solver::getVertices, Solver.h:42-71; Solver.cpp:157,393 write _vertices every
+ * substep): pies_tick_begin queues one tick plus the copy of its final positions into one of two pinned host buffers
+ * (a copy stream moves frame k while the compute stream already runs frame k+1) and returns at once with the frame's
+ * id (1, 2, ...).  pies_export_acquire blocks until that frame's copy has landed and returns n x 4 floats
+ * (x, y, z, invMass); the pointer stays valid until pies_export_release or until two more frames have begun.  A
+ * third pies_tick_begin while the oldest frame is still acquired fails with PIES_ERR_STATE. */
+int pies_tick_begin(pies_solver_t* s, uint64_t* frame);
+int pies_export_acquire(pies_solver_t* s, uint64_t frame, const float** pos4, uint32_t* n);
+int pies_export_release(pies_solver_t* s, uint64_t frame);
 /* _simFailed latch (Solver.cpp:26-28,853-856) */
 int pies_failed(pies_solver_t* s, int* failed);
 /* Point-triangle contacts of the last PD substep (Solver::_triCollisions, Solver.h:187), in list order:
@@ -186,6 +221,9 @@ int pies_collision_pairs(pies_solver_t* s, uint64_t* pairs);
 int pies_count(const pies_solver_t* s, int what, uint32_t* out);
 /* out: n x 3 floats for POSITION/PREV_POSITION/VELOCITY, n floats for RADIUS/INV_MASS */
 int pies_read_nodes(pies_solver_t* s, int what, float* out, uint32_t n);
+/* Positions into a caller array with a byte stride (Solver::Vertex::position of a std::vector<Vertex>:
+ * `_vertices[i].position = node.position`, Solver.cpp:157,393).  After pies_tick this is a host-side copy. */
+int pies_read_positions_strided(pies_solver_t* s, void* dst, uint64_t stride_bytes, uint32_t n);
 int pies_write_nodes(pies_solver_t* s, int what, const float* in, uint32_t n);
 /* node ids of a container, flattened, in the order the host added them */
 int pies_get_ids(const pies_solver_t* s, int type, uint32_t* out, uint32_t capacity);
@@ -202,7 +240,8 @@ int pies_get_batches(pies_solver_t* s, int type, uint32_t* batch_offsets, uint32
 /* Times one kernel class in isolation: a graph holding only that class's launches of one substep is
  * replayed a few times back to back between two HIP events recorded on the solver's stream (the launches form
  * one dependent chain, so time / launches is the per-launch device time including the kernel boundary).  Returns the launches
- * timed, the total milliseconds and the units (constraints or nodes) processed.  Perturbs the state. */
+ * timed, the total milliseconds and the units (constraints or nodes) processed.  One class's working set is usually cache
+ * resident in such a replay: these are launch-latency figures, not bandwidth figures.  The node state is put back. */
 enum { PIES_KERNEL_PREDICT = 0, PIES_KERNEL_POSITION = 1, PIES_KERNEL_DISTANCE = 2, PIES_KERNEL_TET = 3,
        PIES_KERNEL_BEND = 4, PIES_KERNEL_FLOOR = 5, PIES_KERNEL_VELOCITY = 6, PIES_KERNEL_HASH = 7,
        PIES_KERNEL_COLLIDE = 8,
@@ -216,6 +255,13 @@ enum { PIES_KERNEL_PREDICT = 0, PIES_KERNEL_POSITION = 1, PIES_KERNEL_DISTANCE =
         * per-node steps the launches execute, SURVEY 8d figures) */
        PIES_KERNEL_LAYER = 18, PIES_KERNEL_COUNT = 19 };
 int pies_profile_substep(pies_solver_t* s, int kernel, uint32_t* launches, double* total_ms, uint64_t* units);
+/* Times one kernel class where it runs: `substeps` whole substeps are launched eagerly (every kernel of the substep
+ * runs, so the caches hold what the substep leaves in them) and each launch of the class is bracketed by two HIP events
+ * on the solver's stream.  launches = bracketed launches (for PIES_KERNEL_HASH / _COLLIDE one bracket is the whole grid
+ * build / resolve pass), total_ms = the sum of their event times, units as in pies_profile_substep.  For the CG classes
+ * (PD_SPMV, PD_CG_UPDATE) the solves of this pass do not take the converged early exit, so every bracketed launch does
+ * the full work.  The node state is put back afterwards. */
+int pies_profile_in_situ(pies_solver_t* s, int kernel, uint32_t substeps, uint32_t* launches, double* total_ms, uint64_t* units);
 /* launches per substep of the captured graph, per kernel class (PIES_KERNEL_COUNT entries) */
 int pies_launch_counts(pies_solver_t* s, uint32_t* out);
 

@@ -15,8 +15,9 @@ OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(5)
 PBD, PD = 0, 1
 POSITION, DISTANCE, TET, VOLUME, BEND, SHAPE, GOAL, TRIANGLES, LINES, NODES = range(10)
 SCHEDULE_EXACT, SCHEDULE_COLOURED, SCHEDULE_LAYERED = 0, 1, 2
+SCHEDULE_DEFAULT = SCHEDULE_LAYERED  # PIES_SCHEDULE_DEFAULT
 DEVICE_NONE = -1  # PIES_DEVICE_NONE: host-only handle (scenes and schedules, no compute)
-FLAG_RELEASE_HINGE, FLAG_NODE_COLLISIONS, FLAG_TRIANGLE_COLLISIONS = 0, 1, 2
+FLAG_RELEASE_HINGE, FLAG_NODE_COLLISIONS, FLAG_TRIANGLE_COLLISIONS, FLAG_REFERENCE_COLLISION_ORDER = 0, 1, 2, 3
 NODE_POSITION, NODE_PREV_POSITION, NODE_VELOCITY, NODE_RADIUS, NODE_INV_MASS = range(5)
 KERNEL_NAMES = ["predict", "position", "distance", "tet", "bend", "floor", "velocity", "hash", "collide",
                 "pd_predict", "pd_local_distance", "pd_local_tet", "pd_local_volume", "pd_rhs", "pd_spmv", "pd_cg_update",
@@ -37,7 +38,8 @@ SYMBOLS = [
     "pies_set_pcg", "pies_get_pcg_stats", "pies_collision_pairs", "pies_add_shape_constraint",
     "pies_add_goal_constraint", "pies_set_goal_transform", "pies_add_fixed_regions", "pies_update_fixed_regions",
     "pies_add_linked_regions", "pies_create_shape_matching_box", "pies_create_shape_matching_sheet", "pies_get_group",
-    "pies_get_tri_contacts",
+    "pies_get_tri_contacts", "pies_tick_begin", "pies_export_acquire", "pies_export_release",
+    "pies_read_positions_strided", "pies_set_pcg_retry", "pies_get_pcg_health", "pies_profile_in_situ",
 ]
 
 
@@ -117,6 +119,13 @@ def load():
         "pies_create_shape_matching_sheet": [vp, u32, u32, pf, f32, f32],
         "pies_get_group": [vp, i32, u32, pu, u32, pu],
         "pies_get_tri_contacts": [vp, pu, u32, pu],
+        "pies_tick_begin": [vp, C.POINTER(C.c_uint64)],
+        "pies_export_acquire": [vp, C.c_uint64, C.POINTER(pf), pu],
+        "pies_export_release": [vp, C.c_uint64],
+        "pies_read_positions_strided": [vp, vp, C.c_uint64, u32],
+        "pies_set_pcg_retry": [vp, i32],
+        "pies_get_pcg_health": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), pu, pu],
+        "pies_profile_in_situ": [vp, i32, u32, pu, C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -299,6 +308,15 @@ class Solver:
         self._ck(self._L.pies_get_pcg_stats(self._h, C.byref(r), C.byref(it), C.byref(n)))
         return r.value, it.value, n.value
 
+    def set_pcg_retry(self, enabled):
+        self._ck(self._L.pies_set_pcg_retry(self._h, int(enabled)))
+
+    def pcg_health(self):
+        """dict: short_solves / solves (kept substeps, since finalize), substeps_retried, budget (CG iterations captured)."""
+        a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32()
+        self._ck(self._L.pies_get_pcg_health(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(short_solves=a.value, solves=b.value, substeps_retried=c.value, budget=d.value)
+
     def finalize(self):
         self._ck(self._L.pies_finalize(self._h))
 
@@ -313,6 +331,30 @@ class Solver:
 
     def synchronize(self):
         self._ck(self._L.pies_synchronize(self._h))
+
+    def tick_begin(self):
+        """Queues one tick and the asynchronous export of its positions; returns the frame id."""
+        f = C.c_uint64()
+        self._ck(self._L.pies_tick_begin(self._h, C.byref(f)))
+        return f.value
+
+    def export_acquire(self, frame):
+        """Blocks until `frame` has landed in pinned host memory; returns an (n, 4) float32 view (x, y, z, invMass)
+        that is valid until export_release(frame)."""
+        p, n = C.POINTER(C.c_float)(), C.c_uint32()
+        self._ck(self._L.pies_export_acquire(self._h, frame, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return np.zeros((0, 4), np.float32)
+        return np.ctypeslib.as_array(p, shape=(n.value, 4))
+
+    def export_release(self, frame):
+        self._ck(self._L.pies_export_release(self._h, frame))
+
+    def read_positions_strided(self, stride_floats):
+        n = self.count(NODES)
+        out = np.zeros((n, stride_floats), dtype=np.float32)
+        self._ck(self._L.pies_read_positions_strided(self._h, out.ctypes.data_as(C.c_void_p), 4 * stride_floats, n))
+        return out
 
     @property
     def failed(self):
@@ -401,6 +443,13 @@ class Solver:
         out = np.zeros(KERNEL_COUNT, dtype=np.uint32)
         self._ck(self._L.pies_launch_counts(self._h, _pu(out)))
         return dict(zip(KERNEL_NAMES, out.tolist()))
+
+    def profile_in_situ(self, kernel, substeps=3):
+        """Whole substeps launched eagerly with HIP events around every launch of `kernel` (all other kernels run as
+        well, so caches are in the state the substep leaves them in); returns (launches, ms, units)."""
+        n, ms, units = C.c_uint32(), C.c_double(), C.c_uint64()
+        self._ck(self._L.pies_profile_in_situ(self._h, kernel, substeps, C.byref(n), C.byref(ms), C.byref(units)))
+        return n.value, ms.value, units.value
 
     def profile_substep(self, kernel):
         """One un-graphed substep with per-dispatch timing of `kernel`; returns (launches, ms, units)."""

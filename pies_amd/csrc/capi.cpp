@@ -52,6 +52,8 @@ static void free_device(pies_solver* s) {
   s->pd = PdArrays{};
   s->hash = HashArrays{};
   s->d_layer = LayerDevice{};
+  s->snapPos = s->snapPrev = s->snapVel = nullptr;
+  s->snapQuat = nullptr;
 }
 
 static int upload_nodes(pies_solver* s) {
@@ -76,27 +78,29 @@ static int upload_nodes(pies_solver* s) {
     HIP_TRY(s, hipStreamSynchronize(s->stream));  // the staging vectors die with this scope
   }
   s->hostNodesDirty = false;
-  s->deviceAhead = false;
+  s->stale = 0;
   return PIES_OK;
 }
 
-// Host mirror <- HBM (positions, previous positions, velocities).
-static int download_nodes(pies_solver* s) {
+// Host mirror <- HBM: the arrays of `mask` (bit 0 positions, 1 previous positions, 2 velocities) that are stale, one
+// copy each through the pinned staging buffer.
+static int download_nodes(pies_solver* s, uint32_t mask = 7u) {
   const uint32_t n = s->nd.n;
-  if (!s->deviceAhead || n == 0) { s->deviceAhead = false; return PIES_OK; }
-  std::vector<float4> buf(n);
+  mask &= s->stale;
+  if (n == 0 || !s->h_stage) { s->stale = 0; return PIES_OK; }
   float* dst[3] = {s->h_pos.data(), s->h_prev.data(), s->h_vel.data()};
   const float4* src[3] = {s->nd.pos, s->nd.prev, s->nd.vel};
   for (int a = 0; a < 3; ++a) {
-    HIP_TRY(s, hipMemcpyAsync(buf.data(), src[a], n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+    if (!(mask & (1u << a))) continue;
+    HIP_TRY(s, hipMemcpyAsync(s->h_stage, src[a], n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(s, hipStreamSynchronize(s->stream));
     for (uint32_t i = 0; i < n; ++i) {
-      dst[a][3 * i] = buf[i].x;
-      dst[a][3 * i + 1] = buf[i].y;
-      dst[a][3 * i + 2] = buf[i].z;
+      dst[a][3 * i] = s->h_stage[i].x;
+      dst[a][3 * i + 1] = s->h_stage[i].y;
+      dst[a][3 * i + 2] = s->h_stage[i].z;
     }
+    s->stale &= ~(1u << a);
   }
-  s->deviceAhead = false;
   return PIES_OK;
 }
 
@@ -211,6 +215,21 @@ static void build_layer_program(const pies_solver* s, std::vector<LayerItem>& pr
   }
 }
 
+// Solver.cpp:85-130 in the reference's order (schedule EXACT, the flag, or ranges wider than two cells) or in the
+// parallel visiting order of DESIGN.md section 6
+static void probe_mark(pies_solver* s, int k) {
+  if (s->probe && s->probe->kernel == k) s->probe->mark();
+}
+static bool reference_collision_order(const pies_solver* s) {
+  if (!s->collideFast) return true;
+  return s->collisionOrderFlag >= 0 ? s->collisionOrderFlag != 0 : s->schedule == PIES_SCHEDULE_EXACT;
+}
+static uint32_t enqueue_collide(pies_solver* s, bool rearm = false) {
+  if (reference_collision_order(s))
+    return launch_collide_reference(s->stream, s->hash, s->nd, s->opt.gridSpacing, s->opt.friction, s->opt.staticFrictionThreshold);
+  return launch_collide(s->stream, s->hash, s->nd, s->opt.friction, s->opt.staticFrictionThreshold, rearm);
+}
+
 static void enqueue_layered_substep(pies_solver* s, int only, uint32_t* counts, uint64_t* units) {
   hipStream_t st = s->stream;
   std::vector<LayerItem> prog;
@@ -227,35 +246,39 @@ static void enqueue_layered_substep(pies_solver* s, int only, uint32_t* counts, 
   D.bc_lid = d.bc_lid; D.bc_aw = s->d_bc_aw;
   const float dt = s->opt.fixedTimestepSize / s->opt.timeSubsteps;
   const LayerParams P = {s->opt.floorHeight, dt, s->opt.gravity, s->opt.damping, s->opt.friction};
-  auto ON = [&](int k) { return only < 0 || only == k; };
-  auto C = [&](int k) { if (counts) ++counts[k]; };
+  int cur = -1;  // class of the launch being made: with a probe attached only that class's units are tallied
+  auto ON = [&](int k) { const bool on = only < 0 || only == k; cur = k; if (on) probe_mark(s, k); return on; };
+  auto C = [&](int k) { probe_mark(s, k); if (counts) ++counts[k]; };
+  auto U = [&](uint64_t u) { if (units && (only >= 0 || (s->probe && s->probe->kernel == cur))) *units += u; };
   for (const LayerItem& item : prog) {
     switch (item.type) {
       case ITEM_COLLIDE: {  // Solver.cpp:81-130
-        uint32_t nb = 6, nc = 27;
-        if (ON(PIES_KERNEL_HASH)) { nb = launch_hash_build(st, s->hash, s->nd, s->opt.gridSpacing); if (units) *units += s->nd.n; }
-        if (ON(PIES_KERNEL_COLLIDE)) { nc = launch_collide(st, s->hash, s->nd, s->opt.friction, s->opt.staticFrictionThreshold); if (units) *units += s->nd.n; }
+        uint32_t nb = 33, nc = 1;
+        if (ON(PIES_KERNEL_HASH)) { nb = launch_hash_build(st, s->hash, s->nd, s->opt.gridSpacing); U(s->nd.n); }
+        probe_mark(s, PIES_KERNEL_HASH);
+        if (ON(PIES_KERNEL_COLLIDE)) { nc = enqueue_collide(s, only == PIES_KERNEL_COLLIDE); U(s->nd.n); }
+        probe_mark(s, PIES_KERNEL_COLLIDE);
         if (counts) { counts[PIES_KERNEL_HASH] += nb; counts[PIES_KERNEL_COLLIDE] += nc; }
         break;
       }
       case ITEM_LAYER:
-        if (ON(PIES_KERNEL_LAYER)) { launch_layer(st, s->nd, D, item.launch, P); if (units) *units += item.bytes; }
+        if (ON(PIES_KERNEL_LAYER)) { launch_layer(st, s->nd, D, item.launch, P); U(item.bytes); }
         C(PIES_KERNEL_LAYER);
         break;
       case ITEM_LPREDICT:
-        if (ON(PIES_KERNEL_PREDICT)) { launch_lpredict(st, s->nd, D, P); if (units) *units += s->nd.n; }
+        if (ON(PIES_KERNEL_PREDICT)) { launch_lpredict(st, s->nd, D, P); U(s->nd.n); }
         C(PIES_KERNEL_PREDICT);
         break;
       case ITEM_LVELOCITY:
-        if (ON(PIES_KERNEL_VELOCITY)) { launch_lvelocity(st, s->nd, D, P); if (units) *units += s->nd.n; }
+        if (ON(PIES_KERNEL_VELOCITY)) { launch_lvelocity(st, s->nd, D, P); U(s->nd.n); }
         C(PIES_KERNEL_VELOCITY);
         break;
       case ITEM_LFLOOR:
-        if (ON(PIES_KERNEL_FLOOR)) { launch_lfloor(st, s->nd, D, P); if (units) *units += s->nd.n; }
+        if (ON(PIES_KERNEL_FLOOR)) { launch_lfloor(st, s->nd, D, P); U(s->nd.n); }
         C(PIES_KERNEL_FLOOR);
         break;
       case ITEM_LPOSITION:
-        if (ON(PIES_KERNEL_POSITION)) { launch_lposition(st, D, item.batch.start, item.batch.count); if (units) *units += item.batch.count; }
+        if (ON(PIES_KERNEL_POSITION)) { launch_lposition(st, D, item.batch.start, item.batch.count); U(item.batch.count); }
         C(PIES_KERNEL_POSITION);
         break;
       case ITEM_TO_NODES:
@@ -271,9 +294,10 @@ static void enqueue_layered_substep(pies_solver* s, int only, uint32_t* counts, 
 static void enqueue_pbd_substep(pies_solver* s, int only, uint32_t* counts, uint64_t* units = nullptr) {
   hipStream_t st = s->stream;
   const float dt = s->opt.fixedTimestepSize / s->opt.timeSubsteps;
-  auto C = [&](int k) { if (counts) ++counts[k]; };
-  auto ON = [&](int k) { return only < 0 || only == k; };  // profile pass: launch one kernel class only
-  auto U = [&](uint64_t u) { if (units) *units += u; };
+  int cur = -1;
+  auto C = [&](int k) { probe_mark(s, k); if (counts) ++counts[k]; };
+  auto ON = [&](int k) { const bool on = only < 0 || only == k; cur = k; if (on) probe_mark(s, k); return on; };  // profile pass: one kernel class only
+  auto U = [&](uint64_t u) { if (units && (only >= 0 || (s->probe && s->probe->kernel == cur))) *units += u; };
 
   if (s->layer.active) { enqueue_layered_substep(s, only, counts, units); return; }
   if (ON(PIES_KERNEL_PREDICT)) { launch_predict(st, s->nd, dt, s->opt.gravity); U(s->nd.n); }
@@ -282,9 +306,11 @@ static void enqueue_pbd_substep(pies_solver* s, int only, uint32_t* counts, uint
     const WaveData W = {s->d_pc_id, s->d_pc_tw, s->d_dc_ids, s->d_dc_rw, s->d_tc_ids, s->d_tc_q0, s->d_tc_q1, s->d_tc_q2, s->d_bc_ids, s->d_bc_aw};
     size_t barrier = 0;
     auto collide = [&] {
-      uint32_t nb = 6, nc = 27;
+      uint32_t nb = 33, nc = 1;
       if (ON(PIES_KERNEL_HASH)) { nb = launch_hash_build(st, s->hash, s->nd, s->opt.gridSpacing); U(s->nd.n); }
-      if (ON(PIES_KERNEL_COLLIDE)) { nc = launch_collide(st, s->hash, s->nd, s->opt.friction, s->opt.staticFrictionThreshold); U(s->nd.n); }
+      probe_mark(s, PIES_KERNEL_HASH);
+      if (ON(PIES_KERNEL_COLLIDE)) { nc = enqueue_collide(s, only == PIES_KERNEL_COLLIDE); U(s->nd.n); }
+      probe_mark(s, PIES_KERNEL_COLLIDE);
       if (counts) { counts[PIES_KERNEL_HASH] += nb; counts[PIES_KERNEL_COLLIDE] += nc; }
     };
     for (size_t l = 0; l < s->wave.levels.size(); ++l) {
@@ -317,9 +343,11 @@ static void enqueue_pbd_substep(pies_solver* s, int only, uint32_t* counts, uint
       C(PIES_KERNEL_BEND);
     }
     if (s->nodeCollisions) {  // Solver.cpp:81-130
-      uint32_t nb = 6, nc = 27;
+      uint32_t nb = 33, nc = 1;
       if (ON(PIES_KERNEL_HASH)) { nb = launch_hash_build(st, s->hash, s->nd, s->opt.gridSpacing); U(s->nd.n); }
-      if (ON(PIES_KERNEL_COLLIDE)) { nc = launch_collide(st, s->hash, s->nd, s->opt.friction, s->opt.staticFrictionThreshold); U(s->nd.n); }
+      probe_mark(s, PIES_KERNEL_HASH);
+      if (ON(PIES_KERNEL_COLLIDE)) { nc = enqueue_collide(s, only == PIES_KERNEL_COLLIDE); U(s->nd.n); }
+      probe_mark(s, PIES_KERNEL_COLLIDE);
       if (counts) { counts[PIES_KERNEL_HASH] += nb; counts[PIES_KERNEL_COLLIDE] += nc; }
     }
     if (ON(PIES_KERNEL_FLOOR)) { launch_floor(st, s->nd, s->opt.floorHeight); U(s->nd.n); }
@@ -335,9 +363,10 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
   hipStream_t st = s->stream;
   const float h = s->opt.fixedTimestepSize / s->opt.timeSubsteps;
   const PdArrays& pd = s->pd;
-  auto ON = [&](int k) { return only < 0 || only == k; };
-  auto C = [&](int k, uint32_t n = 1) { if (counts) counts[k] += n; };
-  auto U = [&](uint64_t u) { if (units && only >= 0) *units += u; };
+  int cur = -1;
+  auto ON = [&](int k) { const bool on = only < 0 || only == k; cur = k; if (on) probe_mark(s, k); return on; };
+  auto C = [&](int k, uint32_t n = 1) { if (k != PIES_KERNEL_PD_SPMV && k != PIES_KERNEL_PD_CG_UPDATE) probe_mark(s, k); if (counts) counts[k] += n; };
+  auto U = [&](uint64_t u) { if (units && (only >= 0 || (s->probe && s->probe->kernel == cur))) *units += u; };
   const uint32_t nDist = (uint32_t)s->h_distance.size(), nTet = (uint32_t)s->h_tet.size(), nVol = (uint32_t)s->h_volume.size();
   if (ON(PIES_KERNEL_PD_PREDICT)) { launch_pd_predict(st, s->nd, pd, h, s->opt.floorHeight + s->opt.collisionThickness); U(s->nd.n); }
   C(PIES_KERNEL_PD_PREDICT);
@@ -346,7 +375,7 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
     launch_tri_detect(st, pd.tri, s->nd, pd.kdiag, pd.cg.cdiag, pd.cg.dinv, s->opt.collisionThresholdDistance, s->opt.collisionThickness);
   for (uint32_t it = 0; it < s->opt.iterations; ++it) {
     // local step (Solver.cpp:270-308): position constraints project to a constant, uploaded once
-    if (ON(PIES_KERNEL_PD_LOCAL_DISTANCE) && nDist) {
+    if (nDist && ON(PIES_KERNEL_PD_LOCAL_DISTANCE)) {
       launch_pd_local_distance(st, s->nd.pos, s->d_dc_ids, s->d_dc_rw, pd.contrib + s->slotBase[PIES_DISTANCE], nDist);
       U(nDist);
     }
@@ -359,12 +388,12 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
       }
       C(PIES_KERNEL_PD_LOCAL_TET);
     } else {
-    if (ON(PIES_KERNEL_PD_LOCAL_TET) && nTet) {
+    if (nTet && ON(PIES_KERNEL_PD_LOCAL_TET)) {
       launch_pd_local_tet(st, false, s->nd.pos, s->d_tc_ids, s->d_tc_q0, s->d_tc_q1, s->d_tc_q2, pd.contrib + s->slotBase[PIES_TET], nTet);
       U(nTet);
     }
     if (nTet) C(PIES_KERNEL_PD_LOCAL_TET);
-    if (ON(PIES_KERNEL_PD_LOCAL_VOLUME) && nVol) {
+    if (nVol && ON(PIES_KERNEL_PD_LOCAL_VOLUME)) {
       launch_pd_local_tet(st, true, s->nd.pos, s->d_vc_ids, s->d_vc_q0, s->d_vc_q1, s->d_vc_q2, pd.contrib + s->slotBase[PIES_VOLUME], nVol);
       U(nVol);
     }
@@ -377,7 +406,13 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
     }
     if (ON(PIES_KERNEL_PD_RHS)) { launch_pd_rhs(st, s->nd, pd); U(s->nd.n); }    // Solver.cpp:266, 310-349
     C(PIES_KERNEL_PD_RHS);
-    if (only < 0) launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, s->pcgTol, -1, it == 0, it + 1 == s->opt.iterations);  // Solver.cpp:356-364
+    if (only < 0) {  // Solver.cpp:356-364
+      const bool probed = s->probe && (s->probe->kernel == PIES_KERNEL_PD_SPMV || s->probe->kernel == PIES_KERNEL_PD_CG_UPDATE);
+      // a probed solve never takes the converged early exit: every bracketed launch does a full SpMV / vector update
+      launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, s->pcgTol, -1, it == 0, it + 1 == s->opt.iterations, probed,
+                      probed ? [](void* ctx, int cls) { probe_mark(static_cast<pies_solver*>(ctx), cls); } : (void (*)(void*, int))nullptr, s);
+      if (probed && units) *units += (uint64_t)s->nd.n * s->pcgBudget;
+    }
     else if (only == PIES_KERNEL_PD_SPMV) { launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, 0.f, 1); U((uint64_t)s->nd.n * s->pcgBudget); }
     else if (only == PIES_KERNEL_PD_CG_UPDATE) { launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, 0.f, 0); U((uint64_t)s->nd.n * s->pcgBudget); }
     C(PIES_KERNEL_PD_SPMV, s->pcgBudget);
@@ -502,7 +537,9 @@ static int poll_failure(pies_solver* s) {
                : flag & 16 ? "more than 1000 triangles in one grid cell (the reference's safety latch, Solver.cpp:751-755)"
                : flag & 32 ? "a triangle's swept bounding box is non-finite or spans more than 4 grid cells per axis"
                : flag & 64 ? "point-triangle contact list overflow"
-                          : "a node left the supported cell range (non-finite position or range > 2 cells)";
+               : flag & 8  ? "node-node collision pass: the wait for a neighbouring group timed out (PIES_COLLIDE_SPIN_LIMIT)"
+               : flag & 128 ? "node-node collision grid: more cell entries than the build reserves (64 per node)"
+                          : "a node left the supported cell range (non-finite position)";
   }
   return PIES_OK;
 }
@@ -552,6 +589,11 @@ int pies_create(const pies_options_t* options, int device, pies_solver_t** out) 
   if (options) s->opt = *options; else pies_default_options(&s->opt);
   if (s->opt.timeSubsteps == 0) s->opt.timeSubsteps = 1;
   s->device = device;
+  if (const char* e = std::getenv("PIES_SCHEDULE")) {  // overrides PIES_SCHEDULE_DEFAULT, not an explicit pies_set_schedule
+    if (!std::strcmp(e, "exact")) s->schedule = PIES_SCHEDULE_EXACT;
+    else if (!std::strcmp(e, "coloured")) s->schedule = PIES_SCHEDULE_COLOURED;
+    else if (!std::strcmp(e, "layered")) s->schedule = PIES_SCHEDULE_LAYERED;
+  }
   if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
     delete s;
     return PIES_ERR_HIP;
@@ -565,8 +607,16 @@ int pies_destroy(pies_solver_t* s) {
   if (s->device == PIES_DEVICE_NONE) { delete s; return PIES_OK; }
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
+  if (s->copyStream) (void)hipStreamSynchronize(s->copyStream);
   free_device(s);
   if (s->h_stage) (void)hipHostFree(s->h_stage);
+  for (int b = 0; b < 2; ++b) {
+    if (s->h_export[b]) (void)hipHostFree(s->h_export[b]);
+    if (s->evTick[b]) (void)hipEventDestroy(s->evTick[b]);
+    if (s->evCopied[b]) (void)hipEventDestroy(s->evCopied[b]);
+  }
+  if (s->d_export) (void)hipFree(s->d_export);
+  if (s->copyStream) (void)hipStreamDestroy(s->copyStream);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
   return PIES_OK;
@@ -586,7 +636,7 @@ int pies_clear(pies_solver_t* s) {
   for (Plan& p : s->plan) { p.order.clear(); p.batches.clear(); }
   s->constraintId = 0;
   s->sceneDirty = true;
-  s->deviceAhead = false;
+  s->stale = 0;
   s->hostNodesDirty = false;
   return PIES_OK;  // like the reference, the failure latch is not reset (Solver.cpp:488-507)
 }
@@ -601,6 +651,14 @@ int pies_get_options(const pies_solver_t* s, pies_options_t* out) {
 
 int pies_set_flag(pies_solver_t* s, int flag, int value) {
   if (!s) return PIES_ERR_INVALID;
+  if (flag == PIES_FLAG_REFERENCE_COLLISION_ORDER) {
+    const int v = value != 0 ? 1 : 0;
+    if (s->collisionOrderFlag != v) {
+      s->collisionOrderFlag = v;
+      if (!s->sceneDirty) s->graphDirty = true;  // same buffers, another resolve kernel in the captured substep
+    }
+    return PIES_OK;
+  }
   bool* target = flag == PIES_FLAG_RELEASE_HINGE       ? &s->releaseHinge
                  : flag == PIES_FLAG_NODE_COLLISIONS   ? &s->nodeCollisions
                  : flag == PIES_FLAG_TRIANGLE_COLLISIONS ? &s->triangleCollisions
@@ -608,8 +666,15 @@ int pies_set_flag(pies_solver_t* s, int flag, int value) {
   if (!target) return fail(s, PIES_ERR_INVALID, "pies_set_flag: unknown flag");
   if (*target != (value != 0)) {
     *target = value != 0;
-    if (int rc = scene_sync_host(s)) return rc;
-    s->sceneDirty = true;  // the launch sequence changes: re-capture
+    // releaseHinge only drops the position-constraint launches (Solver.cpp:59): with per-container batches (COLOURED,
+    // LAYERED, PD) the plans and buffers stay valid and the substep is captured again; schedule EXACT bakes the
+    // position constraints into its dependency levels, and the collision flags decide which buffers exist
+    const bool captureOnly = flag == PIES_FLAG_RELEASE_HINGE && !s->sceneDirty && (s->opt.solver == PIES_SOLVER_PD || !s->wave.active);
+    if (captureOnly) s->graphDirty = true;
+    else {
+      if (int rc = scene_sync_host(s)) return rc;
+      s->sceneDirty = true;
+    }
   }
   return PIES_OK;
 }
@@ -620,6 +685,7 @@ int pies_set_schedule(pies_solver_t* s, int schedule) {
   if (schedule != s->schedule) {
     if (int rc = scene_sync_host(s)) return rc;
     s->schedule = schedule;
+    s->collisionOrderFlag = -1;  // the node-node order follows the schedule again
     s->sceneDirty = true;
   }
   return PIES_OK;
@@ -628,18 +694,23 @@ int pies_set_schedule(pies_solver_t* s, int schedule) {
 int pies_set_pcg(pies_solver_t* s, float rel_tol, uint32_t max_iters) {
   if (!s || !(rel_tol >= 0.0f) || max_iters == 0 || max_iters > 4096) return fail(s, PIES_ERR_INVALID, "pies_set_pcg: bad argument");
   if (rel_tol != s->pcgTol || max_iters != s->pcgMaxIters) {
-    if (int rc = scene_sync_host(s)) return rc;
     s->pcgTol = rel_tol;
     s->pcgMaxIters = max_iters;
     s->pcgBudget = std::min(max_iters, 32u);
-    s->sceneDirty = true;  // the captured launch sequence changes
+    s->graphDirty = true;  // the captured launch sequence changes, nothing else
   }
+  return PIES_OK;
+}
+
+int pies_set_pcg_retry(pies_solver_t* s, int enabled) {
+  if (!s) return PIES_ERR_INVALID;
+  s->pcgRetry = enabled != 0;
   return PIES_OK;
 }
 
 int pies_get_pcg_stats(pies_solver_t* s, float* max_rel_residual, uint32_t* max_iters_used, uint32_t* solves) {
   if (!s) return PIES_ERR_INVALID;
-  float st[4] = {0, 0, 0, 0};
+  float st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (s->opt.solver == PIES_SOLVER_PD && s->pd.cg.stats) {
     HIP_TRY(s, hipSetDevice(s->device));
     HIP_TRY(s, hipMemcpyAsync(st, s->pd.cg.stats, sizeof(st), hipMemcpyDeviceToHost, s->stream));
@@ -648,6 +719,23 @@ int pies_get_pcg_stats(pies_solver_t* s, float* max_rel_residual, uint32_t* max_
   if (max_rel_residual) *max_rel_residual = std::sqrt(st[0]);
   if (max_iters_used) *max_iters_used = static_cast<uint32_t>(st[1]);
   if (solves) *solves = static_cast<uint32_t>(st[2]);
+  return PIES_OK;
+}
+
+int pies_get_pcg_health(pies_solver_t* s, uint64_t* short_solves, uint64_t* solves_total, uint32_t* substeps_retried, uint32_t* budget) {
+  if (!s) return PIES_ERR_INVALID;
+  float st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (s->opt.solver == PIES_SOLVER_PD && s->pd.cg.stats) {
+    HIP_TRY(s, hipSetDevice(s->device));
+    HIP_TRY(s, hipMemcpyAsync(st, s->pd.cg.stats, sizeof(st), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+  }
+  // stats[4], [5]: solves left above the tolerance / solves run by the substeps whose result was kept (a substep
+  // that pies_tick ran again takes its counts back), since the buffers were built
+  if (short_solves) *short_solves = static_cast<uint64_t>(st[4]);
+  if (solves_total) *solves_total = static_cast<uint64_t>(st[5]);
+  if (substeps_retried) *substeps_retried = s->pcgRetries;
+  if (budget) *budget = s->pcgBudget;
   return PIES_OK;
 }
 
@@ -696,13 +784,13 @@ int pies_finalize(pies_solver_t* s) {
   }
   const bool isPD = s->opt.solver == PIES_SOLVER_PD;
   const bool collide = s->nodeCollisions && !isPD;
+  s->collideFast = true;
   if (collide && !s->h_radius.empty()) {
-    // NodeCompRange (Solver.cpp:877-901) spans ceil(fract + 2R) cells per axis with R = (r + 0.5)/gridSpacing;
-    // the device passes assume at most 2, i.e. 2R <= 1 (true for the reference defaults r = 0.5, spacing 2).
+    // NodeCompRange (Solver.cpp:877-901) spans ceil(fract + 2R) cells per axis with R = (r + 0.5)/gridSpacing.  The parallel
+    // visiting order needs at most 2, i.e. 2R <= 1 (true for the reference defaults r = 0.5, spacing 2); other scenes run
+    // the pass in the reference's own order (one sequential chain, any range up to the reference's 50 cells per axis).
     const float rmax = *std::max_element(s->h_radius.begin(), s->h_radius.end());
-    if (!(2.0f * ((rmax + 0.5f) / s->opt.gridSpacing) <= 1.0f))
-      return fail(s, PIES_ERR_UNSUPPORTED,
-                  "node-node collisions need gridSpacing >= 2*(max radius + 0.5) in this build (a node may span at most 2 cells per axis)");
+    s->collideFast = 2.0f * ((rmax + 0.5f) / s->opt.gridSpacing) <= 1.0f;
   }
   if (int rc = download_nodes(s)) return rc;
   HIP_TRY(s, hipStreamSynchronize(s->stream));
@@ -828,28 +916,40 @@ int pies_finalize(pies_solver_t* s) {
   if (collide && n) {
     HashArrays& H = s->hash;
     H.n = n;
+    // (cell, node) entries: NodeCompRange spans ceil(fract + 2R) <= 1 + ceil(2R) cells per axis (an over-long range is empty,
+    // Solver.cpp:896-898), which only depends on the radius: the sum is an upper bound for any positions.  8 per node for
+    // the reference's defaults.
+    uint64_t entries = 0;
+    for (float r : s->h_radius) {
+      const float twoR = 2.0f * ((r + 0.5f) / s->opt.gridSpacing);
+      const uint64_t len = std::isfinite(twoR) && twoR >= 0.0f && twoR < 64.0f ? std::min<uint64_t>(50, 1 + static_cast<uint64_t>(std::ceil(twoR))) : 0;
+      entries += len * len * len;
+    }
+    if (entries > 0x7fff0000ull) return fail(s, PIES_ERR_UNSUPPORTED, "node-node collisions: more than 2^31 (cell, node) entries (gridSpacing is tiny against the radii)");
+    H.maxEntries = static_cast<uint32_t>(entries + 64);
     uint32_t cap = 1024;
-    while (cap < 16ull * n && cap < (1u << 30)) cap <<= 1;  // distinct cells <= 8n: load factor <= 0.5
+    const uint64_t want = s->collideFast ? 16ull * n : 2ull * H.maxEntries;  // distinct cells <= 8n resp. <= entries: load factor <= 0.5
+    while (cap < want && cap < (1u << 30)) cap <<= 1;
     H.capacity = cap;
     H.mask = cap - 1;
+    if (int rc = dev_alloc(s, n, &H.rng, true)) return rc;
+    if (int rc = dev_alloc(s, n + 1ull, &H.entCount, true)) return rc;
+    if (int rc = dev_alloc(s, n + 1ull, &H.entOff, true)) return rc;
+    if (int rc = dev_alloc(s, (n + 1ull) / 2048 + 2, &H.scanSums, true)) return rc;
+    for (int b = 0; b < 2; ++b) {
+      if (int rc = dev_alloc(s, H.maxEntries, &H.key[b], true)) return rc;
+      if (int rc = dev_alloc(s, H.maxEntries, &H.val[b], true)) return rc;
+    }
+    if (int rc = dev_alloc(s, 256ull * ((H.maxEntries + kRadixTile - 1) / kRadixTile), &H.hist, true)) return rc;
     if (int rc = dev_alloc(s, cap, &H.keys)) return rc;
     HIP_TRY(s, hipMemsetAsync(H.keys, 0xFF, static_cast<size_t>(cap) * sizeof(uint64_t), s->stream));
-    if (int rc = dev_alloc(s, cap, &H.cnt, true)) return rc;
     if (int rc = dev_alloc(s, cap, &H.start, true)) return rc;
-    if (int rc = dev_alloc(s, cap, &H.fill, true)) return rc;
+    if (int rc = dev_alloc(s, cap, &H.end, true)) return rc;
     if (int rc = dev_alloc(s, cap, &H.gcnt, true)) return rc;
-    if (int rc = dev_alloc(s, cap, &H.gstart, true)) return rc;
-    if (int rc = dev_alloc(s, cap, &H.gfill, true)) return rc;
-    if (int rc = dev_alloc(s, 8ull * n, &H.used, true)) return rc;
-    if (int rc = dev_alloc(s, kHashCounters, &H.counters, true)) return rc;
     if (int rc = dev_alloc(s, cap, &H.done, true)) return rc;
+    if (int rc = dev_alloc(s, std::min<uint64_t>(cap, H.maxEntries), &H.used, true)) return rc;
+    if (int rc = dev_alloc(s, kHashCounters, &H.counters, true)) return rc;
     if (int rc = dev_alloc(s, 27ull * n, &H.passList, true)) return rc;
-    if (int rc = dev_alloc(s, 8ull * n, &H.nodeSlot, true)) return rc;
-    if (int rc = dev_alloc(s, n, &H.rng, true)) return rc;
-    if (int rc = dev_alloc(s, 8ull * n, &H.bucket, true)) return rc;
-    if (int rc = dev_alloc(s, 8ull * n, &H.bucketSorted, true)) return rc;
-    if (int rc = dev_alloc(s, n, &H.group, true)) return rc;
-    if (int rc = dev_alloc(s, n, &H.groupSorted, true)) return rc;
     HIP_TRY(s, hipStreamSynchronize(s->stream));
   }
   if (isPD) {
@@ -874,9 +974,40 @@ int pies_finalize(pies_solver_t* s) {
     }
     if (const char* e = std::getenv("PIES_NO_TET_PAIRS"); e && e[0] == '1') s->tetVolumePaired = false;
     if (int rc = pd_build(s)) return rc;
+    if (n) {  // input of a substep, kept until its solves are known to have met the tolerance (pd_tick_checked)
+      if (int rc = dev_alloc(s, n, &s->snapPos)) return rc;
+      if (int rc = dev_alloc(s, n, &s->snapPrev)) return rc;
+      if (int rc = dev_alloc(s, n, &s->snapVel)) return rc;
+      if (s->pd.shape.count)
+        if (int rc = dev_alloc(s, 4ull * s->pd.shape.count, &s->snapQuat)) return rc;
+    }
   }
   if (int rc = capture_graph(s)) return rc;
   s->sceneDirty = false;
+  s->graphDirty = false;
+  return PIES_OK;
+}
+
+// Brings HBM and the captured graph up to date with the host-side scene.
+static int ensure_ready(pies_solver* s) {
+  if (s->sceneDirty || s->hostNodesDirty)
+    if (int rc = pies_finalize(s)) return rc;
+  HIP_TRY(s, hipSetDevice(s->device));
+  if (s->graphDirty) {
+    HIP_TRY(s, hipStreamSynchronize(s->stream));  // the old graph may still be running
+    if (int rc = capture_graph(s)) return rc;
+    s->graphDirty = false;
+  }
+  return PIES_OK;
+}
+
+static int launch_substep(pies_solver* s) {
+  if (s->graphExec) {
+    HIP_TRY(s, hipGraphLaunch(s->graphExec, s->stream));
+  } else {  // PIES_NO_GRAPH=1: eager launches (debug / tracing)
+    enqueue_substep(s, nullptr);
+    HIP_TRY(s, hipGetLastError());
+  }
   return PIES_OK;
 }
 
@@ -884,21 +1015,17 @@ int pies_tick_async(pies_solver_t* s) {
   if (!s) return PIES_ERR_INVALID;
   if (s->device == PIES_DEVICE_NONE) return fail(s, PIES_ERR_HIP, "host-only handle (PIES_DEVICE_NONE): there is no CPU solver");
   if (s->simFailed) return PIES_OK;  // Solver.cpp:26-28
-  if (s->sceneDirty || s->hostNodesDirty)
-    if (int rc = pies_finalize(s)) return rc;
-  HIP_TRY(s, hipSetDevice(s->device));
+  if (int rc = ensure_ready(s)) return rc;
   if (s->nd.n == 0) return PIES_OK;
   if (s->opt.solver == PIES_SOLVER_PD) {
     if (s->goalDirty)
       if (int rc = pd_upload_goals(s)) return rc;
     HIP_TRY(s, hipMemsetAsync(s->pd.cg.stats, 0, 4 * sizeof(float), s->stream));
   }
-  for (uint32_t sub = 0; sub < s->opt.timeSubsteps; ++sub) {
-    if (s->graphExec) HIP_TRY(s, hipGraphLaunch(s->graphExec, s->stream));
-    else enqueue_substep(s, nullptr);  // PIES_NO_GRAPH=1: eager launches (debug / tracing)
-  }
+  for (uint32_t sub = 0; sub < s->opt.timeSubsteps; ++sub)
+    if (int rc = launch_substep(s)) return rc;
   if (under_profiler()) HIP_TRY(s, hipStreamSynchronize(s->stream));
-  s->deviceAhead = true;
+  s->stale = 7u;
   return PIES_OK;
 }
 
@@ -907,25 +1034,156 @@ int pies_synchronize(pies_solver_t* s) {
   if (s->device == PIES_DEVICE_NONE) return PIES_OK;
   HIP_TRY(s, hipSetDevice(s->device));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
+  if (int rc = poll_failure(s)) return rc;  // a loop of pies_tick_async learns here that the simulation failed
   return adapt_pcg_budget(s);
+}
+
+// Projective Dynamics, synchronous tick: the reference's global step is a direct solve (Solver.cpp:258-262, 356), the
+// device's a CG with a captured iteration budget.  A substep in which a solve ends above the tolerance (new contacts
+// stiffen the system from one substep to the next) is therefore not kept: the node state is put back and the substep
+// runs again with four times the budget, up to the ceiling of pies_set_pcg.
+static int pd_tick_checked(pies_solver* s) {
+  const uint32_t n = s->nd.n;
+  float before[8], after[8];
+  HIP_TRY(s, hipMemsetAsync(s->pd.cg.stats, 0, 4 * sizeof(float), s->stream));
+  for (uint32_t sub = 0; sub < s->opt.timeSubsteps; ++sub) {
+    HIP_TRY(s, hipMemcpyAsync(before, s->pd.cg.stats, sizeof(before), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(s, hipMemcpyAsync(s->snapPos, s->nd.pos, n * sizeof(float4), hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(s, hipMemcpyAsync(s->snapPrev, s->nd.prev, n * sizeof(float4), hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(s, hipMemcpyAsync(s->snapVel, s->nd.vel, n * sizeof(float4), hipMemcpyDeviceToDevice, s->stream));
+    if (s->snapQuat)
+      HIP_TRY(s, hipMemcpyAsync(s->snapQuat, s->pd.shape.quat, 4ull * s->pd.shape.count * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    for (;;) {
+      if (int rc = launch_substep(s)) return rc;
+      HIP_TRY(s, hipMemcpyAsync(after, s->pd.cg.stats, sizeof(after), hipMemcpyDeviceToHost, s->stream));
+      HIP_TRY(s, hipStreamSynchronize(s->stream));
+      const bool ranShort = after[3] > before[3];
+      if (!ranShort || s->pcgBudget >= s->pcgMaxIters) {
+        if (ranShort) s->pcgShortSolves += static_cast<uint64_t>(after[3] - before[3]);
+        break;
+      }
+      // put the substep's input back (the statistics too: the attempt does not count) and capture a larger budget
+      HIP_TRY(s, hipMemcpyAsync(s->nd.pos, s->snapPos, n * sizeof(float4), hipMemcpyDeviceToDevice, s->stream));
+      HIP_TRY(s, hipMemcpyAsync(s->nd.prev, s->snapPrev, n * sizeof(float4), hipMemcpyDeviceToDevice, s->stream));
+      HIP_TRY(s, hipMemcpyAsync(s->nd.vel, s->snapVel, n * sizeof(float4), hipMemcpyDeviceToDevice, s->stream));
+      if (s->snapQuat)
+        HIP_TRY(s, hipMemcpyAsync(s->pd.shape.quat, s->snapQuat, 4ull * s->pd.shape.count * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+      HIP_TRY(s, hipMemcpyAsync(s->pd.cg.stats, before, sizeof(before), hipMemcpyHostToDevice, s->stream));
+      HIP_TRY(s, hipStreamSynchronize(s->stream));
+      s->pcgBudget = std::min(s->pcgMaxIters, std::max(32u, 4u * s->pcgBudget));
+      s->pcgCalm = 0;
+      s->pcgWindowMax = 0;
+      s->pcgCooldown = 60;
+      ++s->pcgRetries;
+      if (const char* e = std::getenv("PIES_PCG_DEBUG"); e && e[0] == '1')
+        std::fprintf(stderr, "[pies] pcg: substep ran short (residual^2 %.3g): again with budget %u\n", after[0], s->pcgBudget);
+      if (int rc = capture_graph(s)) return rc;
+    }
+  }
+  return PIES_OK;
 }
 
 int pies_tick(pies_solver_t* s) {
   if (!s) return PIES_ERR_INVALID;
   if (s->simFailed) return PIES_OK;
-  if (int rc = pies_tick_async(s)) return rc;
+  if (s->opt.solver == PIES_SOLVER_PD && s->pcgRetry && s->device != PIES_DEVICE_NONE && !under_profiler()) {
+    if (int rc = ensure_ready(s)) return rc;
+    if (s->nd.n == 0) return PIES_OK;
+    if (s->goalDirty)
+      if (int rc = pd_upload_goals(s)) return rc;
+    if (int rc = pd_tick_checked(s)) return rc;
+    s->stale = 7u;
+  } else {
+    if (int rc = pies_tick_async(s)) return rc;
+  }
   const uint32_t n = s->nd.n;
   if (n == 0) return PIES_OK;
-  // Solver.cpp:157 : _vertices[i].position = position -- one D2H copy per tick
-  HIP_TRY(s, hipMemcpyAsync(s->h_stage, s->nd.pos, n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  // Solver.cpp:157 : _vertices[i].position = position -- one D2H copy per tick; the host mirror's positions are
+  // current afterwards (pies_read_nodes / pies_read_positions_strided copy from it without touching the device)
+  if (int rc = download_nodes(s, 1u)) return rc;
   if (int rc = poll_failure(s)) return rc;
-  if (int rc = adapt_pcg_budget(s)) return rc;
-  for (uint32_t i = 0; i < n; ++i) {
-    s->h_pos[3 * i] = s->h_stage[i].x;
-    s->h_pos[3 * i + 1] = s->h_stage[i].y;
-    s->h_pos[3 * i + 2] = s->h_stage[i].z;
+  return adapt_pcg_budget(s);
+}
+
+// ---- render-state export: frame k leaves through a copy stream while frame k+1 computes -----------------------
+static int export_prepare(pies_solver* s) {
+  const uint32_t n = s->nd.n;
+  if (!s->copyStream) {
+    HIP_TRY(s, hipStreamCreateWithFlags(&s->copyStream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+      HIP_TRY(s, hipEventCreateWithFlags(&s->evTick[b], hipEventDisableTiming));
+      HIP_TRY(s, hipEventCreateWithFlags(&s->evCopied[b], hipEventDisableTiming));
+    }
   }
+  if (s->h_export_n < n || !s->d_export) {
+    HIP_TRY(s, hipStreamSynchronize(s->copyStream));
+    for (int b = 0; b < 2; ++b) {
+      if (s->h_export[b]) (void)hipHostFree(s->h_export[b]);
+      s->h_export[b] = nullptr;
+      HIP_TRY(s, hipHostMalloc((void**)&s->h_export[b], std::max<size_t>(n, 1) * sizeof(float4), hipHostMallocDefault));
+    }
+    if (s->d_export) (void)hipFree(s->d_export);
+    s->d_export = nullptr;
+    HIP_TRY(s, hipMalloc((void**)&s->d_export, std::max<size_t>(n, 1) * sizeof(float4)));
+    s->h_export_n = n;
+  }
+  return PIES_OK;
+}
+
+int pies_tick_begin(pies_solver_t* s, uint64_t* frame) {
+  if (!s || !frame) return PIES_ERR_INVALID;
+  *frame = 0;
+  if (s->device == PIES_DEVICE_NONE) return fail(s, PIES_ERR_HIP, "host-only handle (PIES_DEVICE_NONE): there is no CPU solver");
+  const uint64_t f = s->frameBegun + 1;
+  if (s->frameAcquired && s->frameAcquired + 2 <= f)
+    return fail(s, PIES_ERR_STATE, "pies_tick_begin: the frame two ticks back is still acquired (pies_export_release it first)");
+  if (int rc = pies_tick_async(s)) return rc;  // a failed simulation still hands out (unchanged) frames
+  if (int rc = export_prepare(s)) return rc;
+  const uint32_t n = s->nd.n;
+  const int b = static_cast<int>(f & 1u);
+  if (n) {
+    // d_export is free once the previous frame's D2H copy has read it; by now that copy finished long ago
+    if (f > 1) HIP_TRY(s, hipStreamWaitEvent(s->stream, s->evCopied[b ^ 1], 0));
+    HIP_TRY(s, hipMemcpyAsync(s->d_export, s->nd.pos, n * sizeof(float4), hipMemcpyDeviceToDevice, s->stream));
+  }
+  HIP_TRY(s, hipEventRecord(s->evTick[b], s->stream));
+  HIP_TRY(s, hipStreamWaitEvent(s->copyStream, s->evTick[b], 0));
+  if (n) HIP_TRY(s, hipMemcpyAsync(s->h_export[b], s->d_export, n * sizeof(float4), hipMemcpyDeviceToHost, s->copyStream));
+  HIP_TRY(s, hipEventRecord(s->evCopied[b], s->copyStream));
+  s->frameBegun = f;
+  *frame = f;
+  return PIES_OK;
+}
+
+int pies_export_acquire(pies_solver_t* s, uint64_t frame, const float** pos4, uint32_t* n) {
+  if (!s || !pos4) return PIES_ERR_INVALID;
+  *pos4 = nullptr;
+  if (n) *n = 0;
+  if (frame == 0 || frame > s->frameBegun || frame + 2 <= s->frameBegun)
+    return fail(s, PIES_ERR_STATE, "pies_export_acquire: only the last two frames begun are held");
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipEventSynchronize(s->evCopied[frame & 1u]));
+  s->frameAcquired = frame;
+  *pos4 = reinterpret_cast<const float*>(s->h_export[frame & 1u]);
+  if (n) *n = s->nd.n;
+  return PIES_OK;
+}
+
+int pies_export_release(pies_solver_t* s, uint64_t frame) {
+  if (!s) return PIES_ERR_INVALID;
+  if (s->frameAcquired == frame) s->frameAcquired = 0;
+  return PIES_OK;
+}
+
+int pies_read_positions_strided(pies_solver_t* s, void* dst, uint64_t stride_bytes, uint32_t n) {
+  if (!s || (!dst && n) || stride_bytes < 3 * sizeof(float)) return PIES_ERR_INVALID;
+  if (n != s->nodeCount()) return fail(s, PIES_ERR_INVALID, "pies_read_positions_strided: n does not match the node count");
+  if (s->device != PIES_DEVICE_NONE) {
+    HIP_TRY(s, hipSetDevice(s->device));
+    if (int rc = download_nodes(s, 1u)) return rc;
+  }
+  char* out = static_cast<char*>(dst);
+  for (uint32_t i = 0; i < n; ++i) std::memcpy(out + static_cast<size_t>(i) * stride_bytes, &s->h_pos[3 * static_cast<size_t>(i)], 3 * sizeof(float));
   return PIES_OK;
 }
 
@@ -988,7 +1246,10 @@ int pies_count(const pies_solver_t* s, int what, uint32_t* out) {
 int pies_read_nodes(pies_solver_t* s, int what, float* out, uint32_t n) {
   if (!s || (!out && n)) return PIES_ERR_INVALID;
   if (n != s->nodeCount()) return fail(s, PIES_ERR_INVALID, "pies_read_nodes: n does not match the node count");
-  if (int rc = scene_sync_host(s)) return rc;
+  if (s->device != PIES_DEVICE_NONE && what >= PIES_NODE_POSITION && what <= PIES_NODE_VELOCITY) {
+    HIP_TRY(s, hipSetDevice(s->device));
+    if (int rc = download_nodes(s, 1u << what)) return rc;  // the requested array only
+  }
   const std::vector<float>* src = nullptr;
   switch (what) {
     case PIES_NODE_POSITION: src = &s->h_pos; break;
@@ -1017,6 +1278,7 @@ int pies_write_nodes(pies_solver_t* s, int what, const float* in, uint32_t n) {
   }
   if (!dst->empty()) std::memcpy(dst->data(), in, dst->size() * sizeof(float));
   s->hostNodesDirty = true;
+  if (what == PIES_NODE_RADIUS) s->sceneDirty = true;  // the collision grid is sized from the radii
   return PIES_OK;
 }
 
@@ -1097,65 +1359,142 @@ int pies_launch_counts(pies_solver_t* s, uint32_t* out) {
   return PIES_OK;
 }
 
+// Node state kept aside while a measurement pass steps the solver, put back afterwards.
+namespace {
+struct StateGuard {
+  pies_solver* s;
+  float4 *pos = nullptr, *prev = nullptr, *vel = nullptr;
+  bool ok = false;
+  explicit StateGuard(pies_solver* s_) : s(s_) {
+    const size_t bytes = static_cast<size_t>(s->nd.n) * sizeof(float4);
+    if (!bytes) { ok = true; return; }
+    if (hipMalloc((void**)&pos, bytes) != hipSuccess || hipMalloc((void**)&prev, bytes) != hipSuccess || hipMalloc((void**)&vel, bytes) != hipSuccess) return;
+    ok = hipMemcpyAsync(pos, s->nd.pos, bytes, hipMemcpyDeviceToDevice, s->stream) == hipSuccess &&
+         hipMemcpyAsync(prev, s->nd.prev, bytes, hipMemcpyDeviceToDevice, s->stream) == hipSuccess &&
+         hipMemcpyAsync(vel, s->nd.vel, bytes, hipMemcpyDeviceToDevice, s->stream) == hipSuccess;
+  }
+  ~StateGuard() {
+    const size_t bytes = static_cast<size_t>(s->nd.n) * sizeof(float4);
+    if (ok && bytes) {
+      (void)hipMemcpyAsync(s->nd.pos, pos, bytes, hipMemcpyDeviceToDevice, s->stream);
+      (void)hipMemcpyAsync(s->nd.prev, prev, bytes, hipMemcpyDeviceToDevice, s->stream);
+      (void)hipMemcpyAsync(s->nd.vel, vel, bytes, hipMemcpyDeviceToDevice, s->stream);
+      (void)hipStreamSynchronize(s->stream);
+    }
+    if (pos) (void)hipFree(pos);
+    if (prev) (void)hipFree(prev);
+    if (vel) (void)hipFree(vel);
+  }
+};
+}  // namespace
+
 int pies_profile_substep(pies_solver_t* s, int kernel, uint32_t* launches, double* total_ms, uint64_t* units) {
   if (!s || kernel < 0 || kernel >= PIES_KERNEL_COUNT) return PIES_ERR_INVALID;
   if (s->device == PIES_DEVICE_NONE) return fail(s, PIES_ERR_HIP, "host-only handle");
   const bool isPD = s->opt.solver == PIES_SOLVER_PD;
   const bool pdClass = kernel >= PIES_KERNEL_PD_PREDICT && kernel <= PIES_KERNEL_PD_VELOCITY;
   if (isPD != pdClass) return fail(s, PIES_ERR_INVALID, "pies_profile_substep: kernel class of the other solver");
-  if (s->sceneDirty || s->hostNodesDirty)
-    if (int rc = pies_finalize(s)) return rc;
-  HIP_TRY(s, hipSetDevice(s->device));
+  if (int rc = ensure_ready(s)) return rc;
   if (launches) *launches = 0;
   if (total_ms) *total_ms = 0.0;
   if (units) *units = 0;
   if (s->nd.n == 0 || s->launchCounts[kernel] == 0) return PIES_OK;
-  // a graph holding ONLY this class's launches of one substep, replayed back to back: the launches
-  // form one dependent chain, so wall time / launches is the per-launch device time incl. the kernel
-  // boundary (no events or extension launches: robust under rocprofv3)
+  // a graph holding ONLY this class's launches of one substep, replayed back to back: the launches form one dependent
+  // chain, so wall time / launches is the per-launch device time incl. the kernel boundary.  The working set of one
+  // class usually fits the caches: these are isolated-replay times, NOT bandwidth figures (pies_profile_in_situ).
   uint64_t u = 0;
   const int reps = 5;
-  double ms = 0.0;
   auto enqueue_one = [&](uint64_t* units_) {
     if (isPD) enqueue_pd_substep(s, kernel, nullptr, units_);
     else enqueue_pbd_substep(s, kernel, nullptr, units_);
   };
-  // device time between two events recorded on the solver's stream, around the replays
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  HIP_TRY(s, hipEventCreate(&ev0));
-  HIP_TRY(s, hipEventCreate(&ev1));
-  hipGraph_t g = nullptr;
-  hipGraphExec_t ge = nullptr;
+  StateGuard keep(s);
+  if (!keep.ok) return fail(s, PIES_ERR_HIP, "pies_profile_substep: no memory to keep the node state aside");
+  struct Scope {  // everything the pass creates is released on every return path
+    hipStream_t st;
+    bool capturing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    ~Scope() {
+      if (capturing) { hipGraph_t tmp = nullptr; (void)hipStreamEndCapture(st, &tmp); if (tmp) (void)hipGraphDestroy(tmp); }
+      if (ev0) (void)hipEventDestroy(ev0);
+      if (ev1) (void)hipEventDestroy(ev1);
+      if (ge) (void)hipGraphExecDestroy(ge);
+      if (g) (void)hipGraphDestroy(g);
+    }
+  } sc{s->stream};
+  HIP_TRY(s, hipEventCreate(&sc.ev0));
+  HIP_TRY(s, hipEventCreate(&sc.ev1));
   const bool eager = under_profiler();  // rocprofv3 7.2 segfaults on a second graph instantiation: launch eagerly there
   if (eager) {
     enqueue_one(&u);
+    HIP_TRY(s, hipGetLastError());
   } else {
     HIP_TRY(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    sc.capturing = true;
     enqueue_one(&u);
-    HIP_TRY(s, hipStreamEndCapture(s->stream, &g));
-    HIP_TRY(s, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-    HIP_TRY(s, hipGraphLaunch(ge, s->stream));  // warm
+    sc.capturing = false;
+    HIP_TRY(s, hipStreamEndCapture(s->stream, &sc.g));
+    HIP_TRY(s, hipGraphInstantiate(&sc.ge, sc.g, nullptr, nullptr, 0));
+    HIP_TRY(s, hipGraphLaunch(sc.ge, s->stream));  // warm
   }
   HIP_TRY(s, hipStreamSynchronize(s->stream));
-  HIP_TRY(s, hipEventRecord(ev0, s->stream));
+  HIP_TRY(s, hipEventRecord(sc.ev0, s->stream));
   for (int r = 0; r < reps; ++r) {
-    if (eager) enqueue_one(nullptr);
-    else HIP_TRY(s, hipGraphLaunch(ge, s->stream));
+    if (eager) { enqueue_one(nullptr); HIP_TRY(s, hipGetLastError()); }
+    else HIP_TRY(s, hipGraphLaunch(sc.ge, s->stream));
   }
-  HIP_TRY(s, hipEventRecord(ev1, s->stream));
-  HIP_TRY(s, hipEventSynchronize(ev1));
+  HIP_TRY(s, hipEventRecord(sc.ev1, s->stream));
+  HIP_TRY(s, hipEventSynchronize(sc.ev1));
   float evMs = 0.0f;
-  HIP_TRY(s, hipEventElapsedTime(&evMs, ev0, ev1));
-  ms = evMs;
-  (void)hipEventDestroy(ev0);
-  (void)hipEventDestroy(ev1);
-  if (ge) (void)hipGraphExecDestroy(ge);
-  if (g) (void)hipGraphDestroy(g);
-  s->deviceAhead = true;
-  uint32_t n = s->launchCounts[kernel];
+  HIP_TRY(s, hipEventElapsedTime(&evMs, sc.ev0, sc.ev1));
+  const uint32_t n = s->launchCounts[kernel];
   if (launches) *launches = n * reps;
-  if (total_ms) *total_ms = ms;
+  if (total_ms) *total_ms = evMs;
   if (units) *units = u * reps;
+  return PIES_OK;
+}
+
+int pies_profile_in_situ(pies_solver_t* s, int kernel, uint32_t substeps, uint32_t* launches, double* total_ms, uint64_t* units) {
+  if (!s || kernel < 0 || kernel >= PIES_KERNEL_COUNT || substeps == 0) return PIES_ERR_INVALID;
+  if (s->device == PIES_DEVICE_NONE) return fail(s, PIES_ERR_HIP, "host-only handle");
+  if (int rc = ensure_ready(s)) return rc;
+  if (launches) *launches = 0;
+  if (total_ms) *total_ms = 0.0;
+  if (units) *units = 0;
+  if (s->nd.n == 0) return PIES_OK;
+  StateGuard keep(s);
+  if (!keep.ok) return fail(s, PIES_ERR_HIP, "pies_profile_in_situ: no memory to keep the node state aside");
+  Probe probe;
+  probe.kernel = kernel;
+  probe.stream = s->stream;
+  struct Clear { pies_solver* s; Probe* p; ~Clear() { s->probe = nullptr; for (hipEvent_t e : p->events) (void)hipEventDestroy(e); } } clear{s, &probe};
+  const bool isPD = s->opt.solver == PIES_SOLVER_PD;
+  uint64_t u = 0;
+  if (isPD) enqueue_pd_substep(s, -1, nullptr, nullptr);  // warm: caches and clocks as in a running simulation
+  else enqueue_pbd_substep(s, -1, nullptr, nullptr);
+  HIP_TRY(s, hipGetLastError());
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  s->probe = &probe;
+  for (uint32_t r = 0; r < substeps; ++r) {
+    if (isPD) enqueue_pd_substep(s, -1, nullptr, &u);
+    else enqueue_pbd_substep(s, -1, nullptr, &u);
+    HIP_TRY(s, hipGetLastError());
+  }
+  s->probe = nullptr;
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  if (probe.failed || (probe.used & 1u)) return fail(s, PIES_ERR_HIP, "pies_profile_in_situ: event bookkeeping failed");
+  double ms = 0.0;
+  for (size_t k = 0; k + 1 < probe.used; k += 2) {
+    float e = 0.0f;
+    HIP_TRY(s, hipEventElapsedTime(&e, probe.events[k], probe.events[k + 1]));
+    ms += e;
+  }
+  if (launches) *launches = static_cast<uint32_t>(probe.used / 2);
+  if (total_ms) *total_ms = ms;
+  if (units) *units = u;
+  s->stale = 7u;
   return PIES_OK;
 }
 

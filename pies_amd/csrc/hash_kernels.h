@@ -9,27 +9,46 @@
 
 namespace pies {
 
-constexpr uint32_t kCounterTicket = 32, kCounterEpoch = 33, kHashCounters = 64;
+// counters[]: [0] cells in use [1] cell entries E [3] failure flags [4..30] groups per pass [31] resolved pairs
+// [32] ticket (k_collide_flow) [33] epoch [34..36] / [37..39] bounding box of the cell ranges (min / max, as int)
+// [44] progress of k_collide_reference (nodes visited, diagnostics)
+constexpr uint32_t kCounterUsed = 0, kCounterEntries = 1, kCounterFlags = 3, kCounterPass0 = 4, kCounterPairs = 31, kCounterTicket = 32,
+                   kCounterEpoch = 33, kCounterBoxMin = 34, kCounterBoxMax = 37, kCounterProgress = 44, kHashCounters = 64;
+// failure flags: 1 non-finite position, 2 cell index overflow, 4 more than kMaxBucket nodes in a cell, 8 k_collide_flow wait timed
+// out, 128 more cell entries than reserved  (16, 32, 64 belong to the triangle grid's word, tri_kernels.h)
+constexpr uint32_t kRadixTile = 4096;  // entries per workgroup of a radix pass (256 threads x 16)
+
 struct HashArrays {
-  uint32_t n;         // nodes (capacity of every per-pass list)
-  uint32_t capacity;  // table slots, power of two
+  uint32_t n;           // nodes
+  uint32_t maxEntries;  // reserved (cell, node) entries
+  uint32_t capacity;    // cell index slots, power of two
   uint32_t mask;
-  uint64_t* keys;     // packed cell id, ~0 = empty
-  uint32_t *cnt, *start, *fill;     // nodes overlapping the cell
-  uint32_t *gcnt, *gstart, *gfill;  // nodes whose minimum cell it is (a "group")
-  uint32_t* used;                   // slots in use
-  uint32_t* counters;               // [0] used slots [1] bucket entries [2] grouped nodes [3] failure flag [4..30] groups per pass [31] resolved pairs [32] ticket [33] epoch
-  uint32_t* done;                   // per table slot: epoch in which the cell's group was resolved (k_collide_flow)
-  uint32_t* passList;               // 27 x n group slots
-  uint32_t* nodeSlot;               // n x 8: table slot of each cell of the node's range
-  int4* rng;                        // per node: min cell x,y,z and packed lengths
-  uint32_t *bucket, *bucketSorted;  // 8n
-  uint32_t *group, *groupSorted;    // n
+  // per node
+  int4* rng;            // min cell x, y, z and packed lengths (8 bits each) at build time
+  uint32_t* entCount;   // n + 1: cells the node overlaps (lx * ly * lz), then their exclusive prefix sum in entOff
+  uint32_t* entOff;
+  uint32_t* scanSums;   // tile sums of the prefix sum
+  // (cell key, node) entries: node-major before the sort, ascending (key, node) after it; ping-pong buffers
+  uint64_t* key[2];
+  uint32_t* val[2];     // node index | 0x80000000 when the cell is the node's minimum cell
+  uint32_t* hist;       // radix digit counts, [256][workgroups]
+  // cell index: open addressing on the exact key -> bucket [start, end) in the sorted entries
+  uint64_t* keys;
+  uint32_t *start, *end;
+  uint32_t* gcnt;       // nodes whose minimum cell it is (a "group")
+  uint32_t* used;       // slots in use
+  uint32_t* done;       // per slot: epoch in which the cell's group was resolved (k_collide_flow)
+  uint32_t* passList;   // 27 x n group slots
+  uint32_t* counters;
 };
 
-// reset + count + alloc + fill + sort; returns the number of launches
+// zero + range + prefix sum + emit + radix sort + cell index; returns the number of launches
 uint32_t launch_hash_build(hipStream_t st, const HashArrays& H, const NodeArrays& nd, float gridSpacing);
-// the 27 resolve passes (Solver.cpp:85-130); returns the number of launches
-uint32_t launch_collide(hipStream_t st, const HashArrays& H, const NodeArrays& nd, float friction, float staticThreshold);
+// the resolve of Solver.cpp:85-130 in the parallel visiting order; returns the number of launches.
+// rearm: the launch first resets the work queue of k_collide_flow (a replay without a new hash build, profile passes)
+uint32_t launch_collide(hipStream_t st, const HashArrays& H, const NodeArrays& nd, float friction, float staticThreshold, bool rearm = false);
+// the same loop in the reference's order: ascending node index, range from the current position (one sequential chain)
+uint32_t launch_collide_reference(hipStream_t st, const HashArrays& H, const NodeArrays& nd, float gridSpacing, float friction,
+                                  float staticThreshold);
 
 }  // namespace pies

@@ -1,25 +1,36 @@
 // Node-node collision broad phase and resolve for the PBD substep (reference: Include/Pies/SpatialHash.h,
 // Src/Solver.cpp:81-130 and :877-901).
 //
-// Broad phase.  The reference keeps a parallel_flat_hash_map<CellId, vector<Node*>> that is cleared and
-// rebuilt every solver iteration by 16 threads which each scan all nodes.  Here the grid is rebuilt on the
-// device in five small kernels: (1) every node computes its cell range with the reference's NodeCompRange
-// arithmetic and counts itself into an open-addressing table keyed by the exact cell id (no hash
-// aliasing: full 63-bit key compare); (2) buckets get contiguous storage by bump allocation from the
-// final counts; (3) nodes are filled in; (4) each bucket is sorted by node index -- which is exactly the
-// bucket order of the reference (its insert threads scan the nodes in index order).  Only cells that
-// were used are touched when the table is reset.
+// Broad phase.  The reference keeps a parallel_flat_hash_map<CellId, vector<Node*>> that is cleared and rebuilt every
+// solver iteration by 16 threads which each scan all nodes.  Here the grid is rebuilt on the device as a sort:
+//   (1) k_grid_range   every node computes its cell range with the reference's NodeCompRange arithmetic (up to 50 cells
+//                      per axis, like the reference) and the number of cells it overlaps; the bounding box of all
+//                      ranges is reduced with one atomic per wavefront;
+//   (2) prefix sum     of the per-node cell counts -> each node's first entry (three small kernels);
+//   (3) k_grid_emit    one (cell key, node) entry per overlapped cell, node-major.  The key packs the cell's coordinates
+//                      relative to the bounding box with just the bits the box needs, so a scene of 23 x 45 x 45 cells
+//                      sorts on 17 bits;
+//   (4) radix sort     least-significant-digit, 8 bits per pass, stable: histogram, prefix sum of the (digit, workgroup)
+//                      counts, scatter with ballot-based ranks.  Only the passes the key width needs do work (the
+//                      captured graph holds all eight; the rest exit at once).  Stable + node-major input = every
+//                      bucket lists its nodes in ascending index, which is the reference's bucket order (its insert
+//                      threads scan the nodes in index order);
+//   (5) k_grid_cells   bucket boundaries from neighbouring keys; each bucket's [start, end) goes into an exact-key
+//                      open-addressing index (full 64-bit compare: two cells never alias, the reference's map is exact
+//                      as well) that the resolve uses to find a cell's bucket with one or two probes.
 //
-// Resolve.  The reference visits nodes 0..N-1 sequentially and, per node, every bucket of its cell range
-// in dx,dy,dz order, resolving each overlapping pair immediately (positions and velocities of both
-// nodes).  That loop is order dependent, so the device fixes a *documented* order that exposes
-// parallelism (DESIGN.md "Node-node collisions"): nodes are grouped by the minimum cell of their range;
-// groups whose minimum cells agree modulo 3 on every axis touch disjoint node sets (a range spans at
-// most 2 cells per axis), so the 27 residue classes are 27 passes; inside a pass one wavefront owns one
-// group and visits its nodes in ascending index.  Per visited node the wave walks the buckets exactly
-// like the reference: 64 candidates at a time are tested in parallel, and hits are resolved one by one
-// in lane (= bucket) order, re-testing the remaining candidates after each resolve because the visiting
-// node has moved.  The per-pair arithmetic is the reference's, operation for operation.
+// Resolve.  Two orders:
+//  * k_collide_reference - the reference's loop as it stands (Solver.cpp:85-130): nodes 0..N-1 in ascending index, each
+//    querying the cell range of its CURRENT position (SpatialHash.h:101-127), buckets in dx,dy,dz order, every overlapping
+//    pair resolved at once (positions and velocities of both nodes, the self pair included).  The loop is one dependent
+//    chain, so it runs on one wavefront: 64 candidates are tested at a time and hits are resolved one by one in bucket
+//    order, re-testing the rest after each resolve because the visiting node has moved.  Bit-identical to the loop; slow.
+//  * k_collide_flow - a documented order that exposes parallelism (DESIGN.md "Node-node collisions"): nodes are grouped
+//    by the minimum cell of their range; groups whose minimum cells agree modulo 3 on every axis touch disjoint node
+//    sets (needs ranges of at most 2 cells per axis), so the 27 residue classes are 27 passes; inside a pass one
+//    wavefront owns one group and visits its nodes in ascending index, each with the range it was inserted with.
+// The per-pair arithmetic is the reference's, operation for operation, in both.
+#include <climits>
 #include <cstdint>
 #include <cstdlib>
 
@@ -30,119 +41,372 @@ namespace pies {
 
 constexpr int kBlock = 256;
 constexpr uint32_t kMaxBucket = 2048;  // nodes overlapping one cell before the simulation is declared failed
+constexpr uint32_t kMinFlag = 0x80000000u, kNodeMask = 0x7fffffffu;
 
 static inline dim3 grid_for(uint32_t n) { return dim3((n + kBlock - 1) / kBlock); }
 
-// ---- reset: only the slots the previous build used ------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_hash_reset(HashArrays H) {
-  const uint32_t used = H.counters[0];
+// ---- the cell box of a build: origin and bits per axis of the packed key --------------------------------------
+struct GridBox {
+  int mn[3];
+  uint32_t ext[3];   // max - min per axis
+  uint32_t bits[3];
+  bool empty;
+};
+PIES_DEV GridBox grid_box(const uint32_t* __restrict__ counters) {
+  GridBox B;
+  B.empty = false;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    B.mn[a] = static_cast<int>(counters[kCounterBoxMin + a]);
+    const int mx = static_cast<int>(counters[kCounterBoxMax + a]);
+    if (mx < B.mn[a]) B.empty = true;
+    B.ext[a] = B.empty ? 0u : static_cast<uint32_t>(mx - B.mn[a]);
+    B.bits[a] = B.ext[a] ? 32u - static_cast<uint32_t>(__builtin_clz(B.ext[a])) : 0u;
+  }
+  return B;
+}
+PIES_DEV uint32_t grid_passes(const GridBox& B) { return (B.bits[0] + B.bits[1] + B.bits[2] + 7u) >> 3; }
+PIES_DEV bool in_box(const GridBox& B, int x, int y, int z) {
+  return !B.empty && x >= B.mn[0] && y >= B.mn[1] && z >= B.mn[2] && static_cast<uint32_t>(x - B.mn[0]) <= B.ext[0] &&
+         static_cast<uint32_t>(y - B.mn[1]) <= B.ext[1] && static_cast<uint32_t>(z - B.mn[2]) <= B.ext[2];
+}
+PIES_DEV uint64_t box_key(const GridBox& B, int x, int y, int z) {  // in_box(x, y, z)
+  return (static_cast<uint64_t>(static_cast<uint32_t>(x - B.mn[0])) << (B.bits[1] + B.bits[2])) |
+         (static_cast<uint64_t>(static_cast<uint32_t>(y - B.mn[1])) << B.bits[2]) | static_cast<uint64_t>(static_cast<uint32_t>(z - B.mn[2]));
+}
+PIES_DEV void box_cell(const GridBox& B, uint64_t key, int& x, int& y, int& z) {
+  z = B.mn[2] + static_cast<int>(key & ((1ull << B.bits[2]) - 1ull));
+  y = B.mn[1] + static_cast<int>((key >> B.bits[2]) & ((1ull << B.bits[1]) - 1ull));
+  x = B.mn[0] + static_cast<int>(key >> (B.bits[1] + B.bits[2]));
+}
+// bucket of cell (x, y, z): index slot or ~0
+PIES_DEV uint32_t find_bucket(const HashArrays& H, const GridBox& B, int x, int y, int z) {
+  if (!in_box(B, x, y, z)) return 0xffffffffu;
+  return find_cell(H.keys, H.mask, box_key(B, x, y, z));
+}
+
+// NodeCompRange (Solver.cpp:877-901).  Returns false for a non-finite position; an over-long range is empty, like the
+// reference's (:896-898).
+PIES_DEV bool node_range(float px, float py, float pz, float radius, float scale, int& mx, int& my, int& mz, uint32_t& lx, uint32_t& ly,
+                         uint32_t& lz) {
+  const float R = (radius + 0.5f) / scale;
+  const float gx = px / scale - R, gy = py / scale - R, gz = pz / scale - R;
+  const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+  const float twoR = 2 * R;
+  const float cx = ceilf((gx - fx) + twoR), cy = ceilf((gy - fy) + twoR), cz = ceilf((gz - fz) + twoR);
+  const bool finite = (fabsf(fx) < 1.0e6f) && (fabsf(fy) < 1.0e6f) && (fabsf(fz) < 1.0e6f) && (cx >= 0.0f) && (cy >= 0.0f) && (cz >= 0.0f) &&
+                      (cx < 1.0e6f) && (cy < 1.0e6f) && (cz < 1.0e6f);  // false for NaN as well
+  mx = finite ? static_cast<int>(fx) : 0;
+  my = finite ? static_cast<int>(fy) : 0;
+  mz = finite ? static_cast<int>(fz) : 0;
+  lx = finite ? static_cast<uint32_t>(cx) : 0u;
+  ly = finite ? static_cast<uint32_t>(cy) : 0u;
+  lz = finite ? static_cast<uint32_t>(cz) : 0u;
+  if (lx > 50 || ly > 50 || lz > 50) lx = ly = lz = 0;
+  return finite;
+}
+
+// ---- reset: only the index slots the previous build used; counters; bounding box --------------------------------
+__global__ void __launch_bounds__(kBlock) k_grid_reset(HashArrays H) {
+  const uint32_t used = H.counters[kCounterUsed];
   for (uint32_t u = blockIdx.x * kBlock + threadIdx.x; u < used; u += gridDim.x * kBlock) {
     const uint32_t s = H.used[u];
     H.keys[s] = kEmpty;
-    H.cnt[s] = 0;
     H.gcnt[s] = 0;
   }
 }
-__global__ void k_hash_zero(HashArrays H) {
+__global__ void k_grid_zero(HashArrays H) {
   const uint32_t t = threadIdx.x;
-  if (t < 3) H.counters[t] = 0;            // used, total entries, total grouped nodes
-  if (t >= 4 && t < 4 + 27) H.counters[t] = 0;  // groups per pass      (counters[3] = sticky failure flag)
-  if (t == kCounterTicket) H.counters[t] = 0;   // k_collide_flow's work queue
-  if (t == kCounterEpoch) H.counters[t] += 1;   // completion stamps of earlier builds are stale by construction
+  if (t == kCounterUsed || t == kCounterEntries || t == 2) H.counters[t] = 0;
+  if (t >= kCounterPass0 && t < kCounterPass0 + 27) H.counters[t] = 0;  // groups per pass   (counters[3] = sticky failure flags)
+  if (t == kCounterTicket) H.counters[t] = 0;                            // k_collide_flow's work queue
+  if (t == kCounterEpoch) H.counters[t] += 1;  // completion stamps of earlier builds are stale by construction
+  if (t >= kCounterBoxMin && t < kCounterBoxMin + 3) H.counters[t] = static_cast<uint32_t>(INT_MAX);
+  if (t >= kCounterBoxMax && t < kCounterBoxMax + 3) H.counters[t] = static_cast<uint32_t>(INT_MIN);
 }
 
-// ---- count: NodeCompRange (Solver.cpp:877-901) + insertion into the cell table ---------------------
-__global__ void __launch_bounds__(kBlock) k_hash_count(HashArrays H, const float4* __restrict__ pos, const float* __restrict__ radius,
+// ---- range: NodeCompRange + cells per node + bounding box ---------------------------------------------------------
+PIES_DEV int wave_min(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+  return v;
+}
+PIES_DEV int wave_max(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__global__ void __launch_bounds__(kBlock) k_grid_range(HashArrays H, const float4* __restrict__ pos, const float* __restrict__ radius,
                                                        uint32_t n, float scale) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const float4 p = pos[i];
-  const float R = (radius[i] + 0.5f) / scale;
-  const float gx = p.x / scale - R, gy = p.y / scale - R, gz = p.z / scale - R;
-  const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
-  const float twoR = 2 * R;
-  uint32_t lx = static_cast<uint32_t>(ceilf((gx - fx) + twoR));
-  uint32_t ly = static_cast<uint32_t>(ceilf((gy - fy) + twoR));
-  uint32_t lz = static_cast<uint32_t>(ceilf((gz - fz) + twoR));
-  const bool finite = (fabsf(fx) < 1.0e6f) && (fabsf(fy) < 1.0e6f) && (fabsf(fz) < 1.0e6f);  // also false for NaN
-  if (lx > 50 || ly > 50 || lz > 50) lx = ly = lz = 0;  // the reference returns an empty range (Solver.cpp:896-898)
-  if (!finite || lx > 2 || ly > 2 || lz > 2) {          // outside what this build supports: latch the failure
-    atomicOr(&H.counters[3], 1u);
-    lx = ly = lz = 0;
+  int mx = 0, my = 0, mz = 0;
+  uint32_t lx = 0, ly = 0, lz = 0;
+  if (i < n) {
+    const float4 p = pos[i];
+    if (!node_range(p.x, p.y, p.z, radius[i], scale, mx, my, mz, lx, ly, lz)) atomicOr(&H.counters[kCounterFlags], 1u);
+    H.rng[i] = make_int4(mx, my, mz, static_cast<int>(lx | (ly << 8) | (lz << 16)));
+    H.entCount[i] = lx * ly * lz;
   }
-  const int mx = finite ? static_cast<int>(fx) : 0, my = finite ? static_cast<int>(fy) : 0, mz = finite ? static_cast<int>(fz) : 0;
-  H.rng[i] = make_int4(mx, my, mz, static_cast<int>(lx | (ly << 8) | (lz << 16)));
-  uint32_t e = 0;
-  for (uint32_t dx = 0; dx < lx; ++dx)
-    for (uint32_t dy = 0; dy < ly; ++dy)
-      for (uint32_t dz = 0; dz < lz; ++dz, ++e) {
-        const uint64_t key = pack_cell(mx + (int)dx, my + (int)dy, mz + (int)dz);
-        uint32_t h = hash_cell(key, H.mask);
-        uint32_t slot = 0xffffffffu;
-        for (int probe = 0; probe < 4096; ++probe) {
-          const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&H.keys[h]), kEmpty, key);
-          if (old == kEmpty) {
-            H.used[atomicAdd(&H.counters[0], 1u)] = h;
-            slot = h;
-            break;
-          }
-          if (old == key) { slot = h; break; }
-          h = (h + 1) & H.mask;
-        }
-        if (slot == 0xffffffffu) { atomicOr(&H.counters[3], 2u); H.nodeSlot[i * 8 + e] = slot; continue; }
-        atomicAdd(&H.cnt[slot], 1u);
-        if (e == 0) atomicAdd(&H.gcnt[slot], 1u);  // this cell is the node's minimum cell
-        H.nodeSlot[i * 8 + e] = slot;
-      }
-}
-
-// ---- alloc: contiguous storage per bucket / per group, pass lists ----------------------------------
-__global__ void __launch_bounds__(kBlock) k_hash_alloc(HashArrays H) {
-  const uint32_t used = H.counters[0];
-  for (uint32_t u = blockIdx.x * kBlock + threadIdx.x; u < used; u += gridDim.x * kBlock) {
-    const uint32_t s = H.used[u];
-    if (H.cnt[s] > kMaxBucket) atomicOr(&H.counters[3], 4u);  // runaway pile-up: latch, like Solver.cpp:741-755
-    H.start[s] = atomicAdd(&H.counters[1], H.cnt[s]);
-    H.fill[s] = 0;
-    const uint32_t gc = H.gcnt[s];
-    if (gc) {
-      H.gstart[s] = atomicAdd(&H.counters[2], gc);
-      H.gfill[s] = 0;
-      const uint64_t key = H.keys[s];
-      const int x = static_cast<int>((key >> 42) & 0x1fffff) - kCoordBias, y = static_cast<int>((key >> 21) & 0x1fffff) - kCoordBias,
-                z = static_cast<int>(key & 0x1fffff) - kCoordBias;
-      const uint32_t pass = static_cast<uint32_t>(mod3(x) + 3 * mod3(y) + 9 * mod3(z));
-      H.passList[static_cast<size_t>(pass) * H.n + atomicAdd(&H.counters[4 + pass], 1u)] = s;
+  if (i == n) H.entCount[n] = 0;  // so that the exclusive prefix sum ends with the total
+  const bool have = i < n && lx * ly * lz != 0u;
+  int lo[3] = {have ? mx : INT_MAX, have ? my : INT_MAX, have ? mz : INT_MAX};
+  int hi[3] = {have ? mx + static_cast<int>(lx) - 1 : INT_MIN, have ? my + static_cast<int>(ly) - 1 : INT_MIN,
+               have ? mz + static_cast<int>(lz) - 1 : INT_MIN};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = wave_min(lo[a]);
+    hi[a] = wave_max(hi[a]);
+  }
+  if ((threadIdx.x & 63) == 0 && lo[0] != INT_MAX) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      atomicMin(reinterpret_cast<int*>(&H.counters[kCounterBoxMin + a]), lo[a]);
+      atomicMax(reinterpret_cast<int*>(&H.counters[kCounterBoxMax + a]), hi[a]);
     }
   }
 }
 
-// ---- fill ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_hash_fill(HashArrays H, uint32_t n) {
+// ---- exclusive prefix sum of uint32 (tile sums, scan of the sums, add) -----------------------------------------
+constexpr uint32_t kScanTile = 2048;  // 256 threads x 8
+PIES_DEV uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds, uint32_t& total) {  // 256 threads; lds: 8 words
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(incl, off, 64);
+    if (lane >= static_cast<uint32_t>(off)) incl += t;
+  }
+  if (lane == 63) lds[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (uint32_t w = 0; w < wave; ++w) base += lds[w];
+  total = lds[0] + lds[1] + lds[2] + lds[3];
+  __syncthreads();
+  return base + incl - v;
+}
+__global__ void __launch_bounds__(kBlock) k_scan_tiles(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n,
+                                                       uint32_t* __restrict__ sums) {
+  __shared__ uint32_t lds[8];
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 8u;
+  uint32_t v[8], s = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    v[k] = base + k < n ? in[base + k] : 0u;
+    s += v[k];
+  }
+  uint32_t total;
+  uint32_t run = block_exclusive_scan(s, lds, total);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (base + k < n) out[base + k] = run;
+    run += v[k];
+  }
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(1024) k_scan_sums(uint32_t* __restrict__ sums, uint32_t m) {  // one workgroup, in place
+  __shared__ uint32_t part[1024];
+  const uint32_t t = threadIdx.x, per = (m + 1023u) / 1024u;
+  const uint32_t lo = min(m, t * per), hi = min(m, lo + per);
+  uint32_t s = 0;
+  for (uint32_t k = lo; k < hi; ++k) s += sums[k];
+  part[t] = s;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan of the 1024 partial sums
+    const uint32_t a = t >= off ? part[t - off] : 0u;
+    __syncthreads();
+    part[t] += a;
+    __syncthreads();
+  }
+  uint32_t run = part[t] - s;
+  for (uint32_t k = lo; k < hi; ++k) {
+    const uint32_t v = sums[k];
+    sums[k] = run;
+    run += v;
+  }
+}
+__global__ void __launch_bounds__(kBlock) k_scan_add(uint32_t* __restrict__ out, uint32_t n, const uint32_t* __restrict__ sums) {
+  const uint32_t add = sums[blockIdx.x];
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 8u;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (base + k < n) out[base + k] += add;
+}
+
+// ---- emit: one (cell key, node) entry per overlapped cell, node-major --------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_grid_emit(HashArrays H, uint32_t n) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i == 0) {
+    const uint32_t total = H.entOff[n];
+    if (total > H.maxEntries) atomicOr(&H.counters[kCounterFlags], 128u);
+    H.counters[kCounterEntries] = min(total, H.maxEntries);
+  }
   if (i >= n) return;
   const int4 rg = H.rng[i];
   const uint32_t lx = rg.w & 0xff, ly = (rg.w >> 8) & 0xff, lz = (rg.w >> 16) & 0xff;
-  const uint32_t ne = lx * ly * lz;
-  for (uint32_t e = 0; e < ne; ++e) {
-    const uint32_t s = H.nodeSlot[i * 8 + e];
-    if (s == 0xffffffffu) continue;
-    H.bucket[H.start[s] + atomicAdd(&H.fill[s], 1u)] = i;
-    if (e == 0) H.group[H.gstart[s] + atomicAdd(&H.gfill[s], 1u)] = i;
+  const uint32_t base = H.entOff[i];
+  if (base + lx * ly * lz > H.maxEntries) return;  // flagged above: the host latches the failure
+  const GridBox B = grid_box(H.counters);
+  uint32_t e = 0;
+  for (uint32_t dx = 0; dx < lx; ++dx)
+    for (uint32_t dy = 0; dy < ly; ++dy)
+      for (uint32_t dz = 0; dz < lz; ++dz, ++e) {
+        H.key[0][base + e] = box_key(B, rg.x + static_cast<int>(dx), rg.y + static_cast<int>(dy), rg.z + static_cast<int>(dz));
+        H.val[0][base + e] = i | (e == 0 ? kMinFlag : 0u);  // e == 0: the node's minimum cell
+      }
+}
+
+// ---- radix sort of the entries by key: 8 bits per pass, stable ------------------------------------------------
+// Pass p reads buffer p & 1 and writes the other one.  A workgroup owns kRadixTile consecutive entries; wavefront w of
+// it the w-th quarter, sixteen rounds of 64 consecutive entries - so (workgroup, wavefront, round, lane) is the input order.
+__global__ void __launch_bounds__(kBlock) k_radix_hist(HashArrays H, uint32_t pass, uint32_t nblkMax) {
+  __shared__ uint32_t h[256];
+  const GridBox B = grid_box(H.counters);
+  if (pass >= grid_passes(B)) return;
+  const uint32_t E = H.counters[kCounterEntries];
+  const uint32_t blk = blockIdx.x;
+  if (blk * kRadixTile >= E) return;
+  const uint64_t* __restrict__ src = H.key[pass & 1u];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll 4
+  for (uint32_t k = 0; k < kRadixTile / kBlock; ++k) {
+    const uint32_t t = blk * kRadixTile + k * kBlock + threadIdx.x;
+    if (t < E) atomicAdd(&h[static_cast<uint32_t>(src[t] >> (8u * pass)) & 255u], 1u);
+  }
+  __syncthreads();
+  H.hist[threadIdx.x * nblkMax + blk] = h[threadIdx.x];
+}
+// exclusive prefix sum over (digit, workgroup) in digit-major order, one workgroup
+__global__ void __launch_bounds__(1024) k_radix_scan(HashArrays H, uint32_t pass, uint32_t nblkMax) {
+  __shared__ uint32_t part[1024];
+  const GridBox B = grid_box(H.counters);
+  if (pass >= grid_passes(B)) return;
+  const uint32_t E = H.counters[kCounterEntries];
+  const uint32_t nblk = (E + kRadixTile - 1u) / kRadixTile;
+  const uint32_t m = 256u * nblk, t = threadIdx.x, per = (m + 1023u) / 1024u;
+  const uint32_t lo = min(m, t * per), hi = min(m, lo + per);
+  auto at = [&](uint32_t L) { return (L / nblk) * nblkMax + (L % nblk); };
+  uint32_t s = 0;
+  for (uint32_t k = lo; k < hi; ++k) s += H.hist[at(k)];
+  part[t] = s;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    const uint32_t a = t >= off ? part[t - off] : 0u;
+    __syncthreads();
+    part[t] += a;
+    __syncthreads();
+  }
+  uint32_t run = part[t] - s;
+  for (uint32_t k = lo; k < hi; ++k) {
+    const uint32_t v = H.hist[at(k)];
+    H.hist[at(k)] = run;
+    run += v;
+  }
+}
+__global__ void __launch_bounds__(kBlock) k_radix_scatter(HashArrays H, uint32_t pass, uint32_t nblkMax) {
+  __shared__ uint32_t cnt[4][256];  // per wavefront: running count of a digit, then the wavefront's base inside the workgroup
+  __shared__ uint32_t gbase[256];
+  const GridBox B = grid_box(H.counters);
+  if (pass >= grid_passes(B)) return;
+  const uint32_t E = H.counters[kCounterEntries];
+  const uint32_t blk = blockIdx.x;
+  if (blk * kRadixTile >= E) return;
+  const uint64_t* __restrict__ skey = H.key[pass & 1u];
+  const uint32_t* __restrict__ sval = H.val[pass & 1u];
+  uint64_t* __restrict__ dkey = H.key[(pass & 1u) ^ 1u];
+  uint32_t* __restrict__ dval = H.val[(pass & 1u) ^ 1u];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  constexpr int kRounds = kRadixTile / kBlock;  // 16
+  for (uint32_t d = lane; d < 256u; d += 64u) cnt[wave][d] = 0;
+  __builtin_amdgcn_wave_barrier();
+  uint64_t key[kRounds];
+  uint32_t val[kRounds], rank[kRounds];
+  const uint32_t first = blk * kRadixTile + wave * (kRadixTile / 4u);
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const uint32_t t = first + static_cast<uint32_t>(r) * 64u + lane;
+    const bool valid = t < E;
+    key[r] = valid ? skey[t] : 0ull;
+    val[r] = valid ? sval[t] : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const uint32_t t = first + static_cast<uint32_t>(r) * 64u + lane;
+    const bool valid = t < E;
+    const uint32_t d = static_cast<uint32_t>(key[r] >> (8u * pass)) & 255u;
+    unsigned long long peers = __ballot(valid);  // lanes of this round holding the same digit
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long m = __ballot(valid && bit);
+      peers &= bit ? m : ~m;
+    }
+    rank[r] = 0;
+    if (valid) {
+      const uint32_t before = cnt[wave][d];
+      rank[r] = before + static_cast<uint32_t>(__popcll(peers & ((1ull << lane) - 1ull)));
+      if (static_cast<uint32_t>(__builtin_ctzll(peers)) == lane) cnt[wave][d] = before + static_cast<uint32_t>(__popcll(peers));
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  {  // thread d: wavefront bases of digit d inside the workgroup, and the workgroup's base in the output
+    const uint32_t d = threadIdx.x;
+    uint32_t run = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t c = cnt[w][d];
+      cnt[w][d] = run;
+      run += c;
+    }
+    gbase[d] = H.hist[d * nblkMax + blk];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kRounds; ++r) {
+    const uint32_t t = first + static_cast<uint32_t>(r) * 64u + lane;
+    if (t < E) {
+      const uint32_t d = static_cast<uint32_t>(key[r] >> (8u * pass)) & 255u;
+      const uint32_t at = gbase[d] + cnt[wave][d] + rank[r];
+      dkey[at] = key[r];
+      dval[at] = val[r];
+    }
   }
 }
 
-// ---- sort: ascending node index inside every bucket and every group (rank sort, one wave per cell) ---
-__global__ void __launch_bounds__(kBlock) k_hash_sort(HashArrays H) {
-  if (H.counters[3]) return;  // failed: the host latches _simFailed
-  const uint32_t used = H.counters[0];
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
-  for (uint32_t u = wave; u < used; u += nwaves) {
+// ---- cells: bucket boundaries -> cell index; groups per pass ------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_grid_cells(HashArrays H) {
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t E = H.counters[kCounterEntries];
+  if (t >= E) return;
+  const GridBox B = grid_box(H.counters);
+  const uint32_t fb = grid_passes(B) & 1u;  // the buffer the last pass wrote
+  const uint64_t* __restrict__ key = H.key[fb];
+  const uint64_t k = key[t];
+  const bool head = t == 0 || key[t - 1] != k;
+  const bool tail = t + 1 == E || key[t + 1] != k;
+  const bool isMin = (H.val[fb][t] & kMinFlag) != 0u;
+  if (!(head || tail || isMin)) return;
+  bool created;
+  const uint32_t slot = insert_cell(H.keys, H.mask, k, created);
+  if (slot == 0xffffffffu) { atomicOr(&H.counters[kCounterFlags], 2u); return; }
+  if (created) H.used[atomicAdd(&H.counters[kCounterUsed], 1u)] = slot;
+  if (head) H.start[slot] = t;
+  if (tail) H.end[slot] = t + 1;
+  if (isMin) atomicAdd(&H.gcnt[slot], 1u);
+}
+__global__ void __launch_bounds__(kBlock) k_grid_groups(HashArrays H) {
+  const uint32_t used = H.counters[kCounterUsed];
+  const GridBox B = grid_box(H.counters);
+  for (uint32_t u = blockIdx.x * kBlock + threadIdx.x; u < used; u += gridDim.x * kBlock) {
     const uint32_t s = H.used[u];
-    rank_sort(H.bucket, H.bucketSorted, H.start[s], H.cnt[s], lane);
-    const uint32_t gc = H.gcnt[s];
-    if (gc) rank_sort(H.group, H.groupSorted, H.gstart[s], gc, lane);
+    if (H.end[s] - H.start[s] > kMaxBucket) atomicOr(&H.counters[kCounterFlags], 4u);  // runaway pile-up: latch, like Solver.cpp:741-755
+    if (H.gcnt[s]) {
+      int x, y, z;
+      box_cell(B, H.keys[s], x, y, z);
+      const uint32_t pass = static_cast<uint32_t>(mod3(x) + 3 * mod3(y) + 9 * mod3(z));
+      H.passList[static_cast<size_t>(pass) * H.n + atomicAdd(&H.counters[kCounterPass0 + pass], 1u)] = s;
+    }
   }
 }
 
@@ -203,14 +467,70 @@ PIES_DEV void resolve_pair(PairState& a, float imi, bool self, float hdx, float 
   }
 }
 
+// The nodes of a group are the entries of its own cell's bucket that carry kMinFlag (ascending node index, like the
+// bucket).  Returns the bucket-relative position of the next one at or after `from`, or cnt.
+PIES_DEV uint32_t next_min_entry(const uint32_t* __restrict__ val, uint32_t start, uint32_t cnt, uint32_t from, int lane) {
+  for (uint32_t base = from & ~63u; base < cnt; base += 64) {
+    const uint32_t e = base + static_cast<uint32_t>(lane);
+    const bool f = e < cnt && e >= from && (val[start + e] & kMinFlag) != 0u;
+    const unsigned long long m = __ballot(f);
+    if (m) return base + static_cast<uint32_t>(__builtin_ctzll(m));
+  }
+  return cnt;
+}
+
+// One bucket [bs, bs + bc) met by visiting node i, whose state `a` lives in registers: 64 candidates are tested at a time,
+// hits are resolved one by one in bucket order and the rest re-tested (the visiting node has moved).  Candidate state
+// comes straight from global memory.  Returns the number of resolved pairs.
+PIES_DEV uint32_t collide_bucket_global(const uint32_t* __restrict__ val, uint32_t bs, uint32_t bc, uint32_t i, PairState& a, float imi, float ri,
+                                        float* pos, float* vel, const float* __restrict__ radius, int lane, const LaneRole role,
+                                        float friction, float staticThreshold) {
+  uint32_t resolved = 0;
+  for (uint32_t base = 0; base < bc; base += 64) {
+    const bool valid = base + lane < bc;
+    const uint32_t j = valid ? (val[bs + base + lane] & kNodeMask) : 0xffffffffu;
+    float pjx = 0.f, pjy = 0.f, pjz = 0.f, imj = 1.f, rj = 0.f, wjx = 0.f, wjy = 0.f, wjz = 0.f;
+    if (valid) {  // candidate state up front: a resolve then needs no further loads
+      pjx = ld(pos + 4 * j); pjy = ld(pos + 4 * j + 1); pjz = ld(pos + 4 * j + 2); imj = ld(pos + 4 * j + 3);
+      wjx = ld(vel + 4 * j); wjy = ld(vel + 4 * j + 1); wjz = ld(vel + 4 * j + 2);
+      rj = radius[j];
+    }
+    int cursor = 0;
+    for (;;) {
+      if (valid && j == i) { pjx = a.pix; pjy = a.piy; pjz = a.piz; }  // the self pair sees the node's current position
+      const float ddx = pjx - a.pix, ddy = pjy - a.piy, ddz = pjz - a.piz;
+      const float dist = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+      const float disp = ri + rj - dist;
+      const bool hit = valid && lane >= cursor && disp > 0.0f;
+      const unsigned long long m = __ballot(hit);
+      if (m == 0ull) break;
+      const int l = __builtin_ctzll(m);
+      const uint32_t hj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(j), l));
+      float ojx, ojy, ojz, vjx, vjy, vjz;
+      resolve_pair(a, imi, hj == i, bcast(ddx, l), bcast(ddy, l), bcast(ddz, l), bcast(dist, l), bcast(disp, l), bcast(imj, l),
+                   bcast(pjx, l), bcast(pjy, l), bcast(pjz, l), bcast(wjx, l), bcast(wjy, l), bcast(wjz, l), friction,
+                   staticThreshold, role, ojx, ojy, ojz, vjx, vjy, vjz);
+      if (hj != i && lane == l) {
+        st(pos + 4 * hj, ojx); st(pos + 4 * hj + 1, ojy); st(pos + 4 * hj + 2, ojz);
+        st(vel + 4 * hj, vjx); st(vel + 4 * hj + 1, vjy); st(vel + 4 * hj + 2, vjz);
+      }
+      ++resolved;
+      cursor = l + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores are in L2 before its next loads
+  }
+  return resolved;
+}
+
 // Resolve of one group straight from global memory: every candidate's state is fetched again for every visiting
 // node.  Only used for groups whose neighbourhood does not fit the LDS staging of k_collide (dense pile-ups).
-PIES_DEV uint32_t collide_group_global(const HashArrays& H, float* pos, float* vel, const float* __restrict__ radius, uint32_t gslot,
-                                       int lane, const LaneRole role, float friction, float staticThreshold) {
+PIES_DEV uint32_t collide_group_global(const HashArrays& H, const GridBox& B, const uint32_t* __restrict__ val, float* pos, float* vel,
+                                       const float* __restrict__ radius, uint32_t gslot, int lane, const LaneRole role, float friction,
+                                       float staticThreshold) {
   uint32_t resolved = 0;
-  const uint32_t gs = H.gstart[gslot], gc = H.gcnt[gslot];
-  for (uint32_t k = 0; k < gc; ++k) {
-    const uint32_t i = H.groupSorted[gs + k];
+  const uint32_t gs = H.start[gslot], gn = H.end[gslot] - gs;
+  for (uint32_t ge = next_min_entry(val, gs, gn, 0, lane); ge < gn; ge = next_min_entry(val, gs, gn, ge + 1, lane)) {
+    const uint32_t i = val[gs + ge] & kNodeMask;
     PairState a = {ld(pos + 4 * i), ld(pos + 4 * i + 1), ld(pos + 4 * i + 2), ld(vel + 4 * i), ld(vel + 4 * i + 1), ld(vel + 4 * i + 2)};
     const float imi = ld(pos + 4 * i + 3);
     const float ri = radius[i];
@@ -219,42 +539,10 @@ PIES_DEV uint32_t collide_group_global(const HashArrays& H, float* pos, float* v
     for (uint32_t dx = 0; dx < lx; ++dx)
       for (uint32_t dy = 0; dy < ly; ++dy)
         for (uint32_t dz = 0; dz < lz; ++dz) {
-          const uint32_t cs = find_cell(H.keys, H.mask, pack_cell(rg.x + (int)dx, rg.y + (int)dy, rg.z + (int)dz));
+          const uint32_t cs = find_bucket(H, B, rg.x + (int)dx, rg.y + (int)dy, rg.z + (int)dz);
           if (cs == 0xffffffffu) continue;
-          const uint32_t bs = H.start[cs], bc = H.cnt[cs];
-          for (uint32_t base = 0; base < bc; base += 64) {
-            const bool valid = base + lane < bc;
-            const uint32_t j = valid ? H.bucketSorted[bs + base + lane] : 0xffffffffu;
-            float pjx = 0.f, pjy = 0.f, pjz = 0.f, imj = 1.f, rj = 0.f, wjx = 0.f, wjy = 0.f, wjz = 0.f;
-            if (valid) {  // candidate state up front: a resolve then needs no further loads
-              pjx = ld(pos + 4 * j); pjy = ld(pos + 4 * j + 1); pjz = ld(pos + 4 * j + 2); imj = ld(pos + 4 * j + 3);
-              wjx = ld(vel + 4 * j); wjy = ld(vel + 4 * j + 1); wjz = ld(vel + 4 * j + 2);
-              rj = radius[j];
-            }
-            int cursor = 0;
-            for (;;) {
-              if (valid && j == i) { pjx = a.pix; pjy = a.piy; pjz = a.piz; }  // the self pair sees the node's current position
-              const float ddx = pjx - a.pix, ddy = pjy - a.piy, ddz = pjz - a.piz;
-              const float dist = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
-              const float disp = ri + rj - dist;
-              const bool hit = valid && lane >= cursor && disp > 0.0f;
-              const unsigned long long m = __ballot(hit);
-              if (m == 0ull) break;
-              const int l = __builtin_ctzll(m);
-              const uint32_t hj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(j), l));
-              float ojx, ojy, ojz, vjx, vjy, vjz;
-              resolve_pair(a, imi, hj == i, bcast(ddx, l), bcast(ddy, l), bcast(ddz, l), bcast(dist, l), bcast(disp, l), bcast(imj, l),
-                           bcast(pjx, l), bcast(pjy, l), bcast(pjz, l), bcast(wjx, l), bcast(wjy, l), bcast(wjz, l), friction,
-                           staticThreshold, role, ojx, ojy, ojz, vjx, vjy, vjz);
-              if (hj != i && lane == l) {
-                st(pos + 4 * hj, ojx); st(pos + 4 * hj + 1, ojy); st(pos + 4 * hj + 2, ojz);
-                st(vel + 4 * hj, vjx); st(vel + 4 * hj + 1, vjy); st(vel + 4 * hj + 2, vjz);
-              }
-              ++resolved;
-              cursor = l + 1;
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores are in L2 before its next loads
-          }
+          const uint32_t bs = H.start[cs];
+          resolved += collide_bucket_global(val, bs, H.end[cs] - bs, i, a, imi, ri, pos, vel, radius, lane, role, friction, staticThreshold);
         }
     if (lane == 0) {
       st(pos + 4 * i, a.pix); st(pos + 4 * i + 1, a.piy); st(pos + 4 * i + 2, a.piz);
@@ -283,7 +571,9 @@ constexpr uint32_t kColSlots = PIES_COL_SLOTS;       // table capacity per wavef
 constexpr uint32_t kColMaxUnique = PIES_COL_MAX_UNIQUE;   // live entries allowed: an interior group of BASELINE config 4 (spacing 0.9, cells of 2.0) sees 216-343 distinct nodes
 constexpr uint32_t kColMaxEntries = 1024; // bucket entries of the 8 cells
 constexpr uint32_t kColEmpty = 0xffffffffu, kColDirty = 0x80000000u;
-constexpr uint32_t kColMaxSpins = 1u << 18;  // polls of one completion stamp before the wait is declared dead (~0.3 s)
+constexpr uint32_t kColMaxSpins = 1u << 18;  // default polls of one completion stamp before the wait is declared dead (~0.3 s);
+                                             // PIES_COLLIDE_SPIN_LIMIT overrides it (0 = wait for ever; PIES_PROFILER_SAFE=1 implies 0:
+                                             // counter collection serialises and slows the launch)
 struct ColTable {
   uint32_t key[kColSlots];  // node index | kColDirty
   float px[kColSlots], py[kColSlots], pz[kColSlots], im[kColSlots], vx[kColSlots], vy[kColSlots], vz[kColSlots], r[kColSlots];
@@ -301,17 +591,18 @@ PIES_DEV uint32_t col_find(const uint32_t* key, uint32_t j) {  // j is present
 // One group on the staged path (or, for a dense neighbourhood, the unstaged one).  Node state is read and written
 // through agent-scope (sc1) loads and stores: in k_collide_flow the previous owner of a node may be a wavefront
 // of the same launch on another XCD.  Returns the number of resolved pairs.
-PIES_DEV uint32_t collide_group(const HashArrays& H, ColTable& T, float* pos, float* vel, const float* __restrict__ radius, uint32_t gslot,
-                                int lane, const LaneRole role, float friction, float staticThreshold, int forceGlobal) {
+PIES_DEV uint32_t collide_group(const HashArrays& H, const GridBox& B, const uint32_t* __restrict__ val, ColTable& T, float* pos, float* vel,
+                                const float* __restrict__ radius, uint32_t gslot, int lane, const LaneRole role, float friction,
+                                float staticThreshold, int forceGlobal) {
   uint32_t resolved = 0;
-  const uint32_t gs = H.gstart[gslot], gc = H.gcnt[gslot];
-  if (gc == 0) return 0;
+  if (H.gcnt[gslot] == 0) return 0;
   // ---- the 2x2x2 cells above the group's cell: lanes 0..7 look one up each ------------------------------
-  const int4 rg0 = H.rng[H.groupSorted[gs]];
+  int gx, gy, gz;
+  box_cell(B, H.keys[gslot], gx, gy, gz);
   uint32_t myStart = 0, myCnt = 0;
   if (lane < 8) {
-    const uint32_t cs = find_cell(H.keys, H.mask, pack_cell(rg0.x + ((lane >> 2) & 1), rg0.y + ((lane >> 1) & 1), rg0.z + (lane & 1)));
-    if (cs != 0xffffffffu) { myStart = H.start[cs]; myCnt = H.cnt[cs]; }
+    const uint32_t cs = find_bucket(H, B, gx + ((lane >> 2) & 1), gy + ((lane >> 1) & 1), gz + (lane & 1));
+    if (cs != 0xffffffffu) { myStart = H.start[cs]; myCnt = H.end[cs] - myStart; }
   }
   uint32_t cStart[8], cCnt[8], cOff[9];
   cOff[0] = 0;
@@ -330,7 +621,7 @@ PIES_DEV uint32_t collide_group(const HashArrays& H, ColTable& T, float* pos, fl
       for (uint32_t base = 0; base < cCnt[c] && staged; base += 64) {
         bool fresh = false;
         if (base + lane < cCnt[c]) {
-          const uint32_t j = H.bucketSorted[cStart[c] + base + lane];
+          const uint32_t j = val[cStart[c] + base + lane] & kNodeMask;
           uint32_t h = col_hash(j);
           for (;;) {  // at most kColMaxUnique + 64 live entries: the probe ends
             const uint32_t old = atomicCAS(&T.key[h], kColEmpty, j);
@@ -346,7 +637,7 @@ PIES_DEV uint32_t collide_group(const HashArrays& H, ColTable& T, float* pos, fl
     }
   }
   if (!staged) {
-    return collide_group_global(H, pos, vel, radius, gslot, lane, role, friction, staticThreshold);
+    return collide_group_global(H, B, val, pos, vel, radius, gslot, lane, role, friction, staticThreshold);
   }
   for (uint32_t t = lane; t < kColSlots; t += 64) {
     const uint32_t j = T.key[t];
@@ -356,8 +647,9 @@ PIES_DEV uint32_t collide_group(const HashArrays& H, ColTable& T, float* pos, fl
     T.r[t] = radius[j];
   }
   // ---- the visiting order of collide_group_global on the staged copies -----------------------------------
-  for (uint32_t k = 0; k < gc; ++k) {
-    const uint32_t i = H.groupSorted[gs + k];
+  // (the group's own cell is cell 0 of the eight)
+  for (uint32_t ge = next_min_entry(val, cStart[0], cCnt[0], 0, lane); ge < cCnt[0]; ge = next_min_entry(val, cStart[0], cCnt[0], ge + 1, lane)) {
+    const uint32_t i = val[cStart[0] + ge] & kNodeMask;
     const uint32_t si = col_find(T.key, i);
     PairState a = {T.px[si], T.py[si], T.pz[si], T.vx[si], T.vy[si], T.vz[si]};
     const float imi = T.im[si], ri = T.r[si];
@@ -435,10 +727,12 @@ __global__ void __launch_bounds__(kColBlock) k_collide(HashArrays H, float4* pos
   const LaneRole role = {lane % 3, lane / 3};
   const uint32_t wave = (blockIdx.x * kColBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kColBlock) >> 6;
   if (H.counters[3]) return;  // failed: the host latches _simFailed
+  const GridBox B = grid_box(H.counters);
+  const uint32_t* __restrict__ val = H.val[grid_passes(B) & 1u];
   const uint32_t ngroups = H.counters[4 + pass];
   uint32_t resolved = 0;  // statistics, one atomic per wave at the end (a per-pair atomic on one word serialises the chip)
   for (uint32_t g = wave; g < ngroups; g += nwaves)
-    resolved += collide_group(H, T, pos, vel, radius, H.passList[static_cast<size_t>(pass) * H.n + g], lane, role, friction,
+    resolved += collide_group(H, B, val, T, pos, vel, radius, H.passList[static_cast<size_t>(pass) * H.n + g], lane, role, friction,
                               staticThreshold, forceGlobal);
   if (lane == 0 && resolved) atomicAdd(&H.counters[31], resolved);
 }
@@ -451,7 +745,7 @@ __global__ void __launch_bounds__(kColBlock) k_collide(HashArrays H, float4* pos
 // after each pass (a pass lasted as long as its slowest group, with ~1.7 wavefronts per SIMD).
 PIES_DEV uint32_t ldu(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __global__ void __launch_bounds__(kColBlock) k_collide_flow(HashArrays H, float4* pos4, float4* vel4, const float* __restrict__ radius,
-                                                            float friction, float staticThreshold, int forceGlobal) {
+                                                            float friction, float staticThreshold, int forceGlobal, uint32_t maxSpins) {
   __shared__ ColTable tables[kColBlock / 64];
   ColTable& T = tables[threadIdx.x >> 6];
   float* pos = reinterpret_cast<float*>(pos4);
@@ -459,6 +753,8 @@ __global__ void __launch_bounds__(kColBlock) k_collide_flow(HashArrays H, float4
   const int lane = threadIdx.x & 63;
   const LaneRole role = {lane % 3, lane / 3};
   if (H.counters[3]) return;
+  const GridBox B = grid_box(H.counters);
+  const uint32_t* __restrict__ val = H.val[grid_passes(B) & 1u];
   const uint32_t epoch = H.counters[kCounterEpoch];
   // inclusive prefix of the groups per pass, lane p holding pass p
   uint32_t incl = lane < 27 ? H.counters[4 + lane] : 0u;
@@ -478,59 +774,144 @@ __global__ void __launch_bounds__(kColBlock) k_collide_flow(HashArrays H, float4
     const uint32_t before = pass ? static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), pass - 1)) : 0u;
     const uint32_t gslot = H.passList[static_cast<size_t>(pass) * H.n + (ticket - before)];
     // ---- wait for the conflicting groups of earlier passes -------------------------------------------------
-    const uint64_t key = H.keys[gslot];
-    const int x = static_cast<int>((key >> 42) & 0x1fffff) - kCoordBias, y = static_cast<int>((key >> 21) & 0x1fffff) - kCoordBias,
-              z = static_cast<int>(key & 0x1fffff) - kCoordBias;
+    int x, y, z;
+    box_cell(B, H.keys[gslot], x, y, z);
     bool gaveUp = false;
     for (int q = lane; q < 125; q += 64) {
       const int dx = q % 5 - 2, dy = (q / 5) % 5 - 2, dz = q / 25 - 2;
       if (dx == 0 && dy == 0 && dz == 0) continue;
       const uint32_t other = static_cast<uint32_t>(mod3(x + dx) + 3 * mod3(y + dy) + 9 * mod3(z + dz));
       if (other >= pass) continue;
-      const uint32_t os = find_cell(H.keys, H.mask, pack_cell(x + dx, y + dy, z + dz));
+      const uint32_t os = find_bucket(H, B, x + dx, y + dy, z + dz);
       if (os == 0xffffffffu || H.gcnt[os] == 0u) continue;
       uint32_t spins = 0;
       while (ldu(H.done + os) != epoch) {
         __builtin_amdgcn_s_sleep(2);
-        if ((++spins & 255u) == 0u && (spins > kColMaxSpins || ldu(H.counters + 3))) { gaveUp = true; break; }
+        if ((++spins & 255u) == 0u && ((maxSpins && spins > maxSpins) || ldu(H.counters + 3))) { gaveUp = true; break; }
       }
     }
     if (__ballot(gaveUp)) {  // a predecessor never finished (or the simulation failed elsewhere): latch and leave
       if (lane == 0) atomicOr(&H.counters[3], 8u);
       break;
     }
-    resolved += collide_group(H, T, pos, vel, radius, gslot, lane, role, friction, staticThreshold, forceGlobal);
-    if (lane == 0) __hip_atomic_store(H.done + gslot, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the stamps were polled relaxed; this fence orders every later load of the wavefront after them (pairs with the
+    // release store below): the predecessors' node writes are visible by the memory model, not by cache behaviour
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    resolved += collide_group(H, B, val, T, pos, vel, radius, gslot, lane, role, friction, staticThreshold, forceGlobal);
+    if (lane == 0) __hip_atomic_store(H.done + gslot, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (lane == 0 && resolved) atomicAdd(&H.counters[31], resolved);
+}
+
+
+// The reference's loop as it stands (Solver.cpp:85-130, SpatialHash.h:101-127): nodes in ascending index; a node's
+// cell range comes from its position when its turn starts (the node may have been moved by earlier pairs of this
+// pass), buckets are those of the grid built at the start of the iteration, visited in dx, dy, dz order.  The loop is
+// one dependent chain: one wavefront runs it.  Lanes look up to 64 cells of the range at once.
+__global__ void __launch_bounds__(64) k_collide_reference(HashArrays H, float4* pos4, float4* vel4, const float* __restrict__ radius, uint32_t n,
+                                                          float scale, float friction, float staticThreshold) {
+  if (H.counters[kCounterFlags]) return;  // failed: the host latches _simFailed
+  float* pos = reinterpret_cast<float*>(pos4);
+  float* vel = reinterpret_cast<float*>(vel4);
+  const int lane = threadIdx.x & 63;
+  const LaneRole role = {lane % 3, lane / 3};
+  const GridBox B = grid_box(H.counters);
+  const uint32_t* __restrict__ val = H.val[grid_passes(B) & 1u];
+  uint32_t resolved = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    PairState a = {ld(pos + 4 * i), ld(pos + 4 * i + 1), ld(pos + 4 * i + 2), ld(vel + 4 * i), ld(vel + 4 * i + 1), ld(vel + 4 * i + 2)};
+    const float imi = ld(pos + 4 * i + 3);
+    const float ri = radius[i];
+    int mx, my, mz;
+    uint32_t lx, ly, lz;
+    if (!node_range(a.pix, a.piy, a.piz, ri, scale, mx, my, mz, lx, ly, lz)) {
+      if (lane == 0) atomicOr(&H.counters[kCounterFlags], 1u);
+      break;
+    }
+    const uint32_t ncell = lx * ly * lz;
+    for (uint32_t cbase = 0; cbase < ncell; cbase += 64) {
+      const uint32_t c = cbase + static_cast<uint32_t>(lane);
+      uint32_t myStart = 0, myCnt = 0;
+      if (c < ncell) {  // cell c of the range, dz fastest (SpatialHash.h:108-125)
+        const uint32_t dz = c % lz, dy = (c / lz) % ly, dx = c / (lz * ly);
+        const uint32_t cs = find_bucket(H, B, mx + static_cast<int>(dx), my + static_cast<int>(dy), mz + static_cast<int>(dz));
+        if (cs != 0xffffffffu) { myStart = H.start[cs]; myCnt = H.end[cs] - myStart; }
+      }
+      const uint32_t here = min(64u, ncell - cbase);
+      for (uint32_t q = 0; q < here; ++q) {
+        const uint32_t bs = static_cast<uint32_t>(__shfl(static_cast<int>(myStart), static_cast<int>(q), 64));
+        const uint32_t bc = static_cast<uint32_t>(__shfl(static_cast<int>(myCnt), static_cast<int>(q), 64));
+        if (bc) resolved += collide_bucket_global(val, bs, bc, i, a, imi, ri, pos, vel, radius, lane, role, friction, staticThreshold);
+      }
+    }
+    if (lane == 0) {
+      st(pos + 4 * i, a.pix); st(pos + 4 * i + 1, a.piy); st(pos + 4 * i + 2, a.piz);
+      st(vel + 4 * i, a.vix); st(vel + 4 * i + 1, a.viy); st(vel + 4 * i + 2, a.viz);
+      if ((i & 1023u) == 0u) H.counters[kCounterProgress] = i;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (lane == 0 && resolved) atomicAdd(&H.counters[kCounterPairs], resolved);
+}
+
+// resets the work queue of k_collide_flow without a new hash build (profile replays)
+__global__ void k_collide_rearm(HashArrays H) {
+  if (threadIdx.x == 0) {
+    H.counters[kCounterTicket] = 0;
+    H.counters[kCounterEpoch] += 1;
+  }
 }
 
 // ----------------------------------------------------------------------------------------------------
 uint32_t launch_hash_build(hipStream_t st_, const HashArrays& H, const NodeArrays& nd, float scale) {
   if (nd.n == 0) return 0;
+  const uint32_t n = nd.n;
+  uint32_t launches = 0;
   const dim3 wide(std::min<uint32_t>(2048u, (H.capacity / 8 + kBlock - 1) / kBlock));
-  hipLaunchKernelGGL(k_hash_reset, wide, dim3(kBlock), 0, st_, H);
-  hipLaunchKernelGGL(k_hash_zero, dim3(1), dim3(64), 0, st_, H);
-  hipLaunchKernelGGL(k_hash_count, grid_for(nd.n), dim3(kBlock), 0, st_, H, nd.pos, nd.radius, nd.n, scale);
-  hipLaunchKernelGGL(k_hash_alloc, wide, dim3(kBlock), 0, st_, H);
-  hipLaunchKernelGGL(k_hash_fill, grid_for(nd.n), dim3(kBlock), 0, st_, H, nd.n);
-  hipLaunchKernelGGL(k_hash_sort, wide, dim3(kBlock), 0, st_, H);
-  return 6;
+  hipLaunchKernelGGL(k_grid_reset, wide, dim3(kBlock), 0, st_, H); ++launches;
+  hipLaunchKernelGGL(k_grid_zero, dim3(1), dim3(64), 0, st_, H); ++launches;
+  hipLaunchKernelGGL(k_grid_range, grid_for(n + 1), dim3(kBlock), 0, st_, H, nd.pos, nd.radius, n, scale); ++launches;
+  const uint32_t m = n + 1, tiles = (m + kScanTile - 1) / kScanTile;
+  hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kBlock), 0, st_, H.entCount, H.entOff, m, H.scanSums); ++launches;
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st_, H.scanSums, tiles); ++launches;
+  hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kBlock), 0, st_, H.entOff, m, H.scanSums); ++launches;
+  hipLaunchKernelGGL(k_grid_emit, grid_for(n), dim3(kBlock), 0, st_, H, n); ++launches;
+  const uint32_t nblkMax = (H.maxEntries + kRadixTile - 1) / kRadixTile;
+  for (uint32_t pass = 0; pass < 8; ++pass) {  // passes beyond the key width exit at once
+    hipLaunchKernelGGL(k_radix_hist, dim3(nblkMax), dim3(kBlock), 0, st_, H, pass, nblkMax);
+    hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, st_, H, pass, nblkMax);
+    hipLaunchKernelGGL(k_radix_scatter, dim3(nblkMax), dim3(kBlock), 0, st_, H, pass, nblkMax);
+    launches += 3;
+  }
+  hipLaunchKernelGGL(k_grid_cells, grid_for(H.maxEntries), dim3(kBlock), 0, st_, H); ++launches;
+  hipLaunchKernelGGL(k_grid_groups, wide, dim3(kBlock), 0, st_, H); ++launches;
+  return launches;
 }
 
-uint32_t launch_collide(hipStream_t st_, const HashArrays& H, const NodeArrays& nd, float friction, float staticThreshold) {
+uint32_t launch_collide(hipStream_t st_, const HashArrays& H, const NodeArrays& nd, float friction, float staticThreshold, bool rearm) {
   if (nd.n == 0) return 0;
   const dim3 grid(std::max<uint32_t>(1u, std::min<uint32_t>(2048u, (nd.n / 8 + 1) / 2)));
   auto flag = [](const char* name) { const char* e = std::getenv(name); return e && e[0] == '1' ? 1 : 0; };
   const int forceGlobal = flag("PIES_COLLIDE_GLOBAL");  // diagnostics, read when the substep is captured
   const int passes = flag("PIES_COLLIDE_PASSES");
   if (!passes) {
-    hipLaunchKernelGGL(k_collide_flow, grid, dim3(kColBlock), 0, st_, H, nd.pos, nd.vel, nd.radius, friction, staticThreshold, forceGlobal);
+    uint32_t maxSpins = kColMaxSpins;
+    if (const char* e = std::getenv("PIES_COLLIDE_SPIN_LIMIT")) maxSpins = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+    else if (flag("PIES_PROFILER_SAFE")) maxSpins = 0;
+    if (rearm) hipLaunchKernelGGL(k_collide_rearm, dim3(1), dim3(64), 0, st_, H);
+    hipLaunchKernelGGL(k_collide_flow, grid, dim3(kColBlock), 0, st_, H, nd.pos, nd.vel, nd.radius, friction, staticThreshold, forceGlobal,
+                       maxSpins);
     return 1;
   }
   for (uint32_t pass = 0; pass < 27; ++pass)
     hipLaunchKernelGGL(k_collide, grid, dim3(kColBlock), 0, st_, H, nd.pos, nd.vel, nd.radius, pass, friction, staticThreshold, forceGlobal);
   return 27;
+}
+
+uint32_t launch_collide_reference(hipStream_t st_, const HashArrays& H, const NodeArrays& nd, float scale, float friction, float staticThreshold) {
+  if (nd.n == 0) return 0;
+  hipLaunchKernelGGL(k_collide_reference, dim3(1), dim3(64), 0, st_, H, nd.pos, nd.vel, nd.radius, nd.n, scale, friction, staticThreshold);
+  return 1;
 }
 
 }  // namespace pies

@@ -312,19 +312,20 @@ hipError_t layer_prepare(uint32_t maxGroupNodes) {
 
 void launch_layer(hipStream_t st, const NodeArrays& nd, const LayerData& D, const LayerLaunch& L0, const LayerParams& P) {
   if (L0.groups == 0 || L0.nseg == 0) return;
-  // timing experiments / tests: read at every capture (a launch is recorded into the substep graph once)
-  const int skipMask = [] { const char* e = getenv("PIES_EXP_LAYER_SKIP"); return e ? atoi(e) : 0; }();
   LayerLaunch L = L0;
+  const size_t lds = layer_lds_bytes(D.maxGroupNodes);
+#ifdef PIES_EXPERIMENTS  // timing experiments that change the work done: never part of the product build (build.py)
+  const int skipMask = [] { const char* e = getenv("PIES_EXP_LAYER_SKIP"); return e ? atoi(e) : 0; }();
   if (skipMask) {
     L.nseg = 0;
     for (uint32_t s = 0; s < L0.nseg; ++s)
       if (!((skipMask >> L0.seg[s].kind) & 1)) L.seg[L.nseg++] = L0.seg[s];
   }
-  const size_t lds = layer_lds_bytes(D.maxGroupNodes);
   const int variant = [] { const char* e = getenv("PIES_EXP_TET"); return e ? atoi(e) : 0; }();
-  const uint32_t forceBlock = [] { const char* e = getenv("PIES_LAYER_BLOCK"); return e ? (uint32_t)atoi(e) : 0u; }();
+  if (variant == 1) { hipLaunchKernelGGL((k_layer<256, 1>), dim3(L.groups), dim3(256), lds, st, nd, D, L, P); return; }  // no SVD
+#endif
+  const uint32_t forceBlock = [] { const char* e = getenv("PIES_LAYER_BLOCK"); return e ? (uint32_t)atoi(e) : 0u; }();  // speed only
   const uint32_t want = forceBlock ? forceBlock : L.maxClass;
-  if (variant == 1) { hipLaunchKernelGGL((k_layer<256, 1>), dim3(L.groups), dim3(256), lds, st, nd, D, L, P); return; }  // experiment: no SVD
   if (want <= 256) hipLaunchKernelGGL((k_layer<256, 0>), dim3(L.groups), dim3(256), lds, st, nd, D, L, P);
   else if (want <= 512) hipLaunchKernelGGL((k_layer<512, 0>), dim3(L.groups), dim3(512), lds, st, nd, D, L, P);
   else hipLaunchKernelGGL((k_layer<1024, 0>), dim3(L.groups), dim3(1024), lds, st, nd, D, L, P);

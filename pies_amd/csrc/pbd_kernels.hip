@@ -205,8 +205,10 @@ void launch_distance(hipStream_t st, float4* pos, const uint2* ids, const float2
 void launch_tet(hipStream_t st, float4* pos, const uint4* ids, const float4* q0, const float4* q1, const float4* q2,
                 uint32_t start, uint32_t count) {
   if (count == 0) return;
+#ifdef PIES_EXPERIMENTS  // timing experiments that change the arithmetic: never part of the product build (build.py)
   static const int variant = [] { const char* e = getenv("PIES_EXP_TET"); return e ? atoi(e) : 0; }();
   if (variant == 1) { PIES_LAUNCH(k_tet<1>, kProjBlock, count, st, pos, ids, q0, q1, q2, start, count); return; }
+#endif
   PIES_LAUNCH(k_tet<0>, kProjBlock, count, st, pos, ids, q0, q1, q2, start, count);
 }
 void launch_bend(hipStream_t st, float4* pos, const uint4* ids, const float2* angle_w, uint32_t start, uint32_t count) {

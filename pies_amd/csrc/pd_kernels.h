@@ -38,7 +38,9 @@ struct CgArrays {
   float4* cAp;
   int useCAp;
   float* scal;   // rz[2][3], bb[3], iterations
-  float* stats;  // max relative residual^2 over the tick's solves, max iterations, number of solves
+  float* stats;  // over the tick: [0] max relative residual^2 of its solves, [1] max iterations, [2] solves, [3] solves that ended
+                 // above the tolerance; since the buffers were built: [4] solves above the tolerance, [5] solves
+  float tol2;    // squared relative tolerance of the solve whose statistics are being closed
 };
 
 // ShapeMatchingConstraint data (fp64 like the reference) and the fp64 contribution slots of shape and
@@ -85,8 +87,10 @@ void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd);
 // part: -1 = the solve; profile passes: 1 = the SpMV (+ direction update) kernels only, 0 = the vector-update kernels only
 // first / last: the first and the last solve of a substep (a solve's statistics are closed by the next solve's first
 // kernel, the last one's by a launch of its own)
+// neverExit: the iterations do not take the converged early exit (in-situ timing); hook(ctx, class) is called before and
+// after every k_cg_ap (PIES_KERNEL_PD_SPMV) and k_cg_update (PIES_KERNEL_PD_CG_UPDATE) launch
 void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, int maxIters, float tol, int part = -1, bool first = true,
-                     bool last = true);
+                     bool last = true, bool neverExit = false, void (*hook)(void*, int) = nullptr, void* hookCtx = nullptr);
 void launch_pd_stabilize(hipStream_t st, const NodeArrays& nd, const PdArrays& pd);
 // staticFriction = false leaves the floor friction (Solver.cpp:473-484) to launch_pd_static_friction, which the
 // reference runs after the point-triangle friction

@@ -576,15 +576,21 @@ PIES_DEV void solve_statistics(const CgArrays& A, const float* __restrict__ prev
   block_reduce_partials<6>(prevPartB, 6, A.nparts, red);
   if (threadIdx.x == 0) {
     float worst = 0.f;
+    bool above = false;  // the very test the CG kernels take their early exit on (all_converged)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float bb = A.scal[6 + c];
       const float rel = bb > 0.f ? red[3 + c] / bb : 0.f;
       worst = fmaxf(worst, rel);
+      above = above || !(red[3 + c] <= A.tol2 * bb);
     }
     A.stats[0] = fmaxf(A.stats[0], worst);  // max over solves of ||r||^2 / ||b||^2
     A.stats[1] = fmaxf(A.stats[1], A.scal[9]);
     A.stats[2] += 1.0f;
+    const float ranShort = above ? 1.0f : 0.0f;  // the solve used its whole captured budget and is still above the tolerance
+    A.stats[3] += ranShort;
+    A.stats[4] += ranShort;
+    A.stats[5] += 1.0f;
   }
 }
 
@@ -954,7 +960,8 @@ void launch_pd_local_shape(hipStream_t st, const float4* pos, const PdArrays& pd
   if (pd.shape.count == 0) return;
   hipLaunchKernelGGL(k_pd_local_shape, dim3(pd.shape.count), dim3(kBlock), 0, st, pos, pd.shape, pd.contribD);
 }
-void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, int maxIters, float tol, int part, bool first, bool last) {
+void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, int maxIters, float tol, int part, bool first, bool last,
+                     bool neverExit, void (*hook)(void*, int), void* hookCtx) {
   if (nd.n == 0) return;
   CgArrays A = pd.cg;
   const dim3 grid(A.nparts), block(kBlock);
@@ -965,7 +972,8 @@ void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, i
     }
     return;
   }
-  const float tol2 = tol * tol;
+  const float tol2 = neverExit ? -1.0f : tol * tol;
+  A.tol2 = tol * tol;
   float* pb[2] = {pd.cg.partB, pd.cg.partBnext};
   // every solve of a substep runs the same number of iterations, so the previous solve left its final partials here
   const bool rows = A.useCAp && A.tIncCnt;
@@ -976,8 +984,11 @@ void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, i
     A.partB = pb[k & 1];       // residual partials of iteration k (k = 0 reads partI instead)
     A.partBnext = pb[(k + 1) & 1];
     if (rows) hipLaunchKernelGGL(k_contact_rows<1>, rgrid, block, 0, st, A, nd.pos, k, tol2);
+    if (hook) hook(hookCtx, 14);  // PIES_KERNEL_PD_SPMV
     hipLaunchKernelGGL(k_cg_ap, grid, block, 0, st, A, k, tol2);
+    if (hook) { hook(hookCtx, 14); hook(hookCtx, 15); }  // PIES_KERNEL_PD_CG_UPDATE
     hipLaunchKernelGGL(k_cg_update, grid, block, 0, st, A, nd.pos, k, tol2);
+    if (hook) hook(hookCtx, 15);
   }
   if (!last) return;
   A.partB = pb[maxIters & 1];

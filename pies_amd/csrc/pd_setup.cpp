@@ -214,7 +214,7 @@ int pd_build(pies_solver* s) {
   if (int rc = dev_alloc(s, kCgBlocks * 6, &cg.partB, true)) return rc;
   if (int rc = dev_alloc(s, kCgBlocks * 6, &cg.partBnext, true)) return rc;
   if (int rc = dev_alloc(s, 16, &cg.scal, true)) return rc;
-  if (int rc = dev_alloc(s, 4, &cg.stats, true)) return rc;
+  if (int rc = dev_alloc(s, 8, &cg.stats, true)) return rc;
   // ---- point-triangle contact pipeline (Solver.cpp:680-875) ------------------------------------------------
   pd.tri = TriArrays{};
   cg.tIncCnt = cg.tIncStart = cg.tInc = nullptr;

@@ -120,6 +120,24 @@ struct LayerDevice {
   uint2* bc_lid = nullptr;
 };
 
+// In-situ timing of one kernel class (pies_profile_in_situ): whole substeps are launched eagerly and every launch of the
+// class is bracketed by two events on the solver's stream.
+struct Probe {
+  int kernel = -1;
+  hipStream_t stream = nullptr;
+  std::vector<hipEvent_t> events;  // begin, end, begin, end, ...
+  size_t used = 0;
+  bool failed = false;
+  void mark() {
+    if (used == events.size()) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreate(&e) != hipSuccess) { failed = true; return; }
+      events.push_back(e);
+    }
+    if (hipEventRecord(events[used++], stream) != hipSuccess) failed = true;
+  }
+};
+
 template <class T> struct DevArray {
   T* p = nullptr;
   size_t n = 0;
@@ -135,10 +153,12 @@ struct pies_solver {
 
   bool releaseHinge = false;
   bool nodeCollisions = true;
+  bool collideFast = true;         // every node's cell range spans at most 2 cells per axis: the parallel visiting order may run
   bool tetVolumePaired = false;    // PD: h_volume[k] and h_tet[k] are the same element for every k (fused local step)
   bool triangleCollisions = true;  // PD point-triangle CCD contacts (Solver.cpp:693-797); extension flag to switch off
   bool simFailed = false;
-  int schedule = PIES_SCHEDULE_EXACT;
+  int schedule = PIES_SCHEDULE_DEFAULT;
+  int collisionOrderFlag = -1;     // PIES_FLAG_REFERENCE_COLLISION_ORDER: -1 follows the schedule (EXACT: reference order)
 
   // ---- host mirror ----
   std::vector<float> h_pos, h_prev, h_vel;  // n x 3
@@ -156,7 +176,10 @@ struct pies_solver {
   uint32_t constraintId = 0;
 
   bool sceneDirty = true;    // topology/rest data changed: rebuild plans + upload everything
-  bool deviceAhead = false;  // device node state is newer than the host mirror
+  // which host mirror arrays are older than the device's (bit 0 positions, 1 previous positions, 2 velocities):
+  // a read of one array copies that array only, through the pinned staging buffer
+  uint32_t stale = 0;
+  bool graphDirty = false;   // only the launch sequence changed (releaseHinge, CG budget): re-capture, no re-upload
   bool hostNodesDirty = false;  // host node state edited (pies_write_nodes): upload nodes only
 
   // ---- plans ----
@@ -198,11 +221,27 @@ struct pies_solver {
   std::vector<void*> allocations;
   float4* h_stage = nullptr;  // pinned staging for the per-tick position read-back
   size_t h_stage_n = 0;
+  // ---- render-state export (Solver.h:42-71): frame k is copied out while frame k+1 computes ----
+  hipStream_t copyStream = nullptr;
+  hipEvent_t evTick[2] = {nullptr, nullptr};    // frame's positions are in d_export
+  hipEvent_t evCopied[2] = {nullptr, nullptr};  // frame's positions are in h_export[frame & 1]
+  float4* h_export[2] = {nullptr, nullptr};     // pinned
+  size_t h_export_n = 0;
+  float4* d_export = nullptr;
+  uint64_t frameBegun = 0;      // frames begun so far (frame ids start at 1)
+  uint64_t frameAcquired = 0;   // frame the host currently holds (0: none)
+  // ---- PD: a substep whose solve ends above the tolerance is run again with a larger CG budget (pies_tick) ----
+  float4 *snapPos = nullptr, *snapPrev = nullptr, *snapVel = nullptr;
+  double* snapQuat = nullptr;
+  bool pcgRetry = true;
+  uint32_t pcgRetries = 0;         // substeps run again since the handle was created
+  uint64_t pcgShortSolves = 0;     // solves left above the tolerance (budget at its ceiling, or asynchronous ticks)
 
   hipGraph_t graph = nullptr;
   hipGraphExec_t graphExec = nullptr;
   std::vector<std::pair<hipGraph_t, hipGraphExec_t>> retiredGraphs;  // profile-pass graphs, freed with the handle
   uint32_t launchCounts[PIES_KERNEL_COUNT] = {};
+  pies::Probe* probe = nullptr;  // set for the duration of pies_profile_in_situ
 
   uint32_t nodeCount() const { return static_cast<uint32_t>(h_radius.size()); }
 };

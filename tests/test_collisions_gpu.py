@@ -1,8 +1,11 @@
 """GPU parity of the PBD node-node collision pass (Src/Solver.cpp:81-130, SpatialHash.h, NodeCompRange).
 
-The reference loop is order dependent; the device visits nodes in its documented pass order (DESIGN.md
-"Node-node collisions") and the oracle replays that rule (flag 2 = 1) with the reference's per-pair
-arithmetic, so positions and velocities are expected to agree bit for bit.  Gate: 1e-5 * spacing."""
+The reference loop is order dependent.  The device has two orders:
+  * rule 0 - the reference's own loop (ascending node index, cell range from the node's current position), run as one
+    sequential chain; the default under PIES_SCHEDULE_EXACT, compared with the oracle's UNMODIFIED loop (rule 0);
+  * rule 1 - the parallel visiting order of DESIGN.md "Node-node collisions", which the oracle replays (flag 2 = 1) with
+    the reference's per-pair arithmetic.
+In both, positions and velocities are expected to agree bit for bit.  Gate: 1e-5 * spacing."""
 import numpy as np
 import pytest
 
@@ -27,9 +30,13 @@ def pair(pies, oracle, build, iterations, ticks, rule=1, **opt):
     for s in (g, o):
         build(s)
     o.set_flag(oracle.FLAG_COLLISION_RULE, rule)
+    g.set_flag(pies.FLAG_REFERENCE_COLLISION_ORDER, rule == 0)
     g.tick(ticks)
     o.tick(ticks)
     return g, o
+
+
+RULES = pytest.mark.parametrize("rule", [0, 1], ids=["reference-order", "parallel-order"])
 
 
 def check(g, o, exact=True):
@@ -43,27 +50,30 @@ def check(g, o, exact=True):
     assert not g.failed
 
 
-def test_two_spheres(pies, oracle):
+@RULES
+def test_two_spheres(pies, oracle, rule):
     def build(s):
         s.addNodes([[0.0, 5, 0], [0.8, 5, 0], [7.3, 5, 1.0]])
-    g, o = pair(pies, oracle, build, 2, 3, gravity=0.0)
+    g, o = pair(pies, oracle, build, 2, 3, rule=rule, gravity=0.0)
     check(g, o)
     assert g.collision_pairs == o.collision_pairs > 0
 
 
-def test_jittered_particles_small(pies, oracle):
+@RULES
+def test_jittered_particles_small(pies, oracle, rule):
     """BASELINE config 4 in miniature: loose particles (addNodes: radius 0.5, mass 1) on a 0.9 lattice."""
     p, v = particles((6, 7, 8))
 
     def build(s):
         s.addNodes(p)
         s.set_velocities(v)
-    g, o = pair(pies, oracle, build, 4, 5)
+    g, o = pair(pies, oracle, build, 4, 5, rule=rule)
     check(g, o)
     assert g.collision_pairs == o.collision_pairs > 1000
 
 
-def test_negative_coordinates_and_mixed_radii(pies, oracle):
+@RULES
+def test_negative_coordinates_and_mixed_radii(pies, oracle, rule):
     rng = np.random.default_rng(5)
     p = rng.uniform(-6, 6, (900, 3)).astype(np.float32) + np.float32([0, 8, 0])
     r = rng.uniform(0.2, 0.5, 900).astype(np.float32)
@@ -72,13 +82,15 @@ def test_negative_coordinates_and_mixed_radii(pies, oracle):
 
     def build(s):
         s.add_nodes_raw(p, vel=v, radius=r, invMass=im)
-    g, o = pair(pies, oracle, build, 3, 4, friction=0.2, staticFrictionThreshold=0.5)
+    g, o = pair(pies, oracle, build, 3, 4, rule=rule, friction=0.2, staticFrictionThreshold=0.5)
     check(g, o)
     assert g.collision_pairs == o.collision_pairs > 0
 
 
 def test_beam_with_constraints_and_collisions(pies, oracle):
-    """The reference's default PBD tick: constraints + node-node pass + floor, every iteration."""
+    """The reference's default PBD tick: constraints + node-node pass + floor, every iteration.  Schedule EXACT is the
+    reference's order throughout - container-order sweeps AND the ascending-index collision loop - against the oracle
+    with nothing replayed; schedule COLOURED runs the exported sweep order and the parallel collision order."""
     def build(s):
         scenes.build_beam(s, (5, 4, 6), translation=(0, 0.6, 0), w_tet=0.002)
         s.set_radii(np.full(120, 0.5, np.float32))  # lattice neighbours touch; the perturbation makes them overlap
@@ -92,10 +104,26 @@ def test_beam_with_constraints_and_collisions(pies, oracle):
         if schedule == 1:
             for t in (pies.DISTANCE, pies.TET):
                 o.permute(t, g.order(t))
-        o.set_flag(oracle.FLAG_COLLISION_RULE, 1)
+        o.set_flag(oracle.FLAG_COLLISION_RULE, 0 if schedule == 0 else 1)
         g.tick(4); o.tick(4)
         check(g, o)
         assert g.collision_pairs == o.collision_pairs > 0
+        assert g.launch_counts()["collide"] == 4
+
+
+def test_config1_lattice_reference_order(pies, oracle):
+    """BASELINE config 1 (10x10x10 beam, 10 iterations) as the reference runs it by default: node-node pass on, radius
+    0.475 (neighbours 0.05 apart from touching; the perturbation makes many overlap), schedule EXACT = the reference's
+    order.  The oracle runs its plain loops."""
+    g = pies.Solver(scenes.pbd_options(pies, 10))
+    o = oracle.OracleSolver(scenes.pbd_options(oracle, 10))
+    for s in (g, o):
+        scenes.build_beam(s, scenes.L1K, w_tet=0.002, translation=(0, 0.5, 0))
+        scenes.perturb(s, 12, 0.06)
+    g.set_schedule(pies.SCHEDULE_EXACT)
+    g.tick(2); o.tick(2)
+    check(g, o)
+    assert g.collision_pairs == o.collision_pairs > 1000
 
 
 def test_device_rule_vs_reference_order_is_a_small_perturbation(oracle):
@@ -118,11 +146,21 @@ def test_device_rule_vs_reference_order_is_a_small_perturbation(oracle):
     assert com < 0.05 and ext < 0.5
 
 
-def test_unsupported_grid_spacing_is_refused(pies):
-    g = pies.Solver(scenes.pbd_options(pies, 2, gridSpacing=1.0))  # 2R = 2 > 1: ranges would span 3 cells
-    g.addNodes([[0, 5, 0], [1, 5, 0]])
-    with pytest.raises(pies.PiesError):
-        g.tick()
+@pytest.mark.parametrize("spacing", [1.0, 0.3, 0.045])
+def test_small_grid_spacing_runs_in_reference_order(pies, oracle, spacing):
+    """gridSpacing < 2 (r + 0.5): a node spans 3 and more cells per axis (NodeCompRange allows up to 50,
+    Solver.cpp:896-898; at spacing 0.045 the range is 45 cells wide for r = 0.5 and EMPTY for the larger radius, which
+    then never collides as a visiting node).  The parallel order needs ranges of at most 2 cells, so these scenes run the
+    reference's loop whatever the flag says."""
+    p, v = particles((4, 3, 5), spacing=0.8)
+    r = np.full(len(p), 0.5, np.float32)
+    r[::7] = 0.7
+
+    def build(s):
+        s.add_nodes_raw(p, vel=v, radius=r, invMass=np.ones(len(p), np.float32))
+    g, o = pair(pies, oracle, build, 2, 2, rule=0, gridSpacing=spacing)
+    check(g, o)
+    assert g.collision_pairs == o.collision_pairs > 0
 
 
 def test_config4_l500k_one_tick(pies, oracle):
@@ -152,6 +190,8 @@ def test_dense_cells_take_the_unstaged_path(pies, oracle):
     g, o = pair(pies, oracle, build, 3, 2)
     check(g, o)
     assert g.collision_pairs == o.collision_pairs > 700
+    g, o = pair(pies, oracle, build, 2, 1, rule=0)  # and the sequential chain over the same dense buckets
+    check(g, o)
 
 
 def test_resolve_variants_agree(pies, monkeypatch):

@@ -130,6 +130,7 @@ def test_floor_and_friction(pies, oracle):
 def test_sheet_position_constraints_and_release_hinge(pies, oracle):
     for hinge in (0, 1):
         g = pies.Solver(scenes.pbd_options(pies, 6))
+        g.set_schedule(pies.SCHEDULE_EXACT)  # the oracle sweeps in container order
         o = oracle.OracleSolver(scenes.pbd_options(oracle, 6))
         for s in (g, o):
             s.create_sheet(9, 7, translation=(0, 3, 0), scale=0.5, mass=2.0, w=0.7)
@@ -144,6 +145,7 @@ def test_sheet_position_constraints_and_release_hinge(pies, oracle):
 def test_bend_sheet(pies, oracle):
     # acosf differs between device libm and glibc by a few ulp: tolerance only
     g = pies.Solver(scenes.pbd_options(pies, 5))
+    g.set_schedule(pies.SCHEDULE_EXACT)
     o = oracle.OracleSolver(scenes.pbd_options(oracle, 5))
     for s in (g, o):
         s.create_bend_sheet(8, 8, translation=(0, 4, 0), scale=1.0, w=0.6)
@@ -337,6 +339,7 @@ def test_unstructured_delaunay_beam(pies, oracle, schedule):
 
 def test_empty_and_unconstrained(pies, oracle):
     g = pies.Solver(scenes.pbd_options(pies, 2))
+    g.set_schedule(pies.SCHEDULE_EXACT)
     g.set_flag(1, 0)
     g.tick()  # no nodes: no-op
     assert g.count(pies.NODES) == 0
@@ -351,6 +354,7 @@ def test_empty_and_unconstrained(pies, oracle):
 
 def test_edit_after_tick_and_substeps(pies, oracle):
     g = pies.Solver(scenes.pbd_options(pies, 3, timeSubsteps=3))
+    g.set_schedule(pies.SCHEDULE_EXACT)
     o = oracle.OracleSolver(scenes.pbd_options(oracle, 3, timeSubsteps=3))
     for s in (g, o):
         scenes.build_beam(s, (3, 3, 3))
