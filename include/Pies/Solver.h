@@ -9,11 +9,12 @@
 //
 // Differences from the reference, all documented in DESIGN.md: tick() runs on the GPU; getters return
 // host mirrors refreshed once per tick (Solver.cpp:157,393 refresh per substep, which nothing can observe);
-// addTriMeshVolume needs tetgen, which is not part of this build (use addTetMeshVolume with a
-// pre-tetrahedralised mesh); errors surface as std::runtime_error carrying pies_last_error().
+// addTriMeshVolume needs tetgen, which is not part of this build (addTetMeshVolume takes tetgen's output arrays, or
+// just elements, and does what addTriMeshVolume does after its tetrahedralize() call); errors surface as std::runtime_error carrying pies_last_error().
 // Shape/goal matching (regions, createShapeMatching*) are Projective-Dynamics constraints, as in the reference.
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -163,24 +164,76 @@ public:
     throw std::runtime_error("Pies::Solver::addTriMeshVolume needs tetgen (not part of this build): tetrahedralise offline and "
                              "call addTetMeshVolume");
   }
-  // Pre-tetrahedralised replacement for addTriMeshVolume: vertices, 4 indices per tet, 3 per boundary face.
+  // addTriMeshVolume after its tetrahedralize() call (PrimitiveUtilities.cpp:243-328), for hosts that mesh offline:
+  // `vertices`, `tetIndices` (4 per element), `triFaceIndices` (3 per face) and `face2tet` (2 per face, -1 = no element on
+  // that side) are tetgen's pointlist, tetrahedronlist, trifacelist and face2tetlist.  Like the reference: a face with an
+  // element on both sides is skipped, boundary faces become triangles with the winding SWITCHED to (v0, v2, v1) so that
+  // normals point outward (:255-266); mass = density, radius 0.5 (:176-177, :281-282); one strain and one volume
+  // constraint per element when the respective stiffness is not 0 (:293-315).  An empty `face2tet` treats every face as a
+  // boundary face.
   void addTetMeshVolume(const std::vector<glm::vec3>& vertices, const std::vector<uint32_t>& tetIndices,
-                        const std::vector<uint32_t>& surfaceTriIndices, const glm::vec3& initialVelocity, float density,
-                        float strainStiffness, float minStrain, float maxStrain, float volumeStiffness, float compression,
+                        const std::vector<uint32_t>& triFaceIndices, const std::vector<int>& face2tet, const glm::vec3& initialVelocity,
+                        float density, float strainStiffness, float minStrain, float maxStrain, float volumeStiffness, float compression,
                         float stretching) {
-    const uint32_t n = static_cast<uint32_t>(vertices.size());
-    std::vector<float> p = _flatten(vertices), v(3 * n), r(n, 0.5f), im(n, 1.0f / density);
-    for (uint32_t i = 0; i < n; ++i) { v[3 * i] = initialVelocity[0]; v[3 * i + 1] = initialVelocity[1]; v[3 * i + 2] = initialVelocity[2]; }
-    uint32_t first = 0;
-    _ck(pies_add_nodes_ex(_h, n, p.data(), v.data(), r.data(), im.data(), &first));
-    std::vector<uint32_t> t(tetIndices), f(surfaceTriIndices);
-    for (uint32_t& id : t) id += first;
-    for (uint32_t& id : f) id += first;
-    const uint32_t nt = static_cast<uint32_t>(t.size() / 4);
-    if (strainStiffness != 0.0f) _ck(pies_add_tet_constraints(_h, nt, t.data(), strainStiffness, minStrain, maxStrain));
-    if (volumeStiffness != 0.0f) _ck(pies_add_volume_constraints(_h, nt, t.data(), volumeStiffness, compression, stretching));
-    _ck(pies_add_triangles(_h, static_cast<uint32_t>(f.size() / 3), f.data()));
-    _syncRenderState();
+    std::vector<uint32_t> surface;
+    const size_t nf = triFaceIndices.size() / 3;
+    for (size_t i = 0; i < nf; ++i) {
+      if (!face2tet.empty() && face2tet[2 * i] >= 0 && face2tet[2 * i + 1] >= 0) continue;
+      surface.push_back(triFaceIndices[3 * i]);
+      surface.push_back(triFaceIndices[3 * i + 2]);  // switched winding
+      surface.push_back(triFaceIndices[3 * i + 1]);
+    }
+    _addTetMesh(vertices, tetIndices, surface, initialVelocity, density, strainStiffness, minStrain, maxStrain, volumeStiffness,
+                compression, stretching);
+  }
+  // The same without a face list: the boundary is derived from the elements (a face that belongs to exactly one element,
+  // elements in order, faces opposite vertex 0, 1, 2, 3) and every triangle is wound so that its normal points away from the
+  // element's fourth vertex, i.e. outward.
+  void addTetMeshVolume(const std::vector<glm::vec3>& vertices, const std::vector<uint32_t>& tetIndices, const glm::vec3& initialVelocity,
+                        float density, float strainStiffness, float minStrain, float maxStrain, float volumeStiffness, float compression,
+                        float stretching) {
+    struct Face { uint32_t key[3]; uint32_t tet, opposite; };
+    static const int kFace[4][3] = {{1, 2, 3}, {0, 3, 2}, {0, 1, 3}, {0, 2, 1}};
+    std::vector<Face> faces;
+    const size_t nt = tetIndices.size() / 4;
+    for (size_t t = 0; t < nt; ++t)
+      for (uint32_t f = 0; f < 4; ++f) {
+        Face fc{{tetIndices[4 * t + kFace[f][0]], tetIndices[4 * t + kFace[f][1]], tetIndices[4 * t + kFace[f][2]]}, static_cast<uint32_t>(t), f};
+        if (fc.key[0] > fc.key[1]) std::swap(fc.key[0], fc.key[1]);
+        if (fc.key[1] > fc.key[2]) std::swap(fc.key[1], fc.key[2]);
+        if (fc.key[0] > fc.key[1]) std::swap(fc.key[0], fc.key[1]);
+        faces.push_back(fc);
+      }
+    std::vector<size_t> order(faces.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    auto less = [&](size_t a, size_t b) {
+      for (int k = 0; k < 3; ++k)
+        if (faces[a].key[k] != faces[b].key[k]) return faces[a].key[k] < faces[b].key[k];
+      return a < b;
+    };
+    std::sort(order.begin(), order.end(), less);
+    std::vector<char> boundary(faces.size(), 0);
+    for (size_t i = 0; i < order.size();) {
+      size_t j = i + 1;
+      while (j < order.size() && faces[order[i]].key[0] == faces[order[j]].key[0] && faces[order[i]].key[1] == faces[order[j]].key[1] &&
+             faces[order[i]].key[2] == faces[order[j]].key[2])
+        ++j;
+      if (j == i + 1) boundary[order[i]] = 1;
+      i = j;
+    }
+    std::vector<uint32_t> surface;
+    for (size_t i = 0; i < faces.size(); ++i) {
+      if (!boundary[i]) continue;
+      const uint32_t t = faces[i].tet, f = faces[i].opposite;
+      uint32_t a = tetIndices[4 * t + kFace[f][0]], b = tetIndices[4 * t + kFace[f][1]], c = tetIndices[4 * t + kFace[f][2]];
+      const glm::vec3 &pa = vertices[a], &pb = vertices[b], &pc = vertices[c], &pd = vertices[tetIndices[4 * t + f]];
+      const float ux = pb[0] - pa[0], uy = pb[1] - pa[1], uz = pb[2] - pa[2], vx = pc[0] - pa[0], vy = pc[1] - pa[1], vz = pc[2] - pa[2];
+      const float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+      if (nx * (pd[0] - pa[0]) + ny * (pd[1] - pa[1]) + nz * (pd[2] - pa[2]) > 0.0f) std::swap(b, c);  // normal towards the inside: flip
+      surface.push_back(a); surface.push_back(b); surface.push_back(c);
+    }
+    _addTetMesh(vertices, tetIndices, surface, initialVelocity, density, strainStiffness, minStrain, maxStrain, volumeStiffness,
+                compression, stretching);
   }
   void addFixedRegions(const std::vector<glm::mat4>& regionMatrices, float w) {
     std::vector<float> m = _flattenMats(regionMatrices);
@@ -246,6 +299,24 @@ private:
       for (int c = 0; c < 4; ++c)
         for (int r = 0; r < 4; ++r) m[16 * k + 4 * c + r] = v[k][c][r];
     return m;
+  }
+  // nodes, constraints and (already outward-wound) surface triangles of a tetrahedral mesh (PrimitiveUtilities.cpp:268-326)
+  void _addTetMesh(const std::vector<glm::vec3>& vertices, const std::vector<uint32_t>& tetIndices, const std::vector<uint32_t>& surface,
+                   const glm::vec3& initialVelocity, float density, float strainStiffness, float minStrain, float maxStrain,
+                   float volumeStiffness, float compression, float stretching) {
+    const uint32_t n = static_cast<uint32_t>(vertices.size());
+    std::vector<float> p = _flatten(vertices), v(3 * size_t(n)), r(n, 0.5f), im(n, 1.0f / density);
+    for (uint32_t i = 0; i < n; ++i) { v[3 * i] = initialVelocity[0]; v[3 * i + 1] = initialVelocity[1]; v[3 * i + 2] = initialVelocity[2]; }
+    uint32_t first = 0;
+    _ck(pies_add_nodes_ex(_h, n, p.data(), v.data(), r.data(), im.data(), &first));
+    std::vector<uint32_t> t(tetIndices), f(surface);
+    for (uint32_t& id : t) id += first;
+    for (uint32_t& id : f) id += first;
+    const uint32_t nt = static_cast<uint32_t>(t.size() / 4);
+    if (strainStiffness != 0.0f) _ck(pies_add_tet_constraints(_h, nt, t.data(), strainStiffness, minStrain, maxStrain));
+    if (volumeStiffness != 0.0f) _ck(pies_add_volume_constraints(_h, nt, t.data(), volumeStiffness, compression, stretching));
+    _ck(pies_add_triangles(_h, static_cast<uint32_t>(f.size() / 3), f.data()));
+    _syncRenderState();
   }
   void _ck(int rc) const {
     if (rc != PIES_OK) throw std::runtime_error(std::string("Pies::Solver: ") + pies_last_error(_h));

@@ -356,6 +356,9 @@ class Solver:
         self._ck(self._L.pies_read_positions_strided(self._h, out.ctypes.data_as(C.c_void_p), 4 * stride_floats, n))
         return out
 
+    def last_error(self):
+        return self._L.pies_last_error(self._h).decode()
+
     @property
     def failed(self):
         f = C.c_int()

@@ -217,6 +217,19 @@ static void build_layer_program(const pies_solver* s, std::vector<LayerItem>& pr
 
 // Solver.cpp:85-130 in the reference's order (schedule EXACT, the flag, or ranges wider than two cells) or in the
 // parallel visiting order of DESIGN.md section 6
+// (cell, node) entries of the collision grid: NodeCompRange spans ceil(fract + 2R) <= 1 + ceil(2R) cells per axis (an
+// over-long range is empty, Solver.cpp:896-898), which only depends on the radius, so the sum bounds any positions.  8
+// per node for the reference's defaults.  fast: every range spans at most 2 cells per axis (2R <= 1).
+static void collision_grid_bound(const pies_solver* s, uint64_t& entries, bool& fast) {
+  entries = 0;
+  fast = true;
+  for (float r : s->h_radius) {
+    const float twoR = 2.0f * ((r + 0.5f) / s->opt.gridSpacing);
+    const uint64_t len = std::isfinite(twoR) && twoR >= 0.0f && twoR < 64.0f ? std::min<uint64_t>(50, 1 + static_cast<uint64_t>(std::ceil(twoR))) : 0;
+    entries += len * len * len;
+    if (!(twoR <= 1.0f)) fast = false;
+  }
+}
 static void probe_mark(pies_solver* s, int k) {
   if (s->probe && s->probe->kernel == k) s->probe->mark();
 }
@@ -784,14 +797,11 @@ int pies_finalize(pies_solver_t* s) {
   }
   const bool isPD = s->opt.solver == PIES_SOLVER_PD;
   const bool collide = s->nodeCollisions && !isPD;
+  // The parallel visiting order of the node-node pass needs ranges of at most 2 cells per axis (true for the reference
+  // defaults r = 0.5, spacing 2); other scenes run the pass in the reference's own order (one sequential chain, any range
+  // up to the reference's 50 cells per axis).
   s->collideFast = true;
-  if (collide && !s->h_radius.empty()) {
-    // NodeCompRange (Solver.cpp:877-901) spans ceil(fract + 2R) cells per axis with R = (r + 0.5)/gridSpacing.  The parallel
-    // visiting order needs at most 2, i.e. 2R <= 1 (true for the reference defaults r = 0.5, spacing 2); other scenes run
-    // the pass in the reference's own order (one sequential chain, any range up to the reference's 50 cells per axis).
-    const float rmax = *std::max_element(s->h_radius.begin(), s->h_radius.end());
-    s->collideFast = 2.0f * ((rmax + 0.5f) / s->opt.gridSpacing) <= 1.0f;
-  }
+  if (collide) { uint64_t e; collision_grid_bound(s, e, s->collideFast); }
   if (int rc = download_nodes(s)) return rc;
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   free_device(s);
@@ -916,15 +926,9 @@ int pies_finalize(pies_solver_t* s) {
   if (collide && n) {
     HashArrays& H = s->hash;
     H.n = n;
-    // (cell, node) entries: NodeCompRange spans ceil(fract + 2R) <= 1 + ceil(2R) cells per axis (an over-long range is empty,
-    // Solver.cpp:896-898), which only depends on the radius: the sum is an upper bound for any positions.  8 per node for
-    // the reference's defaults.
     uint64_t entries = 0;
-    for (float r : s->h_radius) {
-      const float twoR = 2.0f * ((r + 0.5f) / s->opt.gridSpacing);
-      const uint64_t len = std::isfinite(twoR) && twoR >= 0.0f && twoR < 64.0f ? std::min<uint64_t>(50, 1 + static_cast<uint64_t>(std::ceil(twoR))) : 0;
-      entries += len * len * len;
-    }
+    bool fast = true;
+    collision_grid_bound(s, entries, fast);
     if (entries > 0x7fff0000ull) return fail(s, PIES_ERR_UNSUPPORTED, "node-node collisions: more than 2^31 (cell, node) entries (gridSpacing is tiny against the radii)");
     H.maxEntries = static_cast<uint32_t>(entries + 64);
     uint32_t cap = 1024;
@@ -1278,7 +1282,12 @@ int pies_write_nodes(pies_solver_t* s, int what, const float* in, uint32_t n) {
   }
   if (!dst->empty()) std::memcpy(dst->data(), in, dst->size() * sizeof(float));
   s->hostNodesDirty = true;
-  if (what == PIES_NODE_RADIUS) s->sceneDirty = true;  // the collision grid is sized from the radii
+  if (what == PIES_NODE_RADIUS && s->hash.counters && !s->sceneDirty) {  // the collision grid is sized from the radii
+    uint64_t entries;
+    bool fast;
+    collision_grid_bound(s, entries, fast);
+    if (entries + 64 > s->hash.maxEntries || fast != s->collideFast) s->sceneDirty = true;
+  }
   return PIES_OK;
 }
 

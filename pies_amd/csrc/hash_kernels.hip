@@ -571,7 +571,7 @@ constexpr uint32_t kColSlots = PIES_COL_SLOTS;       // table capacity per wavef
 constexpr uint32_t kColMaxUnique = PIES_COL_MAX_UNIQUE;   // live entries allowed: an interior group of BASELINE config 4 (spacing 0.9, cells of 2.0) sees 216-343 distinct nodes
 constexpr uint32_t kColMaxEntries = 1024; // bucket entries of the 8 cells
 constexpr uint32_t kColEmpty = 0xffffffffu, kColDirty = 0x80000000u;
-constexpr uint32_t kColMaxSpins = 1u << 18;  // default polls of one completion stamp before the wait is declared dead (~0.3 s);
+constexpr uint32_t kColMaxSpins = 1u << 22;  // default polls of one completion stamp before the wait is declared dead (~5 s);
                                              // PIES_COLLIDE_SPIN_LIMIT overrides it (0 = wait for ever; PIES_PROFILER_SAFE=1 implies 0:
                                              // counter collection serialises and slows the launch)
 struct ColTable {
