@@ -1,18 +1,29 @@
 #!/usr/bin/env python3
-"""Benchmark of the Pies PBD substep on MI355X (BASELINE.json metric: substeps/sec and
-constraint-projections/sec at 100k particles, HBM GB/s vs peak).
+"""Benchmark of the Pies solver loop on MI355X (BASELINE.json metric: substeps/sec and constraint-projections/sec at
+100k particles, HBM GB/s vs peak).
 
-A "step" is one Solver::tick = `timeSubsteps` (1) substep of BASELINE config 2: the 20x20x250 lattice
-(100 000 particles, 649 156 distance + 539 334 tet-strain constraints), PBD, 20 iterations, node-node
-collisions off, synthetic perturbed rest state already resident in HBM.
+A "step" is one Solver::tick = `timeSubsteps` (1) substep of BASELINE configs[1]: the 20x20x250 lattice beam (100 000
+particles, 649 156 distance + 539 334 tet-strain constraints), PBD, 20 iterations, node-node collisions off, synthetic
+perturbed rest state already resident in HBM.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one body per GPU)
 
-Rank 0 prints ONE JSON line.  `value` is whole-job substeps/s (N independent bodies, weak scaling; the
-only collective is the timing barrier / max-reduce).  `roofline` is measured live for the dominant kernel
-(k_layer: the LDS-resident sweep of schedule LAYERED) between two HIP events on the solver's stream; `cpu_baseline` is the CPU oracle
-(a single-threaded restatement of the reference loop) timed on this host on a bounded sample.
+Rank 0 prints ONE JSON line.  `value` is whole-job substeps/s (N independent bodies, weak scaling; the only collective is
+the timing barrier / max-reduce).  How every other number is obtained:
+
+* `roofline` (and the `roofline` of every `other_configs` entry): the dominant kernel class is timed IN SITU - whole
+  substeps are launched eagerly and every launch of the class is bracketed by two HIP events on the solver's stream
+  (pies_profile_in_situ), so the caches hold what the substep leaves in them; `achieved` = SURVEY 8d's algorithmic bytes of
+  the launches timed / the time between their events.  `traffic` is the HBM byte count per launch of the same kernel from
+  the rocprofv3 --pmc passes committed under profiles/ (`traffic_source` names the file; collected by
+  tools/profile_round.sh, never inside this run).
+* `cpu_baseline`: the CPU oracle (oracle/pies_oracle.cpp, a single-threaded restatement of the reference loop with the
+  reference's own threading where it has any), built -O3 -march=native ON this host, timed on a bounded sample.
+* `tick_inclusive`: the same workload through pies_tick (one pinned D2H copy of the positions per tick + the host-side
+  unpack a C++ host pays) and through the double-buffered asynchronous export.
+* `exact_order` / `coloured_schedule` / `order_deviation`: the other schedules' throughput and how far their results are
+  from the reference order (EXACT).
 """
 import argparse
 import json
@@ -37,6 +48,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec)
 BYTES = {"predict": 48, "position": 44, "distance": 52, "tet": 160, "bend": 136, "floor": 20, "velocity": 40,
          "layer": 1}  # a layer launch fuses several kinds: the library tallies its units in algorithmic bytes directly
 ITERATIONS = 20
+K = {name: i for i, name in enumerate(capi.KERNEL_NAMES)}
+DEVICE_KERNEL = {"layer": "k_layer", "tet": "k_tet", "wave": "k_wave", "pd_local_tet": "k_pd_local_tet_pair", "pd_spmv": "k_cg_ap",
+                 "pd_rhs": "k_pd_rhs", "pd_cg_update": "k_cg_update", "collide": "k_collide_flow", "hash": "k_radix_scatter"}
 
 
 def log(msg):
@@ -87,21 +101,54 @@ def timed_ticks(solver, steps, warmup, barrier):
     return time.perf_counter() - t0
 
 
+# ---- rooflines ---------------------------------------------------------------------------------------------------------
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc passes (separate FETCH_SIZE / WRITE_SIZE
+    passes, gfx950 correction (2 FETCH + WRITE) * 1024, see profiles/README.md); (None, None) when no pass was recorded."""
+    for name in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as f:
+                v = json.load(f).get(kernel_name, {}).get("hbm_bytes_per_launch")
+            if v is not None:
+                return v, "profiles/" + name
+        except OSError:
+            pass
+    return None, None
+
+
+def roofline(solver, cls, bytes_per_unit, substeps=3, note=None):
+    """In-situ roofline block of kernel class `cls` (a name of capi.KERNEL_NAMES)."""
+    launches, ms, units = solver.profile_in_situ(K[cls], substeps)
+    if launches == 0 or ms <= 0:
+        return None
+    nbytes = bytes_per_unit * units
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    kname = DEVICE_KERNEL.get(cls, "k_" + cls)
+    traffic, src = pmc_traffic(kname)
+    out = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "traffic": traffic, "traffic_source": src, "avg_launch_us": 1e3 * ms / launches, "launches_timed": launches,
+           "bytes_per_launch": nbytes / launches,
+           "method": "HIP events on the solver's stream around every launch of the class inside %d eagerly launched whole substeps "
+                     "(pies_profile_in_situ)" % substeps}
+    if note:
+        out["note"] = note
+    return out
+
+
 def pd_bytes(solver):
-    """Algorithmic bytes per unit of the PD kernels; units are constraints for the local
-    steps and rows (nodes) for the rest."""
+    """Algorithmic bytes per unit of the PD kernels; units are constraints for the local steps and rows
+    (nodes) for the rest."""
     n = solver.count(capi.NODES)
     nnz = solver.count(capi.SYSTEM_NNZ)
     paired = solver.count(capi.VOLUME) > 0 and solver.launch_counts().get("pd_local_volume", 0) == 0
-    # the fused strain + volume local step leaves one record per corner of the element pair
     inc = (4 * (solver.count(capi.TET) + (0 if paired else solver.count(capi.VOLUME)) + solver.count(capi.BEND))
            + 2 * solver.count(capi.DISTANCE) + solver.count(capi.POSITION))
-    # strain + volume constraints over the same elements run fused (no separate volume launches): ids 16 + Qinv 36 +
-    # 2 x (min, max, w) 24 + four positions 48 + 2 x 36 projected gradients
     return {
-        "pd_predict": 52, "pd_local_distance": 64, "pd_local_tet": 196 if paired else 148, "pd_local_volume": 148,
-        # gather formulation: one 12-byte contribution + its 4-byte slot index per (constraint, node) incidence,
-        # inertia term in, right-hand side out (the survey's scatter formulation would be 148 B per tetrahedron)
+        # SURVEY 8d: 148 B per tet / volume projection; a fused strain + volume launch does two projections per unit
+        "pd_local_tet": 296 if paired else 148, "pd_local_volume": 148, "pd_local_distance": 64, "pd_predict": 52,
+        # gather formulation: one 12-byte contribution + its 4-byte slot index per (constraint, node) incidence, inertia term
+        # in, right-hand side out (the survey's scatter formulation would be 148 B per tetrahedron)
         "pd_rhs": (16.0 * inc + 32.0 * n) / n,
         "pd_spmv": (8.0 * nnz + 28.0 * n) / n,   # col + val per stored entry; rowptr, x, y per row; 3 right-hand sides fused
         "pd_cg_update": 120,                     # the PCG iteration's 10 three-component vector passes
@@ -109,87 +156,253 @@ def pd_bytes(solver):
     }
 
 
-def kernel_profile(solver, bytes_per_unit=None):
-    """Per kernel class: launches per substep, average per-launch device time (us), algorithmic GB/s.
-    Each class is timed in isolation by replaying a graph of only its launches (pies_profile_substep)."""
+def replay_latencies(solver, bytes_per_unit=None):
+    """Per kernel class: launches per substep and the average per-launch time of an ISOLATED replay (a graph holding only
+    that class's launches, pies_profile_substep).  One class's working set is usually cache resident in such a replay, so
+    these are launch-latency figures (kernel boundary + dependent memory round trips), not bandwidth figures."""
     out = {}
     lc = solver.launch_counts()
-    BYTES = bytes_per_unit or globals()["BYTES"]
     for k, name in enumerate(capi.KERNEL_NAMES):
-        if name not in BYTES or lc.get(name, 0) == 0:
+        if lc.get(name, 0) == 0 or name in ("hash", "collide"):
             continue
         launches, ms, units = solver.profile_substep(k)
         if launches == 0:
             continue
-        out[name] = {
-            "launches_per_substep": lc[name],
-            "avg_us": 1e3 * ms / launches,
-            "units_per_launch": units / launches,
-            "algorithmic_GBs": BYTES[name] * units / (ms * 1e-3) / 1e9 if ms > 0 else None,
-        }
-        out[name]["hbm_frac"] = out[name]["algorithmic_GBs"] / HBM_PEAK_GBS if ms > 0 else None
+        out[name] = {"launches_per_substep": lc[name], "isolated_replay_avg_us": 1e3 * ms / launches, "units_per_launch": units / launches}
     return out
 
 
-def pd_beam(dims, device):
-    """BASELINE configs[2] pattern: lattice beam, Projective Dynamics, tets + volume (w = 1), 10 iterations,
-    the k = 0 end cap pinned."""
+# ---- scenes of the other configs ----------------------------------------------------------------------------------------
+def pd_beam(dims, device, settle=34, mod=capi):
+    """BASELINE configs[2] pattern: lattice beam, Projective Dynamics, tets + volume (w = 1), 10 iterations, the k = 0 end
+    cap pinned."""
     W, H, D = dims
-    g = capi.Solver(capi.Options(solver=capi.PD, iterations=10), device=device)
+    opts = mod.Options(solver=mod.PD, iterations=10)
+    g = mod.Solver(opts, device=device) if mod is capi else mod.OracleSolver(opts)
     g.create_tet_box(W, H, D, translation=(0.0, 2.0, 0.0), w=1.0, volume=True, triangles=True)
     g.add_position(np.array([D * (j + H * i) for i in range(W) for j in range(H)], dtype=np.uint32), 2.0)
-    g.finalize()
-    for _ in range(34):  # a host ticks and synchronises once per frame: the captured CG iteration budget settles to what
-        g.tick_async(1)  # the solves use (two spare iterations after 8 calm frames, one after 24 more)
-        g.synchronize()
+    if mod is capi:
+        g.finalize()
+        for _ in range(settle):  # a host ticks and synchronises once per frame: the captured CG iteration budget settles to
+            g.tick_async(1)      # what the solves use (two spare iterations after 8 calm frames, one after 24 more)
+            g.synchronize()
     return g
 
 
-def scale_profiles(device):
-    """Per-kernel algorithmic bandwidth of the projection and SpMV kernels at 1M particles (100x100x100), where
-    a launch is long enough for HBM rather than the kernel boundary to bound it."""
-    out = {}
-    for name, sched in (("pbd_1m", capi.SCHEDULE_LAYERED), ("pbd_1m_coloured", capi.SCHEDULE_COLOURED)):
-        log(name)
-        g = build_scene(capi, scenes.L1M, 99, schedule=sched, device=device)
-        g.finalize()
-        el = timed_ticks(g, 3, 1, lambda: None)
-        out[name] = {"substeps_per_sec": 3 / el, "projections_per_sec": 3 / el * scenes.projections_per_substep(g, capi, ITERATIONS),
-                     "launches_per_substep": sum(g.launch_counts().values()), "kernels": kernel_profile(g)}
-        g.close()
-    log("pd_1m")
-    g = pd_beam(scenes.L1M, device)
-    el = timed_ticks(g, 3, 1, lambda: None)
-    out["pd_1m"] = {"substeps_per_sec": 3 / el, "pcg_stats": g.pcg_stats(), "kernels": kernel_profile(g, pd_bytes(g))}
-    g.close()
+def config4_particles():
+    W, H, D = scenes.L500K
+    rng = np.random.default_rng(1234)
+    p = np.stack(np.meshgrid(np.arange(W), np.arange(H), np.arange(D), indexing="ij"), -1).reshape(-1, 3) * 0.9
+    p = p + rng.uniform(-0.05, 0.05, p.shape) + [0, 0.5, 0]
+    v = np.random.default_rng(4321).uniform(-1, 1, p.shape)
+    return p.astype(np.float32), v.astype(np.float32)
+
+
+def contact_scene(mod, device=None):
+    """One GPU's share of BASELINE configs[4] with contacts that bind: the 25x25x400 body (250 000 particles) lying on the
+    floor and a second, small body landing on it (the scene of tests/test_tri_collisions_gpu.py's config-5 parity test)."""
+    opts = mod.Options(solver=mod.PD, iterations=10)
+    g = mod.Solver(opts, device=device) if mod is capi else mod.OracleSolver(opts)
+    W, H, D = scenes.L250K
+    g.create_tet_box(W, H, D, translation=(0.0, 0.04, 0.0), w=1.0, volume=True, triangles=True)
+    g.create_tet_box(8, 6, 30, translation=(3.3, 0.04 + (H - 1) + 0.04, 40.4), w=1.0, volume=True, triangles=True)
+    v = g.velocities
+    v[W * H * D:, 1] = -2.0
+    g.set_velocities(v)
+    g.set_prev_positions(g.positions)
+    return g
+
+
+def frame_loop(g, frames):
+    """substeps/s of a host that synchronises once per frame (the CG budget follows the contacts)"""
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        g.tick_async(1)
+        g.synchronize()
+    return frames * g.options.timeSubsteps / (time.perf_counter() - t0)
+
+
+def host_cores():
+    """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands out a share of
+    a large host; OpenMP threads beyond the share only spin against each other)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def oracle_module():
+    """The CPU oracle built -O3 -march=native on THIS host (falls back to the portable build if that compile fails)."""
+    os.environ["PIES_ORACLE_NATIVE"] = "1"
+    import oracle_api as ora
+    try:
+        ora.lib()
+        flags = "g++ -O3 -march=native -ffp-contract=off"
+    except Exception as e:  # noqa: BLE001
+        log("native oracle build failed (%s): portable build" % e)
+        os.environ["PIES_ORACLE_NATIVE"] = "0"
+        ora.lib()
+        flags = "g++ -O3 -march=x86-64-v3 -ffp-contract=off"
+    return ora, flags
+
+
+def timed_oracle_ticks(o, budget_s, max_ticks):
+    """Bounded sample: one warm tick (page-in; also the yardstick), then as many ticks as fit the budget."""
+    t0 = time.perf_counter()
+    o.tick(1)
+    one = time.perf_counter() - t0
+    ticks = max(1, min(max_ticks, int(budget_s / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    o.tick(ticks)
+    return ticks, time.perf_counter() - t0
+
+
+def cpu_all_cores(ora, dims, threads, budget_s):
+    """The same oracle with every host core: the containers re-ordered into the conflict-free colour classes of a coloured
+    plan (built by a host-only handle: no GPU involved) and each class swept with OpenMP threads."""
+    plan = build_scene(capi, dims, 1234, schedule=capi.SCHEDULE_COLOURED, device=capi.DEVICE_NONE)
+    plan.finalize()
+    o = build_scene(ora, dims, 1234)
+    for t in (capi.DISTANCE, capi.TET):
+        o.permute(t, plan.order(t))
+        o.set_batches(t, plan.batches(t))
+    plan.close()
+    o.set_threads(threads)
+    ticks, dt = timed_oracle_ticks(o, budget_s, 12)
+    return {"value": ticks / dt, "unit": "substeps/s", "cores": threads,
+            "sample": "%d ticks, colour classes swept with %d OpenMP threads (bit-identical to the sequential sweep in that order)" % (ticks, threads)}
+
+
+def cpu_baseline(dims, budget_s, with_all_cores=True):
+    ora, flags = oracle_module()
+    o = build_scene(ora, dims, 1234)
+    ticks, dt = timed_oracle_ticks(o, budget_s, 8)
+    out = {
+        "value": ticks / dt, "unit": "substeps/s", "cores": 1, "kind": "port",
+        "sample": "%d ticks of the same %dx%dx%d workload (20 iterations; oracle/pies_oracle.cpp, %s, built on this host; 1 thread: "
+                  "the reference's projection loops are single-threaded, Src/Solver.cpp:58-75)" % ((ticks,) + tuple(dims) + (flags,)),
+        "projections_per_sec": ticks * scenes.projections_per_substep(o, ora, ITERATIONS) / dt,
+        "host_cpus": os.cpu_count(),
+    }
+    if with_all_cores:
+        out["all_cores"] = cpu_all_cores(ora, dims, host_cores(), budget_s)
     return out
 
 
-def pmc_traffic(kernel_name):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (collected
-    separately, see profiles/README.md); None when no pass has been recorded for this round."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f).get(kernel_name, {}).get("hbm_bytes_per_launch")
-    except OSError:
-        return None
+def cpu_baseline_pd(dims, budget_s):
+    ora, flags = oracle_module()
+    o = pd_beam(dims, None, mod=ora)
+    o.set_reference_threads(True)
+    ticks, dt = timed_oracle_ticks(o, budget_s, 4)
+    return {"value": ticks / dt, "unit": "substeps/s", "cores": 8, "kind": "port",
+            "sample": "%d ticks of the same PD workload (%s); threading as the reference: threadCount = 8 threads for collision detection "
+                      "(Solver.h:36), everything else 1 thread; the global step is a banded fp32 Cholesky re-factored every substep "
+                      "(bandwidth 421; Eigen's SimplicialLLT of the reference is a sparse factorisation with fewer operations: this "
+                      "figure is a lower bound of the reference's speed)" % (ticks, flags)}
+
+
+def cpu_baseline_collisions(budget_s):
+    ora, flags = oracle_module()
+    p, v = config4_particles()
+    o = ora.OracleSolver(scenes.pbd_options(ora, 4))
+    o.addNodes(p)
+    o.set_velocities(v)
+    o.set_reference_threads(True)  # 16 insert threads, each scanning every node (SpatialHash.h:134-176)
+    ticks, dt = timed_oracle_ticks(o, budget_s, 4)
+    return {"value": ticks / dt, "unit": "substeps/s", "cores": min(16, host_cores()), "kind": "port",
+            "sample": "%d ticks of the same 500k-particle workload (%s); threading as the reference: 16 threads for the hash insert "
+                      "(SpatialHash.h:134), the resolve loop 1 thread (Solver.cpp:85-130); reference collision order" % (ticks, flags)}
+
+
+# ---- secondary measurements --------------------------------------------------------------------------------------------
+def tick_inclusive(dims, device, sched, steps):
+    """What a host pays per tick beyond the resident figure: pies_tick (pinned D2H of the positions + unpack into the
+    host mirror + the strided write into a Vertex array, i.e. Pies::Solver::tick) and the asynchronous export pipeline
+    (pies_tick_begin / pies_export_acquire: frame k travels while frame k+1 computes)."""
+    g = build_scene(capi, dims, 1234, schedule=sched, device=device)
+    g.finalize()
+    g.tick(3)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.tick()
+        g.read_positions_strided(9)
+    sync = steps / (time.perf_counter() - t0)
+    frames = [g.tick_begin()]
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        frames.append(g.tick_begin())
+        f = frames.pop(0)
+        g.export_acquire(f)
+        g.export_release(f)
+    asyn = steps / (time.perf_counter() - t0)
+    g.export_acquire(frames[0])
+    g.export_release(frames[0])
+    g.close()
+    return {"pies_tick_substeps_per_sec": sync, "async_export_substeps_per_sec": asyn, "steps": steps,
+            "note": "pies_tick: one 1.6 MB pinned D2H copy + host unpack + strided write into a 36-byte Vertex stream per tick "
+                    "(what Pies::Solver::tick does); async export: the copy of frame k overlaps the kernels of frame k+1"}
+
+
+def order_deviation(device):
+    import deviation
+    out = {}
+    names = {capi.SCHEDULE_COLOURED: "coloured", capi.SCHEDULE_LAYERED: "layered"}
+
+    def beam(dims, iters):
+        def make(schedule):
+            g = capi.Solver(scenes.pbd_options(capi, iters), device=device)
+            scenes.build_beam(g, dims)
+            scenes.perturb(g, 1234, 0.05)
+            g.set_flag(capi.FLAG_NODE_COLLISIONS, 0)
+            g.set_schedule(schedule)
+            return g
+        d = deviation.compare(make, capi, [capi.SCHEDULE_EXACT, capi.SCHEDULE_COLOURED, capi.SCHEDULE_LAYERED])
+        return {names[k]: v for k, v in d.items()}
+    out["config1_l1k_10_iterations"] = beam(scenes.L1K, 10)
+    log("order deviation: config 2")
+    out["config2_l100k_20_iterations"] = beam(scenes.L100K, ITERATIONS)
+    log("order deviation: collisions")
+    from test_collisions_gpu import particles
+    p, v = particles((25, 50, 50))  # config 4 at 1/8 (the reference-order pass is one sequential chain, ~20 us per node)
+
+    def make(rule):
+        g = capi.Solver(scenes.pbd_options(capi, 4), device=device)
+        g.addNodes(p)
+        g.set_velocities(v)
+        g.set_flag(capi.FLAG_REFERENCE_COLLISION_ORDER, rule == 0)
+        return g
+    out["config4_at_62500_particles_parallel_vs_reference_collision_order"] = deviation.compare(make, capi, [0, 1], ticks=(1, 5))[1]
+    out["note"] = ("every schedule sweeps the same constraints with the same arithmetic; EXACT is the reference's order (containers in "
+                   "insertion order, colliding nodes in ascending index). max_abs_dpos / centre_of_mass_delta are against EXACT on the "
+                   "same inputs; residuals = RMS constraint violation of each result (distance: |len - rest|; tet: singular values of F "
+                   "outside [0.8, 1]). Report, not a gate (SURVEY 8c).")
+    return out
 
 
 def extra_configs(device):
-    """Short secondary measurements of the other single-GPU BASELINE configs (not the headline value)."""
+    """The other single-GPU BASELINE configs, each with its own in-situ roofline block (not the headline value)."""
     out = {}
     # configs[2]: 100k beam, Projective Dynamics, tets + volume (w = 1), 10 iterations, k = 0 end cap pinned
     g = pd_beam(scenes.L100K, device)
     el = timed_ticks(g, 30, 3, lambda: None)
     res, iters, solves = g.pcg_stats()
-    out["pd_config3"] = {"value": 30 / el, "unit": "substeps/s", "workload": "20x20x250 beam, PD, 539334 tet + 539334 volume constraints, "
-                         "10 local/global iterations, floor contacts, Jacobi-PCG rel. tol 3e-7 (iteration budget adapts)",
-                         "pcg_max_rel_residual": res, "pcg_max_iterations_used": iters,
-                         "projections_per_sec": 30 / el * 10 * (g.count(capi.TET) + g.count(capi.VOLUME) + g.count(capi.POSITION))}
-    g.set_flag(capi.FLAG_TRIANGLE_COLLISIONS, 0)  # the profile pass times the tetrahedral pipeline's kernels
-    g.finalize()
-    out["pd_config3"]["kernels"] = kernel_profile(g, pd_bytes(g))
+    B = pd_bytes(g)
+    out["pd_config3"] = {"value": 30 / el, "unit": "substeps/s", "workload": "BASELINE configs[2]: 20x20x250 beam, PD, 539334 tet + 539334 volume "
+                         "constraints, 10 local/global iterations, floor + point-triangle pipeline on, Jacobi-PCG rel. tol 3e-7 (captured "
+                         "iteration budget adapts)", "pcg_max_rel_residual": res, "pcg_max_iterations_used": iters, "pcg_health": g.pcg_health(),
+                         "launches_per_substep": sum(g.launch_counts().values()),
+                         "projections_per_sec": 30 / el * 10 * (g.count(capi.TET) + g.count(capi.VOLUME) + g.count(capi.POSITION)),
+                         "roofline": roofline(g, "pd_local_tet", B["pd_local_tet"], note="fused strain + volume local step: two projections "
+                                              "(2 x 148 B, SURVEY 8d) per element from one gather and one SVD; the launch itself moves 196 B"),
+                         "roofline_spmv": roofline(g, "pd_spmv", B["pd_spmv"], note="SELL-64 SpMV over 3 right-hand sides + fused direction "
+                                                   "update; 8 nnz + 28 N bytes per launch (SURVEY 8d); the solves of the timed pass do not take "
+                                                   "the converged early exit"),
+                         "roofline_rhs": roofline(g, "pd_rhs", B["pd_rhs"])}
+    out["pd_config3"]["isolated_replay_latencies"] = replay_latencies(g)
     g.close()
     # configs[1] on an unstructured mesh: Delaunay beam of the same size (the lattice stands in for tetgen in the headline)
     log("unstructured beam")
@@ -207,108 +420,92 @@ def extra_configs(device):
         un[name] = {"value": 20 / el, "unit": "substeps/s", "launches_per_substep": sum(g.launch_counts().values())}
         g.close()
     out["unstructured_config2"] = un
-    # configs[4], one GPU's share: a 250k-particle body (25x25x400), PD, point-triangle + floor contact pipeline on
-    log("config 5 share")
-    g = pd_beam(scenes.L250K, device)
-    el = timed_ticks(g, 20, 3, lambda: None)
+    # configs[4], one GPU's share, with contacts that bind
+    log("config 5 share (250k particles, PD, binding contacts)")
+    g = contact_scene(capi, device)
+    g.finalize()
+    frame_loop(g, 12)  # the small body lands, the CG budget follows the contacts
+    rate = frame_loop(g, 12)
     res, iters, solves = g.pcg_stats()
-    out["pd_config5_per_gpu"] = {"value": 20 / el, "unit": "substeps/s", "workload": "25x25x400 beam (250000 particles), PD, tets + volume, 10 "
-                                 "iterations, point-triangle CCD + floor contact pipeline on (no contact binds in this window: see pd_contacts); "
-                                 "configs[4] runs one such body per GPU",
-                                 "pcg_max_rel_residual": res, "pcg_max_iterations_used": iters,
-                                 "tri_contacts_last_substep": len(g.tri_collisions)}
+    B = pd_bytes(g)
+    out["pd_config5_per_gpu"] = {"value": rate, "unit": "substeps/s", "workload": "BASELINE configs[4], one GPU's share: 25x25x400 beam (250 000 "
+                                 "particles) on the floor + an 8x6x30 body landing on it, PD, strain + volume constraints, 10 iterations, floor "
+                                 "and point-triangle contacts binding (w = 1e4); a host that synchronises once per frame",
+                                 "tri_contacts_last_substep": len(g.tri_collisions), "pcg_max_rel_residual": res,
+                                 "pcg_max_iterations_used": iters, "pcg_health": g.pcg_health(), "failed": g.failed,
+                                 "launches_per_substep": sum(g.launch_counts().values()),
+                                 "roofline": roofline(g, "pd_local_tet", B["pd_local_tet"], substeps=2),
+                                 "roofline_spmv": roofline(g, "pd_spmv", B["pd_spmv"], substeps=2)}
     g.close()
-    # PD with contacts that actually bind: a short beam resting on a long one that lies on the floor
+    # PD with thousands of contacts: a short beam resting on a long one that lies on the floor
     log("PD contact scene")
     g = capi.Solver(capi.Options(solver=capi.PD, iterations=10), device=device)
     g.create_tet_box(25, 25, 160, translation=(0.0, 0.04, 0.0), w=1.0, volume=True, triangles=True)
     g.create_tet_box(25, 25, 40, translation=(0.3, 0.04 + 24 + 0.07, 10.3), w=1.0, volume=True, triangles=True)
     g.finalize()
-    for _ in range(10):  # frame loop: the upper beam lands, the CG budget follows the contacts
-        g.tick_async(1)
-        g.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(10):
-        g.tick_async(1)
-        g.synchronize()
-    el = time.perf_counter() - t0
+    frame_loop(g, 10)
+    rate = frame_loop(g, 10)
     res, iters, solves = g.pcg_stats()
-    out["pd_contacts"] = {"value": 10 / el, "unit": "substeps/s", "workload": "125000 particles: a 25x25x40 beam resting on a 25x25x160 beam on the "
+    out["pd_contacts"] = {"value": rate, "unit": "substeps/s", "workload": "125000 particles: a 25x25x40 beam resting on a 25x25x160 beam on the "
                           "floor, PD, 10 iterations, floor + point-triangle contacts binding (w = 1e4 on the diagonal)",
                           "tri_contacts_last_substep": len(g.tri_collisions), "pcg_max_rel_residual": res, "pcg_max_iterations_used": iters,
-                          "failed": g.failed}
+                          "pcg_health": g.pcg_health(), "failed": g.failed,
+                          "roofline_spmv": roofline(g, "pd_spmv", pd_bytes(g)["pd_spmv"], substeps=1)}
     g.close()
     # configs[3]: 500k loose particles, node-node collisions + floor, PBD, 4 iterations
-    W, H, D = scenes.L500K
-    rng = np.random.default_rng(1234)
-    p = np.stack(np.meshgrid(np.arange(W), np.arange(H), np.arange(D), indexing="ij"), -1).reshape(-1, 3) * 0.9
-    p = p + rng.uniform(-0.05, 0.05, p.shape) + [0, 0.5, 0]
+    log("config 4 (500k particles, node-node collisions)")
+    p, v = config4_particles()
     g = capi.Solver(scenes.pbd_options(capi, 4), device=device)
-    g.addNodes(p.astype(np.float32))
-    g.set_velocities(np.random.default_rng(4321).uniform(-1, 1, p.shape).astype(np.float32))
+    g.addNodes(p)
+    g.set_velocities(v)
     g.finalize()
-    el = timed_ticks(g, 10, 2, lambda: None)
-    pairs = g.collision_pairs
-    out["collisions_config4"] = {"value": 10 / el, "unit": "substeps/s", "workload": "50x100x100 loose particles (r 0.5, spacing 0.9, "
-                                 "jitter 0.05), PBD, 4 iterations, spatial-hash node-node collisions + floor",
-                                 "resolved_pairs_per_substep": pairs / 12, "failed": g.failed}
+    g.tick_async(2)
+    g.synchronize()
+    g.collision_stats()
+    el = timed_ticks(g, 10, 0, lambda: None)
+    pairs, cand = g.collision_stats()
+    n = g.count(capi.NODES)
+    per_node = 32.0 + 27 * 8.0 + 16.0 * cand / (10 * 4 * n)  # own state + 27 cell headers + 16 B per candidate neighbour
+    out["collisions_config4"] = {"value": 10 / el, "unit": "substeps/s", "workload": "BASELINE configs[3]: 50x100x100 loose particles (r 0.5, spacing "
+                                 "0.9, jitter 0.05), PBD, 4 iterations, grid rebuild + node-node resolve + floor every iteration, parallel "
+                                 "collision order", "resolved_pairs_per_substep": pairs / 10, "candidates_per_node_per_iteration": cand / (40 * n),
+                                 "failed": g.failed, "launches_per_substep": sum(g.launch_counts().values()),
+                                 "roofline": roofline(g, "collide", per_node, substeps=1, note="one bracket = the resolve pass of one "
+                                                      "iteration (k_collide_flow); bytes per node = 32 + 27 x 8 + 16 x candidates looked at"),
+                                 "roofline_grid_build": roofline(g, "hash", 92.0, substeps=1, note="one bracket = one grid rebuild: range, prefix "
+                                                                 "sum, emit, radix sort passes, cell index (about 92 B per node, SURVEY 8d)")}
     g.close()
     return out
 
 
-def host_cores():
-    """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands out a
-    share of a large host; OpenMP threads beyond the share only spin against each other)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
-    return max(1, min(n, 64))
-
-
-def cpu_all_cores(dims, ticks, threads):
-    """The same oracle with every host core: the containers re-ordered into the conflict-free colour classes of a
-    coloured plan (built by a host-only handle: no GPU involved) and each class swept with OpenMP threads."""
-    import oracle_api as ora
-    plan = build_scene(capi, dims, 1234, schedule=capi.SCHEDULE_COLOURED, device=capi.DEVICE_NONE)
-    plan.finalize()
-    o = build_scene(ora, dims, 1234)
-    for t in (capi.DISTANCE, capi.TET):
-        o.permute(t, plan.order(t))
-        o.set_batches(t, plan.batches(t))
-    plan.close()
-    o.set_threads(threads)
-    t0 = time.perf_counter()
-    o.tick(1)  # warm-up, and the yardstick that bounds the sample to about ten seconds
-    one = time.perf_counter() - t0
-    ticks = max(1, min(ticks, int(10.0 / max(one, 1e-3))))
-    t0 = time.perf_counter()
-    o.tick(ticks)
-    dt = time.perf_counter() - t0
-    return {"value": ticks / dt, "unit": "substeps/s", "cores": threads,
-            "sample": "%d ticks, colour classes swept with %d OpenMP threads (bit-identical to the sequential sweep in "
-                      "that order)" % (ticks, threads)}
-
-
-def cpu_baseline(dims, ticks):
-    import oracle_api as ora
-    o = build_scene(ora, dims, 1234)
-    o.tick(1)  # warm caches / page-in
-    t0 = time.perf_counter()
-    o.tick(ticks)
-    dt = time.perf_counter() - t0
-    threads = host_cores()
-    return {
-        "all_cores": cpu_all_cores(dims, 3 * ticks, threads),
-        "value": ticks / dt, "unit": "substeps/s", "cores": 1, "kind": "port",
-        "sample": "%d ticks of the same %dx%dx%d workload (20 iterations, oracle/pies_oracle.cpp, g++ -O2, 1 thread; "
-                  "the reference's projection loops are single-threaded, Src/Solver.cpp:58-75)" % ((ticks,) + tuple(dims)),
-        "projections_per_sec": ticks * scenes.projections_per_substep(o, ora, ITERATIONS) / dt,
-        "host_cpus": os.cpu_count(),
-    }
+def scale_profiles(device):
+    """The same kernels at 1M particles (100x100x100), where a launch is long enough for HBM rather than the kernel boundary
+    to bound it: whole-substep throughput and in-situ rooflines."""
+    out = {}
+    for name, sched in (("pbd_1m", capi.SCHEDULE_LAYERED), ("pbd_1m_coloured", capi.SCHEDULE_COLOURED)):
+        log(name)
+        g = build_scene(capi, scenes.L1M, 99, schedule=sched, device=device)
+        g.finalize()
+        el = timed_ticks(g, 3, 1, lambda: None)
+        out[name] = {"substeps_per_sec": 3 / el, "projections_per_sec": 3 / el * scenes.projections_per_substep(g, capi, ITERATIONS),
+                     "launches_per_substep": sum(g.launch_counts().values())}
+        if sched == capi.SCHEDULE_LAYERED:
+            out[name]["roofline"] = roofline(g, "layer", 1, substeps=1)
+        else:
+            out[name]["roofline"] = roofline(g, "tet", BYTES["tet"], substeps=1)
+            out[name]["roofline_distance"] = roofline(g, "distance", BYTES["distance"], substeps=1)
+        g.close()
+    log("pd_1m")
+    g = pd_beam(scenes.L1M, device, settle=12)
+    el = timed_ticks(g, 3, 1, lambda: None)
+    B = pd_bytes(g)
+    out["pd_1m"] = {"substeps_per_sec": 3 / el, "pcg_stats": g.pcg_stats(),
+                    "roofline": roofline(g, "pd_local_tet", B["pd_local_tet"], substeps=1),
+                    "roofline_spmv": roofline(g, "pd_spmv", B["pd_spmv"], substeps=1),
+                    "roofline_rhs": roofline(g, "pd_rhs", B["pd_rhs"], substeps=1),
+                    "roofline_cg_update": roofline(g, "pd_cg_update", B["pd_cg_update"], substeps=1)}
+    g.close()
+    return out
 
 
 def main():
@@ -318,13 +515,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--dims", type=int, nargs=3, default=list(scenes.L100K))
     ap.add_argument("--schedule", choices=["layered", "coloured", "exact"], default="layered")
+    ap.add_argument("--quick", action="store_true", help="headline + roofline + a one-tick CPU baseline only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-order measurement")
-    ap.add_argument("--cpu-ticks", type=int, default=4)
-    ap.add_argument("--no-kernel-profile", action="store_true", help="skip the per-dispatch timing pass (roofline = null)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the short PD (config 3) and collision (config 4) measurements")
-    ap.add_argument("--no-scale", action="store_true", help="skip the 1M-particle per-kernel bandwidth measurements")
+    ap.add_argument("--no-exact", action="store_true", help="skip the other schedules' throughput")
+    ap.add_argument("--no-deviation", action="store_true", help="skip the order_deviation measurement")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the in-situ timing pass (roofline = null)")
+    ap.add_argument("--no-extras", action="store_true", help="skip BASELINE configs 3-5")
+    ap.add_argument("--no-scale", action="store_true", help="skip the 1M-particle measurements")
+    ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work per baseline sample")
     args = ap.parse_args()
+    if args.quick:
+        args.no_exact = args.no_deviation = args.no_extras = args.no_scale = True
+        args.cpu_budget = min(args.cpu_budget, 1.0)
 
     rank, local_rank, world = dist_env()
     dist = None
@@ -360,22 +562,20 @@ def main():
     log("scene ready, timing %d steps" % args.steps)
     elapsed = timed_ticks(g, args.steps, args.warmup, barrier)
     elapsed, total_substeps = aggregate(elapsed, args.steps * substeps_per_tick, dist)
-    assert np.isfinite(g.positions).all()
+    assert np.isfinite(g.positions).all() and not g.failed
 
     result = None
     if rank == 0:
         value = total_substeps / elapsed
         lc = g.launch_counts()
-        if args.no_kernel_profile:
-            print(json.dumps({"value": value, "unit": "substeps/s", "launches_per_substep": sum(lc.values())}))
-            g.close()
-            return
-        items = ITERATIONS * (g.count(capi.DISTANCE) + g.count(capi.TET) + g.count(capi.POSITION) + g.count(capi.BEND) + g.count(capi.NODES))
-        wave_bytes = ITERATIONS * (BYTES["distance"] * g.count(capi.DISTANCE) + BYTES["tet"] * g.count(capi.TET) + BYTES["position"]
-                                   * g.count(capi.POSITION) + BYTES["bend"] * g.count(capi.BEND) + BYTES["floor"] * g.count(capi.NODES)) / items
-        prof = kernel_profile(g, dict(BYTES, wave=wave_bytes))  # schedule exact: a launch mixes the kinds of one dependency level
-        dom = "layer" if "layer" in prof else "wave" if "wave" in prof else "tet" if "tet" in prof else max(prof, key=lambda k: prof[k]["avg_us"] * prof[k]["launches_per_substep"])
-        achieved = prof[dom]["algorithmic_GBs"]
+        dom = "layer" if lc.get("layer") else "wave" if lc.get("wave") else "tet"
+        per_unit = 1
+        if dom == "tet":
+            per_unit = BYTES["tet"]
+        elif dom == "wave":  # schedule exact: a launch mixes the kinds of one dependency level
+            items = ITERATIONS * (g.count(capi.DISTANCE) + g.count(capi.TET) + g.count(capi.POSITION) + g.count(capi.BEND) + g.count(capi.NODES))
+            per_unit = ITERATIONS * (BYTES["distance"] * g.count(capi.DISTANCE) + BYTES["tet"] * g.count(capi.TET) + BYTES["position"]
+                                     * g.count(capi.POSITION) + BYTES["bend"] * g.count(capi.BEND) + BYTES["floor"] * g.count(capi.NODES)) / items
         result = {
             "metric": "substeps/sec @100k particles (PBD distance+tet-strain, 20 iterations)",
             "value": value, "unit": "substeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -384,15 +584,15 @@ def main():
             "config": {"workload": "BASELINE configs[1]: %dx%dx%d lattice beam, %d particles, %d distance + %d tet-strain "
                                    "constraints, PBD, %d iterations, 1 substep/tick, one body per GPU"
                                    % (dims + (g.count(capi.NODES), g.count(capi.DISTANCE), g.count(capi.TET), ITERATIONS)),
-                       "schedule": args.schedule, "parallelism": "replicas x%d" % world,
-                       "launches_per_substep": sum(lc.values())},
+                       "schedule": args.schedule + (" (PIES_SCHEDULE_DEFAULT: what pies_create / Pies::Solver start with)" if sched == capi.SCHEDULE_DEFAULT else ""),
+                       "parallelism": "replicas x%d" % world, "launches_per_substep": sum(lc.values())},
             "projections_per_sec": value * proj,
-            "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_" + dom),
-                         "avg_launch_us": prof[dom]["avg_us"],
-                         "bytes_per_launch": dict(BYTES, wave=wave_bytes)[dom] * prof[dom]["units_per_launch"]},
-            "kernels": prof,
+            "roofline": None if args.no_roofline else roofline(g, dom, per_unit, note="algorithmic bytes = the projections and per-node steps "
+                                                               "a launch executes (160 B per tet, 52 per distance, 44 per position constraint, 136 per "
+                                                               "bend, 48 / 20 / 40 per node for predict / floor / velocity), tallied by the library"),
         }
+        if result["roofline"]:
+            result["roofline"]["graph_replay_us_per_launch"] = 1e6 * (elapsed / args.steps) / max(1, sum(lc.values()))
         # whole-substep algorithmic traffic over wall time (includes launch gaps)
         per_substep_bytes = (BYTES["predict"] + BYTES["velocity"] + ITERATIONS * BYTES["floor"]) * g.count(capi.NODES) + ITERATIONS * (
             BYTES["distance"] * g.count(capi.DISTANCE) + BYTES["tet"] * g.count(capi.TET) + BYTES["position"] * g.count(capi.POSITION)
@@ -400,8 +600,11 @@ def main():
         result["substep_algorithmic_GBs_per_gpu"] = per_substep_bytes * (value / world) / 1e9
     g.close()
 
-    if rank == 0 and world == 1:
-        if not args.no_exact and args.schedule == "layered":
+    if rank == 0:
+        if world == 1 and not args.quick:
+            log("tick-inclusive figures")
+            result["tick_inclusive"] = tick_inclusive(dims, device_index, sched, max(10, min(args.steps, 100)))
+        if world == 1 and not args.no_exact and args.schedule == "layered":
             log("coloured schedule")
             c = build_scene(capi, dims, 1234, schedule=capi.SCHEDULE_COLOURED, device=device_index)
             c.finalize()
@@ -409,10 +612,11 @@ def main():
             el = timed_ticks(c, steps, 2, lambda: None)
             result["coloured_schedule"] = {"value": steps * substeps_per_tick / el, "unit": "substeps/s",
                                            "launches_per_substep": sum(c.launch_counts().values()), "steps": steps,
-                                           "kernels": kernel_profile(c),
+                                           "roofline": roofline(c, "tet", BYTES["tet"]),
+                                           "isolated_replay_latencies": replay_latencies(c),
                                            "note": "schedule COLOURED: one launch per colour class (24 tet + 9 distance colours per iteration)"}
             c.close()
-        if not args.no_exact and args.schedule != "exact":
+        if world == 1 and not args.no_exact and args.schedule != "exact":
             log("exact schedule")
             e = build_scene(capi, dims, 1234, schedule=capi.SCHEDULE_EXACT, device=device_index)
             e.finalize()
@@ -420,22 +624,30 @@ def main():
             el = timed_ticks(e, steps, 1, lambda: None)
             result["exact_order"] = {"value": steps * substeps_per_tick / el, "unit": "substeps/s",
                                      "launches_per_substep": sum(e.launch_counts().values()), "steps": steps,
-                                     "note": "schedule EXACT: bit-identical to the reference's container-order sweep; one launch per level of "
-                                             "the whole-substep dependency DAG"}
+                                     "note": "schedule EXACT: the reference's order (containers swept sequentially in insertion order); the device "
+                                             "result is bit-identical to the ORACLE's container-order sweep (tests/test_pbd_parity_gpu.py) - the "
+                                             "oracle restates the reference with its own 3x3 SVD, so against Eigen's JacobiSVD this is a rounding-"
+                                             "level tolerance, not bit equality; one launch per level of the whole-substep dependency DAG"}
             e.close()
-        if not args.no_extras:
-            log("configs 3 and 4")
+        if world == 1 and not args.no_deviation:
+            log("order deviation")
+            result["order_deviation"] = order_deviation(device_index)
+        if world == 1 and not args.no_extras:
+            log("configs 3, 4, 5")
             result["other_configs"] = extra_configs(device_index)
-        if not args.no_scale:
-            log("1M-particle profiles")
+        if world == 1 and not args.no_scale:
+            log("1M-particle measurements")
             result["scale_1m"] = scale_profiles(device_index)
         if not args.no_cpu_baseline:
             log("CPU baseline")
-            result["cpu_baseline"] = cpu_baseline(dims, args.cpu_ticks)
+            result["cpu_baseline"] = cpu_baseline(dims, args.cpu_budget, with_all_cores=world == 1 and not args.quick)
+            if world == 1 and not args.no_extras:
+                result["other_configs"]["pd_config3"]["cpu_baseline"] = cpu_baseline_pd(scenes.L100K, args.cpu_budget)
+                result["other_configs"]["collisions_config4"]["cpu_baseline"] = cpu_baseline_collisions(args.cpu_budget)
         log("done")
-    if rank == 0:
         print(json.dumps(result))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

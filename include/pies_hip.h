@@ -216,6 +216,9 @@ int pies_failed(pies_solver_t* s, int* failed);
 int pies_get_tri_contacts(pies_solver_t* s, uint32_t* ids, uint32_t capacity, uint32_t* count);
 /* Node-node pairs resolved by the PBD collision pass since the last call (statistics). */
 int pies_collision_pairs(pies_solver_t* s, uint64_t* pairs);
+/* The same plus the candidates the pass looked at (bucket entries visited, the unit of SURVEY 8d's "16 B per candidate
+ * neighbour"); both counters restart. */
+int pies_collision_stats(pies_solver_t* s, uint64_t* pairs, uint64_t* candidates);
 
 /* ---- state access --------------------------------------------------------------------------- */
 int pies_count(const pies_solver_t* s, int what, uint32_t* out);

@@ -15,6 +15,9 @@
 #include <algorithm>
 #include <array>
 #include <cassert>
+#include <xmmintrin.h>
+#include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -435,35 +438,56 @@ static CellRange nodeCompRange(const Node& node, float scale) {
 }
 
 struct NodeHash {
-  std::unordered_map<CellId, std::vector<uint32_t>, CellHash> map;
-  void clear() { map.clear(); }
+  // 16 sub-maps like phmap's parallel_flat_hash_map<..., 4> the reference relies on (SpatialHash.h:134-176): a cell lives
+  // in sub-map hash % 16.  Single-threaded insertion fills them in one scan; the reference's scheme (`threads` = 16) has
+  // every thread scan ALL nodes and keep the cells of the sub-map it owns - sixteen times the range arithmetic, no locks.
+  // Either way a bucket lists its nodes in ascending index.
+  static constexpr uint32_t kSub = 16;
+  std::unordered_map<CellId, std::vector<uint32_t>, CellHash> sub[kSub];
+  int threads = 1;
+  static uint32_t owner(const CellId& c) { return static_cast<uint32_t>(CellHash()(c) % kSub); }
+  void clear() { for (auto& m : sub) m.clear(); }
   // SpatialHash.h:129-189
   void bulkInsert(const std::vector<Node>& nodes, float scale) {
-    for (uint32_t i = 0; i < nodes.size(); ++i) {
-      CellRange r = nodeCompRange(nodes[i], scale);
-      for (uint32_t dx = 0; dx < r.lengthX; ++dx)
-        for (uint32_t dy = 0; dy < r.lengthY; ++dy)
-          for (uint32_t dz = 0; dz < r.lengthZ; ++dz)
-            map[CellId{r.minX + dx, r.minY + dy, r.minZ + dz}].push_back(i);
+    if (threads <= 1) {
+      for (uint32_t i = 0; i < nodes.size(); ++i) {
+        CellRange r = nodeCompRange(nodes[i], scale);
+        for (uint32_t dx = 0; dx < r.lengthX; ++dx)
+          for (uint32_t dy = 0; dy < r.lengthY; ++dy)
+            for (uint32_t dz = 0; dz < r.lengthZ; ++dz) {
+              CellId c{r.minX + dx, r.minY + dy, r.minZ + dz};
+              sub[owner(c)][c].push_back(i);
+            }
+      }
+      return;
     }
+#pragma omp parallel for num_threads(kSub) schedule(static, 1)
+    for (int t = 0; t < static_cast<int>(kSub); ++t) {  // thread t owns sub-map t (SpatialHash.h:141-176)
+      for (uint32_t i = 0; i < nodes.size(); ++i) {
+        CellRange r = nodeCompRange(nodes[i], scale);
+        for (uint32_t dx = 0; dx < r.lengthX; ++dx)
+          for (uint32_t dy = 0; dy < r.lengthY; ++dy)
+            for (uint32_t dz = 0; dz < r.lengthZ; ++dz) {
+              CellId c{r.minX + dx, r.minY + dy, r.minZ + dz};
+              if (owner(c) == static_cast<uint32_t>(t)) sub[t][c].push_back(i);
+            }
+      }
+    }
+  }
+  const std::vector<uint32_t>* find(const CellId& c) const {
+    const auto& m = sub[owner(c)];
+    auto it = m.find(c);
+    return it != m.end() ? &it->second : nullptr;
   }
   void findCollisions(const CellRange& r, std::vector<const std::vector<uint32_t>*>& out) const {
     for (uint32_t dx = 0; dx < r.lengthX; ++dx)
       for (uint32_t dy = 0; dy < r.lengthY; ++dy)
-        for (uint32_t dz = 0; dz < r.lengthZ; ++dz) {
-          auto it = map.find(CellId{r.minX + dx, r.minY + dy, r.minZ + dz});
-          if (it != map.end()) out.push_back(&it->second);
-        }
+        for (uint32_t dz = 0; dz < r.lengthZ; ++dz)
+          if (const auto* b = find(CellId{r.minX + dx, r.minY + dy, r.minZ + dz})) out.push_back(b);
   }
   // SpatialHash.h:101-127
   void findCollisions(const Node& node, float scale, std::vector<const std::vector<uint32_t>*>& out) const {
-    CellRange r = nodeCompRange(node, scale);
-    for (uint32_t dx = 0; dx < r.lengthX; ++dx)
-      for (uint32_t dy = 0; dy < r.lengthY; ++dy)
-        for (uint32_t dz = 0; dz < r.lengthZ; ++dz) {
-          auto it = map.find(CellId{r.minX + dx, r.minY + dy, r.minZ + dz});
-          if (it != map.end()) out.push_back(&it->second);
-        }
+    findCollisions(nodeCompRange(node, scale), out);
   }
 };
 
@@ -622,9 +646,22 @@ struct SparseSym {  // full symmetric matrix as per-row ordered maps (setup-time
 struct BandedLLT {
   uint32_t n = 0, bw = 0;
   std::vector<uint32_t> perm, iperm;  // perm[new] = old
-  std::vector<float> L;               // row-major band: L[i*(bw+1) + (j - i + bw)] for i-bw <= j <= i
+  std::vector<float> L;               // column-major band: L(i, j) at L[j*(bw+1) + (i - j)] for j <= i <= j+bw
 
-  void order(const SparseSym& A) {
+  static uint32_t bandwidth_of(const SparseSym& A, const std::vector<uint32_t>& ip) {
+    uint32_t b = 0;
+    for (uint32_t i = 0; i < A.rows.size(); ++i)
+      for (auto& kv : A.rows[i]) {
+        uint32_t a = ip[i], c = ip[kv.first];
+        b = std::max(b, a > c ? a - c : c - a);
+      }
+    return b;
+  }
+
+  // Ordering with the smallest bandwidth among reverse Cuthill-McKee and the three sorts by a coordinate (`xyz`: 3 per
+  // node; for a beam the sort along its axis gives one cross-section, where Cuthill-McKee from a corner gives diagonal
+  // shells three times as wide).  Only rounding depends on the choice.
+  void order(const SparseSym& A, const float* xyz = nullptr) {
     n = static_cast<uint32_t>(A.rows.size());
     perm.clear();
     std::vector<char> seen(n, 0);
@@ -647,36 +684,68 @@ struct BandedLLT {
     std::reverse(perm.begin(), perm.end());
     iperm.assign(n, 0);
     for (uint32_t i = 0; i < n; ++i) iperm[perm[i]] = i;
-    bw = 0;
-    for (uint32_t i = 0; i < n; ++i)
-      for (auto& kv : A.rows[i]) {
-        uint32_t a = iperm[i], b = iperm[kv.first];
-        bw = std::max(bw, a > b ? a - b : b - a);
+    bw = bandwidth_of(A, iperm);
+    if (xyz) {
+      for (int axis = 0; axis < 3; ++axis) {
+        std::vector<uint32_t> p(n), ip(n);
+        std::iota(p.begin(), p.end(), 0u);
+        std::stable_sort(p.begin(), p.end(), [&](uint32_t a, uint32_t b) { return xyz[3 * a + axis] < xyz[3 * b + axis]; });
+        for (uint32_t i = 0; i < n; ++i) ip[p[i]] = i;
+        const uint32_t b = bandwidth_of(A, ip);
+        if (b < bw) { bw = b; perm.swap(p); iperm.swap(ip); }
       }
+    }
   }
 
+  // sum of a[k] * b[k] over [0, m): sixteen interleaved partial sums combined in a fixed order, so that the compiler may use
+  // vector registers without being allowed to reassociate
+  static float dot(const float* __restrict a, const float* __restrict b, ptrdiff_t m) {
+    float acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    ptrdiff_t k = 0;
+    for (; k + 16 <= m; k += 16)
+      for (int u = 0; u < 16; ++u) acc[u] += a[k + u] * b[k + u];
+    float tail = 0.0f;
+    for (; k < m; ++k) tail += a[k] * b[k];
+    for (int w = 8; w >= 1; w >>= 1)
+      for (int u = 0; u < w; ++u) acc[u] += acc[u + w];
+    return acc[0] + tail;
+  }
+
+  // Column-major band: L(i, j), j <= i <= j + bw, at L[j * (bw + 1) + (i - j)].  Right-looking (outer-product) form: after
+  // column k is scaled, every later column j of the window takes  L(j.., j) -= L(j, k) * L(j.., k)  - contiguous updates
+  // without a reduction, which the compiler vectorises as they stand (2.5e11 multiply-adds at 250k nodes).
+  // Fill-in decays geometrically away from K's sparsity pattern (K is dominated by m/h^2) and ends as subnormal numbers,
+  // which x86 multiplies in microcode ~100x slower: they are flushed to zero while the factorisation and the
+  // substitutions run (differences of 1e-38 in entries of order 1e3).
+  struct FlushSubnormals {
+    unsigned saved;
+    FlushSubnormals() : saved(_mm_getcsr()) { _mm_setcsr(saved | 0x8040u); }
+    ~FlushSubnormals() { _mm_setcsr(saved); }
+  };
+
   bool factor(const SparseSym& A) {
-    const ptrdiff_t W = static_cast<ptrdiff_t>(bw) + 1;
+    FlushSubnormals ftz;
+    const size_t W = static_cast<size_t>(bw) + 1;
     L.assign(static_cast<size_t>(n) * W, 0.0f);
     for (uint32_t io = 0; io < n; ++io)
       for (auto& kv : A.rows[io]) {
         uint32_t i = iperm[io], j = iperm[kv.first];
-        if (j <= i) L[i * W + (j + bw - i)] = kv.second;
+        if (j <= i) L[j * W + (i - j)] = kv.second;
       }
-    for (uint32_t i = 0; i < n; ++i) {
-      uint32_t j0 = i > bw ? i - bw : 0;
-      float* Li = L.data() + (static_cast<ptrdiff_t>(i) * W + bw - i);  // Li[j] valid for j0 <= j <= i
-      for (uint32_t j = j0; j <= i; ++j) {
-        const float* Lj = L.data() + (static_cast<ptrdiff_t>(j) * W + bw - j);
-        uint32_t k0 = std::max(j0, j > bw ? j - bw : 0u);
-        float s = Li[j];
-        for (uint32_t k = k0; k < j; ++k) s -= Li[k] * Lj[k];
-        if (j < i) {
-          Li[j] = s / Lj[j];
-        } else {
-          if (!(s > 0.0f)) return false;
-          Li[i] = std::sqrt(s);
-        }
+    for (uint32_t k = 0; k < n; ++k) {
+      float* __restrict ck = L.data() + k * W;
+      if (!(ck[0] > 0.0f)) return false;
+      const float d = std::sqrt(ck[0]);
+      ck[0] = d;
+      const uint32_t m = std::min<uint32_t>(bw, n - 1 - k);  // rows k+1 .. k+m below the diagonal
+      for (uint32_t r = 1; r <= m; ++r) ck[r] = ck[r] / d;
+      for (uint32_t r = 1; r <= m; ++r) {  // column j = k + r, rows j .. k + m
+        const float f = ck[r];
+        if (f == 0.0f) continue;
+        float* __restrict cj = L.data() + (static_cast<size_t>(k) + r) * W;
+        const float* __restrict src = ck + r;
+        const uint32_t len = m - r + 1;
+        for (uint32_t t = 0; t < len; ++t) cj[t] -= f * src[t];
       }
     }
     return true;
@@ -684,20 +753,22 @@ struct BandedLLT {
 
   // x (old ordering, stride 1 column) <- A^-1 b
   void solve(const float* b, float* x) const {
-    const ptrdiff_t W = static_cast<ptrdiff_t>(bw) + 1;
+    FlushSubnormals ftz;
+    const size_t W = static_cast<size_t>(bw) + 1;
     std::vector<float> y(n);
-    for (uint32_t i = 0; i < n; ++i) {
-      uint32_t j0 = i > bw ? i - bw : 0;
-      const float* Li = L.data() + (static_cast<ptrdiff_t>(i) * W + bw - i);
-      float s = b[perm[i]];
-      for (uint32_t k = j0; k < i; ++k) s -= Li[k] * y[k];
-      y[i] = s / Li[i];
+    for (uint32_t i = 0; i < n; ++i) y[i] = b[perm[i]];
+    for (uint32_t k = 0; k < n; ++k) {  // L y = b, column by column
+      const float* __restrict ck = L.data() + k * W;
+      const float v = y[k] / ck[0];
+      y[k] = v;
+      const uint32_t m = std::min<uint32_t>(bw, n - 1 - k);
+      float* __restrict yy = y.data() + k + 1;
+      for (uint32_t r = 0; r < m; ++r) yy[r] -= ck[r + 1] * v;
     }
-    for (uint32_t ii = n; ii-- > 0;) {
-      float s = y[ii];
-      uint32_t j1 = std::min<uint32_t>(n - 1, ii + bw);
-      for (uint32_t k = ii + 1; k <= j1; ++k) s -= L[k * W + (ii + bw - k)] * y[k];
-      y[ii] = s / L[ii * W + bw];
+    for (uint32_t k = n; k-- > 0;) {  // L^T x = y: row k of L^T is column k of L
+      const float* ck = L.data() + k * W;
+      const uint32_t m = std::min<uint32_t>(bw, n - 1 - k);
+      y[k] = (y[k] - dot(ck + 1, y.data() + k + 1, m)) / ck[0];
     }
     for (uint32_t i = 0; i < n; ++i) x[perm[i]] = y[i];
   }
@@ -744,6 +815,9 @@ struct ora_solver {
   // node at most once, so the result is bit-identical to the single-threaded sweep in the same order.
   int threads = 1;
   std::vector<uint32_t> batchOffs[5];
+  // the reference's own threading (CPU baseline): 16 threads for the node-hash insert (SpatialHash.h:134), threadCount
+  // threads for the PD collision detection (Solver.h:36, Solver.cpp:558-566); everything else is single-threaded there
+  bool referenceThreads = false;
 
   NodeHash hashNodes;
   std::vector<StaticCollision> staticCollisions;
@@ -923,9 +997,17 @@ void ora_solver::detectPD() {
           for (uint32_t dz = 0; dz < r.lengthZ; ++dz) triHash[CellId{r.minX + dx, r.minY + dy, r.minZ + dz}].push_back(ti);
     }
   }
-  for (uint32_t t = 0; t < T; ++t) {  // thread t, then the merge keeps this order (:852-874)
-    std::vector<TriCollision> mine;
-    std::vector<StaticCollision> mineStatic;
+  // threadCount threads, triangle ids strided (:714-715); with referenceThreads the loop really runs on that many OpenMP
+  // threads like the reference's std::threads, otherwise thread after thread - the merge (:852-874) is in thread order
+  // either way, so the lists are the same
+  std::vector<std::vector<TriCollision>> perThreadTri(T);
+  std::vector<std::vector<StaticCollision>> perThreadStatic(T);
+  std::vector<char> perThreadFailed(T, 0);
+#pragma omp parallel for num_threads(static_cast<int>(T)) schedule(static, 1) if (referenceThreads && T > 1)
+  for (int ti = 0; ti < static_cast<int>(T); ++ti) {
+    const uint32_t t = static_cast<uint32_t>(ti);
+    std::vector<TriCollision>& mine = perThreadTri[t];
+    std::vector<StaticCollision>& mineStatic = perThreadStatic[t];
     bool failed = false;
     std::vector<const std::vector<uint32_t>*> buckets;
     for (size_t triId = t; triId < triangles.size() && !failed; triId += T) {
@@ -986,9 +1068,12 @@ void ora_solver::detectPD() {
         }
       }
     }
-    if (failed) { simFailed = true; return; }  // :853-856
-    triCollisions.insert(triCollisions.end(), mine.begin(), mine.end());
-    staticCollisions.insert(staticCollisions.end(), mineStatic.begin(), mineStatic.end());
+    perThreadFailed[t] = failed ? 1 : 0;
+  }
+  for (uint32_t t = 0; t < T; ++t) {
+    if (perThreadFailed[t]) { simFailed = true; return; }  // :853-856
+    triCollisions.insert(triCollisions.end(), perThreadTri[t].begin(), perThreadTri[t].end());
+    staticCollisions.insert(staticCollisions.end(), perThreadStatic[t].begin(), perThreadStatic[t].end());
   }
 }
 
@@ -1006,6 +1091,12 @@ static inline bool tri_contact_normal(const std::vector<Node>& nodes, const TriC
     return true;
   }
   return false;
+}
+
+static std::vector<float> node_xyz(const std::vector<Node>& nodes) {
+  std::vector<float> p(3 * nodes.size());
+  for (size_t i = 0; i < nodes.size(); ++i) { p[3 * i] = nodes[i].position.x; p[3 * i + 1] = nodes[i].position.y; p[3 * i + 2] = nodes[i].position.z; }
+  return p;
 }
 
 // Src/Solver.cpp:162-486
@@ -1029,7 +1120,7 @@ void ora_solver::tickPD() {
     for (auto& c : goalCons)
       for (uint32_t id : c.ids) stiffness.ref(id, id) += c.w;  // :139-145
     for (auto& c : bendCons) addStiffness<BendCon, 4>(c, stiffness);
-    llt.order(stiffness);
+    llt.order(stiffness, node_xyz(nodes).data());
     state.assign(3 * n, 0.f);
     force.assign(3 * n, 0.f);
     msn.assign(3 * n, 0.f);
@@ -1060,10 +1151,15 @@ void ora_solver::tickPD() {
         auto it = stiffness.rows[i].find(kv.first);
         sys.ref(i, kv.first) = (it != stiffness.rows[i].end() ? it->second : 0.0f) + kv.second;
       }
-    if (!triCollisions.empty()) llt.order(sys);  // contact blocks fall outside K's band
-    else if (llt.bw == 0 || orderedWithContacts) llt.order(stiffness);
+    if (!triCollisions.empty()) llt.order(sys, node_xyz(nodes).data());  // contact blocks fall outside K's band
+    else if (llt.bw == 0 || orderedWithContacts) llt.order(stiffness, node_xyz(nodes).data());
     orderedWithContacts = !triCollisions.empty();
+    const bool timing = std::getenv("PIES_ORACLE_TIMING") != nullptr;
+    const auto tFactor0 = std::chrono::steady_clock::now();
     if (!llt.factor(sys)) { simFailed = true; return; }
+    if (timing)
+      std::fprintf(stderr, "[oracle] n %u bandwidth %u: factorisation %.2f s\n", nodeCount, llt.bw,
+                   std::chrono::duration<double>(std::chrono::steady_clock::now() - tFactor0).count());
 
     for (uint32_t iter = 0; iter < opt.iterations; ++iter) {
       force = msn;  // :266
@@ -1692,6 +1788,10 @@ void ora_set_batches(ora_solver* s, int type, const uint32_t* offs, uint32_t n_b
   s->batchOffs[type].assign(offs, offs + (n_batches ? n_batches + 1 : 0));
 }
 void ora_set_threads(ora_solver* s, int threads) { s->threads = threads < 1 ? 1 : threads; }
+void ora_set_reference_threads(ora_solver* s, int on) {
+  s->referenceThreads = on != 0;
+  s->hashNodes.threads = on ? 16 : 1;
+}
 void ora_set_collision_order(ora_solver* s, const uint32_t* order, uint32_t n) {
   s->collisionOrder.assign(order, order + n);
 }

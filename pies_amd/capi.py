@@ -40,6 +40,7 @@ SYMBOLS = [
     "pies_add_linked_regions", "pies_create_shape_matching_box", "pies_create_shape_matching_sheet", "pies_get_group",
     "pies_get_tri_contacts", "pies_tick_begin", "pies_export_acquire", "pies_export_release",
     "pies_read_positions_strided", "pies_set_pcg_retry", "pies_get_pcg_health", "pies_profile_in_situ",
+    "pies_collision_stats",
 ]
 
 
@@ -124,6 +125,7 @@ def load():
         "pies_export_release": [vp, C.c_uint64],
         "pies_read_positions_strided": [vp, vp, C.c_uint64, u32],
         "pies_set_pcg_retry": [vp, i32],
+        "pies_collision_stats": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
         "pies_get_pcg_health": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), pu, pu],
         "pies_profile_in_situ": [vp, i32, u32, pu, C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
     }
@@ -379,6 +381,12 @@ class Solver:
         n = C.c_uint64()
         self._ck(self._L.pies_collision_pairs(self._h, C.byref(n)))
         return n.value
+
+    def collision_stats(self):
+        """(resolved pairs, candidates looked at) since the last call"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._ck(self._L.pies_collision_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     # -- state ---------------------------------------------------------------------------------
     def count(self, what):

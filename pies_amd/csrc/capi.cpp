@@ -1228,6 +1228,22 @@ int pies_collision_pairs(pies_solver_t* s, uint64_t* pairs) {
   return PIES_OK;
 }
 
+int pies_collision_stats(pies_solver_t* s, uint64_t* pairs, uint64_t* candidates) {
+  if (!s) return PIES_ERR_INVALID;
+  if (pairs) *pairs = 0;
+  if (candidates) *candidates = 0;
+  if (!s->hash.counters) return PIES_OK;
+  uint32_t v[kHashCounters];
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipMemcpyAsync(v, s->hash.counters, sizeof(v), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  HIP_TRY(s, hipMemsetAsync(s->hash.counters + kCounterPairs, 0, sizeof(uint32_t), s->stream));
+  HIP_TRY(s, hipMemsetAsync(s->hash.counters + kCounterCandidates, 0, 2 * sizeof(uint32_t), s->stream));
+  if (pairs) *pairs = v[kCounterPairs];
+  if (candidates) *candidates = static_cast<uint64_t>(v[kCounterCandidates]) | (static_cast<uint64_t>(v[kCounterCandidates + 1]) << 32);
+  return PIES_OK;
+}
+
 int pies_count(const pies_solver_t* s, int what, uint32_t* out) {
   if (!s || !out) return PIES_ERR_INVALID;
   switch (what) {

@@ -11,9 +11,10 @@ namespace pies {
 
 // counters[]: [0] cells in use [1] cell entries E [3] failure flags [4..30] groups per pass [31] resolved pairs
 // [32] ticket (k_collide_flow) [33] epoch [34..36] / [37..39] bounding box of the cell ranges (min / max, as int)
-// [44] progress of k_collide_reference (nodes visited, diagnostics)
+// [44] progress of k_collide_reference (nodes visited, diagnostics) [46..47] candidates tested (64 bit, statistics)
 constexpr uint32_t kCounterUsed = 0, kCounterEntries = 1, kCounterFlags = 3, kCounterPass0 = 4, kCounterPairs = 31, kCounterTicket = 32,
-                   kCounterEpoch = 33, kCounterBoxMin = 34, kCounterBoxMax = 37, kCounterProgress = 44, kHashCounters = 64;
+                   kCounterEpoch = 33, kCounterBoxMin = 34, kCounterBoxMax = 37, kCounterProgress = 44, kCounterCandidates = 46 /* 64 bit: [46], [47] */,
+                   kHashCounters = 64;
 // failure flags: 1 non-finite position, 2 cell index overflow, 4 more than kMaxBucket nodes in a cell, 8 k_collide_flow wait timed
 // out, 128 more cell entries than reserved  (16, 32, 64 belong to the triangle grid's word, tri_kernels.h)
 constexpr uint32_t kRadixTile = 4096;  // entries per workgroup of a radix pass (256 threads x 16)

@@ -484,8 +484,9 @@ PIES_DEV uint32_t next_min_entry(const uint32_t* __restrict__ val, uint32_t star
 // comes straight from global memory.  Returns the number of resolved pairs.
 PIES_DEV uint32_t collide_bucket_global(const uint32_t* __restrict__ val, uint32_t bs, uint32_t bc, uint32_t i, PairState& a, float imi, float ri,
                                         float* pos, float* vel, const float* __restrict__ radius, int lane, const LaneRole role,
-                                        float friction, float staticThreshold) {
+                                        float friction, float staticThreshold, uint32_t& tested) {
   uint32_t resolved = 0;
+  tested += bc;  // statistics: candidates this visit looks at (SURVEY 8d counts 16 B per candidate neighbour)
   for (uint32_t base = 0; base < bc; base += 64) {
     const bool valid = base + lane < bc;
     const uint32_t j = valid ? (val[bs + base + lane] & kNodeMask) : 0xffffffffu;
@@ -526,7 +527,7 @@ PIES_DEV uint32_t collide_bucket_global(const uint32_t* __restrict__ val, uint32
 // node.  Only used for groups whose neighbourhood does not fit the LDS staging of k_collide (dense pile-ups).
 PIES_DEV uint32_t collide_group_global(const HashArrays& H, const GridBox& B, const uint32_t* __restrict__ val, float* pos, float* vel,
                                        const float* __restrict__ radius, uint32_t gslot, int lane, const LaneRole role, float friction,
-                                       float staticThreshold) {
+                                       float staticThreshold, uint32_t& tested) {
   uint32_t resolved = 0;
   const uint32_t gs = H.start[gslot], gn = H.end[gslot] - gs;
   for (uint32_t ge = next_min_entry(val, gs, gn, 0, lane); ge < gn; ge = next_min_entry(val, gs, gn, ge + 1, lane)) {
@@ -542,7 +543,7 @@ PIES_DEV uint32_t collide_group_global(const HashArrays& H, const GridBox& B, co
           const uint32_t cs = find_bucket(H, B, rg.x + (int)dx, rg.y + (int)dy, rg.z + (int)dz);
           if (cs == 0xffffffffu) continue;
           const uint32_t bs = H.start[cs];
-          resolved += collide_bucket_global(val, bs, H.end[cs] - bs, i, a, imi, ri, pos, vel, radius, lane, role, friction, staticThreshold);
+          resolved += collide_bucket_global(val, bs, H.end[cs] - bs, i, a, imi, ri, pos, vel, radius, lane, role, friction, staticThreshold, tested);
         }
     if (lane == 0) {
       st(pos + 4 * i, a.pix); st(pos + 4 * i + 1, a.piy); st(pos + 4 * i + 2, a.piz);
@@ -593,7 +594,7 @@ PIES_DEV uint32_t col_find(const uint32_t* key, uint32_t j) {  // j is present
 // of the same launch on another XCD.  Returns the number of resolved pairs.
 PIES_DEV uint32_t collide_group(const HashArrays& H, const GridBox& B, const uint32_t* __restrict__ val, ColTable& T, float* pos, float* vel,
                                 const float* __restrict__ radius, uint32_t gslot, int lane, const LaneRole role, float friction,
-                                float staticThreshold, int forceGlobal) {
+                                float staticThreshold, int forceGlobal, uint32_t& tested) {
   uint32_t resolved = 0;
   if (H.gcnt[gslot] == 0) return 0;
   // ---- the 2x2x2 cells above the group's cell: lanes 0..7 look one up each ------------------------------
@@ -637,7 +638,7 @@ PIES_DEV uint32_t collide_group(const HashArrays& H, const GridBox& B, const uin
     }
   }
   if (!staged) {
-    return collide_group_global(H, B, val, pos, vel, radius, gslot, lane, role, friction, staticThreshold);
+    return collide_group_global(H, B, val, pos, vel, radius, gslot, lane, role, friction, staticThreshold, tested);
   }
   for (uint32_t t = lane; t < kColSlots; t += 64) {
     const uint32_t j = T.key[t];
@@ -663,6 +664,7 @@ PIES_DEV uint32_t collide_group(const HashArrays& H, const GridBox& B, const uin
 #pragma unroll
           for (int q = 0; q < 8; ++q)
             if (c == static_cast<uint32_t>(q)) { off = cOff[q]; bc = cCnt[q]; }
+          tested += bc;
           for (uint32_t base = 0; base < bc; base += 64) {
             const bool valid = base + lane < bc;
             const uint32_t sj = valid ? T.ent[off + base + lane] : 0u;
@@ -730,11 +732,12 @@ __global__ void __launch_bounds__(kColBlock) k_collide(HashArrays H, float4* pos
   const GridBox B = grid_box(H.counters);
   const uint32_t* __restrict__ val = H.val[grid_passes(B) & 1u];
   const uint32_t ngroups = H.counters[4 + pass];
-  uint32_t resolved = 0;  // statistics, one atomic per wave at the end (a per-pair atomic on one word serialises the chip)
+  uint32_t resolved = 0, tested = 0;  // statistics, one atomic per wave at the end (a per-pair atomic on one word serialises the chip)
   for (uint32_t g = wave; g < ngroups; g += nwaves)
     resolved += collide_group(H, B, val, T, pos, vel, radius, H.passList[static_cast<size_t>(pass) * H.n + g], lane, role, friction,
-                              staticThreshold, forceGlobal);
+                              staticThreshold, forceGlobal, tested);
   if (lane == 0 && resolved) atomicAdd(&H.counters[31], resolved);
+  if (lane == 0 && tested) atomicAdd(reinterpret_cast<unsigned long long*>(&H.counters[kCounterCandidates]), static_cast<unsigned long long>(tested));
 }
 
 // The same order of conflicting groups in ONE launch.  Groups are handed out through a ticket counter in pass-major
@@ -764,7 +767,7 @@ __global__ void __launch_bounds__(kColBlock) k_collide_flow(HashArrays H, float4
     if (lane >= off) incl += v;
   }
   const uint32_t total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 26));
-  uint32_t resolved = 0;
+  uint32_t resolved = 0, tested = 0;
   for (;;) {
     uint32_t ticket = 0;
     if (lane == 0) ticket = atomicAdd(&H.counters[kCounterTicket], 1u);
@@ -797,10 +800,11 @@ __global__ void __launch_bounds__(kColBlock) k_collide_flow(HashArrays H, float4
     // the stamps were polled relaxed; this fence orders every later load of the wavefront after them (pairs with the
     // release store below): the predecessors' node writes are visible by the memory model, not by cache behaviour
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    resolved += collide_group(H, B, val, T, pos, vel, radius, gslot, lane, role, friction, staticThreshold, forceGlobal);
+    resolved += collide_group(H, B, val, T, pos, vel, radius, gslot, lane, role, friction, staticThreshold, forceGlobal, tested);
     if (lane == 0) __hip_atomic_store(H.done + gslot, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (lane == 0 && resolved) atomicAdd(&H.counters[31], resolved);
+  if (lane == 0 && tested) atomicAdd(reinterpret_cast<unsigned long long*>(&H.counters[kCounterCandidates]), static_cast<unsigned long long>(tested));
 }
 
 
@@ -817,7 +821,7 @@ __global__ void __launch_bounds__(64) k_collide_reference(HashArrays H, float4* 
   const LaneRole role = {lane % 3, lane / 3};
   const GridBox B = grid_box(H.counters);
   const uint32_t* __restrict__ val = H.val[grid_passes(B) & 1u];
-  uint32_t resolved = 0;
+  uint32_t resolved = 0, tested = 0;
   for (uint32_t i = 0; i < n; ++i) {
     PairState a = {ld(pos + 4 * i), ld(pos + 4 * i + 1), ld(pos + 4 * i + 2), ld(vel + 4 * i), ld(vel + 4 * i + 1), ld(vel + 4 * i + 2)};
     const float imi = ld(pos + 4 * i + 3);
@@ -841,7 +845,7 @@ __global__ void __launch_bounds__(64) k_collide_reference(HashArrays H, float4* 
       for (uint32_t q = 0; q < here; ++q) {
         const uint32_t bs = static_cast<uint32_t>(__shfl(static_cast<int>(myStart), static_cast<int>(q), 64));
         const uint32_t bc = static_cast<uint32_t>(__shfl(static_cast<int>(myCnt), static_cast<int>(q), 64));
-        if (bc) resolved += collide_bucket_global(val, bs, bc, i, a, imi, ri, pos, vel, radius, lane, role, friction, staticThreshold);
+        if (bc) resolved += collide_bucket_global(val, bs, bc, i, a, imi, ri, pos, vel, radius, lane, role, friction, staticThreshold, tested);
       }
     }
     if (lane == 0) {
@@ -852,6 +856,7 @@ __global__ void __launch_bounds__(64) k_collide_reference(HashArrays H, float4* 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   if (lane == 0 && resolved) atomicAdd(&H.counters[kCounterPairs], resolved);
+  if (lane == 0 && tested) atomicAdd(reinterpret_cast<unsigned long long*>(&H.counters[kCounterCandidates]), static_cast<unsigned long long>(tested));
 }
 
 // resets the work queue of k_collide_flow without a new hash build (profile replays)

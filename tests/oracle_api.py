@@ -33,11 +33,17 @@ class Options(C.Structure):
 
 
 def build(force=False):
-    if force or not os.path.exists(_SO) or any(
-            os.path.getmtime(os.path.join(_ROOT, "oracle", f)) > os.path.getmtime(_SO)
+    """The portable build (AVX2 + FMA), or - PIES_ORACLE_NATIVE=1, set by bench.py's cpu_baseline leg - the
+    -O3 -march=native one, which is always compiled on the machine that runs it."""
+    native = os.environ.get("PIES_ORACLE_NATIVE") == "1"
+    so = _SO.replace("libpies_oracle.so", "libpies_oracle_native.so") if native else _SO
+    if force or native or not os.path.exists(so) or any(
+            os.path.getmtime(os.path.join(_ROOT, "oracle", f)) > os.path.getmtime(so)
             for f in ("pies_oracle.cpp", "ora_math.h", "Makefile")):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle")])
-    return _SO
+        if native and os.path.exists(so):
+            os.remove(so)
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle")] + (["native"] if native else []))
+    return so
 
 
 _lib = None
@@ -84,6 +90,7 @@ def lib():
         L.ora_set_collision_order.argtypes = [vp, pu, u32]
         L.ora_set_batches.argtypes = [vp, i32, pu, u32]
         L.ora_set_threads.argtypes = [vp, i32]
+        L.ora_set_reference_threads.argtypes = [vp, i32]
         L.ora_count.restype = u32
         L.ora_count.argtypes = [vp, i32]
         L.ora_stat_collision_pairs.restype = C.c_uint64
@@ -242,6 +249,10 @@ class OracleSolver:
         """Conflict-free batches (n+1 slot offsets) of a container, for the multi-threaded sweep (set_threads > 1)."""
         offsets = _u32(offsets)
         lib().ora_set_batches(self._h, ctype, _pu(offsets), max(0, len(offsets) - 1))
+
+    def set_reference_threads(self, on):
+        """the reference's own threading: 16 threads for the node-hash insert, threadCount for PD collision detection"""
+        lib().ora_set_reference_threads(self._h, int(on))
 
     def set_threads(self, n):
         lib().ora_set_threads(self._h, int(n))

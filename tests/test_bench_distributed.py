@@ -50,3 +50,27 @@ def test_single_process_aggregate_is_identity():
     sys.path.insert(0, ROOT)
     import bench
     assert bench.aggregate(2.5, 40, None) == (2.5, 40)
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_end_to_end_on_one_gpu():
+    """main()'s N > 1 branch as the driver launches it - one fresh process per rank through torch.distributed.run,
+    process-group init, the all-reduce barrier around the timed region, max time / summed substeps, rank 0's JSON line -
+    rehearsed on a one-GPU box: both ranks share the card (device = LOCAL_RANK modulo the device count) and the timing
+    record travels over gloo (PIES_BENCH_BACKEND; the driver's 8-GPU run uses RCCL)."""
+    import json
+    import subprocess
+    env = dict(os.environ, PIES_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+           "--dims", "10", "10", "60", "--quick"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]  # rank 0 prints ONE line
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 5 and r["warmup"] == 2 and r["scaling"] == "weak"
+    assert r["config"]["parallelism"] == "replicas x2"
+    # value = the substeps of BOTH ranks over the slower rank's time
+    assert r["value"] * r["ms_per_step"] * r["steps"] / 1e3 == pytest.approx(2 * 5, rel=1e-6)
+    assert r["roofline"]["frac"] > 0 and r["cpu_baseline"]["value"] > 0

@@ -1,0 +1,50 @@
+"""Distance between the fast schedules and the reference order (report, don't gate).  The numbers printed
+here are the ones bench.py emits as `order_deviation`; the assertions only pin what must hold for any valid Gauss-Seidel
+order: finite states, the same bulk motion, constraint residuals of the same size."""
+import numpy as np
+import pytest
+
+import deviation
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config1_layered_and_coloured_vs_exact(pies):
+    names = {pies.SCHEDULE_EXACT: "exact", pies.SCHEDULE_COLOURED: "coloured", pies.SCHEDULE_LAYERED: "layered"}
+
+    def make(schedule):
+        g = pies.Solver(scenes.pbd_options(pies, 10))
+        scenes.build_beam(g, scenes.L1K)
+        scenes.perturb(g, 1234, 0.03)
+        g.set_flag(pies.FLAG_NODE_COLLISIONS, 0)
+        g.set_schedule(schedule)
+        return g
+    d = deviation.compare(make, pies, [pies.SCHEDULE_EXACT, pies.SCHEDULE_COLOURED, pies.SCHEDULE_LAYERED])
+    for sched, per in d.items():
+        for when, e in per.items():
+            print("config 1 %-8s vs exact %s: max|dpos| %.3g  com %.3g  residuals %s (exact: %s)" % (
+                names[sched], when, e["max_abs_dpos"], e["centre_of_mass_delta"], e["residuals"], e["residuals_reference_order"]))
+            assert e["finite"]
+            assert e["centre_of_mass_delta"] < 0.05          # lattice spacing 1, body size 9
+            for k, v in e["residuals"].items():
+                r = e["residuals_reference_order"][k]
+                assert v < 2.0 * r + 1e-3 and r < 2.0 * v + 1e-3, (k, v, r)
+
+
+def test_collision_rule_1_vs_reference_order(pies):
+    """config 4 in miniature (the reference-order pass is one sequential chain: ~20 us per node)"""
+    from test_collisions_gpu import particles
+    p, v = particles((12, 14, 16))
+
+    def make(rule):
+        g = pies.Solver(scenes.pbd_options(pies, 4))
+        g.addNodes(p)
+        g.set_velocities(v)
+        g.set_flag(pies.FLAG_REFERENCE_COLLISION_ORDER, rule == 0)
+        return g
+    d = deviation.compare(make, pies, [0, 1])
+    for when, e in d[1].items():
+        print("config 4 (12x14x16) parallel vs reference collision order %s: max|dpos| %.3g  com %.3g  extent %.3g" % (
+            when, e["max_abs_dpos"], e["centre_of_mass_delta"], e["extent_delta"]))
+        assert e["finite"] and e["centre_of_mass_delta"] < 0.05 and e["extent_delta"] < 0.5

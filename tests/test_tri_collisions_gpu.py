@@ -139,3 +139,36 @@ def test_thousands_of_contacts_level_schedule(pies, oracle, monkeypatch, contact
         assert np.abs(g.positions - o.positions).max() <= tol, t
         assert np.abs(g.velocities - o.velocities).max() <= tol / 0.012, t
     assert most > 1024 and not g.failed
+
+
+def test_config5_l250k_with_binding_contacts(pies, oracle):
+    """BASELINE config 5, one GPU's share: a 250 000-particle body (25x25x400 lattice beam, strain + volume constraints,
+    PD, 10 local/global iterations) with the point-triangle pipeline on AND binding: the beam lies on the floor (floor
+    contacts along its whole length) and a second body lands on it.  Teacher-forced ticks against the oracle (direct fp32
+    solve, re-ordered and re-factored with the contact blocks every substep like Solver.cpp:242-262): contact lists
+    equal entry for entry, positions within the PD tolerance."""
+    g = pies.Solver(pd_options(pies, 10))
+    o = oracle.OracleSolver(pd_options(oracle, 10))
+    W, H, D = scenes.L250K
+    for s in (g, o):
+        s.create_tet_box(W, H, D, translation=(0.0, 0.04, 0.0), w=1.0, volume=True, triangles=True)
+        s.create_tet_box(8, 6, 30, translation=(3.3, 0.04 + (H - 1) + 0.04, 40.4), w=1.0, volume=True, triangles=True)
+        v = s.velocities
+        v[W * H * D:, 1] = -2.0
+        s.set_velocities(v)
+        s.set_prev_positions(s.positions)
+    assert g.count(pies.NODES) == 250000 + 8 * 6 * 30
+    tol = tol_for(o.positions)
+    seen = 0
+    for t in range(3):
+        sync_state(g, o)
+        g.tick(); o.tick()
+        cg_, co = g.tri_collisions, o.tri_collisions
+        assert np.array_equal(cg_, co), (t, len(cg_), len(co))
+        seen = max(seen, len(co))
+        assert np.abs(g.positions - o.positions).max() <= tol, (t, np.abs(g.positions - o.positions).max(), tol)
+        assert np.abs(g.velocities - o.velocities).max() <= tol / 0.012, t
+        res, iters_used, solves = g.pcg_stats()
+        assert solves == 10 and res <= 3e-7 * 1.0001, (t, res)
+    assert seen > 200 and o.count(oracle.STATICS) > 10000 and not g.failed
+    assert g.pcg_health()["short_solves"] == 0

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""The program tools/profile_round.sh puts under rocprofv3: N ticks of one of bench.py's workloads, whole substeps
+(every kernel in its place), nothing else.  usage: profile_target.py config2|config3|config4|contacts N"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import bench  # noqa: E402
+import scenes  # noqa: E402
+from pies_amd import capi  # noqa: E402
+
+what, n = sys.argv[1], int(sys.argv[2])
+if what == "config2":
+    g = bench.build_scene(capi, scenes.L100K, 1234, schedule=capi.SCHEDULE_LAYERED, device=0)
+elif what == "config3":
+    g = bench.pd_beam(scenes.L100K, 0, settle=4)
+elif what == "config4":
+    p, v = bench.config4_particles()
+    g = capi.Solver(scenes.pbd_options(capi, 4), device=0)
+    g.addNodes(p)
+    g.set_velocities(v)
+elif what == "contacts":
+    g = bench.contact_scene(capi, 0)
+    g.finalize()
+    for _ in range(8):
+        g.tick_async(1)
+        g.synchronize()
+else:
+    raise SystemExit("unknown workload")
+g.finalize()
+for _ in range(n):
+    g.tick_async(1)
+    g.synchronize()
+print(what, "ticks", n, "failed", g.failed)
+g.close()
