@@ -266,7 +266,7 @@ static void enqueue_layered_substep(pies_solver* s, int only, uint32_t* counts, 
   for (const LayerItem& item : prog) {
     switch (item.type) {
       case ITEM_COLLIDE: {  // Solver.cpp:81-130
-        uint32_t nb = 33, nc = 1;
+        uint32_t nb = 34, nc = 1;
         if (ON(PIES_KERNEL_HASH)) { nb = launch_hash_build(st, s->hash, s->nd, s->opt.gridSpacing); U(s->nd.n); }
         probe_mark(s, PIES_KERNEL_HASH);
         if (ON(PIES_KERNEL_COLLIDE)) { nc = enqueue_collide(s, only == PIES_KERNEL_COLLIDE); U(s->nd.n); }
@@ -319,7 +319,7 @@ static void enqueue_pbd_substep(pies_solver* s, int only, uint32_t* counts, uint
     const WaveData W = {s->d_pc_id, s->d_pc_tw, s->d_dc_ids, s->d_dc_rw, s->d_tc_ids, s->d_tc_q0, s->d_tc_q1, s->d_tc_q2, s->d_bc_ids, s->d_bc_aw};
     size_t barrier = 0;
     auto collide = [&] {
-      uint32_t nb = 33, nc = 1;
+      uint32_t nb = 34, nc = 1;
       if (ON(PIES_KERNEL_HASH)) { nb = launch_hash_build(st, s->hash, s->nd, s->opt.gridSpacing); U(s->nd.n); }
       probe_mark(s, PIES_KERNEL_HASH);
       if (ON(PIES_KERNEL_COLLIDE)) { nc = enqueue_collide(s, only == PIES_KERNEL_COLLIDE); U(s->nd.n); }
@@ -356,7 +356,7 @@ static void enqueue_pbd_substep(pies_solver* s, int only, uint32_t* counts, uint
       C(PIES_KERNEL_BEND);
     }
     if (s->nodeCollisions) {  // Solver.cpp:81-130
-      uint32_t nb = 33, nc = 1;
+      uint32_t nb = 34, nc = 1;
       if (ON(PIES_KERNEL_HASH)) { nb = launch_hash_build(st, s->hash, s->nd, s->opt.gridSpacing); U(s->nd.n); }
       probe_mark(s, PIES_KERNEL_HASH);
       if (ON(PIES_KERNEL_COLLIDE)) { nc = enqueue_collide(s, only == PIES_KERNEL_COLLIDE); U(s->nd.n); }
@@ -940,11 +940,12 @@ int pies_finalize(pies_solver_t* s) {
     if (int rc = dev_alloc(s, n + 1ull, &H.entCount, true)) return rc;
     if (int rc = dev_alloc(s, n + 1ull, &H.entOff, true)) return rc;
     if (int rc = dev_alloc(s, (n + 1ull) / 2048 + 2, &H.scanSums, true)) return rc;
+    if (int rc = dev_alloc(s, 6ull * ((n + 1ull + 255) / 256), &H.boxPart, true)) return rc;
     for (int b = 0; b < 2; ++b) {
       if (int rc = dev_alloc(s, H.maxEntries, &H.key[b], true)) return rc;
       if (int rc = dev_alloc(s, H.maxEntries, &H.val[b], true)) return rc;
     }
-    if (int rc = dev_alloc(s, 256ull * ((H.maxEntries + kRadixTile - 1) / kRadixTile), &H.hist, true)) return rc;
+    if (int rc = dev_alloc(s, 256ull * ((H.maxEntries + kRadixTile - 1) / kRadixTile) + 256, &H.hist, true)) return rc;  // + the 256 digit totals
     if (int rc = dev_alloc(s, cap, &H.keys)) return rc;
     HIP_TRY(s, hipMemsetAsync(H.keys, 0xFF, static_cast<size_t>(cap) * sizeof(uint64_t), s->stream));
     if (int rc = dev_alloc(s, cap, &H.start, true)) return rc;

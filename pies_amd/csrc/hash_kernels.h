@@ -29,6 +29,7 @@ struct HashArrays {
   uint32_t* entCount;   // n + 1: cells the node overlaps (lx * ly * lz), then their exclusive prefix sum in entOff
   uint32_t* entOff;
   uint32_t* scanSums;   // tile sums of the prefix sum
+  int* boxPart;         // per workgroup of k_grid_range: bounding box of its nodes' cell ranges (min x y z, max x y z)
   // (cell key, node) entries: node-major before the sort, ascending (key, node) after it; ping-pong buffers
   uint64_t* key[2];
   uint32_t* val[2];     // node index | 0x80000000 when the cell is the node's minimum cell

@@ -112,7 +112,6 @@ __global__ void __launch_bounds__(kBlock) k_grid_reset(HashArrays H) {
   for (uint32_t u = blockIdx.x * kBlock + threadIdx.x; u < used; u += gridDim.x * kBlock) {
     const uint32_t s = H.used[u];
     H.keys[s] = kEmpty;
-    H.gcnt[s] = 0;
   }
 }
 __global__ void k_grid_zero(HashArrays H) {
@@ -121,8 +120,6 @@ __global__ void k_grid_zero(HashArrays H) {
   if (t >= kCounterPass0 && t < kCounterPass0 + 27) H.counters[t] = 0;  // groups per pass   (counters[3] = sticky failure flags)
   if (t == kCounterTicket) H.counters[t] = 0;                            // k_collide_flow's work queue
   if (t == kCounterEpoch) H.counters[t] += 1;  // completion stamps of earlier builds are stale by construction
-  if (t >= kCounterBoxMin && t < kCounterBoxMin + 3) H.counters[t] = static_cast<uint32_t>(INT_MAX);
-  if (t >= kCounterBoxMax && t < kCounterBoxMax + 3) H.counters[t] = static_cast<uint32_t>(INT_MIN);
 }
 
 // ---- range: NodeCompRange + cells per node + bounding box ---------------------------------------------------------
@@ -152,17 +149,51 @@ __global__ void __launch_bounds__(kBlock) k_grid_range(HashArrays H, const float
   int lo[3] = {have ? mx : INT_MAX, have ? my : INT_MAX, have ? mz : INT_MAX};
   int hi[3] = {have ? mx + static_cast<int>(lx) - 1 : INT_MIN, have ? my + static_cast<int>(ly) - 1 : INT_MIN,
                have ? mz + static_cast<int>(lz) - 1 : INT_MIN};
+  // bounding box of the workgroup's ranges -> boxPart[workgroup]; k_grid_box reduces the partial boxes (six global
+  // atomics per wavefront on six words took 0.5 ms at 500k nodes)
+  __shared__ int part[4][6];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     lo[a] = wave_min(lo[a]);
     hi[a] = wave_max(hi[a]);
   }
-  if ((threadIdx.x & 63) == 0 && lo[0] != INT_MAX) {
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { part[threadIdx.x >> 6][a] = lo[a]; part[threadIdx.x >> 6][3 + a] = hi[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int a = threadIdx.x;
+    int v = part[0][a];
+    for (int w = 1; w < 4; ++w) v = a < 3 ? min(v, part[w][a]) : max(v, part[w][a]);
+    H.boxPart[blockIdx.x * 6 + a] = v;
+  }
+}
+__global__ void __launch_bounds__(1024) k_grid_box(HashArrays H, uint32_t nparts) {
+  __shared__ int red[16][6];
+  int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
+  for (uint32_t b = threadIdx.x; b < nparts; b += 1024) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      atomicMin(reinterpret_cast<int*>(&H.counters[kCounterBoxMin + a]), lo[a]);
-      atomicMax(reinterpret_cast<int*>(&H.counters[kCounterBoxMax + a]), hi[a]);
+      lo[a] = min(lo[a], H.boxPart[b * 6 + a]);
+      hi[a] = max(hi[a], H.boxPart[b * 6 + 3 + a]);
     }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = wave_min(lo[a]);
+    hi[a] = wave_max(hi[a]);
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { red[threadIdx.x >> 6][a] = lo[a]; red[threadIdx.x >> 6][3 + a] = hi[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int a = threadIdx.x;
+    int v = red[0][a];
+    for (int w = 1; w < 16; ++w) v = a < 3 ? min(v, red[w][a]) : max(v, red[w][a]);
+    H.counters[(a < 3 ? kCounterBoxMin : kCounterBoxMax - 3) + a] = static_cast<uint32_t>(v);
   }
 }
 
@@ -276,36 +307,31 @@ __global__ void __launch_bounds__(kBlock) k_radix_hist(HashArrays H, uint32_t pa
   __syncthreads();
   H.hist[threadIdx.x * nblkMax + blk] = h[threadIdx.x];
 }
-// exclusive prefix sum over (digit, workgroup) in digit-major order, one workgroup
-__global__ void __launch_bounds__(1024) k_radix_scan(HashArrays H, uint32_t pass, uint32_t nblkMax) {
-  __shared__ uint32_t part[1024];
+// Prefix sums of the (digit, workgroup) counts in digit-major order, in two steps: workgroup d of this kernel turns row d
+// (the counts of digit d over the sorting workgroups) into its exclusive prefix and leaves the row's total in
+// hist[256 * nblkMax + d]; the scatter kernel adds the exclusive prefix of the 256 totals.
+__global__ void __launch_bounds__(kBlock) k_radix_scan(HashArrays H, uint32_t pass, uint32_t nblkMax) {
+  __shared__ uint32_t lds[8];
   const GridBox B = grid_box(H.counters);
   if (pass >= grid_passes(B)) return;
   const uint32_t E = H.counters[kCounterEntries];
   const uint32_t nblk = (E + kRadixTile - 1u) / kRadixTile;
-  const uint32_t m = 256u * nblk, t = threadIdx.x, per = (m + 1023u) / 1024u;
-  const uint32_t lo = min(m, t * per), hi = min(m, lo + per);
-  auto at = [&](uint32_t L) { return (L / nblk) * nblkMax + (L % nblk); };
-  uint32_t s = 0;
-  for (uint32_t k = lo; k < hi; ++k) s += H.hist[at(k)];
-  part[t] = s;
-  __syncthreads();
-  for (uint32_t off = 1; off < 1024; off <<= 1) {
-    const uint32_t a = t >= off ? part[t - off] : 0u;
-    __syncthreads();
-    part[t] += a;
-    __syncthreads();
+  uint32_t* __restrict__ row = H.hist + static_cast<size_t>(blockIdx.x) * nblkMax;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < nblk; base += kBlock) {
+    const uint32_t k = base + threadIdx.x;
+    const uint32_t v = k < nblk ? row[k] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan(v, lds, total);
+    if (k < nblk) row[k] = carry + ex;
+    carry += total;
   }
-  uint32_t run = part[t] - s;
-  for (uint32_t k = lo; k < hi; ++k) {
-    const uint32_t v = H.hist[at(k)];
-    H.hist[at(k)] = run;
-    run += v;
-  }
+  if (threadIdx.x == 0) H.hist[256u * nblkMax + blockIdx.x] = carry;
 }
 __global__ void __launch_bounds__(kBlock) k_radix_scatter(HashArrays H, uint32_t pass, uint32_t nblkMax) {
   __shared__ uint32_t cnt[4][256];  // per wavefront: running count of a digit, then the wavefront's base inside the workgroup
   __shared__ uint32_t gbase[256];
+  __shared__ uint32_t scanLds[8];
   const GridBox B = grid_box(H.counters);
   if (pass >= grid_passes(B)) return;
   const uint32_t E = H.counters[kCounterEntries];
@@ -359,7 +385,9 @@ __global__ void __launch_bounds__(kBlock) k_radix_scatter(HashArrays H, uint32_t
       cnt[w][d] = run;
       run += c;
     }
-    gbase[d] = H.hist[d * nblkMax + blk];
+    uint32_t all;
+    const uint32_t digitBase = block_exclusive_scan(H.hist[256u * nblkMax + d], scanLds, all);  // entries with a smaller digit
+    gbase[d] = digitBase + H.hist[d * nblkMax + blk];
   }
   __syncthreads();
 #pragma unroll
@@ -376,37 +404,67 @@ __global__ void __launch_bounds__(kBlock) k_radix_scatter(HashArrays H, uint32_t
 
 // ---- cells: bucket boundaries -> cell index; groups per pass ------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_grid_cells(HashArrays H) {
-  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  // a workgroup takes kRadixTile consecutive entries; the cells it creates are collected in LDS and appended to the list
+  // of cells in use with ONE global atomic (47k appends on one word took 0.4 ms at 500k nodes)
+  __shared__ uint32_t made[kRadixTile];  // at most one cell per entry of the tile (buckets of one node)
+  __shared__ uint32_t nmade, base;
   const uint32_t E = H.counters[kCounterEntries];
-  if (t >= E) return;
+  const uint32_t first = blockIdx.x * kRadixTile;
+  if (first >= E) return;
+  if (threadIdx.x == 0) nmade = 0;
+  __syncthreads();
   const GridBox B = grid_box(H.counters);
   const uint32_t fb = grid_passes(B) & 1u;  // the buffer the last pass wrote
   const uint64_t* __restrict__ key = H.key[fb];
-  const uint64_t k = key[t];
-  const bool head = t == 0 || key[t - 1] != k;
-  const bool tail = t + 1 == E || key[t + 1] != k;
-  const bool isMin = (H.val[fb][t] & kMinFlag) != 0u;
-  if (!(head || tail || isMin)) return;
-  bool created;
-  const uint32_t slot = insert_cell(H.keys, H.mask, k, created);
-  if (slot == 0xffffffffu) { atomicOr(&H.counters[kCounterFlags], 2u); return; }
-  if (created) H.used[atomicAdd(&H.counters[kCounterUsed], 1u)] = slot;
-  if (head) H.start[slot] = t;
-  if (tail) H.end[slot] = t + 1;
-  if (isMin) atomicAdd(&H.gcnt[slot], 1u);
+  for (uint32_t r = 0; r < kRadixTile / kBlock; ++r) {
+    const uint32_t t = first + r * kBlock + threadIdx.x;
+    if (t >= E) break;
+    const uint64_t k = key[t];
+    const bool head = t == 0 || key[t - 1] != k;
+    const bool tail = t + 1 == E || key[t + 1] != k;
+    if (!(head || tail)) continue;
+    bool created;
+    const uint32_t slot = insert_cell(H.keys, H.mask, k, created);  // whichever of the bucket's two ends comes first creates it
+    if (slot == 0xffffffffu) { atomicOr(&H.counters[kCounterFlags], 2u); continue; }
+    if (created) made[atomicAdd(&nmade, 1u)] = slot;
+    if (head) H.start[slot] = t;
+    if (tail) H.end[slot] = t + 1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && nmade) base = atomicAdd(&H.counters[kCounterUsed], nmade);
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < nmade; k += kBlock) H.used[base + k] = made[k];
 }
+// one lane per cell in use: its group size (entries carrying kMinFlag) and its place in the pass list.  Places are handed
+// out per workgroup: one global atomic per (workgroup, pass) instead of one per cell on 27 words.
 __global__ void __launch_bounds__(kBlock) k_grid_groups(HashArrays H) {
+  __shared__ uint32_t lcount[27], lbase[27];
   const uint32_t used = H.counters[kCounterUsed];
   const GridBox B = grid_box(H.counters);
-  for (uint32_t u = blockIdx.x * kBlock + threadIdx.x; u < used; u += gridDim.x * kBlock) {
-    const uint32_t s = H.used[u];
-    if (H.end[s] - H.start[s] > kMaxBucket) atomicOr(&H.counters[kCounterFlags], 4u);  // runaway pile-up: latch, like Solver.cpp:741-755
-    if (H.gcnt[s]) {
-      int x, y, z;
-      box_cell(B, H.keys[s], x, y, z);
-      const uint32_t pass = static_cast<uint32_t>(mod3(x) + 3 * mod3(y) + 9 * mod3(z));
-      H.passList[static_cast<size_t>(pass) * H.n + atomicAdd(&H.counters[kCounterPass0 + pass], 1u)] = s;
+  const uint32_t* __restrict__ val = H.val[grid_passes(B) & 1u];
+  for (uint32_t first = blockIdx.x * kBlock; first < used; first += gridDim.x * kBlock) {  // uniform per workgroup
+    if (threadIdx.x < 27) lcount[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t u = first + threadIdx.x;
+    uint32_t s = 0, pass = 0, rank = 0, gc = 0;
+    if (u < used) {
+      s = H.used[u];
+      const uint32_t bs = H.start[s], be = H.end[s];
+      if (be - bs > kMaxBucket) atomicOr(&H.counters[kCounterFlags], 4u);  // runaway pile-up: latch, like Solver.cpp:741-755
+      for (uint32_t e = bs; e < be; ++e) gc += val[e] >> 31;
+      H.gcnt[s] = gc;
+      if (gc) {
+        int x, y, z;
+        box_cell(B, H.keys[s], x, y, z);
+        pass = static_cast<uint32_t>(mod3(x) + 3 * mod3(y) + 9 * mod3(z));
+        rank = atomicAdd(&lcount[pass], 1u);
+      }
     }
+    __syncthreads();
+    if (threadIdx.x < 27 && lcount[threadIdx.x]) lbase[threadIdx.x] = atomicAdd(&H.counters[kCounterPass0 + threadIdx.x], lcount[threadIdx.x]);
+    __syncthreads();
+    if (gc) H.passList[static_cast<size_t>(pass) * H.n + lbase[pass] + rank] = s;
+    __syncthreads();
   }
 }
 
@@ -876,6 +934,7 @@ uint32_t launch_hash_build(hipStream_t st_, const HashArrays& H, const NodeArray
   hipLaunchKernelGGL(k_grid_reset, wide, dim3(kBlock), 0, st_, H); ++launches;
   hipLaunchKernelGGL(k_grid_zero, dim3(1), dim3(64), 0, st_, H); ++launches;
   hipLaunchKernelGGL(k_grid_range, grid_for(n + 1), dim3(kBlock), 0, st_, H, nd.pos, nd.radius, n, scale); ++launches;
+  hipLaunchKernelGGL(k_grid_box, dim3(1), dim3(1024), 0, st_, H, grid_for(n + 1).x); ++launches;
   const uint32_t m = n + 1, tiles = (m + kScanTile - 1) / kScanTile;
   hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kBlock), 0, st_, H.entCount, H.entOff, m, H.scanSums); ++launches;
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st_, H.scanSums, tiles); ++launches;
@@ -884,11 +943,11 @@ uint32_t launch_hash_build(hipStream_t st_, const HashArrays& H, const NodeArray
   const uint32_t nblkMax = (H.maxEntries + kRadixTile - 1) / kRadixTile;
   for (uint32_t pass = 0; pass < 8; ++pass) {  // passes beyond the key width exit at once
     hipLaunchKernelGGL(k_radix_hist, dim3(nblkMax), dim3(kBlock), 0, st_, H, pass, nblkMax);
-    hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, st_, H, pass, nblkMax);
+    hipLaunchKernelGGL(k_radix_scan, dim3(256), dim3(kBlock), 0, st_, H, pass, nblkMax);
     hipLaunchKernelGGL(k_radix_scatter, dim3(nblkMax), dim3(kBlock), 0, st_, H, pass, nblkMax);
     launches += 3;
   }
-  hipLaunchKernelGGL(k_grid_cells, grid_for(H.maxEntries), dim3(kBlock), 0, st_, H); ++launches;
+  hipLaunchKernelGGL(k_grid_cells, dim3(nblkMax), dim3(kBlock), 0, st_, H); ++launches;
   hipLaunchKernelGGL(k_grid_groups, wide, dim3(kBlock), 0, st_, H); ++launches;
   return launches;
 }
