@@ -545,10 +545,10 @@ static int poll_failure(pies_solver* s) {
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   if (flag) {  // like the reference's latch (Solver.cpp:741-755, 853-856): tick becomes a no-op
     s->simFailed = true;
-    s->error = flag & 2    ? "collision grid overflow"
+    s->error = flag & 2    ? "collision grid overflow (more cells or (cell, triangle) entries than reserved)"
                : flag & 4  ? "more than 2048 nodes overlap one grid cell (runaway pile-up)"
-               : flag & 16 ? "more than 1000 triangles in one grid cell (the reference's safety latch, Solver.cpp:751-755)"
-               : flag & 32 ? "a triangle's swept bounding box is non-finite or spans more than 4 grid cells per axis"
+               : flag & 16 ? "more than 1000 triangles in one grid cell, or more than 1000 cells in a triangle's search range (the reference's safety latches, Solver.cpp:741-755)"
+               : flag & 32 ? "a triangle's swept bounding box is non-finite"
                : flag & 64 ? "point-triangle contact list overflow"
                : flag & 8  ? "node-node collision pass: the wait for a neighbouring group timed out (PIES_COLLIDE_SPIN_LIMIT)"
                : flag & 128 ? "node-node collision grid: more cell entries than the build reserves (64 per node)"

@@ -236,6 +236,7 @@ int pd_build(pies_solver* s) {
     T.capacity = cap;
     T.mask = cap - 1;
     T.maxContacts = 16 * nt + 1024;
+    T.maxEntries = kTriMaxEntries * nt;
     if (int rc = dev_alloc(s, cap, &T.keys)) return rc;
     HIP_TRY(s, hipMemsetAsync(T.keys, 0xFF, static_cast<size_t>(cap) * sizeof(uint64_t), s->stream));
     if (int rc = dev_alloc(s, cap, &T.cnt, true)) return rc;

@@ -8,8 +8,13 @@
 
 namespace pies {
 
-constexpr uint32_t kTriMaxCellsPerAxis = 4;                     // a triangle's swept AABB may span 4^3 world-unit cells
-constexpr uint32_t kTriMaxEntries = kTriMaxCellsPerAxis * kTriMaxCellsPerAxis * kTriMaxCellsPerAxis;
+// A triangle's box over position and previous position spans up to 50 cells per axis when it is inserted (TriCompRange,
+// Solver.cpp:974-976) and up to 20 when it searches (sweptTriRange, :672-674); a longer range is EMPTY, as in the
+// reference.  Storage is reserved for kTriMaxEntries (cell, triangle) entries per triangle on average (a triangle of a
+// simulation mesh spans 1-8 world-unit cells); the first kTriMaxEntries cells of a triangle have their index slot cached
+// between the count and the fill pass, the rest are looked up again.  More entries in total than reserved latch a failure.
+constexpr uint32_t kTriInsertMaxCells = 50, kTriSearchMaxCells = 20;
+constexpr uint32_t kTriMaxEntries = 64;
 constexpr float kTriContactW = 10000.0f;                        // PointTriangleCollisionConstraint::w (CollisionConstraint.h:32)
 
 struct TriArrays {
@@ -25,6 +30,7 @@ struct TriArrays {
   uint32_t* triSlot;   // nt x kTriMaxEntries
   int4* rng;           // per triangle: min cell, packed lengths
   uint32_t *bucket, *bucketSorted;
+  uint32_t maxEntries;  // (cell, triangle) entries reserved in bucket / bucketSorted
   // contacts of the current substep, in the reference's list order
   uint32_t maxContacts;
   uint32_t *cntTri, *offTri;  // contacts per triangle and their list offsets, indexed by merge_rank(triangle)

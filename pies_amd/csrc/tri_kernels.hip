@@ -181,10 +181,9 @@ __global__ void __launch_bounds__(kBlock) k_tri_count(TriArrays T, const float4*
     m[k] = ok ? static_cast<int>(f) : 0;
     len[k] = ok ? static_cast<uint32_t>(ceilf(mx[k]) - static_cast<float>(static_cast<long long>(f))) : 0u;
   }
-  if (!ok || len[0] > kTriMaxCellsPerAxis || len[1] > kTriMaxCellsPerAxis || len[2] > kTriMaxCellsPerAxis) {
-    atomicOr(&T.counters[3], 32u);  // non-finite, or wider than this build's 4 cells per axis (the reference allows 20 / 50)
-    len[0] = len[1] = len[2] = 0;
-  }
+  if (!ok) atomicOr(&T.counters[3], 32u);  // non-finite
+  if (!ok || len[0] > kTriInsertMaxCells || len[1] > kTriInsertMaxCells || len[2] > kTriInsertMaxCells)
+    len[0] = len[1] = len[2] = 0;  // the reference returns an empty range (Solver.cpp:974-976)
   T.rng[t] = make_int4(m[0], m[1], m[2], static_cast<int>(len[0] | (len[1] << 8) | (len[2] << 16)));
   uint32_t e = 0;
   for (uint32_t dx = 0; dx < len[0]; ++dx)
@@ -192,7 +191,7 @@ __global__ void __launch_bounds__(kBlock) k_tri_count(TriArrays T, const float4*
       for (uint32_t dz = 0; dz < len[2]; ++dz, ++e) {
         bool created;
         const uint32_t s = insert_cell(T.keys, T.mask, pack_cell(m[0] + (int)dx, m[1] + (int)dy, m[2] + (int)dz), created);
-        T.triSlot[t * kTriMaxEntries + e] = s;
+        if (e < kTriMaxEntries) T.triSlot[t * kTriMaxEntries + e] = s;
         if (s == 0xffffffffu) { atomicOr(&T.counters[3], 2u); continue; }
         if (created) T.used[atomicAdd(&T.counters[0], 1u)] = s;
         atomicAdd(&T.cnt[s], 1u);
@@ -203,7 +202,9 @@ __global__ void __launch_bounds__(kBlock) k_tri_alloc(TriArrays T) {
   for (uint32_t u = blockIdx.x * kBlock + threadIdx.x; u < used; u += gridDim.x * kBlock) {
     const uint32_t s = T.used[u];
     if (T.cnt[s] > 1000u) atomicOr(&T.counters[3], 16u);  // Solver.cpp:751-755: a bucket of more than 1000 triangles fails the sim
-    T.start[s] = atomicAdd(&T.counters[1], T.cnt[s]);
+    const uint32_t at = atomicAdd(&T.counters[1], T.cnt[s]);
+    if (at + T.cnt[s] > T.maxEntries) { atomicOr(&T.counters[3], 2u); T.cnt[s] = 0; }  // more (cell, triangle) entries than reserved
+    T.start[s] = at;
     T.fill[s] = 0;
   }
 }
@@ -211,11 +212,17 @@ __global__ void __launch_bounds__(kBlock) k_tri_fill(TriArrays T) {
   const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= T.nt) return;
   const int4 rg = T.rng[t];
-  const uint32_t ne = (rg.w & 0xff) * ((rg.w >> 8) & 0xff) * ((rg.w >> 16) & 0xff);
-  for (uint32_t e = 0; e < ne; ++e) {
-    const uint32_t s = T.triSlot[t * kTriMaxEntries + e];
-    if (s != 0xffffffffu) T.bucket[T.start[s] + atomicAdd(&T.fill[s], 1u)] = t;
-  }
+  const uint32_t lx = rg.w & 0xff, ly = (rg.w >> 8) & 0xff, lz = (rg.w >> 16) & 0xff;
+  uint32_t e = 0;
+  for (uint32_t dx = 0; dx < lx; ++dx)
+    for (uint32_t dy = 0; dy < ly; ++dy)
+      for (uint32_t dz = 0; dz < lz; ++dz, ++e) {
+        const uint32_t s = e < kTriMaxEntries ? T.triSlot[t * kTriMaxEntries + e]
+                                              : find_cell(T.keys, T.mask, pack_cell(rg.x + (int)dx, rg.y + (int)dy, rg.z + (int)dz));
+        if (s == 0xffffffffu) continue;
+        const uint32_t k = atomicAdd(&T.fill[s], 1u);
+        if (k < T.cnt[s]) T.bucket[T.start[s] + k] = t;  // cnt was zeroed for a bucket beyond the reserved storage
+      }
 }
 __global__ void __launch_bounds__(kBlock) k_tri_sort(TriArrays T) {
   if (T.counters[3]) return;
@@ -250,14 +257,16 @@ __global__ void __launch_bounds__(kBlock) k_tri_detect(TriArrays T, const float4
 #pragma unroll
   for (int i = 0; i < 3; ++i) { a1[i] = xyz(pos[ia[i]]); a0[i] = xyz(prev[ia[i]]); }
   const int4 rg = T.rng[t];
-  const uint32_t lx = rg.w & 0xff, ly = (rg.w >> 8) & 0xff, lz = (rg.w >> 16) & 0xff;
-  uint32_t count = 0;
+  uint32_t lx = rg.w & 0xff, ly = (rg.w >> 8) & 0xff, lz = (rg.w >> 16) & 0xff;
+  if (lx > kTriSearchMaxCells || ly > kTriSearchMaxCells || lz > kTriSearchMaxCells) lx = ly = lz = 0;  // sweptTriRange: empty (Solver.cpp:672-674)
+  uint32_t count = 0, nonEmpty = 0;
   const uint32_t base = FILL ? T.offTri[rank] : 0u;
   for (uint32_t dx = 0; dx < lx; ++dx)
     for (uint32_t dy = 0; dy < ly; ++dy)
       for (uint32_t dz = 0; dz < lz; ++dz) {
         const uint32_t s = find_cell(T.keys, T.mask, pack_cell(rg.x + (int)dx, rg.y + (int)dy, rg.z + (int)dz));
         if (s == 0xffffffffu) continue;
+        if (!FILL && ++nonEmpty > 1000u) atomicOr(&T.counters[3], 16u);  // Solver.cpp:741-745: more than 1000 buckets in a range fails the sim
         const uint32_t bs = T.start[s], bc = T.cnt[s];
         for (uint32_t k = member; k < bc; k += TEAM) {
           const uint32_t o = T.bucketSorted[bs + k];

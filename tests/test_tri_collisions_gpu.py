@@ -172,3 +172,35 @@ def test_config5_l250k_with_binding_contacts(pies, oracle):
         assert solves == 10 and res <= 3e-7 * 1.0001, (t, res)
     assert seen > 200 and o.count(oracle.STATICS) > 10000 and not g.failed
     assert g.pcg_health()["short_solves"] == 0
+
+
+def test_wide_triangles_use_the_reference_range_limits(pies, oracle):
+    """A triangle's box over position and previous position may span up to 50 world-unit cells per axis when it is
+    inserted (TriCompRange, Solver.cpp:974-976) and up to 20 when it searches (sweptTriRange, :672-674); longer ranges
+    are empty.  Scene: a 30-cell-wide triangle (inserted, does not search), a 12-cell-wide one (does both), a 60-cell
+    wide one (neither), and a small tet box falling through them."""
+    big = np.float32([[-5.2, 1.30, -5.1], [24.7, 1.32, -5.3], [-5.4, 1.31, 24.6],       # 30 cells in x and z
+                      [-2.3, 0.90, -2.2], [9.4, 0.93, -2.1], [-2.2, 0.91, 9.5],         # 12 cells
+                      [-30.5, 0.5, -30.2], [29.6, 0.52, -30.1], [-30.3, 0.51, 29.4]])   # 60 cells: empty range
+    g = pies.Solver(pd_options(pies, 5))
+    o = oracle.OracleSolver(pd_options(oracle, 5))
+    for s in (g, o):
+        s.addNodes(big)
+        s.add_triangles([[0, 1, 2], [3, 4, 5], [6, 7, 8]])
+        s.create_tet_box(3, 3, 3, translation=(0.35, 1.40, 0.45), scale=0.6, w=1.0)
+        v = s.velocities
+        v[9:, 1] = -6.0
+        s.set_velocities(v)
+        s.set_prev_positions(s.positions)
+    tol = tol_for(o.positions[9:])
+    seen = 0
+    for t in range(8):
+        sync_state(g, o)
+        g.tick(); o.tick()
+        cg_, co = g.tri_collisions, o.tri_collisions
+        assert np.array_equal(cg_, co), (t, len(cg_), len(co))
+        seen += len(co)
+        assert np.abs(g.positions - o.positions).max() <= tol, t
+    assert seen > 20 and not g.failed and not o.failed
+    hit = set(int(b) for b in np.unique(o.tri_collisions[:, 1:])) if len(o.tri_collisions) else set()
+    assert not (hit & {6, 7, 8})  # nothing ever touches the triangle whose range is empty
