@@ -263,8 +263,12 @@ int pies_profile_substep(pies_solver_t* s, int kernel, uint32_t* launches, doubl
  * on the solver's stream.  launches = bracketed launches (for PIES_KERNEL_HASH / _COLLIDE one bracket is the whole grid
  * build / resolve pass), total_ms = the sum of their event times, units as in pies_profile_substep.  For the CG classes
  * (PD_SPMV, PD_CG_UPDATE) the solves of this pass do not take the converged early exit, so every bracketed launch does
- * the full work.  The node state is put back afterwards. */
-int pies_profile_in_situ(pies_solver_t* s, int kernel, uint32_t substeps, uint32_t* launches, double* total_ms, uint64_t* units);
+ * the full work.  bracket_overhead_ms (may be NULL): what one bracket costs by itself, measured in the same pass around one
+ * and around two launches of an empty kernel (the event packets and the wait for the end-of-kernel cache write-back: several
+ * microseconds, i.e. most of a bracket around a short kernel) - subtract it per launch to compare with rocprofv3's
+ * kernel durations.  The node state is put back afterwards. */
+int pies_profile_in_situ(pies_solver_t* s, int kernel, uint32_t substeps, uint32_t* launches, double* total_ms, uint64_t* units,
+                         double* bracket_overhead_ms);
 /* launches per substep of the captured graph, per kernel class (PIES_KERNEL_COUNT entries) */
 int pies_launch_counts(pies_solver_t* s, uint32_t* out);
 

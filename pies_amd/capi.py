@@ -127,7 +127,7 @@ def load():
         "pies_set_pcg_retry": [vp, i32],
         "pies_collision_stats": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
         "pies_get_pcg_health": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), pu, pu],
-        "pies_profile_in_situ": [vp, i32, u32, pu, C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
+        "pies_profile_in_situ": [vp, i32, u32, pu, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -457,10 +457,12 @@ class Solver:
 
     def profile_in_situ(self, kernel, substeps=3):
         """Whole substeps launched eagerly with HIP events around every launch of `kernel` (all other kernels run as
-        well, so caches are in the state the substep leaves them in); returns (launches, ms, units)."""
-        n, ms, units = C.c_uint32(), C.c_double(), C.c_uint64()
-        self._ck(self._L.pies_profile_in_situ(self._h, kernel, substeps, C.byref(n), C.byref(ms), C.byref(units)))
-        return n.value, ms.value, units.value
+        well, so caches are in the state the substep leaves them in); returns (launches, ms, units, bracket_overhead_ms):
+        ms is the sum of the brackets, bracket_overhead_ms what one bracket costs around nothing (calibrated in the same
+        pass with an empty kernel)."""
+        n, ms, units, ov = C.c_uint32(), C.c_double(), C.c_uint64(), C.c_double()
+        self._ck(self._L.pies_profile_in_situ(self._h, kernel, substeps, C.byref(n), C.byref(ms), C.byref(units), C.byref(ov)))
+        return n.value, ms.value, units.value, ov.value
 
     def profile_substep(self, kernel):
         """One un-graphed substep with per-dispatch timing of `kernel`; returns (launches, ms, units)."""

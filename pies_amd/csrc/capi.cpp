@@ -396,7 +396,8 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
     if (s->tetVolumePaired) {  // both projections in one launch, accounted to the strain class
       if (ON(PIES_KERNEL_PD_LOCAL_TET)) {
         launch_pd_local_tet_pair(st, s->nd.pos, s->d_tc_ids, s->d_tc_q0, s->d_tc_q1, s->d_tc_q2, s->d_vc_q2,
-                                 pd.contrib + s->slotBase[PIES_TET], pd.contrib + s->slotBase[PIES_VOLUME], nTet);
+                                 pd.contrib + s->slotBase[PIES_TET], pd.contrib + s->slotBase[PIES_VOLUME], nTet,
+                                 tri && only < 0 ? &pd.tri : nullptr, s->opt.collisionThickness);  // + the contacts' local step
         U(nTet);
       }
       C(PIES_KERNEL_PD_LOCAL_TET);
@@ -415,7 +416,7 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
     if (only < 0) {
       launch_pd_local_bend(st, s->nd.pos, s->d_bc_ids, s->d_bc_aw, pd.contrib + s->slotBase[PIES_BEND], (uint32_t)s->h_bend.size());
       launch_pd_local_shape(st, s->nd.pos, pd);                        // goal targets are constants between transform updates
-      if (tri) launch_pd_local_tri(st, pd.tri, s->nd.pos, s->opt.collisionThickness);  // Solver.cpp:298-300
+      if (tri && !(s->tetVolumePaired && nTet)) launch_pd_local_tri(st, pd.tri, s->nd.pos, s->opt.collisionThickness);  // Solver.cpp:298-300
     }
     if (ON(PIES_KERNEL_PD_RHS)) { launch_pd_rhs(st, s->nd, pd); U(s->nd.n); }    // Solver.cpp:266, 310-349
     C(PIES_KERNEL_PD_RHS);
@@ -1482,7 +1483,8 @@ int pies_profile_substep(pies_solver_t* s, int kernel, uint32_t* launches, doubl
   return PIES_OK;
 }
 
-int pies_profile_in_situ(pies_solver_t* s, int kernel, uint32_t substeps, uint32_t* launches, double* total_ms, uint64_t* units) {
+int pies_profile_in_situ(pies_solver_t* s, int kernel, uint32_t substeps, uint32_t* launches, double* total_ms, uint64_t* units,
+                         double* bracket_overhead_ms) {
   if (!s || kernel < 0 || kernel >= PIES_KERNEL_COUNT || substeps == 0) return PIES_ERR_INVALID;
   if (s->device == PIES_DEVICE_NONE) return fail(s, PIES_ERR_HIP, "host-only handle");
   if (int rc = ensure_ready(s)) return rc;
@@ -1520,6 +1522,33 @@ int pies_profile_in_situ(pies_solver_t* s, int kernel, uint32_t substeps, uint32
   if (launches) *launches = static_cast<uint32_t>(probe.used / 2);
   if (total_ms) *total_ms = ms;
   if (units) *units = u;
+  if (bracket_overhead_ms) {
+    // What a bracket costs by itself (the two event packets, the wait for the kernel's end-of-kernel cache write-back): the
+    // same brackets around ONE and around TWO launches of an empty kernel; the difference is the empty kernel, the rest the
+    // overhead.  Short kernels (a few microseconds) are dominated by it.
+    const int reps = 24;
+    double one = 0.0, two = 0.0;
+    launch_noop(s->stream);  // first launch of the kernel: code object load, not part of the calibration
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    for (int count = 1; count <= 2; ++count) {
+      probe.used = 0;
+      for (int r = 0; r < reps; ++r) {
+        probe.mark();
+        for (int c = 0; c < count; ++c) launch_noop(s->stream);
+        probe.mark();
+      }
+      HIP_TRY(s, hipGetLastError());
+      HIP_TRY(s, hipStreamSynchronize(s->stream));
+      double sum = 0.0;
+      for (size_t k = 0; k + 1 < probe.used; k += 2) {
+        float e = 0.0f;
+        HIP_TRY(s, hipEventElapsedTime(&e, probe.events[k], probe.events[k + 1]));
+        sum += e;
+      }
+      (count == 1 ? one : two) = sum / reps;
+    }
+    *bracket_overhead_ms = std::max(0.0, one - std::max(0.0, two - one));
+  }
   s->stale = 7u;
   return PIES_OK;
 }

@@ -78,6 +78,8 @@ void launch_lfloor(hipStream_t st, const NodeArrays& nd, const LayerData& D, con
 void launch_lposition(hipStream_t st, const LayerData& D, uint32_t start, uint32_t count);
 void launch_lcopy(hipStream_t st, const NodeArrays& nd, const LayerData& D, bool toNodeArray);
 
+// an empty kernel (one wavefront): calibrates the cost of an event bracket (pies_profile_in_situ)
+void launch_noop(hipStream_t st);
 // Solver.cpp:47-52
 void launch_predict(hipStream_t st, const NodeArrays& nd, float dt, float gravity);
 // Solver.cpp:132-136

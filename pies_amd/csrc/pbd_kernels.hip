@@ -193,6 +193,8 @@ void launch_velocity(hipStream_t st, const NodeArrays& nd, float dt, float dampi
   if (nd.n == 0) return;
   PIES_LAUNCH(k_velocity, kBlock, nd.n, st, nd.pos, nd.prev, nd.vel, nd.radius, nd.n, dt, damping, friction, floorHeight);
 }
+__global__ void k_noop() {}
+void launch_noop(hipStream_t st) { hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, st); }
 void launch_position(hipStream_t st, float4* pos, const uint32_t* ids, const float4* target_w, uint32_t start,
                      uint32_t count) {
   if (count == 0) return;

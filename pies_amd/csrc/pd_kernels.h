@@ -79,8 +79,11 @@ void launch_pd_local_distance(hipStream_t st, const float4* pos, const uint2* id
 void launch_pd_local_tet(hipStream_t st, bool volume, const float4* pos, const uint4* ids, const float4* q0, const float4* q1,
                          const float4* q2, Vec3f* contrib, uint32_t count);
 // strain + volume constraints over identical elements (same ids, same Qinv), fused
+// tri != nullptr: the launch also runs the local step of the point-triangle contacts (launch_pd_local_tri's work) in a few
+// extra workgroups
 void launch_pd_local_tet_pair(hipStream_t st, const float4* pos, const uint4* ids, const float4* q0, const float4* q1, const float4* q2,
-                              const float4* vq2, Vec3f* contribTet, Vec3f* contribVol, uint32_t count);
+                              const float4* vq2, Vec3f* contribTet, Vec3f* contribVol, uint32_t count, const TriArrays* tri = nullptr,
+                              float thickness = 0.0f);
 void launch_pd_local_bend(hipStream_t st, const float4* pos, const uint4* ids, const float2* angle_w, Vec3f* contrib, uint32_t count);
 void launch_pd_local_shape(hipStream_t st, const float4* pos, const PdArrays& pd);
 void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd);

@@ -191,8 +191,8 @@ __global__ void __launch_bounds__(kBlock) k_pd_local_tet(const float4* __restric
 // projections - the arithmetic of each is exactly that of its own kernel above.
 PIES_DEV void local_tet_pair(const float4* __restrict__ pos, const uint4* __restrict__ ids, const float4* __restrict__ q0,
                              const float4* __restrict__ q1, const float4* __restrict__ q2, const float4* __restrict__ vq2,
-                             Vec3f* __restrict__ contribTet, uint32_t count) {
-  const uint32_t c = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
+                             Vec3f* __restrict__ contribTet, uint32_t count, uint32_t tetBlocks) {
+  const uint32_t c = xcd_block(blockIdx.x, tetBlocks) * kBlock + threadIdx.x;  // (the launch may carry extra workgroups behind these)
   if (c >= count) return;
   const float4 a2 = q2[c], v2 = vq2[c];
   TetFrame t;
@@ -210,11 +210,54 @@ PIES_DEV void local_tet_pair(const float4* __restrict__ pos, const uint4* __rest
 }
 // (Asking for 5 wavefronts per SIMD - 77 VGPRs instead of 108, no spill - measured the same on one box: 26.0 / 186 us
 // against 26.1 / 192 us at 100k / 5.8M element pairs.)
+// Local step of the point-triangle contacts (CollisionConstraint.cpp:86-124) and w * (AtA p)_i (:176-194): the body of
+// tri_kernels.hip's k_pd_local_tri (same IEEE sequence), run by a few extra workgroups of the fused strain + volume launch
+// so that a substep without contacts does not pay a launch boundary per local/global iteration for it.
+PIES_DEV void local_tri_contacts(const TriArrays& T, const float4* __restrict__ pos, float thickness, uint32_t block, uint32_t nblocks) {
+  const uint32_t M = T.counters[2];
+  for (uint32_t c = block * kBlock + threadIdx.x; c < M; c += nblocks * kBlock) {
+    const uint4 id = T.ids[c];
+    const float4 q[4] = {pos[id.x], pos[id.y], pos[id.z], pos[id.w]};
+    float p[4][3] = {{q[0].x, q[0].y, q[0].z}, {q[1].x, q[1].y, q[1].z}, {q[2].x, q[2].y, q[2].z}, {q[3].x, q[3].y, q[3].z}};
+    const float rel[3] = {p[0][0] - p[1][0], p[0][1] - p[1][1], p[0][2] - p[1][2]};
+    const float a[3] = {p[2][0] - p[1][0], p[2][1] - p[1][1], p[2][2] - p[1][2]};
+    const float b[3] = {p[3][0] - p[1][0], p[3][1] - p[1][1], p[3][2] - p[1][2]};
+    const float cr[3] = {a[1] * b[2] - b[1] * a[2], a[2] * b[0] - b[2] * a[0], a[0] * b[1] - b[0] * a[1]};
+    const float inv = 1.0f / sqrtf(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+    const float n[3] = {cr[0] * inv, cr[1] * inv, cr[2] * inv};
+    const float nDotP = n[0] * rel[0] + n[1] * rel[1] + n[2] * rel[2];
+    if (nDotP < thickness) {
+      const float d = thickness - nDotP;
+      p[0][0] = p[0][0] + d * n[0];
+      p[0][1] = p[0][1] + d * n[1];
+      p[0][2] = p[0][2] + d * n[2];
+    }
+    // AtA = [[3,-1,-1,-1],[-1,1,0,0],[-1,0,1,0],[-1,0,0,1]], products accumulated from 0 in column order
+    const float AtA[4][4] = {{3.f, -1.f, -1.f, -1.f}, {-1.f, 1.f, 0.f, 0.f}, {-1.f, 0.f, 1.f, 0.f}, {-1.f, 0.f, 0.f, 1.f}};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ax += AtA[i][k] * p[k][0];
+        ay += AtA[i][k] * p[k][1];
+        az += AtA[i][k] * p[k][2];
+      }
+      T.contrib[4 * c + i] = make_float4(kTriContactW * ax, kTriContactW * ay, kTriContactW * az, 0.f);
+    }
+  }
+}
+constexpr uint32_t kTriLocalBlocks = 64;  // extra workgroups of the fused launch that sweep the contact list
 __global__ void __launch_bounds__(kBlock) k_pd_local_tet_pair(const float4* __restrict__ pos, const uint4* __restrict__ ids,
                                                               const float4* __restrict__ q0, const float4* __restrict__ q1,
                                                               const float4* __restrict__ q2, const float4* __restrict__ vq2,
-                                                              Vec3f* __restrict__ contribTet, uint32_t count) {
-  local_tet_pair(pos, ids, q0, q1, q2, vq2, contribTet, count);
+                                                              Vec3f* __restrict__ contribTet, uint32_t count, TriArrays T,
+                                                              float thickness, uint32_t tetBlocks) {
+  if (blockIdx.x >= tetBlocks) {  // uniform per workgroup
+    local_tri_contacts(T, pos, thickness, blockIdx.x - tetBlocks, kTriLocalBlocks);
+    return;
+  }
+  local_tet_pair(pos, ids, q0, q1, q2, vq2, contribTet, count, tetBlocks);
 }
 
 // BendConstraint in PD (Constraints.cpp:312-366): A = B = I, contribution = w * projected_i.
@@ -947,10 +990,14 @@ void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd) {
                      pd.incSlotD, nd.pos, pd.nstatic, pd.statp, pd.rhs, pd.cg.tIncCnt, pd.cg.tIncStart, pd.cg.tInc, pd.tContrib, nd.n);
 }
 void launch_pd_local_tet_pair(hipStream_t st, const float4* pos, const uint4* ids, const float4* q0, const float4* q1, const float4* q2,
-                              const float4* vq2, Vec3f* contribTet, Vec3f* contribVol, uint32_t count) {
+                              const float4* vq2, Vec3f* contribTet, Vec3f* contribVol, uint32_t count, const TriArrays* tri,
+                              float thickness) {
   if (count == 0) return;
   (void)contribVol;  // the pair's two contributions are added into the strain constraint's records
-  hipLaunchKernelGGL(k_pd_local_tet_pair, grid_for(count), dim3(kBlock), 0, st, pos, ids, q0, q1, q2, vq2, contribTet, count);
+  const uint32_t tetBlocks = grid_for(count).x;
+  const bool withTri = tri && tri->nt;
+  hipLaunchKernelGGL(k_pd_local_tet_pair, dim3(tetBlocks + (withTri ? kTriLocalBlocks : 0u)), dim3(kBlock), 0, st, pos, ids, q0, q1, q2, vq2,
+                     contribTet, count, withTri ? *tri : TriArrays{}, thickness, tetBlocks);
 }
 void launch_pd_local_bend(hipStream_t st, const float4* pos, const uint4* ids, const float2* angle_w, Vec3f* contrib, uint32_t count) {
   if (count == 0) return;

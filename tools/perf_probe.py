@@ -32,13 +32,17 @@ elif what == "contacts":
     bench.frame_loop(g, 12)
     B = bench.pd_bytes(g)
     classes = {k: B[k] for k in ("pd_local_tet", "pd_rhs", "pd_spmv")}
+if os.environ.get("PROBE_NO_TRI") == "1":
+    g.set_flag(capi.FLAG_TRIANGLE_COLLISIONS, 0)
 g.finalize()
 el = bench.timed_ticks(g, ticks, 3, lambda: None)
 print("%s: %.1f substeps/s (%.3f ms/substep), %d launches/substep, failed %s" % (what, ticks / el, 1e3 * el / ticks, sum(g.launch_counts().values()), g.failed))
 for cls, per in classes.items():
-    n, ms, units = g.profile_in_situ(bench.K[cls], 2)
+    n, ms, units, ov = g.profile_in_situ(bench.K[cls], 2)
     if n:
-        print("  in situ %-14s %4d brackets  avg %9.1f us   %8.1f GB/s by the survey's bytes" % (cls, n, 1e3 * ms / n, per * units / (ms * 1e-3) / 1e9))
+        net = max(ms - n * ov, 0.05 * ms)
+        print("  in situ %-14s %4d brackets  avg %9.1f us (bracket %.1f - overhead %.1f)   %8.1f GB/s by the survey's bytes" % (
+            cls, n, 1e3 * net / n, 1e3 * ms / n, 1e3 * ov, per * units / (net * 1e-3) / 1e9))
     try:
         n, ms, units = g.profile_substep(bench.K[cls])
         if n:
