@@ -102,22 +102,22 @@ def timed_ticks(solver, steps, warmup, barrier):
 
 
 # ---- rooflines ---------------------------------------------------------------------------------------------------------
-def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc passes (separate FETCH_SIZE / WRITE_SIZE
-    passes, gfx950 correction (2 FETCH + WRITE) * 1024, see profiles/README.md); (None, None) when no pass was recorded."""
-    for name in ("r02_pmc_traffic.json", "pmc_traffic.json"):
-        path = os.path.join(ROOT, "profiles", name)
+def pmc_traffic(kernel_name, workload):
+    """HBM bytes per launch of `kernel_name` in `workload` from the committed rocprofv3 --pmc passes (separate FETCH_SIZE /
+    WRITE_SIZE passes over tools/profile_target.py <workload>, gfx950 correction (2 FETCH + WRITE) * 1024, see
+    profiles/README.md); (None, None) when no pass was recorded."""
+    for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")), reverse=True):
         try:
-            with open(path) as f:
-                v = json.load(f).get(kernel_name, {}).get("hbm_bytes_per_launch")
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                v = json.load(f).get(workload, {}).get(kernel_name, {}).get("hbm_bytes_per_launch")
             if v is not None:
-                return v, "profiles/" + name
-        except OSError:
+                return v, "profiles/%s [%s][%s]" % (name, workload, kernel_name)
+        except (OSError, ValueError, AttributeError):
             pass
     return None, None
 
 
-def roofline(solver, cls, bytes_per_unit, substeps=3, note=None):
+def roofline(solver, cls, bytes_per_unit, substeps=3, note=None, workload="config2"):
     """In-situ roofline block of kernel class `cls` (a name of capi.KERNEL_NAMES)."""
     launches, ms, units, overhead_ms = solver.profile_in_situ(K[cls], substeps)
     if launches == 0 or ms <= 0:
@@ -126,7 +126,7 @@ def roofline(solver, cls, bytes_per_unit, substeps=3, note=None):
     net_ms = max(ms - launches * overhead_ms, 0.05 * ms)  # the brackets' own cost, calibrated in the same pass, taken off
     achieved = nbytes / (net_ms * 1e-3) / 1e9
     kname = DEVICE_KERNEL.get(cls, "k_" + cls)
-    traffic, src = pmc_traffic(kname)
+    traffic, src = pmc_traffic(kname, workload)
     out = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "traffic": traffic, "traffic_source": src, "avg_launch_us": 1e3 * net_ms / launches, "launches_timed": launches,
            "bytes_per_launch": nbytes / launches, "avg_bracket_us": 1e3 * ms / launches, "bracket_overhead_us": 1e3 * overhead_ms,
@@ -147,8 +147,10 @@ def pd_bytes(solver):
     inc = (4 * (solver.count(capi.TET) + (0 if paired else solver.count(capi.VOLUME)) + solver.count(capi.BEND))
            + 2 * solver.count(capi.DISTANCE) + solver.count(capi.POSITION))
     return {
-        # 148 B per tet / volume projection; a fused strain + volume launch does two projections per unit
-        "pd_local_tet": 296 if paired else 148, "pd_local_volume": 148, "pd_local_distance": 64, "pd_predict": 52,
+        # 148 B per tet / volume projection.  A fused strain + volume launch does two projections per element from
+        # ONE gather: ids 16 + Qinv 36 + 2 x (min, max, w) 24 + four positions 48 + 2 x 36 projected gradients = 196 B is all
+        # there is to move (2 x 148 would count the shared inputs twice and put the kernel above the roofline at 1M)
+        "pd_local_tet": 196 if paired else 148, "pd_local_volume": 148, "pd_local_distance": 64, "pd_predict": 52,
         # gather formulation: one 12-byte contribution + its 4-byte slot index per (constraint, node) incidence, inertia term
         # in, right-hand side out (the survey's scatter formulation would be 148 B per tetrahedron)
         "pd_rhs": (16.0 * inc + 32.0 * n) / n,
@@ -175,7 +177,7 @@ def replay_latencies(solver, bytes_per_unit=None):
 
 
 # ---- scenes of the other configs ----------------------------------------------------------------------------------------
-def pd_beam(dims, device, settle=34, mod=capi):
+def pd_beam(dims, device, settle=34, mod=capi, pcg=None):
     """BASELINE configs[2] pattern: lattice beam, Projective Dynamics, tets + volume (w = 1), 10 iterations, the k = 0 end
     cap pinned."""
     W, H, D = dims
@@ -184,6 +186,8 @@ def pd_beam(dims, device, settle=34, mod=capi):
     g.create_tet_box(W, H, D, translation=(0.0, 2.0, 0.0), w=1.0, volume=True, triangles=True)
     g.add_position(np.array([D * (j + H * i) for i in range(W) for j in range(H)], dtype=np.uint32), 2.0)
     if mod is capi:
+        if pcg:
+            g.set_pcg(*pcg)
         g.finalize()
         for _ in range(settle):  # a host ticks and synchronises once per frame: the captured CG iteration budget settles to
             g.tick_async(1)      # what the solves use (two spare iterations after 8 calm frames, one after 24 more)
@@ -398,12 +402,13 @@ def extra_configs(device):
                          "iteration budget adapts)", "pcg_max_rel_residual": res, "pcg_max_iterations_used": iters, "pcg_health": g.pcg_health(),
                          "launches_per_substep": sum(g.launch_counts().values()),
                          "projections_per_sec": 30 / el * 10 * (g.count(capi.TET) + g.count(capi.VOLUME) + g.count(capi.POSITION)),
-                         "roofline": roofline(g, "pd_local_tet", B["pd_local_tet"], note="fused strain + volume local step: two projections "
-                                              "(2 x 148 B, SURVEY 8d) per element from one gather and one SVD; the launch itself moves 196 B"),
-                         "roofline_spmv": roofline(g, "pd_spmv", B["pd_spmv"], note="SELL-64 SpMV over 3 right-hand sides + fused direction "
+                         "roofline": roofline(g, "pd_local_tet", B["pd_local_tet"], workload="config3", note="fused strain + volume local step: two projections per "
+                                              "element from one gather and one SVD = 196 B per element (two separate 148-B projections of "
+                                              "SURVEY 8d would be 296 B: multiply achieved by 1.51 for that count)"),
+                         "roofline_spmv": roofline(g, "pd_spmv", B["pd_spmv"], workload="config3", note="SELL-64 SpMV over 3 right-hand sides + fused direction "
                                                    "update; 8 nnz + 28 N bytes per launch (SURVEY 8d); the solves of the timed pass do not take "
                                                    "the converged early exit"),
-                         "roofline_rhs": roofline(g, "pd_rhs", B["pd_rhs"])}
+                         "roofline_rhs": roofline(g, "pd_rhs", B["pd_rhs"], workload="config3")}
     out["pd_config3"]["isolated_replay_latencies"] = replay_latencies(g)
     g.close()
     # configs[1] on an unstructured mesh: Delaunay beam of the same size (the lattice stands in for tetgen in the headline)
@@ -436,8 +441,8 @@ def extra_configs(device):
                                  "tri_contacts_last_substep": len(g.tri_collisions), "pcg_max_rel_residual": res,
                                  "pcg_max_iterations_used": iters, "pcg_health": g.pcg_health(), "failed": g.failed,
                                  "launches_per_substep": sum(g.launch_counts().values()),
-                                 "roofline": roofline(g, "pd_local_tet", B["pd_local_tet"], substeps=2),
-                                 "roofline_spmv": roofline(g, "pd_spmv", B["pd_spmv"], substeps=2)}
+                                 "roofline": roofline(g, "pd_local_tet", B["pd_local_tet"], substeps=2, workload="contacts"),
+                                 "roofline_spmv": roofline(g, "pd_spmv", B["pd_spmv"], substeps=2, workload="contacts")}
     g.close()
     # PD with thousands of contacts: a short beam resting on a long one that lies on the floor
     log("PD contact scene")
@@ -452,7 +457,7 @@ def extra_configs(device):
                           "floor, PD, 10 iterations, floor + point-triangle contacts binding (w = 1e4 on the diagonal)",
                           "tri_contacts_last_substep": len(g.tri_collisions), "pcg_max_rel_residual": res, "pcg_max_iterations_used": iters,
                           "pcg_health": g.pcg_health(), "failed": g.failed,
-                          "roofline_spmv": roofline(g, "pd_spmv", pd_bytes(g)["pd_spmv"], substeps=1)}
+                          "roofline_spmv": roofline(g, "pd_spmv", pd_bytes(g)["pd_spmv"], substeps=1, workload="none")}
     g.close()
     # configs[3]: 500k loose particles, node-node collisions + floor, PBD, 4 iterations
     log("config 4 (500k particles, node-node collisions)")
@@ -472,9 +477,9 @@ def extra_configs(device):
                                  "0.9, jitter 0.05), PBD, 4 iterations, grid rebuild + node-node resolve + floor every iteration, parallel "
                                  "collision order", "resolved_pairs_per_substep": pairs / 10, "candidates_per_node_per_iteration": cand / (40 * n),
                                  "failed": g.failed, "launches_per_substep": sum(g.launch_counts().values()),
-                                 "roofline": roofline(g, "collide", per_node, substeps=1, note="one bracket = the resolve pass of one "
+                                 "roofline": roofline(g, "collide", per_node, substeps=1, workload="config4", note="one bracket = the resolve pass of one "
                                                       "iteration (k_collide_flow); bytes per node = 32 + 27 x 8 + 16 x candidates looked at"),
-                                 "roofline_grid_build": roofline(g, "hash", 92.0, substeps=1, note="one bracket = one grid rebuild: range, prefix "
+                                 "roofline_grid_build": roofline(g, "hash", 92.0, substeps=1, workload="config4", note="one bracket = one grid rebuild: range, prefix "
                                                                  "sum, emit, radix sort passes, cell index (about 92 B per node, SURVEY 8d)")}
     g.close()
     return out
@@ -492,20 +497,20 @@ def scale_profiles(device):
         out[name] = {"substeps_per_sec": 3 / el, "projections_per_sec": 3 / el * scenes.projections_per_substep(g, capi, ITERATIONS),
                      "launches_per_substep": sum(g.launch_counts().values())}
         if sched == capi.SCHEDULE_LAYERED:
-            out[name]["roofline"] = roofline(g, "layer", 1, substeps=1)
+            out[name]["roofline"] = roofline(g, "layer", 1, substeps=1, workload="none")
         else:
-            out[name]["roofline"] = roofline(g, "tet", BYTES["tet"], substeps=1)
-            out[name]["roofline_distance"] = roofline(g, "distance", BYTES["distance"], substeps=1)
+            out[name]["roofline"] = roofline(g, "tet", BYTES["tet"], substeps=1, workload="none")
+            out[name]["roofline_distance"] = roofline(g, "distance", BYTES["distance"], substeps=1, workload="none")
         g.close()
     log("pd_1m")
     g = pd_beam(scenes.L1M, device, settle=12)
     el = timed_ticks(g, 3, 1, lambda: None)
     B = pd_bytes(g)
     out["pd_1m"] = {"substeps_per_sec": 3 / el, "pcg_stats": g.pcg_stats(),
-                    "roofline": roofline(g, "pd_local_tet", B["pd_local_tet"], substeps=1),
-                    "roofline_spmv": roofline(g, "pd_spmv", B["pd_spmv"], substeps=1),
-                    "roofline_rhs": roofline(g, "pd_rhs", B["pd_rhs"], substeps=1),
-                    "roofline_cg_update": roofline(g, "pd_cg_update", B["pd_cg_update"], substeps=1)}
+                    "roofline": roofline(g, "pd_local_tet", B["pd_local_tet"], substeps=1, workload="none"),
+                    "roofline_spmv": roofline(g, "pd_spmv", B["pd_spmv"], substeps=1, workload="none"),
+                    "roofline_rhs": roofline(g, "pd_rhs", B["pd_rhs"], substeps=1, workload="none"),
+                    "roofline_cg_update": roofline(g, "pd_cg_update", B["pd_cg_update"], substeps=1, workload="none")}
     g.close()
     return out
 
@@ -614,7 +619,7 @@ def main():
             el = timed_ticks(c, steps, 2, lambda: None)
             result["coloured_schedule"] = {"value": steps * substeps_per_tick / el, "unit": "substeps/s",
                                            "launches_per_substep": sum(c.launch_counts().values()), "steps": steps,
-                                           "roofline": roofline(c, "tet", BYTES["tet"]),
+                                           "roofline": roofline(c, "tet", BYTES["tet"], workload="none"),
                                            "isolated_replay_latencies": replay_latencies(c),
                                            "note": "schedule COLOURED: one launch per colour class (24 tet + 9 distance colours per iteration)"}
             c.close()

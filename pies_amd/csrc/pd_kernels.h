@@ -18,10 +18,11 @@ struct Vec3f {
 struct CgArrays {
   uint32_t n;
   uint32_t nparts;  // blocks per CG launch (<= kCgBlocks)
-  // K in sliced ELL form (SELL-64): slice s holds rows 64s..64s+63, one row per lane; entry k of the slice's
-  // rows sits at sliceOff[s] + 64k + lane, so a wavefront's loads of col/val are contiguous.  Rows are padded to
-  // the slice's longest row with (col = the row itself, val = 0).
-  const uint32_t* sliceOff;  // ceil(n/64) + 1 offsets (in entries)
+  // K in sliced ELL form: a slice is one wavefront's rows, 64 / lanesPerRow of them; lane L = lanesPerRow * r + q of the slice
+  // takes entries q, q + lanesPerRow, ... of its row r, entry step j of the slice sits at sliceOff[s] + 64 j + L, so a
+  // wavefront's loads of col/val are contiguous.  Rows are padded to the slice's longest row with (col = the row itself, val = 0).
+  uint32_t lanesPerRow;      // 1 (large systems) or 4
+  const uint32_t* sliceOff;  // slices + 1 offsets (in entries)
   const uint32_t* col;
   const float* val;
   float* cdiag;  // diagonal of the collision matrix (floor contacts)

@@ -601,8 +601,9 @@ template <class Fetch> PIES_DEV void contact_row(const CgArrays& A, uint32_t i, 
 struct SliceSweep {
   uint32_t begin, end, step;
 };
-PIES_DEV SliceSweep slice_sweep(uint32_t n) {
-  const uint32_t nslices = (n + 63u) >> 6;
+template <int LPR> PIES_DEV SliceSweep slice_sweep(uint32_t n) {
+  constexpr uint32_t kRows = 64u / LPR;  // rows of a slice
+  const uint32_t nslices = (n + kRows - 1u) / kRows;
   const uint32_t labels = gridDim.x < 8u ? gridDim.x : 8u;
   const uint32_t x = blockIdx.x % labels, xb = blockIdx.x / labels;
   const uint32_t nbx = (gridDim.x - x + labels - 1u) / labels;  // blocks carrying this label
@@ -708,17 +709,28 @@ __global__ void __launch_bounds__(kBlock) k_contact_rows(CgArrays A, const float
   }
 }
 
-// r = f - (K + C) x ; z = D^-1 r ; partB = {rz, rr} ; partI = {bb}.   One row per lane (SELL-64).
+// the LPR lanes of a row combine their partial sums (pairwise; every lane of the row ends with the total)
+template <int LPR> PIES_DEV void row_combine(float& sx, float& sy, float& sz) {
+#pragma unroll
+  for (int off = LPR / 2; off >= 1; off >>= 1) {
+    sx += __shfl_xor(sx, off, LPR);
+    sy += __shfl_xor(sy, off, LPR);
+    sz += __shfl_xor(sz, off, LPR);
+  }
+}
+
+// r = f - (K + C) x ; z = D^-1 r ; partB = {rz, rr} ; partI = {bb}.   LPR lanes per row (sliced ELL, see CgArrays).
 // prevPartB != nullptr: block 0 first closes the previous solve's statistics (its scal[] entries are still intact:
 // this solve's k_cg_ap(0) is the first kernel to overwrite them).
+template <int LPR>
 __global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __restrict__ x, const float4* __restrict__ f,
                                                     const float* __restrict__ prevPartB) {
   if (prevPartB && blockIdx.x == 0) solve_statistics(A, prevPartB);
   const uint32_t lane = threadIdx.x & 63u;
-  const SliceSweep sw = slice_sweep(A.n);
+  const SliceSweep sw = slice_sweep<LPR>(A.n);
   float acc9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t sl = sw.begin; sl < sw.end; sl += sw.step) {
-    const uint32_t i = (sl << 6) + lane;
+    const uint32_t i = sl * (64u / LPR) + lane / LPR;
     const uint32_t off = A.sliceOff[sl], width = (A.sliceOff[sl + 1] - off) >> 6;
     float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll 4
@@ -730,7 +742,8 @@ __global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __
       sy = fmaf(a, xj.y, sy);
       sz = fmaf(a, xj.z, sz);
     }
-    if (i < A.n) {
+    row_combine<LPR>(sx, sy, sz);
+    if (i < A.n && lane % LPR == 0u) {
       if (A.useCAp) {
         if (A.tIncCnt[i]) {
           const float4 c = A.cAp[i]; sx += c.x; sy += c.y; sz += c.z;
@@ -753,7 +766,7 @@ __global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __
 }
 
 // iteration k:  beta = rz_k / rz_{k-1} (0 for k = 0) ; p = z + beta p_old ; Ap = (K + C) p ; partA = {pAp}
-__global__ void __launch_bounds__(kBlock) k_cg_ap(CgArrays A, int k, float tol2) {
+template <int LPR> __global__ void __launch_bounds__(kBlock) k_cg_ap(CgArrays A, int k, float tol2) {
   float red[9];
   float rz[3], rr[3], bb[3];
   if (k == 0) {
@@ -788,10 +801,10 @@ __global__ void __launch_bounds__(kBlock) k_cg_ap(CgArrays A, int k, float tol2)
   const float4* __restrict__ pold = A.p[(k + 1) & 1];
   float4* __restrict__ pnew = A.p[k & 1];
   const uint32_t lane = threadIdx.x & 63u;
-  const SliceSweep sw = slice_sweep(A.n);
+  const SliceSweep sw = slice_sweep<LPR>(A.n);
   float acc[3] = {0, 0, 0};
   for (uint32_t sl = sw.begin; sl < sw.end; sl += sw.step) {
-    const uint32_t i = (sl << 6) + lane;
+    const uint32_t i = sl * (64u / LPR) + lane / LPR;
     const uint32_t off = A.sliceOff[sl], width = (A.sliceOff[sl + 1] - off) >> 6;
     float sx = 0.f, sy = 0.f, sz = 0.f;
     if (k > 0) {
@@ -816,7 +829,8 @@ __global__ void __launch_bounds__(kBlock) k_cg_ap(CgArrays A, int k, float tol2)
         sz = fmaf(a, zj.z, sz);
       }
     }
-    if (i < A.n) {
+    row_combine<LPR>(sx, sy, sz);
+    if (i < A.n && lane % LPR == 0u) {
       if (A.useCAp) {
         if (A.tIncCnt[i]) {
           const float4 c = A.cAp[i]; sx += c.x; sy += c.y; sz += c.z;
@@ -1014,7 +1028,12 @@ void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, i
   const dim3 grid(A.nparts), block(kBlock);
   if (part >= 0) {  // profile pass: one kind of kernel only, never taking the converged early exit
     for (int k = 0; k < maxIters; ++k) {
-      if (part == 1) hipLaunchKernelGGL(k_cg_ap, grid, block, 0, st, A, k, -1.0f);
+      if (part == 1) {
+        if (A.lanesPerRow == 4) hipLaunchKernelGGL(k_cg_ap<4>, grid, block, 0, st, A, k, -1.0f);
+        else if (A.lanesPerRow == 2) hipLaunchKernelGGL(k_cg_ap<2>, grid, block, 0, st, A, k, -1.0f);
+        else if (A.lanesPerRow == 8) hipLaunchKernelGGL(k_cg_ap<8>, grid, block, 0, st, A, k, -1.0f);
+        else hipLaunchKernelGGL(k_cg_ap<1>, grid, block, 0, st, A, k, -1.0f);
+      }
       else hipLaunchKernelGGL(k_cg_update, grid, block, 0, st, A, nd.pos, k, -1.0f);
     }
     return;
@@ -1026,13 +1045,20 @@ void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, i
   const bool rows = A.useCAp && A.tIncCnt;
   const dim3 rgrid(256);
   if (rows) hipLaunchKernelGGL(k_contact_rows<0>, rgrid, block, 0, st, A, nd.pos, 0, 0.0f);
-  hipLaunchKernelGGL(k_cg_init, grid, block, 0, st, A, nd.pos, pd.rhs, first ? nullptr : pb[maxIters & 1]);
+  const float* prevB = first ? nullptr : pb[maxIters & 1];
+  if (A.lanesPerRow == 4) hipLaunchKernelGGL(k_cg_init<4>, grid, block, 0, st, A, nd.pos, pd.rhs, prevB);
+  else if (A.lanesPerRow == 2) hipLaunchKernelGGL(k_cg_init<2>, grid, block, 0, st, A, nd.pos, pd.rhs, prevB);
+  else if (A.lanesPerRow == 8) hipLaunchKernelGGL(k_cg_init<8>, grid, block, 0, st, A, nd.pos, pd.rhs, prevB);
+  else hipLaunchKernelGGL(k_cg_init<1>, grid, block, 0, st, A, nd.pos, pd.rhs, prevB);
   for (int k = 0; k < maxIters; ++k) {
     A.partB = pb[k & 1];       // residual partials of iteration k (k = 0 reads partI instead)
     A.partBnext = pb[(k + 1) & 1];
     if (rows) hipLaunchKernelGGL(k_contact_rows<1>, rgrid, block, 0, st, A, nd.pos, k, tol2);
     if (hook) hook(hookCtx, 14);  // PIES_KERNEL_PD_SPMV
-    hipLaunchKernelGGL(k_cg_ap, grid, block, 0, st, A, k, tol2);
+    if (A.lanesPerRow == 4) hipLaunchKernelGGL(k_cg_ap<4>, grid, block, 0, st, A, k, tol2);
+    else if (A.lanesPerRow == 2) hipLaunchKernelGGL(k_cg_ap<2>, grid, block, 0, st, A, k, tol2);
+    else if (A.lanesPerRow == 8) hipLaunchKernelGGL(k_cg_ap<8>, grid, block, 0, st, A, k, tol2);
+    else hipLaunchKernelGGL(k_cg_ap<1>, grid, block, 0, st, A, k, tol2);
     if (hook) { hook(hookCtx, 14); hook(hookCtx, 15); }  // PIES_KERNEL_PD_CG_UPDATE
     hipLaunchKernelGGL(k_cg_update, grid, block, 0, st, A, nd.pos, k, tol2);
     if (hook) hook(hookCtx, 15);

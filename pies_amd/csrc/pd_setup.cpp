@@ -68,24 +68,30 @@ int pd_build(pies_solver* s) {
     std::vector<Entry>().swap(r);
   }
   s->pd_nnz = static_cast<uint32_t>(col.size());
-  // CSR -> SELL-64 (see CgArrays): the order of a row's entries (ascending column) is kept
-  const uint32_t nslices = (n + 63u) / 64u;
+  // CSR -> sliced ELL (see CgArrays).  A slice is one wavefront's worth of rows: 64 rows with one lane each.  (Several lanes
+  // per row - lane L r + q taking entries q, q + L, ... of row r, partial sums combined by shuffles - were measured at 100k
+  // rows: k_cg_ap 5.4 us with 1 lane per row, 7.8 / 10.4 / 14.5 us with 2 / 4 / 8: the extra wavefronts only add gather
+  // instructions.  PIES_SELL_LANES keeps the experiment available.)  Entries keep their order (ascending column).
+  uint32_t lpr = 1u;
+  if (const char* e = std::getenv("PIES_SELL_LANES")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) lpr = static_cast<uint32_t>(v); }
+  const uint32_t rps = 64u / lpr;
+  const uint32_t nslices = (n + rps - 1u) / rps;
   std::vector<uint32_t> sliceOff(nslices + 1, 0), sellCol;
   std::vector<float> sellVal;
   for (uint32_t sl = 0; sl < nslices; ++sl) {
     uint32_t width = 0;
-    for (uint32_t i = 64u * sl; i < std::min(n, 64u * sl + 64u); ++i) width = std::max(width, rowptr[i + 1] - rowptr[i]);
-    sliceOff[sl + 1] = sliceOff[sl] + 64u * width;
+    for (uint32_t i = rps * sl; i < std::min(n, rps * sl + rps); ++i) width = std::max(width, rowptr[i + 1] - rowptr[i]);
+    sliceOff[sl + 1] = sliceOff[sl] + 64u * ((width + lpr - 1u) / lpr);
   }
   sellCol.resize(sliceOff[nslices]);
   sellVal.assign(sliceOff[nslices], 0.0f);
   for (uint32_t sl = 0; sl < nslices; ++sl) {
-    const uint32_t width = (sliceOff[sl + 1] - sliceOff[sl]) / 64u;
-    for (uint32_t lane = 0; lane < 64u; ++lane) {
-      const uint32_t i = 64u * sl + lane, self = std::min(i, n - 1u);
+    const uint32_t steps = (sliceOff[sl + 1] - sliceOff[sl]) / 64u;
+    for (uint32_t r = 0; r < rps; ++r) {
+      const uint32_t i = rps * sl + r, self = std::min(i, n - 1u);
       const uint32_t b = i < n ? rowptr[i] : 0u, len = i < n ? rowptr[i + 1] - rowptr[i] : 0u;
-      for (uint32_t k = 0; k < width; ++k) {
-        const size_t at = static_cast<size_t>(sliceOff[sl]) + 64u * k + lane;
+      for (uint32_t k = 0; k < steps * lpr; ++k) {
+        const size_t at = static_cast<size_t>(sliceOff[sl]) + 64u * (k / lpr) + (r * lpr + k % lpr);
         sellCol[at] = k < len ? col[b + k] : self;
         if (k < len) sellVal[at] = val[b + k];
       }
@@ -163,7 +169,11 @@ int pd_build(pies_solver* s) {
   PdArrays& pd = s->pd;
   CgArrays& cg = pd.cg;
   cg.n = n;
-  cg.nparts = std::max(1u, std::min(kCgBlocks, (n + 255u) / 256u));  // 4 wavefronts (= 4 slices in flight) per block
+  // blocks of every CG launch: one per four slices (4 wavefronts per block).  Measured at 100k rows (substeps/s of config 3):
+  // 64 blocks 1039, 128: 1188, 196: 1242, 256: 1268, 391 (this formula): 1246 - fewer blocks make the per-kernel re-reduction of
+  // the partial dot products cheaper and the SpMV slower, by about the same amount.
+  cg.nparts = std::max(1u, std::min(kCgBlocks, (nslices + 3u) / 4u));
+  if (const char* e = std::getenv("PIES_CG_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && v <= (int)kCgBlocks) cg.nparts = static_cast<uint32_t>(v); }
   uint32_t *d_rowptr, *d_col, *d_incPtr, *d_incSlot, *d_tri;
   float *d_val, *d_kdiag;
   if (int rc = upload(s, sliceOff, &d_rowptr)) return rc;
@@ -175,6 +185,7 @@ int pd_build(pies_solver* s) {
   if (int rc = upload(s, triCount, &d_tri)) return rc;
 
   cg.sliceOff = d_rowptr; cg.col = d_col; cg.val = d_val;
+  cg.lanesPerRow = lpr;
   pd.kdiag = d_kdiag; pd.incPtr = d_incPtr; pd.incSlot = d_incSlot; pd.triCount = d_tri;
   pd.contribD = nullptr; pd.incPtrD = nullptr; pd.incSlotD = nullptr;
   pd.shape = ShapeArrays{};

@@ -15,7 +15,8 @@ what, n = sys.argv[1], int(sys.argv[2])
 if what == "config2":
     g = bench.build_scene(capi, scenes.L100K, 1234, schedule=capi.SCHEDULE_LAYERED, device=0)
 elif what == "config3":
-    g = bench.pd_beam(scenes.L100K, 0, settle=4)
+    # PIES_PROFILER_SAFE keeps the captured CG budget where it starts: 3 = what bench.py's loop settles at
+    g = bench.pd_beam(scenes.L100K, 0, settle=0, pcg=(3e-7, 3))
 elif what == "config4":
     p, v = bench.config4_particles()
     g = capi.Solver(scenes.pbd_options(capi, 4), device=0)
@@ -23,6 +24,7 @@ elif what == "config4":
     g.set_velocities(v)
 elif what == "contacts":
     g = bench.contact_scene(capi, 0)
+    g.set_pcg(3e-7, 12)  # (see config3; bench.py's frame loop settles at about 10 with these contacts)
     g.finalize()
     for _ in range(8):
         g.tick_async(1)
