@@ -3,11 +3,14 @@
 //   predict      pos += h v ; Msn_h2 = pos/invMass/h^2 ; floor-contact detection ; system diagonal
 //   local step   one lane = one constraint, all constraints of a container in ONE launch (the local step
 //                only reads positions, Solver.cpp:270-308) -> writes w*(A^T B p)_i per (constraint, node)
-//   rhs          one lane = one node: Msn_h2 + contributions gathered in the reference's summation order
-//                (Solver.cpp:310-349), so the right-hand side is reproducible bit for bit (no atomics)
-//   global step  Jacobi-preconditioned CG on (K + C) x = rhs for the 3 coordinate columns at once; K in CSR,
-//                SpMV with 16 lanes per row; the reference factors K + C with a sparse Cholesky every
-//                substep (Solver.cpp:258-262,356) -- CG to a relative residual replaces the direct solve
+//                (strain + volume constraints over the same elements share one gather and one SVD; the contacts'
+//                local step rides in a few extra workgroups of that launch)
+//   rhs          four lanes = one node: Msn_h2 + the node's contribution records (Solver.cpp:310-349), gathered without
+//                atomics: interleaved partial sums combined pairwise - deterministic, not the reference's term order
+//   global step  Jacobi-preconditioned CG on (K + C) x = rhs for the 3 coordinate columns at once; K in sliced ELL
+//                form (one row per lane, 64 rows per slice); the reference factors K + C with a sparse Cholesky every
+//                substep (Solver.cpp:258-262,356) -- CG to a relative residual replaces the direct solve, and a substep
+//                whose solve ends above it is run again by pies_tick (capi.cpp)
 //   velocity     v = (1-d)(pos-prev)/h + h f/m ; prev = pos ; floor friction
 //
 // Everything here is bandwidth/latency bound (gathers, streams, SpMV at ~15 nnz/row, 3x3 algebra): no MFMA.
