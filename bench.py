@@ -394,10 +394,10 @@ def order_deviation(device):
     out = {}
     names = {capi.SCHEDULE_COLOURED: "coloured", capi.SCHEDULE_LAYERED: "layered"}
 
-    def beam(dims, iters):
+    def beam(dims, iters, tets=True):
         def make(schedule):
             g = capi.Solver(scenes.pbd_options(capi, iters), device=device)
-            scenes.build_beam(g, dims)
+            scenes.build_beam(g, dims, tets=tets)
             scenes.perturb(g, 1234, 0.05)
             g.set_flag(capi.FLAG_NODE_COLLISIONS, 0)
             g.set_schedule(schedule)
@@ -405,6 +405,8 @@ def order_deviation(device):
         d = deviation.compare(make, capi, [capi.SCHEDULE_EXACT, capi.SCHEDULE_COLOURED, capi.SCHEDULE_LAYERED])
         return {names[k]: v for k, v in d.items()}
     out["config1_l1k_10_iterations"] = beam(scenes.L1K, 10)
+    # the same lattice with the distance constraints alone (createBox): a relaxation that converges, for scale
+    out["l1k_distance_constraints_only_10_iterations"] = beam(scenes.L1K, 10, tets=False)
     log("order deviation: config 2")
     out["config2_l100k_20_iterations"] = beam(scenes.L100K, ITERATIONS)
     log("order deviation: collisions")

@@ -48,3 +48,25 @@ def test_collision_rule_1_vs_reference_order(pies):
         print("config 4 (12x14x16) parallel vs reference collision order %s: max|dpos| %.3g  com %.3g  extent %.3g" % (
             when, e["max_abs_dpos"], e["centre_of_mass_delta"], e["extent_delta"]))
         assert e["finite"] and e["centre_of_mass_delta"] < 0.25 and e["extent_delta"] < 2.0
+
+
+def test_distance_only_lattice_orders_agree_closely(pies):
+    """For scale: without the tetrahedral projection of quirk Q2 (which drags the body towards the origin in every order),
+    one tick of the same lattice under its distance constraints alone ends within a few percent of the lattice spacing of the
+    reference order.  (Later ticks drift apart like any two runs of a chaotic system: the perturbed lattice carries random
+    node velocities of 1 per second and the one-sided distance projection of quirk Q1 does not damp them.)"""
+    def make(schedule):
+        g = pies.Solver(scenes.pbd_options(pies, 10))
+        scenes.build_beam(g, scenes.L1K, tets=False)
+        scenes.perturb(g, 1234, 0.03)
+        g.set_flag(pies.FLAG_NODE_COLLISIONS, 0)
+        g.set_schedule(schedule)
+        return g
+    d = deviation.compare(make, pies, [pies.SCHEDULE_EXACT, pies.SCHEDULE_COLOURED, pies.SCHEDULE_LAYERED])
+    for sched, per in d.items():
+        for when, e in per.items():
+            print("distance-only 10^3, schedule %d vs exact %s: max|dpos| %.3g  rms %.3g  residuals %s (exact: %s)" % (
+                sched, when, e["max_abs_dpos"], e["rms_dpos"], e["residuals"], e["residuals_reference_order"]))
+            assert e["finite"]
+            if when == "after_1_ticks":
+                assert e["rms_dpos"] < 0.05 and e["max_abs_dpos"] < 0.2
