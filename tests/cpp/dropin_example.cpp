@@ -24,6 +24,23 @@ int main(int argc, char** argv) {
   if (!(std::isfinite(v.position[0]) && v.position[1] < y0)) return 3;  // the box fell under gravity
   std::printf("dropin ok: %zu vertices, %zu triangles, y %.4f -> %.4f (%s)\n", n, solver.getTriangles().size(), y0, v.position[1],
               pd ? "PD" : "PBD");
+  // tick() in two halves (beginTick queues the substeps and the asynchronous export, endTick waits for the frame): two
+  // frames in flight, and the vertices end where three plain ticks of an identical solver end
+  Pies::Solver twin(options);
+  twin.createTetBox(glm::vec3(0.0f, 4.0f, 0.0f), 1.0f, glm::vec3(0.0f), pd ? 1.0f : 0.002f, 1.0f, false);
+  twin.createBox(glm::vec3(8.0f, 3.0f, 0.0f), 1.0f, 0.5f);
+  twin.addNodes({glm::vec3(20.0f, 2.0f, 0.0f), glm::vec3(20.6f, 2.0f, 0.0f)});
+  for (int i = 0; i < 10; ++i) twin.tick(0.016f);
+  for (int i = 0; i < 3; ++i) solver.tick(0.016f);
+  twin.beginTick();
+  twin.beginTick();
+  twin.endTick();
+  twin.beginTick();
+  twin.endTick();
+  twin.endTick();
+  for (size_t i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k)
+      if (twin.getVertices()[i].position[k] != solver.getVertices()[i].position[k]) return 5;
   Pies::Solver moved(std::move(solver));
   moved.tick(0.0f);
   moved.clear();

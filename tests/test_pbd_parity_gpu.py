@@ -389,3 +389,44 @@ def test_config2_l100k_one_tick(pies, oracle):
     _check(g, o)
     lc = g.launch_counts()
     assert lc["tet"] == 20 * (len(g.batches(pies.TET)) - 1)
+
+
+@pytest.mark.parametrize("schedule", [1, 2])
+def test_release_hinge_toggled_between_ticks_recaptures_only(pies, oracle, schedule):
+    """Solver::releaseHinge flipped at run time (the reference's hosts do): with per-container batches only the launch sequence
+    changes, so the substep is captured again without a re-plan or re-upload - and the exported order stays what the oracle
+    replays."""
+    g = pies.Solver(scenes.pbd_options(pies, 5))
+    o = oracle.OracleSolver(scenes.pbd_options(oracle, 5))
+    for s in (g, o):
+        s.create_sheet(9, 7, translation=(0, 3, 0), scale=0.5, mass=2.0, w=0.7)
+        scenes.perturb(s, 3, 0.05)
+        s.set_flag(1, 0)
+    g.set_schedule(schedule)
+    g.finalize()
+    for t in (pies.POSITION, pies.DISTANCE):
+        if g.count(t):
+            o.permute(t, g.order(t))
+    for hinge in (0, 1, 0, 1):
+        for s in (g, o):
+            s.set_flag(0, hinge)
+            s.tick(2)
+        _check(g, o)
+
+
+def test_schedule_environment_override(pies, monkeypatch):
+    """PIES_SCHEDULE picks the schedule new handles start with (PIES_SCHEDULE_DEFAULT = LAYERED otherwise)."""
+    def launches():
+        g = pies.Solver(scenes.pbd_options(pies, 4))
+        scenes.build_beam(g, (6, 6, 12))
+        g.set_flag(1, 0)
+        lc = g.launch_counts()
+        g.close()
+        return lc
+    assert launches()["layer"] > 0
+    monkeypatch.setenv("PIES_SCHEDULE", "exact")
+    lc = launches()
+    assert lc["layer"] == 0 and lc["wave"] > 0
+    monkeypatch.setenv("PIES_SCHEDULE", "coloured")
+    lc = launches()
+    assert lc["layer"] == 0 and lc["wave"] == 0 and lc["tet"] > 0
