@@ -214,3 +214,22 @@ def test_resolve_variants_agree(pies, monkeypatch):
         monkeypatch.delenv(name)
         assert np.array_equal(ref[0], alt[0]) and np.array_equal(ref[1], alt[1]) and ref[2] == alt[2], name
         assert alt[3] == (81 if name == "PIES_COLLIDE_PASSES" else 3)
+
+
+@RULES
+def test_distant_clusters_use_wide_keys(pies, oracle, rule):
+    """The sort key packs the cell coordinates relative to the bounding box of all ranges: two clusters 300 000 apart on
+    every axis (plus single strays) make the box 150 000 cells per axis - 54 key bits, seven of the eight radix passes -
+    where a compact scene like config 4 needs three."""
+    a, va = particles((5, 4, 6), seed=7)
+    b, vb = particles((4, 5, 3), seed=8)
+    strays = np.float32([[-250000.3, 40.0, 7.0], [12.0, 260000.7, -3.0], [1.0, 2.0, -270000.1]])
+    p = np.concatenate([a, b + np.float32([300000.0, 300000.0, 300000.0]), strays]).astype(np.float32)
+    v = np.concatenate([va, vb, np.zeros_like(strays)]).astype(np.float32)
+
+    def build(s):
+        s.addNodes(p)
+        s.set_velocities(v)
+    g, o = pair(pies, oracle, build, 3, 3, rule=rule, gravity=0.0)
+    check(g, o)
+    assert g.collision_pairs == o.collision_pairs > 500
