@@ -260,3 +260,26 @@ def test_multithreaded_batch_sweep_equals_the_sequential_sweep():
         o.tick(3)
         res.append((o.positions.copy(), o.velocities.copy()))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+def test_svd_against_an_independent_fp32_svd():
+    """The reference calls Eigen::JacobiSVD<Matrix3f> (absent here); the oracle and the device run their own one-sided Jacobi.
+    Only U f(S) V^T is consumed, which does not depend on the algorithm - so ANOTHER fp32 SVD (LAPACK's sgesdd through numpy)
+    must give the same projection up to fp32 rounding.  This measures that rounding-level gap between two fp32 SVD
+    implementations, i.e. the size of the gap to expect against Eigen's."""
+    d = load("svd_fixed.npz")
+    lo, hi = np.float32(d["lo"]), np.float32(d["hi"])
+    worst = 0.0
+    for A in d["A"]:
+        if np.linalg.cond(A.astype(np.float64)) >= 1e3:
+            continue
+        x = np.vstack([np.zeros(3, np.float32), A.T])
+        ours = O.project_tet(x, np.eye(3, dtype=np.float32).reshape(9), float(lo), float(hi))[1:].T
+        U, S, Vt = np.linalg.svd(A.astype(np.float32))
+        Sn = np.clip(S, lo, hi)
+        if np.linalg.det(A.astype(np.float64)) < 0:
+            Sn[2] = -Sn[2]  # the smallest singular value is flipped (Constraints.cpp:106-108)
+        theirs = (U * Sn) @ Vt
+        worst = max(worst, float(np.abs(ours - theirs.astype(np.float32)).max()))
+    print("oracle projection vs LAPACK fp32 SVD: max abs difference %.3g" % worst)
+    assert 0 < worst <= 1e-5
