@@ -582,6 +582,15 @@ void pies_default_options(pies_options_t* o) {
   o->solver = PIES_SOLVER_PD;
 }
 
+// PIES_SCHEDULE overrides PIES_SCHEDULE_DEFAULT for new handles (not an explicit pies_set_schedule)
+static void apply_schedule_environment(pies_solver* s) {
+  if (const char* e = std::getenv("PIES_SCHEDULE")) {
+    if (!std::strcmp(e, "exact")) s->schedule = PIES_SCHEDULE_EXACT;
+    else if (!std::strcmp(e, "coloured")) s->schedule = PIES_SCHEDULE_COLOURED;
+    else if (!std::strcmp(e, "layered")) s->schedule = PIES_SCHEDULE_LAYERED;
+  }
+}
+
 int pies_create(const pies_options_t* options, int device, pies_solver_t** out) {
   if (!out) return PIES_ERR_INVALID;
   *out = nullptr;
@@ -590,6 +599,7 @@ int pies_create(const pies_options_t* options, int device, pies_solver_t** out) 
     if (options) s->opt = *options; else pies_default_options(&s->opt);
     if (s->opt.timeSubsteps == 0) s->opt.timeSubsteps = 1;
     s->device = PIES_DEVICE_NONE;
+    apply_schedule_environment(s);
     *out = s;
     return PIES_OK;
   }
@@ -603,11 +613,7 @@ int pies_create(const pies_options_t* options, int device, pies_solver_t** out) 
   if (options) s->opt = *options; else pies_default_options(&s->opt);
   if (s->opt.timeSubsteps == 0) s->opt.timeSubsteps = 1;
   s->device = device;
-  if (const char* e = std::getenv("PIES_SCHEDULE")) {  // overrides PIES_SCHEDULE_DEFAULT, not an explicit pies_set_schedule
-    if (!std::strcmp(e, "exact")) s->schedule = PIES_SCHEDULE_EXACT;
-    else if (!std::strcmp(e, "coloured")) s->schedule = PIES_SCHEDULE_COLOURED;
-    else if (!std::strcmp(e, "layered")) s->schedule = PIES_SCHEDULE_LAYERED;
-  }
+  apply_schedule_environment(s);
   if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
     delete s;
     return PIES_ERR_HIP;

@@ -2,6 +2,7 @@
 construction against the oracle's own generators, and the Gauss-Seidel schedules (dependency levels /
 colouring).  No compute call is made; tick on such a handle must fail (there is no CPU solver)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -117,3 +118,23 @@ def test_bad_arguments_are_rejected():
         g.set_schedule(5)
     L = capi.load()
     assert L.pies_count(None, 0, None) == capi.ERR_INVALID
+
+
+def test_default_schedule_and_environment_override(monkeypatch):
+    """pies_create starts with PIES_SCHEDULE_DEFAULT (LAYERED: the schedule bench.py's headline is measured on); PIES_SCHEDULE
+    in the environment overrides it for new handles; EXACT keeps the containers in the order the host added the constraints."""
+    import re
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "pies_hip.h")).read()
+    assert re.search(r"#define PIES_SCHEDULE_DEFAULT PIES_SCHEDULE_LAYERED", header) and capi.SCHEDULE_DEFAULT == capi.SCHEDULE_LAYERED
+
+    def tet_order():
+        g = capi.Solver(scenes.pbd_options(capi, 4), device=capi.DEVICE_NONE)
+        scenes.build_beam(g, (6, 6, 14))
+        g.finalize()
+        o = g.order(capi.TET)
+        g.close()
+        return o
+    identity = np.arange(5 * 5 * 13 * 6, dtype=np.uint32)
+    assert not np.array_equal(tet_order(), identity)       # LAYERED: group after group, colour after colour
+    monkeypatch.setenv("PIES_SCHEDULE", "exact")
+    assert np.array_equal(tet_order(), identity)            # the reference's container order
