@@ -127,14 +127,18 @@ def test_default_schedule_and_environment_override(monkeypatch):
     header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "pies_hip.h")).read()
     assert re.search(r"#define PIES_SCHEDULE_DEFAULT PIES_SCHEDULE_LAYERED", header) and capi.SCHEDULE_DEFAULT == capi.SCHEDULE_LAYERED
 
-    def tet_order():
+    def tet_order(schedule=None):
         g = capi.Solver(scenes.pbd_options(capi, 4), device=capi.DEVICE_NONE)
         scenes.build_beam(g, (6, 6, 14))
+        if schedule is not None:
+            g.set_schedule(schedule)
         g.finalize()
         o = g.order(capi.TET)
         g.close()
         return o
-    identity = np.arange(5 * 5 * 13 * 6, dtype=np.uint32)
-    assert not np.array_equal(tet_order(), identity)       # LAYERED: group after group, colour after colour
+    layered, exact = tet_order(capi.SCHEDULE_LAYERED), tet_order(capi.SCHEDULE_EXACT)
+    assert not np.array_equal(layered, exact)
+    assert np.array_equal(tet_order(), layered)             # the default
     monkeypatch.setenv("PIES_SCHEDULE", "exact")
-    assert np.array_equal(tet_order(), identity)            # the reference's container order
+    assert np.array_equal(tet_order(), exact)               # the environment's choice ...
+    assert np.array_equal(tet_order(capi.SCHEDULE_LAYERED), layered)  # ... does not override an explicit pies_set_schedule
