@@ -8,6 +8,7 @@
 
 namespace pies {
 
+constexpr uint32_t kCgRowBlocks = 256;  // extra blocks of k_cg_ap that sum the contact rows (graph variant useCAp)
 constexpr uint32_t kCgBlocks = 1024;  // CG launch shape: <= 1024 blocks x 256 threads (4 per CU), grid-stride
 
 // One contribution record: w * (A^T B p)_i, packed to 12 bytes (global_load/store_dwordx3).

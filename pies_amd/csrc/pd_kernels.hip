@@ -462,6 +462,33 @@ __global__ void __launch_bounds__(kBlock) k_pd_rhs(const float4* __restrict__ ms
   f.x += ax;
   f.y += ay;
   f.z += az;
+  float tx = 0.f, ty = 0.f, tz = 0.f;
+  if (tIncCnt) {  // point-triangle contacts (Solver.cpp:337-340): a node of a contact patch takes part in tens of contacts; the
+    // team's lanes add its records like the ones above (four in flight per lane, partial sums combined pairwise) - one lane
+    // walking the list made this launch 55 us with 29k contacts (2 dependent loads per record), the rest of it takes 10
+    const uint32_t tc = live ? tIncCnt[i] : 0u;
+    const uint32_t ts = tc ? tIncStart[i] : 0u;
+    for (uint32_t k = sub; k < tc; k += 4 * kRhsLanes) {
+      uint32_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = (k + kRhsLanes * u < tc) ? tInc[ts + k + kRhsLanes * u] : 0xffffffffu;
+      float4 c[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c[u] = (v[u] != 0xffffffffu) ? tContrib[4 * (v[u] >> 2) + (v[u] & 3u)] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        tx += c[u].x;
+        ty += c[u].y;
+        tz += c[u].z;
+      }
+    }
+#pragma unroll
+    for (int off = kRhsLanes / 2; off >= 1; off >>= 1) {
+      tx += __shfl_xor(tx, off, kRhsLanes);
+      ty += __shfl_xor(ty, off, kRhsLanes);
+      tz += __shfl_xor(tz, off, kRhsLanes);
+    }
+  }
   if (!live || sub != 0) return;
   if (incPtrD) {  // shape then goal matching: force += float w * double projection (ShapeMatchingConstraint.cpp:58-72,147-161)
     const uint32_t ed = incPtrD[i + 1];
@@ -472,19 +499,9 @@ __global__ void __launch_bounds__(kBlock) k_pd_rhs(const float4* __restrict__ ms
       f.z = static_cast<float>(static_cast<double>(f.z) + c.w * c.z);
     }
   }
-  if (tIncCnt) {  // point-triangle contacts, in contact-list order (Solver.cpp:337-340)
-    const uint32_t tc = tIncCnt[i];
-    if (tc) {
-      const uint32_t ts = tIncStart[i];
-      for (uint32_t k = 0; k < tc; ++k) {
-        const uint32_t v = tInc[ts + k];
-        const float4 c = tContrib[4 * (v >> 2) + (v & 3u)];
-        f.x += c.x;
-        f.y += c.y;
-        f.z += c.z;
-      }
-    }
-  }
+  f.x += tx;  // (after the shape-matching terms, as in the reference's loop order)
+  f.y += ty;
+  f.z += tz;
   const uint32_t ns = nstatic[i];
   if (ns) {
     float4 p = pos[i];
@@ -604,12 +621,12 @@ template <class Fetch> PIES_DEV void contact_row(const CgArrays& A, uint32_t i, 
 struct SliceSweep {
   uint32_t begin, end, step;
 };
-template <int LPR> PIES_DEV SliceSweep slice_sweep(uint32_t n) {
+template <int LPR> PIES_DEV SliceSweep slice_sweep(uint32_t n, uint32_t nblocks) {  // nblocks: the launch's SpMV blocks (the first ones)
   constexpr uint32_t kRows = 64u / LPR;  // rows of a slice
   const uint32_t nslices = (n + kRows - 1u) / kRows;
-  const uint32_t labels = gridDim.x < 8u ? gridDim.x : 8u;
+  const uint32_t labels = nblocks < 8u ? nblocks : 8u;
   const uint32_t x = blockIdx.x % labels, xb = blockIdx.x / labels;
-  const uint32_t nbx = (gridDim.x - x + labels - 1u) / labels;  // blocks carrying this label
+  const uint32_t nbx = (nblocks - x + labels - 1u) / labels;  // blocks carrying this label
   const uint32_t segBeg = static_cast<uint32_t>((static_cast<uint64_t>(nslices) * x) / labels);
   const uint32_t segEnd = static_cast<uint32_t>((static_cast<uint64_t>(nslices) * (x + 1u)) / labels);
   return {segBeg + xb * (kBlock / 64u) + (threadIdx.x >> 6), segEnd, nbx * (kBlock / 64u)};
@@ -642,72 +659,42 @@ PIES_DEV void solve_statistics(const CgArrays& A, const float* __restrict__ prev
 }
 
 // Contact part of (K + C) v for the nodes that take part in contacts, one wavefront per node: lane t takes the node's
-// incidences t, t + 64, ... (list order inside a lane), the 64 partial sums are combined pairwise.  MODE 0: v = x
-// (before k_cg_init); MODE 1: v = p = z + beta p_old of CG iteration k (before k_cg_ap(k), same beta, same early exit).
-// Used by the contact-heavy graph variant only (CgArrays::useCAp): a node of a contact patch sits in tens to hundreds
-// of contacts, and the row's single lane walking them inside the SpMV made one CG iteration ~10x longer.
-template <int MODE>
-__global__ void __launch_bounds__(kBlock) k_contact_rows(CgArrays A, const float4* __restrict__ x, int k, float tol2) {
-  float beta[3] = {0.f, 0.f, 0.f};
-  if (MODE == 1) {
-    float red[9], rz[3], rr[3], bb[3];
-    if (k == 0) {
-      block_reduce_partials<9>(A.partI, 9, A.nparts, red);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { rz[c] = red[c]; rr[c] = red[3 + c]; bb[c] = red[6 + c]; }
-    } else {
-      block_reduce_partials<6>(A.partB, 6, A.nparts, red);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { rz[c] = red[c]; rr[c] = red[3 + c]; bb[c] = A.scal[6 + c]; }
-    }
-    if (all_converged(rr, bb, tol2)) return;
-    if (k > 0) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float old = A.scal[3 * ((k - 1) & 1) + c];
-        beta[c] = old > 0.0f ? rz[c] / old : 0.0f;
-      }
+// incidences t, t + 64, ... (list order inside a lane), the 64 partial sums are combined pairwise.  Used by the
+// contact-heavy graph variant only (CgArrays::useCAp): a node of a contact patch sits in tens to hundreds of contacts, and
+// the row's single lane walking them inside the SpMV made one CG iteration ~10x longer.
+// the wavefront's sum over one node's contact rows; fetch(j, qx, qy, qz) reads the vector
+template <class Fetch> PIES_DEV void contact_rows_of_node(const CgArrays& A, uint32_t node, uint32_t lane, Fetch fetch, float& sx, float& sy, float& sz) {
+  const uint32_t tc = A.tIncCnt[node], ts = A.tIncStart[node];
+  sx = 0.f; sy = 0.f; sz = 0.f;
+  for (uint32_t t = lane; t < tc; t += 64) {
+    const uint32_t v = A.tInc[ts + t];
+    const uint4 id = A.tIds[v >> 2];
+    const bool point = (v & 3u) == 0u;
+    float q0[3], q1[3] = {0.f, 0.f, 0.f}, q2[3] = {0.f, 0.f, 0.f};
+    fetch(point ? id.y : id.x, q0[0], q0[1], q0[2]);
+    if (point) { fetch(id.z, q1[0], q1[1], q1[2]); fetch(id.w, q2[0], q2[1], q2[2]); }
+    sx = fmaf(-kTriContactW, q0[0], sx); sy = fmaf(-kTriContactW, q0[1], sy); sz = fmaf(-kTriContactW, q0[2], sz);
+    if (point) {
+      sx = fmaf(-kTriContactW, q1[0], sx); sy = fmaf(-kTriContactW, q1[1], sy); sz = fmaf(-kTriContactW, q1[2], sz);
+      sx = fmaf(-kTriContactW, q2[0], sx); sy = fmaf(-kTriContactW, q2[1], sy); sz = fmaf(-kTriContactW, q2[2], sz);
     }
   }
-  const float4* __restrict__ pold = A.p[(k + 1) & 1];
-  auto fetch = [&](uint32_t j, float& qx, float& qy, float& qz) {
-    if (MODE == 0) {
-      const float4 v = x[j];
-      qx = v.x; qy = v.y; qz = v.z;
-    } else {
-      const float4 zj = A.z[j];
-      qx = zj.x; qy = zj.y; qz = zj.z;
-      if (k > 0) {
-        const float4 pj = pold[j];
-        qx = fmaf(beta[0], pj.x, qx); qy = fmaf(beta[1], pj.y, qy); qz = fmaf(beta[2], pj.z, qz);
-      }
-    }
-  };
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    sx += __shfl_xor(sx, off, 64);
+    sy += __shfl_xor(sy, off, 64);
+    sz += __shfl_xor(sz, off, 64);
+  }
+}
+// (K + C) x for the nodes with contacts, before k_cg_init (the residual needs the complete row; inside the CG iterations
+// the contact rows are summed by extra blocks of k_cg_ap itself)
+__global__ void __launch_bounds__(kBlock) k_contact_rows(CgArrays A, const float4* __restrict__ x) {
   const uint32_t used = *A.tUsedCount, lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
   for (uint32_t u = wave; u < used; u += nwaves) {
     const uint32_t node = A.tUsed[u];
-    const uint32_t tc = A.tIncCnt[node], ts = A.tIncStart[node];
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (uint32_t t = lane; t < tc; t += 64) {
-      const uint32_t v = A.tInc[ts + t];
-      const uint4 id = A.tIds[v >> 2];
-      const bool point = (v & 3u) == 0u;
-      float q0[3], q1[3] = {0.f, 0.f, 0.f}, q2[3] = {0.f, 0.f, 0.f};
-      fetch(point ? id.y : id.x, q0[0], q0[1], q0[2]);
-      if (point) { fetch(id.z, q1[0], q1[1], q1[2]); fetch(id.w, q2[0], q2[1], q2[2]); }
-      sx = fmaf(-kTriContactW, q0[0], sx); sy = fmaf(-kTriContactW, q0[1], sy); sz = fmaf(-kTriContactW, q0[2], sz);
-      if (point) {
-        sx = fmaf(-kTriContactW, q1[0], sx); sy = fmaf(-kTriContactW, q1[1], sy); sz = fmaf(-kTriContactW, q1[2], sz);
-        sx = fmaf(-kTriContactW, q2[0], sx); sy = fmaf(-kTriContactW, q2[1], sy); sz = fmaf(-kTriContactW, q2[2], sz);
-      }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      sx += __shfl_xor(sx, off, 64);
-      sy += __shfl_xor(sy, off, 64);
-      sz += __shfl_xor(sz, off, 64);
-    }
+    float sx, sy, sz;
+    contact_rows_of_node(A, node, lane, [&](uint32_t j, float& qx, float& qy, float& qz) { const float4 v = x[j]; qx = v.x; qy = v.y; qz = v.z; }, sx, sy, sz);
     if (lane == 0) A.cAp[node] = make_float4(sx, sy, sz, 0.f);
   }
 }
@@ -730,7 +717,7 @@ __global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __
                                                     const float* __restrict__ prevPartB) {
   if (prevPartB && blockIdx.x == 0) solve_statistics(A, prevPartB);
   const uint32_t lane = threadIdx.x & 63u;
-  const SliceSweep sw = slice_sweep<LPR>(A.n);
+  const SliceSweep sw = slice_sweep<LPR>(A.n, gridDim.x);
   float acc9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t sl = sw.begin; sl < sw.end; sl += sw.step) {
     const uint32_t i = sl * (64u / LPR) + lane / LPR;
@@ -769,6 +756,9 @@ __global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __
 }
 
 // iteration k:  beta = rz_k / rz_{k-1} (0 for k = 0) ; p = z + beta p_old ; Ap = (K + C) p ; partA = {pAp}
+// With useCAp the launch carries kCgRowBlocks extra blocks behind the nparts SpMV blocks: they sum the contact rows of p
+// (one wavefront per node, written to cAp) and add their share of p.Ap to partA; k_cg_update adds cAp to Ap.  (Round 2: a
+// launch of their own before every k_cg_ap, 100 launches per substep of a contact scene.)
 template <int LPR> __global__ void __launch_bounds__(kBlock) k_cg_ap(CgArrays A, int k, float tol2) {
   float red[9];
   float rz[3], rr[3], bb[3];
@@ -804,8 +794,33 @@ template <int LPR> __global__ void __launch_bounds__(kBlock) k_cg_ap(CgArrays A,
   const float4* __restrict__ pold = A.p[(k + 1) & 1];
   float4* __restrict__ pnew = A.p[k & 1];
   const uint32_t lane = threadIdx.x & 63u;
-  const SliceSweep sw = slice_sweep<LPR>(A.n);
   float acc[3] = {0, 0, 0};
+  if (blockIdx.x >= A.nparts) {  // contact rows of p = z + beta p_old
+    auto fetch = [&](uint32_t j, float& qx, float& qy, float& qz) {
+      const float4 zj = A.z[j];
+      qx = zj.x; qy = zj.y; qz = zj.z;
+      if (k > 0) {
+        const float4 pj = pold[j];
+        qx = fmaf(beta[0], pj.x, qx); qy = fmaf(beta[1], pj.y, qy); qz = fmaf(beta[2], pj.z, qz);
+      }
+    };
+    const uint32_t used = *A.tUsedCount;
+    const uint32_t wave = ((blockIdx.x - A.nparts) * kBlock + threadIdx.x) >> 6, nwaves = ((gridDim.x - A.nparts) * kBlock) >> 6;
+    for (uint32_t u = wave; u < used; u += nwaves) {
+      const uint32_t node = A.tUsed[u];
+      float sx, sy, sz;
+      contact_rows_of_node(A, node, lane, fetch, sx, sy, sz);
+      if (lane == 0) {
+        A.cAp[node] = make_float4(sx, sy, sz, 0.f);
+        float px, py, pz;
+        fetch(node, px, py, pz);
+        acc[0] += px * sx; acc[1] += py * sy; acc[2] += pz * sz;
+      }
+    }
+    block_write_partial<3>(acc, A.partA, 3);
+    return;
+  }
+  const SliceSweep sw = slice_sweep<LPR>(A.n, A.nparts);
   for (uint32_t sl = sw.begin; sl < sw.end; sl += sw.step) {
     const uint32_t i = sl * (64u / LPR) + lane / LPR;
     const uint32_t off = A.sliceOff[sl], width = (A.sliceOff[sl + 1] - off) >> 6;
@@ -834,11 +849,7 @@ template <int LPR> __global__ void __launch_bounds__(kBlock) k_cg_ap(CgArrays A,
     }
     row_combine<LPR>(sx, sy, sz);
     if (i < A.n && lane % LPR == 0u) {
-      if (A.useCAp) {
-        if (A.tIncCnt[i]) {
-          const float4 c = A.cAp[i]; sx += c.x; sy += c.y; sz += c.z;
-        }
-      } else {
+      if (!A.useCAp) {
         contact_row(A, i, [&](uint32_t j, float& qx, float& qy, float& qz) {
           const float4 zj = A.z[j];
           qx = zj.x; qy = zj.y; qz = zj.z;
@@ -887,8 +898,9 @@ __global__ void __launch_bounds__(kBlock) k_cg_update(CgArrays A, float4* __rest
     if (threadIdx.x < 6) A.partBnext[blockIdx.x * 6 + threadIdx.x] = (k == 0 ? A.partI[blockIdx.x * 9 + threadIdx.x] : A.partB[blockIdx.x * 6 + threadIdx.x]);
     return;
   }
+  const bool rows = A.useCAp && A.tIncCnt;
   float pap[3];
-  block_reduce_partials<3>(A.partA, 3, A.nparts, pap);
+  block_reduce_partials<3>(A.partA, 3, A.nparts + (rows ? kCgRowBlocks : 0u), pap);
   float alpha[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -899,7 +911,12 @@ __global__ void __launch_bounds__(kBlock) k_cg_update(CgArrays A, float4* __rest
   float acc[6] = {0, 0, 0, 0, 0, 0};
   // blocks run concurrently, so the new residual partials go to the other half of a ping-pong pair
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < A.n; i += gridDim.x * kBlock) {
-    const float4 pi = p[i], api = A.ap[i];
+    const float4 pi = p[i];
+    float4 api = A.ap[i];
+    if (rows && A.tIncCnt[i]) {
+      const float4 c = A.cAp[i];
+      api.x += c.x; api.y += c.y; api.z += c.z;
+    }
     float4 xi = x[i], ri = A.r[i];
     xi.x = fmaf(alpha[0], pi.x, xi.x);
     xi.y = fmaf(alpha[1], pi.y, xi.y);
@@ -1029,13 +1046,15 @@ void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, i
   if (nd.n == 0) return;
   CgArrays A = pd.cg;
   const dim3 grid(A.nparts), block(kBlock);
+  const bool rows = A.useCAp && A.tIncCnt;
+  const dim3 agrid(A.nparts + (rows ? kCgRowBlocks : 0u));  // k_cg_ap: SpMV blocks + contact-row blocks
   if (part >= 0) {  // profile pass: one kind of kernel only, never taking the converged early exit
     for (int k = 0; k < maxIters; ++k) {
       if (part == 1) {
-        if (A.lanesPerRow == 4) hipLaunchKernelGGL(k_cg_ap<4>, grid, block, 0, st, A, k, -1.0f);
-        else if (A.lanesPerRow == 2) hipLaunchKernelGGL(k_cg_ap<2>, grid, block, 0, st, A, k, -1.0f);
-        else if (A.lanesPerRow == 8) hipLaunchKernelGGL(k_cg_ap<8>, grid, block, 0, st, A, k, -1.0f);
-        else hipLaunchKernelGGL(k_cg_ap<1>, grid, block, 0, st, A, k, -1.0f);
+        if (A.lanesPerRow == 4) hipLaunchKernelGGL(k_cg_ap<4>, agrid, block, 0, st, A, k, -1.0f);
+        else if (A.lanesPerRow == 2) hipLaunchKernelGGL(k_cg_ap<2>, agrid, block, 0, st, A, k, -1.0f);
+        else if (A.lanesPerRow == 8) hipLaunchKernelGGL(k_cg_ap<8>, agrid, block, 0, st, A, k, -1.0f);
+        else hipLaunchKernelGGL(k_cg_ap<1>, agrid, block, 0, st, A, k, -1.0f);
       }
       else hipLaunchKernelGGL(k_cg_update, grid, block, 0, st, A, nd.pos, k, -1.0f);
     }
@@ -1045,9 +1064,7 @@ void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, i
   A.tol2 = tol * tol;
   float* pb[2] = {pd.cg.partB, pd.cg.partBnext};
   // every solve of a substep runs the same number of iterations, so the previous solve left its final partials here
-  const bool rows = A.useCAp && A.tIncCnt;
-  const dim3 rgrid(256);
-  if (rows) hipLaunchKernelGGL(k_contact_rows<0>, rgrid, block, 0, st, A, nd.pos, 0, 0.0f);
+  if (rows) hipLaunchKernelGGL(k_contact_rows, dim3(256), block, 0, st, A, nd.pos);
   const float* prevB = first ? nullptr : pb[maxIters & 1];
   if (A.lanesPerRow == 4) hipLaunchKernelGGL(k_cg_init<4>, grid, block, 0, st, A, nd.pos, pd.rhs, prevB);
   else if (A.lanesPerRow == 2) hipLaunchKernelGGL(k_cg_init<2>, grid, block, 0, st, A, nd.pos, pd.rhs, prevB);
@@ -1056,12 +1073,11 @@ void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, i
   for (int k = 0; k < maxIters; ++k) {
     A.partB = pb[k & 1];       // residual partials of iteration k (k = 0 reads partI instead)
     A.partBnext = pb[(k + 1) & 1];
-    if (rows) hipLaunchKernelGGL(k_contact_rows<1>, rgrid, block, 0, st, A, nd.pos, k, tol2);
     if (hook) hook(hookCtx, 14);  // PIES_KERNEL_PD_SPMV
-    if (A.lanesPerRow == 4) hipLaunchKernelGGL(k_cg_ap<4>, grid, block, 0, st, A, k, tol2);
-    else if (A.lanesPerRow == 2) hipLaunchKernelGGL(k_cg_ap<2>, grid, block, 0, st, A, k, tol2);
-    else if (A.lanesPerRow == 8) hipLaunchKernelGGL(k_cg_ap<8>, grid, block, 0, st, A, k, tol2);
-    else hipLaunchKernelGGL(k_cg_ap<1>, grid, block, 0, st, A, k, tol2);
+    if (A.lanesPerRow == 4) hipLaunchKernelGGL(k_cg_ap<4>, agrid, block, 0, st, A, k, tol2);
+    else if (A.lanesPerRow == 2) hipLaunchKernelGGL(k_cg_ap<2>, agrid, block, 0, st, A, k, tol2);
+    else if (A.lanesPerRow == 8) hipLaunchKernelGGL(k_cg_ap<8>, agrid, block, 0, st, A, k, tol2);
+    else hipLaunchKernelGGL(k_cg_ap<1>, agrid, block, 0, st, A, k, tol2);
     if (hook) { hook(hookCtx, 14); hook(hookCtx, 15); }  // PIES_KERNEL_PD_CG_UPDATE
     hipLaunchKernelGGL(k_cg_update, grid, block, 0, st, A, nd.pos, k, tol2);
     if (hook) hook(hookCtx, 15);

@@ -221,7 +221,7 @@ int pd_build(pies_solver* s) {
   if (int rc = dev_alloc(s, n, &cg.p[1], true)) return rc;
   if (int rc = dev_alloc(s, n, &cg.ap)) return rc;
   if (int rc = dev_alloc(s, kCgBlocks * 9, &cg.partI, true)) return rc;
-  if (int rc = dev_alloc(s, kCgBlocks * 3, &cg.partA, true)) return rc;
+  if (int rc = dev_alloc(s, (kCgBlocks + kCgRowBlocks) * 3, &cg.partA, true)) return rc;
   if (int rc = dev_alloc(s, kCgBlocks * 6, &cg.partB, true)) return rc;
   if (int rc = dev_alloc(s, kCgBlocks * 6, &cg.partBnext, true)) return rc;
   if (int rc = dev_alloc(s, 16, &cg.scal, true)) return rc;
@@ -275,6 +275,8 @@ int pd_build(pies_solver* s) {
     if (int rc = dev_alloc(s, T.maxContacts, &T.lvl, true)) return rc;
     if (int rc = dev_alloc(s, T.maxContacts, &T.lvOrder, true)) return rc;
     if (int rc = dev_alloc(s, kTriMaxLevels + 1, &T.lvStart, true)) return rc;
+    if (int rc = dev_alloc(s, n, &T.nodeSlot, true)) return rc;
+    if (int rc = dev_alloc(s, T.maxContacts, &T.lvSlots, true)) return rc;
     cg.tIncCnt = T.incCnt; cg.tIncStart = T.incStart; cg.tInc = T.incSorted; cg.tIds = T.ids;
     cg.tUsed = T.usedNodes; cg.tUsedCount = T.counters + 4;
     if (int rc = dev_alloc(s, n, &cg.cAp, true)) return rc;

@@ -26,7 +26,8 @@ struct TriArrays {
   uint64_t* keys;
   uint32_t *cnt, *start, *fill, *used;
   uint32_t* counters;  // [0] used cells [1] bucket entries [2] contacts [3] failure flag [4] nodes with contacts [5] incidences
-                       // [6] dependency levels of the contact list [7] 1: more than kTriMaxLevels levels
+                       // [6] dependency levels of the contact list [7] form of the sequential passes: 0 on an LDS copy of the
+                       // touched nodes, 2 through L2, 1 more than kTriMaxLevels levels (single-wavefront walk)
   uint32_t* triSlot;   // nt x kTriMaxEntries
   int4* rng;           // per triangle: min cell, packed lengths
   uint32_t *bucket, *bucketSorted;
@@ -44,6 +45,8 @@ struct TriArrays {
   uint32_t* lvl;       // per contact
   uint32_t* lvOrder;   // contacts bucketed by level
   uint32_t* lvStart;   // kTriMaxLevels + 1 offsets into lvOrder
+  uint32_t* nodeSlot;  // per node with contacts: its index in usedNodes (= its record in the LDS copy of the sequential passes)
+  uint2* lvSlots;      // per entry of lvOrder: the four nodeSlots of the contact, 16 bit each
 };
 constexpr uint32_t kTriMaxLevels = 2048;  // longer chains (one node in thousands of contacts) take the single-wavefront path
 

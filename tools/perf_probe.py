@@ -32,6 +32,18 @@ elif what == "contacts":
     bench.frame_loop(g, 12)
     B = bench.pd_bytes(g)
     classes = {k: B[k] for k in ("pd_local_tet", "pd_rhs", "pd_spmv")}
+elif what == "pdcontacts":
+    g = capi.Solver(capi.Options(solver=capi.PD, iterations=10), device=0)
+    g.create_tet_box(25, 25, 160, translation=(0.0, 0.04, 0.0), w=1.0, volume=True, triangles=True)
+    g.create_tet_box(25, 25, 40, translation=(0.3, 0.04 + 24 + 0.07, 10.3), w=1.0, volume=True, triangles=True)
+    g.finalize()
+    for _ in range(20):
+        t0 = time.perf_counter()
+        g.tick_async(1)
+        g.synchronize()
+        print("frame %.3f ms  contacts %d  health %s" % (1e3 * (time.perf_counter() - t0), len(g.tri_collisions), g.pcg_health()))
+    B = bench.pd_bytes(g)
+    classes = {k: B[k] for k in ("pd_local_tet", "pd_rhs", "pd_spmv", "pd_cg_update")}
 if os.environ.get("PROBE_NO_TRI") == "1":
     g.set_flag(capi.FLAG_TRIANGLE_COLLISIONS, 0)
 g.finalize()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The program tools/profile_round.sh puts under rocprofv3: N ticks of one of bench.py's workloads, whole substeps
-(every kernel in its place), nothing else.  usage: profile_target.py config2|config3|config4|contacts N"""
+(every kernel in its place), nothing else.  usage: profile_target.py config2|config3|config4|contacts|pdcontacts N"""
 import os
 import sys
 
@@ -26,6 +26,11 @@ elif what == "contacts":
     g = bench.contact_scene(capi, 0)
     g.set_pcg(3e-7, 12)  # (see config3; bench.py's frame loop settles at about 10 with these contacts)
     g.finalize()  # (the profiled ticks are the contact onset: frames 0 .. n-1, thousands of contacts in frames 0-3)
+elif what == "pdcontacts":
+    g = capi.Solver(capi.Options(solver=capi.PD, iterations=10), device=0)
+    g.create_tet_box(25, 25, 160, translation=(0.0, 0.04, 0.0), w=1.0, volume=True, triangles=True)
+    g.create_tet_box(25, 25, 40, translation=(0.3, 0.04 + 24 + 0.07, 10.3), w=1.0, volume=True, triangles=True)
+    g.set_pcg(3e-7, 10)  # (bench.py's frame loop settles at 10 in this scene)
 else:
     raise SystemExit("unknown workload")
 g.finalize()
