@@ -384,8 +384,15 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
   if (ON(PIES_KERNEL_PD_PREDICT)) { launch_pd_predict(st, s->nd, pd, h, s->opt.floorHeight + s->opt.collisionThickness); U(s->nd.n); }
   C(PIES_KERNEL_PD_PREDICT);
   const bool tri = pd.tri.nt != 0;
-  if (tri && only < 0)  // Solver.cpp:240, 245-248: detection, contact list, their blocks of the system matrix
+  if (tri && only < 0) {  // Solver.cpp:240, 245-248: detection, contact list, their blocks of the system matrix
     launch_tri_detect(st, pd.tri, s->nd, pd.kdiag, pd.cg.cdiag, pd.cg.dinv, s->opt.collisionThresholdDistance, s->opt.collisionThickness);
+    // The dependency levels of the list (one workgroup, up to 1 ms with tens of thousands of contacts) are only needed by
+    // the sequential passes behind the local/global iterations: a second branch of the substep, joined there.
+    (void)hipEventRecord(s->evFork, st);
+    (void)hipStreamWaitEvent(s->sideStream, s->evFork, 0);
+    launch_tri_levels(s->sideStream, pd.tri);
+    (void)hipEventRecord(s->evJoin, s->sideStream);
+  }
   for (uint32_t it = 0; it < s->opt.iterations; ++it) {
     // local step (Solver.cpp:270-308): position constraints project to a constant, uploaded once
     if (nDist && ON(PIES_KERNEL_PD_LOCAL_DISTANCE)) {
@@ -433,6 +440,7 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
     C(PIES_KERNEL_PD_CG_UPDATE, s->pcgBudget);
   }
   if (tri && only < 0) {  // :367-383: every stabilisation iteration is a sequential pass over the contacts, then the floor snap
+    (void)hipStreamWaitEvent(st, s->evJoin, 0);
     for (uint32_t ci = 0; ci < s->opt.collisionStabilizationIterations; ++ci) {
       launch_tri_stabilize(st, pd.tri, s->nd, s->opt.collisionThickness);
       launch_pd_stabilize(st, s->nd, pd);
@@ -614,7 +622,13 @@ int pies_create(const pies_options_t* options, int device, pies_solver_t** out) 
   if (s->opt.timeSubsteps == 0) s->opt.timeSubsteps = 1;
   s->device = device;
   apply_schedule_environment(s);
-  if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&s->sideStream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&s->evFork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&s->evJoin, hipEventDisableTiming) != hipSuccess) {
+    if (s->evFork) (void)hipEventDestroy(s->evFork);
+    if (s->sideStream) (void)hipStreamDestroy(s->sideStream);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return PIES_ERR_HIP;
   }
@@ -627,6 +641,7 @@ int pies_destroy(pies_solver_t* s) {
   if (s->device == PIES_DEVICE_NONE) { delete s; return PIES_OK; }
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
+  if (s->sideStream) (void)hipStreamSynchronize(s->sideStream);
   if (s->copyStream) (void)hipStreamSynchronize(s->copyStream);
   free_device(s);
   if (s->h_stage) (void)hipHostFree(s->h_stage);
@@ -637,6 +652,9 @@ int pies_destroy(pies_solver_t* s) {
   }
   if (s->d_export) (void)hipFree(s->d_export);
   if (s->copyStream) (void)hipStreamDestroy(s->copyStream);
+  if (s->evFork) (void)hipEventDestroy(s->evFork);
+  if (s->evJoin) (void)hipEventDestroy(s->evJoin);
+  if (s->sideStream) (void)hipStreamDestroy(s->sideStream);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
   return PIES_OK;

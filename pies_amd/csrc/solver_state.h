@@ -149,6 +149,9 @@ struct pies_solver {
   pies_options_t opt;
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t sideStream = nullptr;  // second branch of the PD substep: the dependency levels of the contact list (needed only by the
+                                     // sequential passes at the end of the substep) are computed beside the local/global iterations
+  hipEvent_t evFork = nullptr, evJoin = nullptr;
   std::string error;
 
   bool releaseHinge = false;

@@ -55,6 +55,8 @@ struct PdArrays;
 // after the predict kernel: grid build, detection (count, scan, fill), per-node incidence + diagonal; returns launches
 uint32_t launch_tri_detect(hipStream_t st, const TriArrays& T, const NodeArrays& nd, const float* kdiag, float* cdiag, float* dinv,
                            float threshold, float thickness);
+// dependency levels of the contact list for the sequential passes (may run on another stream beside the local/global iterations)
+void launch_tri_levels(hipStream_t st, const TriArrays& T);
 void launch_pd_local_tri(hipStream_t st, const TriArrays& T, const float4* pos, float thickness);
 void launch_tri_stabilize(hipStream_t st, const TriArrays& T, const NodeArrays& nd, float thickness);
 void launch_tri_friction(hipStream_t st, const TriArrays& T, const NodeArrays& nd, float friction, float staticThreshold);

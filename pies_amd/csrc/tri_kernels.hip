@@ -243,9 +243,9 @@ PIES_DEV uint32_t merge_rank(uint32_t t, uint32_t nt, uint32_t threads) {
   return th * q + min(th, rem) + t / threads;
 }
 
-// ---- detection (Solver.cpp:714-797).  FILL = false counts a triangle's contacts with TEAM lanes sharing the bucket
-// entries (the count does not depend on the order); FILL = true writes them, one lane per triangle walking the
-// entries in the reference's order, and only for the few triangles that have any. ---------------------------------
+// ---- detection (Solver.cpp:714-797).  TEAM lanes share a triangle's bucket entries.  FILL = false counts its contacts
+// (the count does not depend on the order); FILL = true writes them in the reference's order (a prefix sum over the
+// team's lanes per TEAM entries), only for the triangles that have any. ------------------------------------------
 template <bool FILL, int TEAM>
 __global__ void __launch_bounds__(kBlock) k_tri_detect(TriArrays T, const float4* __restrict__ pos, const float4* __restrict__ prev,
                                                        float threshold) {
@@ -269,42 +269,64 @@ __global__ void __launch_bounds__(kBlock) k_tri_detect(TriArrays T, const float4
         if (s == 0xffffffffu) continue;
         if (!FILL && ++nonEmpty > 1000u) atomicOr(&T.counters[3], 16u);  // Solver.cpp:741-745: more than 1000 buckets in a range fails the sim
         const uint32_t bs = T.start[s], bc = T.cnt[s];
-        for (uint32_t k = member; k < bc; k += TEAM) {
-          const uint32_t o = T.bucketSorted[bs + k];
-          const uint32_t ib = T.tris[3 * o], ic = T.tris[3 * o + 1], idd = T.tris[3 * o + 2];
-          bool common = false;
+        for (uint32_t k0 = 0; k0 < bc; k0 += TEAM) {  // (bc is the team's: its lanes stay together)
+          const uint32_t k = k0 + member;
+          bool hit[3] = {false, false, false};
+          uint32_t ib = 0, ic = 0, idd = 0;
+          if (k < bc) {
+            const uint32_t o = T.bucketSorted[bs + k];
+            ib = T.tris[3 * o]; ic = T.tris[3 * o + 1]; idd = T.tris[3 * o + 2];
+            bool common = false;
 #pragma unroll
-          for (int i = 0; i < 3; ++i) common = common || ia[i] == ib || ia[i] == ic || ia[i] == idd;
-          if (common) continue;
-          const F3 b1 = xyz(pos[ib]), c1 = xyz(pos[ic]), d1 = xyz(pos[idd]);
-          const F3 b0 = xyz(prev[ib]), c0 = xyz(prev[ic]), d0 = xyz(prev[idd]);
-          // Conservative reject before the CCD.  A hit puts the point, at some time in [0,1], within `threshold` of a
-          // point of the moving triangle (proximity branch: at t = 1; crossing branch: on it at the root), so the
-          // point's swept segment must meet the box of the triangle's six corner positions grown by the threshold;
-          // the margin adds 5 % and 1e-3 of the box on top of that, orders of magnitude above the rounding of the
-          // barycentric test.  A triangle with a vanishing normal (NaN inside the CCD, which then cannot say
-          // "outside") is never rejected here, nor is anything non-finite: every comparison below is false for NaN.
-          const F3 nn0 = cross(c0 - b0, d0 - b0), nn1 = cross(c1 - b1, d1 - b1);
-          const bool regular = dot(nn0, nn0) > 0.0f && dot(nn1, nn1) > 0.0f;
-          const F3 lo = {fminf(fminf(fminf(b0.x, c0.x), fminf(d0.x, b1.x)), fminf(c1.x, d1.x)),
-                         fminf(fminf(fminf(b0.y, c0.y), fminf(d0.y, b1.y)), fminf(c1.y, d1.y)),
-                         fminf(fminf(fminf(b0.z, c0.z), fminf(d0.z, b1.z)), fminf(c1.z, d1.z))};
-          const F3 hi = {fmaxf(fmaxf(fmaxf(b0.x, c0.x), fmaxf(d0.x, b1.x)), fmaxf(c1.x, d1.x)),
-                         fmaxf(fmaxf(fmaxf(b0.y, c0.y), fmaxf(d0.y, b1.y)), fmaxf(c1.y, d1.y)),
-                         fmaxf(fmaxf(fmaxf(b0.z, c0.z), fmaxf(d0.z, b1.z)), fmaxf(c1.z, d1.z))};
-          const float margin = 1.05f * threshold + 1.0e-3f * fmaxf(fmaxf(hi.x - lo.x, hi.y - lo.y), hi.z - lo.z);
+            for (int i = 0; i < 3; ++i) common = common || ia[i] == ib || ia[i] == ic || ia[i] == idd;
+            if (!common) {
+              const F3 b1 = xyz(pos[ib]), c1 = xyz(pos[ic]), d1 = xyz(pos[idd]);
+              const F3 b0 = xyz(prev[ib]), c0 = xyz(prev[ic]), d0 = xyz(prev[idd]);
+              // Conservative reject before the CCD.  A hit puts the point, at some time in [0,1], within `threshold` of a
+              // point of the moving triangle (proximity branch: at t = 1; crossing branch: on it at the root), so the
+              // point's swept segment must meet the box of the triangle's six corner positions grown by the threshold;
+              // the margin adds 5 % and 1e-3 of the box on top of that, orders of magnitude above the rounding of the
+              // barycentric test.  A triangle with a vanishing normal (NaN inside the CCD, which then cannot say
+              // "outside") is never rejected here, nor is anything non-finite: every comparison below is false for NaN.
+              const F3 nn0 = cross(c0 - b0, d0 - b0), nn1 = cross(c1 - b1, d1 - b1);
+              const bool regular = dot(nn0, nn0) > 0.0f && dot(nn1, nn1) > 0.0f;
+              const F3 lo = {fminf(fminf(fminf(b0.x, c0.x), fminf(d0.x, b1.x)), fminf(c1.x, d1.x)),
+                             fminf(fminf(fminf(b0.y, c0.y), fminf(d0.y, b1.y)), fminf(c1.y, d1.y)),
+                             fminf(fminf(fminf(b0.z, c0.z), fminf(d0.z, b1.z)), fminf(c1.z, d1.z))};
+              const F3 hi = {fmaxf(fmaxf(fmaxf(b0.x, c0.x), fmaxf(d0.x, b1.x)), fmaxf(c1.x, d1.x)),
+                             fmaxf(fmaxf(fmaxf(b0.y, c0.y), fmaxf(d0.y, b1.y)), fmaxf(c1.y, d1.y)),
+                             fmaxf(fmaxf(fmaxf(b0.z, c0.z), fmaxf(d0.z, b1.z)), fmaxf(c1.z, d1.z))};
+              const float margin = 1.05f * threshold + 1.0e-3f * fmaxf(fmaxf(hi.x - lo.x, hi.y - lo.y), hi.z - lo.z);
 #pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            const bool apart = (fmaxf(a0[i].x, a1[i].x) < lo.x - margin) || (fminf(a0[i].x, a1[i].x) > hi.x + margin) ||
-                               (fmaxf(a0[i].y, a1[i].y) < lo.y - margin) || (fminf(a0[i].y, a1[i].y) > hi.y + margin) ||
-                               (fmaxf(a0[i].z, a1[i].z) < lo.z - margin) || (fminf(a0[i].z, a1[i].z) > hi.z + margin);
-            if (regular && apart) continue;
-            if (!point_triangle_ccd(a0[i] - b0, c0 - b0, d0 - b0, a1[i] - b1, c1 - b1, d1 - b1, threshold)) continue;
-            if (FILL) {
-              const uint32_t c = base + count;
-              if (c < T.maxContacts) T.ids[c] = make_uint4(ia[i], ib, ic, idd);
+              for (int i = 0; i < 3; ++i) {
+                const bool apart = (fmaxf(a0[i].x, a1[i].x) < lo.x - margin) || (fminf(a0[i].x, a1[i].x) > hi.x + margin) ||
+                                   (fmaxf(a0[i].y, a1[i].y) < lo.y - margin) || (fminf(a0[i].y, a1[i].y) > hi.y + margin) ||
+                                   (fmaxf(a0[i].z, a1[i].z) < lo.z - margin) || (fminf(a0[i].z, a1[i].z) > hi.z + margin);
+                if (regular && apart) continue;
+                hit[i] = point_triangle_ccd(a0[i] - b0, c0 - b0, d0 - b0, a1[i] - b1, c1 - b1, d1 - b1, threshold);
+              }
             }
-            ++count;
+          }
+          const uint32_t mine = (hit[0] ? 1u : 0u) + (hit[1] ? 1u : 0u) + (hit[2] ? 1u : 0u);
+          if (FILL) {
+            // the reference's list order: bucket entry after bucket entry, for each the triangle's corners 0, 1, 2 - the
+            // team's lanes hold TEAM consecutive entries, so a lane writes behind the hits of the lanes below it
+            uint32_t incl = mine;
+#pragma unroll
+            for (int off = 1; off < TEAM; off <<= 1) {
+              const uint32_t below = __shfl_up(incl, off, TEAM);
+              if (static_cast<int>(member) >= off) incl += below;
+            }
+            uint32_t c = base + count + (incl - mine);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+              if (hit[i]) {
+                if (c < T.maxContacts) T.ids[c] = make_uint4(ia[i], ib, ic, idd);
+                ++c;
+              }
+            count += __shfl(incl, TEAM - 1, TEAM);  // the team's running total (the same in all its lanes)
+          } else {
+            count += mine;
           }
         }
       }
@@ -530,8 +552,9 @@ constexpr uint32_t kLevelsLdsCap = 49152;  // contacts whose 16-bit levels fit n
 // barriers and a few LDS operations, its list entries were requested four to eight rounds earlier; the number of rounds is
 // the number of levels (the old path relaxed 1024 contacts at a time: the sum of the chunks' chain lengths, 6x as many
 // rounds on a 29k-contact patch: 1.35 ms against 0.2 ms).
-constexpr uint32_t kSeqLdsNodes = 4096, kLvNodesPerThread = kSeqLdsNodes / kSeqBlock, kLvMaxContacts = 65536;
+constexpr uint32_t kSeqLdsNodes = 4096, kLvMaxContacts = 65536;
 PIES_DEV uint32_t ldu32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <uint32_t kLvNodesPerThread>
 PIES_DEV void levels_by_node_owners(const TriArrays& T, uint32_t* heads32, uint32_t* sCnt, const uint32_t M, const uint32_t used, const int tid) {
   // Per owned node: `head` = the list entry the node stands at (position k), nx[0..3] = the entries behind it, pend[0..3]
   // = the four after those, requested at the last refill.  Global memory is only touched at refills - every four rounds,
@@ -637,7 +660,10 @@ __global__ void __launch_bounds__(kSeqBlock) k_tri_levels(TriArrays T, int ldsFo
   const uint32_t M = T.counters[2];
   const int tid = threadIdx.x;
   if (ldsForm && M != 0 && M <= kLvMaxContacts && T.counters[4] <= kSeqLdsNodes) {
-    levels_by_node_owners(T, raw + 4, raw, M, T.counters[4], tid);
+    const uint32_t used = T.counters[4];  // nodes per thread: as few as the touched nodes need (a round's cost is per slot)
+    if (used <= kSeqBlock) levels_by_node_owners<1>(T, raw + 4, raw, M, used, tid);
+    else if (used <= 2 * kSeqBlock) levels_by_node_owners<2>(T, raw + 4, raw, M, used, tid);
+    else levels_by_node_owners<4>(T, raw + 4, raw, M, used, tid);
     return;
   }
   for (int b = tid; b <= static_cast<int>(kTriMaxLevels); b += kSeqBlock) hist[b] = 0;
@@ -836,16 +862,19 @@ uint32_t launch_tri_detect(hipStream_t st_, const TriArrays& T, const NodeArrays
   hipLaunchKernelGGL(k_tri_sort, wide, blk, 0, st_, T);
   hipLaunchKernelGGL((k_tri_detect<false, kTriTeam>), grid_for(T.nt * kTriTeam), blk, 0, st_, T, nd.pos, nd.prev, threshold);
   hipLaunchKernelGGL(k_tri_scan, dim3(1), dim3(1024), 0, st_, T);
-  hipLaunchKernelGGL((k_tri_detect<true, 1>), grid_for(T.nt), blk, 0, st_, T, nd.pos, nd.prev, threshold);
+  hipLaunchKernelGGL((k_tri_detect<true, kTriTeam>), grid_for(T.nt * kTriTeam), blk, 0, st_, T, nd.pos, nd.prev, threshold);
   const dim3 cgrid(std::min<uint32_t>(256u, (T.maxContacts + kBlock - 1) / kBlock));
   hipLaunchKernelGGL(k_inc_count, cgrid, blk, 0, st_, T, cdiag);
   hipLaunchKernelGGL(k_inc_alloc, cgrid, blk, 0, st_, T, kdiag, cdiag, dinv);
   hipLaunchKernelGGL(k_inc_fill, cgrid, blk, 0, st_, T);
   hipLaunchKernelGGL(k_inc_sort, cgrid, blk, 0, st_, T);
+  return 13;
+}
+void launch_tri_levels(hipStream_t st_, const TriArrays& T) {
+  if (T.nt == 0) return;
   const char* e = std::getenv("PIES_TRI_LDS");  // diagnostics, read when the substep is captured: 0 = sequential passes through L2
   const int ldsForm = e && e[0] == '0' ? 0 : 1;
   hipLaunchKernelGGL(k_tri_levels, dim3(1), dim3(kSeqBlock), 0, st_, T, ldsForm);
-  return 14;
 }
 void launch_pd_local_tri(hipStream_t st_, const TriArrays& T, const float4* pos, float thickness) {
   if (T.nt == 0) return;
