@@ -388,10 +388,18 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
     launch_tri_detect(st, pd.tri, s->nd, pd.kdiag, pd.cg.cdiag, pd.cg.dinv, s->opt.collisionThresholdDistance, s->opt.collisionThickness);
     // The dependency levels of the list (one workgroup, up to 1 ms with tens of thousands of contacts) are only needed by
     // the sequential passes behind the local/global iterations: a second branch of the substep, joined there.
-    (void)hipEventRecord(s->evFork, st);
-    (void)hipStreamWaitEvent(s->sideStream, s->evFork, 0);
-    launch_tri_levels(s->sideStream, pd.tri);
-    (void)hipEventRecord(s->evJoin, s->sideStream);
+    // Only in the contact-heavy graph variant: a fork and join inside a hipGraph costs about 100 us per replay (measured:
+    // config 3, no contact, 1 257 -> 1 120 substeps/s with the branch; 29k contacts, 197 -> 234 with it).
+    const char* e = std::getenv("PIES_TRI_SIDE");  // diagnostics: 0 = always in line, 1 = always beside
+    s->triLevelsForked = e ? e[0] != '0' : s->triFastRows;
+    if (s->triLevelsForked) {
+      (void)hipEventRecord(s->evFork, st);
+      (void)hipStreamWaitEvent(s->sideStream, s->evFork, 0);
+      launch_tri_levels(s->sideStream, pd.tri);
+      (void)hipEventRecord(s->evJoin, s->sideStream);
+    } else {
+      launch_tri_levels(st, pd.tri);
+    }
   }
   for (uint32_t it = 0; it < s->opt.iterations; ++it) {
     // local step (Solver.cpp:270-308): position constraints project to a constant, uploaded once
@@ -440,7 +448,7 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
     C(PIES_KERNEL_PD_CG_UPDATE, s->pcgBudget);
   }
   if (tri && only < 0) {  // :367-383: every stabilisation iteration is a sequential pass over the contacts, then the floor snap
-    (void)hipStreamWaitEvent(st, s->evJoin, 0);
+    if (s->triLevelsForked) (void)hipStreamWaitEvent(st, s->evJoin, 0);
     for (uint32_t ci = 0; ci < s->opt.collisionStabilizationIterations; ++ci) {
       launch_tri_stabilize(st, pd.tri, s->nd, s->opt.collisionThickness);
       launch_pd_stabilize(st, s->nd, pd);

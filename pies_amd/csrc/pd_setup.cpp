@@ -275,6 +275,7 @@ int pd_build(pies_solver* s) {
     if (int rc = dev_alloc(s, T.maxContacts, &T.lvl, true)) return rc;
     if (int rc = dev_alloc(s, T.maxContacts, &T.lvOrder, true)) return rc;
     if (int rc = dev_alloc(s, kTriMaxLevels + 1, &T.lvStart, true)) return rc;
+    if (int rc = dev_alloc(s, (n + 31ull) / 32 + 1, &T.usedBits, true)) return rc;
     if (int rc = dev_alloc(s, n, &T.nodeSlot, true)) return rc;
     if (int rc = dev_alloc(s, T.maxContacts, &T.lvSlots, true)) return rc;
     cg.tIncCnt = T.incCnt; cg.tIncStart = T.incStart; cg.tInc = T.incSorted; cg.tIds = T.ids;

@@ -152,6 +152,7 @@ struct pies_solver {
   hipStream_t sideStream = nullptr;  // second branch of the PD substep: the dependency levels of the contact list (needed only by the
                                      // sequential passes at the end of the substep) are computed beside the local/global iterations
   hipEvent_t evFork = nullptr, evJoin = nullptr;
+  bool triLevelsForked = true;
   std::string error;
 
   bool releaseHinge = false;

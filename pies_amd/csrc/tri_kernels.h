@@ -45,6 +45,7 @@ struct TriArrays {
   uint32_t* lvl;       // per contact
   uint32_t* lvOrder;   // contacts bucketed by level
   uint32_t* lvStart;   // kTriMaxLevels + 1 offsets into lvOrder
+  uint32_t* usedBits;  // bitmap over the nodes: takes part in a contact of this substep (usedNodes is read off it, ascending)
   uint32_t* nodeSlot;  // per node with contacts: its index in usedNodes (= its record in the LDS copy of the sequential passes)
   uint2* lvSlots;      // per entry of lvOrder: the four nodeSlots of the contact, 16 bit each
 };

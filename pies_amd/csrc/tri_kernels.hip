@@ -148,7 +148,11 @@ __global__ void __launch_bounds__(kBlock) k_tri_reset(TriArrays T) {
     T.keys[s] = kEmpty;
     T.cnt[s] = 0;
   }
-  for (uint32_t u = blockIdx.x * kBlock + threadIdx.x; u < usedNodes; u += gridDim.x * kBlock) T.incCnt[T.usedNodes[u]] = 0;
+  for (uint32_t u = blockIdx.x * kBlock + threadIdx.x; u < usedNodes; u += gridDim.x * kBlock) {
+    const uint32_t n = T.usedNodes[u];
+    T.incCnt[n] = 0;
+    T.usedBits[n >> 5] = 0;  // (several nodes of a word: every writer stores the same 0)
+  }
 }
 __global__ void k_tri_zero(TriArrays T) {
   const uint32_t t = threadIdx.x;
@@ -377,11 +381,42 @@ __global__ void __launch_bounds__(kBlock) k_inc_count(TriArrays T, float* __rest
     const uint32_t n[4] = {id.x, id.y, id.z, id.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (atomicAdd(&T.incCnt[n[i]], 1u) == 0u) T.usedNodes[atomicAdd(&T.counters[4], 1u)] = n[i];
+      if (atomicAdd(&T.incCnt[n[i]], 1u) == 0u) atomicOr(&T.usedBits[n[i] >> 5], 1u << (n[i] & 31u));
       // diag(w A^T A) = w * (3, 1, 1, 1); multiples of 1e4 add exactly in float, so the order is irrelevant
       atomicAdd(&cdiag[n[i]], kTriContactW * (i == 0 ? 3.0f : 1.0f));
     }
   }
+}
+// The nodes that take part in contacts, in ascending order, from the bitmap k_inc_count marked them in: one workgroup, a
+// thread per run of bitmap words (popcounts, a prefix sum over the threads, then the set bits in order).  An append in
+// arrival order would be cheaper by this launch, but the order decides which wavefront sums which contact rows
+// (k_cg_ap), i.e. the rounding of p.Ap: results would differ from run to run.
+__global__ void __launch_bounds__(1024) k_inc_used(TriArrays T, uint32_t words) {
+  __shared__ uint32_t part[1024];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t chunk = (words + 1023u) / 1024u;
+  const uint32_t lo = min(words, tid * chunk), hi = min(words, lo + chunk);
+  uint32_t sum = 0;
+  for (uint32_t w = lo; w < hi; ++w) sum += static_cast<uint32_t>(__popc(T.usedBits[w]));
+  part[tid] = sum;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    const uint32_t v = tid >= off ? part[tid - off] : 0u;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t at = tid ? part[tid - 1] : 0u;
+  if (sum)
+    for (uint32_t w = lo; w < hi; ++w) {
+      uint32_t bits = T.usedBits[w];
+      while (bits) {
+        const uint32_t b = static_cast<uint32_t>(__ffs(bits)) - 1u;
+        T.usedNodes[at++] = (w << 5) + b;
+        bits &= bits - 1u;
+      }
+    }
+  if (tid == 1023) T.counters[4] = part[1023];
 }
 __global__ void __launch_bounds__(kBlock) k_inc_alloc(TriArrays T, const float* __restrict__ kdiag, const float* __restrict__ cdiag,
                                                       float* __restrict__ dinv) {
@@ -766,13 +801,25 @@ __global__ void __launch_bounds__(kSeqBlock) k_tri_levels(TriArrays T, int ldsFo
 // node.  Three forms, chosen by k_tri_levels (counters[7]):
 //  0  the touched nodes (at most kSeqLdsNodes) are copied into LDS, the levels run on the copy with a barrier that waits
 //     for LDS traffic only, the copy is written back at the end.  A level costs its arithmetic and one LDS round trip
-//     (0.2-0.3 us) instead of one or two L2 round trips (0.75 us stabilisation, 2.0 us friction on a 29k-contact patch);
+//     (0.43 us: the dependent chain cross product - square root - division - dot product - divisions of one contact)
+//     instead of one or two L2 round trips on top of it (0.75 us stabilisation, 2.0 us friction on a 29k-contact patch);
 //     four wavefronts work (levels are 20-110 contacts wide), the other twelve help with the copy and leave.  The
-//     contacts' node slots are staged through LDS kSeqChunk at a time.
+//     contacts' node slots are staged through LDS kSeqChunk at a time.  (Measured and dropped: four lanes per contact,
+//     one vector component each over DPP quad permutes - bit-identical, less than half the instructions, the same
+//     270 us per pass: a level waits for latencies, not for issue slots; one working wavefront without barriers: slower,
+//     levels wider than 64 contacts take two rounds.)
 //  2  node state through agent-scope (L2) loads and stores, a level ends with the stores drained and a workgroup barrier.
 //  1  more levels than kTriMaxLevels: one wavefront walks the list window by window.
-constexpr int kSeqWorkers = 256;
+#ifndef PIES_SEQ_WORKERS
+#define PIES_SEQ_WORKERS 256
+#endif
+constexpr int kSeqWorkers = PIES_SEQ_WORKERS;
 constexpr uint32_t kSeqChunk = 2048;
+// between two levels: with one working wavefront its LDS operations are already in order; with several, a barrier
+PIES_DEV void level_barrier() {
+  if (kSeqWorkers > 64) lds_barrier();
+  else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
 template <int MODE>
 __global__ void __launch_bounds__(kSeqBlock) k_tri_sequential(TriArrays T, float4* pos4, float4* prev4, float4* vel4, float thickness,
                                                               float friction, float staticThreshold) {
@@ -806,7 +853,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_tri_sequential(TriArrays T, float
           k0 = seg;
           kEnd = min(M, seg + kSeqChunk);
           for (uint32_t q = k0 + tid; q < kEnd; q += kSeqWorkers) sSlots[q - k0] = T.lvSlots[q];
-          lds_barrier();
+          level_barrier();
         }
         const uint32_t segEnd = min(hi, kEnd);
         for (uint32_t q = seg + tid; q < segEnd; q += kSeqWorkers) {
@@ -814,7 +861,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_tri_sequential(TriArrays T, float
           LdsNodes io = {{sl.x & 0xffffu, sl.x >> 16, sl.y & 0xffffu, sl.y >> 16}, P, Q};
           tri_contact_step<MODE>(io, thickness, friction, staticThreshold);
         }
-        lds_barrier();
+        level_barrier();
         seg = segEnd;
       }
     }
@@ -865,10 +912,11 @@ uint32_t launch_tri_detect(hipStream_t st_, const TriArrays& T, const NodeArrays
   hipLaunchKernelGGL((k_tri_detect<true, kTriTeam>), grid_for(T.nt * kTriTeam), blk, 0, st_, T, nd.pos, nd.prev, threshold);
   const dim3 cgrid(std::min<uint32_t>(256u, (T.maxContacts + kBlock - 1) / kBlock));
   hipLaunchKernelGGL(k_inc_count, cgrid, blk, 0, st_, T, cdiag);
+  hipLaunchKernelGGL(k_inc_used, dim3(1), dim3(1024), 0, st_, T, (nd.n + 31u) / 32u);
   hipLaunchKernelGGL(k_inc_alloc, cgrid, blk, 0, st_, T, kdiag, cdiag, dinv);
   hipLaunchKernelGGL(k_inc_fill, cgrid, blk, 0, st_, T);
   hipLaunchKernelGGL(k_inc_sort, cgrid, blk, 0, st_, T);
-  return 13;
+  return 14;
 }
 void launch_tri_levels(hipStream_t st_, const TriArrays& T) {
   if (T.nt == 0) return;

@@ -110,6 +110,36 @@ def test_many_contacts_spanning_several_windows(pies, oracle):
     assert most > 128
 
 
+def test_sequential_passes_on_the_lds_copy_equal_the_l2_path_bit_for_bit(pies, monkeypatch):
+    """The stabilisation and friction passes are order dependent; run level by level they give the sequential result whatever
+    the level partition.  Two device solvers on the same scene (thousands of contacts): one with the node-owner levels + the
+    four-lanes-per-contact passes on an LDS copy of the touched nodes, one with the chunked levels + one lane per contact
+    through L2 (PIES_TRI_LDS=0).  Everything else is the same code, so the states must agree bit for bit."""
+    def run(lds):
+        monkeypatch.setenv("PIES_TRI_LDS", lds)
+        monkeypatch.setenv("PIES_TRI_FAST_ROWS", "1")
+        g = pies.Solver(pd_options(pies, 3))
+        g.set_pcg(3e-7, 64)
+        g.create_tet_box(14, 2, 20, translation=(0, 0.02, 0), w=1.0)
+        g.create_tet_box(12, 2, 18, translation=(0.37, 1.05, 0.41), w=1.0)
+        v = g.velocities
+        v[14 * 2 * 20:, 1] = -1.5
+        g.set_velocities(v)
+        g.set_prev_positions(g.positions)
+        out = []
+        for _ in range(4):
+            g.tick()
+            out.append((g.positions.copy(), g.velocities.copy(), g.prev_positions.copy(), g.tri_collisions.copy()))
+        assert not g.failed
+        g.close()
+        return out
+    a, b = run("1"), run("0")
+    assert max(len(t[3]) for t in a) > 1024
+    for t, (x, y) in enumerate(zip(a, b)):
+        for k in range(4):
+            assert np.array_equal(x[k], y[k]), (t, k)
+
+
 @pytest.mark.parametrize("contact_rows,sequential", [("inline", "lds"), ("pass", "lds"), ("pass", "l2")])
 def test_thousands_of_contacts_level_schedule(pies, oracle, monkeypatch, contact_rows, sequential):
     """A plate resting on a larger one: 2000+ contacts per tick, chains of tens of contacts through one node.  Exercises
