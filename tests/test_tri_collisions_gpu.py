@@ -140,6 +140,39 @@ def test_sequential_passes_on_the_lds_copy_equal_the_l2_path_bit_for_bit(pies, m
             assert np.array_equal(x[k], y[k]), (t, k)
 
 
+def test_patch_wider_than_the_lds_copy_takes_the_l2_path(pies, oracle, monkeypatch):
+    """Two 52x52 plates: more than 4096 nodes take part in contacts, so the sequential passes cannot run on an LDS copy and
+    the level kernel takes the chunked relaxation (the automatic choice, no switch set).  One teacher-forced tick against
+    the oracle, and the same tick with the L2 path forced (PIES_TRI_LDS=0) must give the same bits."""
+    monkeypatch.setenv("PIES_TRI_FAST_ROWS", "1")
+    def build(s):
+        s.create_tet_box(52, 2, 52, translation=(0, 0.02, 0), w=1.0)
+        s.create_tet_box(52, 2, 52, translation=(0.37, 1.05, 0.41), w=1.0)
+        v = s.velocities
+        v[52 * 2 * 52:, 1] = -1.5
+        s.set_velocities(v)
+        s.set_prev_positions(s.positions)
+    o = oracle.OracleSolver(pd_options(oracle, 3))
+    build(o)
+    o.tick()
+    states = []
+    for lds in ("1", "0"):
+        monkeypatch.setenv("PIES_TRI_LDS", lds)
+        g = pies.Solver(pd_options(pies, 3))
+        g.set_pcg(3e-7, 256)
+        build(g)
+        g.tick()
+        assert not g.failed
+        states.append((g.positions.copy(), g.velocities.copy(), g.tri_collisions.copy()))
+        g.close()
+    touched = len(np.unique(o.tri_collisions))
+    assert touched > 4096, touched
+    assert np.array_equal(states[0][2], o.tri_collisions)
+    assert np.abs(states[0][0] - o.positions).max() <= 2.0 * tol_for(o.positions)
+    for a, b in zip(states[0], states[1]):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("contact_rows,sequential", [("inline", "lds"), ("pass", "lds"), ("pass", "l2")])
 def test_thousands_of_contacts_level_schedule(pies, oracle, monkeypatch, contact_rows, sequential):
     """A plate resting on a larger one: 2000+ contacts per tick, chains of tens of contacts through one node.  Exercises

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profile, run ON the GPU box (gpurun -- 'bash tools/profile_round.sh r02'): for every workload bench.py reports -
-# config 2 (headline), config 3 (PD), config 4 (node-node collisions) and the 250k contact scene - a rocprofv3
+# config 2 (headline), config 3 (PD), config 4 (node-node collisions), the 250k contact scene and the 125k / 29k-contact scene - a rocprofv3
 # --kernel-trace --stats pass of WHOLE substeps (in situ) and two --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one
 # pass on gfx950), plus a VALU counter pass for the dominant kernel.  Summaries are copied into profiles/ by
 # tools/summarize_profile.py.  rocprofv3 7.2 on this pool crashes on large traced graphs / a second graph instantiation:
@@ -8,7 +8,7 @@
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 R=${1:-r02}; OUT=gpurun_out/$R; mkdir -p $OUT
 export PIES_PROFILER_SAFE=1
-for W in config2 config3 config4 contacts; do
+for W in config2 config3 config4 contacts pdcontacts; do
   echo "== $W trace"; timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -- python3 tools/profile_target.py $W 6 > $OUT/trace_$W.log 2>&1; echo rc=$?
   echo "== $W pmc fetch"; timeout -k 10 280 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$W -- python3 tools/profile_target.py $W 2 > $OUT/fetch_$W.log 2>&1; echo rc=$?
   echo "== $W pmc write"; timeout -k 10 280 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write_$W -- python3 tools/profile_target.py $W 2 > $OUT/write_$W.log 2>&1; echo rc=$?

@@ -20,7 +20,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WORKLOADS = ("config2", "config3", "config4", "contacts")
+WORKLOADS = ("config2", "config3", "config4", "contacts", "pdcontacts")
 
 
 def short(name):
