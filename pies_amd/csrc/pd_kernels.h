@@ -30,6 +30,7 @@ struct CgArrays {
   float* dinv;   // 1 / diag(K + C)
   float4 *r, *z, *p[2], *ap;
   float *partI, *partA, *partB, *partBnext;
+  float *partB0, *partB1;  // the ping-pong pair under fixed names (partB / partBnext are re-pointed per iteration)
   // point-triangle contacts of the substep (null when the pipeline is off): per node, ascending (contact<<2 | local)
   const uint32_t *tIncCnt, *tIncStart, *tInc;
   const uint4* tIds;
@@ -39,7 +40,7 @@ struct CgArrays {
   const uint32_t* tUsedCount;  // how many (device counter)
   float4* cAp;
   int useCAp;
-  float* scal;   // rz[2][3], bb[3], iterations
+  float* scal;   // rz[2][3], bb[3], iterations, [10] the solve has converged, [11] where its final residual partials are
   float* stats;  // over the tick: [0] max relative residual^2 of its solves, [1] max iterations, [2] solves, [3] solves that ended
                  // above the tolerance; since the buffers were built: [4] solves above the tolerance, [5] solves
   float tol2;    // squared relative tolerance of the solve whose statistics are being closed

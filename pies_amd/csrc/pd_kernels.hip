@@ -637,7 +637,12 @@ template <int LPR> PIES_DEV SliceSweep slice_sweep(uint32_t n, uint32_t nblocks)
 // saves a launch per local/global iteration.  prevPartB holds the finished solve's final residual partials.
 PIES_DEV void solve_statistics(const CgArrays& A, const float* __restrict__ prevPartB) {
   float red[6];
-  block_reduce_partials<6>(prevPartB, 6, A.nparts, red);
+  // a solve that converged before its last captured iteration left its final partials where k_cg_ap found them
+  // (scal[10] = 1, scal[11] = 0: partI, 1 / 2: the ping-pong pair); otherwise the last k_cg_update wrote prevPartB
+  const bool done = A.scal[10] != 0.0f;
+  const int where = static_cast<int>(A.scal[11]);
+  if (done && where == 0) block_reduce_partials<6>(A.partI, 9, A.nparts, red);
+  else block_reduce_partials<6>(done ? (where == 1 ? A.partB0 : A.partB1) : prevPartB, 6, A.nparts, red);
   if (threadIdx.x == 0) {
     float worst = 0.f;
     bool above = false;  // the very test the CG kernels take their early exit on (all_converged)
@@ -716,6 +721,7 @@ template <int LPR>
 __global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __restrict__ x, const float4* __restrict__ f,
                                                     const float* __restrict__ prevPartB) {
   if (prevPartB && blockIdx.x == 0) solve_statistics(A, prevPartB);
+  if (blockIdx.x == 0 && threadIdx.x == 0) A.scal[10] = 0.0f;  // this solve has not converged yet (read by k_cg_ap / k_cg_update)
   const uint32_t lane = threadIdx.x & 63u;
   const SliceSweep sw = slice_sweep<LPR>(A.n, gridDim.x);
   float acc9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -760,6 +766,10 @@ __global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __
 // (one wavefront per node, written to cAp) and add their share of p.Ap to partA; k_cg_update adds cAp to Ap.  (Round 2: a
 // launch of their own before every k_cg_ap, 100 launches per substep of a contact scene.)
 template <int LPR> __global__ void __launch_bounds__(kBlock) k_cg_ap(CgArrays A, int k, float tol2) {
+  // The solve converged in an earlier iteration: nothing to do, and nothing to read but this word (without it every block
+  // of the remaining captured launches re-reduced the residual partials to find that out: 4.7 instead of 2.5 us per launch
+  // at 100k rows, and half of config 3's CG launches are such exits).
+  if (A.scal[10] != 0.0f) return;
   float red[9];
   float rz[3], rr[3], bb[3];
   if (k == 0) {
@@ -777,7 +787,13 @@ template <int LPR> __global__ void __launch_bounds__(kBlock) k_cg_ap(CgArrays A,
     A.scal[8] = bb[2];
     A.scal[9] = 0.0f;  // iterations started in this solve
   }
-  if (all_converged(rr, bb, tol2)) return;
+  if (all_converged(rr, bb, tol2)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      A.scal[11] = k == 0 ? 0.0f : static_cast<float>(1 + (k & 1));  // where the final residual partials are (solve_statistics)
+      A.scal[10] = 1.0f;
+    }
+    return;
+  }
   float beta[3] = {0.f, 0.f, 0.f};
   if (k > 0) {
 #pragma unroll
@@ -881,6 +897,7 @@ template <int LPR> __global__ void __launch_bounds__(kBlock) k_cg_ap(CgArrays A,
 
 // alpha = rz_k / pAp ; x += alpha p ; r -= alpha Ap ; z = D^-1 r ; partB = {rz_{k+1}, rr_{k+1}}
 __global__ void __launch_bounds__(kBlock) k_cg_update(CgArrays A, float4* __restrict__ x, int k, float tol2) {
+  if (A.scal[10] != 0.0f) return;  // (see k_cg_ap)
   float red[9];
   float rr[3], bb[3];
   if (k == 0) {
@@ -1049,6 +1066,7 @@ void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, i
   const bool rows = A.useCAp && A.tIncCnt;
   const dim3 agrid(A.nparts + (rows ? kCgRowBlocks : 0u));  // k_cg_ap: SpMV blocks + contact-row blocks
   if (part >= 0) {  // profile pass: one kind of kernel only, never taking the converged early exit
+    (void)hipMemsetAsync(A.scal + 10, 0, sizeof(float), st);  // (the last real solve may have left "converged" behind)
     for (int k = 0; k < maxIters; ++k) {
       if (part == 1) {
         if (A.lanesPerRow == 4) hipLaunchKernelGGL(k_cg_ap<4>, agrid, block, 0, st, A, k, -1.0f);

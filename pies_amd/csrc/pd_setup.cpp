@@ -224,6 +224,8 @@ int pd_build(pies_solver* s) {
   if (int rc = dev_alloc(s, (kCgBlocks + kCgRowBlocks) * 3, &cg.partA, true)) return rc;
   if (int rc = dev_alloc(s, kCgBlocks * 6, &cg.partB, true)) return rc;
   if (int rc = dev_alloc(s, kCgBlocks * 6, &cg.partBnext, true)) return rc;
+  cg.partB0 = cg.partB;
+  cg.partB1 = cg.partBnext;
   if (int rc = dev_alloc(s, 16, &cg.scal, true)) return rc;
   if (int rc = dev_alloc(s, 8, &cg.stats, true)) return rc;
   // ---- point-triangle contact pipeline (Solver.cpp:680-875) ------------------------------------------------
