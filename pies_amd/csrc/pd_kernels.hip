@@ -715,15 +715,18 @@ template <int LPR> PIES_DEV void row_combine(float& sx, float& sy, float& sz) {
 }
 
 // r = f - (K + C) x ; z = D^-1 r ; partB = {rz, rr} ; partI = {bb}.   LPR lanes per row (sliced ELL, see CgArrays).
-// prevPartB != nullptr: block 0 first closes the previous solve's statistics (its scal[] entries are still intact:
+// prevPartB != nullptr: an extra block closes the previous solve's statistics (its scal[] entries are still intact:
 // this solve's k_cg_ap(0) is the first kernel to overwrite them).
 template <int LPR>
 __global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __restrict__ x, const float4* __restrict__ f,
                                                     const float* __restrict__ prevPartB) {
-  if (prevPartB && blockIdx.x == 0) solve_statistics(A, prevPartB);
-  if (blockIdx.x == 0 && threadIdx.x == 0) A.scal[10] = 0.0f;  // this solve has not converged yet (read by k_cg_ap / k_cg_update)
+  if (blockIdx.x == A.nparts) {  // one block behind the SpMV blocks: bookkeeping only (inside block 0 it delayed that block's rows by 2-3 us)
+    if (prevPartB) solve_statistics(A, prevPartB);
+    if (threadIdx.x == 0) A.scal[10] = 0.0f;  // this solve has not converged yet (read by k_cg_ap / k_cg_update)
+    return;
+  }
   const uint32_t lane = threadIdx.x & 63u;
-  const SliceSweep sw = slice_sweep<LPR>(A.n, gridDim.x);
+  const SliceSweep sw = slice_sweep<LPR>(A.n, A.nparts);
   float acc9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t sl = sw.begin; sl < sw.end; sl += sw.step) {
     const uint32_t i = sl * (64u / LPR) + lane / LPR;
@@ -1084,10 +1087,11 @@ void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, i
   // every solve of a substep runs the same number of iterations, so the previous solve left its final partials here
   if (rows) hipLaunchKernelGGL(k_contact_rows, dim3(256), block, 0, st, A, nd.pos);
   const float* prevB = first ? nullptr : pb[maxIters & 1];
-  if (A.lanesPerRow == 4) hipLaunchKernelGGL(k_cg_init<4>, grid, block, 0, st, A, nd.pos, pd.rhs, prevB);
-  else if (A.lanesPerRow == 2) hipLaunchKernelGGL(k_cg_init<2>, grid, block, 0, st, A, nd.pos, pd.rhs, prevB);
-  else if (A.lanesPerRow == 8) hipLaunchKernelGGL(k_cg_init<8>, grid, block, 0, st, A, nd.pos, pd.rhs, prevB);
-  else hipLaunchKernelGGL(k_cg_init<1>, grid, block, 0, st, A, nd.pos, pd.rhs, prevB);
+  const dim3 igrid(A.nparts + 1u);  // k_cg_init: SpMV blocks + the bookkeeping block
+  if (A.lanesPerRow == 4) hipLaunchKernelGGL(k_cg_init<4>, igrid, block, 0, st, A, nd.pos, pd.rhs, prevB);
+  else if (A.lanesPerRow == 2) hipLaunchKernelGGL(k_cg_init<2>, igrid, block, 0, st, A, nd.pos, pd.rhs, prevB);
+  else if (A.lanesPerRow == 8) hipLaunchKernelGGL(k_cg_init<8>, igrid, block, 0, st, A, nd.pos, pd.rhs, prevB);
+  else hipLaunchKernelGGL(k_cg_init<1>, igrid, block, 0, st, A, nd.pos, pd.rhs, prevB);
   for (int k = 0; k < maxIters; ++k) {
     A.partB = pb[k & 1];       // residual partials of iteration k (k = 0 reads partI instead)
     A.partBnext = pb[(k + 1) & 1];
