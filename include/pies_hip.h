@@ -176,7 +176,8 @@ int pies_set_schedule(pies_solver_t* s, int schedule);
  * coordinate column, max_iters the upper bound of CG iterations per solve (defaults 3e-7, 128; the captured graph
  * holds as many as the recent solves needed plus one or two). */
 int pies_set_pcg(pies_solver_t* s, float rel_tol, uint32_t max_iters);
-/* Over the last tick: largest ||r||/||rhs|| left by any solve, most CG iterations any solve used, solves run. */
+/* Over the last pies_tick, or over the pies_tick_async calls since the last synchronisation: largest ||r||/||rhs|| left by
+ * any solve, most CG iterations any solve used, solves run. */
 int pies_get_pcg_stats(pies_solver_t* s, float* max_rel_residual, uint32_t* max_iters_used, uint32_t* solves);
 /* The reference's global step is exact (Solver.cpp:356).  pies_tick therefore does not keep a substep in which a solve
  * ended above rel_tol: the substep's input is restored and it runs again with four times the captured CG budget, up to
@@ -196,7 +197,9 @@ int pies_finalize(pies_solver_t* s);
 /* Solver::tick (Solver.cpp:25-38): timeSubsteps substeps of tickPBD / tickPD, then positions are copied
  * back so that pies_read_nodes / Solver::getVertices are current (Solver.cpp:157,393).  No-op once failed. */
 int pies_tick(pies_solver_t* s);
-/* Same work, but neither the host copy-back nor a stream synchronisation: state stays in HBM. */
+/* Same work, but neither the host copy-back nor a stream synchronisation: state stays in HBM.  (Projective Dynamics: the
+ * captured CG budget can only follow the solves at a host synchronisation, so every 16th call without one in between
+ * synchronises first.) */
 int pies_tick_async(pies_solver_t* s);
 /* Waits for the queued ticks, then latches a device-side failure (pies_failed) and adapts the CG budget. */
 int pies_synchronize(pies_solver_t* s);

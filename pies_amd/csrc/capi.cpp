@@ -494,9 +494,10 @@ static int capture_graph(pies_solver* s) {
 
 // The graph holds a fixed number of CG iterations per solve (converged solves early-exit the rest).  At
 // every host synchronisation the budget follows what the solves needed: it starts at 32, shrinks to (most
-// iterations used over the last 8+ synchronisations) + 2, to + 1 after 24, and quadruples (at least 32, at most
-// pcgMaxIters = 128 by default) when a solve ran out of iterations above the tolerance.
+// iterations used over the last 8+ synchronisations) + a third of that (at least 2), + a quarter (at least 1) after 24,
+// and quadruples (at least 32, at most pcgMaxIters = 128 by default) when a solve ran out of iterations above the tolerance.
 static int adapt_pcg_budget(pies_solver* s) {
+  s->asyncSinceSync = 0;  // (called right after a host synchronisation)
   if (s->opt.solver != PIES_SOLVER_PD || !s->pd.cg.stats || !s->graphExec || s->sceneDirty || under_profiler()) return PIES_OK;
   float st[4] = {0, 0, 0, 0};
   HIP_TRY(s, hipMemcpyAsync(st, s->pd.cg.stats, sizeof(st), hipMemcpyDeviceToHost, s->stream));
@@ -507,11 +508,12 @@ static int adapt_pcg_budget(pies_solver* s) {
   uint32_t budget = s->pcgBudget;
   if (!converged && budget < s->pcgMaxIters) {
     // a solve ran out of iterations above the tolerance (new contacts stiffen the system at once): back to the full
-    // budget now - the reference's solve is a direct one - and no shrinking for the next 60 synchronisations
+    // budget now - the reference's solve is a direct one - and no shrinking for the next 24 synchronisations (a converged
+    // solve's unused captured iterations return on one flag word: a generous budget costs 2.5 us per unused launch)
     budget = std::min(s->pcgMaxIters, std::max(32u, 4u * budget));  // 2..8 -> 32 -> 128: at most two short substeps
     s->pcgCalm = 0;
     s->pcgWindowMax = 0;
-    s->pcgCooldown = 60;
+    s->pcgCooldown = 24;
   } else if (s->pcgCooldown > 0) {
     --s->pcgCooldown;
   } else if (converged) {
@@ -519,9 +521,13 @@ static int adapt_pcg_budget(pies_solver* s) {
     s->pcgWindowMax = std::max(s->pcgWindowMax, used);
     ++s->pcgCalm;
     bool restart = false;
-    if (s->pcgCalm >= 8 && s->pcgWindowMax + 2 < budget) { budget = s->pcgWindowMax + 2; restart = true; }  // two spare iterations ...
-    else if (s->pcgCalm >= 24) {                                                                          // ... one after a long calm
-      if (s->pcgWindowMax + 1 < budget) budget = s->pcgWindowMax + 1;
+    // spare iterations on top of the most any solve of the window used: a third of it (at least two) after 8 calm
+    // synchronisations, a quarter (at least one) after 24.  (Round 2 took + 2 / + 1 flat: a contact patch whose solves use
+    // 5-8 iterations then sat at 8 and ran short on the next fluctuation - back to 32 for 60 frames.)
+    const uint32_t spare8 = std::max(2u, (s->pcgWindowMax + 2u) / 3u), spare24 = std::max(1u, (s->pcgWindowMax + 3u) / 4u);
+    if (s->pcgCalm >= 8 && s->pcgWindowMax + spare8 < budget) { budget = s->pcgWindowMax + spare8; restart = true; }
+    else if (s->pcgCalm >= 24) {
+      if (s->pcgWindowMax + spare24 < budget) budget = s->pcgWindowMax + spare24;
       restart = true;  // the window never looks back further than 24 synchronisations
     }
     if (restart) { s->pcgCalm = 0; s->pcgWindowMax = 0; }
@@ -1056,9 +1062,18 @@ int pies_tick_async(pies_solver_t* s) {
   if (int rc = ensure_ready(s)) return rc;
   if (s->nd.n == 0) return PIES_OK;
   if (s->opt.solver == PIES_SOLVER_PD) {
+    // The captured CG budget can only follow the solves at a host synchronisation.  A caller that queues tick after tick
+    // without one gets one here every 16 ticks (the queue drains once, ~50 us of idle device): measured without it, 150
+    // queued ticks of a contact scene whose budget had settled at 8 ran short when the contacts re-bound (14 iterations
+    // needed), the unconverged positions fed the next tick, and the simulation ended in the failure latch.
+    if (s->asyncSinceSync >= 16) {
+      if (int rc = pies_synchronize(s)) return rc;
+      if (s->simFailed) return PIES_OK;
+    }
+    ++s->asyncSinceSync;
     if (s->goalDirty)
       if (int rc = pd_upload_goals(s)) return rc;
-    HIP_TRY(s, hipMemsetAsync(s->pd.cg.stats, 0, 4 * sizeof(float), s->stream));
+    if (s->asyncSinceSync == 1) HIP_TRY(s, hipMemsetAsync(s->pd.cg.stats, 0, 4 * sizeof(float), s->stream));
   }
   for (uint32_t sub = 0; sub < s->opt.timeSubsteps; ++sub)
     if (int rc = launch_substep(s)) return rc;
@@ -1072,6 +1087,7 @@ int pies_synchronize(pies_solver_t* s) {
   if (s->device == PIES_DEVICE_NONE) return PIES_OK;
   HIP_TRY(s, hipSetDevice(s->device));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
+  s->asyncSinceSync = 0;
   if (int rc = poll_failure(s)) return rc;  // a loop of pies_tick_async learns here that the simulation failed
   return adapt_pcg_budget(s);
 }
@@ -1111,7 +1127,7 @@ static int pd_tick_checked(pies_solver* s) {
       s->pcgBudget = std::min(s->pcgMaxIters, std::max(32u, 4u * s->pcgBudget));
       s->pcgCalm = 0;
       s->pcgWindowMax = 0;
-      s->pcgCooldown = 60;
+      s->pcgCooldown = 24;
       ++s->pcgRetries;
       if (const char* e = std::getenv("PIES_PCG_DEBUG"); e && e[0] == '1')
         std::fprintf(stderr, "[pies] pcg: substep ran short (residual^2 %.3g): again with budget %u\n", after[0], s->pcgBudget);

@@ -153,6 +153,7 @@ struct pies_solver {
                                      // sequential passes at the end of the substep) are computed beside the local/global iterations
   hipEvent_t evFork = nullptr, evJoin = nullptr;
   bool triLevelsForked = true;
+  uint32_t asyncSinceSync = 0;  // PD ticks queued by pies_tick_async since the last host synchronisation
   std::string error;
 
   bool releaseHinge = false;
