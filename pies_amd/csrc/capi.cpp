@@ -439,7 +439,8 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
       const bool probed = s->probe && (s->probe->kernel == PIES_KERNEL_PD_SPMV || s->probe->kernel == PIES_KERNEL_PD_CG_UPDATE);
       // a probed solve never takes the converged early exit: every bracketed launch does a full SpMV / vector update
       launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, s->pcgTol, -1, it == 0, it + 1 == s->opt.iterations, probed,
-                      probed ? [](void* ctx, int cls) { probe_mark(static_cast<pies_solver*>(ctx), cls); } : (void (*)(void*, int))nullptr, s);
+                      probed ? [](void* ctx, int cls) { probe_mark(static_cast<pies_solver*>(ctx), cls); } : (void (*)(void*, int))nullptr, s,
+                      s->pcgOverflow ? (int)(s->pcgMaxIters > s->pcgBudget ? s->pcgMaxIters - s->pcgBudget : 0u) : 0);
       if (probed && units) *units += (uint64_t)s->nd.n * s->pcgBudget;
     }
     else if (only == PIES_KERNEL_PD_SPMV) { launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, 0.f, 1); U((uint64_t)s->nd.n * s->pcgBudget); }
@@ -499,6 +500,7 @@ static int capture_graph(pies_solver* s) {
 static int adapt_pcg_budget(pies_solver* s) {
   s->asyncSinceSync = 0;  // (called right after a host synchronisation)
   if (s->opt.solver != PIES_SOLVER_PD || !s->pd.cg.stats || !s->graphExec || s->sceneDirty || under_profiler()) return PIES_OK;
+  if (s->pcgPinned) return PIES_OK;  // PIES_PCG_BUDGET: tests of the overflow path keep the captured budget where they put it
   float st[4] = {0, 0, 0, 0};
   HIP_TRY(s, hipMemcpyAsync(st, s->pd.cg.stats, sizeof(st), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
@@ -514,6 +516,12 @@ static int adapt_pcg_budget(pies_solver* s) {
     s->pcgCalm = 0;
     s->pcgWindowMax = 0;
     s->pcgCooldown = 24;
+  } else if (used > budget) {
+    // converged, but only because the last launch went on alone (cg_overflow, one workgroup): capture what it needed
+    budget = std::min(s->pcgMaxIters, used + std::max(2u, (used + 2u) / 3u));
+    s->pcgCalm = 0;
+    s->pcgWindowMax = 0;
+    s->pcgCooldown = 8;
   } else if (s->pcgCooldown > 0) {
     --s->pcgCooldown;
   } else if (converged) {
@@ -606,6 +614,11 @@ void pies_default_options(pies_options_t* o) {
 
 // PIES_SCHEDULE overrides PIES_SCHEDULE_DEFAULT for new handles (not an explicit pies_set_schedule)
 static void apply_schedule_environment(pies_solver* s) {
+  if (const char* e = std::getenv("PIES_PCG_OVERFLOW")) s->pcgOverflow = e[0] != '0';
+  if (const char* e = std::getenv("PIES_PCG_BUDGET")) {  // diagnostics: the captured CG iterations, never adapted
+    const int v = std::atoi(e);
+    if (v >= 1 && v <= 4096) { s->pcgPinned = true; s->pcgPinnedBudget = static_cast<uint32_t>(v); s->pcgBudget = std::min(s->pcgMaxIters, s->pcgPinnedBudget); }
+  }
   if (const char* e = std::getenv("PIES_SCHEDULE")) {
     if (!std::strcmp(e, "exact")) s->schedule = PIES_SCHEDULE_EXACT;
     else if (!std::strcmp(e, "coloured")) s->schedule = PIES_SCHEDULE_COLOURED;
@@ -748,7 +761,7 @@ int pies_set_pcg(pies_solver_t* s, float rel_tol, uint32_t max_iters) {
   if (rel_tol != s->pcgTol || max_iters != s->pcgMaxIters) {
     s->pcgTol = rel_tol;
     s->pcgMaxIters = max_iters;
-    s->pcgBudget = std::min(max_iters, 32u);
+    s->pcgBudget = std::min(max_iters, s->pcgPinned ? s->pcgPinnedBudget : 32u);
     s->graphDirty = true;  // the captured launch sequence changes, nothing else
   }
   return PIES_OK;
@@ -1112,7 +1125,7 @@ static int pd_tick_checked(pies_solver* s) {
       HIP_TRY(s, hipMemcpyAsync(after, s->pd.cg.stats, sizeof(after), hipMemcpyDeviceToHost, s->stream));
       HIP_TRY(s, hipStreamSynchronize(s->stream));
       const bool ranShort = after[3] > before[3];
-      if (!ranShort || s->pcgBudget >= s->pcgMaxIters) {
+      if (!ranShort || s->pcgBudget >= s->pcgMaxIters || s->pcgPinned) {
         if (ranShort) s->pcgShortSolves += static_cast<uint64_t>(after[3] - before[3]);
         break;
       }

@@ -641,7 +641,10 @@ PIES_DEV void solve_statistics(const CgArrays& A, const float* __restrict__ prev
   // (scal[10] = 1, scal[11] = 0: partI, 1 / 2: the ping-pong pair); otherwise the last k_cg_update wrote prevPartB
   const bool done = A.scal[10] != 0.0f;
   const int where = static_cast<int>(A.scal[11]);
-  if (done && where == 0) block_reduce_partials<6>(A.partI, 9, A.nparts, red);
+  if (A.scal[10] == 2.0f) {  // the solve went on in cg_overflow: its final ||r||^2 per column is in scal[12..14]
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { red[c] = 0.0f; red[3 + c] = A.scal[12 + c]; }
+  } else if (done && where == 0) block_reduce_partials<6>(A.partI, 9, A.nparts, red);
   else block_reduce_partials<6>(done ? (where == 1 ? A.partB0 : A.partB1) : prevPartB, 6, A.nparts, red);
   if (threadIdx.x == 0) {
     float worst = 0.f;
@@ -898,8 +901,108 @@ template <int LPR> __global__ void __launch_bounds__(kBlock) k_cg_ap(CgArrays A,
   block_write_partial<3>(acc, A.partA, 3);
 }
 
-// alpha = rz_k / pAp ; x += alpha p ; r -= alpha Ap ; z = D^-1 r ; partB = {rz_{k+1}, rr_{k+1}}
-__global__ void __launch_bounds__(kBlock) k_cg_update(CgArrays A, float4* __restrict__ x, int k, float tol2) {
+// sums over the workgroup (every thread gets the totals); NV values
+template <int NV> PIES_DEV void block_sum(float v[NV]) {
+  __shared__ float lds[kBlock / 64][NV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+    for (int q = 0; q < NV; ++q) v[q] += __shfl_xor(v[q], off, 64);
+  __syncthreads();  // (the previous use of lds[] has been read)
+  if (lane == 0)
+#pragma unroll
+    for (int q = 0; q < NV; ++q) lds[wave][q] = v[q];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    float t = lds[0][q];
+    for (int w = 1; w < kBlock / 64; ++w) t += lds[w][q];
+    v[q] = t;
+  }
+}
+
+// The captured iterations of a solve are over and it is still above the tolerance (new contacts stiffened the system
+// since the budget was chosen, and the host has not looked yet): the LAST workgroup of the last k_cg_update to finish goes
+// on alone - plain CG, one workgroup, workgroup barriers instead of kernel boundaries, the contact rows summed lane by
+// lane - until the solve converges or pies_set_pcg's ceiling is reached.  Slow (a single CU: ~0.3 ms per iteration at
+// 125k rows) and rare: it only runs until the next host synchronisation raises the captured budget, and it means that a
+// queue of pies_tick_async calls never feeds an unconverged solve into the next substep.  k0 = iterations done so far.
+PIES_DEV void cg_overflow(const CgArrays& A, float4* __restrict__ x, int k0, int extra, float tol2) {
+  if (A.lanesPerRow != 1u || extra <= 0) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t nslices = (A.n + 63u) / 64u;
+  float red[6];
+  block_reduce_partials<6>(A.partBnext, 6, A.nparts, red);
+  float rz[3] = {red[0], red[1], red[2]}, rr[3] = {red[3], red[4], red[5]}, rzOld[3], bb[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { rzOld[c] = A.scal[3 * ((k0 - 1) & 1) + c]; bb[c] = A.scal[6 + c]; }
+  int k = k0;
+  for (; k < k0 + extra; ++k) {
+    if (all_converged(rr, bb, tol2)) break;
+    float beta[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) beta[c] = rzOld[c] > 0.0f ? rz[c] / rzOld[c] : 0.0f;
+    const float4* __restrict__ pold = A.p[(k + 1) & 1];
+    float4* __restrict__ pnew = A.p[k & 1];
+    for (uint32_t i = tid; i < A.n; i += kBlock) {
+      const float4 zi = A.z[i], pi = pold[i];
+      pnew[i] = make_float4(fmaf(beta[0], pi.x, zi.x), fmaf(beta[1], pi.y, zi.y), fmaf(beta[2], pi.z, zi.z), 0.f);
+    }
+    __syncthreads();
+    float acc[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t sl = wave; sl < nslices; sl += kBlock / 64) {
+      const uint32_t i = sl * 64u + lane;
+      const uint32_t off = A.sliceOff[sl], width = (A.sliceOff[sl + 1] - off) >> 6;
+      float sx = 0.f, sy = 0.f, sz = 0.f;
+      for (uint32_t kk = 0; kk < width; ++kk) {
+        const uint32_t at = off + (kk << 6) + lane;
+        const float a = A.val[at];
+        const float4 pj = pnew[A.col[at]];
+        sx = fmaf(a, pj.x, sx); sy = fmaf(a, pj.y, sy); sz = fmaf(a, pj.z, sz);
+      }
+      if (i < A.n) {
+        contact_row(A, i, [&](uint32_t j, float& qx, float& qy, float& qz) { const float4 v = pnew[j]; qx = v.x; qy = v.y; qz = v.z; }, sx, sy, sz);
+        const float4 pi = pnew[i];
+        const float cd = A.cdiag[i];
+        const float ax = fmaf(cd, pi.x, sx), ay = fmaf(cd, pi.y, sy), az = fmaf(cd, pi.z, sz);
+        A.ap[i] = make_float4(ax, ay, az, 0.f);
+        acc[0] += pi.x * ax; acc[1] += pi.y * ay; acc[2] += pi.z * az;
+      }
+    }
+    block_sum<3>(acc);
+    float alpha[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) alpha[c] = acc[c] > 0.0f ? rz[c] / acc[c] : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) acc[c] = 0.0f;
+    for (uint32_t i = tid; i < A.n; i += kBlock) {
+      const float4 pi = pnew[i], api = A.ap[i];
+      float4 xi = x[i], ri = A.r[i];
+      xi.x = fmaf(alpha[0], pi.x, xi.x); xi.y = fmaf(alpha[1], pi.y, xi.y); xi.z = fmaf(alpha[2], pi.z, xi.z);
+      ri.x = fmaf(-alpha[0], api.x, ri.x); ri.y = fmaf(-alpha[1], api.y, ri.y); ri.z = fmaf(-alpha[2], api.z, ri.z);
+      const float di = A.dinv[i];
+      const float zx = di * ri.x, zy = di * ri.y, zz = di * ri.z;
+      x[i] = xi;
+      A.r[i] = ri;
+      A.z[i] = make_float4(zx, zy, zz, 0.f);
+      acc[0] += ri.x * zx; acc[1] += ri.y * zy; acc[2] += ri.z * zz;
+      acc[3] += ri.x * ri.x; acc[4] += ri.y * ri.y; acc[5] += ri.z * ri.z;
+    }
+    block_sum<6>(acc);  // (its barriers also order this pass's stores before the next pass's loads)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { rzOld[c] = rz[c]; rz[c] = acc[c]; rr[c] = acc[3 + c]; }
+  }
+  if (tid == 0) {
+    A.scal[9] = static_cast<float>(k);
+    A.scal[12] = rr[0]; A.scal[13] = rr[1]; A.scal[14] = rr[2];
+    A.scal[10] = 2.0f;
+  }
+}
+
+// alpha = rz_k / pAp ; x += alpha p ; r -= alpha Ap ; z = D^-1 r ; partB = {rz_{k+1}, rr_{k+1}}.  overflow > 0: this is the
+// solve's last captured iteration and up to `overflow` more may follow inside this launch (cg_overflow).
+__global__ void __launch_bounds__(kBlock) k_cg_update(CgArrays A, float4* __restrict__ x, int k, float tol2, int overflow) {
   if (A.scal[10] != 0.0f) return;  // (see k_cg_ap)
   float red[9];
   float rr[3], bb[3];
@@ -953,6 +1056,17 @@ __global__ void __launch_bounds__(kBlock) k_cg_update(CgArrays A, float4* __rest
     acc[3] += ri.x * ri.x; acc[4] += ri.y * ri.y; acc[5] += ri.z * ri.z;
   }
   block_write_partial<6>(acc, A.partBnext, 6);
+  if (overflow > 0) {
+    __shared__ uint32_t sLast;
+    __threadfence();  // this block's x, r, z and partials are visible before it takes its ticket
+    if (threadIdx.x == 0) sLast = atomicAdd(A.ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (sLast) {
+      if (threadIdx.x == 0) *A.ticket = 0u;
+      __threadfence();
+      cg_overflow(A, x, k + 1, overflow, tol2);
+    }
+  }
 }
 
 // end of the last solve of a substep: its statistics
@@ -1062,7 +1176,7 @@ void launch_pd_local_shape(hipStream_t st, const float4* pos, const PdArrays& pd
   hipLaunchKernelGGL(k_pd_local_shape, dim3(pd.shape.count), dim3(kBlock), 0, st, pos, pd.shape, pd.contribD);
 }
 void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, int maxIters, float tol, int part, bool first, bool last,
-                     bool neverExit, void (*hook)(void*, int), void* hookCtx) {
+                     bool neverExit, void (*hook)(void*, int), void* hookCtx, int overflowIters) {
   if (nd.n == 0) return;
   CgArrays A = pd.cg;
   const dim3 grid(A.nparts), block(kBlock);
@@ -1077,7 +1191,7 @@ void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, i
         else if (A.lanesPerRow == 8) hipLaunchKernelGGL(k_cg_ap<8>, agrid, block, 0, st, A, k, -1.0f);
         else hipLaunchKernelGGL(k_cg_ap<1>, agrid, block, 0, st, A, k, -1.0f);
       }
-      else hipLaunchKernelGGL(k_cg_update, grid, block, 0, st, A, nd.pos, k, -1.0f);
+      else hipLaunchKernelGGL(k_cg_update, grid, block, 0, st, A, nd.pos, k, -1.0f, 0);
     }
     return;
   }
@@ -1101,7 +1215,7 @@ void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, i
     else if (A.lanesPerRow == 8) hipLaunchKernelGGL(k_cg_ap<8>, agrid, block, 0, st, A, k, tol2);
     else hipLaunchKernelGGL(k_cg_ap<1>, agrid, block, 0, st, A, k, tol2);
     if (hook) { hook(hookCtx, 14); hook(hookCtx, 15); }  // PIES_KERNEL_PD_CG_UPDATE
-    hipLaunchKernelGGL(k_cg_update, grid, block, 0, st, A, nd.pos, k, tol2);
+    hipLaunchKernelGGL(k_cg_update, grid, block, 0, st, A, nd.pos, k, tol2, k + 1 == maxIters && !neverExit ? overflowIters : 0);
     if (hook) hook(hookCtx, 15);
   }
   if (!last) return;

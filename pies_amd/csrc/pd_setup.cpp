@@ -227,6 +227,7 @@ int pd_build(pies_solver* s) {
   cg.partB0 = cg.partB;
   cg.partB1 = cg.partBnext;
   if (int rc = dev_alloc(s, 16, &cg.scal, true)) return rc;
+  if (int rc = dev_alloc(s, 1, &cg.ticket, true)) return rc;
   if (int rc = dev_alloc(s, 8, &cg.stats, true)) return rc;
   // ---- point-triangle contact pipeline (Solver.cpp:680-875) ------------------------------------------------
   pd.tri = TriArrays{};

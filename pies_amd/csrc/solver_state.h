@@ -153,6 +153,9 @@ struct pies_solver {
                                      // sequential passes at the end of the substep) are computed beside the local/global iterations
   hipEvent_t evFork = nullptr, evJoin = nullptr;
   bool triLevelsForked = true;
+  bool pcgOverflow = true;      // a solve above the tolerance after its captured iterations goes on inside the last launch (PIES_PCG_OVERFLOW=0: off)
+  bool pcgPinned = false;       // PIES_PCG_BUDGET
+  uint32_t pcgPinnedBudget = 32;
   uint32_t asyncSinceSync = 0;  // PD ticks queued by pies_tick_async since the last host synchronisation
   std::string error;
 

@@ -140,6 +140,33 @@ def test_sequential_passes_on_the_lds_copy_equal_the_l2_path_bit_for_bit(pies, m
             assert np.array_equal(x[k], y[k]), (t, k)
 
 
+def test_two_captured_iterations_and_the_rest_in_the_last_launch(pies, oracle, monkeypatch):
+    """PIES_PCG_BUDGET=2 pins the captured CG iterations at two; thousands of w = 1e4 contacts need 8-14.  The last captured
+    launch goes on alone (cg_overflow: one workgroup, contact rows summed lane by lane) and the substeps still meet the
+    tolerance and stay with the oracle's direct solves."""
+    monkeypatch.setenv("PIES_PCG_BUDGET", "2")
+    g = pies.Solver(pd_options(pies, 3))
+    o = oracle.OracleSolver(pd_options(oracle, 3))
+    for s in (g, o):
+        s.create_tet_box(14, 2, 20, translation=(0, 0.02, 0), w=1.0)
+        s.create_tet_box(12, 2, 18, translation=(0.37, 1.05, 0.41), w=1.0)
+        v = s.velocities
+        v[14 * 2 * 20:, 1] = -1.5
+        s.set_velocities(v)
+        s.set_prev_positions(s.positions)
+    tol = 2.0 * tol_for(o.positions)
+    most = 0
+    for t in range(3):
+        sync_state(g, o)
+        g.tick(); o.tick()
+        assert np.array_equal(g.tri_collisions, o.tri_collisions), t
+        res, iters_used, solves = g.pcg_stats()
+        most = max(most, iters_used)
+        assert g.pcg_health()["budget"] == 2 and res <= 3e-7 * 1.0001, (t, res, iters_used)
+        assert np.abs(g.positions - o.positions).max() <= tol, t
+    assert most > 4 and g.pcg_health()["short_solves"] == 0 and not g.failed
+
+
 def test_patch_wider_than_the_lds_copy_takes_the_l2_path(pies, oracle, monkeypatch):
     """Two 52x52 plates: more than 4096 nodes take part in contacts, so the sequential passes cannot run on an LDS copy and
     the level kernel takes the chunked relaxation (the automatic choice, no switch set).  One teacher-forced tick against
