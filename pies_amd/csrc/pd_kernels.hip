@@ -9,8 +9,10 @@
 //                atomics: interleaved partial sums combined pairwise - deterministic, not the reference's term order
 //   global step  Jacobi-preconditioned CG on (K + C) x = rhs for the 3 coordinate columns at once; K in sliced ELL
 //                form (one row per lane, 64 rows per slice); the reference factors K + C with a sparse Cholesky every
-//                substep (Solver.cpp:258-262,356) -- CG to a relative residual replaces the direct solve, and a substep
-//                whose solve ends above it is run again by pies_tick (capi.cpp)
+//                substep (Solver.cpp:258-262,356) -- CG to a relative residual replaces the direct solve; the graph holds a
+//                budget of iterations per solve, a converged solve's remaining launches return on one flag word, a solve
+//                that needs more goes on inside its last launch (cg_overflow), and a substep whose solve still ends above
+//                the tolerance is run again by pies_tick (capi.cpp)
 //   velocity     v = (1-d)(pos-prev)/h + h f/m ; prev = pos ; floor friction
 //
 // Everything here is bandwidth/latency bound (gathers, streams, SpMV at ~15 nnz/row, 3x3 algebra): no MFMA.

@@ -11,9 +11,10 @@
 //              along the triangle normal, w = 1e4; its 4x4 block is added to the system matrix through a
 //              per-node list of contacts (diagonal into cdiag, off-diagonals applied inside the SpMV).
 //   sequential parts (stabilisation :367-383 via CollisionConstraint.cpp:126-162, friction Solver.cpp:431-471)
-//              are order dependent Gauss-Seidel passes over the contact list.  They run in ONE wavefront that
-//              takes 64 contacts at a time, finds the dependency levels inside the window (two contacts
-//              conflict when they share a node) and executes level after level -- the sequential result.
+//              are order dependent Gauss-Seidel passes over the contact list.  They run level by level of the list's
+//              dependency DAG (two contacts conflict when they share a node; k_tri_levels) - the sequential result -
+//              on an LDS copy of the touched nodes when these fit, through L2 otherwise; lists with more than
+//              kTriMaxLevels levels are walked by one wavefront, 64 contacts at a time.
 #include <cstdint>
 #include <cstdlib>
 
