@@ -40,9 +40,9 @@ struct CgArrays {
   const uint32_t* tUsedCount;  // how many (device counter)
   float4* cAp;
   int useCAp;
-  float* scal;   // rz[2][3], bb[3], iterations, [10] the solve has converged (2: inside cg_overflow), [11] where its final residual
-                 // partials are, [12..14] final ||r||^2 per column after cg_overflow
-  uint32_t* ticket;  // last-workgroup-done counter of the solve's last k_cg_update
+  float* scal;   // rz[2][3], bb[3], iterations, [10] the solve is over (converged, or went on inside its last launch), [11] where
+                 // its final residual partials are
+  uint32_t* ticket;  // grid barrier counter of the solve's last k_cg_update (zeroed by k_cg_init)
   float* stats;  // over the tick: [0] max relative residual^2 of its solves, [1] max iterations, [2] solves, [3] solves that ended
                  // above the tolerance; since the buffers were built: [4] solves above the tolerance, [5] solves
   float tol2;    // squared relative tolerance of the solve whose statistics are being closed
@@ -97,8 +97,8 @@ void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd);
 // kernel, the last one's by a launch of its own)
 // neverExit: the iterations do not take the converged early exit (in-situ timing); hook(ctx, class) is called before and
 // after every k_cg_ap (PIES_KERNEL_PD_SPMV) and k_cg_update (PIES_KERNEL_PD_CG_UPDATE) launch; overflowIters: iterations a
-// solve that is still above the tolerance after its maxIters captured ones may go on for inside the last launch (one
-// workgroup, see cg_overflow)
+// solve that is still above the tolerance after its maxIters captured ones may go on for inside the last launch (see
+// k_cg_update)
 void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, int maxIters, float tol, int part = -1, bool first = true,
                      bool last = true, bool neverExit = false, void (*hook)(void*, int) = nullptr, void* hookCtx = nullptr,
                      int overflowIters = 0);

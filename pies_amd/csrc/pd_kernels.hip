@@ -11,7 +11,7 @@
 //                form (one row per lane, 64 rows per slice); the reference factors K + C with a sparse Cholesky every
 //                substep (Solver.cpp:258-262,356) -- CG to a relative residual replaces the direct solve; the graph holds a
 //                budget of iterations per solve, a converged solve's remaining launches return on one flag word, a solve
-//                that needs more goes on inside its last launch (cg_overflow), and a substep whose solve still ends above
+//                that needs more goes on inside its last launch (k_cg_update, grid barriers), and a substep whose solve still ends above
 //                the tolerance is run again by pies_tick (capi.cpp)
 //   velocity     v = (1-d)(pos-prev)/h + h f/m ; prev = pos ; floor friction
 //
@@ -643,10 +643,7 @@ PIES_DEV void solve_statistics(const CgArrays& A, const float* __restrict__ prev
   // (scal[10] = 1, scal[11] = 0: partI, 1 / 2: the ping-pong pair); otherwise the last k_cg_update wrote prevPartB
   const bool done = A.scal[10] != 0.0f;
   const int where = static_cast<int>(A.scal[11]);
-  if (A.scal[10] == 2.0f) {  // the solve went on in cg_overflow: its final ||r||^2 per column is in scal[12..14]
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { red[c] = 0.0f; red[3 + c] = A.scal[12 + c]; }
-  } else if (done && where == 0) block_reduce_partials<6>(A.partI, 9, A.nparts, red);
+  if (done && where == 0) block_reduce_partials<6>(A.partI, 9, A.nparts, red);
   else block_reduce_partials<6>(done ? (where == 1 ? A.partB0 : A.partB1) : prevPartB, 6, A.nparts, red);
   if (threadIdx.x == 0) {
     float worst = 0.f;
@@ -727,7 +724,10 @@ __global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __
                                                     const float* __restrict__ prevPartB) {
   if (blockIdx.x == A.nparts) {  // one block behind the SpMV blocks: bookkeeping only (inside block 0 it delayed that block's rows by 2-3 us)
     if (prevPartB) solve_statistics(A, prevPartB);
-    if (threadIdx.x == 0) A.scal[10] = 0.0f;  // this solve has not converged yet (read by k_cg_ap / k_cg_update)
+    if (threadIdx.x == 0) {
+      A.scal[10] = 0.0f;  // this solve has not converged yet (read by k_cg_ap / k_cg_update)
+      *A.ticket = 0u;     // grid barrier counter of the solve's last k_cg_update
+    }
     return;
   }
   const uint32_t lane = threadIdx.x & 63u;
@@ -767,6 +767,70 @@ __global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __
     }
   }
   block_write_partial<9>(acc9, A.partI, 9);
+}
+
+// The SpMV rows of iteration k for this workgroup's slices: p = z + beta p_old (written), Ap = (K + C) p (written; the contact
+// part only when inlineContacts, i.e. summed by the row's lane), acc += p.Ap.
+template <int LPR> PIES_DEV void cg_ap_rows(const CgArrays& A, int k, const float beta[3], bool inlineContacts, float acc[3]) {
+  const float4* __restrict__ pold = A.p[(k + 1) & 1];
+  float4* __restrict__ pnew = A.p[k & 1];
+  const uint32_t lane = threadIdx.x & 63u;
+  const SliceSweep sw = slice_sweep<LPR>(A.n, A.nparts);
+  for (uint32_t sl = sw.begin; sl < sw.end; sl += sw.step) {
+    const uint32_t i = sl * (64u / LPR) + lane / LPR;
+    const uint32_t off = A.sliceOff[sl], width = (A.sliceOff[sl + 1] - off) >> 6;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    if (k > 0) {
+#pragma unroll 4
+      for (uint32_t kk = 0; kk < width; ++kk) {
+        const uint32_t at = off + (kk << 6) + lane;
+        const float a = A.val[at];
+        const uint32_t j = A.col[at];
+        const float4 zj = A.z[j], pj = pold[j];
+        sx = fmaf(a, fmaf(beta[0], pj.x, zj.x), sx);
+        sy = fmaf(a, fmaf(beta[1], pj.y, zj.y), sy);
+        sz = fmaf(a, fmaf(beta[2], pj.z, zj.z), sz);
+      }
+    } else {
+#pragma unroll 4
+      for (uint32_t kk = 0; kk < width; ++kk) {
+        const uint32_t at = off + (kk << 6) + lane;
+        const float a = A.val[at];
+        const float4 zj = A.z[A.col[at]];
+        sx = fmaf(a, zj.x, sx);
+        sy = fmaf(a, zj.y, sy);
+        sz = fmaf(a, zj.z, sz);
+      }
+    }
+    row_combine<LPR>(sx, sy, sz);
+    if (i < A.n && lane % LPR == 0u) {
+      if (inlineContacts) {
+        contact_row(A, i, [&](uint32_t j, float& qx, float& qy, float& qz) {
+          const float4 zj = A.z[j];
+          qx = zj.x; qy = zj.y; qz = zj.z;
+          if (k > 0) {
+            const float4 pj = pold[j];
+            qx = fmaf(beta[0], pj.x, qx); qy = fmaf(beta[1], pj.y, qy); qz = fmaf(beta[2], pj.z, qz);
+          }
+        }, sx, sy, sz);
+      }
+      const float4 zi = A.z[i];
+      float px = zi.x, py = zi.y, pz = zi.z;
+      if (k > 0) {
+        const float4 pi = pold[i];
+        px = fmaf(beta[0], pi.x, px);
+        py = fmaf(beta[1], pi.y, py);
+        pz = fmaf(beta[2], pi.z, pz);
+      }
+      const float cd = A.cdiag[i];
+      const float ax = fmaf(cd, px, sx), ay = fmaf(cd, py, sy), az = fmaf(cd, pz, sz);
+      pnew[i] = make_float4(px, py, pz, 0.f);
+      A.ap[i] = make_float4(ax, ay, az, 0.f);
+      acc[0] += px * ax;
+      acc[1] += py * ay;
+      acc[2] += pz * az;
+    }
+  }
 }
 
 // iteration k:  beta = rz_k / rz_{k-1} (0 for k = 0) ; p = z + beta p_old ; Ap = (K + C) p ; partA = {pAp}
@@ -816,7 +880,6 @@ template <int LPR> __global__ void __launch_bounds__(kBlock) k_cg_ap(CgArrays A,
     A.scal[9] = static_cast<float>(k + 1);
   }
   const float4* __restrict__ pold = A.p[(k + 1) & 1];
-  float4* __restrict__ pnew = A.p[k & 1];
   const uint32_t lane = threadIdx.x & 63u;
   float acc[3] = {0, 0, 0};
   if (blockIdx.x >= A.nparts) {  // contact rows of p = z + beta p_old
@@ -844,166 +907,70 @@ template <int LPR> __global__ void __launch_bounds__(kBlock) k_cg_ap(CgArrays A,
     block_write_partial<3>(acc, A.partA, 3);
     return;
   }
-  const SliceSweep sw = slice_sweep<LPR>(A.n, A.nparts);
-  for (uint32_t sl = sw.begin; sl < sw.end; sl += sw.step) {
-    const uint32_t i = sl * (64u / LPR) + lane / LPR;
-    const uint32_t off = A.sliceOff[sl], width = (A.sliceOff[sl + 1] - off) >> 6;
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    if (k > 0) {
-#pragma unroll 4
-      for (uint32_t kk = 0; kk < width; ++kk) {
-        const uint32_t at = off + (kk << 6) + lane;
-        const float a = A.val[at];
-        const uint32_t j = A.col[at];
-        const float4 zj = A.z[j], pj = pold[j];
-        sx = fmaf(a, fmaf(beta[0], pj.x, zj.x), sx);
-        sy = fmaf(a, fmaf(beta[1], pj.y, zj.y), sy);
-        sz = fmaf(a, fmaf(beta[2], pj.z, zj.z), sz);
-      }
-    } else {
-#pragma unroll 4
-      for (uint32_t kk = 0; kk < width; ++kk) {
-        const uint32_t at = off + (kk << 6) + lane;
-        const float a = A.val[at];
-        const float4 zj = A.z[A.col[at]];
-        sx = fmaf(a, zj.x, sx);
-        sy = fmaf(a, zj.y, sy);
-        sz = fmaf(a, zj.z, sz);
-      }
-    }
-    row_combine<LPR>(sx, sy, sz);
-    if (i < A.n && lane % LPR == 0u) {
-      if (!A.useCAp) {
-        contact_row(A, i, [&](uint32_t j, float& qx, float& qy, float& qz) {
-          const float4 zj = A.z[j];
-          qx = zj.x; qy = zj.y; qz = zj.z;
-          if (k > 0) {
-            const float4 pj = pold[j];
-            qx = fmaf(beta[0], pj.x, qx); qy = fmaf(beta[1], pj.y, qy); qz = fmaf(beta[2], pj.z, qz);
-          }
-        }, sx, sy, sz);
-      }
-      const float4 zi = A.z[i];
-      float px = zi.x, py = zi.y, pz = zi.z;
-      if (k > 0) {
-        const float4 pi = pold[i];
-        px = fmaf(beta[0], pi.x, px);
-        py = fmaf(beta[1], pi.y, py);
-        pz = fmaf(beta[2], pi.z, pz);
-      }
-      const float cd = A.cdiag[i];
-      const float ax = fmaf(cd, px, sx), ay = fmaf(cd, py, sy), az = fmaf(cd, pz, sz);
-      pnew[i] = make_float4(px, py, pz, 0.f);
-      A.ap[i] = make_float4(ax, ay, az, 0.f);
-      acc[0] += px * ax;
-      acc[1] += py * ay;
-      acc[2] += pz * az;
-    }
-  }
+  cg_ap_rows<LPR>(A, k, beta, !A.useCAp, acc);
   block_write_partial<3>(acc, A.partA, 3);
 }
 
-// sums over the workgroup (every thread gets the totals); NV values
-template <int NV> PIES_DEV void block_sum(float v[NV]) {
-  __shared__ float lds[kBlock / 64][NV];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1)
-#pragma unroll
-    for (int q = 0; q < NV; ++q) v[q] += __shfl_xor(v[q], off, 64);
-  __syncthreads();  // (the previous use of lds[] has been read)
-  if (lane == 0)
-#pragma unroll
-    for (int q = 0; q < NV; ++q) lds[wave][q] = v[q];
+// x += alpha p ; r -= alpha Ap ; z = D^-1 r for this workgroup's rows; acc += {r.z, r.r} per column
+PIES_DEV void cg_update_rows(const CgArrays& A, float4* __restrict__ x, int k, const float alpha[3], bool addCAp, float acc[6]) {
+  const float4* __restrict__ p = A.p[k & 1];
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < A.n; i += gridDim.x * kBlock) {
+    const float4 pi = p[i];
+    float4 api = A.ap[i];
+    if (addCAp && A.tIncCnt[i]) {
+      const float4 c = A.cAp[i];
+      api.x += c.x; api.y += c.y; api.z += c.z;
+    }
+    float4 xi = x[i], ri = A.r[i];
+    xi.x = fmaf(alpha[0], pi.x, xi.x);
+    xi.y = fmaf(alpha[1], pi.y, xi.y);
+    xi.z = fmaf(alpha[2], pi.z, xi.z);
+    ri.x = fmaf(-alpha[0], api.x, ri.x);
+    ri.y = fmaf(-alpha[1], api.y, ri.y);
+    ri.z = fmaf(-alpha[2], api.z, ri.z);
+    const float di = A.dinv[i];
+    const float zx = di * ri.x, zy = di * ri.y, zz = di * ri.z;
+    x[i] = xi;
+    A.r[i] = ri;
+    A.z[i] = make_float4(zx, zy, zz, 0.f);
+    acc[0] += ri.x * zx; acc[1] += ri.y * zy; acc[2] += ri.z * zz;
+    acc[3] += ri.x * ri.x; acc[4] += ri.y * ri.y; acc[5] += ri.z * ri.z;
+  }
+}
+
+// Barrier across the workgroups of a launch whose workgroups are all resident (k_cg_update: at most 1024 of 256 threads with
+// a few hundred bytes of LDS, the chip holds 5 x 256 of them).  `counter` only grows (the solve's first kernel zeroes it);
+// release before the arrival, acquire after the last one, as a grid-wide synchronisation has to.  The wait is bounded: a
+// workgroup that gives up returns false and leaves, the others follow at their next barrier (the solve then stays where it
+// was and is counted as short).
+PIES_DEV bool grid_barrier(uint32_t* counter, uint32_t nblocks, uint32_t& passed) {
+  __shared__ uint32_t sOk;
   __syncthreads();
-#pragma unroll
-  for (int q = 0; q < NV; ++q) {
-    float t = lds[0][q];
-    for (int w = 1; w < kBlock / 64; ++w) t += lds[w][q];
-    v[q] = t;
+  if (threadIdx.x == 0) {
+    __threadfence();
+    atomicAdd(counter, 1u);
+    const uint32_t target = (passed + 1u) * nblocks;
+    uint32_t spins = 0, ok = 1u;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 20)) { ok = 0u; break; }  // ~1 s
+    }
+    __threadfence();
+    sOk = ok;
   }
+  __syncthreads();
+  ++passed;
+  return sOk != 0u;
 }
 
-// The captured iterations of a solve are over and it is still above the tolerance (new contacts stiffened the system
-// since the budget was chosen, and the host has not looked yet): the LAST workgroup of the last k_cg_update to finish goes
-// on alone - plain CG, one workgroup, workgroup barriers instead of kernel boundaries, the contact rows summed lane by
-// lane - until the solve converges or pies_set_pcg's ceiling is reached.  Slow (a single CU: ~0.3 ms per iteration at
-// 125k rows) and rare: it only runs until the next host synchronisation raises the captured budget, and it means that a
-// queue of pies_tick_async calls never feeds an unconverged solve into the next substep.  k0 = iterations done so far.
-PIES_DEV void cg_overflow(const CgArrays& A, float4* __restrict__ x, int k0, int extra, float tol2) {
-  if (A.lanesPerRow != 1u || extra <= 0) return;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t nslices = (A.n + 63u) / 64u;
-  float red[6];
-  block_reduce_partials<6>(A.partBnext, 6, A.nparts, red);
-  float rz[3] = {red[0], red[1], red[2]}, rr[3] = {red[3], red[4], red[5]}, rzOld[3], bb[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) { rzOld[c] = A.scal[3 * ((k0 - 1) & 1) + c]; bb[c] = A.scal[6 + c]; }
-  int k = k0;
-  for (; k < k0 + extra; ++k) {
-    if (all_converged(rr, bb, tol2)) break;
-    float beta[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) beta[c] = rzOld[c] > 0.0f ? rz[c] / rzOld[c] : 0.0f;
-    const float4* __restrict__ pold = A.p[(k + 1) & 1];
-    float4* __restrict__ pnew = A.p[k & 1];
-    for (uint32_t i = tid; i < A.n; i += kBlock) {
-      const float4 zi = A.z[i], pi = pold[i];
-      pnew[i] = make_float4(fmaf(beta[0], pi.x, zi.x), fmaf(beta[1], pi.y, zi.y), fmaf(beta[2], pi.z, zi.z), 0.f);
-    }
-    __syncthreads();
-    float acc[6] = {0, 0, 0, 0, 0, 0};
-    for (uint32_t sl = wave; sl < nslices; sl += kBlock / 64) {
-      const uint32_t i = sl * 64u + lane;
-      const uint32_t off = A.sliceOff[sl], width = (A.sliceOff[sl + 1] - off) >> 6;
-      float sx = 0.f, sy = 0.f, sz = 0.f;
-      for (uint32_t kk = 0; kk < width; ++kk) {
-        const uint32_t at = off + (kk << 6) + lane;
-        const float a = A.val[at];
-        const float4 pj = pnew[A.col[at]];
-        sx = fmaf(a, pj.x, sx); sy = fmaf(a, pj.y, sy); sz = fmaf(a, pj.z, sz);
-      }
-      if (i < A.n) {
-        contact_row(A, i, [&](uint32_t j, float& qx, float& qy, float& qz) { const float4 v = pnew[j]; qx = v.x; qy = v.y; qz = v.z; }, sx, sy, sz);
-        const float4 pi = pnew[i];
-        const float cd = A.cdiag[i];
-        const float ax = fmaf(cd, pi.x, sx), ay = fmaf(cd, pi.y, sy), az = fmaf(cd, pi.z, sz);
-        A.ap[i] = make_float4(ax, ay, az, 0.f);
-        acc[0] += pi.x * ax; acc[1] += pi.y * ay; acc[2] += pi.z * az;
-      }
-    }
-    block_sum<3>(acc);
-    float alpha[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) alpha[c] = acc[c] > 0.0f ? rz[c] / acc[c] : 0.0f;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) acc[c] = 0.0f;
-    for (uint32_t i = tid; i < A.n; i += kBlock) {
-      const float4 pi = pnew[i], api = A.ap[i];
-      float4 xi = x[i], ri = A.r[i];
-      xi.x = fmaf(alpha[0], pi.x, xi.x); xi.y = fmaf(alpha[1], pi.y, xi.y); xi.z = fmaf(alpha[2], pi.z, xi.z);
-      ri.x = fmaf(-alpha[0], api.x, ri.x); ri.y = fmaf(-alpha[1], api.y, ri.y); ri.z = fmaf(-alpha[2], api.z, ri.z);
-      const float di = A.dinv[i];
-      const float zx = di * ri.x, zy = di * ri.y, zz = di * ri.z;
-      x[i] = xi;
-      A.r[i] = ri;
-      A.z[i] = make_float4(zx, zy, zz, 0.f);
-      acc[0] += ri.x * zx; acc[1] += ri.y * zy; acc[2] += ri.z * zz;
-      acc[3] += ri.x * ri.x; acc[4] += ri.y * ri.y; acc[5] += ri.z * ri.z;
-    }
-    block_sum<6>(acc);  // (its barriers also order this pass's stores before the next pass's loads)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { rzOld[c] = rz[c]; rz[c] = acc[c]; rr[c] = acc[3 + c]; }
-  }
-  if (tid == 0) {
-    A.scal[9] = static_cast<float>(k);
-    A.scal[12] = rr[0]; A.scal[13] = rr[1]; A.scal[14] = rr[2];
-    A.scal[10] = 2.0f;
-  }
-}
-
-// alpha = rz_k / pAp ; x += alpha p ; r -= alpha Ap ; z = D^-1 r ; partB = {rz_{k+1}, rr_{k+1}}.  overflow > 0: this is the
-// solve's last captured iteration and up to `overflow` more may follow inside this launch (cg_overflow).
+// alpha = rz_k / pAp ; x += alpha p ; r -= alpha Ap ; z = D^-1 r ; partB = {rz_{k+1}, rr_{k+1}}.
+// overflow > 0: this is the solve's last captured iteration.  If the residual is still above the tolerance after it (new
+// contacts stiffened the system since the budget was chosen, and the host has not looked yet), the launch goes on: its
+// workgroups run up to `overflow` more iterations themselves, a grid barrier where the captured path has a kernel boundary
+// (k_cg_ap's rows, barrier, these rows, barrier), the contact rows summed lane by lane.  An iteration costs about what a
+// captured one does, so neither pies_tick nor a blind queue of pies_tick_async calls feeds an unconverged solve into the
+// next substep, and the host raises the captured budget at its next look.  (The first version let the last workgroup to
+// finish go on alone: 4 ms per iteration at 125k rows, a second per frame at a contact onset.)
 __global__ void __launch_bounds__(kBlock) k_cg_update(CgArrays A, float4* __restrict__ x, int k, float tol2, int overflow) {
   if (A.scal[10] != 0.0f) return;  // (see k_cg_ap)
   float red[9];
@@ -1032,42 +999,47 @@ __global__ void __launch_bounds__(kBlock) k_cg_update(CgArrays A, float4* __rest
     const float rzk = A.scal[3 * (k & 1) + c];
     alpha[c] = pap[c] > 0.0f ? rzk / pap[c] : 0.0f;
   }
-  const float4* __restrict__ p = A.p[k & 1];
   float acc[6] = {0, 0, 0, 0, 0, 0};
   // blocks run concurrently, so the new residual partials go to the other half of a ping-pong pair
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < A.n; i += gridDim.x * kBlock) {
-    const float4 pi = p[i];
-    float4 api = A.ap[i];
-    if (rows && A.tIncCnt[i]) {
-      const float4 c = A.cAp[i];
-      api.x += c.x; api.y += c.y; api.z += c.z;
-    }
-    float4 xi = x[i], ri = A.r[i];
-    xi.x = fmaf(alpha[0], pi.x, xi.x);
-    xi.y = fmaf(alpha[1], pi.y, xi.y);
-    xi.z = fmaf(alpha[2], pi.z, xi.z);
-    ri.x = fmaf(-alpha[0], api.x, ri.x);
-    ri.y = fmaf(-alpha[1], api.y, ri.y);
-    ri.z = fmaf(-alpha[2], api.z, ri.z);
-    const float di = A.dinv[i];
-    const float zx = di * ri.x, zy = di * ri.y, zz = di * ri.z;
-    x[i] = xi;
-    A.r[i] = ri;
-    A.z[i] = make_float4(zx, zy, zz, 0.f);
-    acc[0] += ri.x * zx; acc[1] += ri.y * zy; acc[2] += ri.z * zz;
-    acc[3] += ri.x * ri.x; acc[4] += ri.y * ri.y; acc[5] += ri.z * ri.z;
-  }
+  cg_update_rows(A, x, k, alpha, rows, acc);
   block_write_partial<6>(acc, A.partBnext, 6);
-  if (overflow > 0) {
-    __shared__ uint32_t sLast;
-    __threadfence();  // this block's x, r, z and partials are visible before it takes its ticket
-    if (threadIdx.x == 0) sLast = atomicAdd(A.ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
-    __syncthreads();
-    if (sLast) {
-      if (threadIdx.x == 0) *A.ticket = 0u;
-      __threadfence();
-      cg_overflow(A, x, k + 1, overflow, tol2);
-    }
+  if (overflow <= 0 || A.lanesPerRow != 1u) return;
+  // ---- the iterations beyond the captured ones --------------------------------------------------------------------
+  float* const pb[2] = {A.partB0, A.partB1};
+  uint32_t passed = 0;
+  int kk = k + 1;
+  float rzOld[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) rzOld[c] = A.scal[3 * (k & 1) + c];  // (kept in registers: block 0 does not have to publish them)
+  for (;;) {
+    if (!grid_barrier(A.ticket, gridDim.x, passed)) return;  // the partials of iteration kk - 1 are complete
+    float rz[3];
+    block_reduce_partials<6>(pb[kk & 1], 6, A.nparts, red);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { rz[c] = red[c]; rr[c] = red[3 + c]; }
+    if (all_converged(rr, bb, tol2) || kk >= k + 1 + overflow) break;
+    float beta[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) beta[c] = rzOld[c] > 0.0f ? rz[c] / rzOld[c] : 0.0f;
+    float a3[3] = {0, 0, 0};
+    cg_ap_rows<1>(A, kk, beta, true, a3);
+    block_write_partial<3>(a3, A.partA, 3);
+    if (!grid_barrier(A.ticket, gridDim.x, passed)) return;
+    block_reduce_partials<3>(A.partA, 3, A.nparts, pap);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) alpha[c] = pap[c] > 0.0f ? rz[c] / pap[c] : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) acc[c] = 0.0f;
+    cg_update_rows(A, x, kk, alpha, false, acc);
+    block_write_partial<6>(acc, pb[(kk + 1) & 1], 6);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rzOld[c] = rz[c];
+    ++kk;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // where the final residual partials are, and how many iterations it took
+    A.scal[9] = static_cast<float>(kk);
+    A.scal[11] = static_cast<float>(1 + (kk & 1));
+    A.scal[10] = 1.0f;
   }
 }
 
