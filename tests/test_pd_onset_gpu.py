@@ -3,7 +3,7 @@ the device's is a CG with a captured iteration budget that follows what recent s
 the system from one substep to the next, a solve can end above the tolerance: pies_tick then puts the substep's input
 back and runs it again with a larger budget, so every substep it returns met the tolerance; pies_tick_async cannot do
 that and counts the short solves instead (pies_get_pcg_health).  Second half of round 2: before it comes to that, the last
-captured launch of a solve that is still above the tolerance goes on by itself (one workgroup, plain CG) up to the ceiling
+captured launch of a solve that is still above the tolerance goes on by itself (grid barriers for kernel boundaries) up to the ceiling
 of pies_set_pcg, so that neither path hands an unconverged solve to the next substep."""
 import numpy as np
 import pytest

@@ -142,7 +142,7 @@ def test_sequential_passes_on_the_lds_copy_equal_the_l2_path_bit_for_bit(pies, m
 
 def test_two_captured_iterations_and_the_rest_in_the_last_launch(pies, oracle, monkeypatch):
     """PIES_PCG_BUDGET=2 pins the captured CG iterations at two; thousands of w = 1e4 contacts need 8-14.  The last captured
-    launch goes on alone (cg_overflow: one workgroup, contact rows summed lane by lane) and the substeps still meet the
+    launch goes on by itself (k_cg_update: grid barriers, contact rows summed lane by lane) and the substeps still meet the
     tolerance and stay with the oracle's direct solves."""
     monkeypatch.setenv("PIES_PCG_BUDGET", "2")
     g = pies.Solver(pd_options(pies, 3))
