@@ -469,8 +469,10 @@ __global__ void __launch_bounds__(kBlock) k_grid_groups(HashArrays H) {
 }
 
 // ---- resolve ---------------------------------------------------------------------------------------
-// Node state is read and written through agent-scope relaxed atomics (L2-served, write-through): within a
-// pass exactly one wavefront touches a given node, and that wavefront must see its own earlier writes.
+// The unstaged path reads and writes node state through agent-scope relaxed atomics (L2-served, write-through): within a
+// pass exactly one wavefront touches a given node, and that wavefront must see its own earlier writes.  (The staged path
+// moves whole records with ordinary 16-byte loads and stores between the acquire fence behind the wait and the release
+// store of the completion stamp, group_resolve.)
 PIES_DEV float ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 PIES_DEV void st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 PIES_DEV float bcast(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
@@ -647,14 +649,26 @@ PIES_DEV uint32_t col_find(const uint32_t* key, uint32_t j) {  // j is present
   return h;
 }
 
-// One group on the staged path (or, for a dense neighbourhood, the unstaged one).  Node state is read and written
-// through agent-scope (sc1) loads and stores: in k_collide_flow the previous owner of a node may be a wavefront
-// of the same launch on another XCD.  Returns the number of resolved pairs.
-PIES_DEV uint32_t collide_group(const HashArrays& H, const GridBox& B, const uint32_t* __restrict__ val, ColTable& T, float* pos, float* vel,
-                                const float* __restrict__ radius, uint32_t gslot, int lane, const LaneRole role, float friction,
-                                float staticThreshold, int forceGlobal, uint32_t& tested) {
-  uint32_t resolved = 0;
-  if (H.gcnt[gslot] == 0) return 0;
+// One group on the staged path (or, for a dense neighbourhood, the unstaged one), in two halves.
+//  * group_prepare reads only what the grid build left behind (buckets, entries, ranges): the group's eight buckets, the
+//    table of distinct nodes, the table slot of every bucket entry, and - in registers, one own-cell entry per lane - the
+//    group's own nodes with their ranges and slots.  k_collide_flow runs it BEFORE it waits for the conflicting groups of
+//    earlier passes, so this half (about a quarter of a group's time) is off the chain of the 27 passes.
+//  * group_resolve loads the node state, replays the visiting order of collide_group_global on the copies and writes the
+//    touched nodes back.  Node state is read and written through agent-scope (sc1) loads and stores: in k_collide_flow the
+//    previous owner of a node may be a wavefront of the same launch on another XCD.  Returns the number of resolved pairs.
+struct GroupPlan {
+  uint32_t cStart[8], cCnt[8], cOff[9];  // the 2x2x2 buckets above the group's cell (wave uniform)
+  bool empty, staged, ownInLanes;
+  uint32_t ownVal, ownRng, ownSlot;      // lane e: entry e of the own cell (cell 0), its range word and table slot
+};
+PIES_DEV void group_prepare(const HashArrays& H, const GridBox& B, const uint32_t* __restrict__ val, ColTable& T, uint32_t gslot, int lane,
+                            int forceGlobal, GroupPlan& P) {
+  P.empty = H.gcnt[gslot] == 0;
+  P.staged = false;
+  P.ownInLanes = false;
+  P.ownVal = P.ownRng = P.ownSlot = 0;
+  if (P.empty) return;
   // ---- the 2x2x2 cells above the group's cell: lanes 0..7 look one up each ------------------------------
   int gx, gy, gz;
   box_cell(B, H.keys[gslot], gx, gy, gz);
@@ -663,24 +677,24 @@ PIES_DEV uint32_t collide_group(const HashArrays& H, const GridBox& B, const uin
     const uint32_t cs = find_bucket(H, B, gx + ((lane >> 2) & 1), gy + ((lane >> 1) & 1), gz + (lane & 1));
     if (cs != 0xffffffffu) { myStart = H.start[cs]; myCnt = H.end[cs] - myStart; }
   }
-  uint32_t cStart[8], cCnt[8], cOff[9];
-  cOff[0] = 0;
+  P.cOff[0] = 0;
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
-    cStart[c] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(myStart), c));
-    cCnt[c] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(myCnt), c));
-    cOff[c + 1] = cOff[c] + cCnt[c];
+    P.cStart[c] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(myStart), c));
+    P.cCnt[c] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(myCnt), c));
+    P.cOff[c + 1] = P.cOff[c] + P.cCnt[c];
   }
-  bool staged = !forceGlobal && cOff[8] <= kColMaxEntries;
+  bool staged = !forceGlobal && P.cOff[8] <= kColMaxEntries;
   if (staged) {
     for (uint32_t t = lane; t < kColSlots; t += 64) T.key[t] = kColEmpty;
     uint32_t unique = 0;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      for (uint32_t base = 0; base < cCnt[c] && staged; base += 64) {
+      for (uint32_t base = 0; base < P.cCnt[c] && staged; base += 64) {
         bool fresh = false;
-        if (base + lane < cCnt[c]) {
-          const uint32_t j = val[cStart[c] + base + lane] & kNodeMask;
+        if (base + lane < P.cCnt[c]) {
+          const uint32_t v = val[P.cStart[c] + base + lane];
+          const uint32_t j = v & kNodeMask;
           uint32_t h = col_hash(j);
           for (;;) {  // at most kColMaxUnique + 64 live entries: the probe ends
             const uint32_t old = atomicCAS(&T.key[h], kColEmpty, j);
@@ -688,31 +702,66 @@ PIES_DEV uint32_t collide_group(const HashArrays& H, const GridBox& B, const uin
             if (old == j) break;
             h = (h + 1) & (kColSlots - 1);
           }
-          T.ent[cOff[c] + base + lane] = static_cast<uint16_t>(h);
+          T.ent[P.cOff[c] + base + lane] = static_cast<uint16_t>(h);
+          if (c == 0 && base == 0) {  // the own cell's first 64 entries stay in the lanes
+            P.ownVal = v;
+            P.ownSlot = h;
+            if (v & kMinFlag) P.ownRng = static_cast<uint32_t>(H.rng[j].w);
+          }
         }
         unique += static_cast<uint32_t>(__popcll(__ballot(fresh)));
         if (unique > kColMaxUnique) staged = false;
       }
     }
   }
-  if (!staged) {
+  P.staged = staged;
+  P.ownInLanes = staged && P.cCnt[0] <= 64u;
+}
+PIES_DEV uint32_t group_resolve(const HashArrays& H, const GridBox& B, const uint32_t* __restrict__ val, ColTable& T, float* pos, float* vel,
+                                const float* __restrict__ radius, uint32_t gslot, int lane, const LaneRole role, float friction,
+                                float staticThreshold, const GroupPlan& P, uint32_t& tested) {
+  uint32_t resolved = 0;
+  if (P.empty) return 0;
+  if (!P.staged) {
     return collide_group_global(H, B, val, pos, vel, radius, gslot, lane, role, friction, staticThreshold, tested);
   }
+  const uint32_t* cStart = P.cStart;
+  const uint32_t* cCnt = P.cCnt;
+  const uint32_t* cOff = P.cOff;
+  // Node records as two 16-byte loads (and stores, below).  Coherence with the wavefronts that owned these nodes earlier
+  // in the launch, possibly on another XCD, is the memory model's: the caller's acquire fence at agent scope after the
+  // wait orders these loads behind the predecessors' stores, which their release store of the completion stamp published
+  // (round 1 read and wrote eight relaxed agent-scope dwords per node instead).
+  const float4* pos4 = reinterpret_cast<const float4*>(pos);
+  const float4* vel4 = reinterpret_cast<const float4*>(vel);
   for (uint32_t t = lane; t < kColSlots; t += 64) {
     const uint32_t j = T.key[t];
     if (j == kColEmpty) continue;
-    T.px[t] = ld(pos + 4 * j); T.py[t] = ld(pos + 4 * j + 1); T.pz[t] = ld(pos + 4 * j + 2); T.im[t] = ld(pos + 4 * j + 3);
-    T.vx[t] = ld(vel + 4 * j); T.vy[t] = ld(vel + 4 * j + 1); T.vz[t] = ld(vel + 4 * j + 2);
+    const float4 pj = pos4[j], vj = vel4[j];
+    T.px[t] = pj.x; T.py[t] = pj.y; T.pz[t] = pj.z; T.im[t] = pj.w;
+    T.vx[t] = vj.x; T.vy[t] = vj.y; T.vz[t] = vj.z;
     T.r[t] = radius[j];
   }
   // ---- the visiting order of collide_group_global on the staged copies -----------------------------------
   // (the group's own cell is cell 0 of the eight)
-  for (uint32_t ge = next_min_entry(val, cStart[0], cCnt[0], 0, lane); ge < cCnt[0]; ge = next_min_entry(val, cStart[0], cCnt[0], ge + 1, lane)) {
-    const uint32_t i = val[cStart[0] + ge] & kNodeMask;
-    const uint32_t si = col_find(T.key, i);
+  // the group's own nodes in ascending entry order: from the lanes when the own cell has at most 64 entries (no global
+  // load and no table probe per node), otherwise looked up one by one
+  unsigned long long own = P.ownInLanes ? __ballot(static_cast<uint32_t>(lane) < cCnt[0] && (P.ownVal & kMinFlag) != 0u) : 0ull;
+  for (uint32_t ge = P.ownInLanes ? (own ? static_cast<uint32_t>(__builtin_ctzll(own)) : cCnt[0]) : next_min_entry(val, cStart[0], cCnt[0], 0, lane);
+       ge < cCnt[0];
+       ge = P.ownInLanes ? ((own &= own - 1ull) ? static_cast<uint32_t>(__builtin_ctzll(own)) : cCnt[0]) : next_min_entry(val, cStart[0], cCnt[0], ge + 1, lane)) {
+    uint32_t i, si, rw;
+    if (P.ownInLanes) {
+      i = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(P.ownVal), static_cast<int>(ge))) & kNodeMask;
+      si = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(P.ownSlot), static_cast<int>(ge)));
+      rw = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(P.ownRng), static_cast<int>(ge)));
+    } else {
+      i = val[cStart[0] + ge] & kNodeMask;
+      si = col_find(T.key, i);
+      rw = static_cast<uint32_t>(H.rng[i].w);
+    }
     PairState a = {T.px[si], T.py[si], T.pz[si], T.vx[si], T.vy[si], T.vz[si]};
     const float imi = T.im[si], ri = T.r[si];
-    const uint32_t rw = static_cast<uint32_t>(H.rng[i].w);
     const uint32_t lx = rw & 0xff, ly = (rw >> 8) & 0xff, lz = (rw >> 16) & 0xff;
     for (uint32_t dx = 0; dx < lx; ++dx)
       for (uint32_t dy = 0; dy < ly; ++dy)
@@ -769,11 +818,10 @@ PIES_DEV uint32_t collide_group(const HashArrays& H, const GridBox& B, const uin
     const uint32_t kj = T.key[t];
     if (kj == kColEmpty || !(kj & kColDirty)) continue;
     const uint32_t j = kj & ~kColDirty;
-    st(pos + 4 * j, T.px[t]); st(pos + 4 * j + 1, T.py[t]); st(pos + 4 * j + 2, T.pz[t]);
-    st(vel + 4 * j, T.vx[t]); st(vel + 4 * j + 1, T.vy[t]); st(vel + 4 * j + 2, T.vz[t]);
+    reinterpret_cast<float4*>(pos)[j] = make_float4(T.px[t], T.py[t], T.pz[t], T.im[t]);
+    reinterpret_cast<float4*>(vel)[j] = make_float4(T.vx[t], T.vy[t], T.vz[t], 0.0f);  // (the fourth component of a velocity record is 0 everywhere)
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the group's stores have left the wavefront
-  return resolved;
+  return resolved;  // (the caller's release store of the completion stamp publishes these stores)
 }
 
 // The 27 residue classes as 27 launches: inside a launch no two groups share a node.
@@ -792,8 +840,12 @@ __global__ void __launch_bounds__(kColBlock) k_collide(HashArrays H, float4* pos
   const uint32_t ngroups = H.counters[4 + pass];
   uint32_t resolved = 0, tested = 0;  // statistics, one atomic per wave at the end (a per-pair atomic on one word serialises the chip)
   for (uint32_t g = wave; g < ngroups; g += nwaves)
-    resolved += collide_group(H, B, val, T, pos, vel, radius, H.passList[static_cast<size_t>(pass) * H.n + g], lane, role, friction,
-                              staticThreshold, forceGlobal, tested);
+  {
+    const uint32_t gslot = H.passList[static_cast<size_t>(pass) * H.n + g];
+    GroupPlan P;
+    group_prepare(H, B, val, T, gslot, lane, forceGlobal, P);
+    resolved += group_resolve(H, B, val, T, pos, vel, radius, gslot, lane, role, friction, staticThreshold, P, tested);
+  }
   if (lane == 0 && resolved) atomicAdd(&H.counters[31], resolved);
   if (lane == 0 && tested) atomicAdd(reinterpret_cast<unsigned long long*>(&H.counters[kCounterCandidates]), static_cast<unsigned long long>(tested));
 }
@@ -834,6 +886,9 @@ __global__ void __launch_bounds__(kColBlock) k_collide_flow(HashArrays H, float4
     const uint32_t pass = static_cast<uint32_t>(__popcll(__ballot(lane < 27 && incl <= ticket)));
     const uint32_t before = pass ? static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), pass - 1)) : 0u;
     const uint32_t gslot = H.passList[static_cast<size_t>(pass) * H.n + (ticket - before)];
+    // ---- what does not depend on the predecessors' results: buckets, table of distinct nodes, own entries ------------
+    GroupPlan P;
+    group_prepare(H, B, val, T, gslot, lane, forceGlobal, P);
     // ---- wait for the conflicting groups of earlier passes -------------------------------------------------
     int x, y, z;
     box_cell(B, H.keys[gslot], x, y, z);
@@ -858,7 +913,7 @@ __global__ void __launch_bounds__(kColBlock) k_collide_flow(HashArrays H, float4
     // the stamps were polled relaxed; this fence orders every later load of the wavefront after them (pairs with the
     // release store below): the predecessors' node writes are visible by the memory model, not by cache behaviour
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    resolved += collide_group(H, B, val, T, pos, vel, radius, gslot, lane, role, friction, staticThreshold, forceGlobal, tested);
+    resolved += group_resolve(H, B, val, T, pos, vel, radius, gslot, lane, role, friction, staticThreshold, P, tested);
     if (lane == 0) __hip_atomic_store(H.done + gslot, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (lane == 0 && resolved) atomicAdd(&H.counters[31], resolved);
