@@ -972,24 +972,14 @@ PIES_DEV bool grid_barrier(uint32_t* counter, uint32_t nblocks, uint32_t& passed
 // next substep, and the host raises the captured budget at its next look.  (The first version let the last workgroup to
 // finish go on alone: 4 ms per iteration at 125k rows, a second per frame at a contact onset.)
 __global__ void __launch_bounds__(kBlock) k_cg_update(CgArrays A, float4* __restrict__ x, int k, float tol2, int overflow) {
-  if (A.scal[10] != 0.0f) return;  // (see k_cg_ap)
+  // k_cg_ap(k) has looked at the residual of iteration k: had the solve converged, it would have set the flag and produced
+  // nothing.  (Until the flag existed this kernel re-reduced the residual partials to take the same decision: one block-wide
+  // reduction per launch for nothing.)
+  if (A.scal[10] != 0.0f) return;
   float red[9];
   float rr[3], bb[3];
-  if (k == 0) {
-    block_reduce_partials<9>(A.partI, 9, A.nparts, red);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { rr[c] = red[3 + c]; bb[c] = red[6 + c]; }
-  } else {
-    block_reduce_partials<6>(A.partB, 6, A.nparts, red);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { rr[c] = red[3 + c]; bb[c] = A.scal[6 + c]; }
-  }
-  if (all_converged(rr, bb, tol2)) {
-    // same decision as k_cg_ap(k), which produced nothing: carry the residual partials forward so that
-    // every later kernel of this solve takes the same branch
-    if (threadIdx.x < 6) A.partBnext[blockIdx.x * 6 + threadIdx.x] = (k == 0 ? A.partI[blockIdx.x * 9 + threadIdx.x] : A.partB[blockIdx.x * 6 + threadIdx.x]);
-    return;
-  }
+  for (int c = 0; c < 3; ++c) bb[c] = A.scal[6 + c];  // (written by k_cg_ap(0) of this solve)
   const bool rows = A.useCAp && A.tIncCnt;
   float pap[3];
   block_reduce_partials<3>(A.partA, 3, A.nparts + (rows ? kCgRowBlocks : 0u), pap);
