@@ -385,7 +385,8 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
   C(PIES_KERNEL_PD_PREDICT);
   const bool tri = pd.tri.nt != 0;
   if (tri && only < 0) {  // Solver.cpp:240, 245-248: detection, contact list, their blocks of the system matrix
-    launch_tri_detect(st, pd.tri, s->nd, pd.kdiag, pd.cg.cdiag, pd.cg.dinv, s->opt.collisionThresholdDistance, s->opt.collisionThickness);
+    launch_tri_detect(st, pd.tri, s->nd, pd.kdiag, pd.cg.cdiag, pd.cg.dinv, s->opt.collisionThresholdDistance, s->opt.collisionThickness,
+                      pd.cg.useCAp != 0);
     // The dependency levels of the list (one workgroup, up to 1 ms with tens of thousands of contacts) are only needed by
     // the sequential passes behind the local/global iterations: a second branch of the substep, joined there.
     // Only in the contact-heavy graph variant: a fork and join inside a hipGraph costs about 100 us per replay (measured:

@@ -40,6 +40,9 @@ struct CgArrays {
   const uint32_t* tUsedCount;  // how many (device counter)
   float4* cAp;
   int useCAp;
+  // merged contact rows (tri_kernels.hip k_contact_csr): distinct columns of a node's contact row, -w * multiplicity
+  const uint32_t *rowStart, *rowLen, *rowCol;
+  const float* rowCoef;
   float* scal;   // rz[2][3], bb[3], iterations, [10] the solve is over (converged, or went on inside its last launch), [11] where
                  // its final residual partials are
   uint32_t* ticket;  // grid barrier counter of the solve's last k_cg_update (zeroed by k_cg_init)

@@ -673,6 +673,16 @@ PIES_DEV void solve_statistics(const CgArrays& A, const float* __restrict__ prev
 template <class Fetch> PIES_DEV void contact_rows_of_node(const CgArrays& A, uint32_t node, uint32_t lane, Fetch fetch, float& sx, float& sy, float& sz) {
   const uint32_t tc = A.tIncCnt[node], ts = A.tIncStart[node];
   sx = 0.f; sy = 0.f; sz = 0.f;
+  const uint32_t len = A.rowLen ? A.rowLen[node] : 0xffffffffu;
+  if (len != 0xffffffffu) {  // merged row: one gather of the distinct columns (a handful per node), coefficient = -w * multiplicity
+    const uint32_t off = A.rowStart[node];
+    for (uint32_t t = lane; t < len; t += 64) {
+      const float coef = A.rowCoef[off + t];
+      float q[3];
+      fetch(A.rowCol[off + t], q[0], q[1], q[2]);
+      sx = fmaf(coef, q[0], sx); sy = fmaf(coef, q[1], sy); sz = fmaf(coef, q[2], sz);
+    }
+  } else
   for (uint32_t t = lane; t < tc; t += 64) {
     const uint32_t v = A.tInc[ts + t];
     const uint4 id = A.tIds[v >> 2];

@@ -234,6 +234,8 @@ int pd_build(pies_solver* s) {
   cg.tIncCnt = cg.tIncStart = cg.tInc = nullptr;
   cg.tIds = nullptr;
   cg.tUsed = cg.tUsedCount = nullptr;
+  cg.rowStart = cg.rowLen = cg.rowCol = nullptr;
+  cg.rowCoef = nullptr;
   cg.cAp = nullptr;
   cg.useCAp = 0;
   pd.tContrib = nullptr;
@@ -257,7 +259,7 @@ int pd_build(pies_solver* s) {
     if (int rc = dev_alloc(s, cap, &T.start, true)) return rc;
     if (int rc = dev_alloc(s, cap, &T.fill, true)) return rc;
     if (int rc = dev_alloc(s, static_cast<size_t>(kTriMaxEntries) * nt, &T.used, true)) return rc;
-    if (int rc = dev_alloc(s, 8, &T.counters, true)) return rc;
+    if (int rc = dev_alloc(s, 16, &T.counters, true)) return rc;
     if (int rc = dev_alloc(s, static_cast<size_t>(kTriMaxEntries) * nt, &T.triSlot, true)) return rc;
     if (int rc = dev_alloc(s, nt, &T.rng, true)) return rc;
     if (int rc = dev_alloc(s, static_cast<size_t>(kTriMaxEntries) * nt, &T.bucket, true)) return rc;
@@ -280,9 +282,14 @@ int pd_build(pies_solver* s) {
     if (int rc = dev_alloc(s, kTriMaxLevels + 1, &T.lvStart, true)) return rc;
     if (int rc = dev_alloc(s, (n + 31ull) / 32 + 1, &T.usedBits, true)) return rc;
     if (int rc = dev_alloc(s, n, &T.nodeSlot, true)) return rc;
+    if (int rc = dev_alloc(s, n, &T.rowStart, true)) return rc;
+    if (int rc = dev_alloc(s, n, &T.rowLen, true)) return rc;
+    if (int rc = dev_alloc(s, 6ull * T.maxContacts, &T.rowCol, true)) return rc;
+    if (int rc = dev_alloc(s, 6ull * T.maxContacts, &T.rowCoef, true)) return rc;
     if (int rc = dev_alloc(s, T.maxContacts, &T.lvSlots, true)) return rc;
     cg.tIncCnt = T.incCnt; cg.tIncStart = T.incStart; cg.tInc = T.incSorted; cg.tIds = T.ids;
     cg.tUsed = T.usedNodes; cg.tUsedCount = T.counters + 4;
+    cg.rowStart = T.rowStart; cg.rowLen = T.rowLen; cg.rowCol = T.rowCol; cg.rowCoef = T.rowCoef;
     if (int rc = dev_alloc(s, n, &cg.cAp, true)) return rc;
     if (const char* e = std::getenv("PIES_TRI_FAST_ROWS")) s->triFastRows = std::atoi(e) != 0;  // tests: force a variant from the first tick
     cg.useCAp = s->triFastRows ? 1 : 0;

@@ -26,7 +26,7 @@ struct TriArrays {
   uint64_t* keys;
   uint32_t *cnt, *start, *fill, *used;
   uint32_t* counters;  // [0] used cells [1] bucket entries [2] contacts [3] failure flag [4] nodes with contacts [5] incidences
-                       // [6] dependency levels of the contact list [7] form of the sequential passes: 0 on an LDS copy of the
+                       // [8] merged row entries [6] dependency levels of the contact list [7] form of the sequential passes: 0 on an LDS copy of the
                        // touched nodes, 2 through L2, 1 more than kTriMaxLevels levels (single-wavefront walk)
   uint32_t* triSlot;   // nt x kTriMaxEntries
   int4* rng;           // per triangle: min cell, packed lengths
@@ -45,6 +45,10 @@ struct TriArrays {
   uint32_t* lvl;       // per contact
   uint32_t* lvOrder;   // contacts bucketed by level
   uint32_t* lvStart;   // kTriMaxLevels + 1 offsets into lvOrder
+  // merged contact rows (k_contact_csr; contact-heavy graph variant): per node with contacts the distinct columns of its
+  // row of the contact matrix, ascending, and -w * (how often the column occurs); rowLen = 0xffffffff: not merged
+  uint32_t *rowStart, *rowLen, *rowCol;
+  float* rowCoef;
   uint32_t* usedBits;  // bitmap over the nodes: takes part in a contact of this substep (usedNodes is read off it, ascending)
   uint32_t* nodeSlot;  // per node with contacts: its index in usedNodes (= its record in the LDS copy of the sequential passes)
   uint2* lvSlots;      // per entry of lvOrder: the four nodeSlots of the contact, 16 bit each
@@ -55,7 +59,7 @@ struct PdArrays;
 
 // after the predict kernel: grid build, detection (count, scan, fill), per-node incidence + diagonal; returns launches
 uint32_t launch_tri_detect(hipStream_t st, const TriArrays& T, const NodeArrays& nd, const float* kdiag, float* cdiag, float* dinv,
-                           float threshold, float thickness);
+                           float threshold, float thickness, bool mergedRows);
 // dependency levels of the contact list for the sequential passes (may run on another stream beside the local/global iterations)
 void launch_tri_levels(hipStream_t st, const TriArrays& T);
 void launch_pd_local_tri(hipStream_t st, const TriArrays& T, const float4* pos, float thickness);

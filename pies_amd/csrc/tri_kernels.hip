@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(kBlock) k_tri_reset(TriArrays T) {
 }
 __global__ void k_tri_zero(TriArrays T) {
   const uint32_t t = threadIdx.x;
-  if (t < 8 && t != 3) T.counters[t] = 0;  // [3] is the sticky failure flag
+  if (t < 9 && t != 3) T.counters[t] = 0;  // [3] is the sticky failure flag
 }
 
 // TriCompRange / sweptTriRange: floor(min), ceil(max) - floor(min) over position and prevPosition, world units
@@ -446,6 +446,87 @@ __global__ void __launch_bounds__(kBlock) k_inc_sort(TriArrays T) {
   for (uint32_t u = wave; u < used; u += nwaves) {
     const uint32_t n = T.usedNodes[u];
     rank_sort(T.inc, T.incSorted, T.incStart[n], T.incCnt[n], lane, T.incPos);
+  }
+}
+
+// ---- merged contact rows -------------------------------------------------------------------------------------
+// The off-diagonal part of a node's row of the contact matrix, w * (AtA)_i. summed over its contacts, with equal columns
+// merged: a node of a contact patch sits in tens of contacts over a handful of triangles, so its ~100 row entries name
+// ~15 distinct nodes.  The CG sums these rows once per iteration (k_cg_ap's row blocks): with the merged form a row is one
+// gather of at most a wavefront's width instead of three dependent loads per contact.  One wavefront per node: the raw
+// columns go through a small LDS hash with counts (integer adds: exact), the distinct ones are sorted by column (ranks
+// among at most kRowMaxUnique entries), so the stored order - and with it the rounding of the sum - does not depend on
+// which lane got where first.  A node with more distinct columns than kRowMaxUnique keeps the contact-by-contact form
+// (rowLen = kRowUnmerged).  Storage: 6 entries per contact at most.
+constexpr uint32_t kRowSlots = 512, kRowMaxUnique = 256, kRowUnmerged = 0xffffffffu;
+__global__ void __launch_bounds__(kBlock) k_contact_csr(TriArrays T) {
+  __shared__ uint32_t hkey[kBlock / 64][kRowSlots];
+  __shared__ uint32_t hcnt[kBlock / 64][kRowSlots];
+  __shared__ uint32_t ucol[kBlock / 64][kRowMaxUnique], ucnt[kBlock / 64][kRowMaxUnique];
+  const uint32_t used = T.counters[4];
+  const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
+  for (uint32_t u = wave; u < used; u += nwaves) {
+    const uint32_t node = T.usedNodes[u];
+    const uint32_t tc = T.incCnt[node], ts = T.incStart[node];
+    for (uint32_t t = lane; t < kRowSlots; t += 64) { hkey[w][t] = 0xffffffffu; hcnt[w][t] = 0; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint32_t fresh = 0;
+    for (uint32_t base = 0; base < tc; base += 64) {
+      const uint32_t t = base + lane;
+      uint32_t cols[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+      if (t < tc) {
+        const uint32_t v = T.incSorted[ts + t];
+        const uint4 id = T.ids[v >> 2];
+        if ((v & 3u) == 0u) { cols[0] = id.y; cols[1] = id.z; cols[2] = id.w; }  // the point's row couples to the triangle's nodes,
+        else cols[0] = id.x;                                                       // their rows to the point
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        bool mine = false;
+        if (cols[q] != 0xffffffffu && fresh <= kRowMaxUnique) {
+          uint32_t h = (cols[q] * 2654435761u) >> 23;  // 9 bits
+          for (;;) {
+            const uint32_t old = atomicCAS(&hkey[w][h], 0xffffffffu, cols[q]);
+            if (old == 0xffffffffu) { mine = true; break; }
+            if (old == cols[q]) break;
+            h = (h + 1u) & (kRowSlots - 1u);
+          }
+          atomicAdd(&hcnt[w][h], 1u);
+        }
+        fresh += static_cast<uint32_t>(__popcll(__ballot(mine)));
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (fresh > kRowMaxUnique) {  // (uniform: every lane counted the same ballots)
+      if (lane == 0) T.rowLen[node] = kRowUnmerged;
+      continue;
+    }
+    // compact the occupied slots, then order them by column
+    uint32_t nu = 0;
+    for (uint32_t base = 0; base < kRowSlots; base += 64) {
+      const uint32_t k = hkey[w][base + lane];
+      const bool occ = k != 0xffffffffu;
+      const unsigned long long m = __ballot(occ);
+      if (occ) {
+        const uint32_t at = nu + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+        ucol[w][at] = k;
+        ucnt[w][at] = hcnt[w][base + lane];
+      }
+      nu += static_cast<uint32_t>(__popcll(m));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint32_t off = 0;
+    if (lane == 0) off = atomicAdd(&T.counters[8], nu);
+    off = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(off)));
+    for (uint32_t t = lane; t < nu; t += 64) {
+      const uint32_t c = ucol[w][t];
+      uint32_t rank = 0;
+      for (uint32_t o = 0; o < nu; ++o) rank += ucol[w][o] < c ? 1u : 0u;  // columns are distinct
+      T.rowCol[off + rank] = c;
+      T.rowCoef[off + rank] = -kTriContactW * static_cast<float>(ucnt[w][t]);
+    }
+    if (lane == 0) { T.rowStart[node] = off; T.rowLen[node] = nu; }
   }
 }
 
@@ -899,7 +980,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_tri_sequential(TriArrays T, float
 
 // ------------------------------------------------------------------------------------------------------------
 uint32_t launch_tri_detect(hipStream_t st_, const TriArrays& T, const NodeArrays& nd, const float* kdiag, float* cdiag, float* dinv,
-                           float threshold, float /*thickness*/) {
+                           float threshold, float /*thickness*/, bool mergedRows) {
   if (T.nt == 0) return 0;
   const dim3 wide(std::min<uint32_t>(1024u, (T.nt * 8 + kBlock - 1) / kBlock)), blk(kBlock);
   hipLaunchKernelGGL(k_tri_reset, wide, blk, 0, st_, T);
@@ -917,6 +998,7 @@ uint32_t launch_tri_detect(hipStream_t st_, const TriArrays& T, const NodeArrays
   hipLaunchKernelGGL(k_inc_alloc, cgrid, blk, 0, st_, T, kdiag, cdiag, dinv);
   hipLaunchKernelGGL(k_inc_fill, cgrid, blk, 0, st_, T);
   hipLaunchKernelGGL(k_inc_sort, cgrid, blk, 0, st_, T);
+  if (mergedRows) hipLaunchKernelGGL(k_contact_csr, cgrid, blk, 0, st_, T);
   return 14;
 }
 void launch_tri_levels(hipStream_t st_, const TriArrays& T) {
