@@ -586,6 +586,19 @@ template <class Fetch> PIES_DEV void contact_row(const CgArrays& A, uint32_t i, 
   if (!A.tIncCnt) return;
   const uint32_t tc = A.tIncCnt[i];
   if (!tc) return;
+  if (A.useCAp && A.rowLen) {  // the merged row of this substep exists (contact-heavy variant; reached from the CG continuation)
+    const uint32_t len = A.rowLen[i];
+    if (len != 0xffffffffu) {
+      const uint32_t off = A.rowStart[i];
+      for (uint32_t t = 0; t < len; ++t) {
+        const float coef = A.rowCoef[off + t];
+        float q[3];
+        fetch(A.rowCol[off + t], q[0], q[1], q[2]);
+        sx = fmaf(coef, q[0], sx); sy = fmaf(coef, q[1], sy); sz = fmaf(coef, q[2], sz);
+      }
+      return;
+    }
+  }
   const uint32_t ts = A.tIncStart[i];
   constexpr int kAhead = 4;
   for (uint32_t k0 = 0; k0 < tc; k0 += kAhead) {
