@@ -469,6 +469,12 @@ def extra_configs(device):
     log("config 5 share (250k particles, PD, binding contacts)")
     g = contact_scene(capi, device)
     g.finalize()
+    # one tick to take the first replay of the graph (upload of the executable graph, first touch of the scratch arrays: 8-18
+    # ms that are not the solver's), then the scene is put back to its start
+    p0, q0, v0 = g.positions.copy(), g.prev_positions.copy(), g.velocities.copy()
+    g.tick_async(1)
+    g.synchronize()
+    g.set_positions(p0); g.set_prev_positions(q0); g.set_velocities(v0)
     frames = []
     for _ in range(18):  # the small body lands in frames 0-4 (thousands of contacts bind), then both bodies - w = 1 against m/h^2 = 6944 is
         t0 = time.perf_counter()  # jelly - sag together and the contacts are gone: both regimes are reported
