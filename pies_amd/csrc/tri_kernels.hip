@@ -15,6 +15,7 @@
 //              dependency DAG (two contacts conflict when they share a node; k_tri_levels) - the sequential result -
 //              on an LDS copy of the touched nodes when these fit, through L2 otherwise; lists with more than
 //              kTriMaxLevels levels are walked by one wavefront, 64 contacts at a time.
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 
@@ -459,7 +460,7 @@ __global__ void __launch_bounds__(kBlock) k_inc_sort(TriArrays T) {
 // which lane got where first.  A node with more distinct columns than kRowMaxUnique keeps the contact-by-contact form
 // (rowLen = kRowUnmerged).  Storage: 6 entries per contact at most.
 constexpr uint32_t kRowSlots = 512, kRowMaxUnique = 256, kRowUnmerged = 0xffffffffu;
-__global__ void __launch_bounds__(kBlock) k_contact_csr(TriArrays T) {
+__global__ void __launch_bounds__(kBlock) k_contact_csr(TriArrays T, uint32_t maxUnique) {
   __shared__ uint32_t hkey[kBlock / 64][kRowSlots];
   __shared__ uint32_t hcnt[kBlock / 64][kRowSlots];
   __shared__ uint32_t ucol[kBlock / 64][kRowMaxUnique], ucnt[kBlock / 64][kRowMaxUnique];
@@ -484,7 +485,7 @@ __global__ void __launch_bounds__(kBlock) k_contact_csr(TriArrays T) {
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         bool mine = false;
-        if (cols[q] != 0xffffffffu && fresh <= kRowMaxUnique) {
+        if (cols[q] != 0xffffffffu && fresh <= maxUnique) {
           uint32_t h = (cols[q] * 2654435761u) >> 23;  // 9 bits
           for (;;) {
             const uint32_t old = atomicCAS(&hkey[w][h], 0xffffffffu, cols[q]);
@@ -498,7 +499,7 @@ __global__ void __launch_bounds__(kBlock) k_contact_csr(TriArrays T) {
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (fresh > kRowMaxUnique) {  // (uniform: every lane counted the same ballots)
+    if (fresh > maxUnique) {  // (uniform: every lane counted the same ballots)
       if (lane == 0) T.rowLen[node] = kRowUnmerged;
       continue;
     }
@@ -998,7 +999,11 @@ uint32_t launch_tri_detect(hipStream_t st_, const TriArrays& T, const NodeArrays
   hipLaunchKernelGGL(k_inc_alloc, cgrid, blk, 0, st_, T, kdiag, cdiag, dinv);
   hipLaunchKernelGGL(k_inc_fill, cgrid, blk, 0, st_, T);
   hipLaunchKernelGGL(k_inc_sort, cgrid, blk, 0, st_, T);
-  if (mergedRows) hipLaunchKernelGGL(k_contact_csr, cgrid, blk, 0, st_, T);
+  if (mergedRows) {
+    uint32_t maxUnique = kRowMaxUnique;  // diagnostics: PIES_ROW_MAX_UNIQUE lowers it (rows with more distinct columns stay unmerged)
+    if (const char* e = std::getenv("PIES_ROW_MAX_UNIQUE")) maxUnique = std::min<uint32_t>(kRowMaxUnique, static_cast<uint32_t>(std::max(0, std::atoi(e))));
+    hipLaunchKernelGGL(k_contact_csr, cgrid, blk, 0, st_, T, maxUnique);
+  }
   return 14;
 }
 void launch_tri_levels(hipStream_t st_, const TriArrays& T) {

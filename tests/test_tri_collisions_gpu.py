@@ -200,13 +200,15 @@ def test_patch_wider_than_the_lds_copy_takes_the_l2_path(pies, oracle, monkeypat
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("contact_rows,sequential", [("inline", "lds"), ("pass", "lds"), ("pass", "l2")])
+@pytest.mark.parametrize("contact_rows,sequential", [("inline", "lds"), ("pass", "lds"), ("pass", "l2"), ("pass-unmerged", "lds")])
 def test_thousands_of_contacts_level_schedule(pies, oracle, monkeypatch, contact_rows, sequential):
     """A plate resting on a larger one: 2000+ contacts per tick, chains of tens of contacts through one node.  Exercises
     the dependency levels of the whole contact list (node-owner rounds; with PIES_TRI_LDS=0 the chunked relaxation, more
     than one 1024-contact chunk), the level-by-level stabilisation / friction passes on the LDS copy of the touched nodes
     and through L2, and both variants of the contact rows in the global step."""
-    monkeypatch.setenv("PIES_TRI_FAST_ROWS", "1" if contact_rows == "pass" else "0")
+    monkeypatch.setenv("PIES_TRI_FAST_ROWS", "0" if contact_rows == "inline" else "1")
+    if contact_rows == "pass-unmerged":  # rows with more than 4 distinct columns keep the contact-by-contact form
+        monkeypatch.setenv("PIES_ROW_MAX_UNIQUE", "4")
     monkeypatch.setenv("PIES_TRI_LDS", "1" if sequential == "lds" else "0")
     g = pies.Solver(pd_options(pies, 3))
     g.set_pcg(3e-7, 256)  # thousands of w = 1e4 contacts: the default cap of 32 CG iterations stops above the tolerance
