@@ -518,7 +518,7 @@ static int adapt_pcg_budget(pies_solver* s) {
     s->pcgWindowMax = 0;
     s->pcgCooldown = 24;
   } else if (used > budget) {
-    // converged, but only because the last launch went on alone (cg_overflow, one workgroup): capture what it needed
+    // converged, but only because the last launch went on by itself (k_cg_update's continuation): capture what it needed
     budget = std::min(s->pcgMaxIters, used + std::max(2u, (used + 2u) / 3u));
     s->pcgCalm = 0;
     s->pcgWindowMax = 0;
