@@ -159,12 +159,16 @@ def roofline(solver, cls, bytes_per_unit, substeps=3, note=None, workload="confi
     if launches == 0 or ms <= 0:
         return None
     nbytes = bytes_per_unit * units
-    net_ms = max(ms - launches * overhead_ms, 0.05 * ms)  # the brackets' own cost, calibrated in the same pass, taken off
+    net_ms = ms - launches * overhead_ms  # the brackets' own cost, calibrated in the same pass, taken off
+    clamped = net_ms < 0.25 * ms  # the bracket is mostly overhead: no bandwidth claim from such a difference
+    if clamped:
+        net_ms = ms
     achieved = nbytes / (net_ms * 1e-3) / 1e9
     traffic, src = pmc_traffic(kname, workload)
     out = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "traffic": traffic, "traffic_source": src, "avg_launch_us": 1e3 * net_ms / launches, "launches_timed": launches,
            "bytes_per_launch": nbytes / launches, "avg_bracket_us": 1e3 * ms / launches, "bracket_overhead_us": 1e3 * overhead_ms,
+           "overhead_clamped": clamped,
            "rocprofv3_avg_us": rocprof_average(kname, workload)[0], "rocprofv3_source": rocprof_average(kname, workload)[1],
            "method": "HIP events on the solver's stream around every launch of the class inside %d eagerly launched whole substeps "
                      "(pies_profile_in_situ); avg_launch_us = the bracket minus what a bracket costs around nothing (two event packets "
@@ -360,6 +364,19 @@ def cpu_baseline_collisions(budget_s):
                       "(SpatialHash.h:134), the resolve loop 1 thread (Solver.cpp:85-130); reference collision order" % (ticks, flags)}
 
 
+def cpu_baseline_default_tick(dims, budget_s):
+    """config 2 as Solver::tickPBD runs it by default: node-node pass ON, reference order, the reference's 16 insert threads."""
+    ora, flags = oracle_module()
+    o = ora.OracleSolver(scenes.pbd_options(ora, ITERATIONS))
+    scenes.build_beam(o, dims)
+    scenes.perturb(o, 1234, 0.05)
+    o.set_flag(1, 1)
+    o.set_reference_threads(True)
+    ticks, dt = timed_oracle_ticks(o, budget_s, 3)
+    return {"value": ticks / dt, "unit": "substeps/s", "cores": min(16, host_cores()), "kind": "port",
+            "sample": "%d ticks, node-node pass on, reference order; 16 insert threads (SpatialHash.h:134), the rest 1 thread (%s)" % (ticks, flags)}
+
+
 # ---- secondary measurements --------------------------------------------------------------------------------------------
 def tick_inclusive(dims, device, sched, steps):
     """What a host pays per tick beyond the resident figure: pies_tick (pinned D2H of the positions + unpack into the
@@ -427,30 +444,32 @@ def order_deviation(device):
     return out
 
 
-def extra_configs(device):
-    """The other single-GPU BASELINE configs, each with its own in-situ roofline block (not the headline value)."""
-    out = {}
-    # configs[2]: 100k beam, Projective Dynamics, tets + volume (w = 1), 10 iterations, k = 0 end cap pinned
+def run_config3(device, full):
+    """configs[2]: 100k beam, Projective Dynamics, tets + volume (w = 1), 10 iterations, k = 0 end cap pinned"""
     g = pd_beam(scenes.L100K, device)
     el = timed_ticks(g, 30, 3, lambda: None)
     res, iters, solves = g.pcg_stats()
     B = pd_bytes(g)
-    out["pd_config3"] = {"value": 30 / el, "unit": "substeps/s", "workload": "BASELINE configs[2]: 20x20x250 beam, PD, 539334 tet + 539334 volume "
-                         "constraints, 10 local/global iterations, floor + point-triangle pipeline on, Jacobi-PCG rel. tol 3e-7 (captured "
-                         "iteration budget adapts)", "pcg_max_rel_residual": res, "pcg_max_iterations_used": iters, "pcg_health": g.pcg_health(),
-                         "launches_per_substep": sum(g.launch_counts().values()),
-                         "projections_per_sec": 30 / el * 10 * (g.count(capi.TET) + g.count(capi.VOLUME) + g.count(capi.POSITION)),
-                         "roofline": roofline(g, "pd_local_tet", B["pd_local_tet"], workload="config3", note="fused strain + volume local step: two projections per "
-                                              "element from one gather and one SVD = 196 B per element (two separate 148-B projections of "
-                                              "SURVEY 8d would be 296 B: multiply achieved by 1.51 for that count)"),
-                         "roofline_spmv": roofline(g, "pd_spmv", B["pd_spmv"], workload="config3", note="SELL-64 SpMV over 3 right-hand sides + fused direction "
-                                                   "update; 8 nnz + 28 N bytes per launch (SURVEY 8d); the solves of the timed pass do not take "
-                                                   "the converged early exit"),
-                         "roofline_rhs": roofline(g, "pd_rhs", B["pd_rhs"], workload="config3")}
-    out["pd_config3"]["isolated_replay_latencies"] = replay_latencies(g)
+    out = {"value": 30 / el, "unit": "substeps/s", "workload": "BASELINE configs[2]: 20x20x250 beam, PD, 539334 tet + 539334 volume "
+           "constraints, 10 local/global iterations, floor + point-triangle pipeline on, Jacobi-PCG rel. tol 3e-7 (captured "
+           "iteration budget adapts)", "pcg_max_rel_residual": res, "pcg_max_iterations_used": iters, "pcg_health": g.pcg_health(),
+           "launches_per_substep": sum(g.launch_counts().values()),
+           "projections_per_sec": 30 / el * 10 * (g.count(capi.TET) + g.count(capi.VOLUME) + g.count(capi.POSITION)),
+           "roofline": roofline(g, "pd_local_tet", B["pd_local_tet"], workload="config3", note="fused strain + volume local step: two projections per "
+                                "element from one gather and one SVD = 196 B per element (two separate 148-B projections of "
+                                "SURVEY 8d would be 296 B: multiply achieved by 1.51 for that count)"),
+           "roofline_spmv": roofline(g, "pd_spmv", B["pd_spmv"], workload="config3", note="SELL-64 SpMV over 3 right-hand sides + fused direction "
+                                     "update; 8 nnz + 28 N bytes per launch (SURVEY 8d); the solves of the timed pass do not take "
+                                     "the converged early exit"),
+           "roofline_rhs": roofline(g, "pd_rhs", B["pd_rhs"], workload="config3")}
+    if full:
+        out["isolated_replay_latencies"] = replay_latencies(g)
     g.close()
-    # configs[1] on an unstructured mesh: Delaunay beam of the same size (the lattice stands in for tetgen in the headline)
-    log("unstructured beam")
+    return out
+
+
+def run_unstructured(device):
+    """configs[1] on an unstructured mesh: Delaunay beam of the same size (the lattice stands in for tetgen in the headline)"""
     mesh = scenes.delaunay_beam(scenes.L100K)
     un = {"workload": "Delaunay triangulation of a jittered 20x20x250 lattice: %d particles, %d distance + %d tet-strain constraints, "
                       "PBD, 20 iterations" % (len(mesh[0]), len(mesh[2]), len(mesh[1]))}
@@ -464,9 +483,11 @@ def extra_configs(device):
         el = timed_ticks(g, 20, 2, lambda: None)
         un[name] = {"value": 20 / el, "unit": "substeps/s", "launches_per_substep": sum(g.launch_counts().values())}
         g.close()
-    out["unstructured_config2"] = un
-    # configs[4], one GPU's share, with contacts that bind
-    log("config 5 share (250k particles, PD, binding contacts)")
+    return un
+
+
+def run_config5_share(device):
+    """configs[4], one GPU's share, with contacts that bind"""
     g = contact_scene(capi, device)
     g.finalize()
     # one tick to take the first replay of the graph (upload of the executable graph, first touch of the scratch arrays: 8-18
@@ -485,40 +506,48 @@ def extra_configs(device):
     quiet = [f for f in frames[6:] if f[1] == 0]
     res, iters, solves = g.pcg_stats()
     B = pd_bytes(g)
-    out["pd_config5_per_gpu"] = {"value": len(binding) / max(1e-9, sum(f[0] for f in binding)), "unit": "substeps/s",
-                                 "workload": "BASELINE configs[4], one GPU's share: 25x25x400 beam (250 000 particles) on the floor + an 8x6x30 body "
-                                 "landing on it, PD, strain + volume constraints, 10 iterations, floor and point-triangle contacts (w = 1e4); a host "
-                                 "that synchronises once per frame; value = the frames in which point-triangle contacts bind (contact onset: the CG "
-                                 "budget starts at 32)",
-                                 "frames_with_contacts": len(binding), "contacts_per_frame": [f[1] for f in frames],
-                                 "cg_budget_per_frame": [f[2] for f in frames], "ms_per_frame": [round(1e3 * f[0], 3) for f in frames],
-                                 "value_without_tri_contacts": len(quiet) / max(1e-9, sum(f[0] for f in quiet)) if quiet else None,
-                                 "pcg_max_rel_residual": res, "pcg_max_iterations_used": iters, "pcg_health": g.pcg_health(), "failed": g.failed,
-                                 "launches_per_substep": sum(g.launch_counts().values()),
-                                 "roofline": roofline(g, "pd_local_tet", B["pd_local_tet"], substeps=2, workload="contacts"),
-                                 "roofline_spmv": roofline(g, "pd_spmv", B["pd_spmv"], substeps=2, workload="contacts")}
+    ms = sorted(1e3 * f[0] for f in frames[1:])
+    out = {"value": len(binding) / max(1e-9, sum(f[0] for f in binding)), "unit": "substeps/s",
+           "workload": "BASELINE configs[4], one GPU's share: 25x25x400 beam (250 000 particles) on the floor + an 8x6x30 body "
+           "landing on it, PD, strain + volume constraints, 10 iterations, floor and point-triangle contacts (w = 1e4); a host "
+           "that synchronises once per frame; value = the frames in which point-triangle contacts bind (contact onset: the CG "
+           "budget starts at 32)",
+           "frames_with_contacts": len(binding), "contacts_per_frame": [f[1] for f in frames],
+           "cg_budget_per_frame": [f[2] for f in frames], "ms_per_frame": [round(1e3 * f[0], 3) for f in frames],
+           "max_over_median_frame": ms[-1] / ms[len(ms) // 2],
+           "value_without_tri_contacts": len(quiet) / max(1e-9, sum(f[0] for f in quiet)) if quiet else None,
+           "pcg_max_rel_residual": res, "pcg_max_iterations_used": iters, "pcg_health": g.pcg_health(), "failed": g.failed,
+           "launches_per_substep": sum(g.launch_counts().values()),
+           "roofline": roofline(g, "pd_local_tet", B["pd_local_tet"], substeps=2, workload="contacts"),
+           "roofline_spmv": roofline(g, "pd_spmv", B["pd_spmv"], substeps=2, workload="contacts")}
     g.close()
-    # PD with thousands of contacts: a short beam resting on a long one that lies on the floor
-    log("PD contact scene")
+    return out
+
+
+def run_pd_contacts(device):
+    """PD with thousands of contacts: a short beam resting on a long one that lies on the floor"""
     g = capi.Solver(capi.Options(solver=capi.PD, iterations=10), device=device)
     g.create_tet_box(25, 25, 160, translation=(0.0, 0.04, 0.0), w=1.0, volume=True, triangles=True)
     g.create_tet_box(25, 25, 40, translation=(0.3, 0.04 + 24 + 0.07, 10.3), w=1.0, volume=True, triangles=True)
     g.finalize()
-    # Frames 0-19: the top beam lands and the captured CG budget settles (32 -> 19 -> 8; a change of budget is a re-capture,
-    # about two frames' time).  Frames 20-35, measured: 29k contacts bind.  (Around frame 40 the jelly bodies - w = 1 against
-    # m/h^2 = 6944 - bounce apart and re-bind, and after ~100 frames they have sagged through the floor far enough for the
-    # reference's own latch, more than 1000 triangles in a grid cell, to end the simulation.)
+    # Frames 0-19: the top beam lands and the captured CG budget settles.  Frames 20-35, measured: 29k contacts bind.
+    # (Around frame 40 the jelly bodies - w = 1 against m/h^2 = 6944 - bounce apart and re-bind, and after ~100 frames they
+    # have sagged through the floor far enough for the reference's own latch, more than 1000 triangles in a grid cell, to
+    # end the simulation.)
     frame_loop(g, 20)
     rate = frame_loop(g, 16)
     res, iters, solves = g.pcg_stats()
-    out["pd_contacts"] = {"value": rate, "unit": "substeps/s", "workload": "125000 particles: a 25x25x40 beam resting on a 25x25x160 beam on the "
-                          "floor, PD, 10 iterations, floor + point-triangle contacts binding (w = 1e4 on the diagonal)",
-                          "tri_contacts_last_substep": len(g.tri_collisions), "pcg_max_rel_residual": res, "pcg_max_iterations_used": iters,
-                          "pcg_health": g.pcg_health(), "failed": g.failed,
-                          "roofline_spmv": roofline(g, "pd_spmv", pd_bytes(g)["pd_spmv"], substeps=1, workload="pdcontacts")}
+    out = {"value": rate, "unit": "substeps/s", "workload": "125000 particles: a 25x25x40 beam resting on a 25x25x160 beam on the "
+           "floor, PD, 10 iterations, floor + point-triangle contacts binding (w = 1e4 on the diagonal)",
+           "tri_contacts_last_substep": len(g.tri_collisions), "pcg_max_rel_residual": res, "pcg_max_iterations_used": iters,
+           "pcg_health": g.pcg_health(), "failed": g.failed,
+           "roofline_spmv": roofline(g, "pd_spmv", pd_bytes(g)["pd_spmv"], substeps=1, workload="pdcontacts")}
     g.close()
-    # configs[3]: 500k loose particles, node-node collisions + floor, PBD, 4 iterations
-    log("config 4 (500k particles, node-node collisions)")
+    return out
+
+
+def run_config4(device):
+    """configs[3]: 500k loose particles, node-node collisions + floor, PBD, 4 iterations"""
     p, v = config4_particles()
     g = capi.Solver(scenes.pbd_options(capi, 4), device=device)
     g.addNodes(p)
@@ -531,15 +560,36 @@ def extra_configs(device):
     pairs, cand = g.collision_stats()
     n = g.count(capi.NODES)
     per_node = 32.0 + 27 * 8.0 + 16.0 * cand / (10 * 4 * n)  # own state + 27 cell headers + 16 B per candidate neighbour
-    out["collisions_config4"] = {"value": 10 / el, "unit": "substeps/s", "workload": "BASELINE configs[3]: 50x100x100 loose particles (r 0.5, spacing "
-                                 "0.9, jitter 0.05), PBD, 4 iterations, grid rebuild + node-node resolve + floor every iteration, parallel "
-                                 "collision order", "resolved_pairs_per_substep": pairs / 10, "candidates_per_node_per_iteration": cand / (40 * n),
-                                 "failed": g.failed, "launches_per_substep": sum(g.launch_counts().values()),
-                                 "roofline": roofline(g, "collide", per_node, substeps=1, workload="config4", note="one bracket = the resolve pass of one "
-                                                      "iteration (k_collide_flow); bytes per node = 32 + 27 x 8 + 16 x candidates looked at"),
-                                 "roofline_grid_build": roofline(g, "hash", 92.0, substeps=1, workload="config4", note="one bracket = one grid rebuild: range, prefix "
-                                                                 "sum, emit, radix sort passes, cell index (about 92 B per node, SURVEY 8d)")}
+    out = {"value": 10 / el, "unit": "substeps/s", "workload": "BASELINE configs[3]: 50x100x100 loose particles (r 0.5, spacing "
+           "0.9, jitter 0.05), PBD, 4 iterations, grid rebuild + node-node resolve + floor every iteration, parallel "
+           "collision order", "resolved_pairs_per_substep": pairs / 10, "candidates_per_node_per_iteration": cand / (40 * n),
+           "failed": g.failed, "launches_per_substep": sum(g.launch_counts().values()),
+           "roofline": roofline(g, "collide", per_node, substeps=1, workload="config4", note="one bracket = the resolve pass of one "
+                                "iteration; bytes per node = 32 + 27 x 8 + 16 x candidates looked at"),
+           "roofline_grid_build": roofline(g, "hash", 92.0, substeps=1, workload="config4", note="one bracket = one grid rebuild: range, prefix "
+                                           "sum, emit, radix sort passes, cell index (about 92 B per node, SURVEY 8d)")}
     g.close()
+    return out
+
+
+def run_config2_default_tick(device, dims, steps, with_exact):
+    """The reference's DEFAULT PBD tick on config 2: tickPBD runs the hash rebuild and the node-node pass in every iteration
+    unconditionally (Src/Solver.cpp:81-130); createTetBox gives the nodes radius 0.475.  LAYERED + parallel collision order,
+    and (with_exact) schedule EXACT = the reference's order end to end."""
+    out = {"workload": "config 2 with the node-node pass ON (radius 0.475, gridSpacing 2): what Solver::tickPBD runs by default"}
+    for name, sched, n in (("layered", capi.SCHEDULE_LAYERED, steps), ("exact", capi.SCHEDULE_EXACT, 1)):
+        if name == "exact" and not with_exact:
+            continue
+        g = capi.Solver(scenes.pbd_options(capi, ITERATIONS), device=device)
+        scenes.build_beam(g, dims)
+        scenes.perturb(g, 1234, 0.05)
+        g.set_flag(capi.FLAG_NODE_COLLISIONS, 1)
+        g.set_schedule(sched)
+        g.finalize()
+        el = timed_ticks(g, n, 1 if name == "layered" else 0, lambda: None)
+        out[name] = {"value": n / el, "unit": "substeps/s", "steps": n, "launches_per_substep": sum(g.launch_counts().values()),
+                     "failed": g.failed}
+        g.close()
     return out
 
 
@@ -573,6 +623,109 @@ def scale_profiles(device):
     return out
 
 
+COMPACT_LIMIT = 4096  # bytes: the driver parses the final stdout line; round 2's 30 KB line was dropped
+
+
+def _r(x, digits=4):
+    """Round floats to `digits` significant figures for the compact line."""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x))
+    return x
+
+
+def _pick(d, keys):
+    return {k: _r(d[k]) for k in keys if d and k in d}
+
+
+def compact_line(full):
+    """The ONE stdout line the driver parses: the contract keys, `roofline`, `cpu_baseline` and a dozen scalars.  Everything
+    else (prose, per-frame arrays, per-class latencies, order deviation) lives in bench_full.json."""
+    c = {k: _r(full[k], 6) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data") if k in full}
+    c["config"] = dict(full["config"])
+    c["projections_per_sec"] = _r(full["projections_per_sec"], 6)
+    if full.get("roofline"):
+        c["roofline"] = _pick(full["roofline"], ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us",
+                                                 "bytes_per_launch", "rocprofv3_avg_us", "overhead_clamped"))
+    else:
+        c["roofline"] = None
+    cb = full.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample", "host_cpus", "projections_per_sec"))
+        if cb.get("all_cores"):
+            c["cpu_baseline"]["all_cores"] = _pick(cb["all_cores"], ("value", "cores"))
+    s = {}
+
+    def put(name, *path):
+        d = full
+        for p in path:
+            d = d.get(p) if isinstance(d, dict) else None
+            if d is None:
+                return
+        s[name] = _r(d)
+    put("exact_order", "exact_order", "value")
+    put("coloured", "coloured_schedule", "value")
+    put("pies_tick", "tick_inclusive", "pies_tick_substeps_per_sec")
+    put("async_export", "tick_inclusive", "async_export_substeps_per_sec")
+    put("config2_collisions_on", "config2_default_tick", "layered", "value")
+    put("config2_collisions_on_exact", "config2_default_tick", "exact", "value")
+    put("config3_value", "other_configs", "pd_config3", "value")
+    put("config3_frac_local", "other_configs", "pd_config3", "roofline", "frac")
+    put("config3_frac_spmv", "other_configs", "pd_config3", "roofline_spmv", "frac")
+    put("config4_value", "other_configs", "collisions_config4", "value")
+    put("config4_frac_resolve", "other_configs", "collisions_config4", "roofline", "frac")
+    put("config4_frac_grid", "other_configs", "collisions_config4", "roofline_grid_build", "frac")
+    put("config5_share_value", "other_configs", "pd_config5_per_gpu", "value")
+    put("config5_max_over_median_frame", "other_configs", "pd_config5_per_gpu", "max_over_median_frame")
+    put("pd_contacts_value", "other_configs", "pd_contacts", "value")
+    put("pbd_1m_value", "scale_1m", "pbd_1m", "substeps_per_sec")
+    put("pbd_1m_frac", "scale_1m", "pbd_1m", "roofline", "frac")
+    put("pd_1m_value", "scale_1m", "pd_1m", "substeps_per_sec")
+    put("pd_1m_frac_spmv", "scale_1m", "pd_1m", "roofline_spmv", "frac")
+    c.update(s)
+    if full.get("errors"):
+        c["errors"] = len(full["errors"])
+    c["full_report"] = "bench_full.json"
+    line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    if len(line) > COMPACT_LIMIT:  # never let extras cost the record: drop the scalars, then the sample prose
+        for k in list(s):
+            c.pop(k, None)
+        line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    if len(line) > COMPACT_LIMIT and c.get("cpu_baseline"):
+        c["cpu_baseline"]["sample"] = c["cpu_baseline"]["sample"][:160]
+        c["config"]["workload"] = c["config"]["workload"][:160]
+        line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    assert len(line) <= COMPACT_LIMIT, len(line)
+    return line
+
+
+def _finite(x):
+    """json.dumps(allow_nan=False) refuses nan/inf: the full report maps them to None instead of failing the run."""
+    if isinstance(x, float):
+        return x if np.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    if isinstance(x, np.generic):
+        return _finite(x.item())
+    return x
+
+
+def write_full(full):
+    text = json.dumps(_finite(full), allow_nan=False, indent=1)
+    paths = [os.path.join(ROOT, "bench_full.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_full.json"))
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                f.write(text)
+        except OSError as e:
+            log("could not write %s: %s" % (p, e))
+    print(text, file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -581,16 +734,17 @@ def main():
     ap.add_argument("--dims", type=int, nargs=3, default=list(scenes.L100K))
     ap.add_argument("--schedule", choices=["layered", "coloured", "exact"], default="layered")
     ap.add_argument("--quick", action="store_true", help="headline + roofline + a one-tick CPU baseline only")
+    ap.add_argument("--full", action="store_true", help="also: order deviation, unstructured beam, config 5 share, contact scene, 1M "
+                    "particles, per-class latencies, CPU baselines of configs 3 and 4, the reference-order default tick (minutes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the other schedules' throughput")
-    ap.add_argument("--no-deviation", action="store_true", help="skip the order_deviation measurement")
     ap.add_argument("--no-roofline", action="store_true", help="skip the in-situ timing pass (roofline = null)")
-    ap.add_argument("--no-extras", action="store_true", help="skip BASELINE configs 3-5")
-    ap.add_argument("--no-scale", action="store_true", help="skip the 1M-particle measurements")
-    ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work per baseline sample")
+    ap.add_argument("--no-extras", action="store_true", help="skip BASELINE configs 3 and 4")
+    ap.add_argument("--cpu-budget", type=float, default=8.0, help="seconds of CPU work per baseline sample")
     args = ap.parse_args()
     if args.quick:
-        args.no_exact = args.no_deviation = args.no_extras = args.no_scale = True
+        args.no_exact = args.no_extras = True
+        args.full = False
         args.cpu_budget = min(args.cpu_budget, 1.0)
 
     rank, local_rank, world = dist_env()
@@ -647,15 +801,15 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %dx%dx%d lattice beam, %d particles, %d distance + %d tet-strain "
-                                   "constraints, PBD, %d iterations, 1 substep/tick, one body per GPU"
+                                   "constraints, PBD, %d iterations, 1 substep/tick, collisions off, one body per GPU"
                                    % (dims + (g.count(capi.NODES), g.count(capi.DISTANCE), g.count(capi.TET), ITERATIONS)),
-                       "schedule": args.schedule + (" (PIES_SCHEDULE_DEFAULT: what pies_create / Pies::Solver start with)" if sched == capi.SCHEDULE_DEFAULT else ""),
-                       "parallelism": "replicas x%d" % world, "launches_per_substep": sum(lc.values())},
+                       "schedule": args.schedule, "parallelism": "replicas x%d" % world, "launches_per_substep": sum(lc.values())},
             "projections_per_sec": value * proj,
             "roofline": None if args.no_roofline else roofline(g, dom, per_unit, whole_graph=lc.get(dom, 0) == sum(lc.values()),
                                                                note="algorithmic bytes = the projections and per-node steps "
                                                                "a launch executes (160 B per tet, 52 per distance, 44 per position constraint, 136 per "
                                                                "bend, 48 / 20 / 40 per node for predict / floor / velocity), tallied by the library"),
+            "errors": [],
         }
         if result["roofline"]:
             result["roofline"]["timed_region_us_per_launch"] = 1e6 * (elapsed / args.steps) / max(1, sum(lc.values()))
@@ -667,51 +821,77 @@ def main():
     g.close()
 
     if rank == 0:
-        if world == 1 and not args.quick:
-            log("tick-inclusive figures")
-            result["tick_inclusive"] = tick_inclusive(dims, device_index, sched, max(10, min(args.steps, 100)))
-        if world == 1 and not args.no_exact and args.schedule == "layered":
-            log("coloured schedule")
-            c = build_scene(capi, dims, 1234, schedule=capi.SCHEDULE_COLOURED, device=device_index)
-            c.finalize()
-            steps = max(2, min(args.steps, 50))
-            el = timed_ticks(c, steps, 2, lambda: None)
-            result["coloured_schedule"] = {"value": steps * substeps_per_tick / el, "unit": "substeps/s",
-                                           "launches_per_substep": sum(c.launch_counts().values()), "steps": steps,
-                                           "roofline": roofline(c, "tet", BYTES["tet"], workload="none"),
-                                           "isolated_replay_latencies": replay_latencies(c),
-                                           "note": "schedule COLOURED: one launch per colour class (24 tet + 9 distance colours per iteration)"}
-            c.close()
-        if world == 1 and not args.no_exact and args.schedule != "exact":
-            log("exact schedule")
-            e = build_scene(capi, dims, 1234, schedule=capi.SCHEDULE_EXACT, device=device_index)
-            e.finalize()
-            steps = max(2, min(args.steps, 10))
-            el = timed_ticks(e, steps, 1, lambda: None)
-            result["exact_order"] = {"value": steps * substeps_per_tick / el, "unit": "substeps/s",
-                                     "launches_per_substep": sum(e.launch_counts().values()), "steps": steps,
-                                     "note": "schedule EXACT: the reference's order (containers swept sequentially in insertion order); the device "
-                                             "result is bit-identical to the ORACLE's container-order sweep (tests/test_pbd_parity_gpu.py) - the "
-                                             "oracle restates the reference with its own 3x3 SVD, so against Eigen's JacobiSVD this is a rounding-"
-                                             "level tolerance, not bit equality; one launch per level of the whole-substep dependency DAG"}
-            e.close()
-        if world == 1 and not args.no_deviation:
-            log("order deviation")
-            result["order_deviation"] = order_deviation(device_index)
-        if world == 1 and not args.no_extras:
-            log("configs 3, 4, 5")
-            result["other_configs"] = extra_configs(device_index)
-        if world == 1 and not args.no_scale:
-            log("1M-particle measurements")
-            result["scale_1m"] = scale_profiles(device_index)
+        def section(name, fn, *a, **kw):
+            """An extra must never cost the record: a failing section is logged and named in `errors`."""
+            log(name)
+            try:
+                return fn(*a, **kw)
+            except Exception as e:  # noqa: BLE001
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                result["errors"].append("%s: %s" % (name, e))
+                return None
+
+        one = world == 1
         if not args.no_cpu_baseline:
-            log("CPU baseline")
-            result["cpu_baseline"] = cpu_baseline(dims, args.cpu_budget, with_all_cores=world == 1 and not args.quick)
-            if world == 1 and not args.no_extras:
-                result["other_configs"]["pd_config3"]["cpu_baseline"] = cpu_baseline_pd(scenes.L100K, args.cpu_budget)
-                result["other_configs"]["collisions_config4"]["cpu_baseline"] = cpu_baseline_collisions(args.cpu_budget)
+            result["cpu_baseline"] = section("CPU baseline (config 2)", cpu_baseline, dims, args.cpu_budget,
+                                             with_all_cores=one and not args.quick)
+        if one and not args.quick:
+            result["tick_inclusive"] = section("tick-inclusive figures", tick_inclusive, dims, device_index, sched, max(10, min(args.steps, 50)))
+        if one and not args.no_exact and args.schedule == "layered":
+            def coloured():
+                c = build_scene(capi, dims, 1234, schedule=capi.SCHEDULE_COLOURED, device=device_index)
+                c.finalize()
+                steps = max(2, min(args.steps, 50))
+                el = timed_ticks(c, steps, 2, lambda: None)
+                out = {"value": steps * substeps_per_tick / el, "unit": "substeps/s",
+                       "launches_per_substep": sum(c.launch_counts().values()), "steps": steps,
+                       "roofline": roofline(c, "tet", BYTES["tet"], workload="none"),
+                       "note": "schedule COLOURED: one launch per colour class (24 tet + 9 distance colours per iteration)"}
+                if args.full:
+                    out["isolated_replay_latencies"] = replay_latencies(c)
+                c.close()
+                return out
+            result["coloured_schedule"] = section("coloured schedule", coloured)
+        if one and not args.no_exact and args.schedule != "exact":
+            def exact():
+                e = build_scene(capi, dims, 1234, schedule=capi.SCHEDULE_EXACT, device=device_index)
+                e.finalize()
+                steps = max(2, min(args.steps, 10))
+                el = timed_ticks(e, steps, 1, lambda: None)
+                out = {"value": steps * substeps_per_tick / el, "unit": "substeps/s",
+                       "launches_per_substep": sum(e.launch_counts().values()), "steps": steps,
+                       "note": "schedule EXACT: the reference's order (containers swept sequentially in insertion order); the device "
+                               "result is bit-identical to the ORACLE's container-order sweep (tests/test_pbd_parity_gpu.py) - the "
+                               "oracle restates the reference with its own 3x3 SVD, so against Eigen's JacobiSVD this is a rounding-"
+                               "level tolerance, not bit equality; one launch per level of the whole-substep dependency DAG"}
+                e.close()
+                return out
+            result["exact_order"] = section("exact schedule", exact)
+        if one and not args.no_extras:
+            result["config2_default_tick"] = section("config 2 with the node-node pass on", run_config2_default_tick, device_index, dims,
+                                                     max(2, min(args.steps, 20)), args.full)
+            oc = result["other_configs"] = {}
+            oc["pd_config3"] = section("config 3 (PD)", run_config3, device_index, args.full)
+            oc["collisions_config4"] = section("config 4 (500k particles, node-node collisions)", run_config4, device_index)
+            if args.full:
+                oc["unstructured_config2"] = section("unstructured beam", run_unstructured, device_index)
+                oc["pd_config5_per_gpu"] = section("config 5 share (250k particles, PD, binding contacts)", run_config5_share, device_index)
+                oc["pd_contacts"] = section("PD contact scene", run_pd_contacts, device_index)
+                result["order_deviation"] = section("order deviation", order_deviation, device_index)
+                result["scale_1m"] = section("1M-particle measurements", scale_profiles, device_index)
+                if not args.no_cpu_baseline:
+                    if oc.get("pd_config3"):
+                        oc["pd_config3"]["cpu_baseline"] = section("CPU baseline (config 3)", cpu_baseline_pd, scenes.L100K, args.cpu_budget)
+                    if oc.get("collisions_config4"):
+                        oc["collisions_config4"]["cpu_baseline"] = section("CPU baseline (config 4)", cpu_baseline_collisions, args.cpu_budget)
+                    if result.get("config2_default_tick"):
+                        result["config2_default_tick"]["cpu_baseline"] = section("CPU baseline (config 2, node-node pass on)",
+                                                                                 cpu_baseline_default_tick, dims, args.cpu_budget)
         log("done")
-        print(json.dumps(result))
+        write_full(result)
+        sys.stderr.flush()
+        print(compact_line(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

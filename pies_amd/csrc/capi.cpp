@@ -583,7 +583,7 @@ static int poll_failure(pies_solver* s) {
                : flag & 32 ? "a triangle's swept bounding box is non-finite"
                : flag & 64 ? "point-triangle contact list overflow"
                : flag & 8  ? "node-node collision pass: the wait for a neighbouring group timed out (PIES_COLLIDE_SPIN_LIMIT)"
-               : flag & 128 ? "node-node collision grid: more cell entries than the build reserves (64 per node)"
+               : flag & 128 ? "node-node collision grid: more cell entries than the build reserves (sized from the radii at finalize)"
                           : "a node left the supported cell range (non-finite position)";
   }
   return PIES_OK;

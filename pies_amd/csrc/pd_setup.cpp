@@ -247,23 +247,27 @@ int pd_build(pies_solver* s) {
     uint32_t* d_tris;
     if (int rc = upload(s, s->h_triangles, &d_tris)) return rc;
     T.tris = d_tris;
+    // (cell, triangle) entries: kTriMaxEntries per triangle on average, and never fewer than 2^18 - a handful of wide
+    // triangles (up to 50 cells per axis each, Solver.cpp:974-976) must not run a small scene out of storage
+    const uint64_t entries = std::max<uint64_t>(static_cast<uint64_t>(kTriMaxEntries) * nt, 1ull << 18);
+    if (entries >= (1ull << 31)) return fail(s, PIES_ERR_UNSUPPORTED, "too many surface triangles for the triangle grid");
     uint32_t cap = 1024;
-    while (cap < 2ull * kTriMaxEntries * nt && cap < (1u << 28)) cap <<= 1;
+    while (cap < 2ull * entries) cap <<= 1;
     T.capacity = cap;
     T.mask = cap - 1;
     T.maxContacts = 16 * nt + 1024;
-    T.maxEntries = kTriMaxEntries * nt;
+    T.maxEntries = static_cast<uint32_t>(entries);
     if (int rc = dev_alloc(s, cap, &T.keys)) return rc;
     HIP_TRY(s, hipMemsetAsync(T.keys, 0xFF, static_cast<size_t>(cap) * sizeof(uint64_t), s->stream));
     if (int rc = dev_alloc(s, cap, &T.cnt, true)) return rc;
     if (int rc = dev_alloc(s, cap, &T.start, true)) return rc;
     if (int rc = dev_alloc(s, cap, &T.fill, true)) return rc;
-    if (int rc = dev_alloc(s, static_cast<size_t>(kTriMaxEntries) * nt, &T.used, true)) return rc;
+    if (int rc = dev_alloc(s, static_cast<size_t>(T.maxEntries), &T.used, true)) return rc;
     if (int rc = dev_alloc(s, 16, &T.counters, true)) return rc;
     if (int rc = dev_alloc(s, static_cast<size_t>(kTriMaxEntries) * nt, &T.triSlot, true)) return rc;
     if (int rc = dev_alloc(s, nt, &T.rng, true)) return rc;
-    if (int rc = dev_alloc(s, static_cast<size_t>(kTriMaxEntries) * nt, &T.bucket, true)) return rc;
-    if (int rc = dev_alloc(s, static_cast<size_t>(kTriMaxEntries) * nt, &T.bucketSorted, true)) return rc;
+    if (int rc = dev_alloc(s, static_cast<size_t>(T.maxEntries), &T.bucket, true)) return rc;
+    if (int rc = dev_alloc(s, static_cast<size_t>(T.maxEntries), &T.bucketSorted, true)) return rc;
     if (int rc = dev_alloc(s, nt, &T.cntTri, true)) return rc;
     if (int rc = dev_alloc(s, nt, &T.offTri, true)) return rc;
     if (int rc = dev_alloc(s, T.maxContacts, &T.ids, true)) return rc;

@@ -144,7 +144,7 @@ PIES_DEV bool point_triangle_ccd(F3 ap0, F3 ab0, F3 ac0, F3 ap1, F3 ab1, F3 ac1,
 
 // ---- triangle grid -------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_tri_reset(TriArrays T) {
-  const uint32_t used = T.counters[0], usedNodes = T.counters[4];
+  const uint32_t used = min(T.counters[0], T.maxEntries), usedNodes = T.counters[4];
   for (uint32_t u = blockIdx.x * kBlock + threadIdx.x; u < used; u += gridDim.x * kBlock) {
     const uint32_t s = T.used[u];
     T.keys[s] = kEmpty;
@@ -200,12 +200,16 @@ __global__ void __launch_bounds__(kBlock) k_tri_count(TriArrays T, const float4*
         const uint32_t s = insert_cell(T.keys, T.mask, pack_cell(m[0] + (int)dx, m[1] + (int)dy, m[2] + (int)dz), created);
         if (e < kTriMaxEntries) T.triSlot[t * kTriMaxEntries + e] = s;
         if (s == 0xffffffffu) { atomicOr(&T.counters[3], 2u); continue; }
-        if (created) T.used[atomicAdd(&T.counters[0], 1u)] = s;
+        if (created) {  // (the list of used cells is as long as the entry storage: more distinct cells than that is the
+          const uint32_t u = atomicAdd(&T.counters[0], 1u);  // "more entries than reserved" failure, never a write past it)
+          if (u < T.maxEntries) T.used[u] = s;
+          else atomicOr(&T.counters[3], 2u);
+        }
         atomicAdd(&T.cnt[s], 1u);
       }
 }
 __global__ void __launch_bounds__(kBlock) k_tri_alloc(TriArrays T) {
-  const uint32_t used = T.counters[0];
+  const uint32_t used = min(T.counters[0], T.maxEntries);
   for (uint32_t u = blockIdx.x * kBlock + threadIdx.x; u < used; u += gridDim.x * kBlock) {
     const uint32_t s = T.used[u];
     if (T.cnt[s] > 1000u) atomicOr(&T.counters[3], 16u);  // Solver.cpp:751-755: a bucket of more than 1000 triangles fails the sim
@@ -233,7 +237,7 @@ __global__ void __launch_bounds__(kBlock) k_tri_fill(TriArrays T) {
 }
 __global__ void __launch_bounds__(kBlock) k_tri_sort(TriArrays T) {
   if (T.counters[3]) return;
-  const uint32_t used = T.counters[0];
+  const uint32_t used = min(T.counters[0], T.maxEntries);
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
   for (uint32_t u = wave; u < used; u += nwaves) {

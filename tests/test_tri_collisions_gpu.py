@@ -301,3 +301,40 @@ def test_wide_triangles_use_the_reference_range_limits(pies, oracle):
     assert seen > 20 and not g.failed and not o.failed
     hit = set(int(b) for b in np.unique(o.tri_collisions[:, 1:])) if len(o.tri_collisions) else set()
     assert not (hit & {6, 7, 8})  # nothing ever touches the triangle whose range is empty
+
+
+def test_few_triangles_spanning_many_cells(pies, oracle):
+    """with 2 triangles the list of used cells held 64 x 2 words while one 30 x 30-cell triangle creates
+    ~1 800 cells - a write past the array.  Storage now has a floor (2^18 entries) and the append is bounded: the scene runs
+    like the oracle's."""
+    big = np.float32([[-5.2, 1.30, -5.1], [24.7, 1.32, -5.3], [-5.4, 1.31, 24.6],   # 30 cells in x and z
+                      [-2.3, 0.90, -2.2], [9.4, 0.93, -2.1], [-2.2, 0.91, 9.5]])    # 12 cells
+    g = pies.Solver(pd_options(pies, 4))
+    o = oracle.OracleSolver(pd_options(oracle, 4))
+    for s in (g, o):
+        s.addNodes(big)
+        s.add_triangles([[0, 1, 2], [3, 4, 5]])
+        s.set_prev_positions(s.positions)
+    tol = tol_for(o.positions)
+    for t in range(4):
+        sync_state(g, o)
+        g.tick(); o.tick()
+        assert np.array_equal(g.tri_collisions, o.tri_collisions), t
+        assert np.abs(g.positions - o.positions).max() <= tol, t
+    assert not g.failed and not o.failed
+
+
+def test_more_cells_than_reserved_is_a_latched_failure_not_a_wild_write(pies):
+    """Three slanted triangles spanning 50 cells on every axis = 375 000 (cell, triangle) entries against the 2^18 reserved:
+    the failure latch (like the reference's runaway latches, Solver.cpp:741-755), tick a no-op afterwards."""
+    c = np.float32([[0.2, 0.3, 0.1], [49.6, 49.5, 0.4], [0.3, 49.7, 49.5]])
+    nodes = np.concatenate([c + np.float32([60.0, 0.0, 0.0]) * k for k in range(3)])  # disjoint cells: 375 000 used cells too
+    g = pies.Solver(pd_options(pies, 2))
+    g.addNodes(nodes)
+    g.add_triangles([[0, 1, 2], [3, 4, 5], [6, 7, 8]])
+    g.set_prev_positions(g.positions)
+    g.tick()
+    assert g.failed
+    p = g.positions.copy()
+    g.tick()
+    assert np.array_equal(p, g.positions)
