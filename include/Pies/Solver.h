@@ -67,17 +67,17 @@ public:
   // the constraints were added and the colliding nodes in ascending index - the reference's order, bit for bit the
   // sequential loop; the default (PIES_SCHEDULE_DEFAULT = LAYERED) is the fast one bench.py reports, a sweep over the
   // same constraints in another order (pies_hip.h; DESIGN.md section 3 states how far apart the results are).
-  int schedule = PIES_SCHEDULE_DEFAULT;
+  // -1 (default) leaves the handle's own choice alone: PIES_SCHEDULE_DEFAULT, or what PIES_SCHEDULE=exact|coloured|layered
+  // in the environment selected when the handle was opened.
+  int schedule = -1;
   bool nodeCollisions = true;       // PBD node-node pass (Solver.cpp:81-130)
   bool triangleCollisions = true;   // PD point-triangle contacts (Solver.cpp:693-797)
 
-  Solver() : Solver(SolverOptions{}) {}
-  explicit Solver(const SolverOptions& options, int device = 0) : _options(options) {
-    pies_options_t o;
-    static_assert(sizeof(o) == sizeof(options), "layout");
-    std::memcpy(&o, &options, sizeof(o));
-    if (pies_create(&o, device, &_h) != PIES_OK) throw std::runtime_error("Pies::Solver: no gfx950 HIP device (there is no CPU fallback)");
-  }
+  // Like the reference's (Solver.h:54-55: `Solver() = default`, a converting constructor from the options): constructing a
+  // Solver touches no device.  The device handle is opened by the first call that needs it (add*/create*/tick), which is
+  // where a missing gfx950 device surfaces (std::runtime_error; there is no CPU fallback).
+  Solver() = default;
+  Solver(const SolverOptions& options, int device = 0) : _options(options), _device(device) {}
   Solver(Solver&& rhs) noexcept { *this = std::move(rhs); }
   Solver& operator=(Solver&& rhs) noexcept {
     if (this != &rhs) {
@@ -85,6 +85,8 @@ public:
       _h = rhs._h;
       rhs._h = nullptr;
       _options = rhs._options;
+      _device = rhs._device;
+      for (int k = 0; k < 5; ++k) _pushed[k] = rhs._pushed[k];
       _vertices = std::move(rhs._vertices);
       _lines = std::move(rhs._lines);
       _triangles = std::move(rhs._triangles);
@@ -105,24 +107,19 @@ public:
   }
 
   // Solver.cpp:25-38.  The argument is ignored like in the reference (the step is fixedTimestepSize).
-  void tick(float /*deltaTime*/) {
-    _ck(pies_set_flag(_h, PIES_FLAG_RELEASE_HINGE, releaseHinge ? 1 : 0));
-    _ck(pies_set_flag(_h, PIES_FLAG_NODE_COLLISIONS, nodeCollisions ? 1 : 0));
-    _ck(pies_set_flag(_h, PIES_FLAG_TRIANGLE_COLLISIONS, triangleCollisions ? 1 : 0));
-    _ck(pies_set_schedule(_h, schedule));
-    _ck(pies_tick(_h));
-    _refreshPositions();
-  }
+  void tick(float /*deltaTime*/) { _tickAs(_options.solver); }
+  // Solver.cpp:40, :162: the reference's tickPBD / tickPD run the NAMED solver whatever SolverOptions::solver says.  So do
+  // these: the handle is switched to that solver (pies_set_solver: the device buffers are rebuilt on the next tick if it
+  // differs from the one the last tick ran) and stays there until another tick* asks for the other one.
+  void tickPBD(float /*deltaTime*/) { _tickAs(SolverName::PBD); }
+  void tickPD(float /*deltaTime*/) { _tickAs(SolverName::PD); }
   // tick() in two halves, so that a host can do its own work (or begin the next tick) while this one's positions travel:
   // beginTick queues the substeps and the asynchronous copy of their result, endTick waits for that copy and refreshes
   // getVertices().  At most two ticks may be begun before the first is ended (pies_tick_begin in pies_hip.h).
   void beginTick() {
-    _ck(pies_set_flag(_h, PIES_FLAG_RELEASE_HINGE, releaseHinge ? 1 : 0));
-    _ck(pies_set_flag(_h, PIES_FLAG_NODE_COLLISIONS, nodeCollisions ? 1 : 0));
-    _ck(pies_set_flag(_h, PIES_FLAG_TRIANGLE_COLLISIONS, triangleCollisions ? 1 : 0));
-    _ck(pies_set_schedule(_h, schedule));
+    _pushState(_options.solver);
     uint64_t f = 0;
-    _ck(pies_tick_begin(_h, &f));
+    _ck(pies_tick_begin(_handle(), &f));
     if (_frames[0] == 0) _frames[0] = f; else _frames[1] = f;
   }
   void endTick() {
@@ -132,13 +129,11 @@ public:
     _frames[1] = 0;
     const float* p = nullptr;
     uint32_t n = 0;
-    _ck(pies_export_acquire(_h, f, &p, &n));
+    _ck(pies_export_acquire(_handle(), f, &p, &n));
     const size_t m = n < _vertices.size() ? n : _vertices.size();
     for (size_t i = 0; i < m; ++i) _vertices[i].position = glm::vec3(p[4 * i], p[4 * i + 1], p[4 * i + 2]);
-    _ck(pies_export_release(_h, f));
+    _ck(pies_export_release(_handle(), f));
   }
-  void tickPBD(float dt) { tick(dt); }  // the solver kind is fixed by SolverOptions::solver
-  void tickPD(float dt) { tick(dt); }
 
   const std::vector<Vertex>& getVertices() const { return _vertices; }
   const std::vector<uint32_t>& getLines() const { return _lines; }
@@ -146,7 +141,7 @@ public:
   const SolverOptions& getOptions() const { return _options; }
 
   void clear() {
-    _ck(pies_clear(_h));
+    if (_h) _ck(pies_clear(_h));
     _vertices.clear();
     _lines.clear();
     _triangles.clear();
@@ -156,7 +151,7 @@ public:
   // ---- importing meshes (PrimitiveUtilities.cpp:42-328) ----
   void addNodes(const std::vector<glm::vec3>& vertices) {
     std::vector<float> p = _flatten(vertices);
-    _ck(pies_add_nodes(_h, static_cast<uint32_t>(vertices.size()), p.data(), nullptr));
+    _ck(pies_add_nodes(_handle(), static_cast<uint32_t>(vertices.size()), p.data(), nullptr));
     _syncRenderState();
   }
   void addTriMeshVolume(const std::vector<glm::vec3>&, const std::vector<uint32_t>&, const glm::vec3&, float, float, float, float,
@@ -237,54 +232,54 @@ public:
   }
   void addFixedRegions(const std::vector<glm::mat4>& regionMatrices, float w) {
     std::vector<float> m = _flattenMats(regionMatrices);
-    _ck(pies_add_fixed_regions(_h, static_cast<uint32_t>(regionMatrices.size()), m.data(), w));
+    _ck(pies_add_fixed_regions(_handle(), static_cast<uint32_t>(regionMatrices.size()), m.data(), w));
   }
   void updateFixedRegions(const std::vector<glm::mat4>& regionMatrices) {
     std::vector<float> m = _flattenMats(regionMatrices);
     // the reference asserts and returns on a size mismatch (PrimitiveUtilities.cpp:115-118); here it throws
-    _ck(pies_update_fixed_regions(_h, static_cast<uint32_t>(regionMatrices.size()), m.data()));
+    _ck(pies_update_fixed_regions(_handle(), static_cast<uint32_t>(regionMatrices.size()), m.data()));
   }
   void addLinkedRegions(const std::vector<glm::mat4>& regionMatrices, float w) {
     std::vector<float> m = _flattenMats(regionMatrices);
-    _ck(pies_add_linked_regions(_h, static_cast<uint32_t>(regionMatrices.size()), m.data(), w));
+    _ck(pies_add_linked_regions(_handle(), static_cast<uint32_t>(regionMatrices.size()), m.data(), w));
   }
 
   // ---- primitives (PrimitiveUtilities.cpp:330-1289), reference grid sizes ----
   void createBox(const glm::vec3& translation, float scale, float w) {
     const float t[3] = {translation[0], translation[1], translation[2]};
-    _ck(pies_create_box(_h, 5, 5, 5, t, scale, w, 0, 0, 2u));
+    _ck(pies_create_box(_handle(), 5, 5, 5, t, scale, w, 0, 0, 2u));
     _syncRenderState();
   }
   void createTetBox(const glm::vec3& translation, float scale, const glm::vec3& initialVelocity, float w, float mass, bool hinged) {
     const float t[3] = {translation[0], translation[1], translation[2]}, v[3] = {initialVelocity[0], initialVelocity[1], initialVelocity[2]};
-    if (hinged) _ck(pies_create_tet_box(_h, 10, 2, 10, t, scale, v, w, mass, 3u));
-    else _ck(pies_create_tet_box(_h, 3, 3, 3, t, scale, v, w, mass, 3u));
+    if (hinged) _ck(pies_create_tet_box(_handle(), 10, 2, 10, t, scale, v, w, mass, 3u));
+    else _ck(pies_create_tet_box(_handle(), 3, 3, 3, t, scale, v, w, mass, 3u));
     _syncRenderState();
   }
   void createSheet(const glm::vec3& translation, float scale, float mass, float k) {
     const float t[3] = {translation[0], translation[1], translation[2]};
-    _ck(pies_create_sheet(_h, 20, 20, t, scale, mass, k));
+    _ck(pies_create_sheet(_handle(), 20, 20, t, scale, mass, k));
     _syncRenderState();
   }
   // like the reference, `scale` and `initialVelocity` are accepted and ignored (PrimitiveUtilities.cpp:995,1015)
   void createShapeMatchingBox(const glm::vec3& translation, uint32_t countX, uint32_t countY, uint32_t countZ, float /*scale*/,
                               const glm::vec3& /*initialVelocity*/, float w) {
     const float t[3] = {translation[0], translation[1], translation[2]};
-    _ck(pies_create_shape_matching_box(_h, t, countX, countY, countZ, w));
+    _ck(pies_create_shape_matching_box(_handle(), t, countX, countY, countZ, w));
     _syncRenderState();
   }
   void createShapeMatchingSheet(const glm::vec3& translation, float scale, const glm::vec3& /*initialVelocity*/, float w) {
     const float t[3] = {translation[0], translation[1], translation[2]};
-    _ck(pies_create_shape_matching_sheet(_h, 50, 50, t, scale, w));
+    _ck(pies_create_shape_matching_sheet(_handle(), 50, 50, t, scale, w));
     _syncRenderState();
   }
   void createBendSheet(const glm::vec3& translation, float scale, float w) {
     const float t[3] = {translation[0], translation[1], translation[2]};
-    _ck(pies_create_bend_sheet(_h, 10, 10, t, scale, w));
+    _ck(pies_create_bend_sheet(_handle(), 10, 10, t, scale, w));
     _syncRenderState();
   }
 
-  pies_solver_t* handle() const { return _h; }  // escape hatch to the C ABI (schedules, PCG settings, statistics)
+  pies_solver_t* handle() { return _handle(); }  // escape hatch to the C ABI (schedules, PCG settings, statistics)
 
 private:
   static float _randf() { return static_cast<float>(double(std::rand()) / RAND_MAX); }  // cosmetics only (PrimitiveUtilities.cpp:10-12)
@@ -308,14 +303,14 @@ private:
     std::vector<float> p = _flatten(vertices), v(3 * size_t(n)), r(n, 0.5f), im(n, 1.0f / density);
     for (uint32_t i = 0; i < n; ++i) { v[3 * i] = initialVelocity[0]; v[3 * i + 1] = initialVelocity[1]; v[3 * i + 2] = initialVelocity[2]; }
     uint32_t first = 0;
-    _ck(pies_add_nodes_ex(_h, n, p.data(), v.data(), r.data(), im.data(), &first));
+    _ck(pies_add_nodes_ex(_handle(), n, p.data(), v.data(), r.data(), im.data(), &first));
     std::vector<uint32_t> t(tetIndices), f(surface);
     for (uint32_t& id : t) id += first;
     for (uint32_t& id : f) id += first;
     const uint32_t nt = static_cast<uint32_t>(t.size() / 4);
-    if (strainStiffness != 0.0f) _ck(pies_add_tet_constraints(_h, nt, t.data(), strainStiffness, minStrain, maxStrain));
-    if (volumeStiffness != 0.0f) _ck(pies_add_volume_constraints(_h, nt, t.data(), volumeStiffness, compression, stretching));
-    _ck(pies_add_triangles(_h, static_cast<uint32_t>(f.size() / 3), f.data()));
+    if (strainStiffness != 0.0f) _ck(pies_add_tet_constraints(_handle(), nt, t.data(), strainStiffness, minStrain, maxStrain));
+    if (volumeStiffness != 0.0f) _ck(pies_add_volume_constraints(_handle(), nt, t.data(), volumeStiffness, compression, stretching));
+    _ck(pies_add_triangles(_handle(), static_cast<uint32_t>(f.size() / 3), f.data()));
     _syncRenderState();
   }
   void _ck(int rc) const {
@@ -324,15 +319,15 @@ private:
   // after an add*/create*: new vertices get one colour per primitive, lines/triangles are re-read
   void _syncRenderState() {
     uint32_t n = 0, nl = 0, nt = 0;
-    _ck(pies_count(_h, PIES_NODES, &n));
-    _ck(pies_count(_h, PIES_LINES, &nl));
-    _ck(pies_count(_h, PIES_TRIANGLES, &nt));
+    _ck(pies_count(_handle(), PIES_NODES, &n));
+    _ck(pies_count(_handle(), PIES_LINES, &nl));
+    _ck(pies_count(_handle(), PIES_TRIANGLES, &nt));
     const size_t old = _vertices.size();
     _vertices.resize(n);
     std::vector<float> pos(3 * size_t(n)), rad(n);
     if (n) {
-      _ck(pies_read_nodes(_h, PIES_NODE_POSITION, pos.data(), n));
-      _ck(pies_read_nodes(_h, PIES_NODE_RADIUS, rad.data(), n));
+      _ck(pies_read_nodes(_handle(), PIES_NODE_POSITION, pos.data(), n));
+      _ck(pies_read_nodes(_handle(), PIES_NODE_RADIUS, rad.data(), n));
     }
     const glm::vec3 colour(_randf(), _randf(), _randf());
     const float roughness = _randf(), metallic = static_cast<float>(std::rand() % 2);
@@ -342,9 +337,9 @@ private:
       if (i >= old) { _vertices[i].baseColor = colour; _vertices[i].roughness = roughness; _vertices[i].metallic = metallic; }
     }
     _lines.resize(nl);
-    if (nl) _ck(pies_get_ids(_h, PIES_LINES, _lines.data(), nl));
+    if (nl) _ck(pies_get_ids(_handle(), PIES_LINES, _lines.data(), nl));
     _triangles.resize(nt);
-    if (nt) _ck(pies_get_ids(_h, PIES_TRIANGLES, &_triangles[0].nodeIds[0], 3 * nt));
+    if (nt) _ck(pies_get_ids(_handle(), PIES_TRIANGLES, &_triangles[0].nodeIds[0], 3 * nt));
     renderStateDirty = true;
   }
   // Solver.cpp:157,393: _vertices[i].position = node.position.  pies_tick has already brought the positions to the
@@ -352,11 +347,40 @@ private:
   void _refreshPositions() {
     const uint32_t n = static_cast<uint32_t>(_vertices.size());
     if (!n) return;
-    _ck(pies_read_positions_strided(_h, &_vertices[0].position, sizeof(Vertex), n));
+    _ck(pies_read_positions_strided(_handle(), &_vertices[0].position, sizeof(Vertex), n));
+  }
+
+  // opens the device handle on first use
+  pies_solver_t* _handle() {
+    if (!_h) {
+      pies_options_t o;
+      static_assert(sizeof(o) == sizeof(_options), "layout");
+      std::memcpy(&o, &_options, sizeof(o));
+      if (pies_create(&o, _device, &_h) != PIES_OK) throw std::runtime_error("Pies::Solver: no gfx950 HIP device (there is no CPU fallback)");
+    }
+    return _h;
+  }
+  // the public flags, the schedule and the solver to run reach the handle when they differ from what it was last given
+  void _pushState(SolverName solver) {
+    pies_solver_t* h = _handle();
+    const int now[5] = {releaseHinge ? 1 : 0, nodeCollisions ? 1 : 0, triangleCollisions ? 1 : 0, schedule, static_cast<int>(solver)};
+    if (now[0] != _pushed[0]) _ck(pies_set_flag(h, PIES_FLAG_RELEASE_HINGE, now[0]));
+    if (now[1] != _pushed[1]) _ck(pies_set_flag(h, PIES_FLAG_NODE_COLLISIONS, now[1]));
+    if (now[2] != _pushed[2]) _ck(pies_set_flag(h, PIES_FLAG_TRIANGLE_COLLISIONS, now[2]));
+    if (now[3] != _pushed[3] && now[3] >= 0) _ck(pies_set_schedule(h, now[3]));
+    if (now[4] != _pushed[4]) _ck(pies_set_solver(h, now[4]));
+    for (int k = 0; k < 5; ++k) _pushed[k] = now[k];
+  }
+  void _tickAs(SolverName solver) {
+    _pushState(solver);
+    _ck(pies_tick(_handle()));
+    _refreshPositions();
   }
 
   pies_solver_t* _h = nullptr;
   SolverOptions _options;
+  int _device = 0;
+  int _pushed[5] = {-2, -2, -2, -2, -2};  // releaseHinge, nodeCollisions, triangleCollisions, schedule, solver as last given to the handle
   std::vector<Vertex> _vertices;
   std::vector<uint32_t> _lines;
   std::vector<Triangle> _triangles;

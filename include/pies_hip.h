@@ -103,8 +103,19 @@ enum {
    * the device (bit-identical to the loop, slow).  0: the parallel visiting rule of DESIGN.md section 6 (same contact
    * set and per-pair arithmetic, different order).  Default: 1 under PIES_SCHEDULE_EXACT, 0 otherwise; setting the
    * flag overrides that until the schedule changes. */
-  PIES_FLAG_REFERENCE_COLLISION_ORDER = 3
+  PIES_FLAG_REFERENCE_COLLISION_ORDER = 3,
+  /* The order of the PBD node-node pass, by name (value: PIES_COLLISION_ORDER_*).  Every order resolves the same meetings -
+   * node i meets node j once per grid cell both were inserted into, in each direction, itself included - with the
+   * reference's per-pair arithmetic; the loop is order dependent (Solver.cpp:85-130 moves both nodes at once).
+   *  REFERENCE : the reference's loop (see above); also what every scene with gridSpacing < 2 (r_max + 0.5) runs.
+   *  PAIRS     : default under COLOURED / LAYERED.  A node's meetings with itself first, then the pairs {i < j} in
+   *              ascending order of a 64-bit mix of (i, j), each as its m visits of i to j and m visits of j to i; executed
+   *              by dependency levels, one lane per pair.
+   *  GROUPS    : rounds 1-2's order (nodes grouped by minimum cell, 27 residue classes, ascending index inside a group).
+   * PIES_FLAG_REFERENCE_COLLISION_ORDER = 0 selects PAIRS. */
+  PIES_FLAG_COLLISION_ORDER = 4
 };
+enum { PIES_COLLISION_ORDER_REFERENCE = 0, PIES_COLLISION_ORDER_GROUPS = 1, PIES_COLLISION_ORDER_PAIRS = 2 };
 
 /* node state selectors for pies_read_nodes / pies_write_nodes */
 enum { PIES_NODE_POSITION = 0, PIES_NODE_PREV_POSITION = 1, PIES_NODE_VELOCITY = 2, PIES_NODE_RADIUS = 3, PIES_NODE_INV_MASS = 4 };
@@ -170,6 +181,10 @@ int pies_create_bend_sheet(pies_solver_t* s, uint32_t W, uint32_t H, const float
 
 /* ---- configuration -------------------------------------------------------------------------- */
 int pies_set_flag(pies_solver_t* s, int flag, int value);
+/* Solver::tickPBD / Solver::tickPD (Solver.h:62-63) run the named solver whatever SolverOptions::solver says: this switches
+ * which loop pies_tick runs (PIES_SOLVER_PBD / PIES_SOLVER_PD).  The device buffers of the other loop are built at the next tick
+ * (a full pies_finalize), so alternating every tick is correct but slow.  Node state carries over. */
+int pies_set_solver(pies_solver_t* s, int solver);
 int pies_set_schedule(pies_solver_t* s, int schedule);
 /* PD global step: the reference solves (K + C) x = rhs with a sparse Cholesky factorisation rebuilt every
  * substep (Solver.cpp:258-262,356); here it is a Jacobi-preconditioned CG.  rel_tol bounds ||r||/||rhs|| per
@@ -222,6 +237,16 @@ int pies_collision_pairs(pies_solver_t* s, uint64_t* pairs);
 /* The same plus the candidates the pass looked at (bucket entries visited, the unit of SURVEY 8d's "16 B per candidate
  * neighbour"); both counters restart. */
 int pies_collision_stats(pies_solver_t* s, uint64_t* pairs, uint64_t* candidates);
+/* Pair order (PIES_COLLISION_ORDER_PAIRS): the last pass's dependency levels and listed pairs; since pies_finalize, the passes
+ * that were repeated with the widest slack because a node had moved further than the pair filter allows for, and the passes in
+ * which a node moved further than even that (more than 0.5 in one pass: the result may then miss visits the documented order
+ * makes).  Any pointer may be NULL. */
+/* Pair order: level launches captured per pass (default 96; a single-workgroup kernel finishes deeper orders, slowly).
+ * BASELINE config 4 needs about 75. */
+int pies_set_collision_rounds(pies_solver_t* s, uint32_t rounds);
+/* Diagnostics of the pair order: per node the slack for the next pass, the excursion and the listed partners of the last pass. */
+int pies_debug_pair_state(pies_solver_t* s, float* slack, float* excursion, uint32_t* partners, uint32_t n);
+int pies_get_collision_health(pies_solver_t* s, uint32_t* levels, uint32_t* pairs_listed, uint32_t* passes_repeated, uint32_t* passes_inexact);
 
 /* ---- state access --------------------------------------------------------------------------- */
 int pies_count(const pies_solver_t* s, int what, uint32_t* out);

@@ -41,6 +41,16 @@ inline vec3 normalize(const vec3& a) { return a * (1.0f / std::sqrt(dot(a, a)));
 inline vec3 cross(const vec3& a, const vec3& b) {
   return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
 }
+// Order of the node pairs in collision rule 2 (the device's pair order): murmur3's 64-bit finaliser over (i << 32 | j), i < j.
+// A bijection of the pair, so the order is total; scattered, so that the chains of pairs that share nodes stay short.
+inline uint64_t pair_key(uint32_t i, uint32_t j) {
+  uint64_t k = (static_cast<uint64_t>(i) << 32) | j;
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return k;
+}
+
 inline float clampf(float v, float lo, float hi) { return std::fmin(std::fmax(v, lo), hi); }
 inline float fractf(float v) { return v - std::floor(v); }
 

@@ -808,6 +808,11 @@ struct ora_solver {
   // position).  1: the device's documented rule (DESIGN.md "Node-node collisions"): nodes are visited
   // pass by pass, pass = (min cell mod 3) per axis at hash-build time, then by min cell, then ascending
   // index, and a node queries the cell range it was *inserted* with.  Same per-pair arithmetic.
+  // 2: the device's pair order ("pair order"): the same visits - node i meets node j once per cell that
+  // the ranges they were inserted with share, in each direction, itself included (quirk Q3) - re-ordered pair by pair:
+  // first every node's visits to itself (ascending index), then the unordered pairs {i < j} whose ranges share m > 0 cells
+  // in ascending order of pair_key(i, j), each as m visits of i to j followed by m visits of j to i.  A pure re-ordering of
+  // rule 1's visits; every visit tests the live positions like the reference's loop.
   int collisionRule = 0;
 
   // Optional multi-core replay for the all-cores CPU baseline (bench.py): conflict-free batches of each container
@@ -908,32 +913,72 @@ void ora_solver::tickPBD() {
             return a < b;
           });
         }
+        // one visit of `node` to `other` (:88-126), whatever the order the visits come in
+        auto visit = [&](Node& node, Node* other) {
+          vec3 diff = other->position - node.position;
+          float dist = length(diff);
+          float disp = node.radius + other->radius - dist;
+          if (disp <= 0.0) return;
+          ++stat_collision_pairs;
+          vec3 dir(1.0f, 0.0f, 0.0f);
+          if (dist > 0.00001f) dir = diff / dist;
+          float wSum = node.invMass + other->invMass;
+          node.position += 0.85f * -disp * dir * node.invMass / wSum;
+          other->position += 0.85f * disp * dir * other->invMass / wSum;
+          vec3 relativeVelocity = other->velocity - node.velocity;
+          vec3 perpVel = relativeVelocity - dot(relativeVelocity, dir) * dir;
+          float friction = opt.friction;
+          if (length(perpVel) < opt.staticFrictionThreshold) friction = 1.0f;
+          node.velocity += -friction * perpVel * node.invMass / wSum;
+          other->velocity += friction * perpVel * other->invMass / wSum;
+        };
+        if (collisionRule == 2) {
+          inserted.resize(n);
+          for (size_t k = 0; k < n; ++k) inserted[k] = nodeCompRange(nodes[k], opt.gridSpacing);
+          // cells two inserted ranges share, per axis and in total
+          auto shared = [](int64_t a0, uint32_t la, int64_t b0, uint32_t lb) {
+            const int64_t lo = std::max(a0, b0), hi = std::min(a0 + static_cast<int64_t>(la), b0 + static_cast<int64_t>(lb));
+            return hi > lo ? static_cast<uint32_t>(hi - lo) : 0u;
+          };
+          for (size_t k = 0; k < n; ++k) {  // a node is in every bucket of its own range: it meets itself once per cell
+            const CellRange& r = inserted[k];
+            const uint32_t m = r.lengthX * r.lengthY * r.lengthZ;
+            for (uint32_t t = 0; t < m; ++t) visit(nodes[k], &nodes[k]);
+          }
+          struct Pair { uint64_t key; uint32_t i, j, m; };
+          std::vector<Pair> pairs;
+          for (uint32_t a = 0; a < n; ++a) {
+            const CellRange& ra = inserted[a];
+            // every j > a sharing a cell with a is found in the bucket of the shared box's minimum corner, exactly once
+            for (uint32_t dx = 0; dx < ra.lengthX; ++dx)
+              for (uint32_t dy = 0; dy < ra.lengthY; ++dy)
+                for (uint32_t dz = 0; dz < ra.lengthZ; ++dz) {
+                  const CellId c{ra.minX + dx, ra.minY + dy, ra.minZ + dz};
+                  const std::vector<uint32_t>* bucket = hashNodes.find(c);
+                  if (!bucket) continue;
+                  for (uint32_t b : *bucket) {
+                    if (b <= a) continue;
+                    const CellRange& rb = inserted[b];
+                    if (c.x != std::max(ra.minX, rb.minX) || c.y != std::max(ra.minY, rb.minY) || c.z != std::max(ra.minZ, rb.minZ)) continue;
+                    const uint32_t m = shared(ra.minX, ra.lengthX, rb.minX, rb.lengthX) * shared(ra.minY, ra.lengthY, rb.minY, rb.lengthY) *
+                                       shared(ra.minZ, ra.lengthZ, rb.minZ, rb.lengthZ);
+                    pairs.push_back(Pair{pair_key(a, b), a, b, m});
+                  }
+                }
+          }
+          std::sort(pairs.begin(), pairs.end(), [](const Pair& x, const Pair& y) { return x.key < y.key; });  // (the key is a bijection of (i, j))
+          for (const Pair& pr : pairs) {
+            for (uint32_t t = 0; t < pr.m; ++t) visit(nodes[pr.i], &nodes[pr.j]);
+            for (uint32_t t = 0; t < pr.m; ++t) visit(nodes[pr.j], &nodes[pr.i]);
+          }
+        } else
         for (size_t oi = 0; oi < n; ++oi) {                // :86-130
           const uint32_t ni = collisionOrder.empty() ? static_cast<uint32_t>(oi) : collisionOrder[oi];
           Node& node = nodes[ni];
           if (collisionRule == 1) hashNodes.findCollisions(inserted[ni], scratch);
           else hashNodes.findCollisions(node, opt.gridSpacing, scratch);
-          for (const std::vector<uint32_t>* bucket : scratch) {
-            for (uint32_t otherId : *bucket) {
-              Node* other = &nodes[otherId];
-              vec3 diff = other->position - node.position;
-              float dist = length(diff);
-              float disp = node.radius + other->radius - dist;
-              if (disp <= 0.0) continue;
-              ++stat_collision_pairs;
-              vec3 dir(1.0f, 0.0f, 0.0f);
-              if (dist > 0.00001f) dir = diff / dist;
-              float wSum = node.invMass + other->invMass;
-              node.position += 0.85f * -disp * dir * node.invMass / wSum;
-              other->position += 0.85f * disp * dir * other->invMass / wSum;
-              vec3 relativeVelocity = other->velocity - node.velocity;
-              vec3 perpVel = relativeVelocity - dot(relativeVelocity, dir) * dir;
-              float friction = opt.friction;
-              if (length(perpVel) < opt.staticFrictionThreshold) friction = 1.0f;
-              node.velocity += -friction * perpVel * node.invMass / wSum;
-              other->velocity += friction * perpVel * other->invMass / wSum;
-            }
-          }
+          for (const std::vector<uint32_t>* bucket : scratch)
+            for (uint32_t otherId : *bucket) visit(node, &nodes[otherId]);
           scratch.clear();
         }
       }

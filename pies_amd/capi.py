@@ -17,7 +17,8 @@ POSITION, DISTANCE, TET, VOLUME, BEND, SHAPE, GOAL, TRIANGLES, LINES, NODES = ra
 SCHEDULE_EXACT, SCHEDULE_COLOURED, SCHEDULE_LAYERED = 0, 1, 2
 SCHEDULE_DEFAULT = SCHEDULE_LAYERED  # PIES_SCHEDULE_DEFAULT
 DEVICE_NONE = -1  # PIES_DEVICE_NONE: host-only handle (scenes and schedules, no compute)
-FLAG_RELEASE_HINGE, FLAG_NODE_COLLISIONS, FLAG_TRIANGLE_COLLISIONS, FLAG_REFERENCE_COLLISION_ORDER = 0, 1, 2, 3
+FLAG_RELEASE_HINGE, FLAG_NODE_COLLISIONS, FLAG_TRIANGLE_COLLISIONS, FLAG_REFERENCE_COLLISION_ORDER, FLAG_COLLISION_ORDER = 0, 1, 2, 3, 4
+COLLISION_ORDER_REFERENCE, COLLISION_ORDER_GROUPS, COLLISION_ORDER_PAIRS = 0, 1, 2
 NODE_POSITION, NODE_PREV_POSITION, NODE_VELOCITY, NODE_RADIUS, NODE_INV_MASS = range(5)
 KERNEL_NAMES = ["predict", "position", "distance", "tet", "bend", "floor", "velocity", "hash", "collide",
                 "pd_predict", "pd_local_distance", "pd_local_tet", "pd_local_volume", "pd_rhs", "pd_spmv", "pd_cg_update",
@@ -40,7 +41,7 @@ SYMBOLS = [
     "pies_add_linked_regions", "pies_create_shape_matching_box", "pies_create_shape_matching_sheet", "pies_get_group",
     "pies_get_tri_contacts", "pies_tick_begin", "pies_export_acquire", "pies_export_release",
     "pies_read_positions_strided", "pies_set_pcg_retry", "pies_get_pcg_health", "pies_profile_in_situ",
-    "pies_collision_stats",
+    "pies_collision_stats", "pies_get_collision_health", "pies_set_collision_rounds", "pies_set_solver", "pies_debug_pair_state",
 ]
 
 
@@ -127,6 +128,10 @@ def load():
         "pies_set_pcg_retry": [vp, i32],
         "pies_collision_stats": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
         "pies_get_pcg_health": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), pu, pu],
+        "pies_get_collision_health": [vp, pu, pu, pu, pu],
+        "pies_set_collision_rounds": [vp, u32],
+        "pies_set_solver": [vp, i32],
+        "pies_debug_pair_state": [vp, pf, pf, pu, u32],
         "pies_profile_in_situ": [vp, i32, u32, pu, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)],
     }
     for name, args in sig.items():
@@ -301,6 +306,9 @@ class Solver:
     def set_schedule(self, schedule):
         self._ck(self._L.pies_set_schedule(self._h, schedule))
 
+    def set_solver(self, solver):
+        self._ck(self._L.pies_set_solver(self._h, solver))
+
     def set_pcg(self, rel_tol, max_iters):
         self._ck(self._L.pies_set_pcg(self._h, rel_tol, max_iters))
 
@@ -387,6 +395,22 @@ class Solver:
         a, b = C.c_uint64(), C.c_uint64()
         self._ck(self._L.pies_collision_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def pair_state(self):
+        n = self.count(NODES)
+        sl, ex, dg = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint32)
+        self._ck(self._L.pies_debug_pair_state(self._h, sl.ctypes.data_as(C.POINTER(C.c_float)), ex.ctypes.data_as(C.POINTER(C.c_float)),
+                                               dg.ctypes.data_as(C.POINTER(C.c_uint32)), n))
+        return sl, ex, dg
+
+    def set_collision_rounds(self, rounds):
+        self._ck(self._L.pies_set_collision_rounds(self._h, rounds))
+
+    def collision_health(self):
+        """pair order: levels and listed pairs of the last pass; passes repeated / inexact since finalize"""
+        v = [C.c_uint32() for _ in range(4)]
+        self._ck(self._L.pies_get_collision_health(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("levels", "pairs_listed", "passes_repeated", "passes_inexact"), (x.value for x in v)))
 
     # -- state ---------------------------------------------------------------------------------
     def count(self, what):

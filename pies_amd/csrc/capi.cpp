@@ -233,14 +233,22 @@ static void collision_grid_bound(const pies_solver* s, uint64_t& entries, bool& 
 static void probe_mark(pies_solver* s, int k) {
   if (s->probe && s->probe->kernel == k) s->probe->mark();
 }
-static bool reference_collision_order(const pies_solver* s) {
-  if (!s->collideFast) return true;
-  return s->collisionOrderFlag >= 0 ? s->collisionOrderFlag != 0 : s->schedule == PIES_SCHEDULE_EXACT;
+// PIES_COLLISION_ORDER_*: the reference's loop for ranges wider than two cells per axis (the parallel orders need 2R <= 1),
+// under schedule EXACT, or when asked for; otherwise the pair order (or, when asked for, the group order of rounds 1-2)
+static int collision_order(const pies_solver* s) {
+  if (!s->collideFast) return PIES_COLLISION_ORDER_REFERENCE;
+  if (s->collisionOrderFlag >= 0) return s->collisionOrderFlag;
+  return s->schedule == PIES_SCHEDULE_EXACT ? PIES_COLLISION_ORDER_REFERENCE : PIES_COLLISION_ORDER_PAIRS;
 }
 static uint32_t enqueue_collide(pies_solver* s, bool rearm = false) {
-  if (reference_collision_order(s))
-    return launch_collide_reference(s->stream, s->hash, s->nd, s->opt.gridSpacing, s->opt.friction, s->opt.staticFrictionThreshold);
-  return launch_collide(s->stream, s->hash, s->nd, s->opt.friction, s->opt.staticFrictionThreshold, rearm);
+  switch (collision_order(s)) {
+    case PIES_COLLISION_ORDER_REFERENCE:
+      return launch_collide_reference(s->stream, s->hash, s->nd, s->opt.gridSpacing, s->opt.friction, s->opt.staticFrictionThreshold);
+    case PIES_COLLISION_ORDER_GROUPS:
+      return launch_collide(s->stream, s->hash, s->nd, s->opt.friction, s->opt.staticFrictionThreshold, rearm);
+    default:
+      return launch_collide_pairs(s->stream, s->hash, s->pairs, s->nd, s->opt.friction, s->opt.staticFrictionThreshold, s->pairRounds);
+  }
 }
 
 static void enqueue_layered_substep(pies_solver* s, int only, uint32_t* counts, uint64_t* units) {
@@ -584,6 +592,7 @@ static int poll_failure(pies_solver* s) {
                : flag & 64 ? "point-triangle contact list overflow"
                : flag & 8  ? "node-node collision pass: the wait for a neighbouring group timed out (PIES_COLLIDE_SPIN_LIMIT)"
                : flag & 128 ? "node-node collision grid: more cell entries than the build reserves (sized from the radii at finalize)"
+               : flag & 256 ? "node-node collision pass: more than 512 nodes within reach of one node, or more pairs than reserved (runaway pile-up)"
                           : "a node left the supported cell range (non-finite position)";
   }
   return PIES_OK;
@@ -717,8 +726,11 @@ int pies_get_options(const pies_solver_t* s, pies_options_t* out) {
 
 int pies_set_flag(pies_solver_t* s, int flag, int value) {
   if (!s) return PIES_ERR_INVALID;
-  if (flag == PIES_FLAG_REFERENCE_COLLISION_ORDER) {
-    const int v = value != 0 ? 1 : 0;
+  if (flag == PIES_FLAG_REFERENCE_COLLISION_ORDER || flag == PIES_FLAG_COLLISION_ORDER) {
+    int v = value;
+    if (flag == PIES_FLAG_REFERENCE_COLLISION_ORDER) v = value != 0 ? PIES_COLLISION_ORDER_REFERENCE : PIES_COLLISION_ORDER_PAIRS;
+    if (v != PIES_COLLISION_ORDER_REFERENCE && v != PIES_COLLISION_ORDER_GROUPS && v != PIES_COLLISION_ORDER_PAIRS)
+      return fail(s, PIES_ERR_INVALID, "pies_set_flag: unknown collision order");
     if (s->collisionOrderFlag != v) {
       s->collisionOrderFlag = v;
       if (!s->sceneDirty) s->graphDirty = true;  // same buffers, another resolve kernel in the captured substep
@@ -741,6 +753,17 @@ int pies_set_flag(pies_solver_t* s, int flag, int value) {
       if (int rc = scene_sync_host(s)) return rc;
       s->sceneDirty = true;
     }
+  }
+  return PIES_OK;
+}
+
+int pies_set_solver(pies_solver_t* s, int solver) {
+  if (!s) return PIES_ERR_INVALID;
+  if (solver != PIES_SOLVER_PBD && solver != PIES_SOLVER_PD) return fail(s, PIES_ERR_INVALID, "pies_set_solver: unknown solver");
+  if (solver != s->opt.solver) {
+    if (int rc = scene_sync_host(s)) return rc;
+    s->opt.solver = solver;
+    s->sceneDirty = true;
   }
   return PIES_OK;
 }
@@ -982,6 +1005,7 @@ int pies_finalize(pies_solver_t* s) {
     uint64_t entries = 0;
     bool fast = true;
     collision_grid_bound(s, entries, fast);
+    if (n >= (1u << 25)) return fail(s, PIES_ERR_UNSUPPORTED, "node-node collisions: more than 2^25 nodes");
     if (entries > 0x7fff0000ull) return fail(s, PIES_ERR_UNSUPPORTED, "node-node collisions: more than 2^31 (cell, node) entries (gridSpacing is tiny against the radii)");
     H.maxEntries = static_cast<uint32_t>(entries + 64);
     uint32_t cap = 1024;
@@ -1008,6 +1032,29 @@ int pies_finalize(pies_solver_t* s) {
     if (int rc = dev_alloc(s, std::min<uint64_t>(cap, H.maxEntries), &H.used, true)) return rc;
     if (int rc = dev_alloc(s, kHashCounters, &H.counters, true)) return rc;
     if (int rc = dev_alloc(s, 27ull * n, &H.passList, true)) return rc;
+    s->pairs = PairArrays{};
+    if (s->collideFast) {  // pair order: a node's list of partners (kPairStride slots of its own + a pool), work lists
+
+      PairArrays& P = s->pairs;
+      P.n = n;
+      // list entries: 96 per node on average (BASELINE config 4 lists 15-50), in kPairPools pools; a small scene may list every
+      // pair (a body that has collapsed into a few cells: quirk Q2 does that to a tetrahedral PBD body within a tick)
+      const uint64_t everyPair = std::min<uint64_t>(static_cast<uint64_t>(n) * n, 1ull << 26);
+      P.poolCap = static_cast<uint32_t>(std::min<uint64_t>((std::max<uint64_t>(96ull * n, everyPair) + 65536) / kPairPools + 4096, 0x7fff0000ull / kPairPools));
+      if (int rc = dev_alloc(s, 4ull * n, &P.node, true)) return rc;
+      if (int rc = dev_alloc(s, n, &P.vel0)) return rc;
+      if (int rc = dev_alloc(s, n, &P.exc, true)) return rc;
+      if (int rc = dev_alloc(s, static_cast<size_t>(P.poolCap) * kPairPools, &P.nbr)) return rc;
+      P.frCap = n / 32 + 256;  // a chunk of 64 lanes appends at most 128 nodes to the one sub-list it is dealt to
+      for (int b = 0; b < 2; ++b)
+        if (int rc = dev_alloc(s, static_cast<size_t>(P.frCap) * kPairLists, &P.fr[b])) return rc;
+      if (int rc = dev_alloc(s, 3ull * kPairLists, &P.frCount, true)) return rc;
+      if (int rc = dev_alloc(s, kPairStripes, &P.hitStripe, true)) return rc;
+      if (int rc = dev_alloc(s, n, &P.bq)) return rc;
+      if (int rc = dev_alloc(s, n, &P.left, true)) return rc;
+      if (int rc = dev_alloc(s, kPairPools, &P.pool, true)) return rc;
+      if (int rc = dev_alloc(s, kPairWords, &P.ctl, true)) return rc;
+    }
     HIP_TRY(s, hipStreamSynchronize(s->stream));
   }
   if (isPD) {
@@ -1289,6 +1336,45 @@ int pies_collision_pairs(pies_solver_t* s, uint64_t* pairs) {
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   HIP_TRY(s, hipMemsetAsync(s->hash.counters + 31, 0, sizeof(v), s->stream));
   *pairs = v;
+  return PIES_OK;
+}
+
+int pies_debug_pair_state(pies_solver_t* s, float* slack, float* excursion, uint32_t* degree, uint32_t n) {
+  if (!s || !s->pairs.ctl || n != s->pairs.n) return PIES_ERR_INVALID;
+  std::vector<float4> node(4ull * n);
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  HIP_TRY(s, hipMemcpy(node.data(), s->pairs.node, node.size() * sizeof(float4), hipMemcpyDeviceToHost));
+  if (excursion) HIP_TRY(s, hipMemcpy(excursion, s->pairs.exc, n * sizeof(float), hipMemcpyDeviceToHost));
+  for (uint32_t i = 0; i < n; ++i) {
+    if (slack) slack[i] = node[4ull * i + 2].w;
+    if (degree) std::memcpy(&degree[i], &node[4ull * i + 3].y, sizeof(uint32_t));
+  }
+  return PIES_OK;
+}
+
+int pies_set_collision_rounds(pies_solver_t* s, uint32_t rounds) {
+  if (!s) return PIES_ERR_INVALID;
+  if (rounds > 4096) return fail(s, PIES_ERR_INVALID, "pies_set_collision_rounds: at most 4096");
+  if (rounds != s->pairRounds) {
+    s->pairRounds = rounds;
+    if (!s->sceneDirty) s->graphDirty = true;
+  }
+  return PIES_OK;
+}
+
+int pies_get_collision_health(pies_solver_t* s, uint32_t* rounds, uint32_t* pairs_listed, uint32_t* passes_repeated, uint32_t* passes_inexact) {
+  if (!s) return PIES_ERR_INVALID;
+  uint32_t v[kPairWords] = {0};
+  if (s->pairs.ctl) {
+    HIP_TRY(s, hipSetDevice(s->device));
+    HIP_TRY(s, hipMemcpyAsync(v, s->pairs.ctl, sizeof(v), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+  }
+  if (rounds) *rounds = v[kPairRounds];
+  if (pairs_listed) *pairs_listed = v[kPairEdges] / 2;
+  if (passes_repeated) *passes_repeated = v[kPairRetries];
+  if (passes_inexact) *passes_inexact = v[kPairInexact];
   return PIES_OK;
 }
 

@@ -36,75 +36,14 @@
 
 #include "cell_table.h"
 #include "hash_kernels.h"
+#include "hash_device.h"
 
 namespace pies {
 
 constexpr int kBlock = 256;
 constexpr uint32_t kMaxBucket = 2048;  // nodes overlapping one cell before the simulation is declared failed
-constexpr uint32_t kMinFlag = 0x80000000u, kNodeMask = 0x7fffffffu;
 
 static inline dim3 grid_for(uint32_t n) { return dim3((n + kBlock - 1) / kBlock); }
-
-// ---- the cell box of a build: origin and bits per axis of the packed key --------------------------------------
-struct GridBox {
-  int mn[3];
-  uint32_t ext[3];   // max - min per axis
-  uint32_t bits[3];
-  bool empty;
-};
-PIES_DEV GridBox grid_box(const uint32_t* __restrict__ counters) {
-  GridBox B;
-  B.empty = false;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    B.mn[a] = static_cast<int>(counters[kCounterBoxMin + a]);
-    const int mx = static_cast<int>(counters[kCounterBoxMax + a]);
-    if (mx < B.mn[a]) B.empty = true;
-    B.ext[a] = B.empty ? 0u : static_cast<uint32_t>(mx - B.mn[a]);
-    B.bits[a] = B.ext[a] ? 32u - static_cast<uint32_t>(__builtin_clz(B.ext[a])) : 0u;
-  }
-  return B;
-}
-PIES_DEV uint32_t grid_passes(const GridBox& B) { return (B.bits[0] + B.bits[1] + B.bits[2] + 7u) >> 3; }
-PIES_DEV bool in_box(const GridBox& B, int x, int y, int z) {
-  return !B.empty && x >= B.mn[0] && y >= B.mn[1] && z >= B.mn[2] && static_cast<uint32_t>(x - B.mn[0]) <= B.ext[0] &&
-         static_cast<uint32_t>(y - B.mn[1]) <= B.ext[1] && static_cast<uint32_t>(z - B.mn[2]) <= B.ext[2];
-}
-PIES_DEV uint64_t box_key(const GridBox& B, int x, int y, int z) {  // in_box(x, y, z)
-  return (static_cast<uint64_t>(static_cast<uint32_t>(x - B.mn[0])) << (B.bits[1] + B.bits[2])) |
-         (static_cast<uint64_t>(static_cast<uint32_t>(y - B.mn[1])) << B.bits[2]) | static_cast<uint64_t>(static_cast<uint32_t>(z - B.mn[2]));
-}
-PIES_DEV void box_cell(const GridBox& B, uint64_t key, int& x, int& y, int& z) {
-  z = B.mn[2] + static_cast<int>(key & ((1ull << B.bits[2]) - 1ull));
-  y = B.mn[1] + static_cast<int>((key >> B.bits[2]) & ((1ull << B.bits[1]) - 1ull));
-  x = B.mn[0] + static_cast<int>(key >> (B.bits[1] + B.bits[2]));
-}
-// bucket of cell (x, y, z): index slot or ~0
-PIES_DEV uint32_t find_bucket(const HashArrays& H, const GridBox& B, int x, int y, int z) {
-  if (!in_box(B, x, y, z)) return 0xffffffffu;
-  return find_cell(H.keys, H.mask, box_key(B, x, y, z));
-}
-
-// NodeCompRange (Solver.cpp:877-901).  Returns false for a non-finite position; an over-long range is empty, like the
-// reference's (:896-898).
-PIES_DEV bool node_range(float px, float py, float pz, float radius, float scale, int& mx, int& my, int& mz, uint32_t& lx, uint32_t& ly,
-                         uint32_t& lz) {
-  const float R = (radius + 0.5f) / scale;
-  const float gx = px / scale - R, gy = py / scale - R, gz = pz / scale - R;
-  const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
-  const float twoR = 2 * R;
-  const float cx = ceilf((gx - fx) + twoR), cy = ceilf((gy - fy) + twoR), cz = ceilf((gz - fz) + twoR);
-  const bool finite = (fabsf(fx) < 1.0e6f) && (fabsf(fy) < 1.0e6f) && (fabsf(fz) < 1.0e6f) && (cx >= 0.0f) && (cy >= 0.0f) && (cz >= 0.0f) &&
-                      (cx < 1.0e6f) && (cy < 1.0e6f) && (cz < 1.0e6f);  // false for NaN as well
-  mx = finite ? static_cast<int>(fx) : 0;
-  my = finite ? static_cast<int>(fy) : 0;
-  mz = finite ? static_cast<int>(fz) : 0;
-  lx = finite ? static_cast<uint32_t>(cx) : 0u;
-  ly = finite ? static_cast<uint32_t>(cy) : 0u;
-  lz = finite ? static_cast<uint32_t>(cz) : 0u;
-  if (lx > 50 || ly > 50 || lz > 50) lx = ly = lz = 0;
-  return finite;
-}
 
 // ---- reset: only the index slots the previous build used; counters; bounding box --------------------------------
 __global__ void __launch_bounds__(kBlock) k_grid_reset(HashArrays H) {
@@ -282,7 +221,9 @@ __global__ void __launch_bounds__(kBlock) k_grid_emit(HashArrays H, uint32_t n) 
     for (uint32_t dy = 0; dy < ly; ++dy)
       for (uint32_t dz = 0; dz < lz; ++dz, ++e) {
         H.key[0][base + e] = box_key(B, rg.x + static_cast<int>(dx), rg.y + static_cast<int>(dy), rg.z + static_cast<int>(dz));
-        H.val[0][base + e] = i | (e == 0 ? kMinFlag : 0u);  // e == 0: the node's minimum cell
+        const uint32_t side = (dx ? 4u : 0u) | (dy ? 2u : 0u) | (dz ? 1u : 0u);
+        const uint32_t twoLong = (lx == 2u ? 4u : 0u) | (ly == 2u ? 2u : 0u) | (lz == 2u ? 1u : 0u);
+        H.val[0][base + e] = i | (twoLong << kLongShift) | (side << kSideShift) | (e == 0 ? kMinFlag : 0u);  // e == 0: the node's minimum cell
       }
 }
 

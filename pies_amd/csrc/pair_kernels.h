@@ -1,0 +1,54 @@
+// Launch wrappers of the pair-ordered node-node resolve (pair_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "hash_kernels.h"
+#include "kernels.h"
+
+namespace pies {
+
+// control words of a pass
+constexpr uint32_t kPairLeft = 3;       // nodes that left their slack in this pass (entries of `left`)
+constexpr uint32_t kPairFlags = 4;      // 1: an unlisted pair may have touched (k_pair_verify)  2: list storage overflow
+constexpr uint32_t kPairRetry = 5;      // the pass is being repeated
+constexpr uint32_t kPairRounds = 6;     // rounds the last pass needed (diagnostics)
+constexpr uint32_t kPairRetries = 7;    // lifetime: passes repeated
+constexpr uint32_t kPairInexact = 8;    // lifetime: passes in which a node left its slack in the repeat as well (the result may differ
+                                        // from the documented order by visits that were filtered out)
+constexpr uint32_t kPairEdges = 9;      // pairs listed by the last pass (diagnostics)
+constexpr uint32_t kPairSavedPairs = 10, kPairSavedCand = 11 /* and 12 */;  // statistics counters at the start of the pass
+constexpr uint32_t kPairWords = 16;
+
+constexpr uint32_t kPairLists = 64;     // the frontier is kept as this many sub-lists: a wavefront appends to one of them, so that the
+                                        // appends of a level are spread over 64 counters (same-address atomics take ~8 ns each)
+constexpr uint32_t kPairStripes = 1024; // resolved-pair statistics are counted in stripes for the same reason
+constexpr uint32_t kPairPools = 64;     // list storage is handed out from this many pools (a wavefront of the list kernel uses one)
+
+struct PairArrays {
+  uint32_t n;
+  uint32_t poolCap;        // list entries per pool
+  float4 *node;            // 4 per node, one cache line: [0] x, y, z, invMass  [1] vx, vy, vz, radius  [2] position when the grid was
+                           // built (the filter's distances, the slack test, the repeat), slack (how far the node may stray from there before
+                           // the filtered lists stop being exact; persistent)  [3] first list entry, entries, current entry | round in
+                           // which the node got there << 16, the current entry itself
+  float4 *vel0;            // velocities when the pass started (for the repeat)
+  uint32_t *exc;           // per node: how far it has strayed in this pass (float bits)
+  uint32_t *nbr;           // list entries: other node | (shared cells - 1) << 28, a node's entries ascending by pair key
+  float4 *bq;              // per node: position when the grid was built, radius + slack: all the list kernel gathers of a candidate
+  uint32_t frCap;          // entries of one sub-list of the frontier
+  uint32_t *fr[2];         // frontier: the nodes that moved on to a new entry in the last round, kPairLists sub-lists of frCap entries
+  uint32_t *frCount;       // [3][kPairLists] entries of the sub-lists of round r, at r % 3
+  uint32_t *hitStripe;     // resolved pairs of this pass, striped
+  uint32_t *left;          // the nodes that left their slack in this pass
+  uint32_t *pool;          // entries handed out per pool
+  uint32_t* ctl;
+};
+
+// One pass of Solver.cpp:85-130 in the pair order: save, lists, start, `rounds` level launches, the tail
+// that finishes whatever levels are left, and the (normally skipped) repeat with the widest slack.  Returns the launches.
+uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArrays& P, const NodeArrays& nd, float friction,
+                              float staticThreshold, uint32_t rounds);
+
+}  // namespace pies

@@ -1,0 +1,706 @@
+// Node-node resolve of the PBD substep (Src/Solver.cpp:85-130) in the PAIR ORDER.
+//
+// The reference's loop lets node i meet node j once per grid cell both were inserted into, in each direction, itself
+// included (quirk Q3), and resolves every overlapping meeting at once.  The result depends on the order of the meetings
+// that share a node and on nothing else.  The pair order keeps every meeting and re-orders them pair by pair:
+//   1. every node's meetings with itself (one per cell of its range);
+//   2. the unordered pairs {i < j} whose inserted ranges share m > 0 cells, in ascending order of pair_key(i, j) (a 64-bit
+//      mix of the two indices: a total order that scatters neighbouring pairs), each as m visits of i to j followed by m
+//      visits of j to i.  Every visit tests the live positions, like the reference's.
+// The oracle replays exactly this with a sort and a sequential loop (FLAG_COLLISION_RULE = 2).  On the device the order is
+// executed by dependency levels: a pair's turn comes when it is the next unprocessed pair in the key-sorted lists of BOTH
+// its nodes, and the pairs whose turn has come share no node, so a level is one data-parallel launch.  A scattered key keeps the chains short: 60-80 levels for the 4.5 M pairs
+// of BASELINE config 4, against 27 passes x 350 dependent visits per group in the group order (k_collide_flow).
+//
+// Filter.  Of the ~300 nodes that share a cell with a node only ~20 are near enough to ever touch it.  A pair is listed
+// only if its distance at grid-build time is below r_i + r_j + s_i + s_j, and every node is checked to stay within its
+// slack s_i of its build-time position whenever it has been moved: while that holds, every unlisted visit is a miss
+// (|p_i - p_j| >= d0 - s_i - s_j >= r_i + r_j) and the result is that of the full order.  The slack is per node and follows
+// what the node did in the passes before.  A node that leaves its slack is put on a list; after the pass one wavefront per
+// listed node looks at the unlisted nodes it shares a cell with and tests, with the largest excursions both nodes had in the
+// pass, whether the two can have touched (d0 - e_i - e_j < r_i + r_j).  Only if one such pair exists is the pass repeated from
+// the saved state, the nodes that left their slack now listing every node they share a cell with; a repeat that fails the
+// same test is counted (pies_get_collision_health: passes_inexact).
+#include <climits>
+#include <cstdint>
+
+#include "dev_math.h"
+#include "hash_device.h"
+#include "pair_kernels.h"
+
+namespace pies {
+
+constexpr int kBlock = 256;
+constexpr uint32_t kMaxCand = 512;                         // distinct nodes of a group's 2x2x2 cells (BASELINE config 4: 216-343)
+constexpr uint32_t kMaxOwn = 256;                          // nodes of one group
+constexpr uint32_t kMaxDeg = 1024;                         // listed partners of one node
+constexpr uint32_t kPairNodeMask = 0x0fffffffu;            // partner index; the four bits above hold (shared cells - 1)
+constexpr int kBuildWaves = 2;                            // wavefronts of a workgroup of the list kernel: one group at a time
+
+PIES_DEV uint64_t pair_key(uint32_t i, uint32_t j) {  // i < j; murmur3's 64-bit finaliser (oracle/ora_math.h: pair_key)
+  uint64_t k = (static_cast<uint64_t>(i) << 32) | j;
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return k;
+}
+
+// slack of a node after a pass in which it strayed `exc` from its build-time position
+PIES_DEV float next_slack(float exc, float previous, float r) {
+  const float want = fmaxf(2.0f * exc + 0.1f * r, 0.4f * r);
+  return previous < 1.0e30f ? fmaxf(want, 0.95f * previous) : want;
+}
+
+// ---- one visit (Solver.cpp:88-126), all of it in one lane -------------------------------------------------------------
+struct NodeState {
+  float px, py, pz, w, vx, vy, vz, r;
+};
+// node a visits node b (a != b).  Returns whether the pair was resolved.
+PIES_DEV bool visit(NodeState& a, NodeState& b, float friction, float staticThreshold) {
+  const float dx = b.px - a.px, dy = b.py - a.py, dz = b.pz - a.pz;
+  const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float disp = a.r + b.r - dist;
+  if (!(disp > 0.0f)) return false;
+  float ux = 1.0f, uy = 0.0f, uz = 0.0f;
+  if (dist > 0.00001f) { ux = dx / dist; uy = dy / dist; uz = dz / dist; }
+  const float wSum = a.w + b.w;
+  const float sa = 0.85f * -disp, sb = 0.85f * disp;
+  const float rx = b.vx - a.vx, ry = b.vy - a.vy, rz = b.vz - a.vz;
+  const float rd = rx * ux + ry * uy + rz * uz;
+  const float qx = rx - rd * ux, qy = ry - rd * uy, qz = rz - rd * uz;
+  float fr = friction;
+  if (staticThreshold > 0.0f)  // sqrt(x) < t is false for every t <= 0
+    if (sqrtf(qx * qx + qy * qy + qz * qz) < staticThreshold) fr = 1.0f;
+  a.px += ((sa * ux) * a.w) / wSum; a.py += ((sa * uy) * a.w) / wSum; a.pz += ((sa * uz) * a.w) / wSum;
+  b.px += ((sb * ux) * b.w) / wSum; b.py += ((sb * uy) * b.w) / wSum; b.pz += ((sb * uz) * b.w) / wSum;
+  a.vx += ((-fr * qx) * a.w) / wSum; a.vy += ((-fr * qy) * a.w) / wSum; a.vz += ((-fr * qz) * a.w) / wSum;
+  b.vx += ((fr * qx) * b.w) / wSum; b.vy += ((fr * qy) * b.w) / wSum; b.vz += ((fr * qz) * b.w) / wSum;
+  return true;
+}
+// a node meets itself (quirk Q3): `other` aliases `node`, so the second update of each line sees the first
+PIES_DEV bool visit_self(NodeState& a, float friction, float staticThreshold) {
+  const float dx = a.px - a.px, dy = a.py - a.py, dz = a.pz - a.pz;
+  const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float disp = a.r + a.r - dist;
+  if (!(disp > 0.0f)) return false;
+  float ux = 1.0f, uy = 0.0f, uz = 0.0f;
+  if (dist > 0.00001f) { ux = dx / dist; uy = dy / dist; uz = dz / dist; }
+  const float wSum = a.w + a.w;
+  const float sa = 0.85f * -disp, sb = 0.85f * disp;
+  const float rx = a.vx - a.vx, ry = a.vy - a.vy, rz = a.vz - a.vz;
+  const float rd = rx * ux + ry * uy + rz * uz;
+  const float qx = rx - rd * ux, qy = ry - rd * uy, qz = rz - rd * uz;
+  float fr = friction;
+  if (staticThreshold > 0.0f)
+    if (sqrtf(qx * qx + qy * qy + qz * qz) < staticThreshold) fr = 1.0f;
+  a.px += ((sa * ux) * a.w) / wSum; a.py += ((sa * uy) * a.w) / wSum; a.pz += ((sa * uz) * a.w) / wSum;
+  a.px += ((sb * ux) * a.w) / wSum; a.py += ((sb * uy) * a.w) / wSum; a.pz += ((sb * uz) * a.w) / wSum;
+  a.vx += ((-fr * qx) * a.w) / wSum; a.vy += ((-fr * qy) * a.w) / wSum; a.vz += ((-fr * qz) * a.w) / wSum;
+  a.vx += ((fr * qx) * a.w) / wSum; a.vy += ((fr * qy) * a.w) / wSum; a.vz += ((fr * qz) * a.w) / wSum;
+  return true;
+}
+// ---- the pass's own node records: 64 bytes = one cache line per node ------------------------------------------------------
+//   [0] x, y, z, invMass          [1] vx, vy, vz, radius          [2] position when the grid was built (x, y, z), slack
+//   [3] first list entry, entries, current entry | round in which the node got there << 16, the current entry itself
+// A level touches a node through this line only (the level kernels are bound by the number of scattered memory transactions).
+PIES_DEV NodeState load_node(const float4* __restrict__ node, uint32_t i) {
+  const float4 p = node[4u * i], v = node[4u * i + 1u];
+  return NodeState{p.x, p.y, p.z, p.w, v.x, v.y, v.z, v.w};
+}
+PIES_DEV void store_node(float4* node, uint32_t i, const NodeState& a) {
+  node[4u * i] = make_float4(a.px, a.py, a.pz, a.w);
+  node[4u * i + 1u] = make_float4(a.vx, a.vy, a.vz, a.r);
+}
+PIES_DEV uint4 load_rec(const float4* __restrict__ node, uint32_t i) { return reinterpret_cast<const uint4*>(node)[4u * i + 3u]; }
+PIES_DEV void store_rec(float4* node, uint32_t i, uint4 r) { reinterpret_cast<uint4*>(node)[4u * i + 3u] = r; }
+// a node has been moved: its excursion from the position the lists were built from (p0.xyz) is kept as a maximum; the first time
+// it leaves its slack (p0.w) it is put on the list k_pair_verify works through
+PIES_DEV void note_excursion(const PairArrays& P, uint32_t i, const NodeState& a, const float4 p0) {
+  const float dx = a.px - p0.x, dy = a.py - p0.y, dz = a.pz - p0.z;
+  const float e = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float thr = 0.999f * p0.w;
+  const float old = __uint_as_float(atomicMax(&P.exc[i], __float_as_uint(e)));  // (non-negative floats order like their bits; NaN sorts above everything)
+  if (!(e <= thr) && old <= thr) {
+    const uint32_t at = atomicAdd(&P.ctl[kPairLeft], 1u);
+    if (at < P.n) P.left[at] = i;
+  }
+}
+// resolved pairs are counted per wavefront into one of kPairStripes words (k_pair_check adds them up)
+PIES_DEV void count_hits(const PairArrays& P, uint32_t hits, int lane) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) hits += __shfl_xor(hits, o, 64);
+  if (lane == 0 && hits) atomicAdd(&P.hitStripe[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % kPairStripes], hits);
+}
+// every node's meetings with itself: it is in every bucket of its own range, once per cell (quirk Q3)
+PIES_DEV uint32_t self_visits(const HashArrays& H, const PairArrays& P, uint32_t i, NodeState& a, const float4 p0, float friction, float staticThreshold) {
+  const int4 rg = H.rng[i];
+  const uint32_t m = (rg.w & 0xff) * ((rg.w >> 8) & 0xff) * ((rg.w >> 16) & 0xff);
+  uint32_t hits = 0;
+  for (uint32_t q = 0; q < m; ++q) hits += visit_self(a, friction, staticThreshold) ? 1u : 0u;
+  if (hits) note_excursion(P, i, a, p0);
+  return hits;
+}
+
+// ---- save: the state the pass starts from, control words, the meetings of every node with itself -------------------------
+__global__ void __launch_bounds__(kBlock) k_pair_save(HashArrays H, PairArrays P, const float4* __restrict__ pos, const float4* __restrict__ vel,
+                                                      const float* __restrict__ radius, float friction, float staticThreshold) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  if (i == 0) {
+    P.ctl[kPairFlags] = 0;
+    P.ctl[kPairRetry] = 0;
+    P.ctl[kPairRounds] = 0;
+    P.ctl[kPairEdges] = 0;
+    P.ctl[kPairSavedCand] = H.counters[kCounterCandidates];
+    P.ctl[kPairSavedCand + 1] = H.counters[kCounterCandidates + 1];
+  }
+  if (i < kPairPools) P.pool[i] = 0;
+  if (i < 3u * kPairLists) P.frCount[i] = 0;
+  uint32_t hits = 0;
+  if (i < P.n && !H.counters[kCounterFlags]) {
+    const float4 p = pos[i], v = vel[i];
+    const float r = radius[i];
+    float sl = P.node[4u * i + 2u].w;
+    if (!(sl > 0.0f)) sl = 0.5f * r;  // first pass after pies_finalize
+    const float4 p0 = make_float4(p.x, p.y, p.z, sl);
+    P.node[4u * i + 2u] = p0;
+    P.bq[i] = make_float4(p.x, p.y, p.z, r + sl);
+    P.vel0[i] = v;
+    P.exc[i] = 0u;
+    NodeState a{p.x, p.y, p.z, p.w, v.x, v.y, v.z, r};
+    hits = self_visits(H, P, i, a, p0, friction, staticThreshold);
+    store_node(P.node, i, a);
+    store_rec(P.node, i, make_uint4(0u, 0u, 0u, 0u));
+  }
+  count_hits(P, hits, lane);
+}
+// the same for the repeat of a pass: the saved state is back in place (k_pair_check), the meetings with itself again
+__global__ void __launch_bounds__(kBlock) k_pair_self(HashArrays H, PairArrays P, float friction, float staticThreshold) {
+  if (!P.ctl[kPairRetry] || H.counters[kCounterFlags]) return;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  uint32_t hits = 0;
+  if (i < P.n) {
+    NodeState a = load_node(P.node, i);
+    hits = self_visits(H, P, i, a, P.node[4u * i + 2u], friction, staticThreshold);
+    if (hits) store_node(P.node, i, a);
+  }
+  count_hits(P, hits, lane);
+}
+
+// ---- lists: one workgroup per group (the nodes whose minimum cell is the same cell) ------------------------------------
+// Everything a node of the group can share a cell with sits in the buckets of the 2x2x2 cells above the group's cell.  A node
+// is in several of them; it is taken from the one that is the minimum corner of what its range shares with the block, which
+// the side bits of its entry decide without a look at the node: (cell's offset in the block) & (cell's side in the node's
+// range) == 0 on every axis.  The workgroup's wavefronts share the table of candidates and split the group's own nodes.
+struct BuildLds {
+  uint32_t id[kMaxCand];                                         // the distinct candidates: node index
+  float px[kMaxCand], py[kMaxCand], pz[kMaxCand], rs[kMaxCand];  // position at grid-build time, radius + slack
+  uint32_t rg[kMaxCand];                                         // (min cell - group cell + 1) per axis, 2 bits each; (length - 1) per axis from bit 8
+  uint16_t own[kMaxOwn];                                         // candidates that are the group's own nodes
+  uint32_t ncand, nown;
+  uint64_t lk[kBuildWaves][kMaxDeg];                             // one node's partners: pair key
+  uint32_t le[kBuildWaves][kMaxDeg];                             //                     partner | (shared cells - 1) << 28
+};
+
+// cells two ranges share on one axis: [a0, a0 + la) and [b0, b0 + lb)
+PIES_DEV uint32_t shared_cells(int a0, uint32_t la, int b0, uint32_t lb) {
+  const int lo = max(a0, b0), hi = min(a0 + static_cast<int>(la), b0 + static_cast<int>(lb));
+  return hi > lo ? static_cast<uint32_t>(hi - lo) : 0u;
+}
+
+// appends the accepted candidates of the wavefront's lanes to the node's partner list in LDS; returns the new length
+PIES_DEV uint32_t push_partners(uint64_t* lk, uint32_t* le, uint32_t d, bool accept, uint32_t i, uint32_t j, uint32_t m, int lane) {
+  const unsigned long long mask = __ballot(accept);
+  if (accept) {
+    const uint32_t at = d + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+    if (at < kMaxDeg) {
+      lk[at] = pair_key(min(i, j), max(i, j));
+      le[at] = j | ((m - 1u) << 28);
+    }
+  }
+  return d + static_cast<uint32_t>(__popcll(mask));
+}
+
+// sorts the d partners by key (rank sort: the keys are distinct) and writes the node's list into the wavefront's pool
+PIES_DEV void write_list(const PairArrays& P, const uint64_t* lk, const uint32_t* le, uint32_t i, uint32_t d, uint32_t pool, int lane) {
+  if (d > kMaxDeg) {  // a pile-up beyond anything a simulation survives: latch, like the > 2048 nodes in a cell of the grid
+    if (lane == 0) atomicOr(&P.ctl[kPairFlags], 2u);
+    d = kMaxDeg;
+  }
+  uint32_t at = 0;
+  for (uint32_t tries = 0;; ++tries) {  // a full pool (long lists of one dense group) passes the node on to the next one
+    if (lane == 0 && d) at = atomicAdd(&P.pool[pool], d);
+    at = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(at)));
+    if (at + d <= P.poolCap) break;
+    if (tries + 1u == kPairPools) {  // (the node keeps an empty list; its partners wait for it for ever: flagged, the host latches the failure)
+      if (lane == 0) atomicOr(&P.ctl[kPairFlags], 2u);
+      return;
+    }
+    pool = (pool + 1u) % kPairPools;
+  }
+  const uint32_t off = pool * P.poolCap + at;
+  __builtin_amdgcn_wave_barrier();
+  uint32_t firstEntry = 0;
+  bool haveFirst = false;
+  for (uint32_t e = lane; e < d; e += 64) {
+    const uint64_t k = lk[e];
+    uint32_t rank = 0;
+    for (uint32_t f = 0; f < d; ++f) rank += lk[f] < k ? 1u : 0u;
+    const uint32_t v = le[e];
+    P.nbr[off + rank] = v;
+    if (rank == 0u) { firstEntry = v; haveFirst = true; }
+  }
+  // the node's record: first entry, entries, cursor 0 reached in round 0, the current entry itself (from the lane that holds it)
+  const unsigned long long who = __ballot(haveFirst);
+  const uint32_t v0 = who ? static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(firstEntry), __builtin_ctzll(who))) : 0u;
+  if (lane == 0) store_rec(P.node, i, make_uint4(off, d, 0u, v0));
+  __builtin_amdgcn_wave_barrier();
+}
+
+__global__ void __launch_bounds__(64 * kBuildWaves) k_pair_build(HashArrays H, PairArrays P, uint32_t repeat) {
+  __shared__ BuildLds L;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (repeat && !P.ctl[kPairRetry]) return;
+  if (H.counters[kCounterFlags]) return;
+  const uint32_t used = H.counters[kCounterUsed];
+  const GridBox B = grid_box(H.counters);
+  const uint32_t* __restrict__ val = H.val[grid_passes(B) & 1u];
+  const uint32_t pool = (blockIdx.x * kBuildWaves + wv) % kPairPools;
+  uint64_t* lk = L.lk[wv];
+  uint32_t* le = L.le[wv];
+  uint64_t tested = 0;
+  uint32_t edges = 0;
+  for (uint32_t u = blockIdx.x; u < used; u += gridDim.x) {  // (workgroup uniform)
+    const uint32_t gslot = H.used[u];
+    if (H.gcnt[gslot] == 0u) continue;
+    int gx, gy, gz;
+    box_cell(B, H.keys[gslot], gx, gy, gz);
+    // the 2x2x2 cells above the group's cell (a range spans at most two cells per axis on this path)
+    uint32_t myStart = 0, myCnt = 0;
+    if (lane < 8) {
+      const uint32_t cs = find_bucket(H, B, gx + ((lane >> 2) & 1), gy + ((lane >> 1) & 1), gz + (lane & 1));
+      if (cs != 0xffffffffu) { myStart = H.start[cs]; myCnt = H.end[cs] - myStart; }
+    }
+    uint32_t cStart[8], cCnt[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      cStart[c] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(myStart), c));
+      cCnt[c] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(myCnt), c));
+    }
+    if (threadIdx.x == 0) { L.ncand = 0; L.nown = 0; }
+    __syncthreads();
+    // ---- the distinct nodes of the eight buckets, each from its canonical cell; the group's own nodes.  Cells are dealt to the
+    // wavefronts; a wavefront reserves a run of the table per 64 entries (the order of the table does not matter)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      if ((c % kBuildWaves) != wv) continue;
+      for (uint32_t base = 0; base < cCnt[c]; base += 64) {
+        uint32_t v = 0;
+        bool take = false;
+        if (base + lane < cCnt[c]) {
+          v = val[cStart[c] + base + lane];
+          take = ((v >> kSideShift) & 7u & static_cast<uint32_t>(c)) == 0u;
+        }
+        const unsigned long long tm = __ballot(take);
+        const bool mine = take && c == 0 && (v & kMinFlag) != 0u;
+        const unsigned long long mm = __ballot(mine);
+        uint32_t at = 0, ao = 0;
+        if (lane == 0) {
+          at = atomicAdd(&L.ncand, static_cast<uint32_t>(__popcll(tm)));
+          if (mm) ao = atomicAdd(&L.nown, static_cast<uint32_t>(__popcll(mm)));
+        }
+        at = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(at))) + static_cast<uint32_t>(__popcll(tm & ((1ull << lane) - 1ull)));
+        ao = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ao))) + static_cast<uint32_t>(__popcll(mm & ((1ull << lane) - 1ull)));
+        if (take && at < kMaxCand) {
+          L.id[at] = v & kNodeMask;
+          // the node's range relative to the group's cell, from the entry alone: its minimum is this cell minus the side bits
+          const uint32_t side = (v >> kSideShift) & 7u, two = (v >> kLongShift) & 7u, cc = static_cast<uint32_t>(c);
+          const uint32_t mnx = ((cc >> 2) & 1u) + 1u - ((side >> 2) & 1u), mny = ((cc >> 1) & 1u) + 1u - ((side >> 1) & 1u), mnz = (cc & 1u) + 1u - (side & 1u);
+          L.rg[at] = mnx | (mny << 2) | (mnz << 4) | (((two >> 2) & 1u) << 8) | (((two >> 1) & 1u) << 14) | ((two & 1u) << 20);
+        }
+        if (mine && ao < kMaxOwn && at < kMaxCand) L.own[ao] = static_cast<uint16_t>(at);
+      }
+    }
+    __syncthreads();
+    const uint32_t ncand = L.ncand, nown = L.nown;
+    if (ncand > kMaxCand || nown > kMaxOwn) {
+      // ---- a dense neighbourhood (more than 512 nodes around one cell): candidates straight from the buckets, node by node
+      // (wavefront 0 alone).  A partner sits in several of the node's cells; it is taken where the cell is the minimum corner of
+      // what the two ranges share.
+      if (wv == 0) {
+        for (uint32_t ge = 0; ge < cCnt[0]; ++ge) {
+          const uint32_t v = val[cStart[0] + ge];
+          if (!(v & kMinFlag)) continue;  // (wave uniform)
+          const uint32_t i = v & kNodeMask;
+          const float4 pi = P.node[4u * i + 2u];
+          const float rsi = P.node[4u * i + 1u].w + pi.w;
+          const int4 rgi = H.rng[i];
+          const uint32_t lxi = rgi.w & 0xff, lyi = (rgi.w >> 8) & 0xff, lzi = (rgi.w >> 16) & 0xff;
+          uint32_t d = 0;
+          for (uint32_t dx = 0; dx < lxi; ++dx)
+            for (uint32_t dy = 0; dy < lyi; ++dy)
+              for (uint32_t dz = 0; dz < lzi; ++dz) {
+                const uint32_t c = (dx * 4 + dy * 2 + dz) & 7u;
+                uint32_t bs = 0, bc = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                  if (c == static_cast<uint32_t>(q)) { bs = cStart[q]; bc = cCnt[q]; }
+                tested += bc;
+                const int cx = gx + static_cast<int>(dx), cy = gy + static_cast<int>(dy), cz = gz + static_cast<int>(dz);
+                for (uint32_t base = 0; base < bc; base += 64) {
+                  bool accept = false;
+                  uint32_t j = 0, m = 0;
+                  if (base + lane < bc) {
+                    j = val[bs + base + lane] & kNodeMask;
+                    if (j != i) {
+                      const int4 rgj = H.rng[j];
+                      if (cx == max(rgi.x, rgj.x) && cy == max(rgi.y, rgj.y) && cz == max(rgi.z, rgj.z)) {
+                        m = shared_cells(rgi.x, lxi, rgj.x, rgj.w & 0xff) * shared_cells(rgi.y, lyi, rgj.y, (rgj.w >> 8) & 0xff) *
+                            shared_cells(rgi.z, lzi, rgj.z, (rgj.w >> 16) & 0xff);
+                        const float4 pj = P.node[4u * j + 2u];
+                        const float ddx = pj.x - pi.x, ddy = pj.y - pi.y, ddz = pj.z - pi.z;
+                        const float cut = 1.001f * (rsi + (P.node[4u * j + 1u].w + pj.w));
+                        accept = m != 0u && !(ddx * ddx + ddy * ddy + ddz * ddz >= cut * cut);
+                      }
+                    }
+                  }
+                  d = push_partners(lk, le, d, accept, i, j, m, lane);
+                }
+              }
+          __builtin_amdgcn_wave_barrier();
+          write_list(P, lk, le, i, d, pool, lane);
+          edges += d;
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    for (uint32_t t = threadIdx.x; t < ncand; t += 64 * kBuildWaves) {
+      const float4 p = P.bq[L.id[t]];  // (the one gather per candidate)
+      L.px[t] = p.x; L.py[t] = p.y; L.pz[t] = p.z; L.rs[t] = p.w;
+    }
+    __syncthreads();
+    for (uint32_t o = wv; o < nown; o += kBuildWaves) {
+      const uint32_t si = L.own[o];
+      const uint32_t i = L.id[si];
+      const float pix = L.px[si], piy = L.py[si], piz = L.pz[si], rsi = L.rs[si];
+      const uint32_t rgi = L.rg[si];
+      const uint32_t lxi = ((rgi >> 8) & 63u) + 1u, lyi = ((rgi >> 14) & 63u) + 1u, lzi = ((rgi >> 20) & 63u) + 1u;
+      // the candidates the reference's loop would look at for this node (statistics: SURVEY 8d counts 16 B for each)
+      for (uint32_t dx = 0; dx < lxi; ++dx)
+        for (uint32_t dy = 0; dy < lyi; ++dy)
+          for (uint32_t dz = 0; dz < lzi; ++dz) tested += cCnt[(dx * 4 + dy * 2 + dz) & 7u];
+      uint32_t d = 0;
+      for (uint32_t base = 0; base < ncand; base += 64) {
+        const uint32_t t = base + static_cast<uint32_t>(lane);
+        bool accept = false;
+        uint32_t j = 0, m = 0;
+        if (t < ncand && t != si) {
+          const float ddx = L.px[t] - pix, ddy = L.py[t] - piy, ddz = L.pz[t] - piz;
+          const float cut = 1.001f * (rsi + L.rs[t]);  // (infinite for a node that left its slack in the first attempt)
+          if (!(ddx * ddx + ddy * ddy + ddz * ddz >= cut * cut)) {
+            j = L.id[t];
+            const uint32_t rgj = L.rg[t];
+            m = shared_cells(0, lxi, static_cast<int>(rgj & 3u) - 1, ((rgj >> 8) & 63u) + 1u) *
+                shared_cells(0, lyi, static_cast<int>((rgj >> 2) & 3u) - 1, ((rgj >> 14) & 63u) + 1u) *
+                shared_cells(0, lzi, static_cast<int>((rgj >> 4) & 3u) - 1, ((rgj >> 20) & 63u) + 1u);
+            accept = m != 0u;
+          }
+        }
+        d = push_partners(lk, le, d, accept, i, j, m, lane);
+      }
+      __builtin_amdgcn_wave_barrier();
+      write_list(P, lk, le, i, d, pool, lane);
+      edges += d;
+    }
+    __syncthreads();  // (the table is reused by the next group)
+  }
+  if (lane == 0 && tested) atomicAdd(reinterpret_cast<unsigned long long*>(&H.counters[kCounterCandidates]), static_cast<unsigned long long>(tested));
+  if (lane == 0 && edges) atomicAdd(&P.ctl[kPairEdges], edges);
+}
+
+// ---- one level.  The frontier of round R holds the nodes that moved on to a new entry of their list in round R - 1 (all
+// nodes in round 1).  Node x looks at its entry (x, y): the pair's turn has come when y's current entry is (y, x) as well.  y's
+// record carries the round in which y reached its entry: R itself means that another lane is moving y on right now (too
+// fresh: y's lane of the next round will find x waiting); R - 1 means that y is in this frontier too and sees the same, and
+// the lower index of the two takes the pair; anything older means y has been waiting for x.  The pairs taken in one round
+// share no node.
+// A pair that does not overlap at its first visit is not moved by that visit, so none of its visits does anything: such pairs
+// (two thirds of the listed ones) are finished with one distance test.  A level is bound by the chain of dependent memory
+// round trips of one wavefront (record, partner's record, the two node lines, the next list entries) and of the up to sixteen
+// visits of a pair, not by arithmetic throughput: wavefronts are independent (no workgroup barrier), so that all of a level's
+// wavefronts are resident at once.
+// The frontier of a round is kept as kPairLists sub-lists.  A wavefront works on chunks of 64 consecutive positions of their
+// concatenation and appends to the sub-list its chunk is dealt to (chunk index modulo kPairLists).
+struct FrontierView {
+  uint32_t incl;   // lane s: entries of sub-lists 0 .. s
+  uint32_t total;
+};
+PIES_DEV FrontierView frontier_view(const PairArrays& P, uint32_t round, int lane) {
+  FrontierView v;
+  if (round == 1u) { v.incl = 0; v.total = P.n; return v; }  // (all nodes, by index)
+  uint32_t c = min(__hip_atomic_load(&P.frCount[(round % 3u) * kPairLists + static_cast<uint32_t>(lane)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), P.frCap);
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(c, off, 64);
+    if (lane >= off) c += t;
+  }
+  v.incl = c;
+  v.total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c), 63));
+  return v;
+}
+// position e of the concatenated sub-lists -> the node (e < total)
+PIES_DEV uint32_t frontier_node(const PairArrays& P, const FrontierView& v, uint32_t round, uint32_t e) {
+  if (round == 1u) return e;
+  uint32_t lo = 0;  // number of sub-lists that end at or before e: binary search over the lanes' inclusive sums
+#pragma unroll
+  for (int bit = 32; bit >= 1; bit >>= 1) {
+    const uint32_t probe = lo + static_cast<uint32_t>(bit) - 1u;
+    const uint32_t end = __shfl(v.incl, static_cast<int>(probe), 64);
+    if (end <= e) lo += static_cast<uint32_t>(bit);
+  }
+  const uint32_t prev = __shfl(v.incl, static_cast<int>(lo ? lo - 1u : 0u), 64);  // (every lane shuffles: a lane must not read from an idle one)
+  const uint32_t before = lo ? prev : 0u;
+  return P.fr[round & 1u][lo * P.frCap + (e - before)];
+}
+
+PIES_DEV void process_frontier(const HashArrays& H, const PairArrays& P, float friction, float staticThreshold, uint32_t round, uint32_t first,
+                               uint32_t step, const FrontierView& view, int lane, uint32_t& hits) {
+  float4* node = P.node;
+  uint32_t* next = P.fr[(round + 1u) & 1u];
+  uint32_t* nextCount = P.frCount + ((round + 1u) % 3u) * kPairLists;
+  const uint32_t stampNow = round & 0xffffu, stampPrev = (round - 1u) & 0xffffu;
+  const uint32_t count = view.total;
+  // moves a node on to its next entry (reached in this round); returns whether it has one
+  auto move_on = [&](uint32_t i, const uint4 r) {
+    const uint32_t c = (r.z & 0xffffu) + 1u;
+    const uint32_t entry = c < r.y ? P.nbr[r.x + c] : 0u;
+    store_rec(node, i, make_uint4(r.x, r.y, c | (stampNow << 16), entry));
+    return c < r.y;
+  };
+  for (uint32_t base = first - static_cast<uint32_t>(lane); base < count; base += step) {  // (wave uniform trip count)
+    const uint32_t e = base + static_cast<uint32_t>(lane);
+    bool moveX = false, moveY = false;
+    uint32_t x = 0, y = 0;
+    const uint32_t xe = frontier_node(P, view, round, min(e, count - 1u));  // (every lane takes part in the shuffles)
+    if (e < count) {
+      x = xe;
+      const uint4 rx = load_rec(node, x);
+      // (x's own record must still be the one it reached in the last round: its partner's lane may have moved it on already)
+      if ((rx.z & 0xffffu) < rx.y && (rx.z >> 16) == stampPrev) {
+        y = rx.w & kPairNodeMask;
+        const uint4 ry = load_rec(node, y);
+        const uint32_t sy = ry.z >> 16;
+        bool take = (ry.z & 0xffffu) < ry.y && sy != stampNow && (ry.w & kPairNodeMask) == x;
+        if (take && sy == stampPrev && y < x) take = false;  // y is in this frontier as well and takes the pair
+        if (take) {
+          const bool xLow = x < y;
+          const uint32_t lo = xLow ? x : y, hi = xLow ? y : x;
+          NodeState a = load_node(node, lo), b = load_node(node, hi);
+          const float dx = b.px - a.px, dy = b.py - a.py, dz = b.pz - a.pz;
+          const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+          if (a.r + b.r - dist > 0.0f) {
+            const float4 a0 = node[4u * lo + 2u], b0 = node[4u * hi + 2u];
+            const uint32_t m = (rx.w >> 28) + 1u;
+            uint32_t h = 0;
+            for (uint32_t t = 0; t < m; ++t) h += visit(a, b, friction, staticThreshold) ? 1u : 0u;
+            for (uint32_t t = 0; t < m; ++t) h += visit(b, a, friction, staticThreshold) ? 1u : 0u;
+            store_node(node, lo, a);
+            store_node(node, hi, b);
+            note_excursion(P, lo, a, a0);
+            note_excursion(P, hi, b, b0);
+            hits += h;
+          }
+          moveX = move_on(x, rx);
+          moveY = move_on(y, ry);
+        }
+      }
+    }
+    // the nodes that moved on and have entries left go to the sub-list this chunk is dealt to (one atomic per wavefront; a
+    // sub-list takes at most 128 nodes from each of its chunks: frCap covers that)
+    const unsigned long long mx = __ballot(moveX), my = __ballot(moveY);
+    const uint32_t nx = static_cast<uint32_t>(__popcll(mx)), ny = static_cast<uint32_t>(__popcll(my));
+    if (nx + ny) {
+      const uint32_t sub = (base >> 6) % kPairLists;
+      uint32_t at = 0;
+      if (lane == 0) at = atomicAdd(&nextCount[sub], nx + ny);
+      at = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(at)));
+      uint32_t* dst = next + static_cast<size_t>(sub) * P.frCap;
+      const uint32_t ix = at + static_cast<uint32_t>(__popcll(mx & ((1ull << lane) - 1ull)));
+      const uint32_t iy = at + nx + static_cast<uint32_t>(__popcll(my & ((1ull << lane) - 1ull)));
+      if (moveX && ix < P.frCap) dst[ix] = x;
+      if (moveY && iy < P.frCap) dst[iy] = y;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64) k_pair_round(HashArrays H, PairArrays P, float friction, float staticThreshold, uint32_t round, uint32_t repeat) {
+  if (repeat && !P.ctl[kPairRetry]) return;
+  if (H.counters[kCounterFlags]) return;
+  const int lane = threadIdx.x;
+  const FrontierView view = frontier_view(P, round, lane);
+  if (blockIdx.x == 0) {
+    P.frCount[((round + 2u) % 3u) * kPairLists + threadIdx.x] = 0;  // the lists of the round after the next (read by the previous launch, filled by the next)
+    if (threadIdx.x == 0 && view.total) P.ctl[kPairRounds] = round;
+  }
+  if (view.total == 0u) return;  // (a pass that will be repeated is finished all the same: it finds every node that leaves its slack)
+  uint32_t hits = 0;
+  process_frontier(H, P, friction, staticThreshold, round, blockIdx.x * 64u + threadIdx.x, gridDim.x * 64u, view, lane, hits);
+  count_hits(P, hits, lane);
+}
+
+// Whatever levels are left after the captured rounds (and all levels of a repeated pass): one workgroup, a workgroup barrier
+// where the rounds have a kernel boundary.  Global memory written before the barrier is visible to the workgroup after it.
+__global__ void __launch_bounds__(1024) k_pair_tail(HashArrays H, PairArrays P, float friction, float staticThreshold, uint32_t round, uint32_t repeat) {
+  if (repeat && !P.ctl[kPairRetry]) return;
+  if (!repeat && P.ctl[kPairRetry]) return;
+  if (H.counters[kCounterFlags]) return;
+  const int lane = threadIdx.x & 63;
+  uint32_t hits = 0;
+  for (;; ++round) {
+    const FrontierView view = frontier_view(P, round, lane);
+    if (view.total == 0u) break;  // (the same words for every wavefront: all leave together)
+    __syncthreads();  // every wavefront has read the counts before the lists after the next are cleared
+    if (threadIdx.x < kPairLists) __hip_atomic_store(&P.frCount[((round + 2u) % 3u) * kPairLists + threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) P.ctl[kPairRounds] = round;
+    process_frontier(H, P, friction, staticThreshold, round, threadIdx.x, blockDim.x, view, lane, hits);
+    __threadfence();
+    __syncthreads();
+  }
+  count_hits(P, hits, lane);
+}
+
+// ---- after the pass: can an unlisted pair have touched? -----------------------------------------------------------------
+// One wavefront per node that left its slack: the nodes it shares a cell with but did not list (d0 >= cut) are tested with the
+// largest excursions of the pass.
+__global__ void __launch_bounds__(kBlock) k_pair_verify(HashArrays H, PairArrays P, uint32_t repeat) {
+  if (repeat && !P.ctl[kPairRetry]) return;
+  if (H.counters[kCounterFlags]) return;
+  const uint32_t count = min(P.ctl[kPairLeft], P.n);
+  if (count == 0u) return;
+  const int lane = threadIdx.x & 63;
+  const GridBox B = grid_box(H.counters);
+  const uint32_t* __restrict__ val = H.val[grid_passes(B) & 1u];
+  const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
+  bool bad = false;
+  for (uint32_t u = wave; u < count; u += nwaves) {
+    const uint32_t i = P.left[u];
+    const float4 pi = P.node[4u * i + 2u];
+    const float ri = P.node[4u * i + 1u].w, ei = __uint_as_float(P.exc[i]);
+    const int4 rg = H.rng[i];
+    const uint32_t lx = rg.w & 0xff, ly = (rg.w >> 8) & 0xff, lz = (rg.w >> 16) & 0xff;
+    for (uint32_t dx = 0; dx < lx; ++dx)
+      for (uint32_t dy = 0; dy < ly; ++dy)
+        for (uint32_t dz = 0; dz < lz; ++dz) {
+          const uint32_t cs = find_bucket(H, B, rg.x + static_cast<int>(dx), rg.y + static_cast<int>(dy), rg.z + static_cast<int>(dz));
+          if (cs == 0xffffffffu) continue;
+          const uint32_t bs = H.start[cs], bc = H.end[cs] - bs;
+          for (uint32_t base = 0; base < bc; base += 64) {
+            if (base + lane >= bc) continue;
+            const uint32_t j = val[bs + base + lane] & kNodeMask;
+            if (j == i) continue;
+            const float4 pj = P.node[4u * j + 2u];
+            const float rj = P.node[4u * j + 1u].w;
+            const float ddx = pj.x - pi.x, ddy = pj.y - pi.y, ddz = pj.z - pi.z;
+            const float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+            const float cut = 1.001f * ((ri + pi.w) + (rj + pj.w));
+            if (!(d2 >= cut * cut)) continue;  // listed: it was visited
+            const float reach = 1.001f * (ri + rj + ei + __uint_as_float(P.exc[j]));
+            if (!(d2 >= reach * reach)) bad = true;  // the two may have touched while the pair was skipped
+          }
+        }
+  }
+  if (__ballot(bad) && lane == 0) atomicOr(&P.ctl[kPairFlags], 1u);
+}
+
+// first = after the first attempt.  A failed verification puts the saved state back and arms the repeat, in which the nodes
+// that left their slack get the room they took in the first attempt and more.  Otherwise (and after the repeat) the result goes
+// back to the solver's node arrays and every node's slack follows what it did.
+__global__ void __launch_bounds__(kBlock) k_pair_check(HashArrays H, PairArrays P, float4* pos, float4* vel, uint32_t first) {
+  const uint32_t flags = P.ctl[kPairFlags];
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const bool repeat = first && (flags & 1u);
+  if (!first && !P.ctl[kPairRetry]) return;  // nothing was repeated: the first check has done everything
+  if (i < P.n && !H.counters[kCounterFlags]) {
+    const float4 p0 = P.node[4u * i + 2u];
+    const float e = __uint_as_float(P.exc[i]), sl = p0.w;
+    if (repeat) {
+      const float4 v0 = P.vel0[i];
+      const float r = P.node[4u * i + 1u].w;
+      P.node[4u * i] = make_float4(p0.x, p0.y, p0.z, P.node[4u * i].w);
+      P.node[4u * i + 1u] = make_float4(v0.x, v0.y, v0.z, r);
+      store_rec(P.node, i, make_uint4(0u, 0u, 0u, 0u));
+      P.exc[i] = 0u;
+      if (!(e <= 0.999f * sl)) {  // (the repeat follows the first attempt's course until a newly listed pair touches)
+        const float room = 2.0f * e + 0.2f * r;
+        P.node[4u * i + 2u].w = room;
+        P.bq[i].w = r + room;
+      }
+    } else {
+      const float4 p = P.node[4u * i], v = P.node[4u * i + 1u];
+      pos[i] = p;
+      vel[i] = make_float4(v.x, v.y, v.z, 0.0f);  // (the fourth component of a velocity record is 0 everywhere)
+      P.node[4u * i + 2u].w = next_slack(e, sl, v.w);
+    }
+  }
+  // the pass's resolved pairs go to the statistics when its result stands (a pass that is repeated counts once)
+  if (blockIdx.x == 0 && !repeat) {
+    uint32_t sum = 0;
+    for (uint32_t k = threadIdx.x; k < kPairStripes; k += kBlock) { sum += P.hitStripe[k]; P.hitStripe[k] = 0; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&H.counters[kCounterPairs], sum);
+  } else if (blockIdx.x == 0) {
+    for (uint32_t k = threadIdx.x; k < kPairStripes; k += kBlock) P.hitStripe[k] = 0;
+  }
+  if (i != 0 || first) return;
+  if (flags & 1u) P.ctl[kPairInexact] += 1;
+  if (flags & 2u) atomicOr(&H.counters[kCounterFlags], 256u);  // list storage overflow: the host latches the failure
+  P.ctl[kPairLeft] = 0;
+}
+// (one thread, after every block of the first k_pair_check has read the flags)
+__global__ void k_pair_arm(HashArrays H, PairArrays P) {
+  if (P.ctl[kPairFlags] & 1u) {
+    if (threadIdx.x < kPairPools) P.pool[threadIdx.x] = 0;
+    for (uint32_t k = threadIdx.x; k < 3u * kPairLists; k += 64) P.frCount[k] = 0;
+  }
+  if (threadIdx.x != 0) return;
+  const uint32_t flags = P.ctl[kPairFlags];
+  P.ctl[kPairLeft] = 0;
+  if (!(flags & 1u)) {
+    if (flags & 2u) atomicOr(&H.counters[kCounterFlags], 256u);
+    return;
+  }
+  P.ctl[kPairRetry] = 1;
+  P.ctl[kPairRetries] += 1;
+  P.ctl[kPairFlags] = 0;
+  P.ctl[kPairEdges] = 0;
+  H.counters[kCounterCandidates] = P.ctl[kPairSavedCand];
+  H.counters[kCounterCandidates + 1] = P.ctl[kPairSavedCand + 1];
+}
+
+uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArrays& P, const NodeArrays& nd, float friction,
+                              float staticThreshold, uint32_t rounds) {
+  if (nd.n == 0) return 0;
+  const uint32_t n = nd.n;
+  uint32_t launches = 0;
+  const dim3 perNode((n + kBlock - 1) / kBlock);
+  const dim3 groups(std::max<uint32_t>(1u, std::min<uint32_t>(8192u, n / 8 + 1)));
+  const dim3 level(std::max<uint32_t>(1u, std::min<uint32_t>(8192u, (n + 63u) / 64u)));
+  hipLaunchKernelGGL(k_pair_save, perNode, dim3(kBlock), 0, st, H, P, nd.pos, nd.vel, nd.radius, friction, staticThreshold); ++launches;
+  for (uint32_t repeat = 0; repeat < 2; ++repeat) {
+    if (repeat) { hipLaunchKernelGGL(k_pair_self, perNode, dim3(kBlock), 0, st, H, P, friction, staticThreshold); ++launches; }
+    hipLaunchKernelGGL(k_pair_build, groups, dim3(64 * kBuildWaves), 0, st, H, P, repeat); ++launches;
+    for (uint32_t r = 1; r <= rounds; ++r) {  // (the repeat's launches return at once when nothing is repeated: 2.5 us each)
+      hipLaunchKernelGGL(k_pair_round, level, dim3(64), 0, st, H, P, friction, staticThreshold, r, repeat); ++launches;
+    }
+    hipLaunchKernelGGL(k_pair_tail, dim3(1), dim3(1024), 0, st, H, P, friction, staticThreshold, rounds + 1u, repeat); ++launches;
+    hipLaunchKernelGGL(k_pair_verify, dim3(64), dim3(kBlock), 0, st, H, P, repeat); ++launches;
+    hipLaunchKernelGGL(k_pair_check, perNode, dim3(kBlock), 0, st, H, P, nd.pos, nd.vel, repeat ? 0u : 1u); ++launches;
+    if (!repeat) { hipLaunchKernelGGL(k_pair_arm, dim3(1), dim3(64), 0, st, H, P); ++launches; }
+  }
+  return launches;
+}
+
+}  // namespace pies

@@ -12,6 +12,7 @@
 #include "kernels.h"
 #include "pd_kernels.h"
 #include "hash_kernels.h"
+#include "pair_kernels.h"
 
 namespace pies {
 
@@ -166,7 +167,8 @@ struct pies_solver {
   bool triangleCollisions = true;  // PD point-triangle CCD contacts (Solver.cpp:693-797); extension flag to switch off
   bool simFailed = false;
   int schedule = PIES_SCHEDULE_DEFAULT;
-  int collisionOrderFlag = -1;     // PIES_FLAG_REFERENCE_COLLISION_ORDER: -1 follows the schedule (EXACT: reference order)
+  int collisionOrderFlag = -1;     // PIES_FLAG_COLLISION_ORDER: -1 follows the schedule (EXACT: reference order, otherwise pair order)
+  uint32_t pairRounds = 96;        // level launches captured per pair-ordered pass (a tail kernel finishes deeper orders)
 
   // ---- host mirror ----
   std::vector<float> h_pos, h_prev, h_vel;  // n x 3
@@ -212,6 +214,7 @@ struct pies_solver {
 
   // ---- node-node collisions (PBD) ----
   pies::HashArrays hash{};
+  pies::PairArrays pairs{};  // pair-ordered resolve
 
   // ---- Projective Dynamics ----
   pies::PdArrays pd{};

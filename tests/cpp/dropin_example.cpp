@@ -41,6 +41,26 @@ int main(int argc, char** argv) {
   for (size_t i = 0; i < n; ++i)
     for (int k = 0; k < 3; ++k)
       if (twin.getVertices()[i].position[k] != solver.getVertices()[i].position[k]) return 5;
+  // the reference's construction forms: copy-initialisation from the options (its constructor is not explicit), a
+  // default-constructed solver (no device is opened until something needs one) that is move-assigned later
+  Pies::Solver fromOptions = options;
+  Pies::Solver late;
+  if (late.getOptions().iterations != 4 || !late.getVertices().empty()) return 6;
+  late = std::move(fromOptions);
+  if (late.getOptions().iterations != 6) return 7;
+  // tickPBD / tickPD run the NAMED solver whatever options.solver says (Solver.cpp:40, :162): the same scene ticked with
+  // tickPBD under PD options ends where a PBD solver's tick() ends
+  Pies::SolverOptions other = options;
+  other.solver = pd ? Pies::SolverName::PBD : Pies::SolverName::PD;
+  Pies::Solver named(other), plain(options);
+  for (Pies::Solver* s : {&named, &plain}) s->createTetBox(glm::vec3(0.0f, 4.0f, 0.0f), 1.0f, glm::vec3(0.0f), pd ? 1.0f : 0.002f, 1.0f, false);
+  for (int i = 0; i < 3; ++i) {
+    if (pd) named.tickPD(0.0f); else named.tickPBD(0.0f);
+    plain.tick(0.0f);
+  }
+  for (size_t i = 0; i < plain.getVertices().size(); ++i)
+    for (int k = 0; k < 3; ++k)
+      if (named.getVertices()[i].position[k] != plain.getVertices()[i].position[k]) return 8;
   Pies::Solver moved(std::move(solver));
   moved.tick(0.0f);
   moved.clear();

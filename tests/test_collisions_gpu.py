@@ -1,11 +1,14 @@
 """GPU parity of the PBD node-node collision pass (Src/Solver.cpp:81-130, SpatialHash.h, NodeCompRange).
 
-The reference loop is order dependent.  The device has two orders:
+The reference loop is order dependent.  The device has three orders (PIES_FLAG_COLLISION_ORDER = the oracle's rule number):
   * rule 0 - the reference's own loop (ascending node index, cell range from the node's current position), run as one
-    sequential chain; the default under PIES_SCHEDULE_EXACT, compared with the oracle's UNMODIFIED loop (rule 0);
-  * rule 1 - the parallel visiting order of DESIGN.md "Node-node collisions", which the oracle replays (flag 2 = 1) with
-    the reference's per-pair arithmetic.
-In both, positions and velocities are expected to agree bit for bit.  Gate: 1e-5 * spacing."""
+    sequential chain; the default under PIES_SCHEDULE_EXACT, compared with the oracle's plain loop (rule 0);
+  * rule 2 - the pair order of DESIGN.md "Node-node collisions" (the default otherwise): the same visits, pair by pair in
+    ascending order of a 64-bit mix of the two indices, executed by dependency levels; the oracle replays it with a sort
+    and a sequential loop over ALL pairs that share a cell (the device lists only pairs near enough to touch and checks
+    that this cannot have changed the result);
+  * rule 1 - rounds 1-2's group order (27 residue classes of minimum cells), which the oracle replays as well.
+In all of them positions and velocities are expected to agree bit for bit.  Gate: 1e-5 * spacing."""
 import numpy as np
 import pytest
 
@@ -24,19 +27,19 @@ def particles(dims, spacing=0.9, jitter=0.05, seed=1234, y0=0.5):
     return p.astype(np.float32), v.astype(np.float32)
 
 
-def pair(pies, oracle, build, iterations, ticks, rule=1, **opt):
+def pair(pies, oracle, build, iterations, ticks, rule=2, **opt):
     g = pies.Solver(scenes.pbd_options(pies, iterations, **opt))
     o = oracle.OracleSolver(scenes.pbd_options(oracle, iterations, **opt))
     for s in (g, o):
         build(s)
     o.set_flag(oracle.FLAG_COLLISION_RULE, rule)
-    g.set_flag(pies.FLAG_REFERENCE_COLLISION_ORDER, rule == 0)
+    g.set_flag(pies.FLAG_COLLISION_ORDER, rule)
     g.tick(ticks)
     o.tick(ticks)
     return g, o
 
 
-RULES = pytest.mark.parametrize("rule", [0, 1], ids=["reference-order", "parallel-order"])
+RULES = pytest.mark.parametrize("rule", [0, 1, 2], ids=["reference-order", "group-order", "pair-order"])
 
 
 def check(g, o, exact=True):
@@ -104,11 +107,14 @@ def test_beam_with_constraints_and_collisions(pies, oracle):
         if schedule == 1:
             for t in (pies.DISTANCE, pies.TET):
                 o.permute(t, g.order(t))
-        o.set_flag(oracle.FLAG_COLLISION_RULE, 0 if schedule == 0 else 1)
+        o.set_flag(oracle.FLAG_COLLISION_RULE, 0 if schedule == 0 else 2)
         g.tick(4); o.tick(4)
         check(g, o)
         assert g.collision_pairs == o.collision_pairs > 0
-        assert g.launch_counts()["collide"] == 4
+        if schedule == 0:
+            assert g.launch_counts()["collide"] == 4  # the reference's loop: one launch per iteration
+        else:
+            assert g.collision_health()["passes_inexact"] == 0
 
 
 def test_config1_lattice_reference_order(pies, oracle):
@@ -131,7 +137,7 @@ def test_device_rule_vs_reference_order_is_a_small_perturbation(oracle):
     ascending-index loop on the same scene (both orders are valid Gauss-Seidel sweeps)."""
     p, v = particles((6, 7, 8))
     res = []
-    for rule in (0, 1):
+    for rule in (0, 2):
         o = oracle.OracleSolver(scenes.pbd_options(oracle, 4))
         o.addNodes(p); o.set_velocities(v)
         o.set_flag(oracle.FLAG_COLLISION_RULE, rule)
@@ -173,6 +179,9 @@ def test_config4_l500k_one_tick(pies, oracle):
     g, o = pair(pies, oracle, build, 4, 1)
     check(g, o)
     assert g.collision_pairs == o.collision_pairs > 1_000_000
+    h = g.collision_health()
+    print("config 4, pair order:", h)
+    assert h["passes_inexact"] == 0 and h["levels"] > 0
 
 
 def test_dense_cells_take_the_unstaged_path(pies, oracle):
@@ -187,15 +196,16 @@ def test_dense_cells_take_the_unstaged_path(pies, oracle):
 
     def build(s):
         s.add_nodes_raw(p, vel=v, radius=r, invMass=np.ones(len(p), np.float32))
-    g, o = pair(pies, oracle, build, 3, 2)
-    check(g, o)
-    assert g.collision_pairs == o.collision_pairs > 700
+    for rule in (2, 1):
+        g, o = pair(pies, oracle, build, 3, 2, rule=rule)
+        check(g, o)
+        assert g.collision_pairs == o.collision_pairs > 700
     g, o = pair(pies, oracle, build, 2, 1, rule=0)  # and the sequential chain over the same dense buckets
     check(g, o)
 
 
 def test_resolve_variants_agree(pies, monkeypatch):
-    """The product path resolves all 27 residue classes in one launch (tickets + completion stamps, LDS staging);
+    """(group order) The one-launch form resolves all 27 residue classes in one launch (tickets + completion stamps, LDS staging);
     PIES_COLLIDE_PASSES=1 is the 27-launch form and PIES_COLLIDE_GLOBAL=1 the unstaged one.  The order of
     conflicting groups is the same in all of them, so the results must be identical bit for bit."""
     p, v = particles((9, 8, 10))
@@ -204,6 +214,7 @@ def test_resolve_variants_agree(pies, monkeypatch):
         g = pies.Solver(scenes.pbd_options(pies, 3))
         g.addNodes(p)
         g.set_velocities(v)
+        g.set_flag(pies.FLAG_COLLISION_ORDER, pies.COLLISION_ORDER_GROUPS)
         g.tick(3)
         return g.positions, g.velocities, g.collision_pairs, g.launch_counts()["collide"]
     ref = run()
@@ -233,3 +244,53 @@ def test_distant_clusters_use_wide_keys(pies, oracle, rule):
     g, o = pair(pies, oracle, build, 3, 3, rule=rule, gravity=0.0)
     check(g, o)
     assert g.collision_pairs == o.collision_pairs > 500
+
+
+@pytest.mark.parametrize("spacing", [0.55, 0.7])
+def test_deep_overlaps_leave_the_slack(pies, oracle, spacing):
+    """The pair order lists only pairs near enough to touch while every node stays within its slack of the position the grid
+    was built from.  Here overlaps are deep (spacing 0.55 / 0.7 against r = 0.5): nodes are pushed further than their slack
+    allows for, the device tests the unlisted neighbours of those nodes with the excursions of the pass and, where a pair may
+    have been missed, repeats the pass with those nodes listing everything around them.  The result is still the oracle's,
+    which never filters."""
+    p, v = particles((6, 5, 7), spacing=spacing, jitter=0.05)
+
+    def build(s):
+        s.addNodes(p)
+        s.set_velocities(v)
+    g, o = pair(pies, oracle, build, 2, 2, rule=2)
+    h = g.collision_health()
+    print("deep overlaps, spacing", spacing, h)
+    assert h["passes_inexact"] == 0
+    check(g, o)
+    assert g.collision_pairs == o.collision_pairs > 1000
+
+
+def test_pair_order_is_deterministic_with_levels_in_the_tail(pies):
+    """Two solvers on the same input, most levels in the single-workgroup tail kernel: bit-identical positions and the same
+    number of resolved pairs (a node whose partner's lane has already moved it on in this level must not be taken again)."""
+    p, v = particles((30, 30, 30))
+    runs = []
+    for _ in range(2):
+        g = pies.Solver(scenes.pbd_options(pies, 4))
+        g.addNodes(p)
+        g.set_velocities(v)
+        g.set_collision_rounds(20)
+        g.tick(3)
+        runs.append((g.positions, g.velocities, g.collision_pairs))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]) and runs[0][2] == runs[1][2] > 100000
+
+
+def test_pair_order_deeper_than_the_captured_rounds(pies, oracle):
+    """Only three level launches are captured (pies_set_collision_rounds): the tail kernel finishes the remaining levels."""
+    p, v = particles((7, 6, 8))
+    g = pies.Solver(scenes.pbd_options(pies, 3))
+    o = oracle.OracleSolver(scenes.pbd_options(oracle, 3))
+    for s in (g, o):
+        s.addNodes(p)
+        s.set_velocities(v)
+    o.set_flag(oracle.FLAG_COLLISION_RULE, 2)
+    g.set_collision_rounds(3)
+    g.tick(3); o.tick(3)
+    check(g, o)
+    assert g.collision_pairs == o.collision_pairs > 1000 and g.collision_health()["levels"] > 3

@@ -191,7 +191,7 @@ def _layered_pair(pies, oracle, build, iterations, ticks, collisions=0, hinge=0)
         s.set_flag(1, collisions)
         s.set_flag(0, hinge)
     if collisions:
-        o.set_flag(oracle.FLAG_COLLISION_RULE, 1)  # the device's documented visiting order
+        o.set_flag(oracle.FLAG_COLLISION_RULE, 2)  # the device's default order for the node-node pass: the pair order
     g.set_schedule(pies.SCHEDULE_LAYERED)
     g.finalize()
     for t in (pies.POSITION, pies.DISTANCE, pies.TET, pies.BEND):
