@@ -241,7 +241,7 @@ int pies_collision_stats(pies_solver_t* s, uint64_t* pairs, uint64_t* candidates
  * that were repeated with the widest slack because a node had moved further than the pair filter allows for, and the passes in
  * which a node moved further than even that (more than 0.5 in one pass: the result may then miss visits the documented order
  * makes).  Any pointer may be NULL. */
-/* Pair order: level launches captured per pass (default 96; a single-workgroup kernel finishes deeper orders, slowly).
+/* Pair order: level launches captured per pass (default 128; a single-workgroup kernel finishes deeper orders, slowly).
  * BASELINE config 4 needs about 75. */
 int pies_set_collision_rounds(pies_solver_t* s, uint32_t rounds);
 /* Diagnostics of the pair order: per node the slack for the next pass, the excursion and the listed partners of the last pass. */

@@ -1048,11 +1048,14 @@ int pies_finalize(pies_solver_t* s) {
       P.frCap = n / 32 + 256;  // a chunk of 64 lanes appends at most 128 nodes to the one sub-list it is dealt to
       for (int b = 0; b < 2; ++b)
         if (int rc = dev_alloc(s, static_cast<size_t>(P.frCap) * kPairLists, &P.fr[b])) return rc;
-      if (int rc = dev_alloc(s, 3ull * kPairLists, &P.frCount, true)) return rc;
-      if (int rc = dev_alloc(s, kPairStripes, &P.hitStripe, true)) return rc;
+      if (int rc = dev_alloc(s, 3ull * kPairLists * kPairPad, &P.frCount, true)) return rc;
+      if (int rc = dev_alloc(s, static_cast<size_t>(kPairStripes) * kPairPad, &P.hitStripe, true)) return rc;
       if (int rc = dev_alloc(s, n, &P.bq)) return rc;
+      if (int rc = dev_alloc(s, 64ull * kPairPad, &P.stat, true)) return rc;
+      if (int rc = dev_alloc(s, 4ull * n, &P.grp)) return rc;
+      if (int rc = dev_alloc(s, n, &P.spill)) return rc;
       if (int rc = dev_alloc(s, n, &P.left, true)) return rc;
-      if (int rc = dev_alloc(s, kPairPools, &P.pool, true)) return rc;
+      if (int rc = dev_alloc(s, static_cast<size_t>(kPairPools) * kPairPad, &P.pool, true)) return rc;
       if (int rc = dev_alloc(s, kPairWords, &P.ctl, true)) return rc;
     }
     HIP_TRY(s, hipStreamSynchronize(s->stream));

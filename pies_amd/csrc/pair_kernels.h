@@ -18,12 +18,15 @@ constexpr uint32_t kPairRetries = 7;    // lifetime: passes repeated
 constexpr uint32_t kPairInexact = 8;    // lifetime: passes in which a node left its slack in the repeat as well (the result may differ
                                         // from the documented order by visits that were filtered out)
 constexpr uint32_t kPairEdges = 9;      // pairs listed by the last pass (diagnostics)
-constexpr uint32_t kPairSavedPairs = 10, kPairSavedCand = 11 /* and 12 */;  // statistics counters at the start of the pass
+constexpr uint32_t kPairGroups = 10;     // groups of this grid (entries of `grp`)
+constexpr uint32_t kPairSpilled = 11;    // groups the small list kernel passed on to the large one (entries of `spill`)
 constexpr uint32_t kPairWords = 16;
 
 constexpr uint32_t kPairLists = 64;     // the frontier is kept as this many sub-lists: a wavefront appends to one of them, so that the
                                         // appends of a level are spread over 64 counters (same-address atomics take ~8 ns each)
 constexpr uint32_t kPairStripes = 1024; // resolved-pair statistics are counted in stripes for the same reason
+constexpr uint32_t kPairPad = 32;       // counters that many wavefronts add to sit 128 bytes apart: atomics on one cache line take their turns
+                                        // (measured: 500 000 adds on 64 adjacent words 2.4 ms, on 64 lines 60 us)
 constexpr uint32_t kPairPools = 64;     // list storage is handed out from this many pools (a wavefront of the list kernel uses one)
 
 struct PairArrays {
@@ -41,6 +44,9 @@ struct PairArrays {
   uint32_t *fr[2];         // frontier: the nodes that moved on to a new entry in the last round, kPairLists sub-lists of frCap entries
   uint32_t *frCount;       // [3][kPairLists] entries of the sub-lists of round r, at r % 3
   uint32_t *hitStripe;     // resolved pairs of this pass, striped
+  uint32_t *stat;          // [0..127] candidates looked at (64 x 64 bit), [128..191] listed entries: striped counters of the list kernel
+  uint4 *grp;              // 4 per group: the buckets of the 2x2x2 cells above the group's cell (k_pair_groups)
+  uint32_t *spill;         // groups for the large list kernel
   uint32_t *left;          // the nodes that left their slack in this pass
   uint32_t *pool;          // entries handed out per pool
   uint32_t* ctl;

@@ -129,7 +129,7 @@ PIES_DEV void note_excursion(const PairArrays& P, uint32_t i, const NodeState& a
 PIES_DEV void count_hits(const PairArrays& P, uint32_t hits, int lane) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) hits += __shfl_xor(hits, o, 64);
-  if (lane == 0 && hits) atomicAdd(&P.hitStripe[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % kPairStripes], hits);
+  if (lane == 0 && hits) atomicAdd(&P.hitStripe[((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % kPairStripes) * kPairPad], hits);
 }
 // every node's meetings with itself: it is in every bucket of its own range, once per cell (quirk Q3)
 PIES_DEV uint32_t self_visits(const HashArrays& H, const PairArrays& P, uint32_t i, NodeState& a, const float4 p0, float friction, float staticThreshold) {
@@ -151,11 +151,12 @@ __global__ void __launch_bounds__(kBlock) k_pair_save(HashArrays H, PairArrays P
     P.ctl[kPairRetry] = 0;
     P.ctl[kPairRounds] = 0;
     P.ctl[kPairEdges] = 0;
-    P.ctl[kPairSavedCand] = H.counters[kCounterCandidates];
-    P.ctl[kPairSavedCand + 1] = H.counters[kCounterCandidates + 1];
+    P.ctl[kPairGroups] = 0;
+    P.ctl[kPairSpilled] = 0;
   }
-  if (i < kPairPools) P.pool[i] = 0;
-  if (i < 3u * kPairLists) P.frCount[i] = 0;
+  if (i < kPairPools) P.pool[i * kPairPad] = 0;
+  if (i < 3u * kPairLists) P.frCount[i * kPairPad] = 0;
+  if (i < 64u) { P.stat[i * kPairPad] = 0; P.stat[i * kPairPad + 1u] = 0; P.stat[i * kPairPad + 2u] = 0; }
   uint32_t hits = 0;
   if (i < P.n && !H.counters[kCounterFlags]) {
     const float4 p = pos[i], v = vel[i];
@@ -188,19 +189,67 @@ __global__ void __launch_bounds__(kBlock) k_pair_self(HashArrays H, PairArrays P
   count_hits(P, hits, lane);
 }
 
-// ---- lists: one workgroup per group (the nodes whose minimum cell is the same cell) ------------------------------------
+// ---- groups: one descriptor per group (the nodes whose minimum cell is the same cell) -------------------------------------
+// The list kernel works group by group; what it needs of a group - the buckets of the 2x2x2 cells above the group's cell - is
+// looked up here, one lane per cell in use, where the dependent look-ups of different cells overlap.
+//   descriptor: [0..7] first entry of the eight buckets   [8..11] their lengths, 16 bits each   [12] the cell's slot
+__global__ void __launch_bounds__(kBlock) k_pair_groups(HashArrays H, PairArrays P, uint32_t repeat) {
+  if (repeat && !P.ctl[kPairRetry]) return;
+  if (H.counters[kCounterFlags]) return;
+  __shared__ uint32_t lcount, lbase;
+  const uint32_t used = H.counters[kCounterUsed];
+  const GridBox B = grid_box(H.counters);
+  for (uint32_t first = blockIdx.x * kBlock; first < used; first += gridDim.x * kBlock) {  // (workgroup uniform)
+    if (threadIdx.x == 0) lcount = 0;
+    __syncthreads();
+    const uint32_t u = first + threadIdx.x;
+    uint32_t s = 0, rank = 0;
+    bool have = false;
+    if (u < used) {
+      s = H.used[u];
+      have = H.gcnt[s] != 0u;
+      if (have) rank = atomicAdd(&lcount, 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && lcount) lbase = atomicAdd(&P.ctl[kPairGroups], lcount);
+    __syncthreads();
+    if (have) {
+      int gx, gy, gz;
+      box_cell(B, H.keys[s], gx, gy, gz);
+      uint32_t st[8], cn[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const uint32_t cs = find_bucket(H, B, gx + ((c >> 2) & 1), gy + ((c >> 1) & 1), gz + (c & 1));
+        st[c] = cs != 0xffffffffu ? H.start[cs] : 0u;
+        cn[c] = cs != 0xffffffffu ? min(H.end[cs] - st[c], 0xffffu) : 0u;  // (a bucket holds at most 2048 nodes)
+      }
+      uint4* d = P.grp + 4ull * (lbase + rank);
+      d[0] = make_uint4(st[0], st[1], st[2], st[3]);
+      d[1] = make_uint4(st[4], st[5], st[6], st[7]);
+      d[2] = make_uint4(cn[0] | (cn[1] << 16), cn[2] | (cn[3] << 16), cn[4] | (cn[5] << 16), cn[6] | (cn[7] << 16));
+      d[3] = make_uint4(s, 0u, 0u, 0u);
+    }
+    __syncthreads();
+  }
+}
+
+// ---- lists: one workgroup per group -------------------------------------------------------------------------------------
 // Everything a node of the group can share a cell with sits in the buckets of the 2x2x2 cells above the group's cell.  A node
 // is in several of them; it is taken from the one that is the minimum corner of what its range shares with the block, which
 // the side bits of its entry decide without a look at the node: (cell's offset in the block) & (cell's side in the node's
 // range) == 0 on every axis.  The workgroup's wavefronts share the table of candidates and split the group's own nodes.
+// The kernel exists in two sizes.  The small one (a group of BASELINE config 4 has ~300 candidates, a node ~20 partners) keeps
+// twelve groups in flight per CU - the kernel is bound by the chain of dependent look-ups of a group, not by arithmetic - and
+// passes groups that do not fit on to a list the large one works through.
+template <uint32_t MAXC, uint32_t MAXD, uint32_t MAXOWN>
 struct BuildLds {
-  uint32_t id[kMaxCand];                                         // the distinct candidates: node index
-  float px[kMaxCand], py[kMaxCand], pz[kMaxCand], rs[kMaxCand];  // position at grid-build time, radius + slack
-  uint32_t rg[kMaxCand];                                         // (min cell - group cell + 1) per axis, 2 bits each; (length - 1) per axis from bit 8
-  uint16_t own[kMaxOwn];                                         // candidates that are the group's own nodes
-  uint32_t ncand, nown;
-  uint64_t lk[kBuildWaves][kMaxDeg];                             // one node's partners: pair key
-  uint32_t le[kBuildWaves][kMaxDeg];                             //                     partner | (shared cells - 1) << 28
+  uint32_t id[MAXC];                                 // the distinct candidates: node index
+  float px[MAXC], py[MAXC], pz[MAXC], rs[MAXC];      // position at grid-build time, radius + slack
+  uint32_t rg[MAXC];                                 // (min cell - group cell + 1) per axis, 2 bits each; (length - 1) per axis from bit 8
+  uint16_t own[MAXOWN];                              // candidates that are the group's own nodes
+  uint32_t ncand, nown, spill;
+  uint64_t lk[kBuildWaves][MAXD];                    // one node's partners: pair key
+  uint32_t le[kBuildWaves][MAXD];                    //                     partner | (shared cells - 1) << 28
 };
 
 // cells two ranges share on one axis: [a0, a0 + la) and [b0, b0 + lb)
@@ -210,11 +259,12 @@ PIES_DEV uint32_t shared_cells(int a0, uint32_t la, int b0, uint32_t lb) {
 }
 
 // appends the accepted candidates of the wavefront's lanes to the node's partner list in LDS; returns the new length
+template <uint32_t MAXD>
 PIES_DEV uint32_t push_partners(uint64_t* lk, uint32_t* le, uint32_t d, bool accept, uint32_t i, uint32_t j, uint32_t m, int lane) {
   const unsigned long long mask = __ballot(accept);
   if (accept) {
     const uint32_t at = d + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
-    if (at < kMaxDeg) {
+    if (at < MAXD) {
       lk[at] = pair_key(min(i, j), max(i, j));
       le[at] = j | ((m - 1u) << 28);
     }
@@ -224,13 +274,9 @@ PIES_DEV uint32_t push_partners(uint64_t* lk, uint32_t* le, uint32_t d, bool acc
 
 // sorts the d partners by key (rank sort: the keys are distinct) and writes the node's list into the wavefront's pool
 PIES_DEV void write_list(const PairArrays& P, const uint64_t* lk, const uint32_t* le, uint32_t i, uint32_t d, uint32_t pool, int lane) {
-  if (d > kMaxDeg) {  // a pile-up beyond anything a simulation survives: latch, like the > 2048 nodes in a cell of the grid
-    if (lane == 0) atomicOr(&P.ctl[kPairFlags], 2u);
-    d = kMaxDeg;
-  }
   uint32_t at = 0;
   for (uint32_t tries = 0;; ++tries) {  // a full pool (long lists of one dense group) passes the node on to the next one
-    if (lane == 0 && d) at = atomicAdd(&P.pool[pool], d);
+    if (lane == 0 && d) at = atomicAdd(&P.pool[pool * kPairPad], d);
     at = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(at)));
     if (at + d <= P.poolCap) break;
     if (tries + 1u == kPairPools) {  // (the node keeps an empty list; its partners wait for it for ever: flagged, the host latches the failure)
@@ -258,12 +304,15 @@ PIES_DEV void write_list(const PairArrays& P, const uint64_t* lk, const uint32_t
   __builtin_amdgcn_wave_barrier();
 }
 
+// BIG: the groups the small kernel passed on (and, beyond MAXC candidates, node by node straight from the buckets)
+template <uint32_t MAXC, uint32_t MAXD, uint32_t MAXOWN, bool BIG>
 __global__ void __launch_bounds__(64 * kBuildWaves) k_pair_build(HashArrays H, PairArrays P, uint32_t repeat) {
-  __shared__ BuildLds L;
+  __shared__ BuildLds<MAXC, MAXD, MAXOWN> L;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (repeat && !P.ctl[kPairRetry]) return;
   if (H.counters[kCounterFlags]) return;
-  const uint32_t used = H.counters[kCounterUsed];
+  const uint32_t ngroups = BIG ? min(P.ctl[kPairSpilled], P.n) : min(P.ctl[kPairGroups], P.n);
+  if (ngroups == 0u) return;
   const GridBox B = grid_box(H.counters);
   const uint32_t* __restrict__ val = H.val[grid_passes(B) & 1u];
   const uint32_t pool = (blockIdx.x * kBuildWaves + wv) % kPairPools;
@@ -271,24 +320,17 @@ __global__ void __launch_bounds__(64 * kBuildWaves) k_pair_build(HashArrays H, P
   uint32_t* le = L.le[wv];
   uint64_t tested = 0;
   uint32_t edges = 0;
-  for (uint32_t u = blockIdx.x; u < used; u += gridDim.x) {  // (workgroup uniform)
-    const uint32_t gslot = H.used[u];
-    if (H.gcnt[gslot] == 0u) continue;
-    int gx, gy, gz;
-    box_cell(B, H.keys[gslot], gx, gy, gz);
-    // the 2x2x2 cells above the group's cell (a range spans at most two cells per axis on this path)
-    uint32_t myStart = 0, myCnt = 0;
-    if (lane < 8) {
-      const uint32_t cs = find_bucket(H, B, gx + ((lane >> 2) & 1), gy + ((lane >> 1) & 1), gz + (lane & 1));
-      if (cs != 0xffffffffu) { myStart = H.start[cs]; myCnt = H.end[cs] - myStart; }
-    }
-    uint32_t cStart[8], cCnt[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      cStart[c] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(myStart), c));
-      cCnt[c] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(myCnt), c));
-    }
-    if (threadIdx.x == 0) { L.ncand = 0; L.nown = 0; }
+  uint64_t testedAll = 0;
+  uint32_t edgesAll = 0;
+  for (uint32_t u = blockIdx.x; u < ngroups; u += gridDim.x, testedAll += tested, edgesAll += edges) {  // (workgroup uniform)
+    tested = 0;
+    edges = 0;
+    const uint32_t g = BIG ? P.spill[u] : u;
+    const uint4* __restrict__ desc = P.grp + 4ull * g;
+    const uint4 d0 = desc[0], d1 = desc[1], d2 = desc[2];
+    const uint32_t cStart[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    const uint32_t cCnt[8] = {d2.x & 0xffffu, d2.x >> 16, d2.y & 0xffffu, d2.y >> 16, d2.z & 0xffffu, d2.z >> 16, d2.w & 0xffffu, d2.w >> 16};
+    if (threadIdx.x == 0) { L.ncand = 0; L.nown = 0; L.spill = 0; }
     __syncthreads();
     // ---- the distinct nodes of the eight buckets, each from its canonical cell; the group's own nodes.  Cells are dealt to the
     // wavefronts; a wavefront reserves a run of the table per 64 entries (the order of the table does not matter)
@@ -312,23 +354,29 @@ __global__ void __launch_bounds__(64 * kBuildWaves) k_pair_build(HashArrays H, P
         }
         at = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(at))) + static_cast<uint32_t>(__popcll(tm & ((1ull << lane) - 1ull)));
         ao = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ao))) + static_cast<uint32_t>(__popcll(mm & ((1ull << lane) - 1ull)));
-        if (take && at < kMaxCand) {
+        if (take && at < MAXC) {
           L.id[at] = v & kNodeMask;
           // the node's range relative to the group's cell, from the entry alone: its minimum is this cell minus the side bits
           const uint32_t side = (v >> kSideShift) & 7u, two = (v >> kLongShift) & 7u, cc = static_cast<uint32_t>(c);
           const uint32_t mnx = ((cc >> 2) & 1u) + 1u - ((side >> 2) & 1u), mny = ((cc >> 1) & 1u) + 1u - ((side >> 1) & 1u), mnz = (cc & 1u) + 1u - (side & 1u);
           L.rg[at] = mnx | (mny << 2) | (mnz << 4) | (((two >> 2) & 1u) << 8) | (((two >> 1) & 1u) << 14) | ((two & 1u) << 20);
         }
-        if (mine && ao < kMaxOwn && at < kMaxCand) L.own[ao] = static_cast<uint16_t>(at);
+        if (mine && ao < MAXOWN && at < MAXC) L.own[ao] = static_cast<uint16_t>(at);
       }
     }
     __syncthreads();
     const uint32_t ncand = L.ncand, nown = L.nown;
-    if (ncand > kMaxCand || nown > kMaxOwn) {
-      // ---- a dense neighbourhood (more than 512 nodes around one cell): candidates straight from the buckets, node by node
-      // (wavefront 0 alone).  A partner sits in several of the node's cells; it is taken where the cell is the minimum corner of
-      // what the two ranges share.
+    if (ncand > MAXC || nown > MAXOWN) {
+      if (!BIG) {  // does not fit the small kernel: the large one takes the group
+        if (threadIdx.x == 0) P.spill[atomicAdd(&P.ctl[kPairSpilled], 1u)] = g;
+        __syncthreads();
+        continue;
+      }
+      // ---- a dense neighbourhood: candidates straight from the buckets, node by node (wavefront 0 alone).  A partner sits in
+      // several of the node's cells; it is taken where the cell is the minimum corner of what the two ranges share.
       if (wv == 0) {
+        int gx, gy, gz;
+        box_cell(B, H.keys[desc[3].x], gx, gy, gz);
         for (uint32_t ge = 0; ge < cCnt[0]; ++ge) {
           const uint32_t v = val[cStart[0] + ge];
           if (!(v & kMinFlag)) continue;  // (wave uniform)
@@ -365,10 +413,14 @@ __global__ void __launch_bounds__(64 * kBuildWaves) k_pair_build(HashArrays H, P
                       }
                     }
                   }
-                  d = push_partners(lk, le, d, accept, i, j, m, lane);
+                  d = push_partners<MAXD>(lk, le, d, accept, i, j, m, lane);
                 }
               }
           __builtin_amdgcn_wave_barrier();
+          if (d > MAXD) {  // a pile-up beyond anything a simulation survives: latch, like the > 2048 nodes in a cell of the grid
+            if (lane == 0) atomicOr(&P.ctl[kPairFlags], 2u);
+            d = MAXD;
+          }
           write_list(P, lk, le, i, d, pool, lane);
           edges += d;
         }
@@ -388,9 +440,10 @@ __global__ void __launch_bounds__(64 * kBuildWaves) k_pair_build(HashArrays H, P
       const uint32_t rgi = L.rg[si];
       const uint32_t lxi = ((rgi >> 8) & 63u) + 1u, lyi = ((rgi >> 14) & 63u) + 1u, lzi = ((rgi >> 20) & 63u) + 1u;
       // the candidates the reference's loop would look at for this node (statistics: SURVEY 8d counts 16 B for each)
+      uint32_t looked = 0;
       for (uint32_t dx = 0; dx < lxi; ++dx)
         for (uint32_t dy = 0; dy < lyi; ++dy)
-          for (uint32_t dz = 0; dz < lzi; ++dz) tested += cCnt[(dx * 4 + dy * 2 + dz) & 7u];
+          for (uint32_t dz = 0; dz < lzi; ++dz) looked += cCnt[(dx * 4 + dy * 2 + dz) & 7u];
       uint32_t d = 0;
       for (uint32_t base = 0; base < ncand; base += 64) {
         const uint32_t t = base + static_cast<uint32_t>(lane);
@@ -398,7 +451,7 @@ __global__ void __launch_bounds__(64 * kBuildWaves) k_pair_build(HashArrays H, P
         uint32_t j = 0, m = 0;
         if (t < ncand && t != si) {
           const float ddx = L.px[t] - pix, ddy = L.py[t] - piy, ddz = L.pz[t] - piz;
-          const float cut = 1.001f * (rsi + L.rs[t]);  // (infinite for a node that left its slack in the first attempt)
+          const float cut = 1.001f * (rsi + L.rs[t]);  // (wide for a node that left its slack in the first attempt)
           if (!(ddx * ddx + ddy * ddy + ddz * ddz >= cut * cut)) {
             j = L.id[t];
             const uint32_t rgj = L.rg[t];
@@ -408,29 +461,31 @@ __global__ void __launch_bounds__(64 * kBuildWaves) k_pair_build(HashArrays H, P
             accept = m != 0u;
           }
         }
-        d = push_partners(lk, le, d, accept, i, j, m, lane);
+        d = push_partners<MAXD>(lk, le, d, accept, i, j, m, lane);
       }
       __builtin_amdgcn_wave_barrier();
+      if (d > MAXD) {
+        if (!BIG) { if (lane == 0) L.spill = 1; break; }  // (the large kernel redoes the group; lists written so far are replaced)
+        if (lane == 0) atomicOr(&P.ctl[kPairFlags], 2u);  // a pile-up beyond anything a simulation survives: latch
+        d = MAXD;
+      }
+      tested += looked;
       write_list(P, lk, le, i, d, pool, lane);
       edges += d;
     }
     __syncthreads();  // (the table is reused by the next group)
+    if (!BIG && L.spill) {
+      if (threadIdx.x == 0) P.spill[atomicAdd(&P.ctl[kPairSpilled], 1u)] = g;
+      tested = 0;  // (what this group has counted so far is counted again by the large kernel)
+      edges = 0;
+      __syncthreads();
+    }
   }
-  if (lane == 0 && tested) atomicAdd(reinterpret_cast<unsigned long long*>(&H.counters[kCounterCandidates]), static_cast<unsigned long long>(tested));
-  if (lane == 0 && edges) atomicAdd(&P.ctl[kPairEdges], edges);
+  // statistics, striped (same-address atomics of 16 000 wavefronts would take longer than the lists)
+  if (lane == 0 && testedAll) atomicAdd(reinterpret_cast<unsigned long long*>(&P.stat[(blockIdx.x % 64u) * kPairPad]), static_cast<unsigned long long>(testedAll));
+  if (lane == 0 && edgesAll) atomicAdd(&P.stat[(blockIdx.x % 64u) * kPairPad + 2u], edgesAll);
 }
 
-// ---- one level.  The frontier of round R holds the nodes that moved on to a new entry of their list in round R - 1 (all
-// nodes in round 1).  Node x looks at its entry (x, y): the pair's turn has come when y's current entry is (y, x) as well.  y's
-// record carries the round in which y reached its entry: R itself means that another lane is moving y on right now (too
-// fresh: y's lane of the next round will find x waiting); R - 1 means that y is in this frontier too and sees the same, and
-// the lower index of the two takes the pair; anything older means y has been waiting for x.  The pairs taken in one round
-// share no node.
-// A pair that does not overlap at its first visit is not moved by that visit, so none of its visits does anything: such pairs
-// (two thirds of the listed ones) are finished with one distance test.  A level is bound by the chain of dependent memory
-// round trips of one wavefront (record, partner's record, the two node lines, the next list entries) and of the up to sixteen
-// visits of a pair, not by arithmetic throughput: wavefronts are independent (no workgroup barrier), so that all of a level's
-// wavefronts are resident at once.
 // The frontier of a round is kept as kPairLists sub-lists.  A wavefront works on chunks of 64 consecutive positions of their
 // concatenation and appends to the sub-list its chunk is dealt to (chunk index modulo kPairLists).
 struct FrontierView {
@@ -440,7 +495,7 @@ struct FrontierView {
 PIES_DEV FrontierView frontier_view(const PairArrays& P, uint32_t round, int lane) {
   FrontierView v;
   if (round == 1u) { v.incl = 0; v.total = P.n; return v; }  // (all nodes, by index)
-  uint32_t c = min(__hip_atomic_load(&P.frCount[(round % 3u) * kPairLists + static_cast<uint32_t>(lane)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), P.frCap);
+  uint32_t c = min(__hip_atomic_load(&P.frCount[((round % 3u) * kPairLists + static_cast<uint32_t>(lane)) * kPairPad], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), P.frCap);
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const uint32_t t = __shfl_up(c, off, 64);
@@ -469,7 +524,7 @@ PIES_DEV void process_frontier(const HashArrays& H, const PairArrays& P, float f
                                uint32_t step, const FrontierView& view, int lane, uint32_t& hits) {
   float4* node = P.node;
   uint32_t* next = P.fr[(round + 1u) & 1u];
-  uint32_t* nextCount = P.frCount + ((round + 1u) % 3u) * kPairLists;
+  uint32_t* nextCount = P.frCount + ((round + 1u) % 3u) * kPairLists * kPairPad;
   const uint32_t stampNow = round & 0xffffu, stampPrev = (round - 1u) & 0xffffu;
   const uint32_t count = view.total;
   // moves a node on to its next entry (reached in this round); returns whether it has one
@@ -524,7 +579,7 @@ PIES_DEV void process_frontier(const HashArrays& H, const PairArrays& P, float f
     if (nx + ny) {
       const uint32_t sub = (base >> 6) % kPairLists;
       uint32_t at = 0;
-      if (lane == 0) at = atomicAdd(&nextCount[sub], nx + ny);
+      if (lane == 0) at = atomicAdd(&nextCount[sub * kPairPad], nx + ny);
       at = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(at)));
       uint32_t* dst = next + static_cast<size_t>(sub) * P.frCap;
       const uint32_t ix = at + static_cast<uint32_t>(__popcll(mx & ((1ull << lane) - 1ull)));
@@ -541,7 +596,7 @@ __global__ void __launch_bounds__(64) k_pair_round(HashArrays H, PairArrays P, f
   const int lane = threadIdx.x;
   const FrontierView view = frontier_view(P, round, lane);
   if (blockIdx.x == 0) {
-    P.frCount[((round + 2u) % 3u) * kPairLists + threadIdx.x] = 0;  // the lists of the round after the next (read by the previous launch, filled by the next)
+    P.frCount[(((round + 2u) % 3u) * kPairLists + threadIdx.x) * kPairPad] = 0;  // the lists of the round after the next (read by the previous launch, filled by the next)
     if (threadIdx.x == 0 && view.total) P.ctl[kPairRounds] = round;
   }
   if (view.total == 0u) return;  // (a pass that will be repeated is finished all the same: it finds every node that leaves its slack)
@@ -562,7 +617,7 @@ __global__ void __launch_bounds__(1024) k_pair_tail(HashArrays H, PairArrays P, 
     const FrontierView view = frontier_view(P, round, lane);
     if (view.total == 0u) break;  // (the same words for every wavefront: all leave together)
     __syncthreads();  // every wavefront has read the counts before the lists after the next are cleared
-    if (threadIdx.x < kPairLists) __hip_atomic_store(&P.frCount[((round + 2u) % 3u) * kPairLists + threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < kPairLists) __hip_atomic_store(&P.frCount[(((round + 2u) % 3u) * kPairLists + threadIdx.x) * kPairPad], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x == 0) P.ctl[kPairRounds] = round;
     process_frontier(H, P, friction, staticThreshold, round, threadIdx.x, blockDim.x, view, lane, hits);
     __threadfence();
@@ -647,12 +702,23 @@ __global__ void __launch_bounds__(kBlock) k_pair_check(HashArrays H, PairArrays 
   // the pass's resolved pairs go to the statistics when its result stands (a pass that is repeated counts once)
   if (blockIdx.x == 0 && !repeat) {
     uint32_t sum = 0;
-    for (uint32_t k = threadIdx.x; k < kPairStripes; k += kBlock) { sum += P.hitStripe[k]; P.hitStripe[k] = 0; }
+    for (uint32_t k = threadIdx.x; k < kPairStripes; k += kBlock) { sum += P.hitStripe[k * kPairPad]; P.hitStripe[k * kPairPad] = 0; }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
     if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&H.counters[kCounterPairs], sum);
+    if (threadIdx.x < 64) {  // candidates looked at (64 bit) and listed entries
+      unsigned long long c = *reinterpret_cast<unsigned long long*>(&P.stat[threadIdx.x * kPairPad]);
+      uint32_t e = P.stat[threadIdx.x * kPairPad + 2u];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) { c += __shfl_xor(c, o, 64); e += __shfl_xor(e, o, 64); }
+      if (threadIdx.x == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(&H.counters[kCounterCandidates]), c);
+        P.ctl[kPairEdges] = e;
+      }
+    }
   } else if (blockIdx.x == 0) {
-    for (uint32_t k = threadIdx.x; k < kPairStripes; k += kBlock) P.hitStripe[k] = 0;
+    for (uint32_t k = threadIdx.x; k < kPairStripes; k += kBlock) P.hitStripe[k * kPairPad] = 0;
+    if (threadIdx.x < 64) { P.stat[threadIdx.x * kPairPad] = 0; P.stat[threadIdx.x * kPairPad + 1u] = 0; P.stat[threadIdx.x * kPairPad + 2u] = 0; }
   }
   if (i != 0 || first) return;
   if (flags & 1u) P.ctl[kPairInexact] += 1;
@@ -662,8 +728,8 @@ __global__ void __launch_bounds__(kBlock) k_pair_check(HashArrays H, PairArrays 
 // (one thread, after every block of the first k_pair_check has read the flags)
 __global__ void k_pair_arm(HashArrays H, PairArrays P) {
   if (P.ctl[kPairFlags] & 1u) {
-    if (threadIdx.x < kPairPools) P.pool[threadIdx.x] = 0;
-    for (uint32_t k = threadIdx.x; k < 3u * kPairLists; k += 64) P.frCount[k] = 0;
+    if (threadIdx.x < kPairPools) P.pool[threadIdx.x * kPairPad] = 0;
+    for (uint32_t k = threadIdx.x; k < 3u * kPairLists; k += 64) P.frCount[k * kPairPad] = 0;
   }
   if (threadIdx.x != 0) return;
   const uint32_t flags = P.ctl[kPairFlags];
@@ -676,8 +742,7 @@ __global__ void k_pair_arm(HashArrays H, PairArrays P) {
   P.ctl[kPairRetries] += 1;
   P.ctl[kPairFlags] = 0;
   P.ctl[kPairEdges] = 0;
-  H.counters[kCounterCandidates] = P.ctl[kPairSavedCand];
-  H.counters[kCounterCandidates + 1] = P.ctl[kPairSavedCand + 1];
+  P.ctl[kPairSpilled] = 0;
 }
 
 uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArrays& P, const NodeArrays& nd, float friction,
@@ -689,9 +754,11 @@ uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArr
   const dim3 groups(std::max<uint32_t>(1u, std::min<uint32_t>(8192u, n / 8 + 1)));
   const dim3 level(std::max<uint32_t>(1u, std::min<uint32_t>(8192u, (n + 63u) / 64u)));
   hipLaunchKernelGGL(k_pair_save, perNode, dim3(kBlock), 0, st, H, P, nd.pos, nd.vel, nd.radius, friction, staticThreshold); ++launches;
+  hipLaunchKernelGGL(k_pair_groups, dim3(std::min<uint32_t>(2048u, (H.capacity / 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, H, P, 0u); ++launches;
   for (uint32_t repeat = 0; repeat < 2; ++repeat) {
     if (repeat) { hipLaunchKernelGGL(k_pair_self, perNode, dim3(kBlock), 0, st, H, P, friction, staticThreshold); ++launches; }
-    hipLaunchKernelGGL(k_pair_build, groups, dim3(64 * kBuildWaves), 0, st, H, P, repeat); ++launches;
+    hipLaunchKernelGGL((k_pair_build<384, 96, 64, false>), groups, dim3(64 * kBuildWaves), 0, st, H, P, repeat); ++launches;
+    hipLaunchKernelGGL((k_pair_build<kMaxCand, kMaxDeg, kMaxOwn, true>), dim3(512), dim3(64 * kBuildWaves), 0, st, H, P, repeat); ++launches;
     for (uint32_t r = 1; r <= rounds; ++r) {  // (the repeat's launches return at once when nothing is repeated: 2.5 us each)
       hipLaunchKernelGGL(k_pair_round, level, dim3(64), 0, st, H, P, friction, staticThreshold, r, repeat); ++launches;
     }
