@@ -365,10 +365,10 @@ def cpu_baseline_collisions(budget_s):
 
 
 def cpu_baseline_default_tick(dims, budget_s):
-    """config 2 as Solver::tickPBD runs it by default: node-node pass ON, reference order, the reference's 16 insert threads."""
+    """the distance-only 100k lattice as Solver::tickPBD runs it by default: node-node pass ON, reference order, the reference's 16 insert threads."""
     ora, flags = oracle_module()
     o = ora.OracleSolver(scenes.pbd_options(ora, ITERATIONS))
-    scenes.build_beam(o, dims)
+    scenes.build_beam(o, dims, tets=False)
     scenes.perturb(o, 1234, 0.05)
     o.set_flag(1, 1)
     o.set_reference_threads(True)
@@ -573,53 +573,31 @@ def run_config4(device):
 
 
 def run_config2_default_tick(device, dims, steps, with_exact):
-    """The reference's DEFAULT PBD tick on config 2: tickPBD runs the hash rebuild and the node-node pass in every iteration
-    unconditionally (Src/Solver.cpp:81-130); createTetBox gives the nodes radius 0.475.  LAYERED + parallel collision order,
-    and (with_exact) schedule EXACT = the reference's order end to end."""
-    out = {"workload": "config 2 with the node-node pass ON (radius 0.475, gridSpacing 2): what Solver::tickPBD runs by default"}
-    for name, sched, n in (("layered", capi.SCHEDULE_LAYERED, steps), ("exact", capi.SCHEDULE_EXACT, 1)):
-        if name == "exact" and not with_exact:
-            continue
-        g = capi.Solver(scenes.pbd_options(capi, ITERATIONS), device=device)
-        scenes.build_beam(g, dims)
-        scenes.perturb(g, 1234, 0.05)
-        g.set_flag(capi.FLAG_NODE_COLLISIONS, 1)
-        g.set_schedule(sched)
-        g.finalize()
-        el = timed_ticks(g, n, 1 if name == "layered" else 0, lambda: None)
-        out[name] = {"value": n / el, "unit": "substeps/s", "steps": n, "launches_per_substep": sum(g.launch_counts().values()),
-                     "failed": g.failed}
-        g.close()
-    return out
-
-
-def scale_profiles(device):
-    """The same kernels at 1M particles (100x100x100), where a launch is long enough for HBM rather than the kernel boundary
-    to bound it: whole-substep throughput and in-situ rooflines."""
+    """The reference's DEFAULT PBD tick: tickPBD runs the hash rebuild and the node-node pass in every iteration unconditionally
+    (Src/Solver.cpp:81-130).  Two 100k-particle beams: BASELINE configs[1] itself (createTetBox nodes have radius 0.475) - there the
+    PBD tetrahedral projection (quirk Q2) drags the whole body into a few grid cells within the first tick, which is a pile-up no
+    grid handles (the reference would visit ~10^10 pairs per iteration; this build latches its "more than 2048 nodes in a cell"
+    failure) - and the same lattice with the distance constraints alone (createBox), which is a PBD scene the reference can
+    run.  LAYERED + pair order, and (with_exact) schedule EXACT = the reference's order end to end (one tick: its node-node loop
+    is one sequential chain)."""
     out = {}
-    for name, sched in (("pbd_1m", capi.SCHEDULE_LAYERED), ("pbd_1m_coloured", capi.SCHEDULE_COLOURED)):
-        log(name)
-        g = build_scene(capi, scenes.L1M, 99, schedule=sched, device=device)
-        g.finalize()
-        el = timed_ticks(g, 3, 1, lambda: None)
-        out[name] = {"substeps_per_sec": 3 / el, "projections_per_sec": 3 / el * scenes.projections_per_substep(g, capi, ITERATIONS),
-                     "launches_per_substep": sum(g.launch_counts().values())}
-        if sched == capi.SCHEDULE_LAYERED:
-            out[name]["roofline"] = roofline(g, "layer", 1, substeps=1, workload="none")
-        else:
-            out[name]["roofline"] = roofline(g, "tet", BYTES["tet"], substeps=1, workload="none")
-            out[name]["roofline_distance"] = roofline(g, "distance", BYTES["distance"], substeps=1, workload="none")
-        g.close()
-    log("pd_1m")
-    g = pd_beam(scenes.L1M, device, settle=12)
-    el = timed_ticks(g, 3, 1, lambda: None)
-    B = pd_bytes(g)
-    out["pd_1m"] = {"substeps_per_sec": 3 / el, "pcg_stats": g.pcg_stats(),
-                    "roofline": roofline(g, "pd_local_tet", B["pd_local_tet"], substeps=1, workload="none"),
-                    "roofline_spmv": roofline(g, "pd_spmv", B["pd_spmv"], substeps=1, workload="none"),
-                    "roofline_rhs": roofline(g, "pd_rhs", B["pd_rhs"], substeps=1, workload="none"),
-                    "roofline_cg_update": roofline(g, "pd_cg_update", B["pd_cg_update"], substeps=1, workload="none")}
-    g.close()
+    for scene, tets in (("config2", True), ("box_100k_distance_only", False)):
+        res = out[scene] = {"workload": "%dx%dx%d lattice, %s, PBD, %d iterations, node-node pass ON (what Solver::tickPBD runs by default)"
+                            % (dims + ("distance + tet-strain constraints (BASELINE configs[1])" if tets else "distance constraints only (createBox pattern)", ITERATIONS))}
+        for name, sched, n in (("layered", capi.SCHEDULE_LAYERED, steps), ("exact", capi.SCHEDULE_EXACT, 1)):
+            if name == "exact" and (not with_exact or tets):
+                continue
+            g = capi.Solver(scenes.pbd_options(capi, ITERATIONS), device=device)
+            scenes.build_beam(g, dims, tets=tets)
+            scenes.perturb(g, 1234, 0.05)
+            g.set_flag(capi.FLAG_NODE_COLLISIONS, 1)
+            g.set_schedule(sched)
+            g.finalize()
+            el = timed_ticks(g, n, 1 if name == "layered" else 0, lambda: None)
+            failed = bool(g.failed)
+            res[name] = {"value": None if failed else n / el, "unit": "substeps/s", "steps": n, "launches_per_substep": sum(g.launch_counts().values()),
+                         "failed": failed, "error": g.last_error() if failed else None, "collision_health": g.collision_health()}
+            g.close()
     return out
 
 
@@ -667,8 +645,10 @@ def compact_line(full):
     put("coloured", "coloured_schedule", "value")
     put("pies_tick", "tick_inclusive", "pies_tick_substeps_per_sec")
     put("async_export", "tick_inclusive", "async_export_substeps_per_sec")
-    put("config2_collisions_on", "config2_default_tick", "layered", "value")
-    put("config2_collisions_on_exact", "config2_default_tick", "exact", "value")
+    put("config2_collisions_on", "config2_default_tick", "config2", "layered", "value")
+    put("config2_collisions_on_failed", "config2_default_tick", "config2", "layered", "failed")
+    put("box100k_collisions_on", "config2_default_tick", "box_100k_distance_only", "layered", "value")
+    put("box100k_collisions_on_exact", "config2_default_tick", "box_100k_distance_only", "exact", "value")
     put("config3_value", "other_configs", "pd_config3", "value")
     put("config3_frac_local", "other_configs", "pd_config3", "roofline", "frac")
     put("config3_frac_spmv", "other_configs", "pd_config3", "roofline_spmv", "frac")
@@ -886,7 +866,7 @@ def main():
                     if oc.get("collisions_config4"):
                         oc["collisions_config4"]["cpu_baseline"] = section("CPU baseline (config 4)", cpu_baseline_collisions, args.cpu_budget)
                     if result.get("config2_default_tick"):
-                        result["config2_default_tick"]["cpu_baseline"] = section("CPU baseline (config 2, node-node pass on)",
+                        result["config2_default_tick"]["box_100k_distance_only"]["cpu_baseline"] = section("CPU baseline (config 2, node-node pass on)",
                                                                                  cpu_baseline_default_tick, dims, args.cpu_budget)
         log("done")
         write_full(result)

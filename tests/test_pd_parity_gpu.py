@@ -19,6 +19,36 @@ REL = 1e-5
 
 def tol_for(p):
     return REL * float(np.linalg.norm(p.max(0) - p.min(0))) + 2e-5
+
+
+# Every comparison with the oracle is also RECORDED: the largest |device - oracle| per test, as a multiple of the lattice spacing
+# (1.0 in all these scenes) and of the gate it was held against.  The record goes to gpurun_out/pd_deviation.json (DESIGN.md
+# section 7 quotes it; profiles/r03_pd_deviation.json is a copy).  GATE[...] are the gates of the full-size scenes, in units of the
+# lattice spacing: at most four times the largest deviation measured on the MI355X in round 3 - 7.2e-4 on config 3 (two ticks,
+# coordinates up to 250), 7.4e-4 on config 5's body with binding contacts (three teacher-forced ticks, coordinates up to 400),
+# 1.25e-4 on the 5 000-contact plates.  (1e-4 x spacing, SURVEY 8c's proposal, is what the 10^3 lattice meets: 1.5e-4.)
+_RECORD = {}
+GATE = {"config3_l100k": 2.8e-3, "config5_l250k_contacts": 2.9e-3, "thousands_of_contacts": 4.0e-4}
+
+
+def record(test, what, deviation, gate):
+    import json
+    e = _RECORD.setdefault(test, {}).setdefault(what, {"max_deviation": 0.0, "gate": gate})
+    e["max_deviation"] = max(e["max_deviation"], float(deviation))
+    e["gate"] = float(gate)
+    e["deviation_over_gate"] = e["max_deviation"] / e["gate"] if e["gate"] else None
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "pd_deviation.json"), "w") as f:
+            json.dump(_RECORD, f, indent=1, sort_keys=True)
+
+
+def within(test, g, o, gate, what="positions"):
+    """max |device - oracle| of one state array against `gate` (recorded, then asserted)"""
+    d = float(np.abs(getattr(g, what) - getattr(o, what)).max())
+    record(test, what, d, gate)
+    assert np.isfinite(getattr(g, what)).all() and d <= gate, (test, what, d, gate)
+    return d
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -62,10 +92,7 @@ def test_pd_beam_against_oracle(pies, oracle, dims, iters):
     for t in range(5):
         g.tick(); o.tick()
         for name in ("positions", "velocities", "prev_positions"):
-            a, b = getattr(g, name), getattr(o, name)
-            scale = 1.0 if name != "velocities" else 1.0 / 0.012
-            assert np.isfinite(a).all()
-            assert np.abs(a - b).max() <= TOL * scale, (t, name, np.abs(a - b).max())
+            within("pd_beam_%dx%dx%d" % dims, g, o, TOL * (1.0 if name != "velocities" else 1.0 / 0.012), name)
     res, iters_used, solves = g.pcg_stats()
     assert res <= 1e-6 and iters_used < 12 and solves == iters
     assert o.count(oracle.STATICS) > 0  # floor contacts active (duplicated per triangle incidence)
@@ -117,12 +144,11 @@ def test_config3_l100k_against_oracle(pies, oracle):
         scenes.perturb(s, 21, 0.03)
         s.set_prev_positions(s.positions)
     assert g.count(pies.TET) == g.count(pies.VOLUME) == 539334
-    tol = tol_for(o.positions)
+    tol = GATE["config3_l100k"]
     for t in range(2):
         g.tick(); o.tick()
         for name in ("positions", "prev_positions", "velocities"):
-            d = np.abs(getattr(g, name) - getattr(o, name)).max()
-            assert d <= tol * (1.0 if name != "velocities" else 1.0 / 0.012), (t, name, d, tol)
+            within("config3_l100k", g, o, tol * (1.0 if name != "velocities" else 1.0 / 0.012), name)
     res, iters_used, solves = g.pcg_stats()
     assert solves == 10 and res <= 3e-7 * 1.0001
     assert g.pcg_health()["short_solves"] == 0 and not g.failed
