@@ -184,6 +184,20 @@ def test_config4_l500k_one_tick(pies, oracle):
     assert h["passes_inexact"] == 0 and h["levels"] > 0
 
 
+def test_config4_l500k_one_iteration_reference_order(pies, oracle):
+    """BASELINE config 4 at full size in the REFERENCE's order (rule 0: ascending node index, range from the node's live position):
+    the loop is one dependent chain on one wavefront (~20 us per node), so one iteration - 500 000 visits, >18 M resolved pairs -
+    against the oracle's plain loop.  Exact equality."""
+    p, v = particles(scenes.L500K)
+
+    def build(s):
+        s.addNodes(p)
+        s.set_velocities(v)
+    g, o = pair(pies, oracle, build, 1, 1, rule=0)
+    check(g, o)
+    assert g.collision_pairs == o.collision_pairs > 10_000_000
+
+
 def test_dense_cells_take_the_unstaged_path(pies, oracle):
     """More distinct nodes around one cell than the resolve kernel stages in LDS (256): those groups are resolved
     straight from global memory, the others from LDS, inside the same passes; both must replay the same order."""

@@ -381,6 +381,14 @@ def test_config2_l100k_one_tick_layered(pies, oracle):
     assert g.launch_counts()["layer"] == 41
 
 
+def test_config2_l100k_one_tick_reference_order(pies, oracle):
+    """BASELINE config 2 at full size in the REFERENCE's order (schedule EXACT: every container swept in the order the host added
+    the constraints; 2 879 launches): one tick against the oracle's plain loops, nothing replayed.  Exact equality."""
+    g, o = _pair(pies, oracle, scenes.L100K, 20, pies.SCHEDULE_EXACT, ticks=1)
+    _check(g, o)
+    assert g.launch_counts()["wave"] > 2000
+
+
 def test_config2_l100k_one_tick(pies, oracle):
     """BASELINE config 2 at full size (20x20x250, 20 iterations): one tick against the oracle, coloured
     schedule replayed, plus a checksum over both schedules' launch plans."""
