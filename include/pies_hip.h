@@ -244,6 +244,14 @@ int pies_collision_stats(pies_solver_t* s, uint64_t* pairs, uint64_t* candidates
 /* Pair order: level launches captured per pass (default 128; a single-workgroup kernel finishes deeper orders, slowly).
  * BASELINE config 4 needs about 75. */
 int pies_set_collision_rounds(pies_solver_t* s, uint32_t rounds);
+/* Tuning and diagnostic switches, process wide, by name (value NULL or "" unsets): graph variants and sizes that tests and
+ * profiling scripts pin - PIES_PCG_BUDGET, PIES_PCG_OVERFLOW, PIES_TRI_FAST_ROWS, PIES_TRI_LDS, PIES_ROW_MAX_UNIQUE, PIES_TRI_SIDE,
+ * PIES_NO_GRAPH, PIES_NO_WAVEFRONT, PIES_NO_TET_PAIRS, PIES_LAYER_ONE_STRIP_MAX / _TILE_NODES / _STRIPS_MIN_NODES / PIES_LAYER_BLOCK,
+ * PIES_COLOUR_ROUNDS, PIES_COLOUR_DSATUR, PIES_NO_COLOUR_HINT, PIES_SELL_LANES, PIES_CG_BLOCKS, PIES_COLLIDE_GLOBAL / _PASSES /
+ * _SPIN_LIMIT.  They take effect where the library reads them (pies_create, pies_finalize or the next graph capture).  None of
+ * them is read from the environment: the only environment variables the library looks at are PIES_SCHEDULE (default schedule
+ * of new handles), PIES_PROFILER_SAFE (profiling runs) and the print-only PIES_PCG_DEBUG / PIES_LAYER_DEBUG. */
+int pies_set_tuning(const char* name, const char* value);
 /* Diagnostics of the pair order: per node the slack for the next pass, the excursion and the listed partners of the last pass. */
 int pies_debug_pair_state(pies_solver_t* s, float* slack, float* excursion, uint32_t* partners, uint32_t n);
 int pies_get_collision_health(pies_solver_t* s, uint32_t* levels, uint32_t* pairs_listed, uint32_t* passes_repeated, uint32_t* passes_inexact);

@@ -41,12 +41,19 @@ SYMBOLS = [
     "pies_add_linked_regions", "pies_create_shape_matching_box", "pies_create_shape_matching_sheet", "pies_get_group",
     "pies_get_tri_contacts", "pies_tick_begin", "pies_export_acquire", "pies_export_release",
     "pies_read_positions_strided", "pies_set_pcg_retry", "pies_get_pcg_health", "pies_profile_in_situ",
-    "pies_collision_stats", "pies_get_collision_health", "pies_set_collision_rounds", "pies_set_solver", "pies_debug_pair_state",
+    "pies_collision_stats", "pies_get_collision_health", "pies_set_collision_rounds", "pies_set_solver", "pies_debug_pair_state", "pies_set_tuning",
 ]
 
 
 class PiesError(RuntimeError):
     pass
+
+
+def set_tuning(name, value):
+    """pies_set_tuning: process-wide tuning / diagnostic switch (value None unsets)"""
+    rc = load().pies_set_tuning(name.encode(), None if value is None else str(value).encode())
+    if rc != OK:
+        raise PiesError("pies_set_tuning(%s): invalid name" % name)
 
 
 class Options(C.Structure):
@@ -134,6 +141,7 @@ def load():
         "pies_debug_pair_state": [vp, pf, pf, pu, u32],
         "pies_profile_in_situ": [vp, i32, u32, pu, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)],
     }
+    sig["pies_set_tuning"] = [C.c_char_p, C.c_char_p]
     for name, args in sig.items():
         fn = getattr(L, name)
         fn.argtypes = args

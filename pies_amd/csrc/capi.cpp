@@ -11,9 +11,21 @@
 
 #include "device_util.h"
 
+#include <map>
+#include <mutex>
+
 using namespace pies;
 
 namespace pies {
+
+// pies_set_tuning's registry (see kernels.h: tuning_env).  Values live as long as the process: a pointer handed out stays valid.
+static std::mutex& tuning_mutex() { static std::mutex m; return m; }
+static std::map<std::string, std::string>& tuning_map() { static std::map<std::string, std::string> m; return m; }
+const char* tuning_env(const char* name) {
+  std::lock_guard<std::mutex> lock(tuning_mutex());
+  auto it = tuning_map().find(name);
+  return it == tuning_map().end() || it->second.empty() ? nullptr : it->second.c_str();
+}
 
 // PIES_PROFILER_SAFE=1 (set by the profiling scripts): rocprofv3 7.2 on this pool segfaults when tens of
 // thousands of graph kernel nodes are queued without a synchronisation, or when a graph is destroyed
@@ -399,7 +411,7 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
     // the sequential passes behind the local/global iterations: a second branch of the substep, joined there.
     // Only in the contact-heavy graph variant: a fork and join inside a hipGraph costs about 100 us per replay (measured:
     // config 3, no contact, 1 257 -> 1 120 substeps/s with the branch; 29k contacts, 197 -> 234 with it).
-    const char* e = std::getenv("PIES_TRI_SIDE");  // diagnostics: 0 = always in line, 1 = always beside
+    const char* e = tuning_env("PIES_TRI_SIDE");  // diagnostics: 0 = always in line, 1 = always beside
     s->triLevelsForked = e ? e[0] != '0' : s->triFastRows;
     if (s->triLevelsForked) {
       (void)hipEventRecord(s->evFork, st);
@@ -485,7 +497,7 @@ static int capture_graph(pies_solver* s) {
   destroy_graph(s);
   std::memset(s->launchCounts, 0, sizeof(s->launchCounts));
   if (s->nd.n == 0) return PIES_OK;
-  if (const char* e = std::getenv("PIES_NO_GRAPH"); e && e[0] == '1') {
+  if (const char* e = tuning_env("PIES_NO_GRAPH"); e && e[0] == '1') {
     // count launches without running them: a capture that is thrown away
     HIP_TRY(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
     enqueue_substep(s, s->launchCounts);
@@ -555,7 +567,7 @@ static int adapt_pcg_budget(pies_solver* s) {
   // substep saw (on at 512 contacts, off after 120 synchronisations without any).
   bool fastRows = s->triFastRows;
   if (s->pd.tri.nt && s->pd.tri.counters) {
-    static const int force = [] { const char* e = std::getenv("PIES_TRI_FAST_ROWS"); return e ? std::atoi(e) : -1; }();
+    const int force = [] { const char* e = tuning_env("PIES_TRI_FAST_ROWS"); return e ? std::atoi(e) : -1; }();
     uint32_t contacts = 0;
     HIP_TRY(s, hipMemcpyAsync(&contacts, s->pd.tri.counters + 2, sizeof(contacts), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(s, hipStreamSynchronize(s->stream));
@@ -624,8 +636,8 @@ void pies_default_options(pies_options_t* o) {
 
 // PIES_SCHEDULE overrides PIES_SCHEDULE_DEFAULT for new handles (not an explicit pies_set_schedule)
 static void apply_schedule_environment(pies_solver* s) {
-  if (const char* e = std::getenv("PIES_PCG_OVERFLOW")) s->pcgOverflow = e[0] != '0';
-  if (const char* e = std::getenv("PIES_PCG_BUDGET")) {  // diagnostics: the captured CG iterations, never adapted
+  if (const char* e = tuning_env("PIES_PCG_OVERFLOW")) s->pcgOverflow = e[0] != '0';
+  if (const char* e = tuning_env("PIES_PCG_BUDGET")) {  // diagnostics: the captured CG iterations, never adapted
     const int v = std::atoi(e);
     if (v >= 1 && v <= 4096) { s->pcgPinned = true; s->pcgPinnedBudget = static_cast<uint32_t>(v); s->pcgBudget = std::min(s->pcgMaxIters, s->pcgPinnedBudget); }
   }
@@ -854,7 +866,7 @@ static int build_plans(pies_solver* s, int sched) {
   ids.resize(4 * s->h_bend.size());
   for (size_t i = 0; i < s->h_bend.size(); ++i) std::memcpy(&ids[4 * i], s->h_bend[i].ids, 16);
   build_plan({ids.data(), 4, (uint32_t)s->h_bend.size(), 0xF}, n, sched, s->plan[PIES_BEND]);
-  const char* noWave = std::getenv("PIES_NO_WAVEFRONT");
+  const char* noWave = tuning_env("PIES_NO_WAVEFRONT");
   if (sched == PIES_SCHEDULE_EXACT && !(noWave && noWave[0] == '1')) build_wave_plan(s, s->wave);
   return PIES_OK;
 }
@@ -1080,7 +1092,7 @@ int pies_finalize(pies_solver_t* s) {
       const HostTet &a = s->h_tet[s->plan[PIES_TET].order[k]], &b = s->h_volume[k];
       s->tetVolumePaired = std::memcmp(a.ids, b.ids, sizeof(a.ids)) == 0 && std::memcmp(a.qinv, b.qinv, sizeof(a.qinv)) == 0;
     }
-    if (const char* e = std::getenv("PIES_NO_TET_PAIRS"); e && e[0] == '1') s->tetVolumePaired = false;
+    if (const char* e = tuning_env("PIES_NO_TET_PAIRS"); e && e[0] == '1') s->tetVolumePaired = false;
     if (int rc = pd_build(s)) return rc;
     if (n) {  // input of a substep, kept until its solves are known to have met the tolerance (pd_tick_checked)
       if (int rc = dev_alloc(s, n, &s->snapPos)) return rc;
@@ -1352,6 +1364,21 @@ int pies_debug_pair_state(pies_solver_t* s, float* slack, float* excursion, uint
   for (uint32_t i = 0; i < n; ++i) {
     if (slack) slack[i] = node[4ull * i + 2].w;
     if (degree) std::memcpy(&degree[i], &node[4ull * i + 3].y, sizeof(uint32_t));
+  }
+  return PIES_OK;
+}
+
+int pies_set_tuning(const char* name, const char* value) {
+  if (!name || std::strncmp(name, "PIES_", 5) != 0) return PIES_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(tuning_mutex());
+  if (value && value[0]) {
+    static std::vector<std::string> retired;  // (a value that is replaced may still be pointed at by a caller of tuning_env)
+    auto it = tuning_map().find(name);
+    if (it != tuning_map().end()) retired.push_back(std::move(it->second));
+    tuning_map()[name] = value;
+  } else {
+    auto it = tuning_map().find(name);
+    if (it != tuning_map().end()) it->second.clear();
   }
   return PIES_OK;
 }

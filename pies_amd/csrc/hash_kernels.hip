@@ -951,13 +951,13 @@ uint32_t launch_hash_build(hipStream_t st_, const HashArrays& H, const NodeArray
 uint32_t launch_collide(hipStream_t st_, const HashArrays& H, const NodeArrays& nd, float friction, float staticThreshold, bool rearm) {
   if (nd.n == 0) return 0;
   const dim3 grid(std::max<uint32_t>(1u, std::min<uint32_t>(2048u, (nd.n / 8 + 1) / 2)));
-  auto flag = [](const char* name) { const char* e = std::getenv(name); return e && e[0] == '1' ? 1 : 0; };
+  auto flag = [](const char* name) { const char* e = tuning_env(name); return e && e[0] == '1' ? 1 : 0; };
   const int forceGlobal = flag("PIES_COLLIDE_GLOBAL");  // diagnostics, read when the substep is captured
   const int passes = flag("PIES_COLLIDE_PASSES");
   if (!passes) {
     uint32_t maxSpins = kColMaxSpins;
-    if (const char* e = std::getenv("PIES_COLLIDE_SPIN_LIMIT")) maxSpins = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
-    else if (flag("PIES_PROFILER_SAFE")) maxSpins = 0;
+    if (const char* e = tuning_env("PIES_COLLIDE_SPIN_LIMIT")) maxSpins = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+    else if (const char* e = std::getenv("PIES_PROFILER_SAFE"); e && e[0] == '1') maxSpins = 0;
     if (rearm) hipLaunchKernelGGL(k_collide_rearm, dim3(1), dim3(64), 0, st_, H);
     hipLaunchKernelGGL(k_collide_flow, grid, dim3(kColBlock), 0, st_, H, nd.pos, nd.vel, nd.radius, friction, staticThreshold, forceGlobal,
                        maxSpins);

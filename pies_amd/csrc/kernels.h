@@ -6,6 +6,11 @@
 
 namespace pies {
 
+// Tuning / diagnostic switches that change what is captured (graph variants, CG budget, tile sizes, ...).  They are set with
+// pies_set_tuning (process wide, by name) - NOT read from the environment: a host's environment cannot alter a shipped solver.
+// Returns the value as a string, or nullptr when the switch is not set.  (capi.cpp)
+const char* tuning_env(const char* name);
+
 struct NodeArrays {
   float4* pos;    // x, y, z, invMass
   float4* prev;   // x, y, z, (unused)

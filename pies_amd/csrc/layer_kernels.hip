@@ -324,7 +324,7 @@ void launch_layer(hipStream_t st, const NodeArrays& nd, const LayerData& D, cons
   const int variant = [] { const char* e = getenv("PIES_EXP_TET"); return e ? atoi(e) : 0; }();
   if (variant == 1) { hipLaunchKernelGGL((k_layer<256, 1>), dim3(L.groups), dim3(256), lds, st, nd, D, L, P); return; }  // no SVD
 #endif
-  const uint32_t forceBlock = [] { const char* e = getenv("PIES_LAYER_BLOCK"); return e ? (uint32_t)atoi(e) : 0u; }();  // speed only
+  const uint32_t forceBlock = [] { const char* e = tuning_env("PIES_LAYER_BLOCK"); return e ? (uint32_t)atoi(e) : 0u; }();  // speed only
   const uint32_t want = forceBlock ? forceBlock : L.maxClass;
   if (want <= 256) hipLaunchKernelGGL((k_layer<256, 0>), dim3(L.groups), dim3(256), lds, st, nd, D, L, P);
   else if (want <= 512) hipLaunchKernelGGL((k_layer<512, 0>), dim3(L.groups), dim3(512), lds, st, nd, D, L, P);

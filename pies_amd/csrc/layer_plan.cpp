@@ -258,9 +258,9 @@ bool build_layer_plan(pies_solver* s) {
   // (long bodies); strips pay once the body is large enough to fill the chip four phases at a time; squat bodies in
   // between are left to the coloured schedule.
   uint32_t oneStripMax = 2560, tileTarget = 1280, stripsMinNodes = 300000;
-  if (const char* e = std::getenv("PIES_LAYER_ONE_STRIP_MAX")) oneStripMax = static_cast<uint32_t>(std::atoi(e));
-  if (const char* e = std::getenv("PIES_LAYER_TILE_NODES")) tileTarget = static_cast<uint32_t>(std::atoi(e));
-  if (const char* e = std::getenv("PIES_LAYER_STRIPS_MIN_NODES")) stripsMinNodes = static_cast<uint32_t>(std::atoi(e));
+  if (const char* e = tuning_env("PIES_LAYER_ONE_STRIP_MAX")) oneStripMax = static_cast<uint32_t>(std::atoi(e));
+  if (const char* e = tuning_env("PIES_LAYER_TILE_NODES")) tileTarget = static_cast<uint32_t>(std::atoi(e));
+  if (const char* e = tuning_env("PIES_LAYER_STRIPS_MIN_NODES")) stripsMinNodes = static_cast<uint32_t>(std::atoi(e));
   tileTarget = std::min(tileTarget, kLayerMaxGroupNodes);
   uint32_t L2 = 1, width = 1;
   if (maxPair <= std::min(oneStripMax, kLayerMaxGroupNodes)) {
@@ -340,8 +340,8 @@ bool build_layer_plan(pies_solver* s) {
 
   // ---- per container: tile of every op, colouring inside the tile, execution order ----
   int rounds = 12;
-  if (const char* e = std::getenv("PIES_COLOUR_ROUNDS")) rounds = std::atoi(e);
-  const char* noHint = std::getenv("PIES_NO_COLOUR_HINT");
+  if (const char* e = tuning_env("PIES_COLOUR_ROUNDS")) rounds = std::atoi(e);
+  const char* noHint = tuning_env("PIES_NO_COLOUR_HINT");
   std::vector<uint32_t> localOf(N, 0);
   auto local_index = [&](const LayerTile& tile, uint32_t v) {
     const uint32_t p = posInList[v];

@@ -73,7 +73,7 @@ int pd_build(pies_solver* s) {
   // rows: k_cg_ap 5.4 us with 1 lane per row, 7.8 / 10.4 / 14.5 us with 2 / 4 / 8: the extra wavefronts only add gather
   // instructions.  PIES_SELL_LANES keeps the experiment available.)  Entries keep their order (ascending column).
   uint32_t lpr = 1u;
-  if (const char* e = std::getenv("PIES_SELL_LANES")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) lpr = static_cast<uint32_t>(v); }
+  if (const char* e = tuning_env("PIES_SELL_LANES")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) lpr = static_cast<uint32_t>(v); }
   const uint32_t rps = 64u / lpr;
   const uint32_t nslices = (n + rps - 1u) / rps;
   std::vector<uint32_t> sliceOff(nslices + 1, 0), sellCol;
@@ -173,7 +173,7 @@ int pd_build(pies_solver* s) {
   // 64 blocks 1039, 128: 1188, 196: 1242, 256: 1268, 391 (this formula): 1246 - fewer blocks make the per-kernel re-reduction of
   // the partial dot products cheaper and the SpMV slower, by about the same amount.
   cg.nparts = std::max(1u, std::min(kCgBlocks, (nslices + 3u) / 4u));
-  if (const char* e = std::getenv("PIES_CG_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && v <= (int)kCgBlocks) cg.nparts = static_cast<uint32_t>(v); }
+  if (const char* e = tuning_env("PIES_CG_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && v <= (int)kCgBlocks) cg.nparts = static_cast<uint32_t>(v); }
   uint32_t *d_rowptr, *d_col, *d_incPtr, *d_incSlot, *d_tri;
   float *d_val, *d_kdiag;
   if (int rc = upload(s, sliceOff, &d_rowptr)) return rc;
@@ -295,7 +295,7 @@ int pd_build(pies_solver* s) {
     cg.tUsed = T.usedNodes; cg.tUsedCount = T.counters + 4;
     cg.rowStart = T.rowStart; cg.rowLen = T.rowLen; cg.rowCol = T.rowCol; cg.rowCoef = T.rowCoef;
     if (int rc = dev_alloc(s, n, &cg.cAp, true)) return rc;
-    if (const char* e = std::getenv("PIES_TRI_FAST_ROWS")) s->triFastRows = std::atoi(e) != 0;  // tests: force a variant from the first tick
+    if (const char* e = tuning_env("PIES_TRI_FAST_ROWS")) s->triFastRows = std::atoi(e) != 0;  // tests: force a variant from the first tick
     cg.useCAp = s->triFastRows ? 1 : 0;
     pd.tContrib = T.contrib;
   }

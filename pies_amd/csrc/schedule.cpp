@@ -186,13 +186,13 @@ static bool colours_dsatur(const OpView& ops, uint32_t nodeCount, std::vector<ui
 // small classes dissolve into earlier ones.  Fewer colours = fewer dependent launches per sweep.
 static bool colours_iterated(const OpView& ops, uint32_t nodeCount, std::vector<uint32_t>& key, uint32_t& ncolours) {
   if (!colours(ops, nodeCount, nullptr, key, ncolours)) return false;
-  if (const char* e = std::getenv("PIES_COLOUR_DSATUR"); e && std::atoi(e)) {
+  if (const char* e = tuning_env("PIES_COLOUR_DSATUR"); e && std::atoi(e)) {
     std::vector<uint32_t> k2(ops.count);
     uint32_t n2 = 0;
     if (colours_dsatur(ops, nodeCount, k2, n2) && n2 <= ncolours) { key.swap(k2); ncolours = n2; }
   }
   int rounds = 12;
-  if (const char* e = std::getenv("PIES_COLOUR_ROUNDS")) rounds = std::atoi(e);
+  if (const char* e = tuning_env("PIES_COLOUR_ROUNDS")) rounds = std::atoi(e);
   std::vector<uint32_t> visit(ops.count), best = key, trial(ops.count);
   uint32_t bestN = ncolours;
   for (int r = 0; r < rounds; ++r) {
@@ -214,7 +214,7 @@ static bool colours_iterated(const OpView& ops, uint32_t nodeCount, std::vector<
   }
   key.swap(best);
   ncolours = bestN;
-  const char* noHint = std::getenv("PIES_NO_COLOUR_HINT");
+  const char* noHint = tuning_env("PIES_NO_COLOUR_HINT");
   if (!(noHint && std::atoi(noHint))) {
     uint32_t n = 0;
     if (colours_from_hint(ops, nodeCount, trial, n) && n < ncolours) { key.swap(trial); ncolours = n; }

@@ -1005,14 +1005,14 @@ uint32_t launch_tri_detect(hipStream_t st_, const TriArrays& T, const NodeArrays
   hipLaunchKernelGGL(k_inc_sort, cgrid, blk, 0, st_, T);
   if (mergedRows) {
     uint32_t maxUnique = kRowMaxUnique;  // diagnostics: PIES_ROW_MAX_UNIQUE lowers it (rows with more distinct columns stay unmerged)
-    if (const char* e = std::getenv("PIES_ROW_MAX_UNIQUE")) maxUnique = std::min<uint32_t>(kRowMaxUnique, static_cast<uint32_t>(std::max(0, std::atoi(e))));
+    if (const char* e = tuning_env("PIES_ROW_MAX_UNIQUE")) maxUnique = std::min<uint32_t>(kRowMaxUnique, static_cast<uint32_t>(std::max(0, std::atoi(e))));
     hipLaunchKernelGGL(k_contact_csr, cgrid, blk, 0, st_, T, maxUnique);
   }
   return 14;
 }
 void launch_tri_levels(hipStream_t st_, const TriArrays& T) {
   if (T.nt == 0) return;
-  const char* e = std::getenv("PIES_TRI_LDS");  // diagnostics, read when the substep is captured: 0 = sequential passes through L2
+  const char* e = tuning_env("PIES_TRI_LDS");  // diagnostics, read when the substep is captured: 0 = sequential passes through L2
   const int ldsForm = e && e[0] == '0' ? 0 : 1;
   hipLaunchKernelGGL(k_tri_levels, dim3(1), dim3(kSeqBlock), 0, st_, T, ldsForm);
 }

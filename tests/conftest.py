@@ -26,3 +26,17 @@ def pies():
     from pies_amd import capi
     capi.load()
     return capi
+
+
+@pytest.fixture
+def tune(pies):
+    """tune(name, value): a tuning / diagnostic switch of the library for the duration of one test (pies_set_tuning; value None
+    unsets).  These switches are not read from the environment."""
+    touched = []
+
+    def _set(name, value):
+        touched.append(name)
+        pies.set_tuning(name, value)
+    yield _set
+    for name in touched:
+        pies.set_tuning(name, None)

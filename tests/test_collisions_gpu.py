@@ -218,7 +218,7 @@ def test_dense_cells_take_the_unstaged_path(pies, oracle):
     check(g, o)
 
 
-def test_resolve_variants_agree(pies, monkeypatch):
+def test_resolve_variants_agree(pies, monkeypatch, tune):
     """(group order) The one-launch form resolves all 27 residue classes in one launch (tickets + completion stamps, LDS staging);
     PIES_COLLIDE_PASSES=1 is the 27-launch form and PIES_COLLIDE_GLOBAL=1 the unstaged one.  The order of
     conflicting groups is the same in all of them, so the results must be identical bit for bit."""
@@ -234,9 +234,9 @@ def test_resolve_variants_agree(pies, monkeypatch):
     ref = run()
     assert ref[3] == 3
     for name in ("PIES_COLLIDE_PASSES", "PIES_COLLIDE_GLOBAL"):
-        monkeypatch.setenv(name, "1")
+        tune(name, "1")
         alt = run()
-        monkeypatch.delenv(name)
+        tune(name, None)
         assert np.array_equal(ref[0], alt[0]) and np.array_equal(ref[1], alt[1]) and ref[2] == alt[2], name
         assert alt[3] == (81 if name == "PIES_COLLIDE_PASSES" else 3)
 

@@ -68,10 +68,10 @@ def test_more_than_1000_triangles_in_a_cell_latches(pies):
     _after_failure(g, pies)
 
 
-def test_collision_wait_timeout_latches(pies, monkeypatch):
+def test_collision_wait_timeout_latches(pies, monkeypatch, tune):
     """k_collide_flow's bounded wait: with a spin limit of one poll a wavefront gives up as soon as a predecessor is
     not finished yet, which latches bit 8 (a limit of 0 waits for ever; the default is ~0.3 s)."""
-    monkeypatch.setenv("PIES_COLLIDE_SPIN_LIMIT", "1")
+    tune("PIES_COLLIDE_SPIN_LIMIT", "1")
     rng = np.random.default_rng(5)
     W = 40
     p = np.stack(np.meshgrid(np.arange(W), np.arange(W), np.arange(W), indexing="ij"), -1).reshape(-1, 3) * 0.9
@@ -81,7 +81,7 @@ def test_collision_wait_timeout_latches(pies, monkeypatch):
     g.tick()
     if g.failed:                    # 64k nodes: some wavefront practically always has to wait once
         assert "timed out" in g.last_error()
-    monkeypatch.setenv("PIES_COLLIDE_SPIN_LIMIT", "0")
+    tune("PIES_COLLIDE_SPIN_LIMIT", "0")
     h = pies.Solver(scenes.pbd_options(pies, 4))
     h.addNodes(p)
     h.tick()

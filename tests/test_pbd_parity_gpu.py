@@ -80,7 +80,7 @@ def test_exact_schedule_is_reference_order(pies, oracle):
     assert np.array_equal(g.positions, o.positions)
 
 
-def test_exact_whole_substep_dag_equals_per_container_levels(pies, oracle, monkeypatch):
+def test_exact_whole_substep_dag_equals_per_container_levels(pies, oracle, monkeypatch, tune):
     """EXACT runs one launch per level of the whole-substep dependency DAG (wavefront.cpp); PIES_NO_WAVEFRONT=1
     keeps the older one-launch-per-container-level path.  Same order of every conflicting pair, so the same bits,
     with far fewer launches; bend + position constraints and the collision pass (a barrier) included."""
@@ -93,9 +93,9 @@ def test_exact_whole_substep_dag_equals_per_container_levels(pies, oracle, monke
         g.tick(3)
         lc = g.launch_counts()
         return g.positions, g.velocities, lc
-    monkeypatch.setenv("PIES_NO_WAVEFRONT", "1")
+    tune("PIES_NO_WAVEFRONT", "1")
     p0, v0, lc0 = run()
-    monkeypatch.delenv("PIES_NO_WAVEFRONT")
+    tune("PIES_NO_WAVEFRONT", None)
     p1, v1, lc1 = run()
     assert np.array_equal(p0, p1) and np.array_equal(v0, v1)
     assert lc0["wave"] == 0 and lc1["wave"] > 0 and lc1["tet"] == 0
@@ -214,10 +214,10 @@ def test_layered_is_active_and_fuses_an_iteration_into_two_launches(pies, oracle
     _check(g, o)
 
 
-def test_layered_colour_classes_larger_than_the_workgroup(pies, oracle, monkeypatch):
+def test_layered_colour_classes_larger_than_the_workgroup(pies, oracle, monkeypatch, tune):
     """Cross-sections of 576 nodes give colour classes of ~270 tetrahedra and ~500 distance constraints; with the
     workgroup forced to 256 lanes every class takes two or three passes of the in-kernel loops."""
-    monkeypatch.setenv("PIES_LAYER_BLOCK", "256")
+    tune("PIES_LAYER_BLOCK", "256")
     def build(s):
         scenes.build_beam(s, (24, 24, 26))
         scenes.perturb(s, 3, 0.05)
@@ -273,12 +273,12 @@ def test_layered_wide_body_is_cut_into_strips(pies, oracle):
 
 
 @pytest.mark.parametrize("collisions", [0, 1])
-def test_layered_strips_small_tiles_all_containers(pies, oracle, monkeypatch, collisions):
+def test_layered_strips_small_tiles_all_containers(pies, oracle, monkeypatch, collisions, tune):
     """The strip path forced onto small scenes (tiny tiles, ragged strips): beams, a bend sheet, a hinged sheet with
     position constraints (two of them on one node), with and without the collision pass between the sweeps."""
-    monkeypatch.setenv("PIES_LAYER_ONE_STRIP_MAX", "40")
-    monkeypatch.setenv("PIES_LAYER_TILE_NODES", "90")
-    monkeypatch.setenv("PIES_LAYER_STRIPS_MIN_NODES", "0")
+    tune("PIES_LAYER_ONE_STRIP_MAX", "40")
+    tune("PIES_LAYER_TILE_NODES", "90")
+    tune("PIES_LAYER_STRIPS_MIN_NODES", "0")
     def build(s):
         scenes.build_beam(s, (7, 6, 13), translation=(0.0, 0.3, 0.0))
         scenes.build_beam(s, (5, 9, 4), translation=(1.3, 7.2, 0.4))

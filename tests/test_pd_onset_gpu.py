@@ -51,10 +51,10 @@ def test_contact_onset_with_the_default_budget_meets_the_tolerance(pies, oracle)
     assert np.abs(g.positions.mean(0) - o.positions.mean(0)).max() < 2e-2
 
 
-def test_contact_onset_without_the_overflow_is_repaired_by_a_second_run(pies, monkeypatch):
+def test_contact_onset_without_the_overflow_is_repaired_by_a_second_run(pies, monkeypatch, tune):
     """PIES_PCG_OVERFLOW=0: pies_tick puts a substep whose solve ended above the tolerance back and runs it again with four
     times the budget (the round-2 mechanism, still the net under the overflow when the ceiling is hit)."""
-    monkeypatch.setenv("PIES_PCG_OVERFLOW", "0")
+    tune("PIES_PCG_OVERFLOW", "0")
     g = pies.Solver(pd_options(pies, 3))
     plates(g)
     budgets = []

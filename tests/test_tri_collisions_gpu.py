@@ -32,10 +32,10 @@ def two_boxes(s, gap=0.04, vy=-2.0, offset=(0.4, 0.3)):
 
 
 @pytest.mark.parametrize("contact_rows", ["inline", "pass"])
-def test_two_boxes_contact_lists_and_positions(pies, oracle, monkeypatch, contact_rows):
+def test_two_boxes_contact_lists_and_positions(pies, oracle, monkeypatch, contact_rows, tune):
     """Both graph variants of the global step: contact rows summed by the row's lane inside the SpMV (few contacts) or
     by a wavefront per node in a pass of their own (the variant the host switches to at 512 contacts)."""
-    monkeypatch.setenv("PIES_TRI_FAST_ROWS", "1" if contact_rows == "pass" else "0")
+    tune("PIES_TRI_FAST_ROWS", "1" if contact_rows == "pass" else "0")
     g = pies.Solver(pd_options(pies, 6))
     o = oracle.OracleSolver(pd_options(oracle, 6))
     for s in (g, o):
@@ -110,14 +110,14 @@ def test_many_contacts_spanning_several_windows(pies, oracle):
     assert most > 128
 
 
-def test_sequential_passes_on_the_lds_copy_equal_the_l2_path_bit_for_bit(pies, monkeypatch):
+def test_sequential_passes_on_the_lds_copy_equal_the_l2_path_bit_for_bit(pies, monkeypatch, tune):
     """The stabilisation and friction passes are order dependent; run level by level they give the sequential result whatever
     the level partition.  Two device solvers on the same scene (thousands of contacts): one with the node-owner levels + the
     four-lanes-per-contact passes on an LDS copy of the touched nodes, one with the chunked levels + one lane per contact
     through L2 (PIES_TRI_LDS=0).  Everything else is the same code, so the states must agree bit for bit."""
     def run(lds):
-        monkeypatch.setenv("PIES_TRI_LDS", lds)
-        monkeypatch.setenv("PIES_TRI_FAST_ROWS", "1")
+        tune("PIES_TRI_LDS", lds)
+        tune("PIES_TRI_FAST_ROWS", "1")
         g = pies.Solver(pd_options(pies, 3))
         g.set_pcg(3e-7, 64)
         g.create_tet_box(14, 2, 20, translation=(0, 0.02, 0), w=1.0)
@@ -140,11 +140,11 @@ def test_sequential_passes_on_the_lds_copy_equal_the_l2_path_bit_for_bit(pies, m
             assert np.array_equal(x[k], y[k]), (t, k)
 
 
-def test_two_captured_iterations_and_the_rest_in_the_last_launch(pies, oracle, monkeypatch):
+def test_two_captured_iterations_and_the_rest_in_the_last_launch(pies, oracle, monkeypatch, tune):
     """PIES_PCG_BUDGET=2 pins the captured CG iterations at two; thousands of w = 1e4 contacts need 8-14.  The last captured
     launch goes on by itself (k_cg_update: grid barriers, contact rows summed lane by lane) and the substeps still meet the
     tolerance and stay with the oracle's direct solves."""
-    monkeypatch.setenv("PIES_PCG_BUDGET", "2")
+    tune("PIES_PCG_BUDGET", "2")
     g = pies.Solver(pd_options(pies, 3))
     o = oracle.OracleSolver(pd_options(oracle, 3))
     for s in (g, o):
@@ -167,11 +167,11 @@ def test_two_captured_iterations_and_the_rest_in_the_last_launch(pies, oracle, m
     assert most > 4 and g.pcg_health()["short_solves"] == 0 and not g.failed
 
 
-def test_patch_wider_than_the_lds_copy_takes_the_l2_path(pies, oracle, monkeypatch):
+def test_patch_wider_than_the_lds_copy_takes_the_l2_path(pies, oracle, monkeypatch, tune):
     """Two 52x52 plates: more than 4096 nodes take part in contacts, so the sequential passes cannot run on an LDS copy and
     the level kernel takes the chunked relaxation (the automatic choice, no switch set).  One teacher-forced tick against
     the oracle, and the same tick with the L2 path forced (PIES_TRI_LDS=0) must give the same bits."""
-    monkeypatch.setenv("PIES_TRI_FAST_ROWS", "1")
+    tune("PIES_TRI_FAST_ROWS", "1")
     def build(s):
         s.create_tet_box(52, 2, 52, translation=(0, 0.02, 0), w=1.0)
         s.create_tet_box(52, 2, 52, translation=(0.37, 1.05, 0.41), w=1.0)
@@ -184,7 +184,7 @@ def test_patch_wider_than_the_lds_copy_takes_the_l2_path(pies, oracle, monkeypat
     o.tick()
     states = []
     for lds in ("1", "0"):
-        monkeypatch.setenv("PIES_TRI_LDS", lds)
+        tune("PIES_TRI_LDS", lds)
         g = pies.Solver(pd_options(pies, 3))
         g.set_pcg(3e-7, 256)
         build(g)
@@ -201,15 +201,15 @@ def test_patch_wider_than_the_lds_copy_takes_the_l2_path(pies, oracle, monkeypat
 
 
 @pytest.mark.parametrize("contact_rows,sequential", [("inline", "lds"), ("pass", "lds"), ("pass", "l2"), ("pass-unmerged", "lds")])
-def test_thousands_of_contacts_level_schedule(pies, oracle, monkeypatch, contact_rows, sequential):
+def test_thousands_of_contacts_level_schedule(pies, oracle, monkeypatch, contact_rows, sequential, tune):
     """A plate resting on a larger one: 2000+ contacts per tick, chains of tens of contacts through one node.  Exercises
     the dependency levels of the whole contact list (node-owner rounds; with PIES_TRI_LDS=0 the chunked relaxation, more
     than one 1024-contact chunk), the level-by-level stabilisation / friction passes on the LDS copy of the touched nodes
     and through L2, and both variants of the contact rows in the global step."""
-    monkeypatch.setenv("PIES_TRI_FAST_ROWS", "0" if contact_rows == "inline" else "1")
+    tune("PIES_TRI_FAST_ROWS", "0" if contact_rows == "inline" else "1")
     if contact_rows == "pass-unmerged":  # rows with more than 4 distinct columns keep the contact-by-contact form
-        monkeypatch.setenv("PIES_ROW_MAX_UNIQUE", "4")
-    monkeypatch.setenv("PIES_TRI_LDS", "1" if sequential == "lds" else "0")
+        tune("PIES_ROW_MAX_UNIQUE", "4")
+    tune("PIES_TRI_LDS", "1" if sequential == "lds" else "0")
     g = pies.Solver(pd_options(pies, 3))
     g.set_pcg(3e-7, 256)  # thousands of w = 1e4 contacts: the default cap of 32 CG iterations stops above the tolerance
     o = oracle.OracleSolver(pd_options(oracle, 3))

@@ -15,7 +15,7 @@ what, n = sys.argv[1], int(sys.argv[2])
 if what in ("contacts", "pdcontacts"):
     # PIES_PROFILER_SAFE freezes the graph variant as well: take the one bench.py's loop runs these scenes in (contact rows
     # summed by the extra blocks of k_cg_ap, level kernel on the second stream)
-    os.environ.setdefault("PIES_TRI_FAST_ROWS", "1")
+    capi.set_tuning("PIES_TRI_FAST_ROWS", "1")
 if what == "config2":
     g = bench.build_scene(capi, scenes.L100K, 1234, schedule=capi.SCHEDULE_LAYERED, device=0)
 elif what == "config3":

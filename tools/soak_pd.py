@@ -29,7 +29,7 @@ def build(s, rng_state):
 
 def device_run(state, ticks, forced, env):
     for k, v in env.items():
-        os.environ[k] = v
+        capi.set_tuning(k, v)
     g = capi.Solver(pd_options(capi, state[-1]))
     g.set_pcg(3e-7, 256)
     build(g, state)
@@ -40,7 +40,7 @@ def device_run(state, ticks, forced, env):
         out.append((g.positions.copy(), g.velocities.copy(), g.tri_collisions.copy(), g.pcg_health()["short_solves"], g.failed))
     g.close()
     for k in env:
-        os.environ.pop(k, None)
+        capi.set_tuning(k, None)
     return out
 
 
