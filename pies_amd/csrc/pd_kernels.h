@@ -45,7 +45,7 @@ struct CgArrays {
   const float* rowCoef;
   float* scal;   // rz[2][3], bb[3], iterations, [10] the solve is over (converged, or went on inside its last launch), [11] where
                  // its final residual partials are
-  uint32_t* ticket;  // grid barrier counter of the solve's last k_cg_update (zeroed by k_cg_init)
+  uint32_t* ticket;  // [0] grid barrier counter of the solve's last k_cg_update, [1] its abort word (zeroed by k_cg_init)
   float* stats;  // over the tick: [0] max relative residual^2 of its solves, [1] max iterations, [2] solves, [3] solves that ended
                  // above the tolerance; since the buffers were built: [4] solves above the tolerance, [5] solves
   float tol2;    // squared relative tolerance of the solve whose statistics are being closed
@@ -111,5 +111,8 @@ void launch_pd_stabilize(hipStream_t st, const NodeArrays& nd, const PdArrays& p
 void launch_pd_velocity(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float h, float damping, float gravity,
                         float friction, float staticThreshold, bool staticFriction);
 void launch_pd_static_friction(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float friction, float staticThreshold);
+
+// workgroups of k_cg_update the device holds at once (0: unknown); the CG kernels' grid stays below it, see grid_barrier
+uint32_t cg_update_resident_blocks(int device);
 
 }  // namespace pies

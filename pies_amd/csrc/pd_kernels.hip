@@ -749,7 +749,8 @@ __global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __
     if (prevPartB) solve_statistics(A, prevPartB);
     if (threadIdx.x == 0) {
       A.scal[10] = 0.0f;  // this solve has not converged yet (read by k_cg_ap / k_cg_update)
-      *A.ticket = 0u;     // grid barrier counter of the solve's last k_cg_update
+      A.ticket[0] = 0u;   // grid barrier counter of the solve's last k_cg_update
+      A.ticket[1] = 0u;   // its abort word
     }
     return;
   }
@@ -978,6 +979,10 @@ PIES_DEV bool grid_barrier(uint32_t* counter, uint32_t nblocks, uint32_t& passed
       __builtin_amdgcn_s_sleep(2);
       if (++spins > (1u << 20)) { ok = 0u; break; }  // ~1 s
     }
+    // a workgroup that gives up says so in the abort word; one that arrives late and finds the counter already past its
+    // target (the others have left) must not run an iteration alone: everybody checks the word after the wait
+    if (!ok) __hip_atomic_store(counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (__hip_atomic_load(counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = 0u;
     __threadfence();
     sOk = ok;
   }
@@ -985,6 +990,10 @@ PIES_DEV bool grid_barrier(uint32_t* counter, uint32_t nblocks, uint32_t& passed
   ++passed;
   return sOk != 0u;
 }
+
+// The continuation's grid barrier needs every workgroup of the launch resident at once: how many k_cg_update workgroups the
+// device holds (pd_setup.cpp sizes the CG kernels' grid below it)
+uint32_t cg_update_resident_blocks(int device);
 
 // alpha = rz_k / pAp ; x += alpha p ; r -= alpha Ap ; z = D^-1 r ; partB = {rz_{k+1}, rr_{k+1}}.
 // overflow > 0: this is the solve's last captured iteration.  If the residual is still above the tolerance after it (new
@@ -1058,6 +1067,14 @@ __global__ void __launch_bounds__(kBlock) k_cg_update(CgArrays A, float4* __rest
 
 // end of the last solve of a substep: its statistics
 __global__ void __launch_bounds__(kBlock) k_cg_finish(CgArrays A) { solve_statistics(A, A.partB); }
+
+uint32_t cg_update_resident_blocks(int device) {
+  int perCu = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_cg_update, kBlock, 0) != hipSuccess) return 0;
+  return static_cast<uint32_t>(std::max(0, perCu)) * static_cast<uint32_t>(std::max(0, prop.multiProcessorCount));
+}
 
 // ------------------------------------------------------------------------------------------------------
 // Solver.cpp:367-383 (floor snap; tri/edge stabilisation is a later row) -- idempotent, applied once

@@ -174,6 +174,12 @@ int pd_build(pies_solver* s) {
   // the partial dot products cheaper and the SpMV slower, by about the same amount.
   cg.nparts = std::max(1u, std::min(kCgBlocks, (nslices + 3u) / 4u));
   if (const char* e = tuning_env("PIES_CG_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && v <= (int)kCgBlocks) cg.nparts = static_cast<uint32_t>(v); }
+  // k_cg_update's in-kernel continuation synchronises its workgroups with a grid barrier: the grid must fit the device at once
+  // (occupancy of the kernel x compute units of THIS device; half of it, so that a second solver on the card leaves room)
+  if (s->device >= 0) {
+    const uint32_t resident = cg_update_resident_blocks(s->device);
+    if (resident >= 2) cg.nparts = std::max(1u, std::min(cg.nparts, resident / 2u));
+  }
   uint32_t *d_rowptr, *d_col, *d_incPtr, *d_incSlot, *d_tri;
   float *d_val, *d_kdiag;
   if (int rc = upload(s, sliceOff, &d_rowptr)) return rc;
@@ -227,7 +233,7 @@ int pd_build(pies_solver* s) {
   cg.partB0 = cg.partB;
   cg.partB1 = cg.partBnext;
   if (int rc = dev_alloc(s, 16, &cg.scal, true)) return rc;
-  if (int rc = dev_alloc(s, 1, &cg.ticket, true)) return rc;
+  if (int rc = dev_alloc(s, 2, &cg.ticket, true)) return rc;
   if (int rc = dev_alloc(s, 8, &cg.stats, true)) return rc;
   // ---- point-triangle contact pipeline (Solver.cpp:680-875) ------------------------------------------------
   pd.tri = TriArrays{};

@@ -122,3 +122,43 @@ def test_queued_asynchronous_ticks_let_the_budget_follow(pies):
     assert iters > low and res <= TOL * 1.0001                   # solves went beyond the captured iterations and converged
     assert h["short_solves"] == before["short_solves"]
     assert h["budget"] > low                                     # and the host has captured more by now
+
+
+_TWO_PROCESS_BODY = """
+import sys, os
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+from pies_amd import capi
+from test_pd_parity_gpu import pd_options
+from test_pd_onset_gpu import plates
+g = capi.Solver(pd_options(capi, 3), device=0)
+plates(g)
+worst, most = 0.0, 0
+for t in range(30):
+    g.tick()
+    res, iters, solves = g.pcg_stats()
+    worst = max(worst, res)
+    most = max(most, len(g.tri_collisions))
+h = g.pcg_health()
+assert most > 1000 and not g.failed and np.isfinite(g.positions).all(), (most, g.failed)
+assert worst <= 3e-7 * 1.0001 and h["short_solves"] == 0, (worst, h)
+print("ok", worst, h)
+"""
+
+
+def test_two_processes_share_the_card_through_a_contact_onset(tmp_path):
+    """Two solvers in two processes on the one GPU, both driving the plate into contact at the same time: the in-kernel
+    continuation of a solve (workgroups of one launch synchronising through a grid barrier) needs its whole grid resident, which
+    the library sizes from the kernel's occupancy on this device and halves for exactly this case.  No short solve, no wait
+    that times out, no failure latch - in either process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "onset.py"
+    script.write_text(_TWO_PROCESS_BODY.format(root=root))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for _ in range(2)]
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0 and out.startswith("ok"), (p.returncode, out[-500:], err[-2000:])
