@@ -39,14 +39,22 @@ static bool under_profiler() {
 static void destroy_graph(pies_solver* s) {
   // graphs are not destroyed while a profiler is attached (rocprofv3 7.2 crashes on graph destruction)
   if (!under_profiler()) {
-    if (s->graphExec) (void)hipGraphExecDestroy(s->graphExec);
-    if (s->graph) (void)hipGraphDestroy(s->graph);
+    if (!s->graphFromLadder) {
+      if (s->graphExec) (void)hipGraphExecDestroy(s->graphExec);
+      if (s->graph) (void)hipGraphDestroy(s->graph);
+    }
+    for (auto& kv : s->pdLadder) {
+      if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+      if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
     for (auto& ge : s->retiredGraphs) {
       (void)hipGraphExecDestroy(ge.second);
       (void)hipGraphDestroy(ge.first);
     }
     s->retiredGraphs.clear();
   }
+  s->pdLadder.clear();
+  s->graphFromLadder = false;
   s->graphExec = nullptr;
   s->graph = nullptr;
 }
@@ -493,6 +501,31 @@ static void enqueue_substep(pies_solver* s, uint32_t* counts) {
   else enqueue_pbd_substep(s, -1, counts);
 }
 
+// the rung of the budget ladder that holds `budget` CG iterations: 2, 4, 8, ... and the ceiling of pies_set_pcg
+static uint32_t ladder_rung(const pies_solver* s, uint32_t budget) {
+  uint32_t r = 2;
+  while (r < budget && r < s->pcgMaxIters) r *= 2;
+  return std::min(r, s->pcgMaxIters);
+}
+static bool uses_ladder(const pies_solver* s) {
+  if (s->opt.solver != PIES_SOLVER_PD || s->pcgPinned || under_profiler()) return false;
+  const char* e = tuning_env("PIES_NO_GRAPH");
+  return !(e && e[0] == '1');
+}
+// makes the ladder entry of (pcgBudget, triFastRows) the graph pies_tick launches
+static int select_pd_graph(pies_solver* s) {
+  s->pcgBudget = ladder_rung(s, s->pcgBudget);
+  s->pd.cg.useCAp = s->triFastRows ? 1 : 0;
+  auto it = s->pdLadder.find(static_cast<uint64_t>(s->pcgBudget) | (static_cast<uint64_t>(s->triFastRows ? 1 : 0) << 32));
+  if (it == s->pdLadder.end()) return fail(s, PIES_ERR_STATE, "no captured graph for this CG budget");
+  s->graph = it->second.graph;
+  s->graphExec = it->second.exec;
+  s->graphFromLadder = true;
+  { const char* e = tuning_env("PIES_TRI_SIDE"); s->triLevelsForked = e ? e[0] != '0' : s->triFastRows; }  // (as the entry was captured)
+  std::memcpy(s->launchCounts, it->second.counts, sizeof(s->launchCounts));
+  return PIES_OK;
+}
+
 static int capture_graph(pies_solver* s) {
   destroy_graph(s);
   std::memset(s->launchCounts, 0, sizeof(s->launchCounts));
@@ -505,6 +538,35 @@ static int capture_graph(pies_solver* s) {
     HIP_TRY(s, hipStreamEndCapture(s->stream, &tmp));
     if (tmp) (void)hipGraphDestroy(tmp);
     return PIES_OK;
+  }
+  if (uses_ladder(s)) {
+    // every rung, both contact-row variants when the scene has surface triangles: captured and instantiated now, so that
+    // following the solves later never instantiates a graph in the middle of a frame
+    const uint32_t wantBudget = s->pcgBudget;
+    const bool wantRows = s->triFastRows;
+    std::vector<uint32_t> rungs;
+    for (uint32_t r = 2;; r *= 2) {
+      rungs.push_back(std::min(r, s->pcgMaxIters));
+      if (r >= s->pcgMaxIters) break;
+    }
+    const int variants = s->pd.tri.nt ? 2 : 1;
+    for (int v = 0; v < variants; ++v)
+      for (uint32_t r : rungs) {
+        const bool rows = variants == 2 ? v != 0 : wantRows;
+        s->pcgBudget = r;
+        s->triFastRows = rows;
+        s->pd.cg.useCAp = rows ? 1 : 0;
+        pies_solver::PdGraph g;
+        HIP_TRY(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+        enqueue_substep(s, g.counts);
+        hipError_t e = hipStreamEndCapture(s->stream, &g.graph);
+        if (e != hipSuccess) return fail(s, PIES_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        HIP_TRY(s, hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+        s->pdLadder[static_cast<uint64_t>(r) | (static_cast<uint64_t>(rows ? 1 : 0) << 32)] = g;
+      }
+    s->pcgBudget = wantBudget;
+    s->triFastRows = wantRows;
+    return select_pd_graph(s);
   }
   HIP_TRY(s, hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
   enqueue_substep(s, s->launchCounts);
@@ -579,11 +641,12 @@ static int adapt_pcg_budget(pies_solver* s) {
   if (const char* e = std::getenv("PIES_PCG_DEBUG"); e && e[0] == '1')
     std::fprintf(stderr, "[pies] pcg: residual^2 %.3g (%s) iterations %u budget %u -> %u calm %u cooldown %u contact rows %s\n", st[0],
                  converged ? "ok" : "short", used, s->pcgBudget, budget, s->pcgCalm, s->pcgCooldown, fastRows ? "pass" : "inline");
+  if (!s->pdLadder.empty()) budget = ladder_rung(s, budget);
   if (budget != s->pcgBudget || fastRows != s->triFastRows) {
     s->pcgBudget = budget;
     s->triFastRows = fastRows;
     s->pd.cg.useCAp = fastRows ? 1 : 0;
-    return capture_graph(s);
+    return s->pdLadder.empty() ? capture_graph(s) : select_pd_graph(s);  // (another executable graph of the ladder: no capture)
   }
   return PIES_OK;
 }
@@ -833,8 +896,10 @@ int pies_get_pcg_health(pies_solver_t* s, uint64_t* short_solves, uint64_t* solv
   }
   // stats[4], [5]: solves left above the tolerance / solves run by the substeps whose result was kept (a substep
   // that pies_tick ran again takes its counts back), since the buffers were built
-  if (short_solves) *short_solves = static_cast<uint64_t>(st[4]);
-  if (solves_total) *solves_total = static_cast<uint64_t>(st[5]);
+  uint64_t life[2];
+  std::memcpy(life, st + 4, sizeof(life));  // (64-bit integer counters in the words [4..5] and [6..7])
+  if (short_solves) *short_solves = life[0];
+  if (solves_total) *solves_total = life[1];
   if (substeps_retried) *substeps_retried = s->pcgRetries;
   if (budget) *budget = s->pcgBudget;
   return PIES_OK;
@@ -1207,7 +1272,7 @@ static int pd_tick_checked(pies_solver* s) {
       ++s->pcgRetries;
       if (const char* e = std::getenv("PIES_PCG_DEBUG"); e && e[0] == '1')
         std::fprintf(stderr, "[pies] pcg: substep ran short (residual^2 %.3g): again with budget %u\n", after[0], s->pcgBudget);
-      if (int rc = capture_graph(s)) return rc;
+      if (int rc = s->pdLadder.empty() ? capture_graph(s) : select_pd_graph(s)) return rc;
     }
   }
   return PIES_OK;

@@ -673,8 +673,10 @@ PIES_DEV void solve_statistics(const CgArrays& A, const float* __restrict__ prev
     A.stats[2] += 1.0f;
     const float ranShort = above ? 1.0f : 0.0f;  // the solve used its whole captured budget and is still above the tolerance
     A.stats[3] += ranShort;
-    A.stats[4] += ranShort;
-    A.stats[5] += 1.0f;
+    // lifetime counters, as 64-bit integers in the words [4..5] and [6..7] (a float stops counting at 2^24)
+    unsigned long long* life = reinterpret_cast<unsigned long long*>(A.stats + 4);
+    life[0] += above ? 1ull : 0ull;
+    life[1] += 1ull;
   }
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <map>
 #include <string>
 #include <utility>
 #include <vector>
@@ -251,6 +252,12 @@ struct pies_solver {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graphExec = nullptr;
   std::vector<std::pair<hipGraph_t, hipGraphExec_t>> retiredGraphs;  // profile-pass graphs, freed with the handle
+  // PD: the substep graph exists once per (captured CG iterations, contact-row variant) - a ladder of budgets 2, 4, 8, ... up
+  // to the ceiling of pies_set_pcg, instantiated together - so that following the solves means launching another executable
+  // graph, not capturing and instantiating one in the middle of a frame (~11 ms).  graph / graphExec then alias an entry.
+  struct PdGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; uint32_t counts[32] = {0}; };
+  std::map<uint64_t, PdGraph> pdLadder;
+  bool graphFromLadder = false;
   uint32_t launchCounts[PIES_KERNEL_COUNT] = {};
   pies::Probe* probe = nullptr;  // set for the duration of pies_profile_in_situ
 
