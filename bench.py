@@ -577,14 +577,16 @@ def run_config2_default_tick(device, dims, steps, with_exact):
     (Src/Solver.cpp:81-130).  Two 100k-particle beams: BASELINE configs[1] itself (createTetBox nodes have radius 0.475) - there the
     PBD tetrahedral projection (quirk Q2) drags the whole body into a few grid cells within the first tick, which is a pile-up no
     grid handles (the reference would visit ~10^10 pairs per iteration; this build latches its "more than 2048 nodes in a cell"
-    failure) - and the same lattice with the distance constraints alone (createBox), which is a PBD scene the reference can
-    run.  LAYERED + pair order, and (with_exact) schedule EXACT = the reference's order end to end (one tick: its node-node loop
-    is one sequential chain)."""
+    failure) - and the same lattice with the distance constraints alone (createBox pattern, radius 0.5 = touching spheres).  That
+    scene is not stable under the reference's semantics either (one-sided distance projections, quirk Q1, against the
+    collision pass: the oracle's plain loops blow an 8x8x30 box up from 7 to 11 wide in 12 ticks, and so does every device order),
+    so the figure is for its FIRST FIVE ticks, while the lattice is still a lattice.  LAYERED + pair order, and (with_exact)
+    schedule EXACT = the reference's order end to end (one tick: its node-node loop is one sequential chain)."""
     out = {}
     for scene, tets in (("config2", True), ("box_100k_distance_only", False)):
         res = out[scene] = {"workload": "%dx%dx%d lattice, %s, PBD, %d iterations, node-node pass ON (what Solver::tickPBD runs by default)"
                             % (dims + ("distance + tet-strain constraints (BASELINE configs[1])" if tets else "distance constraints only (createBox pattern)", ITERATIONS))}
-        for name, sched, n in (("layered", capi.SCHEDULE_LAYERED, steps), ("exact", capi.SCHEDULE_EXACT, 1)):
+        for name, sched, n in (("layered", capi.SCHEDULE_LAYERED, min(steps, 5)), ("exact", capi.SCHEDULE_EXACT, 1)):
             if name == "exact" and (not with_exact or tets):
                 continue
             g = capi.Solver(scenes.pbd_options(capi, ITERATIONS), device=device)
@@ -593,7 +595,7 @@ def run_config2_default_tick(device, dims, steps, with_exact):
             g.set_flag(capi.FLAG_NODE_COLLISIONS, 1)
             g.set_schedule(sched)
             g.finalize()
-            el = timed_ticks(g, n, 1 if name == "layered" else 0, lambda: None)
+            el = timed_ticks(g, n, 0, lambda: None)
             failed = bool(g.failed)
             res[name] = {"value": None if failed else n / el, "unit": "substeps/s", "steps": n, "launches_per_substep": sum(g.launch_counts().values()),
                          "failed": failed, "error": g.last_error() if failed else None, "collision_health": g.collision_health()}

@@ -241,8 +241,9 @@ int pies_collision_stats(pies_solver_t* s, uint64_t* pairs, uint64_t* candidates
  * that were repeated with the widest slack because a node had moved further than the pair filter allows for, and the passes in
  * which a node moved further than even that (more than 0.5 in one pass: the result may then miss visits the documented order
  * makes).  Any pointer may be NULL. */
-/* Pair order: level launches captured per pass (default 128; a single-workgroup kernel finishes deeper orders, slowly).
- * BASELINE config 4 needs about 75. */
+/* Pair order: level launches captured per pass.  By default the library follows what the passes need at host synchronisations
+ * (it starts at 96; BASELINE config 4 settles at 48-64); a call pins the count.  A single-workgroup kernel finishes deeper
+ * orders than captured: slow, never wrong. */
 int pies_set_collision_rounds(pies_solver_t* s, uint32_t rounds);
 /* Tuning and diagnostic switches, process wide, by name (value NULL or "" unsets): graph variants and sizes that tests and
  * profiling scripts pin - PIES_PCG_BUDGET, PIES_PCG_OVERFLOW, PIES_TRI_FAST_ROWS, PIES_TRI_LDS, PIES_ROW_MAX_UNIQUE, PIES_TRI_SIDE,

@@ -41,14 +41,31 @@ inline vec3 normalize(const vec3& a) { return a * (1.0f / std::sqrt(dot(a, a)));
 inline vec3 cross(const vec3& a, const vec3& b) {
   return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
 }
-// Order of the node pairs in collision rule 2 (the device's pair order): murmur3's 64-bit finaliser over (i << 32 | j), i < j.
-// A bijection of the pair, so the order is total; scattered, so that the chains of pairs that share nodes stay short.
-inline uint64_t pair_key(uint32_t i, uint32_t j) {
+// Order of the node pairs in collision rule 2 (the device's pair order): pairs are classed by the direction from the lower to
+// the higher node when the grid was built - 13 classes of 45-degree sectors around the 26 lattice directions, orientation
+// folded - and by the parity of the pair's place along that direction (in units of the pair's own extent); inside a class
+// murmur3's 64-bit finaliser over (i << 32 | j) decides.  Pairs of one class seldom share a node (on a lattice never), so
+// the chains of pairs that share nodes stay about as short as the number of classes.  The key is a total order: the hash
+// part alone is a bijection of the pair.  Plain IEEE single precision, no contraction: the device computes the same bits.
+inline uint64_t pair_key(uint32_t i, uint32_t j, const vec3& pi, const vec3& pj) {  // i < j
   uint64_t k = (static_cast<uint64_t>(i) << 32) | j;
   k ^= k >> 33; k *= 0xff51afd7ed558ccdull;
   k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull;
   k ^= k >> 33;
-  return k;
+  const float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
+  const float ax = std::fabs(dx), ay = std::fabs(dy), az = std::fabs(dz);
+  const float lim = 0.41421356f * std::fmax(ax, std::fmax(ay, az));
+  int qx = ax > lim ? (dx < 0.0f ? -1 : 1) : 0, qy = ay > lim ? (dy < 0.0f ? -1 : 1) : 0, qz = az > lim ? (dz < 0.0f ? -1 : 1) : 0;
+  const int lead = qx != 0 ? qx : (qy != 0 ? qy : qz);
+  if (lead < 0) { qx = -qx; qy = -qy; qz = -qz; }
+  const float fx = static_cast<float>(qx), fy = static_cast<float>(qy), fz = static_cast<float>(qz);
+  const float qq = std::fmax(fx * fx + fy * fy + fz * fz, 1.0f);
+  const float ui = (pi.x * fx + pi.y * fy + pi.z * fz) / qq, uj = (pj.x * fx + pj.y * fy + pj.z * fz) / qq;
+  const float len = std::fmax(std::fabs(uj - ui), 0.001f);
+  const float t = std::fmin(std::fmax(std::floor(std::fmin(ui, uj) / len), -1.0e9f), 1.0e9f);
+  const uint32_t parity = static_cast<uint32_t>(static_cast<long long>(t)) & 1u;  // (NaN positions: the grid has failed already)
+  const uint32_t cls = static_cast<uint32_t>((qx + 1) * 9 + (qy + 1) * 3 + (qz + 1)) * 2u + parity;  // < 54
+  return (static_cast<uint64_t>(cls) << 58) | (k >> 6);
 }
 
 inline float clampf(float v, float lo, float hi) { return std::fmin(std::fmax(v, lo), hi); }

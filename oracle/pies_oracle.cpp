@@ -811,8 +811,9 @@ struct ora_solver {
   // 2: the device's pair order ("pair order"): the same visits - node i meets node j once per cell that
   // the ranges they were inserted with share, in each direction, itself included (quirk Q3) - re-ordered pair by pair:
   // first every node's visits to itself (ascending index), then the unordered pairs {i < j} whose ranges share m > 0 cells
-  // in ascending order of pair_key(i, j), each as m visits of i to j followed by m visits of j to i.  A pure re-ordering of
-  // rule 1's visits; every visit tests the live positions like the reference's loop.
+  // in ascending order of pair_key (ora_math.h: direction class and parity from the positions the grid was built from, then a
+  // 64-bit mix of the two indices), each as m visits of i to j followed by m visits of j to i.  A pure re-ordering of rule 1's
+  // visits; every visit tests the live positions like the reference's loop.
   int collisionRule = 0;
 
   // Optional multi-core replay for the all-cores CPU baseline (bench.py): conflict-free batches of each container
@@ -940,13 +941,8 @@ void ora_solver::tickPBD() {
             const int64_t lo = std::max(a0, b0), hi = std::min(a0 + static_cast<int64_t>(la), b0 + static_cast<int64_t>(lb));
             return hi > lo ? static_cast<uint32_t>(hi - lo) : 0u;
           };
-          for (size_t k = 0; k < n; ++k) {  // a node is in every bucket of its own range: it meets itself once per cell
-            const CellRange& r = inserted[k];
-            const uint32_t m = r.lengthX * r.lengthY * r.lengthZ;
-            for (uint32_t t = 0; t < m; ++t) visit(nodes[k], &nodes[k]);
-          }
           struct Pair { uint64_t key; uint32_t i, j, m; };
-          std::vector<Pair> pairs;
+          std::vector<Pair> pairs;  // (listed before any visit: the key looks at the positions the grid was built from)
           for (uint32_t a = 0; a < n; ++a) {
             const CellRange& ra = inserted[a];
             // every j > a sharing a cell with a is found in the bucket of the shared box's minimum corner, exactly once
@@ -962,9 +958,14 @@ void ora_solver::tickPBD() {
                     if (c.x != std::max(ra.minX, rb.minX) || c.y != std::max(ra.minY, rb.minY) || c.z != std::max(ra.minZ, rb.minZ)) continue;
                     const uint32_t m = shared(ra.minX, ra.lengthX, rb.minX, rb.lengthX) * shared(ra.minY, ra.lengthY, rb.minY, rb.lengthY) *
                                        shared(ra.minZ, ra.lengthZ, rb.minZ, rb.lengthZ);
-                    pairs.push_back(Pair{pair_key(a, b), a, b, m});
+                    pairs.push_back(Pair{pair_key(a, b, nodes[a].position, nodes[b].position), a, b, m});
                   }
                 }
+          }
+          for (size_t k = 0; k < n; ++k) {  // a node is in every bucket of its own range: it meets itself once per cell
+            const CellRange& r = inserted[k];
+            const uint32_t m = r.lengthX * r.lengthY * r.lengthZ;
+            for (uint32_t t = 0; t < m; ++t) visit(nodes[k], &nodes[k]);
           }
           std::sort(pairs.begin(), pairs.end(), [](const Pair& x, const Pair& y) { return x.key < y.key; });  // (the key is a bijection of (i, j))
           for (const Pair& pr : pairs) {

@@ -651,6 +651,29 @@ static int adapt_pcg_budget(pies_solver* s) {
   return PIES_OK;
 }
 
+// Pair-ordered node-node pass: the captured level launches follow what the passes need, at host synchronisations (a launch
+// that finds nothing to do costs 2.5 us, and each pass captures the launches twice - once for its repeat).  Deeper orders than
+// captured are finished by the single-workgroup tail kernel, so a short count is slow, never wrong.
+static int adapt_pair_rounds(pies_solver* s) {
+  if (!s->pairs.ctl || s->pairRoundsPinned || !s->graphExec || s->sceneDirty || under_profiler()) return PIES_OK;
+  if (s->opt.solver != PIES_SOLVER_PBD || !s->nodeCollisions) return PIES_OK;
+  uint32_t deepest = 0;
+  HIP_TRY(s, hipMemcpyAsync(&deepest, s->pairs.ctl + kPairDeepest, sizeof(deepest), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  if (deepest == 0) return PIES_OK;  // no pass since the last look
+  HIP_TRY(s, hipMemsetAsync(s->pairs.ctl + kPairDeepest, 0, sizeof(uint32_t), s->stream));
+  uint32_t rounds = s->pairRounds;
+  const uint32_t want = std::min(1024u, ((deepest + deepest / 4u + 8u + 15u) / 16u) * 16u);  // a quarter and eight more, in steps of 16
+  if (deepest > rounds) { rounds = want; s->pairCalm = 0; }
+  else if (want < rounds) { if (++s->pairCalm >= 3) { rounds = want; s->pairCalm = 0; } }
+  else s->pairCalm = 0;
+  if (rounds != s->pairRounds) {
+    s->pairRounds = rounds;
+    return capture_graph(s);
+  }
+  return PIES_OK;
+}
+
 static int poll_failure(pies_solver* s) {
   uint32_t* flagWord = s->hash.counters ? s->hash.counters + 3 : s->pd.tri.counters ? s->pd.tri.counters + 3 : nullptr;
   if (s->simFailed || !flagWord || s->device == PIES_DEVICE_NONE) return PIES_OK;
@@ -1230,6 +1253,7 @@ int pies_synchronize(pies_solver_t* s) {
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   s->asyncSinceSync = 0;
   if (int rc = poll_failure(s)) return rc;  // a loop of pies_tick_async learns here that the simulation failed
+  if (int rc = adapt_pair_rounds(s)) return rc;
   return adapt_pcg_budget(s);
 }
 
@@ -1297,6 +1321,7 @@ int pies_tick(pies_solver_t* s) {
   // current afterwards (pies_read_nodes / pies_read_positions_strided copy from it without touching the device)
   if (int rc = download_nodes(s, 1u)) return rc;
   if (int rc = poll_failure(s)) return rc;
+  if (int rc = adapt_pair_rounds(s)) return rc;
   return adapt_pcg_budget(s);
 }
 
@@ -1451,6 +1476,7 @@ int pies_set_tuning(const char* name, const char* value) {
 int pies_set_collision_rounds(pies_solver_t* s, uint32_t rounds) {
   if (!s) return PIES_ERR_INVALID;
   if (rounds > 4096) return fail(s, PIES_ERR_INVALID, "pies_set_collision_rounds: at most 4096");
+  s->pairRoundsPinned = true;  // an explicit count is kept (the library follows the passes by itself otherwise)
   if (rounds != s->pairRounds) {
     s->pairRounds = rounds;
     if (!s->sceneDirty) s->graphDirty = true;

@@ -18,6 +18,7 @@ constexpr uint32_t kPairRetries = 7;    // lifetime: passes repeated
 constexpr uint32_t kPairInexact = 8;    // lifetime: passes in which a node left its slack in the repeat as well (the result may differ
                                         // from the documented order by visits that were filtered out)
 constexpr uint32_t kPairEdges = 9;      // pairs listed by the last pass (diagnostics)
+constexpr uint32_t kPairDeepest = 12;    // most levels any pass needed since the host last looked (it sizes the captured launches from it)
 constexpr uint32_t kPairGroups = 10;     // groups of this grid (entries of `grp`)
 constexpr uint32_t kPairSpilled = 11;    // groups the small list kernel passed on to the large one (entries of `spill`)
 constexpr uint32_t kPairWords = 16;

@@ -4,13 +4,14 @@
 // included (quirk Q3), and resolves every overlapping meeting at once.  The result depends on the order of the meetings
 // that share a node and on nothing else.  The pair order keeps every meeting and re-orders them pair by pair:
 //   1. every node's meetings with itself (one per cell of its range);
-//   2. the unordered pairs {i < j} whose inserted ranges share m > 0 cells, in ascending order of pair_key(i, j) (a 64-bit
-//      mix of the two indices: a total order that scatters neighbouring pairs), each as m visits of i to j followed by m
-//      visits of j to i.  Every visit tests the live positions, like the reference's.
+//   2. the unordered pairs {i < j} whose inserted ranges share m > 0 cells, in ascending order of pair_key (a class from the
+//      pair's direction and place when the grid was built - pairs of one class seldom share a node -, then a 64-bit mix of
+//      the two indices: a total order), each as m visits of i to j followed by m visits of j to i.  Every visit tests the live
+//      positions, like the reference's.
 // The oracle replays exactly this with a sort and a sequential loop (FLAG_COLLISION_RULE = 2).  On the device the order is
 // executed by dependency levels: a pair's turn comes when it is the next unprocessed pair in the key-sorted lists of BOTH
-// its nodes, and the pairs whose turn has come share no node, so a level is one data-parallel launch.  A scattered key keeps the chains short: 60-80 levels for the 4.5 M pairs
-// of BASELINE config 4, against 27 passes x 350 dependent visits per group in the group order (k_collide_flow).
+// its nodes, and the pairs whose turn has come share no node, so a level is one data-parallel launch.  The classed key keeps the chains short: 30-45 levels for the 3-4 M pairs of
+// BASELINE config 4 (60-80 with the hash alone), against 27 passes x 350 dependent visits per group in the group order.
 //
 // Filter.  Of the ~300 nodes that share a cell with a node only ~20 are near enough to ever touch it.  A pair is listed
 // only if its distance at grid-build time is below r_i + r_j + s_i + s_j, and every node is checked to stay within its
@@ -37,12 +38,27 @@ constexpr uint32_t kMaxDeg = 1024;                         // listed partners of
 constexpr uint32_t kPairNodeMask = 0x0fffffffu;            // partner index; the four bits above hold (shared cells - 1)
 constexpr int kBuildWaves = 2;                            // wavefronts of a workgroup of the list kernel: one group at a time
 
-PIES_DEV uint64_t pair_key(uint32_t i, uint32_t j) {  // i < j; murmur3's 64-bit finaliser (oracle/ora_math.h: pair_key)
+// oracle/ora_math.h: pair_key - direction class and parity of the pair from the positions the grid was built from, then
+// murmur3's 64-bit finaliser over (i << 32 | j); i < j, (pix, ..) the lower node's position
+PIES_DEV uint64_t pair_key(uint32_t i, uint32_t j, float pix, float piy, float piz, float pjx, float pjy, float pjz) {
   uint64_t k = (static_cast<uint64_t>(i) << 32) | j;
   k ^= k >> 33; k *= 0xff51afd7ed558ccdull;
   k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull;
   k ^= k >> 33;
-  return k;
+  const float dx = pjx - pix, dy = pjy - piy, dz = pjz - piz;
+  const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
+  const float lim = 0.41421356f * fmaxf(ax, fmaxf(ay, az));
+  int qx = ax > lim ? (dx < 0.0f ? -1 : 1) : 0, qy = ay > lim ? (dy < 0.0f ? -1 : 1) : 0, qz = az > lim ? (dz < 0.0f ? -1 : 1) : 0;
+  const int lead = qx != 0 ? qx : (qy != 0 ? qy : qz);
+  if (lead < 0) { qx = -qx; qy = -qy; qz = -qz; }
+  const float fx = static_cast<float>(qx), fy = static_cast<float>(qy), fz = static_cast<float>(qz);
+  const float qq = fmaxf(fx * fx + fy * fy + fz * fz, 1.0f);
+  const float ui = (pix * fx + piy * fy + piz * fz) / qq, uj = (pjx * fx + pjy * fy + pjz * fz) / qq;
+  const float len = fmaxf(fabsf(uj - ui), 0.001f);
+  const float t = fminf(fmaxf(floorf(fminf(ui, uj) / len), -1.0e9f), 1.0e9f);
+  const uint32_t parity = static_cast<uint32_t>(static_cast<long long>(t)) & 1u;
+  const uint32_t cls = static_cast<uint32_t>((qx + 1) * 9 + (qy + 1) * 3 + (qz + 1)) * 2u + parity;  // < 54
+  return (static_cast<uint64_t>(cls) << 58) | (k >> 6);
 }
 
 // slack of a node after a pass in which it strayed `exc` from its build-time position
@@ -260,12 +276,13 @@ PIES_DEV uint32_t shared_cells(int a0, uint32_t la, int b0, uint32_t lb) {
 
 // appends the accepted candidates of the wavefront's lanes to the node's partner list in LDS; returns the new length
 template <uint32_t MAXD>
-PIES_DEV uint32_t push_partners(uint64_t* lk, uint32_t* le, uint32_t d, bool accept, uint32_t i, uint32_t j, uint32_t m, int lane) {
+PIES_DEV uint32_t push_partners(uint64_t* lk, uint32_t* le, uint32_t d, bool accept, uint32_t i, uint32_t j, uint32_t m, float pix, float piy, float piz,
+                                float pjx, float pjy, float pjz, int lane) {
   const unsigned long long mask = __ballot(accept);
   if (accept) {
     const uint32_t at = d + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
     if (at < MAXD) {
-      lk[at] = pair_key(min(i, j), max(i, j));
+      lk[at] = i < j ? pair_key(i, j, pix, piy, piz, pjx, pjy, pjz) : pair_key(j, i, pjx, pjy, pjz, pix, piy, piz);
       le[at] = j | ((m - 1u) << 28);
     }
   }
@@ -399,6 +416,7 @@ __global__ void __launch_bounds__(64 * kBuildWaves) k_pair_build(HashArrays H, P
                 for (uint32_t base = 0; base < bc; base += 64) {
                   bool accept = false;
                   uint32_t j = 0, m = 0;
+                  float4 pj = make_float4(0.f, 0.f, 0.f, 0.f);
                   if (base + lane < bc) {
                     j = val[bs + base + lane] & kNodeMask;
                     if (j != i) {
@@ -406,14 +424,14 @@ __global__ void __launch_bounds__(64 * kBuildWaves) k_pair_build(HashArrays H, P
                       if (cx == max(rgi.x, rgj.x) && cy == max(rgi.y, rgj.y) && cz == max(rgi.z, rgj.z)) {
                         m = shared_cells(rgi.x, lxi, rgj.x, rgj.w & 0xff) * shared_cells(rgi.y, lyi, rgj.y, (rgj.w >> 8) & 0xff) *
                             shared_cells(rgi.z, lzi, rgj.z, (rgj.w >> 16) & 0xff);
-                        const float4 pj = P.node[4u * j + 2u];
+                        pj = P.node[4u * j + 2u];
                         const float ddx = pj.x - pi.x, ddy = pj.y - pi.y, ddz = pj.z - pi.z;
                         const float cut = 1.001f * (rsi + (P.node[4u * j + 1u].w + pj.w));
                         accept = m != 0u && !(ddx * ddx + ddy * ddy + ddz * ddz >= cut * cut);
                       }
                     }
                   }
-                  d = push_partners<MAXD>(lk, le, d, accept, i, j, m, lane);
+                  d = push_partners<MAXD>(lk, le, d, accept, i, j, m, pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, lane);
                 }
               }
           __builtin_amdgcn_wave_barrier();
@@ -449,8 +467,10 @@ __global__ void __launch_bounds__(64 * kBuildWaves) k_pair_build(HashArrays H, P
         const uint32_t t = base + static_cast<uint32_t>(lane);
         bool accept = false;
         uint32_t j = 0, m = 0;
+        float pjx = 0.f, pjy = 0.f, pjz = 0.f;
         if (t < ncand && t != si) {
-          const float ddx = L.px[t] - pix, ddy = L.py[t] - piy, ddz = L.pz[t] - piz;
+          pjx = L.px[t]; pjy = L.py[t]; pjz = L.pz[t];
+          const float ddx = pjx - pix, ddy = pjy - piy, ddz = pjz - piz;
           const float cut = 1.001f * (rsi + L.rs[t]);  // (wide for a node that left its slack in the first attempt)
           if (!(ddx * ddx + ddy * ddy + ddz * ddz >= cut * cut)) {
             j = L.id[t];
@@ -461,7 +481,7 @@ __global__ void __launch_bounds__(64 * kBuildWaves) k_pair_build(HashArrays H, P
             accept = m != 0u;
           }
         }
-        d = push_partners<MAXD>(lk, le, d, accept, i, j, m, lane);
+        d = push_partners<MAXD>(lk, le, d, accept, i, j, m, pix, piy, piz, pjx, pjy, pjz, lane);
       }
       __builtin_amdgcn_wave_barrier();
       if (d > MAXD) {
@@ -597,7 +617,7 @@ __global__ void __launch_bounds__(64) k_pair_round(HashArrays H, PairArrays P, f
   const FrontierView view = frontier_view(P, round, lane);
   if (blockIdx.x == 0) {
     P.frCount[(((round + 2u) % 3u) * kPairLists + threadIdx.x) * kPairPad] = 0;  // the lists of the round after the next (read by the previous launch, filled by the next)
-    if (threadIdx.x == 0 && view.total) P.ctl[kPairRounds] = round;
+    if (threadIdx.x == 0 && view.total) { P.ctl[kPairRounds] = round; if (!repeat && round > P.ctl[kPairDeepest]) P.ctl[kPairDeepest] = round; }
   }
   if (view.total == 0u) return;  // (a pass that will be repeated is finished all the same: it finds every node that leaves its slack)
   uint32_t hits = 0;
@@ -618,7 +638,7 @@ __global__ void __launch_bounds__(1024) k_pair_tail(HashArrays H, PairArrays P, 
     if (view.total == 0u) break;  // (the same words for every wavefront: all leave together)
     __syncthreads();  // every wavefront has read the counts before the lists after the next are cleared
     if (threadIdx.x < kPairLists) __hip_atomic_store(&P.frCount[(((round + 2u) % 3u) * kPairLists + threadIdx.x) * kPairPad], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x == 0) P.ctl[kPairRounds] = round;
+    if (threadIdx.x == 0) { P.ctl[kPairRounds] = round; if (!repeat && round > P.ctl[kPairDeepest]) P.ctl[kPairDeepest] = round; }
     process_frontier(H, P, friction, staticThreshold, round, threadIdx.x, blockDim.x, view, lane, hits);
     __threadfence();
     __syncthreads();
@@ -759,10 +779,13 @@ uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArr
     if (repeat) { hipLaunchKernelGGL(k_pair_self, perNode, dim3(kBlock), 0, st, H, P, friction, staticThreshold); ++launches; }
     hipLaunchKernelGGL((k_pair_build<384, 96, 64, false>), groups, dim3(64 * kBuildWaves), 0, st, H, P, repeat); ++launches;
     hipLaunchKernelGGL((k_pair_build<kMaxCand, kMaxDeg, kMaxOwn, true>), dim3(512), dim3(64 * kBuildWaves), 0, st, H, P, repeat); ++launches;
-    for (uint32_t r = 1; r <= rounds; ++r) {  // (the repeat's launches return at once when nothing is repeated: 2.5 us each)
+    // (the repeat lists more partners and runs deeper: half as many launches again; they return at once - 2.5 us each - when
+    // nothing is repeated)
+    const uint32_t captured = repeat ? rounds + rounds / 2u : rounds;
+    for (uint32_t r = 1; r <= captured; ++r) {
       hipLaunchKernelGGL(k_pair_round, level, dim3(64), 0, st, H, P, friction, staticThreshold, r, repeat); ++launches;
     }
-    hipLaunchKernelGGL(k_pair_tail, dim3(1), dim3(1024), 0, st, H, P, friction, staticThreshold, rounds + 1u, repeat); ++launches;
+    hipLaunchKernelGGL(k_pair_tail, dim3(1), dim3(1024), 0, st, H, P, friction, staticThreshold, captured + 1u, repeat); ++launches;
     hipLaunchKernelGGL(k_pair_verify, dim3(64), dim3(kBlock), 0, st, H, P, repeat); ++launches;
     hipLaunchKernelGGL(k_pair_check, perNode, dim3(kBlock), 0, st, H, P, nd.pos, nd.vel, repeat ? 0u : 1u); ++launches;
     if (!repeat) { hipLaunchKernelGGL(k_pair_arm, dim3(1), dim3(64), 0, st, H, P); ++launches; }

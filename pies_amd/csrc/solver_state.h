@@ -169,7 +169,9 @@ struct pies_solver {
   bool simFailed = false;
   int schedule = PIES_SCHEDULE_DEFAULT;
   int collisionOrderFlag = -1;     // PIES_FLAG_COLLISION_ORDER: -1 follows the schedule (EXACT: reference order, otherwise pair order)
-  uint32_t pairRounds = 128;       // level launches captured per pair-ordered pass (a tail kernel finishes deeper orders)
+  bool pairRoundsPinned = false;   // pies_set_collision_rounds: the count is the host's
+  uint32_t pairCalm = 0;           // synchronisations in a row at which fewer level launches would have done
+  uint32_t pairRounds = 96;        // level launches captured per pair-ordered pass (a tail kernel finishes deeper orders)
 
   // ---- host mirror ----
   std::vector<float> h_pos, h_prev, h_vel;  // n x 3

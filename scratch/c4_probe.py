@@ -10,7 +10,7 @@ p, v = bench.config4_particles()
 g = capi.Solver(scenes.pbd_options(capi, 4), device=0)
 g.addNodes(p); g.set_velocities(v)
 g.set_flag(capi.FLAG_COLLISION_ORDER, order)
-g.set_collision_rounds(rounds)
+g.set_collision_rounds(rounds) if rounds else None
 g.finalize()
 for t in range(6):
     t0 = time.perf_counter(); g.tick_async(1); g.synchronize(); print("tick", t, "%.1f ms" % (1e3 * (time.perf_counter() - t0)), g.collision_health(), flush=True)

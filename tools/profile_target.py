@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The program tools/profile_round.sh puts under rocprofv3: N ticks of one of bench.py's workloads, whole substeps
-(every kernel in its place), nothing else.  usage: profile_target.py config2|config3|config4|contacts|pdcontacts N"""
+(every kernel in its place), nothing else.  usage: profile_target.py config2|config3|config4|contacts|pdcontacts|pbd1m|pd1m N"""
 import os
 import sys
 
@@ -21,6 +21,10 @@ if what == "config2":
 elif what == "config3":
     # PIES_PROFILER_SAFE keeps the captured CG budget where it starts: 3 = what bench.py's loop settles at
     g = bench.pd_beam(scenes.L100K, 0, settle=0, pcg=(3e-7, 3))
+elif what == "pbd1m":
+    g = bench.build_scene(capi, scenes.L1M, 99, schedule=capi.SCHEDULE_LAYERED, device=0)
+elif what == "pd1m":
+    g = bench.pd_beam(scenes.L1M, 0, settle=0, pcg=(3e-7, 3))
 elif what == "config4":
     p, v = bench.config4_particles()
     g = capi.Solver(scenes.pbd_options(capi, 4), device=0)

@@ -20,7 +20,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WORKLOADS = ("config2", "config3", "config4", "contacts", "pdcontacts")
+WORKLOADS = ("config2", "config3", "config4", "contacts", "pdcontacts", "pbd1m", "pd1m")
 
 
 def short(name):
@@ -82,6 +82,15 @@ def main(rnd, srcname=None):
         lines.append("== config2 VALU counters per launch (rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY)")
         for k, cs in sorted(out.items()):
             lines.append("%-28s %s" % (k, "  ".join("%s=%.0f" % kv for kv in sorted(cs.items()))))
+    valu4 = counters_of(newest(os.path.join(src, "valu_config4", "*", "*counter_collection.csv")))
+    if valu4:
+        out = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in valu4.items()}
+        with open(os.path.join(dst, "%s_pmc_valu_config4.json" % rnd), "w") as f:
+            json.dump(out, f, indent=1)
+        lines.append("")
+        lines.append("== config4 VALU counters per launch, averaged over the launches of a kernel (same counters)")
+        for k, cs in sorted(out.items()):
+            lines.append("%-28s %s" % (k, "  ".join("%s=%.0f" % kv for kv in sorted(cs.items()))))
     text = "\n".join(lines) + "\n"
     with open(os.path.join(dst, "%s_summary.txt" % rnd), "w") as f:
         f.write(text)
@@ -89,4 +98,4 @@ def main(rnd, srcname=None):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r02", sys.argv[2] if len(sys.argv) > 2 else None)
+    main(sys.argv[1] if len(sys.argv) > 1 else "r03", sys.argv[2] if len(sys.argv) > 2 else None)
