@@ -50,7 +50,7 @@ BYTES = {"predict": 48, "position": 44, "distance": 52, "tet": 160, "bend": 136,
 ITERATIONS = 20
 K = {name: i for i, name in enumerate(capi.KERNEL_NAMES)}
 DEVICE_KERNEL = {"layer": "k_layer", "tet": "k_tet", "wave": "k_wave", "pd_local_tet": "k_pd_local_tet_pair", "pd_spmv": "k_cg_ap",
-                 "pd_rhs": "k_pd_rhs", "pd_cg_update": "k_cg_update", "collide": "k_collide_flow", "hash": "k_radix_scatter"}
+                 "pd_rhs": "k_pd_rhs", "pd_cg_update": "k_cg_update", "collide": "k_pair_round", "hash": "k_radix_scatter"}
 
 
 def log(msg):
@@ -117,6 +117,22 @@ def pmc_traffic(kernel_name, workload):
     return None, None
 
 
+def pmc_traffic_of_pass(prefix, workload, anchor):
+    """HBM bytes per PASS of a multi-kernel stage (the pair-ordered resolve: k_pair_*): the sum over its kernels of
+    (bytes per launch x launches) in the committed --pmc passes, per launch of `anchor` (a kernel that runs once per pass)."""
+    for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")), reverse=True):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                w = json.load(f).get(workload, {})
+            passes = w.get(anchor, {}).get("dispatches")
+            if passes:
+                total = sum(v["hbm_bytes_per_launch"] * v["dispatches"] for k, v in w.items() if k.startswith(prefix))
+                return total / passes, "profiles/%s [%s][%s*] per %s" % (name, workload, prefix, anchor)
+        except (OSError, ValueError, AttributeError, KeyError, TypeError):
+            pass
+    return None, None
+
+
 def rocprof_average(kernel_name, workload):
     """Average duration (us) of `kernel_name` in the committed rocprofv3 --kernel-trace --stats summary of the workload."""
     import csv
@@ -164,8 +180,9 @@ def roofline(solver, cls, bytes_per_unit, substeps=3, note=None, workload="confi
     if clamped:
         net_ms = ms
     achieved = nbytes / (net_ms * 1e-3) / 1e9
-    traffic, src = pmc_traffic(kname, workload)
-    out = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+    traffic, src = pmc_traffic_of_pass("k_pair_", workload, "k_pair_save") if cls == "collide" else pmc_traffic(kname, workload)
+    out = {"bound": "hbm", "kernel": "k_pair_* (one pass)" if cls == "collide" else kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBS,
            "traffic": traffic, "traffic_source": src, "avg_launch_us": 1e3 * net_ms / launches, "launches_timed": launches,
            "bytes_per_launch": nbytes / launches, "avg_bracket_us": 1e3 * ms / launches, "bracket_overhead_us": 1e3 * overhead_ms,
            "overhead_clamped": clamped,
