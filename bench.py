@@ -181,6 +181,9 @@ def roofline(solver, cls, bytes_per_unit, substeps=3, note=None, workload="confi
         net_ms = ms
     achieved = nbytes / (net_ms * 1e-3) / 1e9
     traffic, src = pmc_traffic_of_pass("k_pair_", workload, "k_pair_save") if cls == "collide" else pmc_traffic(kname, workload)
+    if traffic is not None and traffic < 0.01 * nbytes / launches:
+        # the committed --pmc pass averaged launches most of which returned at once (CG kernels of a solve that had converged)
+        traffic, src = None, "%s: average over launches that mostly exit at once - not a figure for the working launch" % src
     out = {"bound": "hbm", "kernel": "k_pair_* (one pass)" if cls == "collide" else kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": achieved / HBM_PEAK_GBS,
            "traffic": traffic, "traffic_source": src, "avg_launch_us": 1e3 * net_ms / launches, "launches_timed": launches,
@@ -617,6 +620,36 @@ def run_config2_default_tick(device, dims, steps, with_exact):
             res[name] = {"value": None if failed else n / el, "unit": "substeps/s", "steps": n, "launches_per_substep": sum(g.launch_counts().values()),
                          "failed": failed, "error": g.last_error() if failed else None, "collision_health": g.collision_health()}
             g.close()
+    return out
+
+
+def scale_profiles(device):
+    """The same kernels at 1M particles (100x100x100), where a launch is long enough for HBM rather than the kernel boundary
+    to bound it: whole-substep throughput and in-situ rooflines."""
+    out = {}
+    for name, sched in (("pbd_1m", capi.SCHEDULE_LAYERED), ("pbd_1m_coloured", capi.SCHEDULE_COLOURED)):
+        log(name)
+        g = build_scene(capi, scenes.L1M, 99, schedule=sched, device=device)
+        g.finalize()
+        el = timed_ticks(g, 3, 1, lambda: None)
+        out[name] = {"substeps_per_sec": 3 / el, "projections_per_sec": 3 / el * scenes.projections_per_substep(g, capi, ITERATIONS),
+                     "launches_per_substep": sum(g.launch_counts().values())}
+        if sched == capi.SCHEDULE_LAYERED:
+            out[name]["roofline"] = roofline(g, "layer", 1, substeps=1, workload="pbd1m")
+        else:
+            out[name]["roofline"] = roofline(g, "tet", BYTES["tet"], substeps=1, workload="none")
+            out[name]["roofline_distance"] = roofline(g, "distance", BYTES["distance"], substeps=1, workload="none")
+        g.close()
+    log("pd_1m")
+    g = pd_beam(scenes.L1M, device, settle=12)
+    el = timed_ticks(g, 3, 1, lambda: None)
+    B = pd_bytes(g)
+    out["pd_1m"] = {"substeps_per_sec": 3 / el, "pcg_stats": g.pcg_stats(),
+                    "roofline": roofline(g, "pd_local_tet", B["pd_local_tet"], substeps=1, workload="pd1m"),
+                    "roofline_spmv": roofline(g, "pd_spmv", B["pd_spmv"], substeps=1, workload="pd1m"),
+                    "roofline_rhs": roofline(g, "pd_rhs", B["pd_rhs"], substeps=1, workload="pd1m"),
+                    "roofline_cg_update": roofline(g, "pd_cg_update", B["pd_cg_update"], substeps=1, workload="pd1m")}
+    g.close()
     return out
 
 

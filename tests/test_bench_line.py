@@ -67,3 +67,39 @@ def test_compact_line_refuses_nan():
 
 def test_full_report_maps_non_finite_to_null():
     assert bench._finite({"a": [float("inf"), 1.0], "b": float("nan")}) == {"a": [None, 1.0], "b": None}
+
+
+def test_every_name_bench_uses_is_defined():
+    """bench.py's optional sections only run on the GPU box and behind --full: a name that a refactoring lost must not wait
+    for that run to be noticed (round 3 lost scale_profiles that way).  Static check: every global name loaded anywhere in the
+    module is defined at module level, imported or a builtin."""
+    import ast
+    import builtins
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    defined = set(dir(builtins)) | {"__file__", "__name__"}
+    for node in ast.walk(tree):
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)):
+            defined.add(node.name)
+            for a in node.args.args + node.args.kwonlyargs if isinstance(node, ast.FunctionDef) else []:
+                defined.add(a.arg)
+            if isinstance(node, ast.FunctionDef):
+                if node.args.vararg:
+                    defined.add(node.args.vararg.arg)
+                if node.args.kwarg:
+                    defined.add(node.args.kwarg.arg)
+        elif isinstance(node, ast.Lambda):
+            for a in node.args.args:
+                defined.add(a.arg)
+        elif isinstance(node, (ast.Import, ast.ImportFrom)):
+            for a in node.names:
+                defined.add((a.asname or a.name).split(".")[0])
+        elif isinstance(node, ast.Name) and isinstance(node.ctx, (ast.Store, ast.Del)):
+            defined.add(node.id)
+        elif isinstance(node, ast.ExceptHandler) and node.name:
+            defined.add(node.name)
+        elif isinstance(node, ast.comprehension):
+            for n in ast.walk(node.target):
+                if isinstance(n, ast.Name):
+                    defined.add(n.id)
+    used = {n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)}
+    assert not (used - defined), sorted(used - defined)
