@@ -107,11 +107,12 @@ enum {
   /* The order of the PBD node-node pass, by name (value: PIES_COLLISION_ORDER_*).  Every order resolves the same meetings -
    * node i meets node j once per grid cell both were inserted into, in each direction, itself included - with the
    * reference's per-pair arithmetic; the loop is order dependent (Solver.cpp:85-130 moves both nodes at once).
-   *  REFERENCE : the reference's loop (see above); also what every scene with gridSpacing < 2 (r_max + 0.5) runs.
+   *  REFERENCE : the reference's loop (see above).
    *  PAIRS     : default under COLOURED / LAYERED.  A node's meetings with itself first, then the pairs {i < j} in
    *              ascending order of a 64-bit mix of (i, j), each as its m visits of i to j and m visits of j to i; executed
    *              by dependency levels, one lane per pair.
-   *  GROUPS    : rounds 1-2's order (nodes grouped by minimum cell, 27 residue classes, ascending index inside a group).
+   *  GROUPS    : rounds 1-2's order (nodes grouped by minimum cell, 27 residue classes, ascending index inside a group);
+   *              needs cell ranges of at most two cells per axis: a scene with gridSpacing < 2 (r_max + 0.5) runs REFERENCE instead.
    * PIES_FLAG_REFERENCE_COLLISION_ORDER = 0 selects PAIRS. */
   PIES_FLAG_COLLISION_ORDER = 4
 };

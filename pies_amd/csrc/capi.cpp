@@ -256,9 +256,11 @@ static void probe_mark(pies_solver* s, int k) {
 // PIES_COLLISION_ORDER_*: the reference's loop for ranges wider than two cells per axis (the parallel orders need 2R <= 1),
 // under schedule EXACT, or when asked for; otherwise the pair order (or, when asked for, the group order of rounds 1-2)
 static int collision_order(const pies_solver* s) {
-  if (!s->collideFast) return PIES_COLLISION_ORDER_REFERENCE;
-  if (s->collisionOrderFlag >= 0) return s->collisionOrderFlag;
-  return s->schedule == PIES_SCHEDULE_EXACT ? PIES_COLLISION_ORDER_REFERENCE : PIES_COLLISION_ORDER_PAIRS;
+  int order = s->collisionOrderFlag >= 0 ? s->collisionOrderFlag
+                                          : (s->schedule == PIES_SCHEDULE_EXACT ? PIES_COLLISION_ORDER_REFERENCE : PIES_COLLISION_ORDER_PAIRS);
+  // the group order needs ranges of at most two cells per axis (2R <= 1); the pair order lists node by node beyond that
+  if (order == PIES_COLLISION_ORDER_GROUPS && !s->collideFast) order = PIES_COLLISION_ORDER_REFERENCE;
+  return order;
 }
 static uint32_t enqueue_collide(pies_solver* s, bool rearm = false) {
   switch (collision_order(s)) {
@@ -1133,7 +1135,7 @@ int pies_finalize(pies_solver_t* s) {
     if (int rc = dev_alloc(s, kHashCounters, &H.counters, true)) return rc;
     if (int rc = dev_alloc(s, 27ull * n, &H.passList, true)) return rc;
     s->pairs = PairArrays{};
-    if (s->collideFast) {  // pair order: a node's list of partners (kPairStride slots of its own + a pool), work lists
+    {  // pair order: every node's list of partners (in pools), the frontier of the level launches
 
       PairArrays& P = s->pairs;
       P.n = n;
@@ -1145,6 +1147,8 @@ int pies_finalize(pies_solver_t* s) {
       if (int rc = dev_alloc(s, n, &P.vel0)) return rc;
       if (int rc = dev_alloc(s, n, &P.exc, true)) return rc;
       if (int rc = dev_alloc(s, static_cast<size_t>(P.poolCap) * kPairPools, &P.nbr)) return rc;
+      if (!s->collideFast)  // ranges wider than two cells per axis: the shared-cell count of an entry does not fit its four bits
+        if (int rc = dev_alloc(s, static_cast<size_t>(P.poolCap) * kPairPools, &P.nbrM)) return rc;
       P.frCap = n / 32 + 256;  // a chunk of 64 lanes appends at most 128 nodes to the one sub-list it is dealt to
       for (int b = 0; b < 2; ++b)
         if (int rc = dev_alloc(s, static_cast<size_t>(P.frCap) * kPairLists, &P.fr[b])) return rc;

@@ -40,6 +40,7 @@ struct PairArrays {
   float4 *vel0;            // velocities when the pass started (for the repeat)
   uint32_t *exc;           // per node: how far it has strayed in this pass (float bits)
   uint32_t *nbr;           // list entries: other node | (shared cells - 1) << 28, a node's entries ascending by pair key
+  uint32_t *nbrM;          // only for scenes with ranges wider than two cells per axis: shared cells of an entry (nbr then holds the node alone)
   float4 *bq;              // per node: position when the grid was built, radius + slack: all the list kernel gathers of a candidate
   uint32_t frCap;          // entries of one sub-list of the frontier
   uint32_t *fr[2];         // frontier: the nodes that moved on to a new entry in the last round, kPairLists sub-lists of frCap entries

@@ -290,7 +290,8 @@ PIES_DEV uint32_t push_partners(uint64_t* lk, uint32_t* le, uint32_t d, bool acc
 }
 
 // sorts the d partners by key (rank sort: the keys are distinct) and writes the node's list into the wavefront's pool
-PIES_DEV void write_list(const PairArrays& P, const uint64_t* lk, const uint32_t* le, uint32_t i, uint32_t d, uint32_t pool, int lane) {
+PIES_DEV void write_list(const PairArrays& P, const uint64_t* lk, const uint32_t* le, uint32_t i, uint32_t d, uint32_t pool, int lane,
+                         const uint32_t* lm = nullptr) {
   uint32_t at = 0;
   for (uint32_t tries = 0;; ++tries) {  // a full pool (long lists of one dense group) passes the node on to the next one
     if (lane == 0 && d) at = atomicAdd(&P.pool[pool * kPairPad], d);
@@ -312,6 +313,7 @@ PIES_DEV void write_list(const PairArrays& P, const uint64_t* lk, const uint32_t
     for (uint32_t f = 0; f < d; ++f) rank += lk[f] < k ? 1u : 0u;
     const uint32_t v = le[e];
     P.nbr[off + rank] = v;
+    if (lm) P.nbrM[off + rank] = lm[e];
     if (rank == 0u) { firstEntry = v; haveFirst = true; }
   }
   // the node's record: first entry, entries, cursor 0 reached in round 0, the current entry itself (from the lane that holds it)
@@ -506,6 +508,81 @@ __global__ void __launch_bounds__(64 * kBuildWaves) k_pair_build(HashArrays H, P
   if (lane == 0 && edgesAll) atomicAdd(&P.stat[(blockIdx.x % 64u) * kPairPad + 2u], edgesAll);
 }
 
+// ---- lists for scenes whose ranges are wider than two cells per axis (gridSpacing < 2 (r + 0.5): NodeCompRange allows up to 50
+// cells per axis): one wavefront per NODE walks the buckets of the node's own range.  A partner sits in several of them; it is
+// taken where the cell is the minimum corner of what the two ranges share (a look at the partner's range: one more gather per
+// candidate than the 2x2x2 path needs).  The number of shared cells does not fit the entry's four bits: it goes to nbrM.
+struct WideLds {
+  uint64_t lk[kMaxDeg];
+  uint32_t le[kMaxDeg], lm[kMaxDeg];
+};
+__global__ void __launch_bounds__(64) k_pair_build_wide(HashArrays H, PairArrays P, uint32_t repeat) {
+  __shared__ WideLds L;
+  const int lane = threadIdx.x;
+  if (repeat && !P.ctl[kPairRetry]) return;
+  if (H.counters[kCounterFlags]) return;
+  const GridBox B = grid_box(H.counters);
+  const uint32_t* __restrict__ val = H.val[grid_passes(B) & 1u];
+  const uint32_t pool = blockIdx.x % kPairPools;
+  uint64_t tested = 0;
+  uint32_t edges = 0;
+  for (uint32_t i = blockIdx.x; i < P.n; i += gridDim.x) {
+    const int4 rgi = H.rng[i];
+    const uint32_t lxi = rgi.w & 0xff, lyi = (rgi.w >> 8) & 0xff, lzi = (rgi.w >> 16) & 0xff;
+    if (lxi * lyi * lzi == 0u) continue;  // an over-long range is empty (Solver.cpp:896-898): the node visits nothing
+    const float4 pi = P.node[4u * i + 2u];
+    const float rsi = P.node[4u * i + 1u].w + pi.w;
+    uint32_t d = 0;
+    for (uint32_t dx = 0; dx < lxi; ++dx)
+      for (uint32_t dy = 0; dy < lyi; ++dy)
+        for (uint32_t dz = 0; dz < lzi; ++dz) {
+          const int cx = rgi.x + static_cast<int>(dx), cy = rgi.y + static_cast<int>(dy), cz = rgi.z + static_cast<int>(dz);
+          const uint32_t cs = find_bucket(H, B, cx, cy, cz);
+          if (cs == 0xffffffffu) continue;
+          const uint32_t bs = H.start[cs], bc = H.end[cs] - bs;
+          tested += bc;
+          for (uint32_t base = 0; base < bc; base += 64) {
+            bool accept = false;
+            uint32_t j = 0, m = 0;
+            float4 pj = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (base + lane < bc) {
+              j = val[bs + base + lane] & kNodeMask;
+              if (j != i) {
+                const int4 rgj = H.rng[j];
+                if (cx == max(rgi.x, rgj.x) && cy == max(rgi.y, rgj.y) && cz == max(rgi.z, rgj.z)) {
+                  m = shared_cells(rgi.x, lxi, rgj.x, rgj.w & 0xff) * shared_cells(rgi.y, lyi, rgj.y, (rgj.w >> 8) & 0xff) *
+                      shared_cells(rgi.z, lzi, rgj.z, (rgj.w >> 16) & 0xff);
+                  pj = P.node[4u * j + 2u];
+                  const float ddx = pj.x - pi.x, ddy = pj.y - pi.y, ddz = pj.z - pi.z;
+                  const float cut = 1.001f * (rsi + (P.node[4u * j + 1u].w + pj.w));
+                  accept = m != 0u && !(ddx * ddx + ddy * ddy + ddz * ddz >= cut * cut);
+                }
+              }
+            }
+            const unsigned long long mask = __ballot(accept);
+            if (accept) {
+              const uint32_t at = d + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+              if (at < kMaxDeg) {
+                L.lk[at] = i < j ? pair_key(i, j, pi.x, pi.y, pi.z, pj.x, pj.y, pj.z) : pair_key(j, i, pj.x, pj.y, pj.z, pi.x, pi.y, pi.z);
+                L.le[at] = j;
+                L.lm[at] = m;
+              }
+            }
+            d += static_cast<uint32_t>(__popcll(mask));
+          }
+        }
+    __builtin_amdgcn_wave_barrier();
+    if (d > kMaxDeg) {  // a pile-up beyond anything a simulation survives: latch
+      if (lane == 0) atomicOr(&P.ctl[kPairFlags], 2u);
+      d = kMaxDeg;
+    }
+    write_list(P, L.lk, L.le, i, d, pool, lane, L.lm);
+    edges += d;
+  }
+  if (lane == 0 && tested) atomicAdd(reinterpret_cast<unsigned long long*>(&P.stat[(blockIdx.x % 64u) * kPairPad]), static_cast<unsigned long long>(tested));
+  if (lane == 0 && edges) atomicAdd(&P.stat[(blockIdx.x % 64u) * kPairPad + 2u], edges);
+}
+
 // The frontier of a round is kept as kPairLists sub-lists.  A wavefront works on chunks of 64 consecutive positions of their
 // concatenation and appends to the sub-list its chunk is dealt to (chunk index modulo kPairLists).
 struct FrontierView {
@@ -577,7 +654,7 @@ PIES_DEV void process_frontier(const HashArrays& H, const PairArrays& P, float f
           const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
           if (a.r + b.r - dist > 0.0f) {
             const float4 a0 = node[4u * lo + 2u], b0 = node[4u * hi + 2u];
-            const uint32_t m = (rx.w >> 28) + 1u;
+            const uint32_t m = P.nbrM ? P.nbrM[rx.x + (rx.z & 0xffffu)] : (rx.w >> 28) + 1u;  // (wide ranges keep the count beside the entry)
             uint32_t h = 0;
             for (uint32_t t = 0; t < m; ++t) h += visit(a, b, friction, staticThreshold) ? 1u : 0u;
             for (uint32_t t = 0; t < m; ++t) h += visit(b, a, friction, staticThreshold) ? 1u : 0u;
@@ -774,11 +851,16 @@ uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArr
   const dim3 groups(std::max<uint32_t>(1u, std::min<uint32_t>(8192u, n / 8 + 1)));
   const dim3 level(std::max<uint32_t>(1u, std::min<uint32_t>(8192u, (n + 63u) / 64u)));
   hipLaunchKernelGGL(k_pair_save, perNode, dim3(kBlock), 0, st, H, P, nd.pos, nd.vel, nd.radius, friction, staticThreshold); ++launches;
-  hipLaunchKernelGGL(k_pair_groups, dim3(std::min<uint32_t>(2048u, (H.capacity / 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, H, P, 0u); ++launches;
+  const bool wide = P.nbrM != nullptr;  // ranges of more than two cells per axis: lists node by node
+  if (!wide) { hipLaunchKernelGGL(k_pair_groups, dim3(std::min<uint32_t>(2048u, (H.capacity / 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, H, P, 0u); ++launches; }
   for (uint32_t repeat = 0; repeat < 2; ++repeat) {
     if (repeat) { hipLaunchKernelGGL(k_pair_self, perNode, dim3(kBlock), 0, st, H, P, friction, staticThreshold); ++launches; }
-    hipLaunchKernelGGL((k_pair_build<384, 96, 64, false>), groups, dim3(64 * kBuildWaves), 0, st, H, P, repeat); ++launches;
-    hipLaunchKernelGGL((k_pair_build<kMaxCand, kMaxDeg, kMaxOwn, true>), dim3(512), dim3(64 * kBuildWaves), 0, st, H, P, repeat); ++launches;
+    if (wide) {
+      hipLaunchKernelGGL(k_pair_build_wide, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(16384u, n))), dim3(64), 0, st, H, P, repeat); ++launches;
+    } else {
+      hipLaunchKernelGGL((k_pair_build<384, 96, 64, false>), groups, dim3(64 * kBuildWaves), 0, st, H, P, repeat); ++launches;
+      hipLaunchKernelGGL((k_pair_build<kMaxCand, kMaxDeg, kMaxOwn, true>), dim3(512), dim3(64 * kBuildWaves), 0, st, H, P, repeat); ++launches;
+    }
     // (the repeat lists more partners and runs deeper: half as many launches again; they return at once - 2.5 us each - when
     // nothing is repeated)
     const uint32_t captured = repeat ? rounds + rounds / 2u : rounds;

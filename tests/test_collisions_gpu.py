@@ -27,12 +27,12 @@ def particles(dims, spacing=0.9, jitter=0.05, seed=1234, y0=0.5):
     return p.astype(np.float32), v.astype(np.float32)
 
 
-def pair(pies, oracle, build, iterations, ticks, rule=2, **opt):
+def pair(pies, oracle, build, iterations, ticks, rule=2, oracle_rule=None, **opt):
     g = pies.Solver(scenes.pbd_options(pies, iterations, **opt))
     o = oracle.OracleSolver(scenes.pbd_options(oracle, iterations, **opt))
     for s in (g, o):
         build(s)
-    o.set_flag(oracle.FLAG_COLLISION_RULE, rule)
+    o.set_flag(oracle.FLAG_COLLISION_RULE, rule if oracle_rule is None else oracle_rule)
     g.set_flag(pies.FLAG_COLLISION_ORDER, rule)
     g.tick(ticks)
     o.tick(ticks)
@@ -152,21 +152,42 @@ def test_device_rule_vs_reference_order_is_a_small_perturbation(oracle):
     assert com < 0.05 and ext < 0.5
 
 
+@pytest.mark.parametrize("rule", [0, 1, 2])
 @pytest.mark.parametrize("spacing", [1.0, 0.3, 0.045])
-def test_small_grid_spacing_runs_in_reference_order(pies, oracle, spacing):
+def test_small_grid_spacing(pies, oracle, spacing, rule):
     """gridSpacing < 2 (r + 0.5): a node spans 3 and more cells per axis (NodeCompRange allows up to 50,
     Solver.cpp:896-898; at spacing 0.045 the range is 45 cells wide for r = 0.5 and EMPTY for the larger radius, which
-    then never collides as a visiting node).  The parallel order needs ranges of at most 2 cells, so these scenes run the
-    reference's loop whatever the flag says."""
+    then never collides as a visiting node).  The group order needs ranges of at most 2 cells, so it runs the reference's
+    loop in these scenes (the oracle is asked for rule 0 then); the pair order lists node by node over the node's own range,
+    with the number of shared cells - up to 45^3 here - beside the entry."""
     p, v = particles((4, 3, 5), spacing=0.8)
     r = np.full(len(p), 0.5, np.float32)
     r[::7] = 0.7
 
     def build(s):
         s.add_nodes_raw(p, vel=v, radius=r, invMass=np.ones(len(p), np.float32))
-    g, o = pair(pies, oracle, build, 2, 2, rule=0, gridSpacing=spacing)
+    g, o = pair(pies, oracle, build, 2, 2, rule=rule, gridSpacing=spacing, oracle_rule=0 if rule == 1 else rule)
     check(g, o)
     assert g.collision_pairs == o.collision_pairs > 0
+    if rule == 2:
+        h = g.collision_health()
+        assert h["levels"] > 0 and h["passes_inexact"] == 0, h
+
+
+def test_wide_ranges_in_the_pair_order_at_scale(pies, oracle):
+    """30 000 loose particles on a grid of 0.6 (ranges of 3-4 cells per axis, 27-64 cells per node, a pair shares up to 36 of
+    them): the pair order against the oracle, two ticks."""
+    p, v = particles((30, 25, 40))
+
+    def build(s):
+        s.addNodes(p)
+        s.set_velocities(v)
+    g, o = pair(pies, oracle, build, 3, 2, rule=2, gridSpacing=0.6)
+    check(g, o)
+    assert g.collision_pairs == o.collision_pairs > 100_000
+    h = g.collision_health()
+    print("wide ranges, pair order:", h)
+    assert h["passes_inexact"] == 0
 
 
 def test_config4_l500k_one_tick(pies, oracle):
