@@ -414,6 +414,8 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
   if (ON(PIES_KERNEL_PD_PREDICT)) { launch_pd_predict(st, s->nd, pd, h, s->opt.floorHeight + s->opt.collisionThickness); U(s->nd.n); }
   C(PIES_KERNEL_PD_PREDICT);
   const bool tri = pd.tri.nt != 0;
+  // the statistics of the substep's last solve are closed by an extra workgroup of the floor-snap launch when there is one
+  const bool statsInStabilize = only < 0 && s->opt.collisionStabilizationIterations > 0 && s->opt.iterations > 0 && s->nd.n != 0;
   if (tri && only < 0) {  // Solver.cpp:240, 245-248: detection, contact list, their blocks of the system matrix
     launch_tri_detect(st, pd.tri, s->nd, pd.kdiag, pd.cg.cdiag, pd.cg.dinv, s->opt.collisionThresholdDistance, s->opt.collisionThickness,
                       pd.cg.useCAp != 0);
@@ -443,7 +445,8 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
       if (ON(PIES_KERNEL_PD_LOCAL_TET)) {
         launch_pd_local_tet_pair(st, s->nd.pos, s->d_tc_ids, s->d_tc_q0, s->d_tc_q1, s->d_tc_q2, s->d_vc_q2,
                                  pd.contrib + s->slotBase[PIES_TET], pd.contrib + s->slotBase[PIES_VOLUME], nTet,
-                                 tri && only < 0 ? &pd.tri : nullptr, s->opt.collisionThickness);  // + the contacts' local step
+                                 tri && only < 0 ? &pd.tri : nullptr, s->opt.collisionThickness, s->pdLocalPacked,
+                                 s->pdLocalPacked ? s->d_pairDictIndex : nullptr, s->d_pairDictTable);  // + the contacts' local step
         U(nTet);
       }
       C(PIES_KERNEL_PD_LOCAL_TET);
@@ -469,7 +472,7 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
     if (only < 0) {  // Solver.cpp:356-364
       const bool probed = s->probe && (s->probe->kernel == PIES_KERNEL_PD_SPMV || s->probe->kernel == PIES_KERNEL_PD_CG_UPDATE);
       // a probed solve never takes the converged early exit: every bracketed launch does a full SpMV / vector update
-      launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, s->pcgTol, -1, it == 0, it + 1 == s->opt.iterations, probed,
+      launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, s->pcgTol, -1, it == 0, it + 1 == s->opt.iterations && !statsInStabilize, probed,
                       probed ? [](void* ctx, int cls) { probe_mark(static_cast<pies_solver*>(ctx), cls); } : (void (*)(void*, int))nullptr, s,
                       s->pcgOverflow ? (int)(s->pcgMaxIters > s->pcgBudget ? s->pcgMaxIters - s->pcgBudget : 0u) : 0);
       if (probed && units) *units += (uint64_t)s->nd.n * s->pcgBudget;
@@ -481,15 +484,15 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
   }
   if (tri && only < 0) {  // :367-383: every stabilisation iteration is a sequential pass over the contacts, then the floor snap
     if (s->triLevelsForked) (void)hipStreamWaitEvent(st, s->evJoin, 0);
-    for (uint32_t ci = 0; ci < s->opt.collisionStabilizationIterations; ++ci) {
-      launch_tri_stabilize(st, pd.tri, s->nd, s->opt.collisionThickness);
-      launch_pd_stabilize(st, s->nd, pd);
-    }
+    // all iterations in one launch (the floor snap of the contacts' nodes between the passes), then the snap of everybody else:
+    // idempotent, so once is what the reference's `iterations` times come to
+    launch_tri_stabilize(st, pd.tri, s->nd, s->opt.collisionThickness, pd.nstatic, pd.statp, s->opt.collisionStabilizationIterations);
+    if (s->opt.collisionStabilizationIterations > 0) launch_pd_stabilize(st, s->nd, pd, statsInStabilize, (int)s->pcgBudget, s->pcgTol);
     launch_pd_velocity(st, s->nd, pd, h, s->opt.damping, s->opt.gravity, s->opt.friction, s->opt.staticFrictionThreshold, false);
     launch_tri_friction(st, pd.tri, s->nd, s->opt.friction, s->opt.staticFrictionThreshold);               // :431-471
     launch_pd_static_friction(st, s->nd, pd, s->opt.friction, s->opt.staticFrictionThreshold);             // :473-484
   } else {
-    if (only < 0 && s->opt.collisionStabilizationIterations > 0) launch_pd_stabilize(st, s->nd, pd);  // the floor snap is idempotent
+    if (only < 0 && s->opt.collisionStabilizationIterations > 0) launch_pd_stabilize(st, s->nd, pd, statsInStabilize, (int)s->pcgBudget, s->pcgTol);  // the floor snap is idempotent
     if (ON(PIES_KERNEL_PD_VELOCITY)) {
       launch_pd_velocity(st, s->nd, pd, h, s->opt.damping, s->opt.gravity, s->opt.friction, s->opt.staticFrictionThreshold, true);
       U(s->nd.n);
@@ -725,6 +728,7 @@ void pies_default_options(pies_options_t* o) {
 // PIES_SCHEDULE overrides PIES_SCHEDULE_DEFAULT for new handles (not an explicit pies_set_schedule)
 static void apply_schedule_environment(pies_solver* s) {
   if (const char* e = tuning_env("PIES_PCG_OVERFLOW")) s->pcgOverflow = e[0] != '0';
+  if (const char* e = tuning_env("PIES_PD_LOCAL_PACKED")) s->pdLocalPacked = e[0] != '0';
   if (const char* e = tuning_env("PIES_PCG_BUDGET")) {  // diagnostics: the captured CG iterations, never adapted
     const int v = std::atoi(e);
     if (v >= 1 && v <= 4096) { s->pcgPinned = true; s->pcgPinnedBudget = static_cast<uint32_t>(v); s->pcgBudget = std::min(s->pcgMaxIters, s->pcgPinnedBudget); }
@@ -1185,6 +1189,41 @@ int pies_finalize(pies_solver_t* s) {
       s->tetVolumePaired = std::memcmp(a.ids, b.ids, sizeof(a.ids)) == 0 && std::memcmp(a.qinv, b.qinv, sizeof(a.qinv)) == 0;
     }
     if (const char* e = tuning_env("PIES_NO_TET_PAIRS"); e && e[0] == '1') s->tetVolumePaired = false;
+    // Rest dictionary: the 64 bytes of constants of an element pair are the same for every element of one shape and material.
+    // With few distinct sets (a createTetBox lattice: one per orientation) the local step reads a 16-bit index per element.
+    s->d_pairDictIndex = nullptr;
+    s->d_pairDictTable = nullptr;
+    s->pairDictSets = 0;
+    const char* de = tuning_env("PIES_PD_REST_DICT");
+    if (s->tetVolumePaired && !(de && de[0] == '0')) {
+      struct Set { float v[16]; bool operator<(const Set& o) const { return std::memcmp(v, o.v, sizeof(v)) < 0; } };
+      std::map<Set, uint16_t> sets;
+      std::vector<uint16_t> index(id.size());
+      std::vector<float4> table;
+      bool ok = true;
+      for (size_t k = 0; ok && k < id.size(); ++k) {
+        const HostTet &a = s->h_tet[s->plan[PIES_TET].order[k]], &b = s->h_volume[k];
+        Set key;
+        std::memcpy(key.v, a.qinv, 9 * sizeof(float));
+        key.v[9] = a.lo; key.v[10] = a.hi; key.v[11] = a.w;
+        key.v[12] = b.qinv[8]; key.v[13] = b.lo; key.v[14] = b.hi; key.v[15] = b.w;
+        auto it = sets.find(key);
+        if (it == sets.end()) {
+          if (sets.size() >= 4096 || (sets.size() + 1) * 16 > id.size()) { ok = false; break; }  // no real compression: per-element arrays
+          it = sets.emplace(key, static_cast<uint16_t>(sets.size())).first;
+          table.push_back(make_float4(key.v[0], key.v[1], key.v[2], key.v[3]));
+          table.push_back(make_float4(key.v[4], key.v[5], key.v[6], key.v[7]));
+          table.push_back(make_float4(key.v[8], key.v[9], key.v[10], key.v[11]));
+          table.push_back(make_float4(key.v[12], key.v[13], key.v[14], key.v[15]));
+        }
+        index[k] = it->second;
+      }
+      if (ok && !index.empty()) {
+        if (int rc = upload(s, index, &s->d_pairDictIndex)) return rc;
+        if (int rc = upload(s, table, &s->d_pairDictTable)) return rc;
+        s->pairDictSets = static_cast<uint32_t>(sets.size());
+      }
+    }
     if (int rc = pd_build(s)) return rc;
     if (n) {  // input of a substep, kept until its solves are known to have met the tolerance (pd_tick_checked)
       if (int rc = dev_alloc(s, n, &s->snapPos)) return rc;

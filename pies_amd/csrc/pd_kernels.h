@@ -91,7 +91,8 @@ void launch_pd_local_tet(hipStream_t st, bool volume, const float4* pos, const u
 // extra workgroups
 void launch_pd_local_tet_pair(hipStream_t st, const float4* pos, const uint4* ids, const float4* q0, const float4* q1, const float4* q2,
                               const float4* vq2, Vec3f* contribTet, Vec3f* contribVol, uint32_t count, const TriArrays* tri = nullptr,
-                              float thickness = 0.0f);
+                              float thickness = 0.0f, bool packed = true, const uint16_t* dictIndex = nullptr,
+                              const float4* dictTable = nullptr);  // packed: two elements per lane; dict*: pd_local_packed.h RestDictionary
 void launch_pd_local_bend(hipStream_t st, const float4* pos, const uint4* ids, const float2* angle_w, Vec3f* contrib, uint32_t count);
 void launch_pd_local_shape(hipStream_t st, const float4* pos, const PdArrays& pd);
 void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd);
@@ -105,7 +106,9 @@ void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd);
 void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, int maxIters, float tol, int part = -1, bool first = true,
                      bool last = true, bool neverExit = false, void (*hook)(void*, int) = nullptr, void* hookCtx = nullptr,
                      int overflowIters = 0);
-void launch_pd_stabilize(hipStream_t st, const NodeArrays& nd, const PdArrays& pd);
+// closeSolve: one more workgroup closes the statistics of the substep's last solve (k_cg_finish's work; maxIters = that solve's
+// captured iterations, tol its tolerance)
+void launch_pd_stabilize(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, bool closeSolve = false, int maxIters = 0, float tol = 0.0f);
 // staticFriction = false leaves the floor friction (Solver.cpp:473-484) to launch_pd_static_friction, which the
 // reference runs after the point-triangle friction
 void launch_pd_velocity(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float h, float damping, float gravity,

@@ -88,7 +88,9 @@ __global__ void __launch_bounds__(kBlock) k_pd_local_distance(const float4* __re
                              w * ((0.0f + -0.5f * p0z) + 0.5f * b.z)};
 }
 
-// Constraints.cpp:186-203
+// Constraints.cpp:186-203.  The reference divides the three components by `den`; here one reciprocal (a correctly rounded
+// division) and three products - the last bit of D may differ, PD parity is by tolerance, and the
+// ten iterations of this loop were a quarter of the local step's instructions with three divisions each.
 PIES_DEV void compute_d(const float s[3], float omegaMin, float omegaMax, float D[3]) {
   D[0] = D[1] = D[2] = 0.0f;
   for (int it = 0; it < 10; ++it) {
@@ -99,9 +101,10 @@ PIES_DEV void compute_d(const float s[3], float omegaMin, float omegaMax, float 
     const float gx = sy * sz, gy = sx * sz, gz = sx * sy;
     const float num = (gx * D[0] + gy * D[1] + gz * D[2]) - C;
     const float den = gx * gx + gy * gy + gz * gz;
-    D[0] = (num * gx) / den;
-    D[1] = (num * gy) / den;
-    D[2] = (num * gz) / den;
+    const float q = num / den;
+    D[0] = q * gx;
+    D[1] = q * gy;
+    D[2] = q * gz;
   }
 }
 
@@ -202,16 +205,19 @@ PIES_DEV void local_tet_pair(const float4* __restrict__ pos, const uint4* __rest
   const float4 a2 = q2[c], v2 = vq2[c];
   TetFrame t;
   tet_frame(pos, ids[c], q0[c], q1[c], a2, t);
-  float s[3];
-  // one record per corner: the strain and the volume contribution of the element added up here (the right-hand side
-  // then gathers 4 records per element pair instead of 8; the volume container's slots stay unused)
-  float ra[4][3], rb[4][3];
-  tet_project<false>(t, a2.y, a2.z, s);
-  tet_records(t, s, a2.w, ra);
-  tet_project<true>(t, v2.y, v2.z, s);
-  tet_records(t, s, v2.w, rb);
+  // One record per corner: the strain and the volume contribution of the element added up (the right-hand side gathers 4
+  // records per element pair instead of 8; the volume container's slots stay unused).  Both projections share U and V, and
+  // w (A^T p) is linear in the projected singular values: the two are combined BEFORE the recomposition,
+  // w_a U diag(s_a) V^T + w_b U diag(s_b) V^T = U diag(w_a s_a + w_b s_b) V^T - one recomposition and one A^T product per
+  // element instead of two (this kernel is bound by VALU issue at 100k particles: 2 230 instructions per lane, 23 us).
+  float sa[3], sb[3];
+  tet_project<false>(t, a2.y, a2.z, sa);
+  tet_project<true>(t, v2.y, v2.z, sb);
+  const float sc[3] = {fmaf(a2.w, sa[0], v2.w * sb[0]), fmaf(a2.w, sa[1], v2.w * sb[1]), fmaf(a2.w, sa[2], v2.w * sb[2])};
+  float rec[4][3];
+  tet_records(t, sc, 1.0f, rec);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) contribTet[i * count + c] = Vec3f{ra[i][0] + rb[i][0], ra[i][1] + rb[i][1], ra[i][2] + rb[i][2]};
+  for (int i = 0; i < 4; ++i) contribTet[i * count + c] = Vec3f{rec[i][0], rec[i][1], rec[i][2]};
 }
 // (Asking for 5 wavefronts per SIMD - 77 VGPRs instead of 108, no spill - measured the same on one box: 26.0 / 186 us
 // against 26.1 / 192 us at 100k / 5.8M element pairs.)
@@ -253,16 +259,28 @@ PIES_DEV void local_tri_contacts(const TriArrays& T, const float4* __restrict__ 
   }
 }
 constexpr uint32_t kTriLocalBlocks = 64;  // extra workgroups of the fused launch that sweep the contact list
+}  // namespace pies
+#include "pd_local_packed.h"
+namespace pies {
+// PACKED: two elements per lane in packed fp32 (pd_local_packed.h; the default), tetBlocks workgroups cover ceil(count / 2)
+// lanes; DICT: the elements' constants come from the rest dictionary
+template <bool PACKED, bool DICT>
 __global__ void __launch_bounds__(kBlock) k_pd_local_tet_pair(const float4* __restrict__ pos, const uint4* __restrict__ ids,
                                                               const float4* __restrict__ q0, const float4* __restrict__ q1,
                                                               const float4* __restrict__ q2, const float4* __restrict__ vq2,
-                                                              Vec3f* __restrict__ contribTet, uint32_t count, TriArrays T,
+                                                              RestDictionary dict, Vec3f* __restrict__ contribTet, uint32_t count, TriArrays T,
                                                               float thickness, uint32_t tetBlocks) {
   if (blockIdx.x >= tetBlocks) {  // uniform per workgroup
     local_tri_contacts(T, pos, thickness, blockIdx.x - tetBlocks, kTriLocalBlocks);
     return;
   }
-  local_tet_pair(pos, ids, q0, q1, q2, vq2, contribTet, count, tetBlocks);
+  if (PACKED) {
+    const uint32_t c0 = 2u * (xcd_block(blockIdx.x, tetBlocks) * kBlock + threadIdx.x);
+    if (c0 >= count) return;
+    local_tet_pair_packed<DICT>(pos, ids, q0, q1, q2, vq2, dict, contribTet, count, c0, c0 + 1u < count ? c0 + 1u : c0);
+  } else {
+    local_tet_pair(pos, ids, q0, q1, q2, vq2, contribTet, count, tetBlocks);
+  }
 }
 
 // BendConstraint in PD (Constraints.cpp:312-366): A = B = I, contribution = w * projected_i.
@@ -423,31 +441,35 @@ __global__ void __launch_bounds__(kBlock) k_pd_local_shape(const float4* __restr
 // lanes that share a node's gather (each with four records in flight).  Measured per launch at 100k / 1M nodes with ~24
 // records per node: 16 lanes 13.1 / 136 us, 8 lanes 10.2 / 95, 4 lanes 9.3 / 88, 2 lanes 10.6 / 105.
 constexpr uint32_t kRhsLanes = PIES_RHS_LANES;
-__global__ void __launch_bounds__(kBlock) k_pd_rhs(const float4* __restrict__ msn, const Vec3f* __restrict__ contrib,
-                                                   const uint32_t* __restrict__ incPtr, const uint32_t* __restrict__ incSlot,
-                                                   const double4* __restrict__ contribD, const uint32_t* __restrict__ incPtrD,
-                                                   const uint32_t* __restrict__ incSlotD, const float4* __restrict__ pos,
-                                                   const uint32_t* __restrict__ nstatic, float4* __restrict__ statp,
-                                                   float4* __restrict__ rhs, const uint32_t* __restrict__ tIncCnt,
-                                                   const uint32_t* __restrict__ tIncStart, const uint32_t* __restrict__ tInc,
-                                                   const float4* __restrict__ tContrib, uint32_t n) {
-  // kRhsLanes lanes per node: lane `sub` adds up the records sub, sub + kRhsLanes, ... of the node's slot list (four
-  // slot indices and records per lane in flight at once), then the partial sums are combined pairwise.  The reference adds
-  // the same terms one after the other; the difference is fp32 rounding of a ~50-term sum (PD parity is by
-  // tolerance).  (Measured at 100k nodes: 1 lane/node 60 us; 16 lanes with the terms added in
-  // list order by one lane 24 us; visiting nodes in Morton order was slower than index order.)
-  const uint32_t i = (xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x) / kRhsLanes, sub = threadIdx.x & (kRhsLanes - 1);
-  const bool live = i < n;
-  float4 f = live ? msn[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-  const uint32_t b = live ? incPtr[i] : 0u, e = live ? incPtr[i + 1] : 0u;
-  float ax = 0.f, ay = 0.f, az = 0.f;
+struct RhsArrays {
+  const float4* msn;
+  const Vec3f* contrib;
+  const uint32_t *incPtr, *incSlot;
+  const double4* contribD;
+  const uint32_t *incPtrD, *incSlotD;
+  const float4* pos;
+  const uint32_t* nstatic;
+  float4* statp;
+  const uint32_t *tIncCnt, *tIncStart, *tInc;
+  const float4* tContrib;
+  uint32_t n;
+};
+// The right-hand side of node i, by the kRhsLanes lanes that share it (`sub` = the lane's place among them; every lane of the
+// wavefront calls these, lanes past the last node with live = false).  The value is complete in the lane with sub == 0.
+// kRhsLanes lanes per node: lane `sub` adds up the records sub, sub + kRhsLanes, ... of the node's slot list (four
+// slot indices and records per lane in flight at once), then the partial sums are combined pairwise.  The reference adds
+// the same terms one after the other; the difference is fp32 rounding of a ~50-term sum (PD parity is by
+// tolerance).  (Measured at 100k nodes: 1 lane/node 60 us; 16 lanes with the terms added in
+// list order by one lane 24 us; visiting nodes in Morton order was slower than index order.)
+// rhs_gather: this lane's share of the records [b, e) of the slot list, added to (ax, ay, az)
+PIES_DEV void rhs_gather(const RhsArrays& R, uint32_t b, uint32_t e, uint32_t sub, float& ax, float& ay, float& az) {
   for (uint32_t k = b + sub; k < e; k += 4 * kRhsLanes) {  // four records per lane in flight: slot indices first, then the records
     uint32_t slot[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) slot[u] = (k + kRhsLanes * u < e) ? incSlot[k + kRhsLanes * u] : 0xffffffffu;
+    for (int u = 0; u < 4; ++u) slot[u] = (k + kRhsLanes * u < e) ? R.incSlot[k + kRhsLanes * u] : 0xffffffffu;
     Vec3f c[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) c[u] = (slot[u] != 0xffffffffu) ? contrib[slot[u]] : Vec3f{0.f, 0.f, 0.f};
+    for (int u = 0; u < 4; ++u) c[u] = (slot[u] != 0xffffffffu) ? R.contrib[slot[u]] : Vec3f{0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       ax += c[u].x;
@@ -455,6 +477,10 @@ __global__ void __launch_bounds__(kBlock) k_pd_rhs(const float4* __restrict__ ms
       az += c[u].z;
     }
   }
+}
+// rhs_finish: the lanes' partial sums combined and added to f (= M s_n / h^2 of the node), then the terms one lane adds: contacts,
+// shape / goal matching, floor
+PIES_DEV float4 rhs_finish(const RhsArrays& R, uint32_t i, uint32_t sub, bool live, float4 f, float ax, float ay, float az) {
 #pragma unroll
   for (int off = kRhsLanes / 2; off >= 1; off >>= 1) {
     ax += __shfl_xor(ax, off, kRhsLanes);
@@ -465,18 +491,18 @@ __global__ void __launch_bounds__(kBlock) k_pd_rhs(const float4* __restrict__ ms
   f.y += ay;
   f.z += az;
   float tx = 0.f, ty = 0.f, tz = 0.f;
-  if (tIncCnt) {  // point-triangle contacts (Solver.cpp:337-340): a node of a contact patch takes part in tens of contacts; the
+  if (R.tIncCnt) {  // point-triangle contacts (Solver.cpp:337-340): a node of a contact patch takes part in tens of contacts; the
     // team's lanes add its records like the ones above (four in flight per lane, partial sums combined pairwise) - one lane
     // walking the list made this launch 55 us with 29k contacts (2 dependent loads per record), the rest of it takes 10
-    const uint32_t tc = live ? tIncCnt[i] : 0u;
-    const uint32_t ts = tc ? tIncStart[i] : 0u;
+    const uint32_t tc = live ? R.tIncCnt[i] : 0u;
+    const uint32_t ts = tc ? R.tIncStart[i] : 0u;
     for (uint32_t k = sub; k < tc; k += 4 * kRhsLanes) {
       uint32_t v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = (k + kRhsLanes * u < tc) ? tInc[ts + k + kRhsLanes * u] : 0xffffffffu;
+      for (int u = 0; u < 4; ++u) v[u] = (k + kRhsLanes * u < tc) ? R.tInc[ts + k + kRhsLanes * u] : 0xffffffffu;
       float4 c[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) c[u] = (v[u] != 0xffffffffu) ? tContrib[4 * (v[u] >> 2) + (v[u] & 3u)] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int u = 0; u < 4; ++u) c[u] = (v[u] != 0xffffffffu) ? R.tContrib[4 * (v[u] >> 2) + (v[u] & 3u)] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         tx += c[u].x;
@@ -491,11 +517,11 @@ __global__ void __launch_bounds__(kBlock) k_pd_rhs(const float4* __restrict__ ms
       tz += __shfl_xor(tz, off, kRhsLanes);
     }
   }
-  if (!live || sub != 0) return;
-  if (incPtrD) {  // shape then goal matching: force += float w * double projection (ShapeMatchingConstraint.cpp:58-72,147-161)
-    const uint32_t ed = incPtrD[i + 1];
-    for (uint32_t k = incPtrD[i]; k < ed; ++k) {
-      const double4 c = contribD[incSlotD[k]];
+  if (!live || sub != 0) return f;
+  if (R.incPtrD) {  // shape then goal matching: force += float w * double projection (ShapeMatchingConstraint.cpp:58-72,147-161)
+    const uint32_t ed = R.incPtrD[i + 1];
+    for (uint32_t k = R.incPtrD[i]; k < ed; ++k) {
+      const double4 c = R.contribD[R.incSlotD[k]];
       f.x = static_cast<float>(static_cast<double>(f.x) + c.w * c.x);
       f.y = static_cast<float>(static_cast<double>(f.y) + c.w * c.y);
       f.z = static_cast<float>(static_cast<double>(f.z) + c.w * c.z);
@@ -504,11 +530,11 @@ __global__ void __launch_bounds__(kBlock) k_pd_rhs(const float4* __restrict__ ms
   f.x += tx;  // (after the shape-matching terms, as in the reference's loop order)
   f.y += ty;
   f.z += tz;
-  const uint32_t ns = nstatic[i];
+  const uint32_t ns = R.nstatic[i];
   if (ns) {
-    float4 p = pos[i];
+    float4 p = R.pos[i];
     if (p.y < 0.0f) p.y = 0.0f;
-    statp[i] = p;
+    R.statp[i] = p;
     const float cx = kStaticW * p.x, cy = kStaticW * p.y, cz = kStaticW * p.z;
     for (uint32_t k = 0; k < ns; ++k) {
       f.x += cx;
@@ -516,7 +542,19 @@ __global__ void __launch_bounds__(kBlock) k_pd_rhs(const float4* __restrict__ ms
       f.z += cz;
     }
   }
-  rhs[i] = f;
+  return f;
+}
+PIES_DEV float4 rhs_of_node(const RhsArrays& R, uint32_t i, uint32_t sub, bool live) {
+  const float4 f = live ? R.msn[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const uint32_t b = live ? R.incPtr[i] : 0u, e = live ? R.incPtr[i + 1] : 0u;
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  rhs_gather(R, b, e, sub, ax, ay, az);
+  return rhs_finish(R, i, sub, live, f, ax, ay, az);
+}
+__global__ void __launch_bounds__(kBlock) k_pd_rhs(RhsArrays R, float4* __restrict__ rhs) {
+  const uint32_t i = (xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x) / kRhsLanes, sub = threadIdx.x & (kRhsLanes - 1);
+  const float4 f = rhs_of_node(R, i, sub, i < R.n);
+  if (i < R.n && sub == 0) rhs[i] = f;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1082,7 +1120,11 @@ uint32_t cg_update_resident_blocks(int device) {
 // Solver.cpp:367-383 (floor snap; tri/edge stabilisation is a later row) -- idempotent, applied once
 // ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_pd_stabilize(float4* __restrict__ pos, const float4* __restrict__ statp,
-                                                         const uint32_t* __restrict__ nstatic, uint32_t n) {
+                                                         const uint32_t* __restrict__ nstatic, uint32_t n, CgArrays A, int closeSolve) {
+  if (closeSolve && blockIdx.x + 1u == gridDim.x) {  // one workgroup behind the others: the statistics of the substep's last solve
+    solve_statistics(A, A.partB);
+    return;
+  }
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   if (nstatic[i]) {
@@ -1158,20 +1200,32 @@ void launch_pd_local_tet(hipStream_t st, bool volume, const float4* pos, const u
   if (volume) hipLaunchKernelGGL(k_pd_local_tet<true>, grid_for(count), dim3(kBlock), 0, st, pos, ids, q0, q1, q2, contrib, count);
   else hipLaunchKernelGGL(k_pd_local_tet<false>, grid_for(count), dim3(kBlock), 0, st, pos, ids, q0, q1, q2, contrib, count);
 }
+static RhsArrays rhs_arrays(const NodeArrays& nd, const PdArrays& pd) {
+  return RhsArrays{pd.msn, pd.contrib, pd.incPtr, pd.incSlot, pd.contribD, pd.incPtrD, pd.incSlotD, nd.pos, pd.nstatic, pd.statp,
+                   pd.cg.tIncCnt, pd.cg.tIncStart, pd.cg.tInc, pd.tContrib, nd.n};
+}
 void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd) {
   if (nd.n == 0) return;
-  hipLaunchKernelGGL(k_pd_rhs, dim3((nd.n + kBlock / kRhsLanes - 1) / (kBlock / kRhsLanes)), dim3(kBlock), 0, st, pd.msn, pd.contrib, pd.incPtr, pd.incSlot, pd.contribD, pd.incPtrD,
-                     pd.incSlotD, nd.pos, pd.nstatic, pd.statp, pd.rhs, pd.cg.tIncCnt, pd.cg.tIncStart, pd.cg.tInc, pd.tContrib, nd.n);
+  hipLaunchKernelGGL(k_pd_rhs, dim3((nd.n + kBlock / kRhsLanes - 1) / (kBlock / kRhsLanes)), dim3(kBlock), 0, st, rhs_arrays(nd, pd), pd.rhs);
 }
 void launch_pd_local_tet_pair(hipStream_t st, const float4* pos, const uint4* ids, const float4* q0, const float4* q1, const float4* q2,
                               const float4* vq2, Vec3f* contribTet, Vec3f* contribVol, uint32_t count, const TriArrays* tri,
-                              float thickness) {
+                              float thickness, bool packed, const uint16_t* dictIndex, const float4* dictTable) {
   if (count == 0) return;
   (void)contribVol;  // the pair's two contributions are added into the strain constraint's records
-  const uint32_t tetBlocks = grid_for(count).x;
   const bool withTri = tri && tri->nt;
-  hipLaunchKernelGGL(k_pd_local_tet_pair, dim3(tetBlocks + (withTri ? kTriLocalBlocks : 0u)), dim3(kBlock), 0, st, pos, ids, q0, q1, q2, vq2,
-                     contribTet, count, withTri ? *tri : TriArrays{}, thickness, tetBlocks);
+  const RestDictionary dict{dictIndex, dictTable};
+  const TriArrays T = withTri ? *tri : TriArrays{};
+  if (packed) {
+    const uint32_t tetBlocks = grid_for((count + 1u) / 2u).x;
+    const dim3 grid(tetBlocks + (withTri ? kTriLocalBlocks : 0u));
+    if (dictIndex) hipLaunchKernelGGL((k_pd_local_tet_pair<true, true>), grid, dim3(kBlock), 0, st, pos, ids, q0, q1, q2, vq2, dict, contribTet, count, T, thickness, tetBlocks);
+    else hipLaunchKernelGGL((k_pd_local_tet_pair<true, false>), grid, dim3(kBlock), 0, st, pos, ids, q0, q1, q2, vq2, dict, contribTet, count, T, thickness, tetBlocks);
+  } else {
+    const uint32_t tetBlocks = grid_for(count).x;
+    hipLaunchKernelGGL((k_pd_local_tet_pair<false, false>), dim3(tetBlocks + (withTri ? kTriLocalBlocks : 0u)), dim3(kBlock), 0, st, pos, ids, q0, q1, q2, vq2,
+                       dict, contribTet, count, T, thickness, tetBlocks);
+  }
 }
 void launch_pd_local_bend(hipStream_t st, const float4* pos, const uint4* ids, const float2* angle_w, Vec3f* contrib, uint32_t count) {
   if (count == 0) return;
@@ -1228,9 +1282,14 @@ void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, i
   A.partB = pb[maxIters & 1];
   hipLaunchKernelGGL(k_cg_finish, dim3(1), block, 0, st, A);
 }
-void launch_pd_stabilize(hipStream_t st, const NodeArrays& nd, const PdArrays& pd) {
+void launch_pd_stabilize(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, bool closeSolve, int maxIters, float tol) {
   if (nd.n == 0) return;
-  hipLaunchKernelGGL(k_pd_stabilize, grid_for(nd.n), dim3(kBlock), 0, st, nd.pos, pd.statp, pd.nstatic, nd.n);
+  CgArrays A = pd.cg;
+  A.tol2 = tol * tol;
+  float* pb[2] = {pd.cg.partB, pd.cg.partBnext};
+  A.partB = pb[maxIters & 1];  // where the last solve's final residual partials are (launch_pd_solve)
+  hipLaunchKernelGGL(k_pd_stabilize, dim3(grid_for(nd.n).x + (closeSolve ? 1u : 0u)), dim3(kBlock), 0, st, nd.pos, pd.statp, pd.nstatic, nd.n, A,
+                     closeSolve ? 1 : 0);
 }
 void launch_pd_velocity(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float h, float damping, float gravity,
                         float friction, float staticThreshold, bool staticFriction) {

@@ -155,6 +155,7 @@ struct pies_solver {
                                      // sequential passes at the end of the substep) are computed beside the local/global iterations
   hipEvent_t evFork = nullptr, evJoin = nullptr;
   bool triLevelsForked = true;
+  bool pdLocalPacked = true;    // strain + volume local step two elements per lane in packed fp32 (PIES_PD_LOCAL_PACKED=0: one per lane)
   bool pcgOverflow = true;      // a solve above the tolerance after its captured iterations goes on inside the last launch (PIES_PCG_OVERFLOW=0: off)
   bool pcgPinned = false;       // PIES_PCG_BUDGET
   uint32_t pcgPinnedBudget = 32;
@@ -164,6 +165,9 @@ struct pies_solver {
   bool releaseHinge = false;
   bool nodeCollisions = true;
   bool collideFast = true;         // every node's cell range spans at most 2 cells per axis: the parallel visiting order may run
+  uint16_t* d_pairDictIndex = nullptr;  // PD, paired elements: index of the element's set of constants (rest dictionary), or nullptr
+  float4* d_pairDictTable = nullptr;
+  uint32_t pairDictSets = 0;
   bool tetVolumePaired = false;    // PD: h_volume[k] and h_tet[k] are the same element for every k (fused local step)
   bool triangleCollisions = true;  // PD point-triangle CCD contacts (Solver.cpp:693-797); extension flag to switch off
   bool simFailed = false;

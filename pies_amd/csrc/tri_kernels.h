@@ -63,7 +63,10 @@ uint32_t launch_tri_detect(hipStream_t st, const TriArrays& T, const NodeArrays&
 // dependency levels of the contact list for the sequential passes (may run on another stream beside the local/global iterations)
 void launch_tri_levels(hipStream_t st, const TriArrays& T);
 void launch_pd_local_tri(hipStream_t st, const TriArrays& T, const float4* pos, float thickness);
-void launch_tri_stabilize(hipStream_t st, const TriArrays& T, const NodeArrays& nd, float thickness);
+// every stabilisation iteration of the substep in one launch: the passes over the contact list with the floor snap of the list's
+// nodes (nstatic / statp: launch_pd_rhs's floor targets) between them; the snap of all other nodes is launch_pd_stabilize's, once, behind it
+void launch_tri_stabilize(hipStream_t st, const TriArrays& T, const NodeArrays& nd, float thickness, const uint32_t* nstatic, const float4* statp,
+                          uint32_t iterations);
 void launch_tri_friction(hipStream_t st, const TriArrays& T, const NodeArrays& nd, float friction, float staticThreshold);
 
 }  // namespace pies

@@ -907,9 +907,15 @@ PIES_DEV void level_barrier() {
   if (kSeqWorkers > 64) lds_barrier();
   else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
+// MODE 0 runs ALL the stabilisation iterations of the substep (Solver.cpp:367-383: every iteration is a pass over the contacts
+// followed by the floor snap of every node with a floor contact): the snap of a node puts it where the right-hand side kernel
+// left its target (statp) and is idempotent, and a pass only touches the nodes of the list (usedNodes) - so the snap of those
+// nodes runs here, between the passes, and the snap of all the others once, in k_pd_stabilize behind this kernel.  (Until
+// round 3 the host launched pass and snap `iterations` times: eight launches of ~4.7 us in a substep without a single contact.)
 template <int MODE>
 __global__ void __launch_bounds__(kSeqBlock) k_tri_sequential(TriArrays T, float4* pos4, float4* prev4, float4* vel4, float thickness,
-                                                              float friction, float staticThreshold) {
+                                                              float friction, float staticThreshold, const uint32_t* __restrict__ nstatic,
+                                                              const float4* __restrict__ statp, uint32_t iterations) {
   __shared__ float4 P[kSeqLdsNodes], Q[kSeqLdsNodes];
   __shared__ uint2 sSlots[kSeqChunk];
   __shared__ uint32_t sLv[kTriMaxLevels + 1];
@@ -919,9 +925,10 @@ __global__ void __launch_bounds__(kSeqBlock) k_tri_sequential(TriArrays T, float
   const int tid = threadIdx.x;
   const uint32_t M = T.counters[2];
   if (M == 0) return;
-  const uint32_t form = T.counters[7];
+  const uint32_t form = T.counters[7], used = T.counters[4];
+  const bool snap = MODE == 0 && nstatic != nullptr;
   if (form == 0) {
-    const uint32_t used = T.counters[4], levels = T.counters[6];
+    const uint32_t levels = T.counters[6];
     float4* second4 = MODE == 0 ? prev4 : vel4;
     for (uint32_t u = tid; u < used; u += kSeqBlock) {
       const uint32_t n = T.usedNodes[u];
@@ -932,24 +939,38 @@ __global__ void __launch_bounds__(kSeqBlock) k_tri_sequential(TriArrays T, float
     __syncthreads();
     if (tid >= kSeqWorkers) return;  // (a wavefront that has ended no longer counts at the barrier)
     uint32_t k0 = 0, kEnd = 0;
-    for (uint32_t lv = 0; lv < levels; ++lv) {
-      const uint32_t lo = sLv[lv], hi = sLv[lv + 1];
-      uint32_t seg = lo;
-      while (seg < hi) {
-        if (min(hi, seg + kSeqChunk) > kEnd) {  // stage the node slots of the next kSeqChunk contacts
-          k0 = seg;
-          kEnd = min(M, seg + kSeqChunk);
-          for (uint32_t q = k0 + tid; q < kEnd; q += kSeqWorkers) sSlots[q - k0] = T.lvSlots[q];
+    for (uint32_t it = 0; it < iterations; ++it) {
+      if (M > kSeqChunk) k0 = kEnd = 0;  // (a list that fits one chunk stays staged)
+      for (uint32_t lv = 0; lv < levels; ++lv) {
+        const uint32_t lo = sLv[lv], hi = sLv[lv + 1];
+        uint32_t seg = lo;
+        while (seg < hi) {
+          if (min(hi, seg + kSeqChunk) > kEnd) {  // stage the node slots of the next kSeqChunk contacts
+            k0 = seg;
+            kEnd = min(M, seg + kSeqChunk);
+            for (uint32_t q = k0 + tid; q < kEnd; q += kSeqWorkers) sSlots[q - k0] = T.lvSlots[q];
+            level_barrier();
+          }
+          const uint32_t segEnd = min(hi, kEnd);
+          for (uint32_t q = seg + tid; q < segEnd; q += kSeqWorkers) {
+            const uint2 sl = sSlots[q - k0];
+            LdsNodes io = {{sl.x & 0xffffu, sl.x >> 16, sl.y & 0xffffu, sl.y >> 16}, P, Q};
+            tri_contact_step<MODE>(io, thickness, friction, staticThreshold);
+          }
           level_barrier();
+          seg = segEnd;
         }
-        const uint32_t segEnd = min(hi, kEnd);
-        for (uint32_t q = seg + tid; q < segEnd; q += kSeqWorkers) {
-          const uint2 sl = sSlots[q - k0];
-          LdsNodes io = {{sl.x & 0xffffu, sl.x >> 16, sl.y & 0xffffu, sl.y >> 16}, P, Q};
-          tri_contact_step<MODE>(io, thickness, friction, staticThreshold);
+      }
+      if (snap) {
+        for (uint32_t u = tid; u < used; u += kSeqWorkers) {
+          const uint32_t n = T.usedNodes[u];
+          if (nstatic[n]) {
+            const float4 sp = statp[n];
+            float4& d = P[u];
+            d.x = sp.x; d.y = sp.y; d.z = sp.z;
+          }
         }
         level_barrier();
-        seg = segEnd;
       }
     }
     for (uint32_t u = tid; u < used; u += kSeqWorkers) {
@@ -961,25 +982,44 @@ __global__ void __launch_bounds__(kSeqBlock) k_tri_sequential(TriArrays T, float
   }
   if (form == 1) {  // too many levels: one wavefront walks the list window by window
     if (tid >= 64) return;
-    for (uint32_t base = 0; base < M; base += 64) {
-      const bool valid = base + tid < M;
-      const uint4 id = valid ? T.ids[base + tid] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-      int maxLevel;
-      const int level = window_levels(valid, id, tid, maxLevel);
-      for (int lv = 0; lv <= maxLevel; ++lv) {
-        if (valid && level == lv) tri_contact_step<MODE>(id, pos, prev, vel, thickness, friction, staticThreshold);
+    for (uint32_t it = 0; it < iterations; ++it) {
+      for (uint32_t base = 0; base < M; base += 64) {
+        const bool valid = base + tid < M;
+        const uint4 id = valid ? T.ids[base + tid] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+        int maxLevel;
+        const int level = window_levels(valid, id, tid, maxLevel);
+        for (int lv = 0; lv <= maxLevel; ++lv) {
+          if (valid && level == lv) tri_contact_step<MODE>(id, pos, prev, vel, thickness, friction, staticThreshold);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+      if (snap) {
+        for (uint32_t u = tid; u < used; u += 64) {
+          const uint32_t n = T.usedNodes[u];
+          if (nstatic[n]) { const float4 sp = statp[n]; st3(pos, n, F3{sp.x, sp.y, sp.z}); }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     }
     return;
   }
   const uint32_t levels = T.counters[6];
-  for (uint32_t lv = 0; lv < levels; ++lv) {
-    const uint32_t lo = T.lvStart[lv], hi = T.lvStart[lv + 1];
-    for (uint32_t k = lo + tid; k < hi; k += kSeqBlock)
-      tri_contact_step<MODE>(T.ids[T.lvOrder[k]], pos, prev, vel, thickness, friction, staticThreshold);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  for (uint32_t it = 0; it < iterations; ++it) {
+    for (uint32_t lv = 0; lv < levels; ++lv) {
+      const uint32_t lo = T.lvStart[lv], hi = T.lvStart[lv + 1];
+      for (uint32_t k = lo + tid; k < hi; k += kSeqBlock)
+        tri_contact_step<MODE>(T.ids[T.lvOrder[k]], pos, prev, vel, thickness, friction, staticThreshold);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    if (snap) {
+      for (uint32_t u = tid; u < used; u += kSeqBlock) {
+        const uint32_t n = T.usedNodes[u];
+        if (nstatic[n]) { const float4 sp = statp[n]; st3(pos, n, F3{sp.x, sp.y, sp.z}); }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   }
 }
 
@@ -1021,13 +1061,15 @@ void launch_pd_local_tri(hipStream_t st_, const TriArrays& T, const float4* pos,
   const dim3 cgrid(std::min<uint32_t>(256u, (T.maxContacts + kBlock - 1) / kBlock));
   hipLaunchKernelGGL(k_pd_local_tri, cgrid, dim3(kBlock), 0, st_, T, pos, thickness);
 }
-void launch_tri_stabilize(hipStream_t st_, const TriArrays& T, const NodeArrays& nd, float thickness) {
-  if (T.nt == 0) return;
-  hipLaunchKernelGGL(k_tri_sequential<0>, dim3(1), dim3(kSeqBlock), 0, st_, T, nd.pos, nd.prev, nd.vel, thickness, 0.0f, 0.0f);
+void launch_tri_stabilize(hipStream_t st_, const TriArrays& T, const NodeArrays& nd, float thickness, const uint32_t* nstatic, const float4* statp,
+                          uint32_t iterations) {
+  if (T.nt == 0 || iterations == 0) return;
+  hipLaunchKernelGGL(k_tri_sequential<0>, dim3(1), dim3(kSeqBlock), 0, st_, T, nd.pos, nd.prev, nd.vel, thickness, 0.0f, 0.0f, nstatic, statp, iterations);
 }
 void launch_tri_friction(hipStream_t st_, const TriArrays& T, const NodeArrays& nd, float friction, float staticThreshold) {
   if (T.nt == 0) return;
-  hipLaunchKernelGGL(k_tri_sequential<1>, dim3(1), dim3(kSeqBlock), 0, st_, T, nd.pos, nd.prev, nd.vel, 0.0f, friction, staticThreshold);
+  hipLaunchKernelGGL(k_tri_sequential<1>, dim3(1), dim3(kSeqBlock), 0, st_, T, nd.pos, nd.prev, nd.vel, 0.0f, friction, staticThreshold,
+                     static_cast<const uint32_t*>(nullptr), static_cast<const float4*>(nullptr), 1u);
 }
 
 }  // namespace pies

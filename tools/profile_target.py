@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The program tools/profile_round.sh puts under rocprofv3: N ticks of one of bench.py's workloads, whole substeps
-(every kernel in its place), nothing else.  usage: profile_target.py config2|config3|config4|contacts|pdcontacts|pbd1m|pd1m N"""
+(every kernel in its place), nothing else.  usage: profile_target.py config2|config3|config4|contacts|pdcontacts|pbd1m|pd1m N [NAME=VALUE ...]"""
 import os
 import sys
 
@@ -12,6 +12,9 @@ import scenes  # noqa: E402
 from pies_amd import capi  # noqa: E402
 
 what, n = sys.argv[1], int(sys.argv[2])
+for kv in sys.argv[3:]:  # further arguments: NAME=VALUE tunings (pies_set_tuning), e.g. PIES_PD_FUSE_RHS=0
+    name, _, value = kv.partition("=")
+    capi.set_tuning(name, value)
 if what in ("contacts", "pdcontacts"):
     # PIES_PROFILER_SAFE freezes the graph variant as well: take the one bench.py's loop runs these scenes in (contact rows
     # summed by the extra blocks of k_cg_ap, level kernel on the second stream)
