@@ -488,9 +488,10 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
     // idempotent, so once is what the reference's `iterations` times come to
     launch_tri_stabilize(st, pd.tri, s->nd, s->opt.collisionThickness, pd.nstatic, pd.statp, s->opt.collisionStabilizationIterations);
     if (s->opt.collisionStabilizationIterations > 0) launch_pd_stabilize(st, s->nd, pd, statsInStabilize, (int)s->pcgBudget, s->pcgTol);
-    launch_pd_velocity(st, s->nd, pd, h, s->opt.damping, s->opt.gravity, s->opt.friction, s->opt.staticFrictionThreshold, false);
-    launch_tri_friction(st, pd.tri, s->nd, s->opt.friction, s->opt.staticFrictionThreshold);               // :431-471
-    launch_pd_static_friction(st, s->nd, pd, s->opt.friction, s->opt.staticFrictionThreshold);             // :473-484
+    // velocities, then the contacts' friction (:431-471), then the floor friction (:473-484).  The floor friction of a node that is
+    // in no contact does not wait for the contacts: the velocity kernel applies it; the contacts' pass ends with that of its own nodes
+    launch_pd_velocity(st, s->nd, pd, h, s->opt.damping, s->opt.gravity, s->opt.friction, s->opt.staticFrictionThreshold, false, pd.tri.usedBits);
+    launch_tri_friction(st, pd.tri, s->nd, s->opt.friction, s->opt.staticFrictionThreshold, pd.nstatic);
   } else {
     if (only < 0 && s->opt.collisionStabilizationIterations > 0) launch_pd_stabilize(st, s->nd, pd, statsInStabilize, (int)s->pcgBudget, s->pcgTol);  // the floor snap is idempotent
     if (ON(PIES_KERNEL_PD_VELOCITY)) {

@@ -112,7 +112,8 @@ void launch_pd_stabilize(hipStream_t st, const NodeArrays& nd, const PdArrays& p
 // staticFriction = false leaves the floor friction (Solver.cpp:473-484) to launch_pd_static_friction, which the
 // reference runs after the point-triangle friction
 void launch_pd_velocity(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float h, float damping, float gravity,
-                        float friction, float staticThreshold, bool staticFriction);
+                        float friction, float staticThreshold, bool staticFriction, const uint32_t* usedBits = nullptr);
+// usedBits (the point-triangle pipeline's bitmap of nodes in contacts): floor friction for the nodes outside it only
 void launch_pd_static_friction(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float friction, float staticThreshold);
 
 // workgroups of k_cg_update the device holds at once (0: unknown); the CG kernels' grid stays below it, see grid_barrier

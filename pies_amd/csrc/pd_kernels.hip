@@ -452,6 +452,7 @@ struct RhsArrays {
   float4* statp;
   const uint32_t *tIncCnt, *tIncStart, *tInc;
   const float4* tContrib;
+  const uint32_t* tUsedCount;  // nodes in contacts this substep (device word; 0: nobody reads tIncCnt)
   uint32_t n;
 };
 // The right-hand side of node i, by the kRhsLanes lanes that share it (`sub` = the lane's place among them; every lane of the
@@ -491,7 +492,7 @@ PIES_DEV float4 rhs_finish(const RhsArrays& R, uint32_t i, uint32_t sub, bool li
   f.y += ay;
   f.z += az;
   float tx = 0.f, ty = 0.f, tz = 0.f;
-  if (R.tIncCnt) {  // point-triangle contacts (Solver.cpp:337-340): a node of a contact patch takes part in tens of contacts; the
+  if (R.tIncCnt && *R.tUsedCount != 0u) {  // point-triangle contacts (Solver.cpp:337-340): a node of a contact patch takes part in tens of contacts; the
     // team's lanes add its records like the ones above (four in flight per lane, partial sums combined pairwise) - one lane
     // walking the list made this launch 55 us with 29k contacts (2 dependent loads per record), the rest of it takes 10
     const uint32_t tc = live ? R.tIncCnt[i] : 0u;
@@ -621,7 +622,7 @@ PIES_DEV bool all_converged(const float rr[3], const float bb[3], float tol2) {
 // the vectors - three dependent trips per batch instead of per contact: a node of a contact patch sits in tens of
 // contacts, and one lane walking them one by one made the SpMV ten times slower than without contacts).
 template <class Fetch> PIES_DEV void contact_row(const CgArrays& A, uint32_t i, Fetch fetch, float& sx, float& sy, float& sz) {
-  if (!A.tIncCnt) return;
+  if (!A.tIncCnt || *A.tUsedCount == 0u) return;  // (no contact in this substep: one uniform word instead of a load per row)
   const uint32_t tc = A.tIncCnt[i];
   if (!tc) return;
   if (A.useCAp && A.rowLen) {  // the merged row of this substep exists (contact-heavy variant; reached from the CG continuation)
@@ -813,7 +814,7 @@ __global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __
     row_combine<LPR>(sx, sy, sz);
     if (i < A.n && lane % LPR == 0u) {
       if (A.useCAp) {
-        if (A.tIncCnt[i]) {
+        if (*A.tUsedCount != 0u && A.tIncCnt[i]) {
           const float4 c = A.cAp[i]; sx += c.x; sy += c.y; sz += c.z;
         }
       } else {
@@ -981,7 +982,7 @@ PIES_DEV void cg_update_rows(const CgArrays& A, float4* __restrict__ x, int k, c
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < A.n; i += gridDim.x * kBlock) {
     const float4 pi = p[i];
     float4 api = A.ap[i];
-    if (addCAp && A.tIncCnt[i]) {
+    if (addCAp && *A.tUsedCount != 0u && A.tIncCnt[i]) {
       const float4 c = A.cAp[i];
       api.x += c.x; api.y += c.y; api.z += c.z;
     }
@@ -1141,9 +1142,12 @@ __global__ void __launch_bounds__(kBlock) k_pd_stabilize(float4* __restrict__ po
 __global__ void __launch_bounds__(kBlock) k_pd_velocity(const float4* __restrict__ pos, float4* __restrict__ prev,
                                                         float4* __restrict__ vel, const uint32_t* __restrict__ nstatic, uint32_t n,
                                                         float h, float damping, float gravity, float friction,
-                                                        float staticThreshold, bool staticFriction) {
+                                                        float staticThreshold, bool staticFriction, const uint32_t* __restrict__ usedBits) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
+  // usedBits: the floor friction of the nodes that are in a point-triangle contact comes after the contacts' friction
+  // (launch_tri_friction applies it); every other node gets it here
+  if (usedBits) staticFriction = ((usedBits[i >> 5] >> (i & 31u)) & 1u) == 0u;
   const float4 p = pos[i];
   const float4 q = prev[i];
   const float k = 1.0f - damping;
@@ -1202,7 +1206,7 @@ void launch_pd_local_tet(hipStream_t st, bool volume, const float4* pos, const u
 }
 static RhsArrays rhs_arrays(const NodeArrays& nd, const PdArrays& pd) {
   return RhsArrays{pd.msn, pd.contrib, pd.incPtr, pd.incSlot, pd.contribD, pd.incPtrD, pd.incSlotD, nd.pos, pd.nstatic, pd.statp,
-                   pd.cg.tIncCnt, pd.cg.tIncStart, pd.cg.tInc, pd.tContrib, nd.n};
+                   pd.cg.tIncCnt, pd.cg.tIncStart, pd.cg.tInc, pd.tContrib, pd.cg.tUsedCount, nd.n};
 }
 void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd) {
   if (nd.n == 0) return;
@@ -1292,10 +1296,10 @@ void launch_pd_stabilize(hipStream_t st, const NodeArrays& nd, const PdArrays& p
                      closeSolve ? 1 : 0);
 }
 void launch_pd_velocity(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float h, float damping, float gravity,
-                        float friction, float staticThreshold, bool staticFriction) {
+                        float friction, float staticThreshold, bool staticFriction, const uint32_t* usedBits) {
   if (nd.n == 0) return;
   hipLaunchKernelGGL(k_pd_velocity, grid_for(nd.n), dim3(kBlock), 0, st, nd.pos, nd.prev, nd.vel, pd.nstatic, nd.n, h, damping, gravity,
-                     friction, staticThreshold, staticFriction);
+                     friction, staticThreshold, staticFriction, usedBits);
 }
 void launch_pd_static_friction(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float friction, float staticThreshold) {
   if (nd.n == 0) return;

@@ -272,6 +272,7 @@ int pd_build(pies_solver* s) {
     if (int rc = dev_alloc(s, 16, &T.counters, true)) return rc;
     if (int rc = dev_alloc(s, static_cast<size_t>(kTriMaxEntries) * nt, &T.triSlot, true)) return rc;
     if (int rc = dev_alloc(s, nt, &T.rng, true)) return rc;
+    if (int rc = dev_alloc(s, 3ull * nt, &T.box, true)) return rc;
     if (int rc = dev_alloc(s, static_cast<size_t>(T.maxEntries), &T.bucket, true)) return rc;
     if (int rc = dev_alloc(s, static_cast<size_t>(T.maxEntries), &T.bucketSorted, true)) return rc;
     if (int rc = dev_alloc(s, nt, &T.cntTri, true)) return rc;

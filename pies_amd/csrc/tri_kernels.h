@@ -30,6 +30,8 @@ struct TriArrays {
                        // touched nodes, 2 through L2, 1 more than kTriMaxLevels levels (single-wavefront walk)
   uint32_t* triSlot;   // nt x kTriMaxEntries
   int4* rng;           // per triangle: min cell, packed lengths
+  float4* box;         // 3 per triangle (k_tri_count): {box min of its six corner positions, regular ? 1 : 0}, {box max, bits(node 0)},
+                       // {bits(node 1), bits(node 2), -, -}: what the detection's reject test needs of a candidate, in one place
   uint32_t *bucket, *bucketSorted;
   uint32_t maxEntries;  // (cell, triangle) entries reserved in bucket / bucketSorted
   // contacts of the current substep, in the reference's list order
@@ -67,6 +69,8 @@ void launch_pd_local_tri(hipStream_t st, const TriArrays& T, const float4* pos, 
 // nodes (nstatic / statp: launch_pd_rhs's floor targets) between them; the snap of all other nodes is launch_pd_stabilize's, once, behind it
 void launch_tri_stabilize(hipStream_t st, const TriArrays& T, const NodeArrays& nd, float thickness, const uint32_t* nstatic, const float4* statp,
                           uint32_t iterations);
-void launch_tri_friction(hipStream_t st, const TriArrays& T, const NodeArrays& nd, float friction, float staticThreshold);
+// nstatic != nullptr: the pass ends with the floor friction (Solver.cpp:473-484) of the nodes of the contact list; the other nodes
+// got theirs in launch_pd_velocity (usedBits)
+void launch_tri_friction(hipStream_t st, const TriArrays& T, const NodeArrays& nd, float friction, float staticThreshold, const uint32_t* nstatic = nullptr);
 
 }  // namespace pies

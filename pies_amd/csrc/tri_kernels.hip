@@ -161,7 +161,10 @@ __global__ void k_tri_zero(TriArrays T) {
   if (t < 9 && t != 3) T.counters[t] = 0;  // [3] is the sticky failure flag
 }
 
-// TriCompRange / sweptTriRange: floor(min), ceil(max) - floor(min) over position and prevPosition, world units
+// TriCompRange / sweptTriRange: floor(min), ceil(max) - floor(min) over position and prevPosition, world units.
+// One lane per triangle walks the cells of its range.  (A lane per CELL - kTriTeam lanes per triangle, as k_tri_fill and
+// k_tri_detect have it - made this kernel 60 us slower on a moving 100k-particle beam: all insertions of neighbouring
+// triangles then hit the same index lines and the cell counter at once.)
 __global__ void __launch_bounds__(kBlock) k_tri_count(TriArrays T, const float4* __restrict__ pos, const float4* __restrict__ prev) {
   const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= T.nt) return;
@@ -192,6 +195,16 @@ __global__ void __launch_bounds__(kBlock) k_tri_count(TriArrays T, const float4*
   if (!ok || len[0] > kTriInsertMaxCells || len[1] > kTriInsertMaxCells || len[2] > kTriInsertMaxCells)
     len[0] = len[1] = len[2] = 0;  // the reference returns an empty range (Solver.cpp:974-976)
   T.rng[t] = make_int4(m[0], m[1], m[2], static_cast<int>(len[0] | (len[1] << 8) | (len[2] << 16)));
+  {  // the candidate record of this triangle for k_tri_detect: box of its six corner positions, "both normals are non-zero", node ids
+    const uint32_t i0 = T.tris[3 * t], i1 = T.tris[3 * t + 1], i2 = T.tris[3 * t + 2];
+    const F3 b1 = xyz(pos[i0]), c1 = xyz(pos[i1]), d1 = xyz(pos[i2]);
+    const F3 b0 = xyz(prev[i0]), c0 = xyz(prev[i1]), d0 = xyz(prev[i2]);
+    const F3 nn0 = cross(c0 - b0, d0 - b0), nn1 = cross(c1 - b1, d1 - b1);
+    const bool regular = dot(nn0, nn0) > 0.0f && dot(nn1, nn1) > 0.0f;
+    T.box[3 * t] = make_float4(mn[0], mn[1], mn[2], regular ? 1.0f : 0.0f);
+    T.box[3 * t + 1] = make_float4(mx[0], mx[1], mx[2], __uint_as_float(i0));
+    T.box[3 * t + 2] = make_float4(__uint_as_float(i1), __uint_as_float(i2), 0.0f, 0.0f);
+  }
   uint32_t e = 0;
   for (uint32_t dx = 0; dx < len[0]; ++dx)
     for (uint32_t dy = 0; dy < len[1]; ++dy)
@@ -219,21 +232,23 @@ __global__ void __launch_bounds__(kBlock) k_tri_alloc(TriArrays T) {
     T.fill[s] = 0;
   }
 }
-__global__ void __launch_bounds__(kBlock) k_tri_fill(TriArrays T) {
-  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+__global__ void __launch_bounds__(kBlock) k_tri_fill(TriArrays T) {  // kTriTeam lanes per triangle, like k_tri_count
+  const uint32_t t = (blockIdx.x * kBlock + threadIdx.x) / kTriTeam, member = threadIdx.x % kTriTeam;
   if (t >= T.nt) return;
   const int4 rg = T.rng[t];
   const uint32_t lx = rg.w & 0xff, ly = (rg.w >> 8) & 0xff, lz = (rg.w >> 16) & 0xff;
-  uint32_t e = 0;
-  for (uint32_t dx = 0; dx < lx; ++dx)
-    for (uint32_t dy = 0; dy < ly; ++dy)
-      for (uint32_t dz = 0; dz < lz; ++dz, ++e) {
-        const uint32_t s = e < kTriMaxEntries ? T.triSlot[t * kTriMaxEntries + e]
-                                              : find_cell(T.keys, T.mask, pack_cell(rg.x + (int)dx, rg.y + (int)dy, rg.z + (int)dz));
-        if (s == 0xffffffffu) continue;
-        const uint32_t k = atomicAdd(&T.fill[s], 1u);
-        if (k < T.cnt[s]) T.bucket[T.start[s] + k] = t;  // cnt was zeroed for a bucket beyond the reserved storage
-      }
+  const uint32_t ncell = lx * ly * lz, lyz = ly * lz;
+  for (uint32_t e = member; e < ncell; e += kTriTeam) {
+    uint32_t s;
+    if (e < kTriMaxEntries) s = T.triSlot[t * kTriMaxEntries + e];
+    else {
+      const uint32_t dx = e / lyz, r = e - dx * lyz, dy = r / lz, dz = r - dy * lz;
+      s = find_cell(T.keys, T.mask, pack_cell(rg.x + (int)dx, rg.y + (int)dy, rg.z + (int)dz));
+    }
+    if (s == 0xffffffffu) continue;
+    const uint32_t k = atomicAdd(&T.fill[s], 1u);
+    if (k < T.cnt[s]) T.bucket[T.start[s] + k] = t;  // cnt was zeroed for a bucket beyond the reserved storage
+  }
 }
 __global__ void __launch_bounds__(kBlock) k_tri_sort(TriArrays T) {
   if (T.counters[3]) return;
@@ -253,9 +268,14 @@ PIES_DEV uint32_t merge_rank(uint32_t t, uint32_t nt, uint32_t threads) {
   return th * q + min(th, rem) + t / threads;
 }
 
-// ---- detection (Solver.cpp:714-797).  TEAM lanes share a triangle's bucket entries.  FILL = false counts its contacts
-// (the count does not depend on the order); FILL = true writes them in the reference's order (a prefix sum over the
-// team's lanes per TEAM entries), only for the triangles that have any. ------------------------------------------
+// ---- detection (Solver.cpp:714-797).  TEAM lanes share a triangle's candidates.  FILL = false counts its contacts (the
+// count does not depend on the order); FILL = true writes them in the reference's order (a prefix sum over the team's lanes
+// per TEAM candidates), only for the triangles that have any.
+// The reference walks the cells of the triangle's range one after the other and each cell's bucket entry by entry.  Here
+// the team looks up TEAM cells at once (a lane per cell: its slot - cached by k_tri_count - and the bucket's start and
+// length), forms the running offsets of the TEAM buckets and then walks their entries as ONE list, TEAM at a time - the same
+// candidates in the same order, but a round of dependent loads (slot, bucket, entry, triangle, nodes) per TEAM cells instead
+// of per cell: a moving triangle spans 18-27 cells, and one cell at a time made this kernel 60 us of a 640 us substep. -----
 template <bool FILL, int TEAM>
 __global__ void __launch_bounds__(kBlock) k_tri_detect(TriArrays T, const float4* __restrict__ pos, const float4* __restrict__ prev,
                                                        float threshold) {
@@ -272,74 +292,127 @@ __global__ void __launch_bounds__(kBlock) k_tri_detect(TriArrays T, const float4
   if (lx > kTriSearchMaxCells || ly > kTriSearchMaxCells || lz > kTriSearchMaxCells) lx = ly = lz = 0;  // sweptTriRange: empty (Solver.cpp:672-674)
   uint32_t count = 0, nonEmpty = 0;
   const uint32_t base = FILL ? T.offTri[rank] : 0u;
-  for (uint32_t dx = 0; dx < lx; ++dx)
-    for (uint32_t dy = 0; dy < ly; ++dy)
-      for (uint32_t dz = 0; dz < lz; ++dz) {
-        const uint32_t s = find_cell(T.keys, T.mask, pack_cell(rg.x + (int)dx, rg.y + (int)dy, rg.z + (int)dz));
-        if (s == 0xffffffffu) continue;
-        if (!FILL && ++nonEmpty > 1000u) atomicOr(&T.counters[3], 16u);  // Solver.cpp:741-745: more than 1000 buckets in a range fails the sim
-        const uint32_t bs = T.start[s], bc = T.cnt[s];
-        for (uint32_t k0 = 0; k0 < bc; k0 += TEAM) {  // (bc is the team's: its lanes stay together)
-          const uint32_t k = k0 + member;
-          bool hit[3] = {false, false, false};
-          uint32_t ib = 0, ic = 0, idd = 0;
-          if (k < bc) {
-            const uint32_t o = T.bucketSorted[bs + k];
-            ib = T.tris[3 * o]; ic = T.tris[3 * o + 1]; idd = T.tris[3 * o + 2];
-            bool common = false;
+  const uint32_t ncell = lx * ly * lz, lyz = ly * lz;
+  for (uint32_t e0 = 0; e0 < ncell; e0 += TEAM) {
+    // this lane's cell of the round: slot, bucket start and length
+    const uint32_t e = e0 + member;
+    uint32_t bs = 0, bc = 0;
+    bool found = false;
+    if (e < ncell) {
+      uint32_t s;
+      if (e < kTriMaxEntries) s = T.triSlot[t * kTriMaxEntries + e];  // (the search range is the range the triangle was inserted with)
+      else {
+        const uint32_t dx = e / lyz, r = e - dx * lyz, dy = r / lz, dz = r - dy * lz;
+        s = find_cell(T.keys, T.mask, pack_cell(rg.x + (int)dx, rg.y + (int)dy, rg.z + (int)dz));
+      }
+      if (s != 0xffffffffu) { found = true; bs = T.start[s]; bc = T.cnt[s]; }
+    }
+    if (!FILL) {  // Solver.cpp:741-745: more than 1000 buckets in a range fails the sim
+      uint32_t f = found ? 1u : 0u;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) common = common || ia[i] == ib || ia[i] == ic || ia[i] == idd;
-            if (!common) {
-              const F3 b1 = xyz(pos[ib]), c1 = xyz(pos[ic]), d1 = xyz(pos[idd]);
-              const F3 b0 = xyz(prev[ib]), c0 = xyz(prev[ic]), d0 = xyz(prev[idd]);
-              // Conservative reject before the CCD.  A hit puts the point, at some time in [0,1], within `threshold` of a
-              // point of the moving triangle (proximity branch: at t = 1; crossing branch: on it at the root), so the
-              // point's swept segment must meet the box of the triangle's six corner positions grown by the threshold;
-              // the margin adds 5 % and 1e-3 of the box on top of that, orders of magnitude above the rounding of the
-              // barycentric test.  A triangle with a vanishing normal (NaN inside the CCD, which then cannot say
-              // "outside") is never rejected here, nor is anything non-finite: every comparison below is false for NaN.
-              const F3 nn0 = cross(c0 - b0, d0 - b0), nn1 = cross(c1 - b1, d1 - b1);
-              const bool regular = dot(nn0, nn0) > 0.0f && dot(nn1, nn1) > 0.0f;
-              const F3 lo = {fminf(fminf(fminf(b0.x, c0.x), fminf(d0.x, b1.x)), fminf(c1.x, d1.x)),
-                             fminf(fminf(fminf(b0.y, c0.y), fminf(d0.y, b1.y)), fminf(c1.y, d1.y)),
-                             fminf(fminf(fminf(b0.z, c0.z), fminf(d0.z, b1.z)), fminf(c1.z, d1.z))};
-              const F3 hi = {fmaxf(fmaxf(fmaxf(b0.x, c0.x), fmaxf(d0.x, b1.x)), fmaxf(c1.x, d1.x)),
-                             fmaxf(fmaxf(fmaxf(b0.y, c0.y), fmaxf(d0.y, b1.y)), fmaxf(c1.y, d1.y)),
-                             fmaxf(fmaxf(fmaxf(b0.z, c0.z), fmaxf(d0.z, b1.z)), fmaxf(c1.z, d1.z))};
-              const float margin = 1.05f * threshold + 1.0e-3f * fmaxf(fmaxf(hi.x - lo.x, hi.y - lo.y), hi.z - lo.z);
+      for (int off = TEAM / 2; off >= 1; off >>= 1) f += __shfl_xor(f, off, TEAM);
+      nonEmpty += f;
+      if (nonEmpty > 1000u && member == 0) atomicOr(&T.counters[3], 16u);
+    }
+    // offsets of the round's buckets in the round's candidate list
+    uint32_t incl = bc;
 #pragma unroll
-              for (int i = 0; i < 3; ++i) {
-                const bool apart = (fmaxf(a0[i].x, a1[i].x) < lo.x - margin) || (fminf(a0[i].x, a1[i].x) > hi.x + margin) ||
-                                   (fmaxf(a0[i].y, a1[i].y) < lo.y - margin) || (fminf(a0[i].y, a1[i].y) > hi.y + margin) ||
-                                   (fmaxf(a0[i].z, a1[i].z) < lo.z - margin) || (fminf(a0[i].z, a1[i].z) > hi.z + margin);
-                if (regular && apart) continue;
-                hit[i] = point_triangle_ccd(a0[i] - b0, c0 - b0, d0 - b0, a1[i] - b1, c1 - b1, d1 - b1, threshold);
-              }
-            }
+    for (int off = 1; off < TEAM; off <<= 1) {
+      const uint32_t below = __shfl_up(incl, off, TEAM);
+      if (static_cast<int>(member) >= off) incl += below;
+    }
+    const uint32_t pre = incl - bc, total = __shfl(incl, TEAM - 1, TEAM);
+    for (uint32_t k0 = 0; k0 < total; k0 += TEAM) {  // (total is the team's: its lanes stay together)
+      const uint32_t k = k0 + member;
+      // where candidate k sits in bucketSorted: its bucket is the last one of the round whose offset is <= k (empty buckets
+      // share their offset with the next one, so "the last" is never one of them): a binary search over the team's lanes
+      // (every lane takes part in every shuffle - a lane past the end of the list searches too and drops the result)
+      uint32_t l = 0;
+#pragma unroll
+      for (int step = TEAM / 2; step >= 1; step >>= 1) {
+        const uint32_t pm = __shfl(pre, static_cast<int>(l) + step, TEAM);
+        if (pm <= k) l += static_cast<uint32_t>(step);
+      }
+      const uint32_t sl = __shfl(bs, static_cast<int>(l), TEAM), pl = __shfl(pre, static_cast<int>(l), TEAM);
+      const uint32_t at = k < total ? sl + (k - pl) : 0xffffffffu;
+      bool hit[3] = {false, false, false};
+      uint32_t ib = 0, ic = 0, idd = 0;
+      uint32_t times = 1;  // counting pass: in how many cells the two triangles meet
+      bool visit = at != 0xffffffffu;
+      if (!FILL && visit) {
+        // The reference tests a candidate once per cell both triangles were inserted into (every hit is listed that often).
+        // The test gives the same answer every time, so the counting pass takes the pair in ONE of those cells - the minimum
+        // corner of what the two ranges share - and multiplies; the other visits end at the candidate's range.  (A moving
+        // triangle of a 100k-particle beam meets ~700 candidates of which ~60 are distinct.)
+        const uint32_t o = T.bucketSorted[at];
+        const int4 ro = T.rng[o];
+        const uint32_t e = e0 + l, dx = e / lyz, r = e - dx * lyz, dy = r / lz, dz = r - dy * lz;
+        const int cx = rg.x + static_cast<int>(dx), cy = rg.y + static_cast<int>(dy), cz = rg.z + static_cast<int>(dz);
+        visit = cx == max(rg.x, ro.x) && cy == max(rg.y, ro.y) && cz == max(rg.z, ro.z);
+        const int ox = min(rg.x + static_cast<int>(lx), ro.x + (ro.w & 0xff)) - max(rg.x, ro.x);
+        const int oy = min(rg.y + static_cast<int>(ly), ro.y + ((ro.w >> 8) & 0xff)) - max(rg.y, ro.y);
+        const int oz = min(rg.z + static_cast<int>(lz), ro.z + ((ro.w >> 16) & 0xff)) - max(rg.z, ro.z);
+        times = static_cast<uint32_t>(ox * oy * oz);
+      }
+      if (visit) {
+        const uint32_t o = T.bucketSorted[at];
+        const float4 r0 = T.box[3 * o], r1 = T.box[3 * o + 1], r2 = T.box[3 * o + 2];  // k_tri_count's record of the candidate
+        ib = __float_as_uint(r1.w); ic = __float_as_uint(r2.x); idd = __float_as_uint(r2.y);
+        bool common = false;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) common = common || ia[i] == ib || ia[i] == ic || ia[i] == idd;
+        if (!common) {
+          // Conservative reject before the CCD.  A hit puts the point, at some time in [0,1], within `threshold` of a
+          // point of the moving triangle (proximity branch: at t = 1; crossing branch: on it at the root), so the
+          // point's swept segment must meet the box of the triangle's six corner positions grown by the threshold;
+          // the margin adds 5 % and 1e-3 of the box on top of that, orders of magnitude above the rounding of the
+          // barycentric test.  A triangle with a vanishing normal (NaN inside the CCD, which then cannot say
+          // "outside") is never rejected here, nor is anything non-finite: every comparison below is false for NaN.
+          // Box and normals come with the candidate's record: its six corner positions are only fetched for a point that
+          // is not rejected (until round 3 every candidate cost six gathers: 47 of this kernel's 60 us).
+          const bool regular = r0.w != 0.0f;
+          const F3 lo = {r0.x, r0.y, r0.z}, hi = {r1.x, r1.y, r1.z};
+          const float margin = 1.05f * threshold + 1.0e-3f * fmaxf(fmaxf(hi.x - lo.x, hi.y - lo.y), hi.z - lo.z);
+          bool test[3];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const bool apart = (fmaxf(a0[i].x, a1[i].x) < lo.x - margin) || (fminf(a0[i].x, a1[i].x) > hi.x + margin) ||
+                               (fmaxf(a0[i].y, a1[i].y) < lo.y - margin) || (fminf(a0[i].y, a1[i].y) > hi.y + margin) ||
+                               (fmaxf(a0[i].z, a1[i].z) < lo.z - margin) || (fminf(a0[i].z, a1[i].z) > hi.z + margin);
+            test[i] = !(regular && apart);
           }
-          const uint32_t mine = (hit[0] ? 1u : 0u) + (hit[1] ? 1u : 0u) + (hit[2] ? 1u : 0u);
-          if (FILL) {
-            // the reference's list order: bucket entry after bucket entry, for each the triangle's corners 0, 1, 2 - the
-            // team's lanes hold TEAM consecutive entries, so a lane writes behind the hits of the lanes below it
-            uint32_t incl = mine;
-#pragma unroll
-            for (int off = 1; off < TEAM; off <<= 1) {
-              const uint32_t below = __shfl_up(incl, off, TEAM);
-              if (static_cast<int>(member) >= off) incl += below;
-            }
-            uint32_t c = base + count + (incl - mine);
+          if (test[0] || test[1] || test[2]) {
+            const F3 b1 = xyz(pos[ib]), c1 = xyz(pos[ic]), d1 = xyz(pos[idd]);
+            const F3 b0 = xyz(prev[ib]), c0 = xyz(prev[ic]), d0 = xyz(prev[idd]);
 #pragma unroll
             for (int i = 0; i < 3; ++i)
-              if (hit[i]) {
-                if (c < T.maxContacts) T.ids[c] = make_uint4(ia[i], ib, ic, idd);
-                ++c;
-              }
-            count += __shfl(incl, TEAM - 1, TEAM);  // the team's running total (the same in all its lanes)
-          } else {
-            count += mine;
+              if (test[i]) hit[i] = point_triangle_ccd(a0[i] - b0, c0 - b0, d0 - b0, a1[i] - b1, c1 - b1, d1 - b1, threshold);
           }
         }
       }
+      const uint32_t mine = ((hit[0] ? 1u : 0u) + (hit[1] ? 1u : 0u) + (hit[2] ? 1u : 0u)) * times;
+      if (FILL) {
+        // the reference's list order: bucket entry after bucket entry, for each the triangle's corners 0, 1, 2 - the
+        // team's lanes hold TEAM consecutive candidates, so a lane writes behind the hits of the lanes below it
+        uint32_t inc2 = mine;
+#pragma unroll
+        for (int off = 1; off < TEAM; off <<= 1) {
+          const uint32_t below = __shfl_up(inc2, off, TEAM);
+          if (static_cast<int>(member) >= off) inc2 += below;
+        }
+        uint32_t c = base + count + (inc2 - mine);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          if (hit[i]) {
+            if (c < T.maxContacts) T.ids[c] = make_uint4(ia[i], ib, ic, idd);
+            ++c;
+          }
+        count += __shfl(inc2, TEAM - 1, TEAM);  // the team's running total (the same in all its lanes)
+      } else {
+        count += mine;
+      }
+    }
+  }
   if (!FILL) {
 #pragma unroll
     for (int off = TEAM / 2; off >= 1; off >>= 1) count += __shfl_xor(count, off, TEAM);
@@ -347,42 +420,56 @@ __global__ void __launch_bounds__(kBlock) k_tri_detect(TriArrays T, const float4
   }
 }
 
-// exclusive scan of the per-triangle counts in the reference's merge order (one block)
+// exclusive scan of the per-triangle counts in the reference's merge order (one block).  Every wavefront takes one contiguous
+// sixteenth of the counts: a coalesced sweep for its sum, the sixteen sums in LDS, and - only for a wavefront whose range holds
+// contacts at all - a second sweep that writes the offsets (wave-wide scans over 64 counts at a time).  A substep without
+// contacts is one sweep of loads that do not depend on each other (the first version gave every thread 41 consecutive counts
+// and a 10-step Hillis-Steele scan over the threads: 10 us at 42k triangles).
 __global__ void __launch_bounds__(1024) k_tri_scan(TriArrays T) {
-  __shared__ uint32_t part[1024];
-  const uint32_t tid = threadIdx.x, nt = T.nt;
-  const uint32_t chunk = (nt + 1023) / 1024;
-  const uint32_t lo = tid * chunk, hi = min(nt, lo + chunk);
+  __shared__ uint32_t wsum[16];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, nt = T.nt;
+  const uint32_t per = (((nt + 15u) / 16u) + 63u) & ~63u;
+  const uint32_t lo = min(nt, wave * per), hi = min(nt, lo + per);
   uint32_t sum = 0;
-#pragma unroll 8
-  for (uint32_t r = lo; r < hi; ++r) sum += T.cntTri[r];
-  part[tid] = sum;
+  for (uint32_t r = lo + lane; r < hi; r += 64u) sum += T.cntTri[r];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if (lane == 0u) wsum[wave] = sum;
   __syncthreads();
-  for (uint32_t off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-    const uint32_t v = tid >= off ? part[tid - off] : 0u;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
+  uint32_t run = 0, total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < 16u; ++w) {
+    const uint32_t v = wsum[w];
+    if (w < wave) run += v;
+    total += v;
   }
-  uint32_t run = tid ? part[tid - 1] : 0u;
-  if (sum == 0u) {  // no contacts in this chunk: offsets are never read (the fill pass skips empty triangles)
-  } else {
-    for (uint32_t r = lo; r < hi; ++r) {
-      T.offTri[r] = run;
-      run += T.cntTri[r];
+  if (sum != 0u) {  // (offsets of a range without contacts are never read: the fill pass skips empty triangles)
+    for (uint32_t r0 = lo; r0 < hi; r0 += 64u) {
+      const uint32_t r = r0 + lane;
+      const uint32_t c = r < hi ? T.cntTri[r] : 0u;
+      uint32_t inc = c;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(inc, off, 64);
+        if (lane >= static_cast<uint32_t>(off)) inc += v;
+      }
+      if (r < hi) T.offTri[r] = run + inc - c;
+      run += __shfl(inc, 63, 64);
     }
   }
-  if (tid == 1023) {
-    const uint32_t total = part[1023];
+  if (tid == 0u) {
     if (total > T.maxContacts) atomicOr(&T.counters[3], 64u);  // contact list overflow: latch
     T.counters[2] = min(total, T.maxContacts);
   }
 }
 
 // ---- per-node incidence of the contacts + their diagonal blocks ---------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_inc_count(TriArrays T, float* __restrict__ cdiag) {
+// Five steps with a device-wide dependency between them (count, used, alloc, fill, sort).  Each is a device function over
+// (first item, stride); the contact-heavy graph variant runs them as five launches, the other one as ONE launch of a single
+// workgroup (k_inc_all) - a substep with few or no contacts pays one launch for the lot instead of five.
+PIES_DEV void inc_count(const TriArrays& T, float* __restrict__ cdiag, uint32_t first, uint32_t stride) {
   const uint32_t M = T.counters[2];
-  for (uint32_t c = blockIdx.x * kBlock + threadIdx.x; c < M; c += gridDim.x * kBlock) {
+  for (uint32_t c = first; c < M; c += stride) {
     const uint4 id = T.ids[c];
     const uint32_t n[4] = {id.x, id.y, id.z, id.w};
 #pragma unroll
@@ -393,12 +480,11 @@ __global__ void __launch_bounds__(kBlock) k_inc_count(TriArrays T, float* __rest
     }
   }
 }
-// The nodes that take part in contacts, in ascending order, from the bitmap k_inc_count marked them in: one workgroup, a
+// The nodes that take part in contacts, in ascending order, from the bitmap inc_count marked them in: one workgroup of 1024, a
 // thread per run of bitmap words (popcounts, a prefix sum over the threads, then the set bits in order).  An append in
-// arrival order would be cheaper by this launch, but the order decides which wavefront sums which contact rows
-// (k_cg_ap), i.e. the rounding of p.Ap: results would differ from run to run.
-__global__ void __launch_bounds__(1024) k_inc_used(TriArrays T, uint32_t words) {
-  __shared__ uint32_t part[1024];
+// arrival order would be cheaper, but the order decides which wavefront sums which contact rows (k_cg_ap), i.e. the rounding
+// of p.Ap: results would differ from run to run.
+PIES_DEV void inc_used(const TriArrays& T, uint32_t words, uint32_t* part) {
   const uint32_t tid = threadIdx.x;
   const uint32_t chunk = (words + 1023u) / 1024u;
   const uint32_t lo = min(words, tid * chunk), hi = min(words, lo + chunk);
@@ -424,10 +510,10 @@ __global__ void __launch_bounds__(1024) k_inc_used(TriArrays T, uint32_t words) 
     }
   if (tid == 1023) T.counters[4] = part[1023];
 }
-__global__ void __launch_bounds__(kBlock) k_inc_alloc(TriArrays T, const float* __restrict__ kdiag, const float* __restrict__ cdiag,
-                                                      float* __restrict__ dinv) {
+PIES_DEV void inc_alloc(const TriArrays& T, const float* __restrict__ kdiag, const float* __restrict__ cdiag, float* __restrict__ dinv,
+                        uint32_t first, uint32_t stride) {
   const uint32_t used = T.counters[4];
-  for (uint32_t u = blockIdx.x * kBlock + threadIdx.x; u < used; u += gridDim.x * kBlock) {
+  for (uint32_t u = first; u < used; u += stride) {
     const uint32_t n = T.usedNodes[u];
     T.incStart[n] = atomicAdd(&T.counters[5], T.incCnt[n]);
     T.incFill[n] = 0;
@@ -435,23 +521,57 @@ __global__ void __launch_bounds__(kBlock) k_inc_alloc(TriArrays T, const float* 
     dinv[n] = 1.0f / (kdiag[n] + cdiag[n]);
   }
 }
-__global__ void __launch_bounds__(kBlock) k_inc_fill(TriArrays T) {
+PIES_DEV void inc_fill(const TriArrays& T, uint32_t first, uint32_t stride) {
   const uint32_t M = T.counters[2];
-  for (uint32_t c = blockIdx.x * kBlock + threadIdx.x; c < M; c += gridDim.x * kBlock) {
+  for (uint32_t c = first; c < M; c += stride) {
     const uint4 id = T.ids[c];
     const uint32_t n[4] = {id.x, id.y, id.z, id.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) T.inc[T.incStart[n[i]] + atomicAdd(&T.incFill[n[i]], 1u)] = (c << 2) | static_cast<uint32_t>(i);
   }
 }
-__global__ void __launch_bounds__(kBlock) k_inc_sort(TriArrays T) {
+PIES_DEV void inc_sort(const TriArrays& T, uint32_t wave, uint32_t nwaves) {
   const uint32_t used = T.counters[4];
   const int lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
   for (uint32_t u = wave; u < used; u += nwaves) {
     const uint32_t n = T.usedNodes[u];
     rank_sort(T.inc, T.incSorted, T.incStart[n], T.incCnt[n], lane, T.incPos);
   }
+}
+__global__ void __launch_bounds__(kBlock) k_inc_count(TriArrays T, float* __restrict__ cdiag) {
+  inc_count(T, cdiag, blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock);
+}
+__global__ void __launch_bounds__(1024) k_inc_used(TriArrays T, uint32_t words) {
+  __shared__ uint32_t part[1024];
+  inc_used(T, words, part);
+}
+__global__ void __launch_bounds__(kBlock) k_inc_alloc(TriArrays T, const float* __restrict__ kdiag, const float* __restrict__ cdiag,
+                                                      float* __restrict__ dinv) {
+  inc_alloc(T, kdiag, cdiag, dinv, blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock);
+}
+__global__ void __launch_bounds__(kBlock) k_inc_fill(TriArrays T) { inc_fill(T, blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock); }
+__global__ void __launch_bounds__(kBlock) k_inc_sort(TriArrays T) {
+  inc_sort(T, (blockIdx.x * kBlock + threadIdx.x) >> 6, (gridDim.x * kBlock) >> 6);
+}
+// the five steps by one workgroup: a step's stores are in L2, and this compute unit's vector cache holds none of the lines
+// they went to, before the next step starts (the fence), and every wavefront has finished the step (the barrier)
+PIES_DEV void step_boundary() {
+  __threadfence();
+  __syncthreads();
+}
+__global__ void __launch_bounds__(1024) k_inc_all(TriArrays T, const float* __restrict__ kdiag, float* __restrict__ cdiag, float* __restrict__ dinv,
+                                                  uint32_t words) {
+  __shared__ uint32_t part[1024];
+  if (T.counters[2] == 0u) return;  // no contact in this substep (k_tri_zero has cleared the counts this chain would write)
+  inc_count(T, cdiag, threadIdx.x, 1024u);
+  step_boundary();
+  inc_used(T, words, part);
+  step_boundary();
+  inc_alloc(T, kdiag, cdiag, dinv, threadIdx.x, 1024u);
+  step_boundary();
+  inc_fill(T, threadIdx.x, 1024u);
+  step_boundary();
+  inc_sort(T, threadIdx.x >> 6, 16u);
 }
 
 // ---- merged contact rows -------------------------------------------------------------------------------------
@@ -907,11 +1027,25 @@ PIES_DEV void level_barrier() {
   if (kSeqWorkers > 64) lds_barrier();
   else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
+// floor friction of one node (Solver.cpp:473-484, once per floor contact of the node; k_pd_static_friction's arithmetic)
+PIES_DEV F3 floor_friction(F3 v, uint32_t ns, float friction, float staticThreshold) {
+  for (uint32_t c = 0; c < ns; ++c) {
+    const float px = v.x, pz = v.z;
+    float fr = friction;
+    if (sqrtf(px * px + 0.0f * 0.0f + pz * pz) < staticThreshold) fr = 1.0f;
+    v.x += -fr * px;
+    v.y += -fr * 0.0f;
+    v.z += -fr * pz;
+  }
+  return v;
+}
 // MODE 0 runs ALL the stabilisation iterations of the substep (Solver.cpp:367-383: every iteration is a pass over the contacts
 // followed by the floor snap of every node with a floor contact): the snap of a node puts it where the right-hand side kernel
 // left its target (statp) and is idempotent, and a pass only touches the nodes of the list (usedNodes) - so the snap of those
 // nodes runs here, between the passes, and the snap of all the others once, in k_pd_stabilize behind this kernel.  (Until
 // round 3 the host launched pass and snap `iterations` times: eight launches of ~4.7 us in a substep without a single contact.)
+// MODE 1 (friction) ends with the floor friction of the list's nodes, which the reference applies after the contacts' friction;
+// k_pd_velocity, before this kernel, has applied it to every node that is in no contact (usedBits).
 template <int MODE>
 __global__ void __launch_bounds__(kSeqBlock) k_tri_sequential(TriArrays T, float4* pos4, float4* prev4, float4* vel4, float thickness,
                                                               float friction, float staticThreshold, const uint32_t* __restrict__ nstatic,
@@ -926,7 +1060,7 @@ __global__ void __launch_bounds__(kSeqBlock) k_tri_sequential(TriArrays T, float
   const uint32_t M = T.counters[2];
   if (M == 0) return;
   const uint32_t form = T.counters[7], used = T.counters[4];
-  const bool snap = MODE == 0 && nstatic != nullptr;
+  const bool snap = MODE == 0 && nstatic != nullptr, floorFr = MODE == 1 && nstatic != nullptr;
   if (form == 0) {
     const uint32_t levels = T.counters[6];
     float4* second4 = MODE == 0 ? prev4 : vel4;
@@ -976,7 +1110,12 @@ __global__ void __launch_bounds__(kSeqBlock) k_tri_sequential(TriArrays T, float
     for (uint32_t u = tid; u < used; u += kSeqWorkers) {
       const uint32_t n = T.usedNodes[u];
       if (MODE == 0) pos4[n] = P[u];
-      second4[n] = Q[u];
+      float4 q = Q[u];
+      if (floorFr) {
+        const F3 v = floor_friction(F3{q.x, q.y, q.z}, nstatic[n], friction, staticThreshold);
+        q.x = v.x; q.y = v.y; q.z = v.z;
+      }
+      second4[n] = q;
     }
     return;
   }
@@ -1001,6 +1140,12 @@ __global__ void __launch_bounds__(kSeqBlock) k_tri_sequential(TriArrays T, float
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     }
+    if (floorFr)
+      for (uint32_t u = tid; u < used; u += 64) {
+        const uint32_t n = T.usedNodes[u];
+        const uint32_t ns = nstatic[n];
+        if (ns) st3(vel, n, floor_friction(ld3(vel, n), ns, friction, staticThreshold));
+      }
     return;
   }
   const uint32_t levels = T.counters[6];
@@ -1021,6 +1166,12 @@ __global__ void __launch_bounds__(kSeqBlock) k_tri_sequential(TriArrays T, float
       __syncthreads();
     }
   }
+  if (floorFr)
+    for (uint32_t u = tid; u < used; u += kSeqBlock) {
+      const uint32_t n = T.usedNodes[u];
+      const uint32_t ns = nstatic[n];
+      if (ns) st3(vel, n, floor_friction(ld3(vel, n), ns, friction, staticThreshold));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1032,12 +1183,16 @@ uint32_t launch_tri_detect(hipStream_t st_, const TriArrays& T, const NodeArrays
   hipLaunchKernelGGL(k_tri_zero, dim3(1), dim3(64), 0, st_, T);
   hipLaunchKernelGGL(k_tri_count, grid_for(T.nt), blk, 0, st_, T, nd.pos, nd.prev);
   hipLaunchKernelGGL(k_tri_alloc, wide, blk, 0, st_, T);
-  hipLaunchKernelGGL(k_tri_fill, grid_for(T.nt), blk, 0, st_, T);
+  hipLaunchKernelGGL(k_tri_fill, grid_for(T.nt * kTriTeam), blk, 0, st_, T);
   hipLaunchKernelGGL(k_tri_sort, wide, blk, 0, st_, T);
   hipLaunchKernelGGL((k_tri_detect<false, kTriTeam>), grid_for(T.nt * kTriTeam), blk, 0, st_, T, nd.pos, nd.prev, threshold);
   hipLaunchKernelGGL(k_tri_scan, dim3(1), dim3(1024), 0, st_, T);
   hipLaunchKernelGGL((k_tri_detect<true, kTriTeam>), grid_for(T.nt * kTriTeam), blk, 0, st_, T, nd.pos, nd.prev, threshold);
   const dim3 cgrid(std::min<uint32_t>(256u, (T.maxContacts + kBlock - 1) / kBlock));
+  if (!mergedRows) {  // the variant for substeps with few or no contacts: the incidence chain as one launch of one workgroup
+    hipLaunchKernelGGL(k_inc_all, dim3(1), dim3(1024), 0, st_, T, kdiag, cdiag, dinv, (nd.n + 31u) / 32u);
+    return 10;
+  }
   hipLaunchKernelGGL(k_inc_count, cgrid, blk, 0, st_, T, cdiag);
   hipLaunchKernelGGL(k_inc_used, dim3(1), dim3(1024), 0, st_, T, (nd.n + 31u) / 32u);
   hipLaunchKernelGGL(k_inc_alloc, cgrid, blk, 0, st_, T, kdiag, cdiag, dinv);
@@ -1066,10 +1221,10 @@ void launch_tri_stabilize(hipStream_t st_, const TriArrays& T, const NodeArrays&
   if (T.nt == 0 || iterations == 0) return;
   hipLaunchKernelGGL(k_tri_sequential<0>, dim3(1), dim3(kSeqBlock), 0, st_, T, nd.pos, nd.prev, nd.vel, thickness, 0.0f, 0.0f, nstatic, statp, iterations);
 }
-void launch_tri_friction(hipStream_t st_, const TriArrays& T, const NodeArrays& nd, float friction, float staticThreshold) {
+void launch_tri_friction(hipStream_t st_, const TriArrays& T, const NodeArrays& nd, float friction, float staticThreshold, const uint32_t* nstatic) {
   if (T.nt == 0) return;
-  hipLaunchKernelGGL(k_tri_sequential<1>, dim3(1), dim3(kSeqBlock), 0, st_, T, nd.pos, nd.prev, nd.vel, 0.0f, friction, staticThreshold,
-                     static_cast<const uint32_t*>(nullptr), static_cast<const float4*>(nullptr), 1u);
+  hipLaunchKernelGGL(k_tri_sequential<1>, dim3(1), dim3(kSeqBlock), 0, st_, T, nd.pos, nd.prev, nd.vel, 0.0f, friction, staticThreshold, nstatic,
+                     static_cast<const float4*>(nullptr), 1u);
 }
 
 }  // namespace pies
