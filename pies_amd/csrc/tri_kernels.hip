@@ -162,23 +162,26 @@ __global__ void k_tri_zero(TriArrays T) {
 }
 
 // TriCompRange / sweptTriRange: floor(min), ceil(max) - floor(min) over position and prevPosition, world units.
-// One lane per triangle walks the cells of its range.  (A lane per CELL - kTriTeam lanes per triangle, as k_tri_fill and
-// k_tri_detect have it - made this kernel 60 us slower on a moving 100k-particle beam: all insertions of neighbouring
-// triangles then hit the same index lines and the cell counter at once.)
+// TEAM lanes per triangle share the cells of its range; the launch uses TEAM = 1.  (Measured on a moving 100k-particle beam,
+// 42k triangles of 18-27 cells: 1, 2 and 4 lanes per triangle take the same 32 us, 8 lanes 50, 16 lanes 90 - the kernel is bound
+// by its 2.2 M atomic operations on the cell index, and more lanes in flight only put more of them on the same lines at once.)
+template <int TEAM>
 __global__ void __launch_bounds__(kBlock) k_tri_count(TriArrays T, const float4* __restrict__ pos, const float4* __restrict__ prev) {
-  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t t = (blockIdx.x * kBlock + threadIdx.x) / TEAM, member = threadIdx.x % TEAM;
   if (t >= T.nt) return;
+  const uint32_t i0 = T.tris[3 * t], i1 = T.tris[3 * t + 1], i2 = T.tris[3 * t + 2];
+  const F3 b1 = xyz(pos[i0]), c1 = xyz(pos[i1]), d1 = xyz(pos[i2]);
+  const F3 b0 = xyz(prev[i0]), c0 = xyz(prev[i1]), d0 = xyz(prev[i2]);
+  const float pv[3][3] = {{b1.x, b1.y, b1.z}, {c1.x, c1.y, c1.z}, {d1.x, d1.y, d1.z}};
+  const float qv[3][3] = {{b0.x, b0.y, b0.z}, {c0.x, c0.y, c0.z}, {d0.x, d0.y, d0.z}};
   float mn[3], mx[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const uint32_t id = T.tris[3 * t + i];
-    const float4 p = pos[id], q = prev[id];
-    const float pv[3] = {p.x, p.y, p.z}, qv[3] = {q.x, q.y, q.z};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      if (i == 0) { mx[k] = pv[k]; mn[k] = pv[k]; }
-      mx[k] = fmaxf(pv[k], mx[k]); mx[k] = fmaxf(qv[k], mx[k]);
-      mn[k] = fminf(pv[k], mn[k]); mn[k] = fminf(qv[k], mn[k]);
+      if (i == 0) { mx[k] = pv[i][k]; mn[k] = pv[i][k]; }
+      mx[k] = fmaxf(pv[i][k], mx[k]); mx[k] = fmaxf(qv[i][k], mx[k]);
+      mn[k] = fminf(pv[i][k], mn[k]); mn[k] = fminf(qv[i][k], mn[k]);
     }
   }
   int m[3];
@@ -191,35 +194,32 @@ __global__ void __launch_bounds__(kBlock) k_tri_count(TriArrays T, const float4*
     m[k] = ok ? static_cast<int>(f) : 0;
     len[k] = ok ? static_cast<uint32_t>(ceilf(mx[k]) - static_cast<float>(static_cast<long long>(f))) : 0u;
   }
-  if (!ok) atomicOr(&T.counters[3], 32u);  // non-finite
+  if (!ok && member == 0) atomicOr(&T.counters[3], 32u);  // non-finite
   if (!ok || len[0] > kTriInsertMaxCells || len[1] > kTriInsertMaxCells || len[2] > kTriInsertMaxCells)
     len[0] = len[1] = len[2] = 0;  // the reference returns an empty range (Solver.cpp:974-976)
-  T.rng[t] = make_int4(m[0], m[1], m[2], static_cast<int>(len[0] | (len[1] << 8) | (len[2] << 16)));
-  {  // the candidate record of this triangle for k_tri_detect: box of its six corner positions, "both normals are non-zero", node ids
-    const uint32_t i0 = T.tris[3 * t], i1 = T.tris[3 * t + 1], i2 = T.tris[3 * t + 2];
-    const F3 b1 = xyz(pos[i0]), c1 = xyz(pos[i1]), d1 = xyz(pos[i2]);
-    const F3 b0 = xyz(prev[i0]), c0 = xyz(prev[i1]), d0 = xyz(prev[i2]);
+  if (member == 0) {
+    T.rng[t] = make_int4(m[0], m[1], m[2], static_cast<int>(len[0] | (len[1] << 8) | (len[2] << 16)));
+    // the candidate record of this triangle for k_tri_detect: box of its six corner positions, "both normals are non-zero", node ids
     const F3 nn0 = cross(c0 - b0, d0 - b0), nn1 = cross(c1 - b1, d1 - b1);
     const bool regular = dot(nn0, nn0) > 0.0f && dot(nn1, nn1) > 0.0f;
     T.box[3 * t] = make_float4(mn[0], mn[1], mn[2], regular ? 1.0f : 0.0f);
     T.box[3 * t + 1] = make_float4(mx[0], mx[1], mx[2], __uint_as_float(i0));
     T.box[3 * t + 2] = make_float4(__uint_as_float(i1), __uint_as_float(i2), 0.0f, 0.0f);
   }
-  uint32_t e = 0;
-  for (uint32_t dx = 0; dx < len[0]; ++dx)
-    for (uint32_t dy = 0; dy < len[1]; ++dy)
-      for (uint32_t dz = 0; dz < len[2]; ++dz, ++e) {
-        bool created;
-        const uint32_t s = insert_cell(T.keys, T.mask, pack_cell(m[0] + (int)dx, m[1] + (int)dy, m[2] + (int)dz), created);
-        if (e < kTriMaxEntries) T.triSlot[t * kTriMaxEntries + e] = s;
-        if (s == 0xffffffffu) { atomicOr(&T.counters[3], 2u); continue; }
-        if (created) {  // (the list of used cells is as long as the entry storage: more distinct cells than that is the
-          const uint32_t u = atomicAdd(&T.counters[0], 1u);  // "more entries than reserved" failure, never a write past it)
-          if (u < T.maxEntries) T.used[u] = s;
-          else atomicOr(&T.counters[3], 2u);
-        }
-        atomicAdd(&T.cnt[s], 1u);
-      }
+  const uint32_t ncell = len[0] * len[1] * len[2], lyz = len[1] * len[2];
+  for (uint32_t e = member; e < ncell; e += TEAM) {
+    const uint32_t dx = e / lyz, r = e - dx * lyz, dy = r / len[2], dz = r - dy * len[2];
+    bool created;
+    const uint32_t s = insert_cell(T.keys, T.mask, pack_cell(m[0] + (int)dx, m[1] + (int)dy, m[2] + (int)dz), created);
+    if (e < kTriMaxEntries) T.triSlot[t * kTriMaxEntries + e] = s;
+    if (s == 0xffffffffu) { atomicOr(&T.counters[3], 2u); continue; }
+    if (created) {  // (the list of used cells is as long as the entry storage: more distinct cells than that is the
+      const uint32_t u = atomicAdd(&T.counters[0], 1u);  // "more entries than reserved" failure, never a write past it)
+      if (u < T.maxEntries) T.used[u] = s;
+      else atomicOr(&T.counters[3], 2u);
+    }
+    atomicAdd(&T.cnt[s], 1u);
+  }
 }
 __global__ void __launch_bounds__(kBlock) k_tri_alloc(TriArrays T) {
   const uint32_t used = min(T.counters[0], T.maxEntries);
@@ -1181,7 +1181,7 @@ uint32_t launch_tri_detect(hipStream_t st_, const TriArrays& T, const NodeArrays
   const dim3 wide(std::min<uint32_t>(1024u, (T.nt * 8 + kBlock - 1) / kBlock)), blk(kBlock);
   hipLaunchKernelGGL(k_tri_reset, wide, blk, 0, st_, T);
   hipLaunchKernelGGL(k_tri_zero, dim3(1), dim3(64), 0, st_, T);
-  hipLaunchKernelGGL(k_tri_count, grid_for(T.nt), blk, 0, st_, T, nd.pos, nd.prev);
+  hipLaunchKernelGGL(k_tri_count<1>, grid_for(T.nt), blk, 0, st_, T, nd.pos, nd.prev);
   hipLaunchKernelGGL(k_tri_alloc, wide, blk, 0, st_, T);
   hipLaunchKernelGGL(k_tri_fill, grid_for(T.nt * kTriTeam), blk, 0, st_, T);
   hipLaunchKernelGGL(k_tri_sort, wide, blk, 0, st_, T);

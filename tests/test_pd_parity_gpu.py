@@ -133,6 +133,70 @@ def test_pd_stiff_system_needs_more_cg_iterations(pies, oracle):
     assert np.abs(g.positions - o.positions).max() <= 3 * tol_for(o.positions)
 
 
+def _two_boxes(s):
+    s.create_tet_box(4, 5, 7, translation=(0.0, 0.02, 0.0), w=1.0, volume=True, triangles=True)
+    s.create_tet_box(2, 2, 2, translation=(7.0, 0.5, 1.0), w=3.0, volume=True, triangles=True)   # another material
+    n = len(s.positions)
+    s.addNodes(np.array([[0, 9, 0], [1.1, 9, 0], [0, 10.2, 0.1], [0.2, 9.1, 0.9]], np.float32))      # one more element: an odd total
+    s.add_tet([n, n + 1, n + 2, n + 3], 2.0)
+    s.add_volume([n, n + 1, n + 2, n + 3], 2.0)
+    scenes.perturb(s, 17, 0.05)
+    s.set_prev_positions(s.positions)
+
+
+def test_pd_local_step_variants_agree(pies, oracle, tune):
+    """The strain + volume local step exists in three forms: one element per lane (the arithmetic of round 2 but for the single
+    recomposition), two elements per lane in packed fp32 with the per-element constants (PIES_PD_REST_DICT=0), and the same with
+    the rest dictionary (the default; this scene has a dozen distinct sets of constants over 439 element pairs - an odd count,
+    so the last lane holds one element).  All three against the oracle within the tolerance, and against each other within a
+    tenth of it: they differ by roundings of the volume projection and of the recomposition only."""
+    o = oracle.OracleSolver(pd_options(oracle, 8))
+    _two_boxes(o)
+    assert (o.count(oracle.TET) % 2) == 1
+    o.tick(3)
+    TOL = tol_for(o.positions)
+    res = []
+    for packed, rest in (("0", None), ("1", "0"), ("1", "1")):
+        tune("PIES_PD_LOCAL_PACKED", packed)
+        tune("PIES_PD_REST_DICT", rest)
+        g = pies.Solver(pd_options(pies, 8))
+        _two_boxes(g)
+        g.tick(3)
+        assert not g.failed and np.isfinite(g.positions).all()
+        d = float(np.abs(g.positions - o.positions).max())
+        record("pd_local_variants", "positions_packed%s_dict%s" % (packed, rest), d, TOL)
+        assert d <= TOL, (packed, rest, d, TOL)
+        res.append(g.positions)
+        g.close()
+    assert np.abs(res[0] - res[1]).max() <= 0.1 * TOL and np.abs(res[1] - res[2]).max() <= 0.1 * TOL
+
+
+def test_pd_flattened_and_inverted_elements(pies, oracle):
+    """Elements with a collapsed direction (a layer of nodes pressed into the layer below: s = 0, the rotation is completed from
+    the other two directions, dev_math.h svd3_recompose) and inverted ones (a node pushed through the opposite face: the
+    smallest singular value is negated, Constraints.cpp:76-128).  The packed local step hands an element with a collapsed
+    direction to the scalar routine; its neighbour in the lane stays on the packed path."""
+    def build(s):
+        s.create_tet_box(4, 4, 4, translation=(0.0, 3.0, 0.0), w=1.0, volume=True, triangles=True)
+        p = s.positions
+        top = np.isclose(p[:, 1], 3.0 + 3.0)
+        p[top, 1] = 3.0 + 2.0                 # the top layer lies in the one below: its elements have no volume
+        inv = np.argmin(np.abs(p - np.array([1.0, 3.0, 1.0])).sum(1))
+        p[inv] += np.array([0.0, 1.6, 0.0], np.float32)   # through the face above: inverted elements around it
+        s.set_positions(p)
+        s.set_prev_positions(p)
+    g = pies.Solver(pd_options(pies, 6))
+    o = oracle.OracleSolver(pd_options(oracle, 6))
+    g.set_pcg(3e-7, 64)
+    for s in (g, o):
+        build(s)
+    TOL = tol_for(o.positions)                # (measured: 1.4e-5 of a lattice spacing, a fifth of the tolerance)
+    for t in range(3):
+        g.tick(); o.tick()
+        assert np.isfinite(g.positions).all() and not g.failed
+        within("pd_flattened_inverted", g, o, TOL)
+
+
 def test_config3_l100k_against_oracle(pies, oracle):
     """BASELINE config 3 at full size (20x20x250 beam, PD, strain + volume constraints, 10 local/global iterations, end
     cap pinned, floor + point-triangle pipeline on): two ticks against the oracle's direct fp32 solve (banded Cholesky,
