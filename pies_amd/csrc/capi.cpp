@@ -262,6 +262,7 @@ static int collision_order(const pies_solver* s) {
   if (order == PIES_COLLISION_ORDER_GROUPS && !s->collideFast) order = PIES_COLLISION_ORDER_REFERENCE;
   return order;
 }
+static bool needs_grid_groups(const pies_solver* s) { return collision_order(s) != PIES_COLLISION_ORDER_PAIRS || !s->collideFast; }
 static uint32_t enqueue_collide(pies_solver* s, bool rearm = false) {
   switch (collision_order(s)) {
     case PIES_COLLISION_ORDER_REFERENCE:
@@ -297,7 +298,7 @@ static void enqueue_layered_substep(pies_solver* s, int only, uint32_t* counts, 
     switch (item.type) {
       case ITEM_COLLIDE: {  // Solver.cpp:81-130
         uint32_t nb = 34, nc = 1;
-        if (ON(PIES_KERNEL_HASH)) { nb = launch_hash_build(st, s->hash, s->nd, s->opt.gridSpacing); U(s->nd.n); }
+        if (ON(PIES_KERNEL_HASH)) { nb = launch_hash_build(st, s->hash, s->nd, s->opt.gridSpacing, s->sortPasses, needs_grid_groups(s)); U(s->nd.n); }
         probe_mark(s, PIES_KERNEL_HASH);
         if (ON(PIES_KERNEL_COLLIDE)) { nc = enqueue_collide(s, only == PIES_KERNEL_COLLIDE); U(s->nd.n); }
         probe_mark(s, PIES_KERNEL_COLLIDE);
@@ -350,7 +351,7 @@ static void enqueue_pbd_substep(pies_solver* s, int only, uint32_t* counts, uint
     size_t barrier = 0;
     auto collide = [&] {
       uint32_t nb = 34, nc = 1;
-      if (ON(PIES_KERNEL_HASH)) { nb = launch_hash_build(st, s->hash, s->nd, s->opt.gridSpacing); U(s->nd.n); }
+      if (ON(PIES_KERNEL_HASH)) { nb = launch_hash_build(st, s->hash, s->nd, s->opt.gridSpacing, s->sortPasses, needs_grid_groups(s)); U(s->nd.n); }
       probe_mark(s, PIES_KERNEL_HASH);
       if (ON(PIES_KERNEL_COLLIDE)) { nc = enqueue_collide(s, only == PIES_KERNEL_COLLIDE); U(s->nd.n); }
       probe_mark(s, PIES_KERNEL_COLLIDE);
@@ -387,7 +388,7 @@ static void enqueue_pbd_substep(pies_solver* s, int only, uint32_t* counts, uint
     }
     if (s->nodeCollisions) {  // Solver.cpp:81-130
       uint32_t nb = 34, nc = 1;
-      if (ON(PIES_KERNEL_HASH)) { nb = launch_hash_build(st, s->hash, s->nd, s->opt.gridSpacing); U(s->nd.n); }
+      if (ON(PIES_KERNEL_HASH)) { nb = launch_hash_build(st, s->hash, s->nd, s->opt.gridSpacing, s->sortPasses, needs_grid_groups(s)); U(s->nd.n); }
       probe_mark(s, PIES_KERNEL_HASH);
       if (ON(PIES_KERNEL_COLLIDE)) { nc = enqueue_collide(s, only == PIES_KERNEL_COLLIDE); U(s->nd.n); }
       probe_mark(s, PIES_KERNEL_COLLIDE);
@@ -680,6 +681,34 @@ static int adapt_pair_rounds(pies_solver* s) {
   return PIES_OK;
 }
 
+// Radix passes of the node grid's sort: a pass takes up to 11 bits of the cell key, whose width follows the cell box of the
+// scene.  The host looks at the box at its synchronisations and captures enough passes for five more bits than it saw (a box 32
+// times the volume); a build whose key does not fit the captured passes latches a failure (k_grid_box).
+static uint32_t sort_passes_for(uint32_t keyBits) { return std::max(1u, std::min(6u, (keyBits + 5u + 10u) / 11u)); }
+static int adapt_sort_passes(pies_solver* s) {
+  if (!s->hash.counters || !s->graphExec || s->sceneDirty || under_profiler()) return PIES_OK;
+  if (s->opt.solver != PIES_SOLVER_PBD || !s->nodeCollisions) return PIES_OK;
+  int box[6];
+  HIP_TRY(s, hipMemcpyAsync(box, s->hash.counters + kCounterBoxMin, sizeof(box), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  uint32_t bits = 0;
+  for (int a = 0; a < 3; ++a) {
+    if (box[3 + a] < box[a]) return PIES_OK;  // no build yet (or an empty one)
+    uint32_t ext = static_cast<uint32_t>(box[3 + a] - box[a]);
+    while (ext) { ++bits; ext >>= 1; }
+  }
+  const uint32_t want = sort_passes_for(bits);
+  uint32_t passes = s->sortPasses;
+  if (want > passes) { passes = want; s->sortCalm = 0; }
+  else if (want < passes) { if (++s->sortCalm >= 8) { passes = want; s->sortCalm = 0; } }
+  else s->sortCalm = 0;
+  if (passes != s->sortPasses) {
+    s->sortPasses = passes;
+    return capture_graph(s);
+  }
+  return PIES_OK;
+}
+
 static int poll_failure(pies_solver* s) {
   uint32_t* flagWord = s->hash.counters ? s->hash.counters + 3 : s->pd.tri.counters ? s->pd.tri.counters + 3 : nullptr;
   if (s->simFailed || !flagWord || s->device == PIES_DEVICE_NONE) return PIES_OK;
@@ -697,6 +726,7 @@ static int poll_failure(pies_solver* s) {
                : flag & 8  ? "node-node collision pass: the wait for a neighbouring group timed out (PIES_COLLIDE_SPIN_LIMIT)"
                : flag & 128 ? "node-node collision grid: more cell entries than the build reserves (sized from the radii at finalize)"
                : flag & 256 ? "node-node collision pass: more than 512 nodes within reach of one node, or more pairs than reserved (runaway pile-up)"
+               : flag & 512 ? "node-node collision grid: the scene's cell box outgrew the captured sort passes between two synchronisations (32 times its volume)"
                           : "a node left the supported cell range (non-finite position)";
   }
   return PIES_OK;
@@ -1115,6 +1145,25 @@ int pies_finalize(pies_solver_t* s) {
     if (n >= (1u << 25)) return fail(s, PIES_ERR_UNSUPPORTED, "node-node collisions: more than 2^25 nodes");
     if (entries > 0x7fff0000ull) return fail(s, PIES_ERR_UNSUPPORTED, "node-node collisions: more than 2^31 (cell, node) entries (gridSpacing is tiny against the radii)");
     H.maxEntries = static_cast<uint32_t>(entries + 64);
+    {  // sort passes to start with: from the cell box of the scene as it stands (adapt_sort_passes follows it from there)
+      float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      float rmax = 0.0f;
+      for (float r : s->h_radius) if (std::isfinite(r)) rmax = std::max(rmax, r);
+      const size_t stride = s->h_pos.size() / std::max<size_t>(1, n);
+      for (size_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) {
+          const float v = s->h_pos[i * stride + a];
+          if (std::isfinite(v)) { lo[a] = std::min(lo[a], v); hi[a] = std::max(hi[a], v); }
+        }
+      uint32_t bits = 0;
+      for (int a = 0; a < 3; ++a) {
+        const double cells = hi[a] >= lo[a] ? (static_cast<double>(hi[a]) - lo[a] + 2.0 * (rmax + 0.5)) / s->opt.gridSpacing + 2.0 : 1.0;
+        uint64_t ext = static_cast<uint64_t>(std::min(cells, 4.0e9));
+        while (ext) { ++bits; ext >>= 1; }
+      }
+      s->sortPasses = sort_passes_for(bits);
+      s->sortCalm = 0;
+    }
     uint32_t cap = 1024;
     const uint64_t want = s->collideFast ? 16ull * n : 2ull * H.maxEntries;  // distinct cells <= 8n resp. <= entries: load factor <= 0.5
     while (cap < want && cap < (1u << 30)) cap <<= 1;
@@ -1129,7 +1178,7 @@ int pies_finalize(pies_solver_t* s) {
       if (int rc = dev_alloc(s, H.maxEntries, &H.key[b], true)) return rc;
       if (int rc = dev_alloc(s, H.maxEntries, &H.val[b], true)) return rc;
     }
-    if (int rc = dev_alloc(s, 256ull * ((H.maxEntries + kRadixTile - 1) / kRadixTile) + 256, &H.hist, true)) return rc;  // + the 256 digit totals
+    if (int rc = dev_alloc(s, 2048ull * ((H.maxEntries + kRadixTile - 1) / kRadixTile) + 2048, &H.hist, true)) return rc;  // (digit, workgroup) counts of a pass + the digit totals
     if (int rc = dev_alloc(s, cap, &H.keys)) return rc;
     HIP_TRY(s, hipMemsetAsync(H.keys, 0xFF, static_cast<size_t>(cap) * sizeof(uint64_t), s->stream));
     if (int rc = dev_alloc(s, cap, &H.start, true)) return rc;
@@ -1298,6 +1347,7 @@ int pies_synchronize(pies_solver_t* s) {
   s->asyncSinceSync = 0;
   if (int rc = poll_failure(s)) return rc;  // a loop of pies_tick_async learns here that the simulation failed
   if (int rc = adapt_pair_rounds(s)) return rc;
+  if (int rc = adapt_sort_passes(s)) return rc;
   return adapt_pcg_budget(s);
 }
 
@@ -1366,6 +1416,7 @@ int pies_tick(pies_solver_t* s) {
   if (int rc = download_nodes(s, 1u)) return rc;
   if (int rc = poll_failure(s)) return rc;
   if (int rc = adapt_pair_rounds(s)) return rc;
+  if (int rc = adapt_sort_passes(s)) return rc;
   return adapt_pcg_budget(s);
 }
 

@@ -21,8 +21,10 @@ struct GridBox {
   int mn[3];
   uint32_t ext[3];   // max - min per axis
   uint32_t bits[3];
+  uint32_t passes, digit;  // the build's radix sort: passes captured in the substep graph, key bits a pass sorts by
   bool empty;
 };
+constexpr uint32_t kRadixMaxDigit = 11;  // bits per pass at most (2048 bins)
 PIES_DEV GridBox grid_box(const uint32_t* __restrict__ counters) {
   GridBox B;
   B.empty = false;
@@ -34,9 +36,15 @@ PIES_DEV GridBox grid_box(const uint32_t* __restrict__ counters) {
     B.ext[a] = B.empty ? 0u : static_cast<uint32_t>(mx - B.mn[a]);
     B.bits[a] = B.ext[a] ? 32u - static_cast<uint32_t>(__builtin_clz(B.ext[a])) : 0u;
   }
+  // The key's bits are dealt evenly to the passes the host captured (launch_hash_build): a box of 17 key bits is sorted in two
+  // passes of 9 bits, not in three of 8 with five more launches that find nothing to do.  More bits than kRadixMaxDigit per
+  // captured pass is latched by k_grid_box (the host follows the box at its synchronisations, with bits to spare).
+  B.passes = counters[kCounterSortPasses];
+  const uint32_t total = B.bits[0] + B.bits[1] + B.bits[2];
+  B.digit = B.passes ? min(kRadixMaxDigit, (total + B.passes - 1u) / B.passes) : 0u;
   return B;
 }
-PIES_DEV uint32_t grid_passes(const GridBox& B) { return (B.bits[0] + B.bits[1] + B.bits[2] + 7u) >> 3; }
+PIES_DEV uint32_t grid_passes(const GridBox& B) { return B.passes; }
 PIES_DEV bool in_box(const GridBox& B, int x, int y, int z) {
   return !B.empty && x >= B.mn[0] && y >= B.mn[1] && z >= B.mn[2] && static_cast<uint32_t>(x - B.mn[0]) <= B.ext[0] &&
          static_cast<uint32_t>(y - B.mn[1]) <= B.ext[1] && static_cast<uint32_t>(z - B.mn[2]) <= B.ext[2];

@@ -13,7 +13,7 @@ namespace pies {
 // [32] ticket (k_collide_flow) [33] epoch [34..36] / [37..39] bounding box of the cell ranges (min / max, as int)
 // [44] progress of k_collide_reference (nodes visited, diagnostics) [46..47] candidates tested (64 bit, statistics)
 constexpr uint32_t kCounterUsed = 0, kCounterEntries = 1, kCounterFlags = 3, kCounterPass0 = 4, kCounterPairs = 31, kCounterTicket = 32,
-                   kCounterEpoch = 33, kCounterBoxMin = 34, kCounterBoxMax = 37, kCounterProgress = 44, kCounterCandidates = 46 /* 64 bit: [46], [47] */,
+                   kCounterEpoch = 33, kCounterBoxMin = 34, kCounterBoxMax = 37, kCounterSortPasses = 40, kCounterProgress = 44, kCounterCandidates = 46 /* 64 bit: [46], [47] */,
                    kHashCounters = 64;
 // failure flags: 1 non-finite position, 2 cell index overflow, 4 more than kMaxBucket nodes in a cell, 8 k_collide_flow wait timed
 // out, 128 more cell entries than reserved  (16, 32, 64 belong to the triangle grid's word, tri_kernels.h)
@@ -45,7 +45,11 @@ struct HashArrays {
 };
 
 // zero + range + prefix sum + emit + radix sort + cell index; returns the number of launches
-uint32_t launch_hash_build(hipStream_t st, const HashArrays& H, const NodeArrays& nd, float gridSpacing);
+// sortPasses: radix passes captured for the entries' sort; a pass takes up to 11 key bits (grid_box, hash_device.h)
+// groups: group sizes and pass lists of the group order (k_grid_groups; also its "too many nodes in a cell" latch) - the pair order
+// over ranges of at most two cells looks at the buckets itself (k_pair_groups) and builds without it
+uint32_t launch_hash_build(hipStream_t st, const HashArrays& H, const NodeArrays& nd, float gridSpacing, uint32_t sortPasses, bool groups = true);
+constexpr uint32_t kMaxBucket = 2048;  // nodes overlapping one cell before the simulation is declared failed
 // the resolve of Solver.cpp:85-130 in the parallel visiting order; returns the number of launches.
 // rearm: the launch first resets the work queue of k_collide_flow (a replay without a new hash build, profile passes)
 uint32_t launch_collide(hipStream_t st, const HashArrays& H, const NodeArrays& nd, float friction, float staticThreshold, bool rearm = false);

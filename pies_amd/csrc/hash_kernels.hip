@@ -41,7 +41,6 @@
 namespace pies {
 
 constexpr int kBlock = 256;
-constexpr uint32_t kMaxBucket = 2048;  // nodes overlapping one cell before the simulation is declared failed
 
 static inline dim3 grid_for(uint32_t n) { return dim3((n + kBlock - 1) / kBlock); }
 
@@ -108,7 +107,7 @@ __global__ void __launch_bounds__(kBlock) k_grid_range(HashArrays H, const float
     H.boxPart[blockIdx.x * 6 + a] = v;
   }
 }
-__global__ void __launch_bounds__(1024) k_grid_box(HashArrays H, uint32_t nparts) {
+__global__ void __launch_bounds__(1024) k_grid_box(HashArrays H, uint32_t nparts, uint32_t sortPasses) {
   __shared__ int red[16][6];
   int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
   for (uint32_t b = threadIdx.x; b < nparts; b += 1024) {
@@ -133,6 +132,21 @@ __global__ void __launch_bounds__(1024) k_grid_box(HashArrays H, uint32_t nparts
     int v = red[0][a];
     for (int w = 1; w < 16; ++w) v = a < 3 ? min(v, red[w][a]) : max(v, red[w][a]);
     H.counters[(a < 3 ? kCounterBoxMin : kCounterBoxMax - 3) + a] = static_cast<uint32_t>(v);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // the sort of this build: the captured passes, and whether they can hold the box's key
+    H.counters[kCounterSortPasses] = sortPasses;
+    uint32_t total = 0;
+    bool empty = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      int lo_ = red[0][a], hi_ = red[0][3 + a];
+      for (int w = 1; w < 16; ++w) { lo_ = min(lo_, red[w][a]); hi_ = max(hi_, red[w][3 + a]); }
+      if (hi_ < lo_) empty = true;
+      const uint32_t ext = empty ? 0u : static_cast<uint32_t>(hi_ - lo_);
+      total += ext ? 32u - static_cast<uint32_t>(__builtin_clz(ext)) : 0u;
+    }
+    if (!empty && total > kRadixMaxDigit * sortPasses) atomicOr(&H.counters[kCounterFlags], 512u);
   }
 }
 
@@ -231,22 +245,23 @@ __global__ void __launch_bounds__(kBlock) k_grid_emit(HashArrays H, uint32_t n) 
 // Pass p reads buffer p & 1 and writes the other one.  A workgroup owns kRadixTile consecutive entries; wavefront w of
 // it the w-th quarter, sixteen rounds of 64 consecutive entries - so (workgroup, wavefront, round, lane) is the input order.
 __global__ void __launch_bounds__(kBlock) k_radix_hist(HashArrays H, uint32_t pass, uint32_t nblkMax) {
-  __shared__ uint32_t h[256];
+  __shared__ uint32_t h[1u << kRadixMaxDigit];
   const GridBox B = grid_box(H.counters);
   if (pass >= grid_passes(B)) return;
+  const uint32_t bins = 1u << B.digit, shift = B.digit * pass;
   const uint32_t E = H.counters[kCounterEntries];
   const uint32_t blk = blockIdx.x;
   if (blk * kRadixTile >= E) return;
   const uint64_t* __restrict__ src = H.key[pass & 1u];
-  h[threadIdx.x] = 0;
+  for (uint32_t d = threadIdx.x; d < bins; d += kBlock) h[d] = 0;
   __syncthreads();
 #pragma unroll 4
   for (uint32_t k = 0; k < kRadixTile / kBlock; ++k) {
     const uint32_t t = blk * kRadixTile + k * kBlock + threadIdx.x;
-    if (t < E) atomicAdd(&h[static_cast<uint32_t>(src[t] >> (8u * pass)) & 255u], 1u);
+    if (t < E) atomicAdd(&h[static_cast<uint32_t>(src[t] >> shift) & (bins - 1u)], 1u);
   }
   __syncthreads();
-  H.hist[threadIdx.x * nblkMax + blk] = h[threadIdx.x];
+  for (uint32_t d = threadIdx.x; d < bins; d += kBlock) H.hist[d * nblkMax + blk] = h[d];
 }
 // Prefix sums of the (digit, workgroup) counts in digit-major order, in two steps: workgroup d of this kernel turns row d
 // (the counts of digit d over the sorting workgroups) into its exclusive prefix and leaves the row's total in
@@ -254,7 +269,7 @@ __global__ void __launch_bounds__(kBlock) k_radix_hist(HashArrays H, uint32_t pa
 __global__ void __launch_bounds__(kBlock) k_radix_scan(HashArrays H, uint32_t pass, uint32_t nblkMax) {
   __shared__ uint32_t lds[8];
   const GridBox B = grid_box(H.counters);
-  if (pass >= grid_passes(B)) return;
+  if (pass >= grid_passes(B) || blockIdx.x >= (1u << B.digit)) return;
   const uint32_t E = H.counters[kCounterEntries];
   const uint32_t nblk = (E + kRadixTile - 1u) / kRadixTile;
   uint32_t* __restrict__ row = H.hist + static_cast<size_t>(blockIdx.x) * nblkMax;
@@ -267,14 +282,16 @@ __global__ void __launch_bounds__(kBlock) k_radix_scan(HashArrays H, uint32_t pa
     if (k < nblk) row[k] = carry + ex;
     carry += total;
   }
-  if (threadIdx.x == 0) H.hist[256u * nblkMax + blockIdx.x] = carry;
+  if (threadIdx.x == 0) H.hist[(1u << kRadixMaxDigit) * nblkMax + blockIdx.x] = carry;
 }
 __global__ void __launch_bounds__(kBlock) k_radix_scatter(HashArrays H, uint32_t pass, uint32_t nblkMax) {
-  __shared__ uint32_t cnt[4][256];  // per wavefront: running count of a digit, then the wavefront's base inside the workgroup
-  __shared__ uint32_t gbase[256];
+  constexpr uint32_t kBins = 1u << kRadixMaxDigit;
+  __shared__ uint32_t cnt[4][kBins];  // per wavefront: running count of a digit, then the wavefront's base inside the workgroup
+  __shared__ uint32_t gbase[kBins];
   __shared__ uint32_t scanLds[8];
   const GridBox B = grid_box(H.counters);
   if (pass >= grid_passes(B)) return;
+  const uint32_t bins = 1u << B.digit, shift = B.digit * pass;
   const uint32_t E = H.counters[kCounterEntries];
   const uint32_t blk = blockIdx.x;
   if (blk * kRadixTile >= E) return;
@@ -284,7 +301,7 @@ __global__ void __launch_bounds__(kBlock) k_radix_scatter(HashArrays H, uint32_t
   uint32_t* __restrict__ dval = H.val[(pass & 1u) ^ 1u];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   constexpr int kRounds = kRadixTile / kBlock;  // 16
-  for (uint32_t d = lane; d < 256u; d += 64u) cnt[wave][d] = 0;
+  for (uint32_t d = lane; d < bins; d += 64u) cnt[wave][d] = 0;
   __builtin_amdgcn_wave_barrier();
   uint64_t key[kRounds];
   uint32_t val[kRounds], rank[kRounds];
@@ -300,10 +317,10 @@ __global__ void __launch_bounds__(kBlock) k_radix_scatter(HashArrays H, uint32_t
   for (int r = 0; r < kRounds; ++r) {
     const uint32_t t = first + static_cast<uint32_t>(r) * 64u + lane;
     const bool valid = t < E;
-    const uint32_t d = static_cast<uint32_t>(key[r] >> (8u * pass)) & 255u;
+    const uint32_t d = static_cast<uint32_t>(key[r] >> shift) & (bins - 1u);
     unsigned long long peers = __ballot(valid);  // lanes of this round holding the same digit
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < static_cast<int>(kRadixMaxDigit); ++b) {  // (bits above the digit's width are zero in every lane)
       const bool bit = (d >> b) & 1u;
       const unsigned long long m = __ballot(valid && bit);
       peers &= bit ? m : ~m;
@@ -317,25 +334,41 @@ __global__ void __launch_bounds__(kBlock) k_radix_scatter(HashArrays H, uint32_t
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
-  {  // thread d: wavefront bases of digit d inside the workgroup, and the workgroup's base in the output
-    const uint32_t d = threadIdx.x;
-    uint32_t run = 0;
+  {  // per digit: the wavefronts' bases inside the workgroup, and the workgroup's base in the output.  A thread takes
+    // kBins / kBlock consecutive digits (their totals scanned in the thread, the threads' sums across the workgroup)
+    constexpr uint32_t kPer = kBins / kBlock;  // 8
+    const uint32_t d0 = threadIdx.x * kPer;
+    uint32_t tot[kPer], mine = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const uint32_t c = cnt[w][d];
-      cnt[w][d] = run;
-      run += c;
+    for (uint32_t q = 0; q < kPer; ++q) {
+      const uint32_t d = d0 + q;
+      tot[q] = d < bins ? H.hist[kBins * nblkMax + d] : 0u;
+      mine += tot[q];
+      if (d < bins) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const uint32_t c = cnt[w][d];
+          cnt[w][d] = run;
+          run += c;
+        }
+      }
     }
     uint32_t all;
-    const uint32_t digitBase = block_exclusive_scan(H.hist[256u * nblkMax + d], scanLds, all);  // entries with a smaller digit
-    gbase[d] = digitBase + H.hist[d * nblkMax + blk];
+    uint32_t digitBase = block_exclusive_scan(mine, scanLds, all);  // entries with a smaller digit
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; ++q) {
+      const uint32_t d = d0 + q;
+      if (d < bins) gbase[d] = digitBase + H.hist[d * nblkMax + blk];
+      digitBase += tot[q];
+    }
   }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     const uint32_t t = first + static_cast<uint32_t>(r) * 64u + lane;
     if (t < E) {
-      const uint32_t d = static_cast<uint32_t>(key[r] >> (8u * pass)) & 255u;
+      const uint32_t d = static_cast<uint32_t>(key[r] >> shift) & (bins - 1u);
       const uint32_t at = gbase[d] + cnt[wave][d] + rank[r];
       dkey[at] = key[r];
       dval[at] = val[r];
@@ -922,7 +955,7 @@ __global__ void k_collide_rearm(HashArrays H) {
 }
 
 // ----------------------------------------------------------------------------------------------------
-uint32_t launch_hash_build(hipStream_t st_, const HashArrays& H, const NodeArrays& nd, float scale) {
+uint32_t launch_hash_build(hipStream_t st_, const HashArrays& H, const NodeArrays& nd, float scale, uint32_t sortPasses, bool groups) {
   if (nd.n == 0) return 0;
   const uint32_t n = nd.n;
   uint32_t launches = 0;
@@ -930,21 +963,21 @@ uint32_t launch_hash_build(hipStream_t st_, const HashArrays& H, const NodeArray
   hipLaunchKernelGGL(k_grid_reset, wide, dim3(kBlock), 0, st_, H); ++launches;
   hipLaunchKernelGGL(k_grid_zero, dim3(1), dim3(64), 0, st_, H); ++launches;
   hipLaunchKernelGGL(k_grid_range, grid_for(n + 1), dim3(kBlock), 0, st_, H, nd.pos, nd.radius, n, scale); ++launches;
-  hipLaunchKernelGGL(k_grid_box, dim3(1), dim3(1024), 0, st_, H, grid_for(n + 1).x); ++launches;
+  hipLaunchKernelGGL(k_grid_box, dim3(1), dim3(1024), 0, st_, H, grid_for(n + 1).x, sortPasses); ++launches;
   const uint32_t m = n + 1, tiles = (m + kScanTile - 1) / kScanTile;
   hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kBlock), 0, st_, H.entCount, H.entOff, m, H.scanSums); ++launches;
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st_, H.scanSums, tiles); ++launches;
   hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kBlock), 0, st_, H.entOff, m, H.scanSums); ++launches;
   hipLaunchKernelGGL(k_grid_emit, grid_for(n), dim3(kBlock), 0, st_, H, n); ++launches;
   const uint32_t nblkMax = (H.maxEntries + kRadixTile - 1) / kRadixTile;
-  for (uint32_t pass = 0; pass < 8; ++pass) {  // passes beyond the key width exit at once
+  for (uint32_t pass = 0; pass < sortPasses; ++pass) {  // the key's bits are dealt evenly to the passes (grid_box)
     hipLaunchKernelGGL(k_radix_hist, dim3(nblkMax), dim3(kBlock), 0, st_, H, pass, nblkMax);
-    hipLaunchKernelGGL(k_radix_scan, dim3(256), dim3(kBlock), 0, st_, H, pass, nblkMax);
+    hipLaunchKernelGGL(k_radix_scan, dim3(1u << kRadixMaxDigit), dim3(kBlock), 0, st_, H, pass, nblkMax);
     hipLaunchKernelGGL(k_radix_scatter, dim3(nblkMax), dim3(kBlock), 0, st_, H, pass, nblkMax);
     launches += 3;
   }
   hipLaunchKernelGGL(k_grid_cells, dim3(nblkMax), dim3(kBlock), 0, st_, H); ++launches;
-  hipLaunchKernelGGL(k_grid_groups, wide, dim3(kBlock), 0, st_, H); ++launches;
+  if (groups) { hipLaunchKernelGGL(k_grid_groups, wide, dim3(kBlock), 0, st_, H); ++launches; }
   return launches;
 }
 

@@ -215,6 +215,7 @@ __global__ void __launch_bounds__(kBlock) k_pair_groups(HashArrays H, PairArrays
   __shared__ uint32_t lcount, lbase;
   const uint32_t used = H.counters[kCounterUsed];
   const GridBox B = grid_box(H.counters);
+  const uint32_t* __restrict__ val = H.val[grid_passes(B) & 1u];
   for (uint32_t first = blockIdx.x * kBlock; first < used; first += gridDim.x * kBlock) {  // (workgroup uniform)
     if (threadIdx.x == 0) lcount = 0;
     __syncthreads();
@@ -223,7 +224,11 @@ __global__ void __launch_bounds__(kBlock) k_pair_groups(HashArrays H, PairArrays
     bool have = false;
     if (u < used) {
       s = H.used[u];
-      have = H.gcnt[s] != 0u;
+      // a group exists where some node has its minimum cell (kMinFlag).  (k_grid_groups leaves that count in gcnt for the
+      // group order; builds for the pair order skip that launch and look here.)
+      const uint32_t bs = H.start[s], be = H.end[s];
+      if (be - bs > kMaxBucket) atomicOr(&H.counters[kCounterFlags], 4u);  // runaway pile-up: latch, like Solver.cpp:741-755
+      for (uint32_t e = bs; e < be && !have; ++e) have = (val[e] >> 31) != 0u;
       if (have) rank = atomicAdd(&lcount, 1u);
     }
     __syncthreads();

@@ -173,6 +173,8 @@ struct pies_solver {
   bool simFailed = false;
   int schedule = PIES_SCHEDULE_DEFAULT;
   int collisionOrderFlag = -1;     // PIES_FLAG_COLLISION_ORDER: -1 follows the schedule (EXACT: reference order, otherwise pair order)
+  uint32_t sortPasses = 3;         // radix passes captured per node-grid build (up to 11 key bits each); follows the scene's cell box
+  uint32_t sortCalm = 0;
   bool pairRoundsPinned = false;   // pies_set_collision_rounds: the count is the host's
   uint32_t pairCalm = 0;           // synchronisations in a row at which fewer level launches would have done
   uint32_t pairRounds = 96;        // level launches captured per pair-ordered pass (a tail kernel finishes deeper orders)
