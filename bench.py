@@ -208,9 +208,11 @@ def pd_bytes(solver):
            + 2 * solver.count(capi.DISTANCE) + solver.count(capi.POSITION))
     return {
         # 148 B per tet / volume projection.  A fused strain + volume launch does two projections per element from
-        # ONE gather: ids 16 + Qinv 36 + 2 x (min, max, w) 24 + four positions 48 + 2 x 36 projected gradients = 196 B is all
-        # there is to move (2 x 148 would count the shared inputs twice and put the kernel above the roofline at 1M)
-        "pd_local_tet": 196 if paired else 148, "pd_local_volume": 148, "pd_local_distance": 64, "pd_predict": 52,
+        # ONE gather and adds the two contributions into one 12-byte record per corner: ids 16 + Qinv 36 + 2 x (min, max, w) 24
+        # + four positions 48 + four records 48 = 172 B (round 2 counted 196: two sets of records); with the rest dictionary
+        # the 60 bytes of constants are a 2-byte index into a cache-resident table: 114 B.  (2 x 148 would count the shared
+        # inputs twice; either older figure puts the kernel above the roofline at 1M particles.)
+        "pd_local_tet": (114 if solver.count(capi.REST_SETS) else 172) if paired else 148, "pd_local_volume": 148, "pd_local_distance": 64, "pd_predict": 52,
         # gather formulation: one 12-byte contribution + its 4-byte slot index per (constraint, node) incidence, inertia term
         # in, right-hand side out (the survey's scatter formulation would be 148 B per tetrahedron)
         "pd_rhs": (16.0 * inc + 32.0 * n) / n,
@@ -476,8 +478,11 @@ def run_config3(device, full):
            "launches_per_substep": sum(g.launch_counts().values()),
            "projections_per_sec": 30 / el * 10 * (g.count(capi.TET) + g.count(capi.VOLUME) + g.count(capi.POSITION)),
            "roofline": roofline(g, "pd_local_tet", B["pd_local_tet"], workload="config3", note="fused strain + volume local step: two projections per "
-                                "element from one gather and one SVD = 196 B per element (two separate 148-B projections of "
-                                "SURVEY 8d would be 296 B: multiply achieved by 1.51 for that count)"),
+                                "element from one gather and one SVD, the two contributions summed into one 12-byte record per "
+                                "corner, the element's 60 bytes of constants a 2-byte index into the rest dictionary: 114 B per "
+                                "element pair (172 without the dictionary; two separate 148-B projections of SURVEY 8d would be "
+                                "296 B: multiply achieved by 2.6 for that count).  Two elements per lane in packed fp32: at 100k "
+                                "particles the launch is bound by VALU issue and launch latency"),
            "roofline_spmv": roofline(g, "pd_spmv", B["pd_spmv"], workload="config3", note="SELL-64 SpMV over 3 right-hand sides + fused direction "
                                      "update; 8 nnz + 28 N bytes per launch (SURVEY 8d); the solves of the timed pass do not take "
                                      "the converged early exit"),

@@ -26,6 +26,7 @@ KERNEL_NAMES = ["predict", "position", "distance", "tet", "bend", "floor", "velo
 KERNEL_PREDICT, KERNEL_POSITION, KERNEL_DISTANCE, KERNEL_TET, KERNEL_BEND, KERNEL_FLOOR, KERNEL_VELOCITY = range(7)
 KERNEL_COUNT = 19
 SYSTEM_NNZ = 10
+REST_SETS = 11
 
 # every symbol include/pies_hip.h declares (checked by tests/test_capi_symbols.py against the header)
 SYMBOLS = [
