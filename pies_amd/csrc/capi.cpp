@@ -686,7 +686,7 @@ static int adapt_pair_rounds(pies_solver* s) {
 // times the volume); a build whose key does not fit the captured passes latches a failure (k_grid_box).
 static uint32_t sort_passes_for(uint32_t keyBits) { return std::max(1u, std::min(6u, (keyBits + 5u + 10u) / 11u)); }
 static int adapt_sort_passes(pies_solver* s) {
-  if (!s->hash.counters || !s->graphExec || s->sceneDirty || under_profiler()) return PIES_OK;
+  if (!s->hash.counters || s->sceneDirty || under_profiler()) return PIES_OK;
   if (s->opt.solver != PIES_SOLVER_PBD || !s->nodeCollisions) return PIES_OK;
   int box[6];
   HIP_TRY(s, hipMemcpyAsync(box, s->hash.counters + kCounterBoxMin, sizeof(box), hipMemcpyDeviceToHost, s->stream));
@@ -704,7 +704,7 @@ static int adapt_sort_passes(pies_solver* s) {
   else s->sortCalm = 0;
   if (passes != s->sortPasses) {
     s->sortPasses = passes;
-    return capture_graph(s);
+    if (s->graphExec) return capture_graph(s);  // (without a captured graph the next tick's launches take the new count)
   }
   return PIES_OK;
 }

@@ -190,6 +190,37 @@ def test_wide_ranges_in_the_pair_order_at_scale(pies, oracle):
     assert h["passes_inexact"] == 0
 
 
+@RULES
+def test_grid_sort_follows_a_growing_box(pies, oracle, rule):
+    """The node grid's radix sort is captured with as many passes as the scene's cell box needs (11 key bits per pass at most, five
+    bits to spare); the host follows the box at every synchronisation.  A cluster flying apart - its box grows from 5 x 6 x 7 cells
+    to sixteen times that per axis over twelve ticks, the key from 9 to 21 bits - stays exact against the oracle tick by tick."""
+    p, v = particles((6, 7, 8))
+    c = p.mean(0)
+    v = (110.0 * (p - c) + v).astype(np.float32)     # radial: the outermost particles leave at ~350 units per second (4 per tick)
+
+    def build(s):
+        s.addNodes(p)
+        s.set_velocities(v)
+    g, o = pair(pies, oracle, build, 2, 0, rule=rule, floorHeight=-1000.0)
+    for t in range(12):
+        g.tick(); o.tick()
+        check(g, o)
+    assert np.ptp(g.positions, axis=0).max() > 8 * np.ptp(p, axis=0).max()
+
+
+def test_a_box_that_outgrows_the_captured_sort_is_latched(pies):
+    """...and a box that grows faster than the spare bits allow between two looks of the host (here: 60 times per axis inside the
+    first tick) is a failure latch, not a wrong grid."""
+    p, v = particles((6, 7, 8))
+    v = (9000.0 * (p - p.mean(0))).astype(np.float32)
+    g = pies.Solver(scenes.pbd_options(pies, 2, floorHeight=-1.0e5))
+    g.addNodes(p)
+    g.set_velocities(v)
+    g.tick(2)
+    assert g.failed and "cell box" in g.last_error(), g.last_error()
+
+
 def test_config4_l500k_one_tick(pies, oracle):
     """BASELINE config 4 at full size (50x100x100 loose particles, 4 iterations): one tick vs the oracle."""
     p, v = particles(scenes.L500K)
