@@ -271,6 +271,7 @@ struct BuildLds {
   uint32_t ncand, nown, spill;
   uint64_t lk[kBuildWaves][MAXD];                    // one node's partners: pair key
   uint32_t le[kBuildWaves][MAXD];                    //                     partner | (shared cells - 1) << 28
+  uint16_t near[kBuildWaves][MAXD];                  // table slots of the candidates within reach of the node (first sweep)
 };
 
 // cells two ranges share on one axis: [a0, a0 + la) and [b0, b0 + lb)
@@ -469,24 +470,42 @@ __global__ void __launch_bounds__(64 * kBuildWaves) k_pair_build(HashArrays H, P
       for (uint32_t dx = 0; dx < lxi; ++dx)
         for (uint32_t dy = 0; dy < lyi; ++dy)
           for (uint32_t dz = 0; dz < lzi; ++dz) looked += cCnt[(dx * 4 + dy * 2 + dz) & 7u];
-      uint32_t d = 0;
+      // Two sweeps.  The first one is the distance test alone over all ~300 candidates and leaves the slots of the ~25 within reach
+      // in LDS; the second one - shared cells and the pair key, 60 % of the instructions of a candidate round - runs over those
+      // only, usually one round instead of five (with one sweep a round paid for the key as soon as one of its lanes passed).
+      uint16_t* near = L.near[wv];
+      uint32_t nn = 0;
       for (uint32_t base = 0; base < ncand; base += 64) {
         const uint32_t t = base + static_cast<uint32_t>(lane);
+        bool reach = false;
+        if (t < ncand && t != si) {
+          const float ddx = L.px[t] - pix, ddy = L.py[t] - piy, ddz = L.pz[t] - piz;
+          const float cut = 1.001f * (rsi + L.rs[t]);  // (wide for a node that left its slack in the first attempt)
+          reach = !(ddx * ddx + ddy * ddy + ddz * ddz >= cut * cut);
+        }
+        const unsigned long long mask = __ballot(reach);
+        if (reach) {
+          const uint32_t at = nn + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+          if (at < MAXD) near[at] = static_cast<uint16_t>(t);
+        }
+        nn += static_cast<uint32_t>(__popcll(mask));
+      }
+      __builtin_amdgcn_wave_barrier();
+      uint32_t d = nn > MAXD ? MAXD + 1u : 0u;  // (more within reach than a list holds: handled below like a list that is too long)
+      for (uint32_t base = 0; base < nn && nn <= MAXD; base += 64) {
+        const uint32_t e = base + static_cast<uint32_t>(lane);
         bool accept = false;
         uint32_t j = 0, m = 0;
         float pjx = 0.f, pjy = 0.f, pjz = 0.f;
-        if (t < ncand && t != si) {
+        if (e < nn) {
+          const uint32_t t = near[e];
           pjx = L.px[t]; pjy = L.py[t]; pjz = L.pz[t];
-          const float ddx = pjx - pix, ddy = pjy - piy, ddz = pjz - piz;
-          const float cut = 1.001f * (rsi + L.rs[t]);  // (wide for a node that left its slack in the first attempt)
-          if (!(ddx * ddx + ddy * ddy + ddz * ddz >= cut * cut)) {
-            j = L.id[t];
-            const uint32_t rgj = L.rg[t];
-            m = shared_cells(0, lxi, static_cast<int>(rgj & 3u) - 1, ((rgj >> 8) & 63u) + 1u) *
-                shared_cells(0, lyi, static_cast<int>((rgj >> 2) & 3u) - 1, ((rgj >> 14) & 63u) + 1u) *
-                shared_cells(0, lzi, static_cast<int>((rgj >> 4) & 3u) - 1, ((rgj >> 20) & 63u) + 1u);
-            accept = m != 0u;
-          }
+          j = L.id[t];
+          const uint32_t rgj = L.rg[t];
+          m = shared_cells(0, lxi, static_cast<int>(rgj & 3u) - 1, ((rgj >> 8) & 63u) + 1u) *
+              shared_cells(0, lyi, static_cast<int>((rgj >> 2) & 3u) - 1, ((rgj >> 14) & 63u) + 1u) *
+              shared_cells(0, lzi, static_cast<int>((rgj >> 4) & 3u) - 1, ((rgj >> 20) & 63u) + 1u);
+          accept = m != 0u;
         }
         d = push_partners<MAXD>(lk, le, d, accept, i, j, m, pix, piy, piz, pjx, pjy, pjz, lane);
       }
