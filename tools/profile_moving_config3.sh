@@ -1,8 +1,10 @@
 #!/bin/bash
+# Kernel trace of config 3 in the state bench.py times (the beam after 34 frames, swinging): per-kernel averages of the last five ticks.
+# On the GPU box: bash tools/profile_moving_config3.sh > gpurun_out/r03_moving_config3.txt (copied to profiles/ afterwards).
 set -e
 export PIES_PROFILER_SAFE=1 TMPDIR=/tmp
-ROOT=$PWD; out=$ROOT/gpurun_out/moving; rm -rf $out; mkdir -p $out
-(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $out -o t -- python3 $ROOT/scratch/prof_moving.py > $out/log.txt 2>&1) || { tail -5 $out/log.txt; exit 1; }
+ROOT=$PWD; out=$ROOT/gpurun_out/moving_config3; rm -rf $out; mkdir -p $out
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $out -o t -- python3 $ROOT/tools/profile_moving_config3.py > $out/log.txt 2>&1) || { tail -5 $out/log.txt; exit 1; }
 python3 - $out/t_kernel_trace.csv <<'PY'
 import csv,sys,collections
 rows=list(csv.DictReader(open(sys.argv[1])))

@@ -1,8 +1,10 @@
 #!/bin/bash
+# Kernel trace of config 4 once the burst is over (ticks 9-11 of 12, 64 captured level launches): per-kernel averages.
+# On the GPU box: bash tools/profile_settled_config4.sh > gpurun_out/r03_settled_config4.txt (copied to profiles/ afterwards).
 set -e
 export PIES_PROFILER_SAFE=1 TMPDIR=/tmp
 ROOT=$PWD; out=$ROOT/gpurun_out/c4s; rm -rf $out; mkdir -p $out
-(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $out -o t -- python3 $ROOT/scratch/prof_c4_settled.py > $out/log.txt 2>&1) || { tail -5 $out/log.txt; exit 1; }
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $out -o t -- python3 $ROOT/tools/profile_settled_config4.py > $out/log.txt 2>&1) || { tail -5 $out/log.txt; exit 1; }
 tail -1 $out/log.txt
 python3 - $out/t_kernel_trace.csv <<'PY'
 import csv,sys,collections
@@ -21,4 +23,4 @@ print("per tick (us): total %.1f   wall %.1f"%(sum(dur.values())/T,(int(seg[-1][
 for n in sorted(dur,key=lambda n:-dur[n])[:22]:
     print("  %-36s x%6.1f  avg %8.2f  per tick %8.1f   (>6us: x%.1f avg %.1f)"%(n,cnt[n]/T,dur[n]/cnt[n],dur[n]/T,wcnt[n]/T,work[n]/max(1,wcnt[n])))
 PY
-rm -f $out/t_kernel_trace.csv
+
