@@ -19,3 +19,4 @@ print("per tick (us): total %.1f"%(sum(dur.values())/5))
 for n in sorted(dur,key=lambda n:-dur[n]):
     print("  %-36s x%5.1f  avg %7.2f  per tick %7.1f"%(n,cnt[n]/5,dur[n]/cnt[n],dur[n]/5))
 PY
+rm -f $out/t_kernel_trace.csv

@@ -24,3 +24,4 @@ for n in sorted(dur,key=lambda n:-dur[n])[:22]:
     print("  %-36s x%6.1f  avg %8.2f  per tick %8.1f   (>6us: x%.1f avg %.1f)"%(n,cnt[n]/T,dur[n]/cnt[n],dur[n]/T,wcnt[n]/T,work[n]/max(1,wcnt[n])))
 PY
 
+rm -f $out/t_kernel_trace.csv
