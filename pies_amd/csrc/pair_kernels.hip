@@ -35,7 +35,15 @@ constexpr int kBlock = 256;
 constexpr uint32_t kMaxCand = 512;                         // distinct nodes of a group's 2x2x2 cells (BASELINE config 4: 216-343)
 constexpr uint32_t kMaxOwn = 256;                          // nodes of one group
 constexpr uint32_t kMaxDeg = 1024;                         // listed partners of one node
-constexpr uint32_t kPairNodeMask = 0x0fffffffu;            // partner index; the four bits above hold (shared cells - 1)
+constexpr uint32_t kPairNodeMask = 0x01ffffffu;            // partner index (n < 2^25); bits 28-31 hold (shared cells - 1)
+// Bits 25-27 of a record's current entry carry the low three bits of the cursor it belongs to.  A record is four words, written
+// and read with one 16-byte access each, and a lane looks at the records of nodes that other lanes may be moving on in the same
+// launch.  The protocol is safe with the old or the new record; an experiment that made lanes read records later in a launch
+// (a lane going on to its node's next pair: half the levels, but each three times as long - dropped) showed readers that got the
+// cursor / stamp word of one version with the entry word of the next.  The tag makes such a view recognisable; a reader that
+// gets one leaves the pair alone, like one that finds the node moved on in this round (whoever moved it sees to it).
+constexpr uint32_t kPairTagShift = 25;
+PIES_DEV bool rec_consistent(const uint4& r) { return ((r.w >> kPairTagShift) & 7u) == (r.z & 7u); }
 constexpr int kBuildWaves = 2;                            // wavefronts of a workgroup of the list kernel: one group at a time
 
 // oracle/ora_math.h: pair_key - direction class and parity of the pair from the positions the grid was built from, then
@@ -651,7 +659,7 @@ PIES_DEV void process_frontier(const HashArrays& H, const PairArrays& P, float f
   // moves a node on to its next entry (reached in this round); returns whether it has one
   auto move_on = [&](uint32_t i, const uint4 r) {
     const uint32_t c = (r.z & 0xffffu) + 1u;
-    const uint32_t entry = c < r.y ? P.nbr[r.x + c] : 0u;
+    const uint32_t entry = (c < r.y ? P.nbr[r.x + c] : 0u) | ((c & 7u) << kPairTagShift);
     store_rec(node, i, make_uint4(r.x, r.y, c | (stampNow << 16), entry));
     return c < r.y;
   };
@@ -664,11 +672,11 @@ PIES_DEV void process_frontier(const HashArrays& H, const PairArrays& P, float f
       x = xe;
       const uint4 rx = load_rec(node, x);
       // (x's own record must still be the one it reached in the last round: its partner's lane may have moved it on already)
-      if ((rx.z & 0xffffu) < rx.y && (rx.z >> 16) == stampPrev) {
+      if (rec_consistent(rx) && (rx.z & 0xffffu) < rx.y && (rx.z >> 16) == stampPrev) {
         y = rx.w & kPairNodeMask;
         const uint4 ry = load_rec(node, y);
         const uint32_t sy = ry.z >> 16;
-        bool take = (ry.z & 0xffffu) < ry.y && sy != stampNow && (ry.w & kPairNodeMask) == x;
+        bool take = rec_consistent(ry) && (ry.z & 0xffffu) < ry.y && sy != stampNow && (ry.w & kPairNodeMask) == x;
         if (take && sy == stampPrev && y < x) take = false;  // y is in this frontier as well and takes the pair
         if (take) {
           const bool xLow = x < y;
