@@ -109,12 +109,11 @@ void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, i
 // closeSolve: one more workgroup closes the statistics of the substep's last solve (k_cg_finish's work; maxIters = that solve's
 // captured iterations, tol its tolerance)
 void launch_pd_stabilize(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, bool closeSolve = false, int maxIters = 0, float tol = 0.0f);
-// staticFriction = false leaves the floor friction (Solver.cpp:473-484) to launch_pd_static_friction, which the
+// staticFriction = false leaves the floor friction (Solver.cpp:473-484) to the contacts' friction pass (launch_tri_friction), which the
 // reference runs after the point-triangle friction
 void launch_pd_velocity(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float h, float damping, float gravity,
                         float friction, float staticThreshold, bool staticFriction, const uint32_t* usedBits = nullptr);
 // usedBits (the point-triangle pipeline's bitmap of nodes in contacts): floor friction for the nodes outside it only
-void launch_pd_static_friction(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float friction, float staticThreshold);
 
 // workgroups of k_cg_update the device holds at once (0: unknown); the CG kernels' grid stays below it, see grid_barrier
 uint32_t cg_update_resident_blocks(int device);

@@ -1169,25 +1169,6 @@ __global__ void __launch_bounds__(kBlock) k_pd_velocity(const float4* __restrict
   vel[i] = make_float4(vx, vy, vz, 0.f);
 }
 
-// Solver.cpp:473-484 on its own (runs after the point-triangle friction when that pipeline is on)
-__global__ void __launch_bounds__(kBlock) k_pd_static_friction(float4* __restrict__ vel, const uint32_t* __restrict__ nstatic, uint32_t n,
-                                                               float friction, float staticThreshold) {
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t ns = nstatic[i];
-  if (!ns) return;
-  float4 v = vel[i];
-  for (uint32_t c = 0; c < ns; ++c) {
-    const float px = v.x, pz = v.z;
-    float fr = friction;
-    if (sqrtf(px * px + 0.0f * 0.0f + pz * pz) < staticThreshold) fr = 1.0f;
-    v.x += -fr * px;
-    v.y += -fr * 0.0f;
-    v.z += -fr * pz;
-  }
-  vel[i] = v;
-}
-
 // ------------------------------------------------------------------------------------------------------
 void launch_pd_predict(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float h, float contactHeight) {
   if (nd.n == 0) return;
@@ -1300,10 +1281,6 @@ void launch_pd_velocity(hipStream_t st, const NodeArrays& nd, const PdArrays& pd
   if (nd.n == 0) return;
   hipLaunchKernelGGL(k_pd_velocity, grid_for(nd.n), dim3(kBlock), 0, st, nd.pos, nd.prev, nd.vel, pd.nstatic, nd.n, h, damping, gravity,
                      friction, staticThreshold, staticFriction, usedBits);
-}
-void launch_pd_static_friction(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float friction, float staticThreshold) {
-  if (nd.n == 0) return;
-  hipLaunchKernelGGL(k_pd_static_friction, grid_for(nd.n), dim3(kBlock), 0, st, nd.vel, pd.nstatic, nd.n, friction, staticThreshold);
 }
 
 }  // namespace pies

@@ -1027,7 +1027,7 @@ PIES_DEV void level_barrier() {
   if (kSeqWorkers > 64) lds_barrier();
   else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
-// floor friction of one node (Solver.cpp:473-484, once per floor contact of the node; k_pd_static_friction's arithmetic)
+// floor friction of one node (Solver.cpp:473-484, once per floor contact of the node; the arithmetic of k_pd_velocity's floor-friction loop)
 PIES_DEV F3 floor_friction(F3 v, uint32_t ns, float friction, float staticThreshold) {
   for (uint32_t c = 0; c < ns; ++c) {
     const float px = v.x, pz = v.z;
