@@ -719,18 +719,117 @@ PIES_DEV void process_frontier(const HashArrays& H, const PairArrays& P, float f
   }
 }
 
-__global__ void __launch_bounds__(64) k_pair_round(HashArrays H, PairArrays P, float friction, float staticThreshold, uint32_t round, uint32_t repeat) {
+// One level as a launch of 256-thread workgroups.  Half the lanes of a frontier find that they have nothing to do (the other
+// node's lane takes the pair, or the partner is not there yet), and a lane that takes a pair runs up to sixteen visits of 350
+// instructions while the rest of its wavefront waits - with one wavefront per workgroup the 1 125 wavefronts of a settled
+// level of config 4 each carried a few such lanes, and the hundred SIMDs that got two of them set the level's time.  Here the
+// workgroup's four wavefronts look at their nodes, the lanes that take a pair put it into LDS, and the pairs are dealt out
+// again densely: the first wavefronts get full loads, the others leave.  Half as many wavefronts run visits, one per SIMD.
+constexpr uint32_t kRoundBlock = 256;
+struct TakenPair {
+  uint32_t x, y;
+  uint4 rx, ry;
+};
+__global__ void __launch_bounds__(kRoundBlock) k_pair_round(HashArrays H, PairArrays P, float friction, float staticThreshold, uint32_t round, uint32_t repeat) {
+  __shared__ TakenPair taken[kRoundBlock];
+  __shared__ uint32_t waveTook[kRoundBlock / 64];
   if (repeat && !P.ctl[kPairRetry]) return;
   if (H.counters[kCounterFlags]) return;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const FrontierView view = frontier_view(P, round, lane);
-  if (blockIdx.x == 0) {
-    P.frCount[(((round + 2u) % 3u) * kPairLists + threadIdx.x) * kPairPad] = 0;  // the lists of the round after the next (read by the previous launch, filled by the next)
-    if (threadIdx.x == 0 && view.total) { P.ctl[kPairRounds] = round; if (!repeat && round > P.ctl[kPairDeepest]) P.ctl[kPairDeepest] = round; }
+  if (blockIdx.x == 0 && wv == 0) {
+    P.frCount[(((round + 2u) % 3u) * kPairLists + static_cast<uint32_t>(lane)) * kPairPad] = 0;  // the lists of the round after the next (read by the previous launch, filled by the next)
+    if (lane == 0 && view.total) { P.ctl[kPairRounds] = round; if (!repeat && round > P.ctl[kPairDeepest]) P.ctl[kPairDeepest] = round; }
   }
-  if (view.total == 0u) return;  // (a pass that will be repeated is finished all the same: it finds every node that leaves its slack)
+  const uint32_t count = view.total;
+  if (count == 0u) return;  // (a pass that will be repeated is finished all the same: it finds every node that leaves its slack)
+  float4* node = P.node;
+  uint32_t* next = P.fr[(round + 1u) & 1u];
+  uint32_t* nextCount = P.frCount + ((round + 1u) % 3u) * kPairLists * kPairPad;
+  const uint32_t stampNow = round & 0xffffu, stampPrev = (round - 1u) & 0xffffu;
+  auto move_on = [&](uint32_t i, const uint4 r) {
+    const uint32_t c = (r.z & 0xffffu) + 1u;
+    const uint32_t entry = (c < r.y ? P.nbr[r.x + c] : 0u) | ((c & 7u) << kPairTagShift);
+    store_rec(node, i, make_uint4(r.x, r.y, c | (stampNow << 16), entry));
+    return c < r.y;
+  };
   uint32_t hits = 0;
-  process_frontier(H, P, friction, staticThreshold, round, blockIdx.x * 64u + threadIdx.x, gridDim.x * 64u, view, lane, hits);
+  for (uint32_t chunk = blockIdx.x; chunk * kRoundBlock < count; chunk += gridDim.x) {  // (workgroup uniform)
+    const uint32_t e = chunk * kRoundBlock + threadIdx.x;
+    // ---- who takes a pair
+    bool take = false;
+    uint32_t x = 0, y = 0;
+    uint4 rx = make_uint4(0u, 0u, 0u, 0u), ry = rx;
+    const uint32_t xe = frontier_node(P, view, round, min(e, count - 1u));  // (every lane takes part in the shuffles)
+    if (e < count) {
+      x = xe;
+      rx = load_rec(node, x);
+      // (x's own record must still be the one it reached in the last round: its partner's lane may have moved it on already)
+      if (rec_consistent(rx) && (rx.z & 0xffffu) < rx.y && (rx.z >> 16) == stampPrev) {
+        y = rx.w & kPairNodeMask;
+        ry = load_rec(node, y);
+        const uint32_t sy = ry.z >> 16;
+        take = rec_consistent(ry) && (ry.z & 0xffffu) < ry.y && sy != stampNow && (ry.w & kPairNodeMask) == x;
+        if (take && sy == stampPrev && y < x) take = false;  // y is in this frontier as well and takes the pair
+      }
+    }
+    // ---- the taken pairs, densely
+    const unsigned long long tm = __ballot(take);
+    if (lane == 0) waveTook[wv] = static_cast<uint32_t>(__popcll(tm));
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kRoundBlock / 64; ++w) {
+      const uint32_t c = waveTook[w];
+      if (w < static_cast<uint32_t>(wv)) before += c;
+      total += c;
+    }
+    if (take) taken[before + static_cast<uint32_t>(__popcll(tm & ((1ull << lane) - 1ull)))] = TakenPair{x, y, rx, ry};
+    __syncthreads();
+    // ---- the visits
+    bool moveX = false, moveY = false;
+    if (threadIdx.x < total) {
+      const TakenPair t = taken[threadIdx.x];
+      x = t.x; y = t.y;
+      const bool xLow = x < y;
+      const uint32_t lo = xLow ? x : y, hi = xLow ? y : x;
+      NodeState a = load_node(node, lo), b = load_node(node, hi);
+      const float dx = b.px - a.px, dy = b.py - a.py, dz = b.pz - a.pz;
+      const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+      if (a.r + b.r - dist > 0.0f) {
+        const float4 a0 = node[4u * lo + 2u], b0 = node[4u * hi + 2u];
+        const uint32_t m = P.nbrM ? P.nbrM[t.rx.x + (t.rx.z & 0xffffu)] : (t.rx.w >> 28) + 1u;  // (wide ranges keep the count beside the entry)
+        uint32_t h = 0;
+        for (uint32_t v = 0; v < m; ++v) h += visit(a, b, friction, staticThreshold) ? 1u : 0u;
+        for (uint32_t v = 0; v < m; ++v) h += visit(b, a, friction, staticThreshold) ? 1u : 0u;
+        store_node(node, lo, a);
+        store_node(node, hi, b);
+        note_excursion(P, lo, a, a0);
+        note_excursion(P, hi, b, b0);
+        hits += h;
+      }
+      moveX = move_on(x, t.rx);
+      moveY = move_on(y, t.ry);
+    }
+    // the nodes that moved on and have entries left go to the sub-list this wavefront's chunk is dealt to (one atomic per
+    // wavefront; a sub-list takes at most 128 nodes from each of its chunks: frCap covers that)
+    if (static_cast<uint32_t>(wv) * 64u < total) {  // (wavefront uniform)
+      const unsigned long long mx = __ballot(moveX), my = __ballot(moveY);
+      const uint32_t nx = static_cast<uint32_t>(__popcll(mx)), ny = static_cast<uint32_t>(__popcll(my));
+      if (nx + ny) {
+        const uint32_t sub = (chunk * (kRoundBlock / 64) + static_cast<uint32_t>(wv)) % kPairLists;
+        uint32_t at = 0;
+        if (lane == 0) at = atomicAdd(&nextCount[sub * kPairPad], nx + ny);
+        at = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(at)));
+        uint32_t* dst = next + static_cast<size_t>(sub) * P.frCap;
+        const uint32_t ix = at + static_cast<uint32_t>(__popcll(mx & ((1ull << lane) - 1ull)));
+        const uint32_t iy = at + nx + static_cast<uint32_t>(__popcll(my & ((1ull << lane) - 1ull)));
+        if (moveX && ix < P.frCap) dst[ix] = x;
+        if (moveY && iy < P.frCap) dst[iy] = y;
+      }
+    }
+    __syncthreads();  // (the table is reused by the next chunk)
+  }
   count_hits(P, hits, lane);
 }
 
@@ -881,7 +980,7 @@ uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArr
   uint32_t launches = 0;
   const dim3 perNode((n + kBlock - 1) / kBlock);
   const dim3 groups(std::max<uint32_t>(1u, std::min<uint32_t>(8192u, n / 8 + 1)));
-  const dim3 level(std::max<uint32_t>(1u, std::min<uint32_t>(8192u, (n + 63u) / 64u)));
+  const dim3 level(std::max<uint32_t>(1u, std::min<uint32_t>(2048u, (n + kRoundBlock - 1u) / kRoundBlock)));
   hipLaunchKernelGGL(k_pair_save, perNode, dim3(kBlock), 0, st, H, P, nd.pos, nd.vel, nd.radius, friction, staticThreshold); ++launches;
   const bool wide = P.nbrM != nullptr;  // ranges of more than two cells per axis: lists node by node
   if (!wide) { hipLaunchKernelGGL(k_pair_groups, dim3(std::min<uint32_t>(2048u, (H.capacity / 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, H, P, 0u); ++launches; }
@@ -897,7 +996,7 @@ uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArr
     // nothing is repeated)
     const uint32_t captured = repeat ? rounds + rounds / 2u : rounds;
     for (uint32_t r = 1; r <= captured; ++r) {
-      hipLaunchKernelGGL(k_pair_round, level, dim3(64), 0, st, H, P, friction, staticThreshold, r, repeat); ++launches;
+      hipLaunchKernelGGL(k_pair_round, level, dim3(kRoundBlock), 0, st, H, P, friction, staticThreshold, r, repeat); ++launches;
     }
     hipLaunchKernelGGL(k_pair_tail, dim3(1), dim3(1024), 0, st, H, P, friction, staticThreshold, captured + 1u, repeat); ++launches;
     hipLaunchKernelGGL(k_pair_verify, dim3(64), dim3(kBlock), 0, st, H, P, repeat); ++launches;
