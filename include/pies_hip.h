@@ -251,7 +251,8 @@ int pies_set_collision_rounds(pies_solver_t* s, uint32_t rounds);
 /* Tuning and diagnostic switches, process wide, by name (value NULL or "" unsets): graph variants and sizes that tests and
  * profiling scripts pin - PIES_PCG_BUDGET, PIES_PCG_OVERFLOW, PIES_TRI_FAST_ROWS, PIES_TRI_LDS, PIES_ROW_MAX_UNIQUE, PIES_TRI_SIDE,
  * PIES_NO_GRAPH, PIES_NO_WAVEFRONT, PIES_NO_TET_PAIRS, PIES_PD_LOCAL_PACKED (0: one element per lane in the PD strain + volume step),
- * PIES_PD_REST_DICT (0: per-element constants instead of the rest dictionary), PIES_LAYER_ONE_STRIP_MAX / _TILE_NODES / _STRIPS_MIN_NODES / PIES_LAYER_BLOCK,
+ * PIES_PD_REST_DICT (0: per-element constants instead of the rest dictionary), PIES_PD_ROW_DICT (0: the PD system matrix as SELL
+ * arrays only, no row dictionary), PIES_LAYER_ONE_STRIP_MAX / _TILE_NODES / _STRIPS_MIN_NODES / PIES_LAYER_BLOCK,
  * PIES_COLOUR_ROUNDS, PIES_COLOUR_DSATUR, PIES_NO_COLOUR_HINT, PIES_SELL_LANES, PIES_CG_BLOCKS, PIES_COLLIDE_GLOBAL / _PASSES /
  * _SPIN_LIMIT.  They take effect where the library reads them (pies_create, pies_finalize or the next graph capture).  None of
  * them is read from the environment: the only environment variables the library looks at are PIES_SCHEDULE (default schedule

@@ -26,6 +26,13 @@ struct CgArrays {
   const uint32_t* sliceOff;  // slices + 1 offsets (in entries)
   const uint32_t* col;
   const float* val;
+  // Row dictionary (pd_setup.cpp; nullptr: none): rows with the same stencil - the same column offsets from the row's own index
+  // and the same values, which is every interior row of a lattice and every class of boundary row - share one copy of it.  A row
+  // is then a 16-bit stencil id, and the SpMV reads (offset, value) pairs that stay in the vector cache instead of 8 bytes per
+  // stored entry from HBM.  Same entries in the same order as the SELL arrays: the sums are bit for bit the same.
+  const uint16_t* rowStencil;  // per row
+  const uint32_t* stencilAt;   // per stencil: first pair, and (at [id + 1]) the end
+  const int2* stencil;         // (column - row, bits of the value)
   float* cdiag;  // diagonal of the collision matrix (floor contacts)
   float* dinv;   // 1 / diag(K + C)
   float4 *r, *z, *p[2], *ap;

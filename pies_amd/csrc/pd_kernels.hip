@@ -800,16 +800,32 @@ __global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __
   float acc9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t sl = sw.begin; sl < sw.end; sl += sw.step) {
     const uint32_t i = sl * (64u / LPR) + lane / LPR;
-    const uint32_t off = A.sliceOff[sl], width = (A.sliceOff[sl + 1] - off) >> 6;
     float sx = 0.f, sy = 0.f, sz = 0.f;
+    if (LPR == 1 && A.rowStencil) {  // row dictionary: the row's (column - row, value) pairs, shared by every row like it
+      if (i < A.n) {
+        const uint32_t id = A.rowStencil[i];
+        const uint32_t b = A.stencilAt[id], e = A.stencilAt[id + 1u];
 #pragma unroll 4
-    for (uint32_t k = 0; k < width; ++k) {
-      const uint32_t at = off + (k << 6) + lane;
-      const float a = A.val[at];
-      const float4 xj = x[A.col[at]];
-      sx = fmaf(a, xj.x, sx);
-      sy = fmaf(a, xj.y, sy);
-      sz = fmaf(a, xj.z, sz);
+        for (uint32_t k = b; k < e; ++k) {
+          const int2 p = A.stencil[k];
+          const float a = __int_as_float(p.y);
+          const float4 xj = x[static_cast<uint32_t>(static_cast<int>(i) + p.x)];
+          sx = fmaf(a, xj.x, sx);
+          sy = fmaf(a, xj.y, sy);
+          sz = fmaf(a, xj.z, sz);
+        }
+      }
+    } else {
+      const uint32_t off = A.sliceOff[sl], width = (A.sliceOff[sl + 1] - off) >> 6;
+#pragma unroll 4
+      for (uint32_t k = 0; k < width; ++k) {
+        const uint32_t at = off + (k << 6) + lane;
+        const float a = A.val[at];
+        const float4 xj = x[A.col[at]];
+        sx = fmaf(a, xj.x, sx);
+        sy = fmaf(a, xj.y, sy);
+        sz = fmaf(a, xj.z, sz);
+      }
     }
     row_combine<LPR>(sx, sy, sz);
     if (i < A.n && lane % LPR == 0u) {
@@ -843,8 +859,36 @@ template <int LPR> PIES_DEV void cg_ap_rows(const CgArrays& A, int k, const floa
   const SliceSweep sw = slice_sweep<LPR>(A.n, A.nparts);
   for (uint32_t sl = sw.begin; sl < sw.end; sl += sw.step) {
     const uint32_t i = sl * (64u / LPR) + lane / LPR;
-    const uint32_t off = A.sliceOff[sl], width = (A.sliceOff[sl + 1] - off) >> 6;
     float sx = 0.f, sy = 0.f, sz = 0.f;
+    if (LPR == 1 && A.rowStencil) {  // row dictionary (see k_cg_init)
+      if (i < A.n) {
+        const uint32_t id = A.rowStencil[i];
+        const uint32_t sb = A.stencilAt[id], se = A.stencilAt[id + 1u];
+        if (k > 0) {
+#pragma unroll 4
+          for (uint32_t q = sb; q < se; ++q) {
+            const int2 pr = A.stencil[q];
+            const float a = __int_as_float(pr.y);
+            const uint32_t j = static_cast<uint32_t>(static_cast<int>(i) + pr.x);
+            const float4 zj = A.z[j], pj = pold[j];
+            sx = fmaf(a, fmaf(beta[0], pj.x, zj.x), sx);
+            sy = fmaf(a, fmaf(beta[1], pj.y, zj.y), sy);
+            sz = fmaf(a, fmaf(beta[2], pj.z, zj.z), sz);
+          }
+        } else {
+#pragma unroll 4
+          for (uint32_t q = sb; q < se; ++q) {
+            const int2 pr = A.stencil[q];
+            const float a = __int_as_float(pr.y);
+            const float4 zj = A.z[static_cast<uint32_t>(static_cast<int>(i) + pr.x)];
+            sx = fmaf(a, zj.x, sx);
+            sy = fmaf(a, zj.y, sy);
+            sz = fmaf(a, zj.z, sz);
+          }
+        }
+      }
+    } else {
+    const uint32_t off = A.sliceOff[sl], width = (A.sliceOff[sl + 1] - off) >> 6;
     if (k > 0) {
 #pragma unroll 4
       for (uint32_t kk = 0; kk < width; ++kk) {
@@ -866,6 +910,7 @@ template <int LPR> PIES_DEV void cg_ap_rows(const CgArrays& A, int k, const floa
         sy = fmaf(a, zj.y, sy);
         sz = fmaf(a, zj.z, sz);
       }
+    }
     }
     row_combine<LPR>(sx, sy, sz);
     if (i < A.n && lane % LPR == 0u) {

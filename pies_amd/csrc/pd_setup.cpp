@@ -9,11 +9,18 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <numeric>
+#include <vector>
 
 #include "device_util.h"
 
 namespace pies {
+struct int2_host {
+  int x, y;
+  bool operator<(const int2_host& o) const { return x != o.x ? x < o.x : y < o.y; }
+};
+static_assert(sizeof(int2_host) == 8, "layout of int2");
 
 namespace {
 struct Entry {
@@ -191,6 +198,47 @@ int pd_build(pies_solver* s) {
   if (int rc = upload(s, triCount, &d_tri)) return rc;
 
   cg.sliceOff = d_rowptr; cg.col = d_col; cg.val = d_val;
+  // Row dictionary: every row as (column - row, value) pairs; rows with equal sequences share an entry.  Used when the scene
+  // has few distinct rows (a lattice: the interior row and the classes of boundary rows, a few hundred at most).
+  cg.rowStencil = nullptr; cg.stencilAt = nullptr; cg.stencil = nullptr;
+  {
+    const char* e = tuning_env("PIES_PD_ROW_DICT");
+    if (lpr == 1u && n != 0 && !(e && e[0] == '0')) {
+      std::map<std::vector<int2_host>, uint16_t> ids;
+      std::vector<uint16_t> rowStencil(n);
+      std::vector<uint32_t> stencilAt(1, 0);
+      std::vector<int2_host> stencil;
+      bool ok = true;
+      std::vector<int2_host> key;
+      for (uint32_t i = 0; ok && i < n; ++i) {
+        key.clear();
+        for (uint32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+          int2_host p;
+          p.x = static_cast<int>(col[k]) - static_cast<int>(i);
+          std::memcpy(&p.y, &val[k], sizeof(float));
+          key.push_back(p);
+        }
+        auto it = ids.find(key);
+        if (it == ids.end()) {
+          if (ids.size() >= 4096 || (ids.size() + 1) * 8 > n) { ok = false; break; }  // no real compression: the SELL arrays
+          it = ids.emplace(key, static_cast<uint16_t>(ids.size())).first;
+          stencil.insert(stencil.end(), key.begin(), key.end());
+          stencilAt.push_back(static_cast<uint32_t>(stencil.size()));
+        }
+        rowStencil[i] = it->second;
+      }
+      if (ok) {
+        uint16_t* d_rs;
+        uint32_t* d_sa;
+        int2_host* d_st;
+        if (int rc = upload(s, rowStencil, &d_rs)) return rc;
+        if (int rc = upload(s, stencilAt, &d_sa)) return rc;
+        if (int rc = upload(s, stencil, &d_st)) return rc;
+        cg.rowStencil = d_rs; cg.stencilAt = d_sa; cg.stencil = reinterpret_cast<const int2*>(d_st);
+        s->pdRowStencils = static_cast<uint32_t>(ids.size());
+      }
+    }
+  }
   cg.lanesPerRow = lpr;
   pd.kdiag = d_kdiag; pd.incPtr = d_incPtr; pd.incSlot = d_incSlot; pd.triCount = d_tri;
   pd.contribD = nullptr; pd.incPtrD = nullptr; pd.incSlotD = nullptr;

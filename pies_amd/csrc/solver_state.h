@@ -168,6 +168,7 @@ struct pies_solver {
   uint16_t* d_pairDictIndex = nullptr;  // PD, paired elements: index of the element's set of constants (rest dictionary), or nullptr
   float4* d_pairDictTable = nullptr;
   uint32_t pairDictSets = 0;
+  uint32_t pdRowStencils = 0;           // PD: distinct rows of the system matrix in its row dictionary (0: none)
   bool tetVolumePaired = false;    // PD: h_volume[k] and h_tet[k] are the same element for every k (fused local step)
   bool triangleCollisions = true;  // PD point-triangle CCD contacts (Solver.cpp:693-797); extension flag to switch off
   bool simFailed = false;
