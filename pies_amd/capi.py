@@ -27,6 +27,7 @@ KERNEL_PREDICT, KERNEL_POSITION, KERNEL_DISTANCE, KERNEL_TET, KERNEL_BEND, KERNE
 KERNEL_COUNT = 19
 SYSTEM_NNZ = 10
 REST_SETS = 11
+ROW_STENCILS = 12
 
 # every symbol include/pies_hip.h declares (checked by tests/test_capi_symbols.py against the header)
 SYMBOLS = [

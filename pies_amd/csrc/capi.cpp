@@ -1625,6 +1625,7 @@ int pies_count(const pies_solver_t* s, int what, uint32_t* out) {
     case PIES_NODES: *out = s->nodeCount(); break;
     case PIES_SYSTEM_NNZ: *out = s->pd_nnz; break;
     case PIES_REST_SETS: *out = s->pdLocalPacked && s->d_pairDictIndex ? s->pairDictSets : 0u; break;
+    case PIES_ROW_STENCILS: *out = s->pd.cg.rowStencil ? s->pdRowStencils : 0u; break;
     default: return PIES_ERR_INVALID;
   }
   return PIES_OK;

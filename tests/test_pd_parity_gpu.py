@@ -171,6 +171,29 @@ def test_pd_local_step_variants_agree(pies, oracle, tune):
     assert np.abs(res[0] - res[1]).max() <= 0.1 * TOL and np.abs(res[1] - res[2]).max() <= 0.1 * TOL
 
 
+def test_row_dictionary_changes_nothing(pies, tune):
+    """The system matrix as a row dictionary (rows with the same stencil share one copy: column offsets from the row and values)
+    against the SELL arrays: the same entries in the same order, so the same sums - positions equal bit for bit after four
+    ticks, pins, floor contacts and two materials included."""
+    res = []
+    for flag in ("0", "1"):
+        tune("PIES_PD_ROW_DICT", flag)
+        g = pies.Solver(pd_options(pies, 6))
+        g.create_tet_box(12, 12, 14, translation=(0.0, 0.02, 0.0), w=1.0, volume=True, triangles=True)
+        g.create_tet_box(6, 5, 7, translation=(20.0, 0.5, 1.0), w=3.0, volume=True, triangles=True)
+        scenes.perturb(g, 17, 0.05)
+        g.set_prev_positions(g.positions)
+        g.add_position(np.arange(0, 35, dtype=np.uint32), 2.0)
+        g.tick(4)
+        assert not g.failed
+        stencils = g.count(pies.ROW_STENCILS)
+        assert (stencils > 0) == (flag == "1") and stencils * 8 <= g.count(pies.NODES), stencils
+        res.append((g.positions, g.velocities, g.pcg_stats()))
+        g.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2]
+
+
 def test_pd_flattened_and_inverted_elements(pies, oracle):
     """Elements with a collapsed direction (a layer of nodes pressed into the layer below: s = 0, the rotation is completed from
     the other two directions, dev_math.h svd3_recompose) and inverted ones (a node pushed through the opposite face: the
