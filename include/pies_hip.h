@@ -72,8 +72,8 @@ enum {
   PIES_LINES = 8,
   PIES_NODES = 9,
   PIES_SYSTEM_NNZ = 10, /* pies_count only: stored entries of the PD system matrix (after pies_finalize) */
-  PIES_REST_SETS = 11   /* pies_count only: distinct sets of element constants in the PD local step's rest dictionary (0: the
-                         * per-element arrays are read; after pies_finalize) */,
+  PIES_REST_SETS = 11,  /* pies_count only: distinct sets of element constants in the PD local step's rest dictionary (0: the
+                         * per-element arrays are read; after pies_finalize) */
   PIES_ROW_STENCILS = 12 /* pies_count only: distinct rows in the row dictionary of the PD system matrix (0: SELL arrays only) */
 };
 
