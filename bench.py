@@ -486,7 +486,7 @@ def run_config3(device, full):
            "roofline_spmv": roofline(g, "pd_spmv", B["pd_spmv"], workload="config3", note="SELL-64 SpMV over 3 right-hand sides + fused direction "
                                      "update; 8 nnz + 28 N bytes per launch (SURVEY 8d); the solves of the timed pass do not take "
                                      "the converged early exit.  On a lattice the launch does not stream the matrix: rows with the same "
-                                     "stencil share one copy of it (row dictionary, DESIGN.md section 5), a row is a 16-bit id"),
+                                     "stencil share one copy of it (row dictionary, DESIGN.md section 5), a row is one word"),
            "roofline_rhs": roofline(g, "pd_rhs", B["pd_rhs"], workload="config3")}
     if full:
         out["isolated_replay_latencies"] = replay_latencies(g)

@@ -28,10 +28,9 @@ struct CgArrays {
   const float* val;
   // Row dictionary (pd_setup.cpp; nullptr: none): rows with the same stencil - the same column offsets from the row's own index
   // and the same values, which is every interior row of a lattice and every class of boundary row - share one copy of it.  A row
-  // is then a 16-bit stencil id, and the SpMV reads (offset, value) pairs that stay in the vector cache instead of 8 bytes per
+  // is then one word (where its stencil starts and how long it is), and the SpMV reads (offset, value) pairs that stay in the vector cache instead of 8 bytes per
   // stored entry from HBM.  Same entries in the same order as the SELL arrays: the sums are bit for bit the same.
-  const uint16_t* rowStencil;  // per row
-  const uint32_t* stencilAt;   // per stencil: first pair, and (at [id + 1]) the end
+  const uint32_t* rowStencil;  // per row: first pair of its stencil | pairs << 24 (one word: no second look-up on the row's chain of loads)
   const int2* stencil;         // (column - row, bits of the value)
   float* cdiag;  // diagonal of the collision matrix (floor contacts)
   float* dinv;   // 1 / diag(K + C)

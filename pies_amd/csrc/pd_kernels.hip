@@ -803,8 +803,8 @@ __global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __
     float sx = 0.f, sy = 0.f, sz = 0.f;
     if (LPR == 1 && A.rowStencil) {  // row dictionary: the row's (column - row, value) pairs, shared by every row like it
       if (i < A.n) {
-        const uint32_t id = A.rowStencil[i];
-        const uint32_t b = A.stencilAt[id], e = A.stencilAt[id + 1u];
+        const uint32_t rs = A.rowStencil[i];
+        const uint32_t b = rs & 0xffffffu, e = b + (rs >> 24);
 #pragma unroll 4
         for (uint32_t k = b; k < e; ++k) {
           const int2 p = A.stencil[k];
@@ -862,8 +862,8 @@ template <int LPR> PIES_DEV void cg_ap_rows(const CgArrays& A, int k, const floa
     float sx = 0.f, sy = 0.f, sz = 0.f;
     if (LPR == 1 && A.rowStencil) {  // row dictionary (see k_cg_init)
       if (i < A.n) {
-        const uint32_t id = A.rowStencil[i];
-        const uint32_t sb = A.stencilAt[id], se = A.stencilAt[id + 1u];
+        const uint32_t rs = A.rowStencil[i];
+        const uint32_t sb = rs & 0xffffffu, se = sb + (rs >> 24);
         if (k > 0) {
 #pragma unroll 4
           for (uint32_t q = sb; q < se; ++q) {

@@ -200,12 +200,12 @@ int pd_build(pies_solver* s) {
   cg.sliceOff = d_rowptr; cg.col = d_col; cg.val = d_val;
   // Row dictionary: every row as (column - row, value) pairs; rows with equal sequences share an entry.  Used when the scene
   // has few distinct rows (a lattice: the interior row and the classes of boundary rows, a few hundred at most).
-  cg.rowStencil = nullptr; cg.stencilAt = nullptr; cg.stencil = nullptr;
+  cg.rowStencil = nullptr; cg.stencil = nullptr;
   {
     const char* e = tuning_env("PIES_PD_ROW_DICT");
     if (lpr == 1u && n != 0 && !(e && e[0] == '0')) {
       std::map<std::vector<int2_host>, uint16_t> ids;
-      std::vector<uint16_t> rowStencil(n);
+      std::vector<uint32_t> rowStencil(n);
       std::vector<uint32_t> stencilAt(1, 0);
       std::vector<int2_host> stencil;
       bool ok = true;
@@ -220,21 +220,19 @@ int pd_build(pies_solver* s) {
         }
         auto it = ids.find(key);
         if (it == ids.end()) {
-          if (ids.size() >= 4096 || (ids.size() + 1) * 8 > n) { ok = false; break; }  // no real compression: the SELL arrays
+          if (ids.size() >= 4096 || (ids.size() + 1) * 8 > n || key.size() > 255 || stencil.size() + key.size() >= (1u << 24)) { ok = false; break; }  // no real compression: the SELL arrays
           it = ids.emplace(key, static_cast<uint16_t>(ids.size())).first;
           stencil.insert(stencil.end(), key.begin(), key.end());
           stencilAt.push_back(static_cast<uint32_t>(stencil.size()));
         }
-        rowStencil[i] = it->second;
+        rowStencil[i] = stencilAt[it->second] | (static_cast<uint32_t>(key.size()) << 24);
       }
       if (ok) {
-        uint16_t* d_rs;
-        uint32_t* d_sa;
+        uint32_t* d_rs;
         int2_host* d_st;
         if (int rc = upload(s, rowStencil, &d_rs)) return rc;
-        if (int rc = upload(s, stencilAt, &d_sa)) return rc;
         if (int rc = upload(s, stencil, &d_st)) return rc;
-        cg.rowStencil = d_rs; cg.stencilAt = d_sa; cg.stencil = reinterpret_cast<const int2*>(d_st);
+        cg.rowStencil = d_rs; cg.stencil = reinterpret_cast<const int2*>(d_st);
         s->pdRowStencils = static_cast<uint32_t>(ids.size());
       }
     }
