@@ -118,8 +118,9 @@ def pmc_traffic(kernel_name, workload):
 
 
 def pmc_traffic_of_pass(prefix, workload, anchor):
-    """HBM bytes per PASS of a multi-kernel stage (the pair-ordered resolve: k_pair_*): the sum over its kernels of
-    (bytes per launch x launches) in the committed --pmc passes, per launch of `anchor` (a kernel that runs once per pass)."""
+    """HBM bytes per PASS of a multi-kernel stage (the pair-ordered resolve: k_pair_*; the grid rebuild: k_grid_*, k_scan_*,
+    k_radix_* - `prefix` may be a tuple): the sum over its kernels of (bytes per launch x launches) in the committed --pmc
+    passes, per launch of `anchor` (a kernel that runs once per pass)."""
     for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")), reverse=True):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -127,7 +128,8 @@ def pmc_traffic_of_pass(prefix, workload, anchor):
             passes = w.get(anchor, {}).get("dispatches")
             if passes:
                 total = sum(v["hbm_bytes_per_launch"] * v["dispatches"] for k, v in w.items() if k.startswith(prefix))
-                return total / passes, "profiles/%s [%s][%s*] per %s" % (name, workload, prefix, anchor)
+                label = prefix if isinstance(prefix, str) else " + ".join(p + "*" for p in prefix)
+                return total / passes, "profiles/%s [%s][%s] per %s" % (name, workload, label, anchor)
         except (OSError, ValueError, AttributeError, KeyError, TypeError):
             pass
     return None, None
@@ -180,11 +182,13 @@ def roofline(solver, cls, bytes_per_unit, substeps=3, note=None, workload="confi
     if clamped:
         net_ms = ms
     achieved = nbytes / (net_ms * 1e-3) / 1e9
-    traffic, src = pmc_traffic_of_pass("k_pair_", workload, "k_pair_save") if cls == "collide" else pmc_traffic(kname, workload)
+    stage = {"collide": (("k_pair_",), "k_pair_save", "k_pair_* (one pass)", "k_pair_round"),
+             "hash": (("k_grid_", "k_scan_", "k_radix_"), "k_grid_range", "k_grid_* + k_scan_* + k_radix_* (one rebuild)", "k_radix_scatter")}.get(cls)
+    traffic, src = pmc_traffic_of_pass(stage[0], workload, stage[1]) if stage else pmc_traffic(kname, workload)
     if traffic is not None and traffic < 0.01 * nbytes / launches:
         # the committed --pmc pass averaged launches most of which returned at once (CG kernels of a solve that had converged)
         traffic, src = None, "%s: average over launches that mostly exit at once - not a figure for the working launch" % src
-    out = {"bound": "hbm", "kernel": "k_pair_* (one pass)" if cls == "collide" else kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    out = {"bound": "hbm", "kernel": stage[2] if stage else kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": achieved / HBM_PEAK_GBS,
            "traffic": traffic, "traffic_source": src, "avg_launch_us": 1e3 * net_ms / launches, "launches_timed": launches,
            "bytes_per_launch": nbytes / launches, "avg_bracket_us": 1e3 * ms / launches, "bracket_overhead_us": 1e3 * overhead_ms,
@@ -607,7 +611,10 @@ def run_config4(device):
                                 "iteration, taken after tick 22 (settled state); bytes per node = 32 + 27 x 8 + 16 x candidates the "
                                 "reference's loop looks at in that state"),
            "roofline_grid_build": roofline(g, "hash", 92.0, substeps=1, workload="config4", note="one bracket = one grid rebuild: range, prefix "
-                                           "sum, emit, radix sort passes, cell index (about 92 B per node, SURVEY 8d)")}
+                                           "sum, emit, radix sort passes, cell index (about 92 B per node, SURVEY 8d - a figure for one "
+                                           "entry per node; a node of this scene overlaps 8 cells, i.e. 8 (key, node) entries of 12 bytes "
+                                           "that are emitted, counted and scattered twice and scanned once more: `traffic` is the PMC "
+                                           "figure of the whole rebuild, about ten times the survey's bytes)")}
     g.close()
     return out
 
