@@ -22,6 +22,7 @@ struct GridBox {
   uint32_t ext[3];   // max - min per axis
   uint32_t bits[3];
   uint32_t passes, digit;  // the build's radix sort: passes captured in the substep graph, key bits a pass sorts by
+  bool packed;             // the key has at most 32 bits: an entry travels through the sort as ONE 64-bit word, key << 32 | value
   bool empty;
 };
 constexpr uint32_t kRadixMaxDigit = 11;  // bits per pass at most (2048 bins)
@@ -42,6 +43,7 @@ PIES_DEV GridBox grid_box(const uint32_t* __restrict__ counters) {
   B.passes = counters[kCounterSortPasses];
   const uint32_t total = B.bits[0] + B.bits[1] + B.bits[2];
   B.digit = B.passes ? min(kRadixMaxDigit, (total + B.passes - 1u) / B.passes) : 0u;
+  B.packed = total <= 32u;
   return B;
 }
 PIES_DEV uint32_t grid_passes(const GridBox& B) { return B.passes; }

@@ -265,8 +265,12 @@ __global__ void __launch_bounds__(kBlock) k_grid_emit(HashArrays H, uint32_t n) 
     const uint32_t node = blockIdx.x * kBlock + (threadIdx.x & ~63u) + l;
     const uint32_t side = (dx ? 4u : 0u) | (dy ? 2u : 0u) | (dz ? 1u : 0u);
     const uint32_t twoLong = (olx == 2u ? 4u : 0u) | (oly == 2u ? 2u : 0u) | (olz == 2u ? 1u : 0u);
-    H.key[0][ob + e] = box_key(B, ox + static_cast<int>(dx), oy + static_cast<int>(dy), oz + static_cast<int>(dz));
-    H.val[0][ob + e] = node | (twoLong << kLongShift) | (side << kSideShift) | (e == 0 ? kMinFlag : 0u);  // e == 0: the node's minimum cell
+    const uint64_t key = box_key(B, ox + static_cast<int>(dx), oy + static_cast<int>(dy), oz + static_cast<int>(dz));
+    const uint32_t val = node | (twoLong << kLongShift) | (side << kSideShift) | (e == 0 ? kMinFlag : 0u);  // e == 0: the node's minimum cell
+    // A key of at most 32 bits (any scene but one that spans billions of cells) travels through the sort in one word with its
+    // value: 8 bytes per entry and pass instead of 8 + 4.  The last pass writes the values out for the kernels that read them.
+    if (B.packed) H.key[0][ob + e] = (key << 32) | val;
+    else { H.key[0][ob + e] = key; H.val[0][ob + e] = val; }
   }
   (void)waveBase;
 }
@@ -278,7 +282,7 @@ __global__ void __launch_bounds__(kBlock) k_radix_hist(HashArrays H, uint32_t pa
   __shared__ uint32_t h[1u << kRadixMaxDigit];
   const GridBox B = grid_box(H.counters);
   if (pass >= grid_passes(B)) return;
-  const uint32_t bins = 1u << B.digit, shift = B.digit * pass;
+  const uint32_t bins = 1u << B.digit, shift = B.digit * pass + (B.packed ? 32u : 0u);
   const uint32_t E = H.counters[kCounterEntries];
   const uint32_t blk = blockIdx.x;
   if (blk * kRadixTile >= E) return;
@@ -321,7 +325,8 @@ __global__ void __launch_bounds__(kBlock) k_radix_scatter(HashArrays H, uint32_t
   __shared__ uint32_t scanLds[8];
   const GridBox B = grid_box(H.counters);
   if (pass >= grid_passes(B)) return;
-  const uint32_t bins = 1u << B.digit, shift = B.digit * pass;
+  const uint32_t bins = 1u << B.digit, shift = B.digit * pass + (B.packed ? 32u : 0u);
+  const bool packed = B.packed, last = pass + 1u == grid_passes(B);
   const uint32_t E = H.counters[kCounterEntries];
   const uint32_t blk = blockIdx.x;
   if (blk * kRadixTile >= E) return;
@@ -341,7 +346,7 @@ __global__ void __launch_bounds__(kBlock) k_radix_scatter(HashArrays H, uint32_t
     const uint32_t t = first + static_cast<uint32_t>(r) * 64u + lane;
     const bool valid = t < E;
     key[r] = valid ? skey[t] : 0ull;
-    val[r] = valid ? sval[t] : 0u;
+    val[r] = (valid && !packed) ? sval[t] : 0u;
   }
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
@@ -403,7 +408,8 @@ __global__ void __launch_bounds__(kBlock) k_radix_scatter(HashArrays H, uint32_t
       const uint32_t d = static_cast<uint32_t>(key[r] >> shift) & (bins - 1u);
       const uint32_t at = gbase[d] + cnt[wave][d] + rank[r];
       dkey[at] = key[r];
-      dval[at] = val[r];
+      if (!packed) dval[at] = val[r];
+      else if (last) dval[at] = static_cast<uint32_t>(key[r]);  // (the values, for the kernels behind the sort)
     }
   }
 }
@@ -425,9 +431,10 @@ __global__ void __launch_bounds__(kBlock) k_grid_cells(HashArrays H) {
   for (uint32_t r = 0; r < kRadixTile / kBlock; ++r) {
     const uint32_t t = first + r * kBlock + threadIdx.x;
     if (t >= E) break;
-    const uint64_t k = key[t];
-    const bool head = t == 0 || key[t - 1] != k;
-    const bool tail = t + 1 == E || key[t + 1] != k;
+    const uint32_t ksh = B.packed ? 32u : 0u;  // (a packed entry: the key is the upper word)
+    const uint64_t k = key[t] >> ksh;
+    const bool head = t == 0 || (key[t - 1] >> ksh) != k;
+    const bool tail = t + 1 == E || (key[t + 1] >> ksh) != k;
     if (!(head || tail)) continue;
     bool created;
     const uint32_t slot = insert_cell(H.keys, H.mask, k, created);  // whichever of the bucket's two ends comes first creates it

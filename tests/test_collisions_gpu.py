@@ -209,6 +209,24 @@ def test_grid_sort_follows_a_growing_box(pies, oracle, rule):
     assert np.ptp(g.positions, axis=0).max() > 8 * np.ptp(p, axis=0).max()
 
 
+@RULES
+def test_clusters_far_apart_take_the_unpacked_sort(pies, oracle, rule):
+    """A cell key of at most 32 bits travels through the grid's sort in one word with its value; two clusters 800 000 units apart
+    on every axis make a box of 57 key bits - six passes of ten bits over (key, value) pairs, the path every other test's scene
+    is too small for.  Exact against the oracle in all three orders."""
+    p, v = particles((5, 4, 6))
+    q = (p + np.float32(8.0e5)).astype(np.float32)
+    pos = np.concatenate([p, q]).astype(np.float32)
+    vel = np.concatenate([v, v]).astype(np.float32)
+
+    def build(s):
+        s.addNodes(pos)
+        s.set_velocities(vel)
+    g, o = pair(pies, oracle, build, 2, 2, rule=rule)
+    check(g, o)
+    assert g.collision_pairs == o.collision_pairs > 100
+
+
 def test_a_box_that_outgrows_the_captured_sort_is_latched(pies):
     """...and a box that grows faster than the spare bits allow between two looks of the host (here: 60 times per axis inside the
     first tick) is a failure latch, not a wrong grid."""
