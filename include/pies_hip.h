@@ -107,10 +107,13 @@ enum {
    * set and per-pair arithmetic, different order).  Default: 1 under PIES_SCHEDULE_EXACT, 0 otherwise; setting the
    * flag overrides that until the schedule changes. */
   PIES_FLAG_REFERENCE_COLLISION_ORDER = 3,
-  /* The order of the PBD node-node pass, by name (value: PIES_COLLISION_ORDER_*).  Every order resolves the same meetings -
-   * node i meets node j once per grid cell both were inserted into, in each direction, itself included - with the
-   * reference's per-pair arithmetic; the loop is order dependent (Solver.cpp:85-130 moves both nodes at once).
-   *  REFERENCE : the reference's loop (see above).
+  /* The order of the PBD node-node pass, by name (value: PIES_COLLISION_ORDER_*).  Every order uses the reference's per-pair
+   * arithmetic; the loop is order dependent (Solver.cpp:85-130 moves both nodes at once).
+   *  REFERENCE : the reference's loop (see above): node i meets every node of every bucket of the cell range recomputed from
+   *              i's LIVE position when its turn comes (SpatialHash.h:101-106), in each direction, itself included.
+   *  PAIRS and GROUPS are a documented deviation: the same per-pair arithmetic, but node i meets node j once per grid cell
+   *  both were INSERTED into at the start of the iteration - the same meetings unless a node crosses a cell boundary
+   *  inside the pass, and a different order.
    *  PAIRS     : default under COLOURED / LAYERED.  A node's meetings with itself first, then the pairs {i < j} in
    *              ascending order of a 64-bit mix of (i, j), each as its m visits of i to j and m visits of j to i; executed
    *              by dependency levels, one lane per pair.
@@ -241,10 +244,6 @@ int pies_collision_pairs(pies_solver_t* s, uint64_t* pairs);
 /* The same plus the candidates the pass looked at (bucket entries visited, the unit of SURVEY 8d's "16 B per candidate
  * neighbour"); both counters restart. */
 int pies_collision_stats(pies_solver_t* s, uint64_t* pairs, uint64_t* candidates);
-/* Pair order (PIES_COLLISION_ORDER_PAIRS): the last pass's dependency levels and listed pairs; since pies_finalize, the passes
- * that were repeated with the widest slack because a node had moved further than the pair filter allows for, and the passes in
- * which a node moved further than even that (more than 0.5 in one pass: the result may then miss visits the documented order
- * makes).  Any pointer may be NULL. */
 /* Pair order: level launches captured per pass.  By default the library follows what the passes need at host synchronisations
  * (it starts at 96; BASELINE config 4 settles at 48-64); a call pins the count.  A single-workgroup kernel finishes deeper
  * orders than captured: slow, never wrong. */
@@ -255,12 +254,17 @@ int pies_set_collision_rounds(pies_solver_t* s, uint32_t rounds);
  * PIES_PD_REST_DICT (0: per-element constants instead of the rest dictionary), PIES_PD_ROW_DICT (0: the PD system matrix as SELL
  * arrays only, no row dictionary), PIES_LAYER_ONE_STRIP_MAX / _TILE_NODES / _STRIPS_MIN_NODES / PIES_LAYER_BLOCK,
  * PIES_COLOUR_ROUNDS, PIES_COLOUR_DSATUR, PIES_NO_COLOUR_HINT, PIES_SELL_LANES, PIES_CG_BLOCKS, PIES_COLLIDE_GLOBAL / _PASSES /
- * _SPIN_LIMIT.  They take effect where the library reads them (pies_create, pies_finalize or the next graph capture).  None of
+ * _SPIN_LIMIT.  They take effect where the library reads them (pies_create, pies_finalize or the next graph capture).  pies_set_tuning must not
+ * race with other API calls of the process (a handle reads the switches at different times of its life).  None of
  * them is read from the environment: the only environment variables the library looks at are PIES_SCHEDULE (default schedule
  * of new handles), PIES_PROFILER_SAFE (profiling runs) and the print-only PIES_PCG_DEBUG / PIES_LAYER_DEBUG. */
 int pies_set_tuning(const char* name, const char* value);
 /* Diagnostics of the pair order: per node the slack for the next pass, the excursion and the listed partners of the last pass. */
 int pies_debug_pair_state(pies_solver_t* s, float* slack, float* excursion, uint32_t* partners, uint32_t n);
+/* Pair order (PIES_COLLISION_ORDER_PAIRS): the last pass's dependency levels and listed pairs; since pies_finalize, the passes
+ * that were repeated with the widest slack because a node had moved further than the pair filter allows for, and the passes in
+ * which a node moved further than even that (more than 0.5 in one pass: the result may then miss visits the documented order
+ * makes).  Any pointer may be NULL. */
 int pies_get_collision_health(pies_solver_t* s, uint32_t* levels, uint32_t* pairs_listed, uint32_t* passes_repeated, uint32_t* passes_inexact);
 
 /* ---- state access --------------------------------------------------------------------------- */

@@ -12,6 +12,7 @@
 #include "device_util.h"
 
 #include <map>
+#include <memory>
 #include <mutex>
 
 using namespace pies;
@@ -20,11 +21,15 @@ namespace pies {
 
 // pies_set_tuning's registry (see kernels.h: tuning_env).  Values live as long as the process: a pointer handed out stays valid.
 static std::mutex& tuning_mutex() { static std::mutex m; return m; }
-static std::map<std::string, std::string>& tuning_map() { static std::map<std::string, std::string> m; return m; }
+// Every value ever set is kept in an append-only list of heap strings, and the map points at the current one: a pointer handed
+// out stays valid and its bytes never change, whatever pies_set_tuning does afterwards.  (pies_set_tuning must still not race
+// with pies_finalize / a capture of the same process: the switches are read at different times of a handle's life.)
+static std::vector<std::unique_ptr<std::string>>& tuning_values() { static std::vector<std::unique_ptr<std::string>> v; return v; }
+static std::map<std::string, const std::string*>& tuning_current() { static std::map<std::string, const std::string*> m; return m; }
 const char* tuning_env(const char* name) {
   std::lock_guard<std::mutex> lock(tuning_mutex());
-  auto it = tuning_map().find(name);
-  return it == tuning_map().end() || it->second.empty() ? nullptr : it->second.c_str();
+  auto it = tuning_current().find(name);
+  return it == tuning_current().end() || !it->second || it->second->empty() ? nullptr : it->second->c_str();
 }
 
 // PIES_PROFILER_SAFE=1 (set by the profiling scripts): rocprofv3 7.2 on this pool segfaults when tens of
@@ -71,6 +76,11 @@ static void free_device(pies_solver* s) {
   s->d_vc_ids = nullptr; s->d_vc_q0 = s->d_vc_q1 = s->d_vc_q2 = nullptr;
   s->pd = PdArrays{};
   s->hash = HashArrays{};
+  s->pairs = PairArrays{};
+  s->d_pairDictIndex = nullptr;
+  s->d_pairDictTable = nullptr;
+  s->pairDictSets = 0;
+  s->pdRowStencils = 0;
   s->d_layer = LayerDevice{};
   s->snapPos = s->snapPrev = s->snapVel = nullptr;
   s->snapQuat = nullptr;
@@ -1195,7 +1205,8 @@ int pies_finalize(pies_solver_t* s) {
       P.n = n;
       // list entries: 96 per node on average (BASELINE config 4 lists 15-50), in kPairPools pools; a small scene may list every
       // pair (a body that has collapsed into a few cells: quirk Q2 does that to a tetrahedral PBD body within a tick)
-      const uint64_t everyPair = std::min<uint64_t>(static_cast<uint64_t>(n) * n, 1ull << 26);
+      // (only a small scene: the n * n floor used to apply to every scene of 8 192 nodes and more - 270 MB per handle)
+      const uint64_t everyPair = n <= 8192u ? static_cast<uint64_t>(n) * n : 0ull;
       P.poolCap = static_cast<uint32_t>(std::min<uint64_t>((std::max<uint64_t>(96ull * n, everyPair) + 65536) / kPairPools + 4096, 0x7fff0000ull / kPairPools));
       if (int rc = dev_alloc(s, 4ull * n, &P.node, true)) return rc;
       if (int rc = dev_alloc(s, n, &P.vel0)) return rc;
@@ -1331,6 +1342,15 @@ int pies_tick_async(pies_solver_t* s) {
     if (s->goalDirty)
       if (int rc = pd_upload_goals(s)) return rc;
     if (s->asyncSinceSync == 1) HIP_TRY(s, hipMemsetAsync(s->pd.cg.stats, 0, 4 * sizeof(float), s->stream));
+  } else if (s->nodeCollisions && s->hash.counters) {
+    // The node grid's captured radix passes hold the scene's cell box plus five key bits, and the host can only follow a
+    // growing box at a synchronisation (adapt_sort_passes): a caller that queues PBD ticks blindly gets one every 16 ticks,
+    // like the PD path above, so that a burst that spreads the particles never outruns the captured passes.
+    if (s->asyncSinceSync >= 16) {
+      if (int rc = pies_synchronize(s)) return rc;
+      if (s->simFailed) return PIES_OK;
+    }
+    ++s->asyncSinceSync;
   }
   for (uint32_t sub = 0; sub < s->opt.timeSubsteps; ++sub)
     if (int rc = launch_substep(s)) return rc;
@@ -1557,13 +1577,10 @@ int pies_set_tuning(const char* name, const char* value) {
   if (!name || std::strncmp(name, "PIES_", 5) != 0) return PIES_ERR_INVALID;
   std::lock_guard<std::mutex> lock(tuning_mutex());
   if (value && value[0]) {
-    static std::vector<std::string> retired;  // (a value that is replaced may still be pointed at by a caller of tuning_env)
-    auto it = tuning_map().find(name);
-    if (it != tuning_map().end()) retired.push_back(std::move(it->second));
-    tuning_map()[name] = value;
+    tuning_values().push_back(std::make_unique<std::string>(value));
+    tuning_current()[name] = tuning_values().back().get();
   } else {
-    auto it = tuning_map().find(name);
-    if (it != tuning_map().end()) it->second.clear();
+    tuning_current().erase(name);
   }
   return PIES_OK;
 }
