@@ -411,6 +411,10 @@ static void enqueue_pbd_substep(pies_solver* s, int only, uint32_t* counts, uint
   C(PIES_KERNEL_VELOCITY);
 }
 
+// The global step's CG with one launch per iteration (pd_cg1_kernels.hip): the contact-light graph variant with one lane per
+// matrix row; the contact-heavy variant (contact rows summed by extra workgroups) keeps the two-launch form.
+static bool pd_single_cg(const pies_solver* s) { return s->pdSingleCg && !s->pd.cg.useCAp && s->pd.cg.lanesPerRow == 1u; }
+
 // One PD substep as a launch sequence (Solver.cpp:228-485).  `only` >= 0 (profile pass) launches one kernel
 // class of the tetrahedral pipeline; units tallies the work items of the launches made.
 static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts = nullptr, uint64_t* units = nullptr) {
@@ -452,7 +456,13 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
       U(nDist);
     }
     if (nDist) C(PIES_KERNEL_PD_LOCAL_DISTANCE);
-    if (s->tetVolumePaired) {  // both projections in one launch, accounted to the strain class
+    if (s->tetVolumePaired && pd.tiles.ntiles) {  // tile-resident: one sum per (tile, node) leaves the chip (pd_tiles.cpp)
+      if (ON(PIES_KERNEL_PD_LOCAL_TET)) {
+        launch_pd_local_tiles(st, s->nd.pos, pd.tiles, s->d_pairDictTable, tri && only < 0 ? &pd.tri : nullptr, s->opt.collisionThickness);
+        U(nTet);
+      }
+      C(PIES_KERNEL_PD_LOCAL_TET);
+    } else if (s->tetVolumePaired) {  // both projections in one launch, accounted to the strain class
       if (ON(PIES_KERNEL_PD_LOCAL_TET)) {
         launch_pd_local_tet_pair(st, s->nd.pos, s->d_tc_ids, s->d_tc_q0, s->d_tc_q1, s->d_tc_q2, s->d_vc_q2,
                                  pd.contrib + s->slotBase[PIES_TET], pd.contrib + s->slotBase[PIES_VOLUME], nTet,
@@ -478,33 +488,44 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
       launch_pd_local_shape(st, s->nd.pos, pd);                        // goal targets are constants between transform updates
       if (tri && !(s->tetVolumePaired && nTet)) launch_pd_local_tri(st, pd.tri, s->nd.pos, s->opt.collisionThickness);  // Solver.cpp:298-300
     }
-    if (ON(PIES_KERNEL_PD_RHS)) { launch_pd_rhs(st, s->nd, pd); U(s->nd.n); }    // Solver.cpp:266, 310-349
-    C(PIES_KERNEL_PD_RHS);
+    // Solver.cpp:266, 310-349.  (When a node's records are a few tile sums, the residual kernel of the one-launch-per-iteration
+    // CG evaluates the right-hand side itself.)
+    const bool single = pd_single_cg(s), fuseRhs = single && only < 0 && pd.rhsLanes == 1 && s->pdFuseRhs;
+    if (!fuseRhs) {
+      if (ON(PIES_KERNEL_PD_RHS)) { launch_pd_rhs(st, s->nd, pd); U(s->nd.n); }
+      C(PIES_KERNEL_PD_RHS);
+    }
+    const int overflow = s->pcgOverflow ? (int)(s->pcgMaxIters > s->pcgBudget ? s->pcgMaxIters - s->pcgBudget : 0u) : 0;
+    const bool lastSolve = it + 1 == s->opt.iterations && !statsInStabilize;
     if (only < 0) {  // Solver.cpp:356-364
       const bool probed = s->probe && (s->probe->kernel == PIES_KERNEL_PD_SPMV || s->probe->kernel == PIES_KERNEL_PD_CG_UPDATE);
       // a probed solve never takes the converged early exit: every bracketed launch does a full SpMV / vector update
-      launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, s->pcgTol, -1, it == 0, it + 1 == s->opt.iterations && !statsInStabilize, probed,
-                      probed ? [](void* ctx, int cls) { probe_mark(static_cast<pies_solver*>(ctx), cls); } : (void (*)(void*, int))nullptr, s,
-                      s->pcgOverflow ? (int)(s->pcgMaxIters > s->pcgBudget ? s->pcgMaxIters - s->pcgBudget : 0u) : 0);
+      auto hook = probed ? [](void* ctx, int cls) { probe_mark(static_cast<pies_solver*>(ctx), cls); } : (void (*)(void*, int))nullptr;
+      if (single) launch_pd_solve1(st, s->nd, pd, (int)s->pcgBudget, s->pcgTol, it == 0, lastSolve, fuseRhs, probed, hook, s, overflow);
+      else launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, s->pcgTol, -1, it == 0, lastSolve, probed, hook, s, overflow);
       if (probed && units) *units += (uint64_t)s->nd.n * s->pcgBudget;
     }
-    else if (only == PIES_KERNEL_PD_SPMV) { launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, 0.f, 1); U((uint64_t)s->nd.n * s->pcgBudget); }
-    else if (only == PIES_KERNEL_PD_CG_UPDATE) { launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, 0.f, 0); U((uint64_t)s->nd.n * s->pcgBudget); }
+    else if (only == PIES_KERNEL_PD_SPMV) {
+      if (single) launch_pd_solve1(st, s->nd, pd, (int)s->pcgBudget, s->pcgTol, true, false, false, true);
+      else launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, 0.f, 1);
+      U((uint64_t)s->nd.n * s->pcgBudget);
+    }
+    else if (only == PIES_KERNEL_PD_CG_UPDATE && !single) { launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, 0.f, 0); U((uint64_t)s->nd.n * s->pcgBudget); }
     C(PIES_KERNEL_PD_SPMV, s->pcgBudget);
-    C(PIES_KERNEL_PD_CG_UPDATE, s->pcgBudget);
+    if (!single) C(PIES_KERNEL_PD_CG_UPDATE, s->pcgBudget);
   }
   if (tri && only < 0) {  // :367-383: every stabilisation iteration is a sequential pass over the contacts, then the floor snap
     if (s->triLevelsForked) (void)hipStreamWaitEvent(st, s->evJoin, 0);
     // all iterations in one launch (the floor snap of the contacts' nodes between the passes), then the snap of everybody else:
     // idempotent, so once is what the reference's `iterations` times come to
     launch_tri_stabilize(st, pd.tri, s->nd, s->opt.collisionThickness, pd.nstatic, pd.statp, s->opt.collisionStabilizationIterations);
-    if (s->opt.collisionStabilizationIterations > 0) launch_pd_stabilize(st, s->nd, pd, statsInStabilize, (int)s->pcgBudget, s->pcgTol);
+    if (s->opt.collisionStabilizationIterations > 0) launch_pd_stabilize(st, s->nd, pd, statsInStabilize, (int)s->pcgBudget, s->pcgTol, pd_single_cg(s));
     // velocities, then the contacts' friction (:431-471), then the floor friction (:473-484).  The floor friction of a node that is
     // in no contact does not wait for the contacts: the velocity kernel applies it; the contacts' pass ends with that of its own nodes
     launch_pd_velocity(st, s->nd, pd, h, s->opt.damping, s->opt.gravity, s->opt.friction, s->opt.staticFrictionThreshold, false, pd.tri.usedBits);
     launch_tri_friction(st, pd.tri, s->nd, s->opt.friction, s->opt.staticFrictionThreshold, pd.nstatic);
   } else {
-    if (only < 0 && s->opt.collisionStabilizationIterations > 0) launch_pd_stabilize(st, s->nd, pd, statsInStabilize, (int)s->pcgBudget, s->pcgTol);  // the floor snap is idempotent
+    if (only < 0 && s->opt.collisionStabilizationIterations > 0) launch_pd_stabilize(st, s->nd, pd, statsInStabilize, (int)s->pcgBudget, s->pcgTol, pd_single_cg(s));  // the floor snap is idempotent
     if (ON(PIES_KERNEL_PD_VELOCITY)) {
       launch_pd_velocity(st, s->nd, pd, h, s->opt.damping, s->opt.gravity, s->opt.friction, s->opt.staticFrictionThreshold, true);
       U(s->nd.n);
@@ -518,11 +539,22 @@ static void enqueue_substep(pies_solver* s, uint32_t* counts) {
   else enqueue_pbd_substep(s, -1, counts);
 }
 
-// the rung of the budget ladder that holds `budget` CG iterations: 2, 4, 8, ... and the ceiling of pies_set_pcg
+// The budget ladder: captured CG iterations per solve of the graphs instantiated together - 2, 3, 4, 6, 8, 12, 16, ... up to
+// the ceiling of pies_set_pcg (the one-launch-per-iteration form pays one launch per unused iteration, so the low rungs are
+// close together); ladder_rung = the rung that holds `budget` iterations
+static std::vector<uint32_t> ladder_rungs(const pies_solver* s) {
+  std::vector<uint32_t> r;
+  for (uint32_t b = 2; b < s->pcgMaxIters; b *= 2) {
+    r.push_back(b);
+    if (b + b / 2 < s->pcgMaxIters) r.push_back(b + b / 2);
+  }
+  r.push_back(s->pcgMaxIters);
+  return r;
+}
 static uint32_t ladder_rung(const pies_solver* s, uint32_t budget) {
-  uint32_t r = 2;
-  while (r < budget && r < s->pcgMaxIters) r *= 2;
-  return std::min(r, s->pcgMaxIters);
+  for (uint32_t r : ladder_rungs(s))
+    if (r >= budget) return r;
+  return s->pcgMaxIters;
 }
 static bool uses_ladder(const pies_solver* s) {
   if (s->opt.solver != PIES_SOLVER_PD || s->pcgPinned || under_profiler()) return false;
@@ -561,11 +593,7 @@ static int capture_graph(pies_solver* s) {
     // following the solves later never instantiates a graph in the middle of a frame
     const uint32_t wantBudget = s->pcgBudget;
     const bool wantRows = s->triFastRows;
-    std::vector<uint32_t> rungs;
-    for (uint32_t r = 2;; r *= 2) {
-      rungs.push_back(std::min(r, s->pcgMaxIters));
-      if (r >= s->pcgMaxIters) break;
-    }
+    const std::vector<uint32_t> rungs = ladder_rungs(s);
     const int variants = s->pd.tri.nt ? 2 : 1;
     for (int v = 0; v < variants; ++v)
       for (uint32_t r : rungs) {
@@ -616,7 +644,7 @@ static int adapt_pcg_budget(pies_solver* s) {
     s->pcgCalm = 0;
     s->pcgWindowMax = 0;
     s->pcgCooldown = 24;
-  } else if (used > budget) {
+  } else if (used > budget || (pd_single_cg(s) && used == budget && budget < s->pcgMaxIters)) {
     // converged, but only because the last launch went on by itself (k_cg_update's continuation): capture what it needed
     budget = std::min(s->pcgMaxIters, used + std::max(2u, (used + 2u) / 3u));
     s->pcgCalm = 0;
@@ -632,7 +660,8 @@ static int adapt_pcg_budget(pies_solver* s) {
     // spare iterations on top of the most any solve of the window used: a third of it (at least two) after 8 calm
     // synchronisations, a quarter (at least one) after 24.  (Round 2 took + 2 / + 1 flat: a contact patch whose solves use
     // 5-8 iterations then sat at 8 and ran short on the next fluctuation - back to 32 for 60 frames.)
-    const uint32_t spare8 = std::max(2u, (s->pcgWindowMax + 2u) / 3u), spare24 = std::max(1u, (s->pcgWindowMax + 3u) / 4u);
+    // (the one-launch-per-iteration form needs one launch beyond the iterations a solve uses - the one that finds it converged)
+    const uint32_t spare8 = std::max(pd_single_cg(s) ? 1u : 2u, (s->pcgWindowMax + 2u) / 3u), spare24 = std::max(1u, (s->pcgWindowMax + 3u) / 4u);
     if (s->pcgCalm >= 8 && s->pcgWindowMax + spare8 < budget) { budget = s->pcgWindowMax + spare8; restart = true; }
     else if (s->pcgCalm >= 24) {
       if (s->pcgWindowMax + spare24 < budget) budget = s->pcgWindowMax + spare24;
@@ -770,6 +799,8 @@ void pies_default_options(pies_options_t* o) {
 static void apply_schedule_environment(pies_solver* s) {
   if (const char* e = tuning_env("PIES_PCG_OVERFLOW")) s->pcgOverflow = e[0] != '0';
   if (const char* e = tuning_env("PIES_PD_LOCAL_PACKED")) s->pdLocalPacked = e[0] != '0';
+  if (const char* e = tuning_env("PIES_PD_CG_SINGLE")) s->pdSingleCg = e[0] != '0';
+  if (const char* e = tuning_env("PIES_PD_FUSE_RHS")) s->pdFuseRhs = e[0] != '0';
   if (const char* e = tuning_env("PIES_PCG_BUDGET")) {  // diagnostics: the captured CG iterations, never adapted
     const int v = std::atoi(e);
     if (v >= 1 && v <= 4096) { s->pcgPinned = true; s->pcgPinnedBudget = static_cast<uint32_t>(v); s->pcgBudget = std::min(s->pcgMaxIters, s->pcgPinnedBudget); }
@@ -1255,6 +1286,7 @@ int pies_finalize(pies_solver_t* s) {
     s->d_pairDictIndex = nullptr;
     s->d_pairDictTable = nullptr;
     s->pairDictSets = 0;
+    s->h_pairDictIndex.clear();
     const char* de = tuning_env("PIES_PD_REST_DICT");
     if (s->tetVolumePaired && !(de && de[0] == '0')) {
       struct Set { float v[16]; bool operator<(const Set& o) const { return std::memcmp(v, o.v, sizeof(v)) < 0; } };
@@ -1279,7 +1311,9 @@ int pies_finalize(pies_solver_t* s) {
         }
         index[k] = it->second;
       }
+      s->h_pairDictIndex.clear();
       if (ok && !index.empty()) {
+        s->h_pairDictIndex = index;
         if (int rc = upload(s, index, &s->d_pairDictIndex)) return rc;
         if (int rc = upload(s, table, &s->d_pairDictTable)) return rc;
         s->pairDictSets = static_cast<uint32_t>(sets.size());

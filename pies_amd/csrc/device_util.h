@@ -38,5 +38,6 @@ template <class T> int upload(pies_solver* s, const std::vector<T>& h, T** d) {
 
 int pd_build(pies_solver* s);         // pd_setup.cpp
 int pd_upload_goals(pies_solver* s);  // pd_setup.cpp
+bool pd_plan_tiles(const pies_solver* s, PdTilePlan& out);  // pd_tiles.cpp; false: the scene keeps per-(element, node) records
 
 }  // namespace pies

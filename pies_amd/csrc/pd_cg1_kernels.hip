@@ -1,0 +1,338 @@
+// Jacobi-preconditioned CG of the PD global step (Solver.cpp:356 solves with a sparse Cholesky), ONE launch per
+// iteration.
+//
+// The two-launch form (pd_cg_kernels.hip) pays two kernel boundaries per iteration because standard CG has two global
+// reductions with a vector update between them: alpha = r.z / p.Ap, then beta = r'.z' / r.z.  At 100k rows a boundary costs as
+// much as the rows (4.5 us per launch, profiles/r03_moving_config3.txt: 350 of a 780-us substep), so the iteration is
+// rearranged (Chronopoulos & Gear 1989): with u = D^-1 r, w = (K + C) u,
+//     gamma_i = r_i.u_i, delta_i = w_i.u_i              (one reduction)
+//     beta_i = gamma_i / gamma_{i-1}, alpha_i = gamma_i / (delta_i - beta_i gamma_i / alpha_{i-1})
+//     p_i = u_i + beta_i p_{i-1};  s_i = w_i + beta_i s_{i-1}   (s = (K + C) p by recurrence)
+//     x_{i+1} = x_i + alpha_i p_i;  r_{i+1} = r_i - alpha_i s_i;  u_{i+1} = D^-1 r_{i+1};  w_{i+1} = (K + C) u_{i+1}
+// which has ONE synchronisation point per iteration.  The remaining dependency - a row of w_{i+1} needs u_{i+1} at its
+// neighbours - is removed by recomputing the neighbour's update while it is gathered: u_{i+1,j} depends on j's own old vectors
+// and the two scalars only.  The kernel keeps the PRECONDITIONED vectors t = D^-1 r, c = D^-1 s, a = D^-1 w (12-byte records),
+// so that u_{i+1,j} = t_j - alpha (a_j + beta c_j) is three gathers and two fused multiply-adds, and row j itself stores
+// exactly that value as its new t: what a neighbour used and what the row keeps are the same bits.  New t / c / a go to the
+// other half of a ping-pong pair (other workgroups are still gathering the old ones).
+//
+// Launches of a solve: k_cg1_init (r = b - (K + C) x, with the right-hand side evaluated in place when it is only a few tile
+// sums per node), k_cg1_first (w_0), then one k_cg1_iter per iteration; a launch that finds the residual of the previous
+// one below the tolerance sets the "done" word and every later launch of the solve returns on it.  Dot products are
+// per-workgroup partial sums that every workgroup of the next launch re-reduces in a fixed order (deterministic, no atomics).
+// The last captured launch goes on by itself behind a grid barrier when the solve needs more iterations than were captured
+// (see grid_barrier).  Contact rows are summed inline by the row's lane: this is the contact-light graph variant; the
+// contact-heavy one keeps the two-launch form.
+#include <algorithm>
+#include <cstdint>
+
+#include "pd_cg_device.h"
+#include "pd_rhs_device.h"
+
+namespace pies {
+
+// f(value, column) for every stored entry of row i (lane `lane` of slice `sl`): the row dictionary or the SELL arrays
+template <class F> PIES_DEV void row_entries(const CgArrays& A, uint32_t sl, uint32_t lane, uint32_t i, F f) {
+  if (A.rowStencil) {
+    if (i < A.n) {
+      const uint32_t rs = A.rowStencil[i];
+      const uint32_t b = rs & 0xffffffu, e = b + (rs >> 24);
+#pragma unroll 4
+      for (uint32_t q = b; q < e; ++q) {
+        const int2 pr = A.stencil[q];
+        f(__int_as_float(pr.y), static_cast<uint32_t>(static_cast<int>(i) + pr.x));
+      }
+    }
+  } else {
+    const uint32_t off = A.sliceOff[sl], width = (A.sliceOff[sl + 1] - off) >> 6;
+#pragma unroll 4
+    for (uint32_t kk = 0; kk < width; ++kk) {
+      const uint32_t at = off + (kk << 6) + lane;
+      f(A.val[at], A.col[at]);  // (padding entries: the row itself with value 0)
+    }
+  }
+}
+
+// r = f - (K + C) x ; t = D^-1 r ; partI = {r.t, r.r, f.f}.  RHS: f is evaluated here (Msn_h2 + the node's records + contacts +
+// shape / goal terms + floor: rhs_of_node with one lane per node) instead of being read from the array k_pd_rhs wrote.
+// prevPart != nullptr: an extra block closes the previous solve's statistics (see k_cg_init).
+template <bool RHS>
+__global__ void __launch_bounds__(kBlock) k_cg1_init(CgArrays A, const float4* __restrict__ x, const float4* __restrict__ f, RhsArrays R,
+                                                     const float* __restrict__ prevPart) {
+  if (blockIdx.x == A.nparts) {
+    if (prevPart) solve_statistics(A, prevPart);
+    if (threadIdx.x == 0) {
+      A.scal[10] = 0.0f;
+      A.ticket[0] = 0u;
+      A.ticket[1] = 0u;
+    }
+    return;
+  }
+  const uint32_t lane = threadIdx.x & 63u;
+  const SliceSweep sw = slice_sweep<1>(A.n, A.nparts);
+  float acc9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Vec3f* __restrict__ t0 = A.t1[0];
+  for (uint32_t sl = sw.begin; sl < sw.end; sl += sw.step) {
+    const uint32_t i = sl * 64u + lane;
+    const bool live = i < A.n;
+    float4 fi = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (RHS) fi = rhs_of_node<1>(R, i, 0u, live);  // (issued first: its gathers are in flight beside the row's)
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    row_entries(A, sl, lane, i, [&](float a, uint32_t j) {
+      const float4 xj = x[j];
+      sx = fmaf(a, xj.x, sx);
+      sy = fmaf(a, xj.y, sy);
+      sz = fmaf(a, xj.z, sz);
+    });
+    if (live) {
+      contact_row(A, i, [&](uint32_t j, float& px, float& py, float& pz) { const float4 v = x[j]; px = v.x; py = v.y; pz = v.z; }, sx, sy, sz);
+      if (!RHS) fi = f[i];
+      const float4 xi = x[i];
+      const float cd = A.cdiag[i], di = A.dinv[i];
+      const float rx = fi.x - fmaf(cd, xi.x, sx), ry = fi.y - fmaf(cd, xi.y, sy), rz = fi.z - fmaf(cd, xi.z, sz);
+      const float tx = di * rx, ty = di * ry, tz = di * rz;
+      t0[i] = Vec3f{tx, ty, tz};
+      acc9[0] += rx * tx; acc9[1] += ry * ty; acc9[2] += rz * tz;
+      acc9[3] += rx * rx; acc9[4] += ry * ry; acc9[5] += rz * rz;
+      acc9[6] += fi.x * fi.x; acc9[7] += fi.y * fi.y; acc9[8] += fi.z * fi.z;
+    }
+  }
+  block_write_partial<9>(acc9, A.partI, 9);
+}
+
+// a_0 = D^-1 w_0, w_0 = (K + C) t_0 ; part1[0] = {., w_0.t_0, .}.  Also the solve's first look at the residual.
+__global__ void __launch_bounds__(kBlock) k_cg1_first(CgArrays A, float tol2) {
+  float red[9];
+  block_reduce_partials<9>(A.partI, 9, A.nparts, red);
+  const float rr[3] = {red[3], red[4], red[5]}, bb[3] = {red[6], red[7], red[8]};
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      A.scal[c] = red[c];  // gamma_0
+      A.scal[6 + c] = bb[c];
+    }
+    A.scal[9] = 0.0f;  // iterations of this solve
+  }
+  if (all_converged(rr, bb, tol2)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      A.scal[11] = 0.0f;  // the final residual partials are partI
+      A.scal[10] = 1.0f;
+    }
+    return;
+  }
+  const uint32_t lane = threadIdx.x & 63u;
+  const SliceSweep sw = slice_sweep<1>(A.n, A.nparts);
+  const Vec3f* __restrict__ t0 = A.t1[0];
+  Vec3f* __restrict__ a0 = A.a1[0];
+  float acc[3] = {0, 0, 0};
+  for (uint32_t sl = sw.begin; sl < sw.end; sl += sw.step) {
+    const uint32_t i = sl * 64u + lane;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    row_entries(A, sl, lane, i, [&](float a, uint32_t j) {
+      const Vec3f tj = t0[j];
+      sx = fmaf(a, tj.x, sx);
+      sy = fmaf(a, tj.y, sy);
+      sz = fmaf(a, tj.z, sz);
+    });
+    if (i < A.n) {
+      contact_row(A, i, [&](uint32_t j, float& px, float& py, float& pz) { const Vec3f v = t0[j]; px = v.x; py = v.y; pz = v.z; }, sx, sy, sz);
+      const Vec3f ti = t0[i];
+      const float cd = A.cdiag[i], di = A.dinv[i];
+      const float wx = fmaf(cd, ti.x, sx), wy = fmaf(cd, ti.y, sy), wz = fmaf(cd, ti.z, sz);
+      a0[i] = Vec3f{di * wx, di * wy, di * wz};
+      acc[0] += wx * ti.x; acc[1] += wy * ti.y; acc[2] += wz * ti.z;
+    }
+  }
+  block_write_partial<3>(acc, A.part1[0] + 3, 9);
+}
+
+// The rows of iteration `it` (the it-th update of x, it >= 1) for this workgroup's slices, given alpha_{it-1} and beta_{it-1}:
+// reads the vectors of parity (it - 1) & 1, writes those of parity it & 1; acc += {r.t, w.t, r.r} of the new vectors.
+// FIRST (it == 1): beta = 0 and there is no c / p yet.
+template <bool FIRST>
+PIES_DEV void cg1_rows(const CgArrays& A, float4* __restrict__ x, int it, const float alpha[3], const float beta[3], float acc[9]) {
+  const Vec3f* __restrict__ tO = A.t1[(it - 1) & 1];
+  const Vec3f* __restrict__ aO = A.a1[(it - 1) & 1];
+  const Vec3f* __restrict__ cO = A.c1[(it - 1) & 1];
+  Vec3f* __restrict__ tN = A.t1[it & 1];
+  Vec3f* __restrict__ aN = A.a1[it & 1];
+  Vec3f* __restrict__ cN = A.c1[it & 1];
+  Vec3f* __restrict__ p = A.p1;
+  // the new preconditioned residual of row j, and (own row) the new c: the SAME two fused multiply-adds wherever it is evaluated
+  auto renew = [&](uint32_t j, float& ux, float& uy, float& uz, float& cx, float& cy, float& cz) {
+    const Vec3f tj = tO[j], aj = aO[j];
+    cx = aj.x; cy = aj.y; cz = aj.z;
+    if (!FIRST) {
+      const Vec3f cj = cO[j];
+      cx = fmaf(beta[0], cj.x, cx); cy = fmaf(beta[1], cj.y, cy); cz = fmaf(beta[2], cj.z, cz);
+    }
+    ux = fmaf(-alpha[0], cx, tj.x); uy = fmaf(-alpha[1], cy, tj.y); uz = fmaf(-alpha[2], cz, tj.z);
+  };
+  auto fetch = [&](uint32_t j, float& ux, float& uy, float& uz) {
+    float cx, cy, cz;
+    renew(j, ux, uy, uz, cx, cy, cz);
+  };
+  const uint32_t lane = threadIdx.x & 63u;
+  const SliceSweep sw = slice_sweep<1>(A.n, A.nparts);
+  for (uint32_t sl = sw.begin; sl < sw.end; sl += sw.step) {
+    const uint32_t i = sl * 64u + lane;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    row_entries(A, sl, lane, i, [&](float a, uint32_t j) {
+      float ux, uy, uz;
+      fetch(j, ux, uy, uz);
+      sx = fmaf(a, ux, sx);
+      sy = fmaf(a, uy, sy);
+      sz = fmaf(a, uz, sz);
+    });
+    if (i < A.n) {
+      contact_row(A, i, fetch, sx, sy, sz);
+      float tx, ty, tz, cx, cy, cz;
+      renew(i, tx, ty, tz, cx, cy, cz);
+      const Vec3f told = tO[i];
+      float px = told.x, py = told.y, pz = told.z;  // p = u + beta p_old, u = the OLD t
+      if (!FIRST) {
+        const Vec3f po = p[i];
+        px = fmaf(beta[0], po.x, px); py = fmaf(beta[1], po.y, py); pz = fmaf(beta[2], po.z, pz);
+      }
+      float4 xi = x[i];
+      xi.x = fmaf(alpha[0], px, xi.x);
+      xi.y = fmaf(alpha[1], py, xi.y);
+      xi.z = fmaf(alpha[2], pz, xi.z);
+      const float cd = A.cdiag[i], di = A.dinv[i], kd = A.kdiag[i] + cd;
+      const float wx = fmaf(cd, tx, sx), wy = fmaf(cd, ty, sy), wz = fmaf(cd, tz, sz);
+      const float rx = kd * tx, ry = kd * ty, rz = kd * tz;
+      x[i] = xi;
+      p[i] = Vec3f{px, py, pz};
+      tN[i] = Vec3f{tx, ty, tz};
+      cN[i] = Vec3f{cx, cy, cz};
+      aN[i] = Vec3f{di * wx, di * wy, di * wz};
+      acc[0] += rx * tx; acc[1] += ry * ty; acc[2] += rz * tz;
+      acc[3] += wx * tx; acc[4] += wy * ty; acc[5] += wz * tz;
+      acc[6] += rx * rx; acc[7] += ry * ry; acc[8] += rz * rz;
+    }
+  }
+}
+
+// alpha_i and beta_i from {gamma_i, delta_i} and the previous iteration's {gamma_{i-1}, alpha_{i-1}}; a column that has nothing
+// left to do (gamma = 0) or whose recurrence breaks down (a non-positive denominator) stands still
+PIES_DEV void cg1_scalars(const float gam[3], const float del[3], const float gamOld[3], const float alphaOld[3], float alpha[3], float beta[3]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    beta[c] = gamOld[c] > 0.0f ? gam[c] / gamOld[c] : 0.0f;
+    const float den = alphaOld[c] > 0.0f ? del[c] - (beta[c] * gam[c]) / alphaOld[c] : del[c];
+    alpha[c] = den > 0.0f ? gam[c] / den : 0.0f;
+  }
+}
+
+// Launch `it` of a solve's iterations (it >= 1): scalars from the partial sums of the launch before, then the rows.
+// overflow > 0: the solve's last captured launch; when the residual is still above the tolerance after its rows, its
+// workgroups (all resident, see cg_update_resident_blocks) run up to `overflow` more iterations themselves, one grid barrier
+// per iteration where the captured path has a kernel boundary.
+template <bool FIRST>
+__global__ void __launch_bounds__(kBlock) k_cg1_iter(CgArrays A, float4* __restrict__ x, int it, float tol2, int overflow) {
+  if (A.scal[10] != 0.0f) return;  // the solve converged in an earlier launch
+  float red[9];
+  float alpha[3], beta[3] = {0.f, 0.f, 0.f}, gam[3], bb[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) bb[c] = A.scal[6 + c];
+  if (FIRST) {
+    block_reduce_partials<3>(A.part1[0] + 3, 9, A.nparts, red + 3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      gam[c] = A.scal[c];
+      alpha[c] = red[3 + c] > 0.0f ? gam[c] / red[3 + c] : 0.0f;
+    }
+  } else {
+    block_reduce_partials<9>(A.part1[(it - 1) & 1], 9, A.nparts, red);
+    const float rr[3] = {red[6], red[7], red[8]};
+    if (all_converged(rr, bb, tol2)) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        A.scal[11] = static_cast<float>(1 + ((it - 1) & 1));  // where the final residual partials are
+        A.scal[10] = 1.0f;
+      }
+      return;
+    }
+    float gamOld[3], alphaOld[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      gam[c] = red[c];
+      gamOld[c] = A.scal[3 * (it & 1) + c];         // gamma_{it-2}
+      alphaOld[c] = A.scal[12 + 3 * (it & 1) + c];  // alpha_{it-2}
+    }
+    cg1_scalars(gam, red + 3, gamOld, alphaOld, alpha, beta);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      A.scal[3 * ((it - 1) & 1) + c] = gam[c];
+      A.scal[12 + 3 * ((it - 1) & 1) + c] = alpha[c];
+    }
+    A.scal[9] = static_cast<float>(it);
+  }
+  float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  cg1_rows<FIRST>(A, x, it, alpha, beta, acc);
+  block_write_partial<9>(acc, A.part1[it & 1], 9);
+  if (overflow <= 0) return;
+  // ---- the iterations beyond the captured ones ----------------------------------------------------------------------
+  uint32_t passed = 0;
+  int kk = it;
+  float gamOld[3], alphaOld[3];
+  for (;;) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { gamOld[c] = gam[c]; alphaOld[c] = alpha[c]; }
+    if (!grid_barrier(A.ticket, gridDim.x, passed)) return;  // the partials of iteration kk are complete
+    block_reduce_partials<9>(A.part1[kk & 1], 9, A.nparts, red);
+    const float rr[3] = {red[6], red[7], red[8]};
+    if (all_converged(rr, bb, tol2) || kk >= it + overflow) break;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gam[c] = red[c];
+    cg1_scalars(gam, red + 3, gamOld, alphaOld, alpha, beta);
+    ++kk;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) acc[c] = 0.0f;
+    cg1_rows<false>(A, x, kk, alpha, beta, acc);
+    block_write_partial<9>(acc, A.part1[kk & 1], 9);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    A.scal[9] = static_cast<float>(kk);
+    A.scal[11] = static_cast<float>(1 + (kk & 1));
+    A.scal[10] = 1.0f;
+  }
+}
+
+// workgroups of k_cg1_iter the device holds at once (its continuation's grid barrier needs all of a launch resident)
+uint32_t cg1_iter_resident_blocks(int device) {
+  int perCu = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_cg1_iter<false>, kBlock, 0) != hipSuccess) return 0;
+  return static_cast<uint32_t>(std::max(0, perCu)) * static_cast<uint32_t>(std::max(0, prop.multiProcessorCount));
+}
+
+void launch_pd_solve1(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, int iters, float tol, bool first, bool last, bool fuseRhs,
+                      bool neverExit, void (*hook)(void*, int), void* hookCtx, int overflowIters) {
+  if (nd.n == 0) return;
+  CgArrays A = pd.cg;
+  A.single = 1;
+  A.tol2 = tol * tol;
+  const float tol2 = neverExit ? -1.0f : tol * tol;
+  const dim3 grid(A.nparts), block(kBlock);
+  // every solve of a substep captures the same number of launches, so the previous solve's last one left its partials here
+  const float* prev = first ? nullptr : A.part1[iters & 1];
+  const RhsArrays R = rhs_arrays(nd, pd);
+  if (fuseRhs) hipLaunchKernelGGL(k_cg1_init<true>, dim3(A.nparts + 1u), block, 0, st, A, nd.pos, pd.rhs, R, prev);
+  else hipLaunchKernelGGL(k_cg1_init<false>, dim3(A.nparts + 1u), block, 0, st, A, nd.pos, pd.rhs, R, prev);
+  hipLaunchKernelGGL(k_cg1_first, grid, block, 0, st, A, tol2);
+  for (int it = 1; it <= iters; ++it) {
+    if (hook) hook(hookCtx, 14);  // PIES_KERNEL_PD_SPMV
+    const int overflow = it == iters && !neverExit ? overflowIters : 0;
+    if (it == 1) hipLaunchKernelGGL(k_cg1_iter<true>, grid, block, 0, st, A, nd.pos, it, tol2, overflow);
+    else hipLaunchKernelGGL(k_cg1_iter<false>, grid, block, 0, st, A, nd.pos, it, tol2, overflow);
+    if (hook) hook(hookCtx, 14);
+  }
+  if (!last) return;
+  A.partB = A.part1[iters & 1];
+  launch_cg_finish(st, A);
+}
+
+}  // namespace pies

@@ -55,6 +55,14 @@ struct CgArrays {
   float* stats;  // over the tick: [0] max relative residual^2 of its solves, [1] max iterations, [2] solves, [3] solves that ended
                  // above the tolerance; since the buffers were built: [4] solves above the tolerance, [5] solves
   float tol2;    // squared relative tolerance of the solve whose statistics are being closed
+  // ---- one launch per CG iteration (pd_cg1_kernels.hip; Chronopoulos-Gear's single-reduction form) ----
+  // the preconditioned vectors t = D^-1 r, c = D^-1 s (s = (K + C) p by recurrence), a = D^-1 w (w = (K + C) t) as 12-byte
+  // records in ping-pong pairs (an iteration's rows read their neighbours' old values while other workgroups write the new
+  // ones), the search direction p, and per workgroup {r.t, w.t, r.r} of the three columns
+  Vec3f *t1[2], *c1[2], *a1[2], *p1;
+  float* part1[2];
+  const float* kdiag;  // diagonal of K (the residual is r = (kdiag + cdiag) t)
+  int single;          // the captured solves are of this form (solve_statistics: where a solve's final partials are)
 };
 
 // ShapeMatchingConstraint data (fp64 like the reference) and the fp64 contribution slots of shape and
@@ -67,6 +75,44 @@ struct ShapeArrays {
   const double* qinv;      // 9 per constraint, row-major
   double* quat;            // 4 per constraint (w,x,y,z), warm-started across iterations and ticks
   const float* w;          // per constraint
+};
+
+struct RhsArrays {
+  const float4* msn;
+  const Vec3f* contrib;
+  const uint32_t *incPtr, *incSlot;
+  const double4* contribD;
+  const uint32_t *incPtrD, *incSlotD;
+  const float4* pos;
+  const uint32_t* nstatic;
+  float4* statp;
+  const uint32_t *tIncCnt, *tIncStart, *tInc;
+  const float4* tContrib;
+  const uint32_t* tUsedCount;  // nodes in contacts this substep (device word; 0: nobody reads tIncCnt)
+  uint32_t n;
+};
+
+// Tile-resident local step (pd_tiles.cpp plans, k_pd_local_tiles runs): the element pairs are cut into tiles of up to 128
+// spatially close elements that touch at most 128 nodes; ONE WAVEFRONT takes a tile: it holds the positions of the tile's nodes
+// in LDS, projects the tile's elements two per lane, parks every element's four contributions in LDS and then adds them up
+// node by node - lane k owns tile nodes k and k + 64 and walks their incidence lists in a fixed order (deterministic, no
+// atomics, no barrier between wavefronts).  What leaves the chip is ONE 12-byte sum per (tile, node) instead of one record
+// per (element, node): 3-4 records per node for the right-hand side to add up instead of 24 (Solver.cpp:270-349).
+// Everything of a tile sits at a fixed stride (no descriptor to chase): tile t owns node[128 t ..], local[128 t ..],
+// inc[512 t ..], nptr[132 t ..] and partial[128 t ..].
+constexpr uint32_t kTileNodes = 128;  // nodes a tile may touch
+constexpr uint32_t kTileElems = 128;  // element pairs of a tile (two per lane)
+constexpr uint32_t kTileNptr = 132;   // stride of the per-node list offsets (129 used)
+struct PdTileArrays {
+  uint32_t ntiles;  // 0: the local step writes per-(element, node) records (k_pd_local_tet_pair)
+  const uint32_t* info;   // per tile: nodes | elements << 16
+  const uint32_t* node;   // global node index per tile node
+  const uint32_t* local;  // per element pair: four 8-bit tile-local node indices
+  const uint16_t* dict;   // per element pair: index into the rest dictionary, or nullptr: the four arrays below
+  const float4 *q0, *q1, *q2, *vq2;
+  const uint16_t* nptr;   // per tile node: first entry of its list in `inc` (nodes + 1 offsets)
+  const uint16_t* inc;    // per (element, corner) of the tile, grouped by node, ascending element: element << 2 | corner
+  Vec3f* partial;         // per tile node: the sum over the tile's elements (records of the right-hand side's gather)
 };
 
 struct PdArrays {
@@ -85,6 +131,8 @@ struct PdArrays {
   const uint32_t* triCount;
   uint32_t* nstatic;
   const float* kdiag;
+  PdTileArrays tiles;
+  uint32_t rhsLanes;  // lanes of k_pd_rhs that share a node: 4 (a node gathers its ~24 per-constraint records) or 1 (tile sums)
   CgArrays cg;
 };
 
@@ -99,9 +147,14 @@ void launch_pd_local_tet_pair(hipStream_t st, const float4* pos, const uint4* id
                               const float4* vq2, Vec3f* contribTet, Vec3f* contribVol, uint32_t count, const TriArrays* tri = nullptr,
                               float thickness = 0.0f, bool packed = true, const uint16_t* dictIndex = nullptr,
                               const float4* dictTable = nullptr);  // packed: two elements per lane; dict*: pd_local_packed.h RestDictionary
+// the strain + volume local step over tiles (see PdTileArrays); dictTable: the rest dictionary's table when T.dict is set;
+// tri as in launch_pd_local_tet_pair
+void launch_pd_local_tiles(hipStream_t st, const float4* pos, const PdTileArrays& T, const float4* dictTable, const TriArrays* tri = nullptr,
+                           float thickness = 0.0f);
 void launch_pd_local_bend(hipStream_t st, const float4* pos, const uint4* ids, const float2* angle_w, Vec3f* contrib, uint32_t count);
 void launch_pd_local_shape(hipStream_t st, const float4* pos, const PdArrays& pd);
 void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd);
+RhsArrays rhs_arrays(const NodeArrays& nd, const PdArrays& pd);
 // part: -1 = the solve; profile passes: 1 = the SpMV (+ direction update) kernels only, 0 = the vector-update kernels only
 // first / last: the first and the last solve of a substep (a solve's statistics are closed by the next solve's first
 // kernel, the last one's by a launch of its own)
@@ -112,9 +165,19 @@ void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd);
 void launch_pd_solve(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, int maxIters, float tol, int part = -1, bool first = true,
                      bool last = true, bool neverExit = false, void (*hook)(void*, int) = nullptr, void* hookCtx = nullptr,
                      int overflowIters = 0);
+// The same solve with ONE launch per CG iteration (pd_cg1_kernels.hip): k_cg1_init (residual; with fuseRhs it evaluates the
+// right-hand side itself and launch_pd_rhs is not needed), k_cg1_first (w = (K + C) D^-1 r), then `iters` launches of
+// k_cg1_iter, each a whole iteration - scalars from the previous launch's partial sums, the neighbours' new preconditioned
+// residual recomputed while it is gathered, x / r / p / s updated for the launch's own rows, the next dot products.  Contact
+// rows are summed inline (the contact-light graph variant); one lane per row.  hook brackets the k_cg1_iter launches
+// (PIES_KERNEL_PD_SPMV).
+void launch_pd_solve1(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, int iters, float tol, bool first, bool last, bool fuseRhs,
+                      bool neverExit = false, void (*hook)(void*, int) = nullptr, void* hookCtx = nullptr, int overflowIters = 0);
+void launch_cg_finish(hipStream_t st, const CgArrays& A);  // the statistics of a substep's last solve (A.partB: its final partials)
 // closeSolve: one more workgroup closes the statistics of the substep's last solve (k_cg_finish's work; maxIters = that solve's
 // captured iterations, tol its tolerance)
-void launch_pd_stabilize(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, bool closeSolve = false, int maxIters = 0, float tol = 0.0f);
+void launch_pd_stabilize(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, bool closeSolve = false, int maxIters = 0, float tol = 0.0f,
+                         bool single = false);  // single: that solve was launch_pd_solve1's
 // staticFriction = false leaves the floor friction (Solver.cpp:473-484) to the contacts' friction pass (launch_tri_friction), which the
 // reference runs after the point-triangle friction
 void launch_pd_velocity(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float h, float damping, float gravity,
@@ -123,5 +186,6 @@ void launch_pd_velocity(hipStream_t st, const NodeArrays& nd, const PdArrays& pd
 
 // workgroups of k_cg_update the device holds at once (0: unknown); the CG kernels' grid stays below it, see grid_barrier
 uint32_t cg_update_resident_blocks(int device);
+uint32_t cg1_iter_resident_blocks(int device);
 
 }  // namespace pies

@@ -181,31 +181,18 @@ struct RestDictionary {
   const float4* table;    // 4 per set: q0, q1, q2 (strain), q2 (volume)
 };
 
-// elements c0 and c1 (c1 == c0 for the odd one out: its result is not written twice)
-template <bool DICT>
-PIES_DEV void local_tet_pair_packed(const float4* __restrict__ pos, const uint4* __restrict__ ids, const float4* __restrict__ q0,
-                                    const float4* __restrict__ q1, const float4* __restrict__ q2, const float4* __restrict__ vq2,
-                                    const RestDictionary& dict, Vec3f* __restrict__ contribTet, uint32_t count, uint32_t c0, uint32_t c1) {
-  const uint4 ia = ids[c0], ib = ids[c1];
-  float4 a0, a1, a2, av, b0, b1, b2, bv;
-  if (DICT) {
-    const uint32_t ka = 4u * dict.index[c0], kb = 4u * dict.index[c1];
-    a0 = dict.table[ka]; a1 = dict.table[ka + 1]; a2 = dict.table[ka + 2]; av = dict.table[ka + 3];
-    b0 = dict.table[kb]; b1 = dict.table[kb + 1]; b2 = dict.table[kb + 2]; bv = dict.table[kb + 3];
-  } else {
-    a0 = q0[c0]; a1 = q1[c0]; a2 = q2[c0]; av = vq2[c0];
-    b0 = q0[c1]; b1 = q1[c1]; b2 = q2[c1]; bv = vq2[c1];
-  }
-  const float4 xa1 = pos[ia.x], xa2 = pos[ia.y], xa3 = pos[ia.z], xa4 = pos[ia.w];
-  const float4 xb1 = pos[ib.x], xb2 = pos[ib.y], xb3 = pos[ib.z], xb4 = pos[ib.w];
+// The strain + volume projection of two elements at once: positions xa[4] / xb[4], constants (Qinv 9, strain lo / hi / w;
+// volume lo / hi / w in the last record) -> rec[i][k] = the sum of both constraints' w (A^T p)_i, component k, elements (x, y)
+PIES_DEV void pair_project_packed(const float4 xa[4], const float4 xb[4], const float4 a0, const float4 a1, const float4 a2, const float4 av,
+                                  const float4 b0, const float4 b1, const float4 b2, const float4 bv, f2 rec[4][3]) {
   // Qinv [col][row] (tet_frame)
   const f2 qi[3][3] = {{f2{a0.x, b0.x}, f2{a0.y, b0.y}, f2{a0.z, b0.z}},
                        {f2{a0.w, b0.w}, f2{a1.x, b1.x}, f2{a1.y, b1.y}},
                        {f2{a1.z, b1.z}, f2{a1.w, b1.w}, f2{a2.x, b2.x}}};
-  const f2 x1[3] = {f2{xa1.x, xb1.x}, f2{xa1.y, xb1.y}, f2{xa1.z, xb1.z}};
-  const f2 P[3][3] = {{f2{xa2.x, xb2.x} - x1[0], f2{xa2.y, xb2.y} - x1[1], f2{xa2.z, xb2.z} - x1[2]},
-                      {f2{xa3.x, xb3.x} - x1[0], f2{xa3.y, xb3.y} - x1[1], f2{xa3.z, xb3.z} - x1[2]},
-                      {f2{xa4.x, xb4.x} - x1[0], f2{xa4.y, xb4.y} - x1[1], f2{xa4.z, xb4.z} - x1[2]}};
+  const f2 x1[3] = {f2{xa[0].x, xb[0].x}, f2{xa[0].y, xb[0].y}, f2{xa[0].z, xb[0].z}};
+  const f2 P[3][3] = {{f2{xa[1].x, xb[1].x} - x1[0], f2{xa[1].y, xb[1].y} - x1[1], f2{xa[1].z, xb[1].z} - x1[2]},
+                      {f2{xa[2].x, xb[2].x} - x1[0], f2{xa[2].y, xb[2].y} - x1[1], f2{xa[2].z, xb[2].z} - x1[2]},
+                      {f2{xa[3].x, xb[3].x} - x1[0], f2{xa[3].y, xb[3].y} - x1[1], f2{xa[3].z, xb[3].z} - x1[2]}};
   f2 F[3][3];  // F = P * Qinv, column-major (mat3_mul_cm)
 #pragma unroll
   for (int c = 0; c < 3; ++c)
@@ -236,13 +223,33 @@ PIES_DEV void local_tet_pair_packed(const float4* __restrict__ pos, const uint4*
   f2 A0[3];
 #pragma unroll
   for (int r = 0; r < 3; ++r) A0[r] = -((qi[r][0] + qi[r][1]) + qi[r][2]);
-  f2 rec[4][3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     rec[0][k] = fma2(A0[2], Fh[2][k], fma2(A0[1], Fh[1][k], A0[0] * Fh[0][k]));
 #pragma unroll
     for (int cc = 0; cc < 3; ++cc) rec[1 + cc][k] = fma2(qi[2][cc], Fh[2][k], fma2(qi[1][cc], Fh[1][k], qi[0][cc] * Fh[0][k]));
   }
+}
+
+// elements c0 and c1 (c1 == c0 for the odd one out: its result is not written twice)
+template <bool DICT>
+PIES_DEV void local_tet_pair_packed(const float4* __restrict__ pos, const uint4* __restrict__ ids, const float4* __restrict__ q0,
+                                    const float4* __restrict__ q1, const float4* __restrict__ q2, const float4* __restrict__ vq2,
+                                    const RestDictionary& dict, Vec3f* __restrict__ contribTet, uint32_t count, uint32_t c0, uint32_t c1) {
+  const uint4 ia = ids[c0], ib = ids[c1];
+  float4 a0, a1, a2, av, b0, b1, b2, bv;
+  if (DICT) {
+    const uint32_t ka = 4u * dict.index[c0], kb = 4u * dict.index[c1];
+    a0 = dict.table[ka]; a1 = dict.table[ka + 1]; a2 = dict.table[ka + 2]; av = dict.table[ka + 3];
+    b0 = dict.table[kb]; b1 = dict.table[kb + 1]; b2 = dict.table[kb + 2]; bv = dict.table[kb + 3];
+  } else {
+    a0 = q0[c0]; a1 = q1[c0]; a2 = q2[c0]; av = vq2[c0];
+    b0 = q0[c1]; b1 = q1[c1]; b2 = q2[c1]; bv = vq2[c1];
+  }
+  const float4 xa[4] = {pos[ia.x], pos[ia.y], pos[ia.z], pos[ia.w]};
+  const float4 xb[4] = {pos[ib.x], pos[ib.y], pos[ib.z], pos[ib.w]};
+  f2 rec[4][3];
+  pair_project_packed(xa, xb, a0, a1, a2, av, b0, b1, b2, bv, rec);
   if (c1 == c0 + 1u) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -109,19 +109,28 @@ int pd_build(pies_solver* s) {
   const uint32_t cnt[5] = {(uint32_t)s->h_position.size(), (uint32_t)s->h_distance.size(), (uint32_t)s->h_tet.size(),
                            (uint32_t)s->h_volume.size(), (uint32_t)s->h_bend.size()};
   const uint32_t arity[5] = {1, 2, 4, 4, 4};
+  // strain + volume element pairs in tiles: one record per (tile, node) instead of four per element (pd_tiles.cpp)
+  PdTilePlan tiles;
+  const bool tiled = pd_plan_tiles(s, tiles);
+  s->pdTiles = tiled ? static_cast<uint32_t>(tiles.info.size()) : 0u;
   uint32_t total = 0;
   for (int t = 0; t < 5; ++t) {
     s->slotBase[t] = total;
-    total += cnt[t] * arity[t];
+    if (!(tiled && (t == PIES_TET || t == PIES_VOLUME))) total += cnt[t] * arity[t];
   }
+  const uint32_t tileSlotBase = total;
+  if (tiled) total += static_cast<uint32_t>(tiles.node.size());  // (kTileNodes slots per tile)
   std::vector<uint32_t> incPtr(n + 1, 0);
   auto for_each_incidence = [&](auto&& fn) {
     // reference order of setupGlobalForceVector calls: position, distance, tet, volume, bend (Solver.cpp:310-327)
     for (uint32_t c = 0; c < cnt[0]; ++c) fn(s->h_position[c].id, s->slotBase[0] + c);
     for (uint32_t c = 0; c < cnt[1]; ++c)
       for (uint32_t i = 0; i < 2; ++i) fn(s->h_distance[c].ids[i], s->slotBase[1] + i * cnt[1] + c);
-    for (uint32_t c = 0; c < cnt[2]; ++c)
+    for (uint32_t c = 0; c < (tiled ? 0u : cnt[2]); ++c)
       for (uint32_t i = 0; i < 4; ++i) fn(s->h_tet[c].ids[i], s->slotBase[2] + i * cnt[2] + c);
+    if (tiled)  // a node's tile sums, in ascending tile order
+      for (uint32_t t = 0; t < tiles.info.size(); ++t)
+        for (uint32_t k = 0; k < (tiles.info[t] & 0xffffu); ++k) fn(tiles.node[static_cast<size_t>(kTileNodes) * t + k], tileSlotBase + kTileNodes * t + k);
     // strain + volume constraints over identical elements (tetVolumePaired): the fused local step adds the volume
     // contribution into the strain constraint's record, so the volume slots are not gathered
     for (uint32_t c = 0; c < (s->tetVolumePaired ? 0u : cnt[3]); ++c)
@@ -184,7 +193,7 @@ int pd_build(pies_solver* s) {
   // k_cg_update's in-kernel continuation synchronises its workgroups with a grid barrier: the grid must fit the device at once
   // (occupancy of the kernel x compute units of THIS device; half of it, so that a second solver on the card leaves room)
   if (s->device >= 0) {
-    const uint32_t resident = cg_update_resident_blocks(s->device);
+    const uint32_t resident = std::min(cg_update_resident_blocks(s->device), cg1_iter_resident_blocks(s->device));
     if (resident >= 2) cg.nparts = std::max(1u, std::min(cg.nparts, resident / 2u));
   }
   uint32_t *d_rowptr, *d_col, *d_incPtr, *d_incSlot, *d_tri;
@@ -238,6 +247,44 @@ int pd_build(pies_solver* s) {
     }
   }
   cg.lanesPerRow = lpr;
+  // lanes of k_pd_rhs per node: four for the ~24 per-element records of a node, one when they are a few tile sums
+  pd.rhsLanes = n && incPtr[n] <= 6ull * n ? 1u : 4u;
+  if (const char* e = tuning_env("PIES_PD_RHS_LANES")) pd.rhsLanes = std::atoi(e) == 1 ? 1u : 4u;
+  pd.tiles = PdTileArrays{};
+  if (tiled) {
+    PdTileArrays& T = pd.tiles;
+    uint32_t *d_info, *d_node, *d_local;
+    uint16_t *d_nptr, *d_inc;
+    if (int rc = upload(s, tiles.info, &d_info)) return rc;
+    if (int rc = upload(s, tiles.node, &d_node)) return rc;
+    if (int rc = upload(s, tiles.local, &d_local)) return rc;
+    if (int rc = upload(s, tiles.nptr, &d_nptr)) return rc;
+    if (int rc = upload(s, tiles.inc, &d_inc)) return rc;
+    T.ntiles = static_cast<uint32_t>(tiles.info.size());
+    T.info = d_info; T.node = d_node; T.local = d_local; T.nptr = d_nptr; T.inc = d_inc;
+    if (!s->h_pairDictIndex.empty() && s->d_pairDictTable) {
+      std::vector<uint16_t> idx(tiles.elem.size());
+      for (size_t k = 0; k < idx.size(); ++k) idx[k] = s->h_pairDictIndex[tiles.elem[k]];
+      uint16_t* d_idx;
+      if (int rc = upload(s, idx, &d_idx)) return rc;
+      T.dict = d_idx;
+    } else {
+      std::vector<float4> q0(tiles.elem.size()), q1(q0.size()), q2(q0.size()), vq2(q0.size());
+      for (size_t k = 0; k < q0.size(); ++k) {
+        const HostTet &a = s->h_tet[tiles.elem[k]], &b = s->h_volume[tiles.elem[k]];
+        q0[k] = make_float4(a.qinv[0], a.qinv[1], a.qinv[2], a.qinv[3]);
+        q1[k] = make_float4(a.qinv[4], a.qinv[5], a.qinv[6], a.qinv[7]);
+        q2[k] = make_float4(a.qinv[8], a.lo, a.hi, a.w);
+        vq2[k] = make_float4(b.qinv[8], b.lo, b.hi, b.w);
+      }
+      float4 *d0, *d1, *d2, *d3;
+      if (int rc = upload(s, q0, &d0)) return rc;
+      if (int rc = upload(s, q1, &d1)) return rc;
+      if (int rc = upload(s, q2, &d2)) return rc;
+      if (int rc = upload(s, vq2, &d3)) return rc;
+      T.q0 = d0; T.q1 = d1; T.q2 = d2; T.vq2 = d3;
+    }
+  }
   pd.kdiag = d_kdiag; pd.incPtr = d_incPtr; pd.incSlot = d_incSlot; pd.triCount = d_tri;
   pd.contribD = nullptr; pd.incPtrD = nullptr; pd.incSlotD = nullptr;
   pd.shape = ShapeArrays{};
@@ -265,6 +312,7 @@ int pd_build(pies_solver* s) {
   if (int rc = dev_alloc(s, n, &pd.statp, true)) return rc;
   if (int rc = dev_alloc(s, n, &pd.nstatic, true)) return rc;
   if (int rc = dev_alloc(s, std::max<size_t>(total, 1), &pd.contrib, true)) return rc;
+  if (tiled) pd.tiles.partial = pd.contrib + tileSlotBase;
   if (int rc = dev_alloc(s, n, &cg.cdiag, true)) return rc;
   if (int rc = dev_alloc(s, n, &cg.dinv, true)) return rc;
   if (int rc = dev_alloc(s, n, &cg.r)) return rc;
@@ -278,7 +326,17 @@ int pd_build(pies_solver* s) {
   if (int rc = dev_alloc(s, kCgBlocks * 6, &cg.partBnext, true)) return rc;
   cg.partB0 = cg.partB;
   cg.partB1 = cg.partBnext;
-  if (int rc = dev_alloc(s, 16, &cg.scal, true)) return rc;
+  if (int rc = dev_alloc(s, 32, &cg.scal, true)) return rc;
+  // one launch per iteration (pd_cg1_kernels.hip): 12-byte vector records in ping-pong pairs, partial sums of 9 per workgroup
+  for (int b = 0; b < 2; ++b) {
+    if (int rc = dev_alloc(s, n, &cg.t1[b], true)) return rc;
+    if (int rc = dev_alloc(s, n, &cg.c1[b], true)) return rc;
+    if (int rc = dev_alloc(s, n, &cg.a1[b], true)) return rc;
+    if (int rc = dev_alloc(s, kCgBlocks * 9, &cg.part1[b], true)) return rc;
+  }
+  if (int rc = dev_alloc(s, n, &cg.p1, true)) return rc;
+  cg.kdiag = d_kdiag;
+  cg.single = 0;
   if (int rc = dev_alloc(s, 2, &cg.ticket, true)) return rc;
   if (int rc = dev_alloc(s, 8, &cg.stats, true)) return rc;
   // ---- point-triangle contact pipeline (Solver.cpp:680-875) ------------------------------------------------

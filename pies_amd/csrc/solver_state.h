@@ -140,6 +140,17 @@ struct Probe {
   }
 };
 
+// Tiles of the PD strain + volume local step (pd_tiles.cpp; device form: PdTileArrays), fixed strides per tile
+struct PdTilePlan {
+  std::vector<uint32_t> info;    // per tile: nodes | elements << 16
+  std::vector<uint32_t> node;    // kTileNodes per tile: global node index (unused slots repeat the last node)
+  std::vector<uint32_t> elem;    // kTileElems per tile: host element index (unused slots repeat the last element)
+  std::vector<uint32_t> local;   // kTileElems per tile
+  std::vector<uint16_t> nptr;    // kTileNptr per tile
+  std::vector<uint16_t> inc;     // 4 * kTileElems per tile
+  uint64_t tileNodes = 0;        // sum of the tiles' node counts
+};
+
 template <class T> struct DevArray {
   T* p = nullptr;
   size_t n = 0;
@@ -156,6 +167,8 @@ struct pies_solver {
   hipEvent_t evFork = nullptr, evJoin = nullptr;
   bool triLevelsForked = true;
   bool pdLocalPacked = true;    // strain + volume local step two elements per lane in packed fp32 (PIES_PD_LOCAL_PACKED=0: one per lane)
+  bool pdSingleCg = true;       // the global step's CG with one launch per iteration where it applies (PIES_PD_CG_SINGLE=0: the two-launch form everywhere)
+  bool pdFuseRhs = true;        // its residual kernel evaluates the right-hand side when a node's records are tile sums (PIES_PD_FUSE_RHS=0: k_pd_rhs)
   bool pcgOverflow = true;      // a solve above the tolerance after its captured iterations goes on inside the last launch (PIES_PCG_OVERFLOW=0: off)
   bool pcgPinned = false;       // PIES_PCG_BUDGET
   uint32_t pcgPinnedBudget = 32;
@@ -168,6 +181,8 @@ struct pies_solver {
   uint16_t* d_pairDictIndex = nullptr;  // PD, paired elements: index of the element's set of constants (rest dictionary), or nullptr
   float4* d_pairDictTable = nullptr;
   uint32_t pairDictSets = 0;
+  std::vector<uint16_t> h_pairDictIndex;  // host copy (the tile plan stores it in tile order)
+  uint32_t pdTiles = 0;                  // PD: tiles of the strain + volume local step (0: per-(element, node) records)
   uint32_t pdRowStencils = 0;           // PD: distinct rows of the system matrix in its row dictionary (0: none)
   bool tetVolumePaired = false;    // PD: h_volume[k] and h_tet[k] are the same element for every k (fused local step)
   bool triangleCollisions = true;  // PD point-triangle CCD contacts (Solver.cpp:693-797); extension flag to switch off
