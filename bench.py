@@ -32,7 +32,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "tests")):
+for p in (ROOT, os.path.join(ROOT, "benchlib")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -453,7 +453,7 @@ def order_deviation(device):
     log("order deviation: config 2")
     out["config2_l100k_20_iterations"] = beam(scenes.L100K, ITERATIONS)
     log("order deviation: collisions")
-    from test_collisions_gpu import particles
+    particles = scenes.loose_particles
     p, v = particles((25, 50, 50))  # config 4 at 1/8 (the reference-order pass is one sequential chain, ~20 us per node)
 
     def make(rule):

@@ -75,3 +75,12 @@ def build_unstructured(solver, mesh, w_tet=0.05, w_dist=0.5, radius=0.3):
     solver.add_nodes_raw(pos, radius=radius)
     solver.add_distance(edges, w_dist)
     solver.add_tet(tets, w_tet)
+
+
+def loose_particles(dims, spacing=0.9, jitter=0.05, seed=1234, y0=0.5):
+    W, H, D = dims
+    rng = np.random.default_rng(seed)
+    p = np.stack(np.meshgrid(np.arange(W), np.arange(H), np.arange(D), indexing="ij"), -1).reshape(-1, 3).astype(np.float64)
+    p = p * spacing + rng.uniform(-jitter, jitter, p.shape) + [0, y0, 0]
+    v = np.random.default_rng(4321).uniform(-1, 1, p.shape)
+    return p.astype(np.float32), v.astype(np.float32)

@@ -646,7 +646,7 @@ static int adapt_pcg_budget(pies_solver* s) {
     s->pcgCooldown = 24;
   } else if (used > budget || (pd_single_cg(s) && used == budget && budget < s->pcgMaxIters)) {
     // converged, but only because the last launch went on by itself (k_cg_update's continuation): capture what it needed
-    budget = std::min(s->pcgMaxIters, used + std::max(2u, (used + 2u) / 3u));
+    budget = std::min(s->pcgMaxIters, used + std::max(pd_single_cg(s) ? 1u : 2u, (used + 2u) / 3u));
     s->pcgCalm = 0;
     s->pcgWindowMax = 0;
     s->pcgCooldown = 8;

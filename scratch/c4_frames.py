@@ -1,7 +1,7 @@
 """config 4 frame by frame (tick + synchronise): per-frame time, levels, captured rounds"""
 import sys, time, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "tests")): sys.path.insert(0, p)
+for p in (ROOT, os.path.join(ROOT, "benchlib")): sys.path.insert(0, p)
 import numpy as np, bench, scenes
 from pies_amd import capi
 p, v = bench.config4_particles()

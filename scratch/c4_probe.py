@@ -1,7 +1,7 @@
 """config 4 probe: substeps/s and health for a collision order"""
 import sys, time, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "tests")): sys.path.insert(0, p)
+for p in (ROOT, os.path.join(ROOT, "benchlib")): sys.path.insert(0, p)
 import numpy as np, bench, scenes
 from pies_amd import capi
 order = int(sys.argv[1]) if len(sys.argv) > 1 else 2

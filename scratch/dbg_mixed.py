@@ -1,6 +1,6 @@
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "tests")): sys.path.insert(0, p)
+for p in (ROOT, os.path.join(ROOT, "benchlib")): sys.path.insert(0, p)
 import numpy as np, scenes
 from pies_amd import capi as pies
 import oracle_api as oracle

@@ -1,6 +1,6 @@
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "tests")): sys.path.insert(0, p)
+for p in (ROOT, os.path.join(ROOT, "benchlib")): sys.path.insert(0, p)
 import numpy as np, bench, scenes
 from pies_amd import capi
 t0=time.perf_counter(); g = bench.contact_scene(capi, 0); g.finalize(); print("finalize %.1f ms" % (1e3*(time.perf_counter()-t0)))

@@ -1,0 +1,9 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "benchlib")):
+    sys.path.insert(0, p)
+import bench, scenes
+from pies_amd import capi
+g = bench.pd_beam(scenes.L100K, 0, settle=40)
+print(g.pcg_health())
+g.close()

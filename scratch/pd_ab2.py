@@ -5,7 +5,7 @@ difference to the first variant after the timed ticks."""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "tests")):
+for p in (ROOT, os.path.join(ROOT, "benchlib")):
     sys.path.insert(0, p)
 import numpy as np  # noqa: E402
 import bench  # noqa: E402

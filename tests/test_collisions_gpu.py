@@ -18,13 +18,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
-def particles(dims, spacing=0.9, jitter=0.05, seed=1234, y0=0.5):
-    W, H, D = dims
-    rng = np.random.default_rng(seed)
-    p = np.stack(np.meshgrid(np.arange(W), np.arange(H), np.arange(D), indexing="ij"), -1).reshape(-1, 3).astype(np.float64)
-    p = p * spacing + rng.uniform(-jitter, jitter, p.shape) + [0, y0, 0]
-    v = np.random.default_rng(4321).uniform(-1, 1, p.shape)
-    return p.astype(np.float32), v.astype(np.float32)
+particles = scenes.loose_particles
 
 
 def pair(pies, oracle, build, iterations, ticks, rule=2, oracle_rule=None, **opt):

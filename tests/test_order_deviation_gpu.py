@@ -34,7 +34,7 @@ def test_config1_layered_and_coloured_vs_exact(pies):
 
 def test_pair_order_vs_reference_order(pies):
     """config 4 in miniature (the reference-order pass is one sequential chain: ~20 us per node)"""
-    from test_collisions_gpu import particles
+    particles = scenes.loose_particles
     p, v = particles((12, 14, 16))
 
     def make(rule):

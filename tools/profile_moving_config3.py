@@ -2,7 +2,7 @@
 """config 3 as bench.py measures it (the beam after 34 settle ticks, swinging), 8 more ticks: for a kernel trace of the moving state"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "tests")):
+for p in (ROOT, os.path.join(ROOT, "benchlib")):
     sys.path.insert(0, p)
 import bench, scenes
 from pies_amd import capi

@@ -2,7 +2,7 @@
 """config 4, 12 ticks (the last four are the settled state): for a kernel trace"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "tests")):
+for p in (ROOT, os.path.join(ROOT, "benchlib")):
     sys.path.insert(0, p)
 import bench, scenes
 from pies_amd import capi
