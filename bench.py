@@ -53,6 +53,18 @@ DEVICE_KERNEL = {"layer": "k_layer", "tet": "k_tet", "wave": "k_wave", "pd_local
                  "pd_rhs": "k_pd_rhs", "pd_cg_update": "k_cg_update", "collide": "k_pair_round", "hash": "k_radix_scatter"}
 
 
+def device_kernel(solver, cls):
+    """Name of the kernel that runs class `cls` in the graph variant `solver` captured."""
+    if cls == "pd_local_tet" and solver.count(capi.PD_TILES):
+        return "k_pd_local_tiles"
+    if solver.count(capi.PD_CG_SINGLE):
+        if cls == "pd_spmv":
+            return "k_cg1_iter"
+        if cls == "pd_rhs" and solver.count(capi.PD_TILES):
+            return "k_cg1_init"
+    return DEVICE_KERNEL.get(cls, "k_" + cls)
+
+
 def log(msg):
     """Progress on stderr (stdout carries the one JSON line)."""
     print("[bench %6.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
@@ -156,7 +168,7 @@ def roofline(solver, cls, bytes_per_unit, substeps=3, note=None, workload="confi
     timed as the replay of that very graph between two events (duration / launches).  Otherwise in situ: every launch of the
     class inside eagerly launched whole substeps is bracketed by two events, and what a bracket costs around nothing (measured
     in the same pass) is taken off."""
-    kname = DEVICE_KERNEL.get(cls, "k_" + cls)
+    kname = device_kernel(solver, cls)
     if whole_graph:
         launches, ms, units = solver.profile_substep(K[cls])
         if launches == 0 or ms <= 0:
@@ -208,22 +220,64 @@ def pd_bytes(solver):
     n = solver.count(capi.NODES)
     nnz = solver.count(capi.SYSTEM_NNZ)
     paired = solver.count(capi.VOLUME) > 0 and solver.launch_counts().get("pd_local_volume", 0) == 0
-    inc = (4 * (solver.count(capi.TET) + (0 if paired else solver.count(capi.VOLUME)) + solver.count(capi.BEND))
+    tiles, records = solver.count(capi.PD_TILES), solver.count(capi.PD_TILE_RECORDS)
+    ntet = solver.count(capi.TET)
+    inc = (4 * (ntet + (0 if paired else solver.count(capi.VOLUME)) + solver.count(capi.BEND))
            + 2 * solver.count(capi.DISTANCE) + solver.count(capi.POSITION))
+    # 148 B per tet / volume projection.  A fused strain + volume launch does two projections per element from
+    # ONE gather and adds the two contributions into one 12-byte record per corner: ids 16 + Qinv 36 + 2 x (min, max, w) 24
+    # + four positions 48 + four records 48 = 172 B; with the rest dictionary the 60 bytes of constants are a 2-byte index
+    # into a cache-resident table: 114 B.
+    local = (114 if solver.count(capi.REST_SETS) else 172) if paired else 148
+    if tiles and paired:
+        # tile-resident (round 4): per element pair four 8-bit node indices 4 + its four list entries 8 + constants (2 with the
+        # dictionary, 64 without); per (tile, node) record: node index 4 + position 16 + list offset 2 + the sum written 12
+        local = 12 + (2 if solver.count(capi.REST_SETS) else 64) + 34.0 * records / max(1, ntet)
+        inc = inc - 4 * ntet + records  # what the right-hand side gathers: one sum per (tile, node)
+    rhs = (16.0 * inc + 32.0 * n) / n
+    single = bool(solver.count(capi.PD_CG_SINGLE))
     return {
-        # 148 B per tet / volume projection.  A fused strain + volume launch does two projections per element from
-        # ONE gather and adds the two contributions into one 12-byte record per corner: ids 16 + Qinv 36 + 2 x (min, max, w) 24
-        # + four positions 48 + four records 48 = 172 B (round 2 counted 196: two sets of records); with the rest dictionary
-        # the 60 bytes of constants are a 2-byte index into a cache-resident table: 114 B.  (2 x 148 would count the shared
-        # inputs twice; either older figure puts the kernel above the roofline at 1M particles.)
-        "pd_local_tet": (114 if solver.count(capi.REST_SETS) else 172) if paired else 148, "pd_local_volume": 148, "pd_local_distance": 64, "pd_predict": 52,
-        # gather formulation: one 12-byte contribution + its 4-byte slot index per (constraint, node) incidence, inertia term
-        # in, right-hand side out (the survey's scatter formulation would be 148 B per tetrahedron)
-        "pd_rhs": (16.0 * inc + 32.0 * n) / n,
-        "pd_spmv": (8.0 * nnz + 28.0 * n) / n,   # col + val per stored entry; rowptr, x, y per row; 3 right-hand sides fused
+        "pd_local_tet": local, "pd_local_volume": 148, "pd_local_distance": 64, "pd_predict": 52,
+        # gather formulation: one 12-byte contribution + its 4-byte slot index per incidence, inertia term in, right-hand side
+        # out.  When the residual kernel of the one-launch CG evaluates the right-hand side itself (tiles), the launch also does
+        # the residual's SpMV: + 8 nnz + 28 N (and the right-hand side is never written)
+        "pd_rhs": rhs + ((8.0 * nnz + 28.0 * n) / n - 16.0 if single and tiles else 0.0),
+        # SpMV 8 nnz + 28 N; a whole PCG iteration (SpMV + its ten three-component vector passes) 8 nnz + 148 N.
+        # k_cg1_iter IS a whole iteration in one launch; k_cg_ap is the SpMV (+ the direction update) of the two-launch form
+        "pd_spmv": (8.0 * nnz + (148.0 if single else 28.0) * n) / n,
+        "pd_spmv_only": (8.0 * nnz + 28.0 * n) / n,
         "pd_cg_update": 120,                     # the PCG iteration's 10 three-component vector passes
         "pd_velocity": 60,
     }
+
+
+def pd_rooflines(g, workload, substeps):
+    """The three PD rooflines of a solver in its captured variant: local step, the CG iteration (by SURVEY 8d's bytes of what the
+    launch does AND by the SpMV's bytes alone), right-hand side."""
+    B = pd_bytes(g)
+    single, tiles = bool(g.count(capi.PD_CG_SINGLE)), bool(g.count(capi.PD_TILES))
+    out = {"roofline": roofline(g, "pd_local_tet", B["pd_local_tet"], substeps=substeps, workload=workload, note=(
+        "tile-resident strain + volume local step (one wavefront per tile of 128 element pairs, two per lane in packed fp32): the "
+        "bytes are what the launch has to move - 12-14 B per element pair + 34 B per (tile, node) sum; SURVEY 8d's count for the "
+        "same work would be two 148-B projections + the 148-B scatter into the right-hand side per element.  The launch is bound "
+        "by VALU issue (about 2 000 instructions per lane), not by HBM" if tiles else
+        "fused strain + volume local step: two projections per element from one gather and one SVD, one 12-byte record per "
+        "corner; bound by VALU issue at 100k particles"))}
+    sp = roofline(g, "pd_spmv", B["pd_spmv"], substeps=substeps, workload=workload, note=(
+        "ONE launch = one whole PCG iteration (Chronopoulos-Gear form: scalars from the previous launch's partial sums, the "
+        "neighbours' new preconditioned residual recomputed in the gather, x / r / p / s of the own rows, the next dot products): "
+        "SURVEY 8d's 8 nnz + 148 N bytes per launch; frac_spmv_bytes_only prices the same launch by the SpMV's 8 nnz + 28 N alone.  "
+        "The solves of the timed pass do not take the converged early exit.  On a lattice the launch does not stream the matrix: "
+        "rows with the same stencil share one copy of it (row dictionary)" if single else
+        "SELL-64 SpMV over 3 right-hand sides + fused direction update; 8 nnz + 28 N bytes per launch (SURVEY 8d)"))
+    if sp:
+        sp["frac_spmv_bytes_only"] = sp["frac"] * B["pd_spmv_only"] / B["pd_spmv"]
+    out["roofline_spmv"] = sp
+    out["roofline_rhs"] = roofline(g, "pd_rhs", B["pd_rhs"], substeps=substeps, workload=workload, note=(
+        "the residual kernel of the one-launch CG, which also evaluates the right-hand side (inertia term + the node's 3-4 tile sums "
+        "+ contact / goal / floor terms): there is no k_pd_rhs launch and the right-hand side never travels through HBM" if single and tiles
+        else None))
+    return out
 
 
 def replay_latencies(solver, bytes_per_unit=None):
@@ -270,12 +324,12 @@ def config4_particles():
     return p.astype(np.float32), v.astype(np.float32)
 
 
-def contact_scene(mod, device=None):
+def contact_scene(mod, device=None, dims=None):
     """One GPU's share of BASELINE configs[4] with contacts that bind: the 25x25x400 body (250 000 particles) lying on the
     floor and a second, small body landing on it (the scene of tests/test_tri_collisions_gpu.py's config-5 parity test)."""
     opts = mod.Options(solver=mod.PD, iterations=10)
     g = mod.Solver(opts, device=device) if mod is capi else mod.OracleSolver(opts)
-    W, H, D = scenes.L250K
+    W, H, D = dims or scenes.L250K
     g.create_tet_box(W, H, D, translation=(0.0, 0.04, 0.0), w=1.0, volume=True, triangles=True)
     g.create_tet_box(8, 6, 30, translation=(3.3, 0.04 + (H - 1) + 0.04, 40.4), w=1.0, volume=True, triangles=True)
     v = g.velocities
@@ -475,35 +529,29 @@ def run_config3(device, full):
     g = pd_beam(scenes.L100K, device)
     el = timed_ticks(g, 30, 3, lambda: None)
     res, iters, solves = g.pcg_stats()
-    B = pd_bytes(g)
     out = {"value": 30 / el, "unit": "substeps/s", "workload": "BASELINE configs[2]: 20x20x250 beam, PD, 539334 tet + 539334 volume "
            "constraints, 10 local/global iterations, floor + point-triangle pipeline on, Jacobi-PCG rel. tol 3e-7 (captured "
            "iteration budget adapts)", "pcg_max_rel_residual": res, "pcg_max_iterations_used": iters, "pcg_health": g.pcg_health(),
-           "launches_per_substep": sum(g.launch_counts().values()),
-           "projections_per_sec": 30 / el * 10 * (g.count(capi.TET) + g.count(capi.VOLUME) + g.count(capi.POSITION)),
-           "roofline": roofline(g, "pd_local_tet", B["pd_local_tet"], workload="config3", note="fused strain + volume local step: two projections per "
-                                "element from one gather and one SVD, the two contributions summed into one 12-byte record per "
-                                "corner, the element's 60 bytes of constants a 2-byte index into the rest dictionary: 114 B per "
-                                "element pair (172 without the dictionary; two separate 148-B projections of SURVEY 8d would be "
-                                "296 B: multiply achieved by 2.6 for that count).  Two elements per lane in packed fp32: at 100k "
-                                "particles the launch is bound by VALU issue and launch latency"),
-           "roofline_spmv": roofline(g, "pd_spmv", B["pd_spmv"], workload="config3", note="SELL-64 SpMV over 3 right-hand sides + fused direction "
-                                     "update; 8 nnz + 28 N bytes per launch (SURVEY 8d); the solves of the timed pass do not take "
-                                     "the converged early exit.  On a lattice the launch does not stream the matrix: rows with the same "
-                                     "stencil share one copy of it (row dictionary, DESIGN.md section 5), a row is one word"),
-           "roofline_rhs": roofline(g, "pd_rhs", B["pd_rhs"], workload="config3")}
+           "launches_per_substep": sum(g.launch_counts().values()), "tiles": g.count(capi.PD_TILES),
+           "tile_records_per_node": g.count(capi.PD_TILE_RECORDS) / max(1, g.count(capi.NODES)), "cg_one_launch_per_iteration": bool(g.count(capi.PD_CG_SINGLE)),
+           "projections_per_sec": 30 / el * 10 * (g.count(capi.TET) + g.count(capi.VOLUME) + g.count(capi.POSITION))}
+    out.update(pd_rooflines(g, "config3", 3))
     if full:
         out["isolated_replay_latencies"] = replay_latencies(g)
     g.close()
     return out
 
 
-def run_unstructured(device):
-    """configs[1] on an unstructured mesh: Delaunay beam of the same size (the lattice stands in for tetgen in the headline)"""
+def run_unstructured(device, with_coloured=True):
+    """configs[1] and configs[2] on an unstructured mesh: Delaunay beam of the same size (the lattice stands in for tetgen in the
+    headline): PBD under LAYERED (and COLOURED), and PD with its local-step / CG-iteration / right-hand-side rooflines on the
+    paths a lattice does not take (SELL matrix instead of the row dictionary, per-element rest constants)."""
     mesh = scenes.delaunay_beam(scenes.L100K)
     un = {"workload": "Delaunay triangulation of a jittered 20x20x250 lattice: %d particles, %d distance + %d tet-strain constraints, "
                       "PBD, 20 iterations" % (len(mesh[0]), len(mesh[2]), len(mesh[1]))}
     for name, sched in (("layered", capi.SCHEDULE_LAYERED), ("coloured", capi.SCHEDULE_COLOURED)):
+        if name == "coloured" and not with_coloured:
+            continue
         g = capi.Solver(scenes.pbd_options(capi, ITERATIONS), device=device)
         scenes.build_unstructured(g, mesh)
         scenes.perturb(g, 1234, 0.03)
@@ -513,10 +561,26 @@ def run_unstructured(device):
         el = timed_ticks(g, 20, 2, lambda: None)
         un[name] = {"value": 20 / el, "unit": "substeps/s", "launches_per_substep": sum(g.launch_counts().values())}
         g.close()
+    g = capi.Solver(capi.Options(solver=capi.PD, iterations=10), device=device)
+    scenes.build_unstructured_pd(g, mesh)
+    g.finalize()
+    for _ in range(20):
+        g.tick_async(1)
+        g.synchronize()
+    el = timed_ticks(g, 20, 2, lambda: None)
+    res, iters, solves = g.pcg_stats()
+    pd = un["pd"] = {"value": 20 / el, "unit": "substeps/s", "workload": "the same mesh, PD: a strain + a volume constraint per tetrahedron (w = 1), "
+                     "surface triangles, end cap pinned, 10 local/global iterations", "pcg_max_rel_residual": res,
+                     "pcg_max_iterations_used": iters, "pcg_health": g.pcg_health(), "failed": g.failed,
+                     "rest_sets": g.count(capi.REST_SETS), "row_stencils": g.count(capi.ROW_STENCILS), "tiles": g.count(capi.PD_TILES),
+                     "tile_records_per_node": g.count(capi.PD_TILE_RECORDS) / max(1, g.count(capi.NODES)),
+                     "launches_per_substep": sum(g.launch_counts().values())}
+    pd.update(pd_rooflines(g, "none", 2))
+    g.close()
     return un
 
 
-def run_config5_share(device):
+def run_config5_share(device, with_rooflines=True):
     """configs[4], one GPU's share, with contacts that bind"""
     g = contact_scene(capi, device)
     g.finalize()
@@ -535,7 +599,6 @@ def run_config5_share(device):
     binding = [f for f in frames if f[1] > 0]
     quiet = [f for f in frames[6:] if f[1] == 0]
     res, iters, solves = g.pcg_stats()
-    B = pd_bytes(g)
     ms = sorted(1e3 * f[0] for f in frames[1:])
     out = {"value": len(binding) / max(1e-9, sum(f[0] for f in binding)), "unit": "substeps/s",
            "workload": "BASELINE configs[4], one GPU's share: 25x25x400 beam (250 000 particles) on the floor + an 8x6x30 body "
@@ -548,10 +611,41 @@ def run_config5_share(device):
            "value_without_tri_contacts": len(quiet) / max(1e-9, sum(f[0] for f in quiet)) if quiet else None,
            "pcg_max_rel_residual": res, "pcg_max_iterations_used": iters, "pcg_health": g.pcg_health(), "failed": g.failed,
            "launches_per_substep": sum(g.launch_counts().values()),
-           "roofline": roofline(g, "pd_local_tet", B["pd_local_tet"], substeps=2, workload="contacts"),
-           "roofline_spmv": roofline(g, "pd_spmv", B["pd_spmv"], substeps=2, workload="contacts")}
+           }
+    if with_rooflines:
+        out.update(pd_rooflines(g, "contacts", 2))
     g.close()
     return out
+
+
+def run_config5_rank(device, dims, barrier, dist):
+    """BASELINE configs[4] as a multi-rank workload: every rank owns one body of the config-5 pattern (lying on the floor, a
+    small body landing on it: floor and point-triangle contacts bind) and runs 18 frames of one tick + one synchronisation;
+    value = the frames of all ranks over the slowest rank's time (the same max / sum reduce as the headline)."""
+    g = contact_scene(capi, device, dims)
+    g.finalize()
+    p0, q0, v0 = g.positions.copy(), g.prev_positions.copy(), g.velocities.copy()
+    g.tick_async(1)  # first replay of the graph (upload of the executable graph, first touch of scratch arrays), then back to the start
+    g.synchronize()
+    g.set_positions(p0); g.set_prev_positions(q0); g.set_velocities(v0)
+    frames = 18
+    barrier()
+    t0 = time.perf_counter()
+    contacts = 0
+    for _ in range(frames):
+        g.tick_async(1)
+        g.synchronize()
+        contacts = max(contacts, len(g.tri_collisions))
+    barrier()
+    el = time.perf_counter() - t0
+    failed = bool(g.failed)
+    n = g.count(capi.NODES)
+    g.close()
+    el, total = aggregate(el, frames, dist)
+    return {"value": total / el, "unit": "substeps/s", "frames_per_rank": frames, "particles_per_rank": n, "max_tri_contacts_rank0": contacts,
+            "failed_rank0": failed, "workload": "BASELINE configs[4] pattern, one body per rank: %dx%dx%d beam on the floor + an 8x6x30 body "
+            "landing on it, PD, strain + volume constraints, 10 iterations, floor and point-triangle contacts; one tick + one "
+            "synchronisation per frame, contact onset included" % tuple(dims)}
 
 
 def run_pd_contacts(device):
@@ -650,11 +744,13 @@ def run_config2_default_tick(device, dims, steps, with_exact):
     return out
 
 
-def scale_profiles(device):
+def scale_profiles(device, with_coloured=True):
     """The same kernels at 1M particles (100x100x100), where a launch is long enough for HBM rather than the kernel boundary
     to bound it: whole-substep throughput and in-situ rooflines."""
     out = {}
     for name, sched in (("pbd_1m", capi.SCHEDULE_LAYERED), ("pbd_1m_coloured", capi.SCHEDULE_COLOURED)):
+        if sched == capi.SCHEDULE_COLOURED and not with_coloured:
+            continue
         log(name)
         g = build_scene(capi, scenes.L1M, 99, schedule=sched, device=device)
         g.finalize()
@@ -669,13 +765,13 @@ def scale_profiles(device):
         g.close()
     log("pd_1m")
     g = pd_beam(scenes.L1M, device, settle=12)
-    el = timed_ticks(g, 3, 1, lambda: None)
-    B = pd_bytes(g)
-    out["pd_1m"] = {"substeps_per_sec": 3 / el, "pcg_stats": g.pcg_stats(),
-                    "roofline": roofline(g, "pd_local_tet", B["pd_local_tet"], substeps=1, workload="pd1m"),
-                    "roofline_spmv": roofline(g, "pd_spmv", B["pd_spmv"], substeps=1, workload="pd1m"),
-                    "roofline_rhs": roofline(g, "pd_rhs", B["pd_rhs"], substeps=1, workload="pd1m"),
-                    "roofline_cg_update": roofline(g, "pd_cg_update", B["pd_cg_update"], substeps=1, workload="pd1m")}
+    el = timed_ticks(g, 5, 1, lambda: None)
+    out["pd_1m"] = {"substeps_per_sec": 5 / el, "pcg_stats": g.pcg_stats(), "pcg_health": g.pcg_health(), "tiles": g.count(capi.PD_TILES),
+                    "tile_records_per_node": g.count(capi.PD_TILE_RECORDS) / max(1, g.count(capi.NODES)),
+                    "launches_per_substep": sum(g.launch_counts().values())}
+    out["pd_1m"].update(pd_rooflines(g, "pd1m", 1))
+    if not g.count(capi.PD_CG_SINGLE):
+        out["pd_1m"]["roofline_cg_update"] = roofline(g, "pd_cg_update", pd_bytes(g)["pd_cg_update"], substeps=1, workload="pd1m")
     g.close()
     return out
 
@@ -723,14 +819,14 @@ def compact_line(full):
     put("exact_order", "exact_order", "value")
     put("coloured", "coloured_schedule", "value")
     put("pies_tick", "tick_inclusive", "pies_tick_substeps_per_sec")
-    put("async_export", "tick_inclusive", "async_export_substeps_per_sec")
     put("config2_collisions_on", "config2_default_tick", "config2", "layered", "value")
     put("config2_collisions_on_failed", "config2_default_tick", "config2", "layered", "failed")
     put("box100k_collisions_on", "config2_default_tick", "box_100k_distance_only", "layered", "value")
     put("box100k_collisions_on_exact", "config2_default_tick", "box_100k_distance_only", "exact", "value")
     put("config3_value", "other_configs", "pd_config3", "value")
     put("config3_frac_local", "other_configs", "pd_config3", "roofline", "frac")
-    put("config3_frac_spmv", "other_configs", "pd_config3", "roofline_spmv", "frac")
+    put("config3_frac_spmv", "other_configs", "pd_config3", "roofline_spmv", "frac_spmv_bytes_only")
+    put("config3_frac_pcg_iter", "other_configs", "pd_config3", "roofline_spmv", "frac")
     put("config4_value", "other_configs", "collisions_config4", "value")
     put("config4_settled", "other_configs", "collisions_config4", "settled_value")
     put("config4_frac_resolve", "other_configs", "collisions_config4", "roofline", "frac")
@@ -741,10 +837,20 @@ def compact_line(full):
     put("pbd_1m_value", "scale_1m", "pbd_1m", "substeps_per_sec")
     put("pbd_1m_frac", "scale_1m", "pbd_1m", "roofline", "frac")
     put("pd_1m_value", "scale_1m", "pd_1m", "substeps_per_sec")
-    put("pd_1m_frac_spmv", "scale_1m", "pd_1m", "roofline_spmv", "frac")
+    put("pd_1m_frac_local", "scale_1m", "pd_1m", "roofline", "frac")
+    put("pd_1m_frac_spmv", "scale_1m", "pd_1m", "roofline_spmv", "frac_spmv_bytes_only")
+    put("pd_1m_frac_pcg_iter", "scale_1m", "pd_1m", "roofline_spmv", "frac")
+    put("pd_1m_frac_rhs", "scale_1m", "pd_1m", "roofline_rhs", "frac")
+    put("unstructured_value", "other_configs", "unstructured_config2", "layered", "value")
+    put("unstructured_pd_value", "other_configs", "unstructured_config2", "pd", "value")
+    put("unstructured_pd_frac_pcg_iter", "other_configs", "unstructured_config2", "pd", "roofline_spmv", "frac")
+    put("config5_value", "config5_all_ranks", "value")
+    put("value_export_inclusive", "tick_inclusive", "async_export_substeps_per_sec")
     c.update(s)
     if full.get("errors"):
         c["errors"] = len(full["errors"])
+    if full.get("skipped"):
+        c["skipped"] = len(full["skipped"])
     c["full_report"] = "bench_full.json"
     line = json.dumps(c, allow_nan=False, separators=(",", ":"))
     if len(line) > COMPACT_LIMIT:  # never let extras cost the record: drop the scalars, then the sample prose
@@ -801,6 +907,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true", help="skip the in-situ timing pass (roofline = null)")
     ap.add_argument("--no-extras", action="store_true", help="skip BASELINE configs 3 and 4")
     ap.add_argument("--cpu-budget", type=float, default=8.0, help="seconds of CPU work per baseline sample")
+    ap.add_argument("--config5-dims", type=int, nargs=3, default=list(scenes.L250K), help="the large body of the config-5 region (tests shrink it)")
+    ap.add_argument("--time-budget", type=float, default=80.0, help="seconds after which the default run starts no further optional section "
+                    "(they are named in `skipped`; --full ignores it)")
     args = ap.parse_args()
     if args.quick:
         args.no_exact = args.no_extras = True
@@ -863,7 +972,10 @@ def main():
             "config": {"workload": "BASELINE configs[1]: %dx%dx%d lattice beam, %d particles, %d distance + %d tet-strain "
                                    "constraints, PBD, %d iterations, 1 substep/tick, collisions off, one body per GPU"
                                    % (dims + (g.count(capi.NODES), g.count(capi.DISTANCE), g.count(capi.TET), ITERATIONS)),
-                       "schedule": args.schedule, "parallelism": "replicas x%d" % world, "launches_per_substep": sum(lc.values())},
+                       "schedule": args.schedule, "parallelism": "replicas x%d" % world, "launches_per_substep": sum(lc.values()),
+                       "value_is": "state resident in HBM across ticks (pies_tick_async); value_export_inclusive = the same ticks with "
+                                   "every frame's positions delivered to the host (asynchronous export), pies_tick = the synchronous "
+                                   "Pies::Solver::tick"},
             "projections_per_sec": value * proj,
             "roofline": None if args.no_roofline else roofline(g, dom, per_unit, whole_graph=lc.get(dom, 0) == sum(lc.values()),
                                                                note="algorithmic bytes = the projections and per-node steps "
@@ -879,6 +991,14 @@ def main():
             + BYTES["bend"] * g.count(capi.BEND))
         result["substep_algorithmic_GBs_per_gpu"] = per_substep_bytes * (value / world) / 1e9
     g.close()
+
+    # BASELINE configs[4] on every rank (N > 1: the second timed region; N = 1 runs the same scene as a section below)
+    c5 = None
+    if world > 1:
+        log("config 5 region (one contact scene per rank)")
+        c5 = run_config5_rank(device_index, tuple(args.config5_dims), barrier, dist)
+    if rank == 0 and c5 is not None:
+        result["config5_all_ranks"] = c5
 
     if rank == 0:
         def section(name, fn, *a, **kw):
@@ -929,17 +1049,27 @@ def main():
                 return out
             result["exact_order"] = section("exact schedule", exact)
         if one and not args.no_extras:
-            result["config2_default_tick"] = section("config 2 with the node-node pass on", run_config2_default_tick, device_index, dims,
-                                                     max(2, min(args.steps, 20)), args.full)
+            result["skipped"] = []
+
+            def optional(name, fn, *a, **kw):
+                """Sections of the default run beyond configs 2-4: started only while the run is inside its time budget."""
+                if not args.full and time.perf_counter() - T_START > args.time_budget:
+                    result["skipped"].append(name)
+                    log("skipped (time budget): " + name)
+                    return None
+                return section(name, fn, *a, **kw)
+
             oc = result["other_configs"] = {}
             oc["pd_config3"] = section("config 3 (PD)", run_config3, device_index, args.full)
             oc["collisions_config4"] = section("config 4 (500k particles, node-node collisions)", run_config4, device_index)
+            result["scale_1m"] = optional("1M-particle measurements", scale_profiles, device_index, args.full)
+            oc["pd_config5_per_gpu"] = optional("config 5 share (250k particles, PD, binding contacts)", run_config5_share, device_index, args.full)
+            oc["unstructured_config2"] = optional("unstructured beam (PBD and PD)", run_unstructured, device_index, args.full)
+            result["config2_default_tick"] = optional("config 2 with the node-node pass on", run_config2_default_tick, device_index, dims,
+                                                      max(2, min(args.steps, 20)), args.full)
             if args.full:
-                oc["unstructured_config2"] = section("unstructured beam", run_unstructured, device_index)
-                oc["pd_config5_per_gpu"] = section("config 5 share (250k particles, PD, binding contacts)", run_config5_share, device_index)
                 oc["pd_contacts"] = section("PD contact scene", run_pd_contacts, device_index)
                 result["order_deviation"] = section("order deviation", order_deviation, device_index)
-                result["scale_1m"] = section("1M-particle measurements", scale_profiles, device_index)
                 if not args.no_cpu_baseline:
                     if oc.get("pd_config3"):
                         oc["pd_config3"]["cpu_baseline"] = section("CPU baseline (config 3)", cpu_baseline_pd, scenes.L100K, args.cpu_budget)

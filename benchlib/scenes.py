@@ -77,6 +77,35 @@ def build_unstructured(solver, mesh, w_tet=0.05, w_dist=0.5, radius=0.3):
     solver.add_tet(tets, w_tet)
 
 
+def boundary_triangles(pos, tets):
+    """Faces that belong to exactly one tetrahedron, wound so that the normal points away from the tetrahedron's fourth node
+    (what addTriMeshVolume keeps of tetgen's face list, Src/PrimitiveUtilities.cpp:243-266)."""
+    tets = np.asarray(tets, dtype=np.int64)
+    faces = np.concatenate([tets[:, [1, 2, 3]], tets[:, [0, 3, 2]], tets[:, [0, 1, 3]], tets[:, [0, 2, 1]]])
+    opp = np.concatenate([tets[:, 0], tets[:, 1], tets[:, 2], tets[:, 3]])
+    key = np.sort(faces, axis=1)
+    _, first, counts = np.unique(key, axis=0, return_index=True, return_counts=True)
+    keep = first[counts == 1]
+    f, o = faces[keep], opp[keep]
+    p = np.asarray(pos, dtype=np.float64)
+    nrm = np.cross(p[f[:, 1]] - p[f[:, 0]], p[f[:, 2]] - p[f[:, 0]])
+    flip = np.einsum("ij,ij->i", nrm, p[o] - p[f[:, 0]]) > 0
+    f[flip] = f[flip][:, [0, 2, 1]]
+    return f.astype(np.uint32)
+
+
+def build_unstructured_pd(solver, mesh, w=1.0, pin_w=2.0, radius=0.5, triangles=True):
+    """BASELINE configs[2] on an unstructured mesh: a strain and a volume constraint per tetrahedron (added pairwise, like
+    createTetBox / addTriMeshVolume do), the surface faces as collision triangles, the z ~ 0 end cap pinned."""
+    pos, tets, _ = mesh
+    solver.add_nodes_raw(pos, radius=radius)
+    solver.add_tet(tets, w)
+    solver.add_volume(tets, w)
+    if triangles:
+        solver.add_triangles(boundary_triangles(pos, tets))
+    solver.add_position(np.nonzero(np.asarray(pos)[:, 2] < 0.5)[0].astype(np.uint32), pin_w)
+
+
 def loose_particles(dims, spacing=0.9, jitter=0.05, seed=1234, y0=0.5):
     W, H, D = dims
     rng = np.random.default_rng(seed)

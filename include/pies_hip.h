@@ -74,7 +74,10 @@ enum {
   PIES_SYSTEM_NNZ = 10, /* pies_count only: stored entries of the PD system matrix (after pies_finalize) */
   PIES_REST_SETS = 11,  /* pies_count only: distinct sets of element constants in the PD local step's rest dictionary (0: the
                          * per-element arrays are read; after pies_finalize) */
-  PIES_ROW_STENCILS = 12 /* pies_count only: distinct rows in the row dictionary of the PD system matrix (0: SELL arrays only) */
+  PIES_ROW_STENCILS = 12, /* pies_count only: distinct rows in the row dictionary of the PD system matrix (0: SELL arrays only) */
+  PIES_PD_TILES = 13,     /* pies_count only: tiles of the PD strain + volume local step (0: one record per (element, node)) */
+  PIES_PD_TILE_RECORDS = 14, /* pies_count only: (tile, node) sums the right-hand side gathers */
+  PIES_PD_CG_SINGLE = 15  /* pies_count only: 1 when the captured global step runs one launch per CG iteration */
 };
 
 /* How the sequential Gauss-Seidel sweeps of tickPBD (Solver.cpp:58-75) are mapped to the device.

@@ -28,6 +28,9 @@ KERNEL_COUNT = 19
 SYSTEM_NNZ = 10
 REST_SETS = 11
 ROW_STENCILS = 12
+PD_TILES = 13
+PD_TILE_RECORDS = 14
+PD_CG_SINGLE = 15
 
 # every symbol include/pies_hip.h declares (checked by tests/test_capi_symbols.py against the header)
 SYMBOLS = [

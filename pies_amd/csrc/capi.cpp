@@ -494,13 +494,16 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
     if (!fuseRhs) {
       if (ON(PIES_KERNEL_PD_RHS)) { launch_pd_rhs(st, s->nd, pd); U(s->nd.n); }
       C(PIES_KERNEL_PD_RHS);
+    } else if (counts) {
+      counts[PIES_KERNEL_PD_RHS] += 1;  // (the residual kernel that evaluates the right-hand side is counted - and bracketed - as this class)
     }
     const int overflow = s->pcgOverflow ? (int)(s->pcgMaxIters > s->pcgBudget ? s->pcgMaxIters - s->pcgBudget : 0u) : 0;
     const bool lastSolve = it + 1 == s->opt.iterations && !statsInStabilize;
     if (only < 0) {  // Solver.cpp:356-364
       const bool probed = s->probe && (s->probe->kernel == PIES_KERNEL_PD_SPMV || s->probe->kernel == PIES_KERNEL_PD_CG_UPDATE);
       // a probed solve never takes the converged early exit: every bracketed launch does a full SpMV / vector update
-      auto hook = probed ? [](void* ctx, int cls) { probe_mark(static_cast<pies_solver*>(ctx), cls); } : (void (*)(void*, int))nullptr;
+      auto hook = s->probe ? [](void* ctx, int cls) { probe_mark(static_cast<pies_solver*>(ctx), cls); } : (void (*)(void*, int))nullptr;
+      if (fuseRhs && units && s->probe && s->probe->kernel == PIES_KERNEL_PD_RHS) *units += s->nd.n;
       if (single) launch_pd_solve1(st, s->nd, pd, (int)s->pcgBudget, s->pcgTol, it == 0, lastSolve, fuseRhs, probed, hook, s, overflow);
       else launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, s->pcgTol, -1, it == 0, lastSolve, probed, hook, s, overflow);
       if (probed && units) *units += (uint64_t)s->nd.n * s->pcgBudget;
@@ -539,11 +542,12 @@ static void enqueue_substep(pies_solver* s, uint32_t* counts) {
   else enqueue_pbd_substep(s, -1, counts);
 }
 
-// The budget ladder: captured CG iterations per solve of the graphs instantiated together - 2, 3, 4, 6, 8, 12, 16, ... up to
+// The budget ladder: captured CG iterations per solve of the graphs instantiated together - 1, 2, 3, 4, 6, 8, 12, 16, ... up to
 // the ceiling of pies_set_pcg (the one-launch-per-iteration form pays one launch per unused iteration, so the low rungs are
 // close together); ladder_rung = the rung that holds `budget` iterations
 static std::vector<uint32_t> ladder_rungs(const pies_solver* s) {
   std::vector<uint32_t> r;
+  if (s->pcgMaxIters > 1) r.push_back(1);  // (a body at rest: the solves end at their first look at the residual)
   for (uint32_t b = 2; b < s->pcgMaxIters; b *= 2) {
     r.push_back(b);
     if (b + b / 2 < s->pcgMaxIters) r.push_back(b + b / 2);
@@ -1677,6 +1681,9 @@ int pies_count(const pies_solver_t* s, int what, uint32_t* out) {
     case PIES_SYSTEM_NNZ: *out = s->pd_nnz; break;
     case PIES_REST_SETS: *out = s->pdLocalPacked && s->d_pairDictIndex ? s->pairDictSets : 0u; break;
     case PIES_ROW_STENCILS: *out = s->pd.cg.rowStencil ? s->pdRowStencils : 0u; break;
+    case PIES_PD_TILES: *out = s->pd.tiles.ntiles; break;
+    case PIES_PD_TILE_RECORDS: *out = s->pd.tiles.ntiles ? s->pdTileRecords : 0u; break;
+    case PIES_PD_CG_SINGLE: *out = s->opt.solver == PIES_SOLVER_PD && pd_single_cg(s) ? 1u : 0u; break;
     default: return PIES_ERR_INVALID;
   }
   return PIES_OK;

@@ -320,8 +320,13 @@ void launch_pd_solve1(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, 
   // every solve of a substep captures the same number of launches, so the previous solve's last one left its partials here
   const float* prev = first ? nullptr : A.part1[iters & 1];
   const RhsArrays R = rhs_arrays(nd, pd);
-  if (fuseRhs) hipLaunchKernelGGL(k_cg1_init<true>, dim3(A.nparts + 1u), block, 0, st, A, nd.pos, pd.rhs, R, prev);
-  else hipLaunchKernelGGL(k_cg1_init<false>, dim3(A.nparts + 1u), block, 0, st, A, nd.pos, pd.rhs, R, prev);
+  if (fuseRhs) {
+    if (hook) hook(hookCtx, 13);  // PIES_KERNEL_PD_RHS: the residual kernel that evaluates the right-hand side
+    hipLaunchKernelGGL(k_cg1_init<true>, dim3(A.nparts + 1u), block, 0, st, A, nd.pos, pd.rhs, R, prev);
+    if (hook) hook(hookCtx, 13);
+  } else {
+    hipLaunchKernelGGL(k_cg1_init<false>, dim3(A.nparts + 1u), block, 0, st, A, nd.pos, pd.rhs, R, prev);
+  }
   hipLaunchKernelGGL(k_cg1_first, grid, block, 0, st, A, tol2);
   for (int it = 1; it <= iters; ++it) {
     if (hook) hook(hookCtx, 14);  // PIES_KERNEL_PD_SPMV

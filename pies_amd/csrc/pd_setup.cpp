@@ -113,6 +113,7 @@ int pd_build(pies_solver* s) {
   PdTilePlan tiles;
   const bool tiled = pd_plan_tiles(s, tiles);
   s->pdTiles = tiled ? static_cast<uint32_t>(tiles.info.size()) : 0u;
+  s->pdTileRecords = tiled ? static_cast<uint32_t>(tiles.tileNodes) : 0u;
   uint32_t total = 0;
   for (int t = 0; t < 5; ++t) {
     s->slotBase[t] = total;

@@ -182,6 +182,7 @@ struct pies_solver {
   float4* d_pairDictTable = nullptr;
   uint32_t pairDictSets = 0;
   std::vector<uint16_t> h_pairDictIndex;  // host copy (the tile plan stores it in tile order)
+  uint32_t pdTileRecords = 0;            // sum of the tiles' node counts
   uint32_t pdTiles = 0;                  // PD: tiles of the strain + volume local step (0: per-(element, node) records)
   uint32_t pdRowStencils = 0;           // PD: distinct rows of the system matrix in its row dictionary (0: none)
   bool tetVolumePaired = false;    // PD: h_volume[k] and h_tet[k] are the same element for every k (fused local step)

@@ -63,7 +63,7 @@ def test_two_rank_bench_end_to_end_on_one_gpu():
     env = dict(os.environ, PIES_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
-           "--dims", "10", "10", "60", "--quick"]
+           "--dims", "10", "10", "60", "--config5-dims", "10", "10", "60", "--quick"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -75,3 +75,5 @@ def test_two_rank_bench_end_to_end_on_one_gpu():
     # value = the substeps of BOTH ranks over the slower rank's time
     assert r["value"] * r["ms_per_step"] * r["steps"] / 1e3 == pytest.approx(2 * 5, rel=1e-4)  # (the line carries 6 significant digits)
     assert r["roofline"]["frac"] > 0 and r["cpu_baseline"]["value"] > 0
+    # the second timed region: BASELINE configs[4]'s pattern (PD + contacts), one body per rank, the same max / sum reduce
+    assert r["config5_value"] > 0

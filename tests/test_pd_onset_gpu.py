@@ -126,7 +126,7 @@ def test_queued_asynchronous_ticks_let_the_budget_follow(pies):
 
 _TWO_PROCESS_BODY = """
 import sys, os
-sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "benchlib"))
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "benchlib")); sys.path.insert(0, os.path.join({root!r}, "tests"))
 import numpy as np
 from pies_amd import capi
 from test_pd_parity_gpu import pd_options

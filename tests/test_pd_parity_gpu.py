@@ -321,3 +321,57 @@ def test_pd_fixed_and_linked_regions(pies, oracle):
     cap = g.group_ids(pies.GOAL, 0)
     # w = 50 against m/h^2 ~ 7e3: the goal nodes are pulled towards the moved region, a little per tick
     assert 0.005 < g.positions[cap, 0].mean() - 1.5 < 0.3
+
+
+def test_pd_unstructured_delaunay_beam(pies, oracle):
+    """BASELINE configs 2-3 call for a tetgen beam (Src/PrimitiveUtilities.cpp:243-328 is the ingestion path): PD on an
+    UNSTRUCTURED mesh - a Delaunay beam, one strain + one volume constraint per tetrahedron, the surface faces as collision
+    triangles, the end cap pinned - takes the paths a lattice does not: per-element rest constants (no rest dictionary), the SELL
+    matrix (no row dictionary), tiles cut by a Morton curve through irregular elements.  Five ticks against the oracle."""
+    mesh = scenes.delaunay_beam((7, 6, 40))
+    g = pies.Solver(pd_options(pies, 10))
+    o = oracle.OracleSolver(pd_options(oracle, 10))
+    for s in (g, o):
+        scenes.build_unstructured_pd(s, mesh)
+        scenes.perturb(s, 21, 0.02)
+        s.set_prev_positions(s.positions)
+    g.finalize()
+    assert g.count(pies.REST_SETS) == 0 and g.count(pies.ROW_STENCILS) == 0 and g.count(pies.PD_TILES) > 0
+    TOL = tol_for(o.positions)
+    for t in range(5):
+        g.tick(); o.tick()
+        for name in ("positions", "velocities", "prev_positions"):
+            within("pd_unstructured_7x6x40", g, o, TOL * (1.0 if name != "velocities" else 1.0 / 0.012), name)
+    res, iters_used, solves = g.pcg_stats()
+    assert res <= 1e-6 and solves == 10 and g.pcg_health()["short_solves"] == 0 and not g.failed
+
+
+def test_pd_unstructured_full_size_properties(pies, tune):
+    """The same kind of mesh at BASELINE's size (100k particles, ~590k element pairs), where the oracle's direct solve is out of
+    reach of a test: size-independent properties instead.  (i) The tile-resident local step + the right-hand side inside the
+    residual kernel against the per-(element, node) records + k_pd_rhs + the two-launch CG of round 3: the same arithmetic per
+    element, other summation orders and another CG recurrence - agreement at rounding level; (ii) every solve below the
+    tolerance; (iii) two runs of the same build are bit-identical."""
+    mesh = scenes.delaunay_beam(scenes.L100K)
+
+    def run(ticks=3):
+        g = pies.Solver(pd_options(pies, 10))
+        scenes.build_unstructured_pd(g, mesh)
+        scenes.perturb(g, 21, 0.02)
+        g.set_prev_positions(g.positions)
+        g.tick(ticks)
+        res, iters_used, solves = g.pcg_stats()
+        out = (g.positions, g.velocities, res, g.pcg_health()["short_solves"], g.failed, g.count(pies.PD_TILES))
+        g.close()
+        return out
+    a = run()
+    b = run()
+    assert a[5] > 0 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])  # deterministic
+    assert a[2] <= 1e-6 and a[3] == 0 and not a[4] and np.isfinite(a[0]).all()
+    tune("PIES_PD_TILE_ELEMS", "0")
+    tune("PIES_PD_CG_SINGLE", "0")
+    c = run()
+    assert c[5] == 0 and c[2] <= 1e-6 and c[3] == 0
+    d = float(np.abs(a[0] - c[0]).max())
+    record("pd_unstructured_l100k_tiles_vs_records", "positions", d, tol_for(c[0]))
+    assert d <= tol_for(c[0]), d
