@@ -643,10 +643,13 @@ struct SparseSym {  // full symmetric matrix as per-row ordered maps (setup-time
   float& ref(uint32_t i, uint32_t j) { return rows[i][j]; }
 };
 
-struct BandedLLT {
+// R = float: the reference's arithmetic (SimplicialLLT<SparseMatrix<float>>).  R = double: the YARDSTICK of the PD tolerance
+// (FLAG_PD_SOLVE_FP64): the same fp32 matrix and right-hand side, factorised and substituted in double, the solution rounded
+// to float once - what the linear solve would return without the fp32 round-off of a system whose entries are ~ m/h^2.
+template <class R> struct BandedLLTOf {
   uint32_t n = 0, bw = 0;
   std::vector<uint32_t> perm, iperm;  // perm[new] = old
-  std::vector<float> L;               // column-major band: L(i, j) at L[j*(bw+1) + (i - j)] for j <= i <= j+bw
+  std::vector<R> L;                   // column-major band: L(i, j) at L[j*(bw+1) + (i - j)] for j <= i <= j+bw
 
   static uint32_t bandwidth_of(const SparseSym& A, const std::vector<uint32_t>& ip) {
     uint32_t b = 0;
@@ -699,12 +702,12 @@ struct BandedLLT {
 
   // sum of a[k] * b[k] over [0, m): sixteen interleaved partial sums combined in a fixed order, so that the compiler may use
   // vector registers without being allowed to reassociate
-  static float dot(const float* __restrict a, const float* __restrict b, ptrdiff_t m) {
-    float acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  static R dot(const R* __restrict a, const R* __restrict b, ptrdiff_t m) {
+    R acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     ptrdiff_t k = 0;
     for (; k + 16 <= m; k += 16)
       for (int u = 0; u < 16; ++u) acc[u] += a[k + u] * b[k + u];
-    float tail = 0.0f;
+    R tail = 0;
     for (; k < m; ++k) tail += a[k] * b[k];
     for (int w = 8; w >= 1; w >>= 1)
       for (int u = 0; u < w; ++u) acc[u] += acc[u + w];
@@ -726,24 +729,24 @@ struct BandedLLT {
   bool factor(const SparseSym& A) {
     FlushSubnormals ftz;
     const size_t W = static_cast<size_t>(bw) + 1;
-    L.assign(static_cast<size_t>(n) * W, 0.0f);
+    L.assign(static_cast<size_t>(n) * W, R(0));
     for (uint32_t io = 0; io < n; ++io)
       for (auto& kv : A.rows[io]) {
         uint32_t i = iperm[io], j = iperm[kv.first];
         if (j <= i) L[j * W + (i - j)] = kv.second;
       }
     for (uint32_t k = 0; k < n; ++k) {
-      float* __restrict ck = L.data() + k * W;
-      if (!(ck[0] > 0.0f)) return false;
-      const float d = std::sqrt(ck[0]);
+      R* __restrict ck = L.data() + k * W;
+      if (!(ck[0] > R(0))) return false;
+      const R d = std::sqrt(ck[0]);
       ck[0] = d;
       const uint32_t m = std::min<uint32_t>(bw, n - 1 - k);  // rows k+1 .. k+m below the diagonal
       for (uint32_t r = 1; r <= m; ++r) ck[r] = ck[r] / d;
       for (uint32_t r = 1; r <= m; ++r) {  // column j = k + r, rows j .. k + m
-        const float f = ck[r];
-        if (f == 0.0f) continue;
-        float* __restrict cj = L.data() + (static_cast<size_t>(k) + r) * W;
-        const float* __restrict src = ck + r;
+        const R f = ck[r];
+        if (f == R(0)) continue;
+        R* __restrict cj = L.data() + (static_cast<size_t>(k) + r) * W;
+        const R* __restrict src = ck + r;
         const uint32_t len = m - r + 1;
         for (uint32_t t = 0; t < len; ++t) cj[t] -= f * src[t];
       }
@@ -752,27 +755,28 @@ struct BandedLLT {
   }
 
   // x (old ordering, stride 1 column) <- A^-1 b
-  void solve(const float* b, float* x) const {
+  template <class B> void solve(const B* b, float* x) const {
     FlushSubnormals ftz;
     const size_t W = static_cast<size_t>(bw) + 1;
-    std::vector<float> y(n);
+    std::vector<R> y(n);
     for (uint32_t i = 0; i < n; ++i) y[i] = b[perm[i]];
     for (uint32_t k = 0; k < n; ++k) {  // L y = b, column by column
-      const float* __restrict ck = L.data() + k * W;
-      const float v = y[k] / ck[0];
+      const R* __restrict ck = L.data() + k * W;
+      const R v = y[k] / ck[0];
       y[k] = v;
       const uint32_t m = std::min<uint32_t>(bw, n - 1 - k);
-      float* __restrict yy = y.data() + k + 1;
+      R* __restrict yy = y.data() + k + 1;
       for (uint32_t r = 0; r < m; ++r) yy[r] -= ck[r + 1] * v;
     }
     for (uint32_t k = n; k-- > 0;) {  // L^T x = y: row k of L^T is column k of L
-      const float* ck = L.data() + k * W;
+      const R* ck = L.data() + k * W;
       const uint32_t m = std::min<uint32_t>(bw, n - 1 - k);
       y[k] = (y[k] - dot(ck + 1, y.data() + k + 1, m)) / ck[0];
     }
-    for (uint32_t i = 0; i < n; ++i) x[perm[i]] = y[i];
+    for (uint32_t i = 0; i < n; ++i) x[perm[i]] = static_cast<float>(y[i]);
   }
 };
+using BandedLLT = BandedLLTOf<float>;
 
 }  // namespace
 
@@ -834,6 +838,9 @@ struct ora_solver {
   uint32_t previousNodeCount = 0;
   SparseSym stiffness;
   BandedLLT llt;
+  BandedLLTOf<double> llt64;  // FLAG_PD_SOLVE_FP64: the yardstick solve
+  std::vector<double> force64;
+  bool solveFp64 = false;
   bool orderedWithContacts = false;
   std::vector<float> state, force, msn;  // N x 3, column-major like Eigen::MatrixXf
   uint64_t stat_collision_pairs = 0;
@@ -1013,7 +1020,7 @@ template <class C, int N> static void addStiffness(const C& c, SparseSym& K) {
     for (int j = 0; j < N; ++j) K.ref(c.nodeIds[i], c.nodeIds[j]) += c.w * c.AtA[i][j];
 }
 // Constraints.h:89-105
-template <class C, int N> static void addForce(const C& c, float* f, size_t n) {
+template <class C, int N, class F> static void addForce(const C& c, F* f, size_t n) {
   for (int i = 0; i < N; ++i) {
     float ax = 0.f, ay = 0.f, az = 0.f;
     for (int k = 0; k < N; ++k) {
@@ -1202,6 +1209,10 @@ void ora_solver::tickPD() {
     orderedWithContacts = !triCollisions.empty();
     const bool timing = std::getenv("PIES_ORACLE_TIMING") != nullptr;
     const auto tFactor0 = std::chrono::steady_clock::now();
+    if (solveFp64) {  // same ordering, the factor in double
+      llt64.n = llt.n; llt64.bw = llt.bw; llt64.perm = llt.perm; llt64.iperm = llt.iperm;
+      if (!llt64.factor(sys)) { simFailed = true; return; }
+    } else
     if (!llt.factor(sys)) { simFailed = true; return; }
     if (timing)
       std::fprintf(stderr, "[oracle] n %u bandwidth %u: factorisation %.2f s\n", nodeCount, llt.bw,
@@ -1228,8 +1239,10 @@ void ora_solver::tickPD() {
         c.projectedPosition = node.position;
         if (node.position.y < 0.0f) c.projectedPosition.y = 0.0f;
       }
-      // RHS :310-349
-      float* f = force.data();
+      // RHS :310-349.  `f` is the reference's float force vector - or, for the fp64 yardstick (FLAG_PD_SOLVE_FP64), a double
+      // copy of it: the contributions w * (AtB p) are the same fp32 values, but they are ADDED without the round-off of a
+      // float accumulator that starts at M s_n / h^2 ~ 1e6 (an ulp of 0.1 per addition, ~50 additions per node)
+      auto accumulate = [&](auto* f) {
       for (auto& c : positionCons) addForce<PositionCon, 1>(c, f, n);
       for (auto& c : distanceCons) addForce<DistanceCon, 2>(c, f, n);
       for (auto& c : tetCons) addForce<TetCon, 4>(c, f, n);
@@ -1267,8 +1280,18 @@ void ora_solver::tickPD() {
         f[n + c.nodeId] += c.w * c.projectedPosition.y;
         f[2 * n + c.nodeId] += c.w * c.projectedPosition.z;
       }
+      };
+      if (solveFp64) {
+        force64.assign(force.begin(), force.end());
+        accumulate(force64.data());
+      } else {
+        accumulate(force.data());
+      }
       // global step :356-364
-      for (int col = 0; col < 3; ++col) llt.solve(&force[col * n], &state[col * n]);
+      for (int col = 0; col < 3; ++col) {
+        if (solveFp64) llt64.solve(&force64[col * n], &state[col * n]);
+        else llt.solve(&force[col * n], &state[col * n]);
+      }
       for (uint32_t i = 0; i < nodeCount; ++i) nodes[i].position = vec3(state[i], state[n + i], state[2 * n + i]);
     }
 
@@ -1441,6 +1464,7 @@ void ora_set_flag(ora_solver* s, int flag, int value) {
   if (flag == 1) s->nodeCollisions = value != 0;
   if (flag == 2) { s->collisionRule = value; s->collisionOrder.clear(); }
   if (flag == 3) s->triangleCollisions = value != 0;
+  if (flag == 4) s->solveFp64 = value != 0;  // FLAG_PD_SOLVE_FP64
 }
 int ora_failed(ora_solver* s) { return s->simFailed ? 1 : 0; }
 

@@ -77,19 +77,28 @@ __global__ void __launch_bounds__(kBlock) k_cg1_init(CgArrays A, const float4* _
     const bool live = i < A.n;
     float4 fi = make_float4(0.f, 0.f, 0.f, 0.f);
     if (RHS) fi = rhs_of_node<1>(R, i, 0u, live);  // (issued first: its gathers are in flight beside the row's)
-    float sx = 0.f, sy = 0.f, sz = 0.f;
+    // (K + C) x in DOUBLE: the products are ~ (m / h^2) |x| ~ 1e6 and cancel against f to a residual five orders smaller; summed
+    // in fp32 the row carries a noise of an ulp of 1e6 (0.1: 2e-5 in x per solve, a random walk over the local/global
+    // iterations - measured against the oracle's fp64 solve: 2.3 x the deviation of the reference's own fp32 arithmetic, in
+    // every variant of the local step and of the CG).  fp64 fused multiply-adds cost this memory-bound launch nothing.
+    double sx = 0.0, sy = 0.0, sz = 0.0;
     row_entries(A, sl, lane, i, [&](float a, uint32_t j) {
       const float4 xj = x[j];
-      sx = fmaf(a, xj.x, sx);
-      sy = fmaf(a, xj.y, sy);
-      sz = fmaf(a, xj.z, sz);
+      const double ad = static_cast<double>(a);
+      sx = fma(ad, static_cast<double>(xj.x), sx);
+      sy = fma(ad, static_cast<double>(xj.y), sy);
+      sz = fma(ad, static_cast<double>(xj.z), sz);
     });
     if (live) {
-      contact_row(A, i, [&](uint32_t j, float& px, float& py, float& pz) { const float4 v = x[j]; px = v.x; py = v.y; pz = v.z; }, sx, sy, sz);
+      float cx = 0.f, cy = 0.f, cz = 0.f;
+      contact_row(A, i, [&](uint32_t j, float& px, float& py, float& pz) { const float4 v = x[j]; px = v.x; py = v.y; pz = v.z; }, cx, cy, cz);
       if (!RHS) fi = f[i];
       const float4 xi = x[i];
       const float cd = A.cdiag[i], di = A.dinv[i];
-      const float rx = fi.x - fmaf(cd, xi.x, sx), ry = fi.y - fmaf(cd, xi.y, sy), rz = fi.z - fmaf(cd, xi.z, sz);
+      const double cdd = static_cast<double>(cd);
+      const float rx = static_cast<float>(static_cast<double>(fi.x) - (fma(cdd, static_cast<double>(xi.x), sx) + static_cast<double>(cx)));
+      const float ry = static_cast<float>(static_cast<double>(fi.y) - (fma(cdd, static_cast<double>(xi.y), sy) + static_cast<double>(cy)));
+      const float rz = static_cast<float>(static_cast<double>(fi.z) - (fma(cdd, static_cast<double>(xi.z), sz) + static_cast<double>(cz)));
       const float tx = di * rx, ty = di * ry, tz = di * rz;
       t0[i] = Vec3f{tx, ty, tz};
       acc9[0] += rx * tx; acc9[1] += ry * ty; acc9[2] += rz * tz;

@@ -41,7 +41,8 @@ __global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __
   float acc9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t sl = sw.begin; sl < sw.end; sl += sw.step) {
     const uint32_t i = sl * (64u / LPR) + lane / LPR;
-    float sx = 0.f, sy = 0.f, sz = 0.f;
+    // (K + C) x in double, like k_cg1_init: the row's products cancel against f to a residual five orders smaller
+    double dx = 0.0, dy = 0.0, dz = 0.0;
     if (LPR == 1 && A.rowStencil) {  // row dictionary: the row's (column - row, value) pairs, shared by every row like it
       if (i < A.n) {
         const uint32_t rs = A.rowStencil[i];
@@ -51,9 +52,9 @@ __global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __
           const int2 p = A.stencil[k];
           const float a = __int_as_float(p.y);
           const float4 xj = x[static_cast<uint32_t>(static_cast<int>(i) + p.x)];
-          sx = fmaf(a, xj.x, sx);
-          sy = fmaf(a, xj.y, sy);
-          sz = fmaf(a, xj.z, sz);
+          dx = fma(static_cast<double>(a), static_cast<double>(xj.x), dx);
+          dy = fma(static_cast<double>(a), static_cast<double>(xj.y), dy);
+          dz = fma(static_cast<double>(a), static_cast<double>(xj.z), dz);
         }
       }
     } else {
@@ -63,12 +64,17 @@ __global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __
         const uint32_t at = off + (k << 6) + lane;
         const float a = A.val[at];
         const float4 xj = x[A.col[at]];
-        sx = fmaf(a, xj.x, sx);
-        sy = fmaf(a, xj.y, sy);
-        sz = fmaf(a, xj.z, sz);
+        dx = fma(static_cast<double>(a), static_cast<double>(xj.x), dx);
+        dy = fma(static_cast<double>(a), static_cast<double>(xj.y), dy);
+        dz = fma(static_cast<double>(a), static_cast<double>(xj.z), dz);
       }
     }
-    row_combine<LPR>(sx, sy, sz);
+    float sx = 0.f, sy = 0.f, sz = 0.f;  // the contact part of the row, and (several lanes per row: the SELL experiments) the lanes' shares
+    if (LPR > 1) {
+      sx = static_cast<float>(dx); sy = static_cast<float>(dy); sz = static_cast<float>(dz);
+      dx = dy = dz = 0.0;
+      row_combine<LPR>(sx, sy, sz);
+    }
     if (i < A.n && lane % LPR == 0u) {
       if (A.useCAp) {
         if (*A.tUsedCount != 0u && A.tIncCnt[i]) {
@@ -79,7 +85,10 @@ __global__ void __launch_bounds__(kBlock) k_cg_init(CgArrays A, const float4* __
       }
       const float4 xi = x[i], fi = f[i];
       const float cd = A.cdiag[i], di = A.dinv[i];
-      const float rx = fi.x - fmaf(cd, xi.x, sx), ry = fi.y - fmaf(cd, xi.y, sy), rz = fi.z - fmaf(cd, xi.z, sz);
+      const double cdd = static_cast<double>(cd);
+      const float rx = static_cast<float>(static_cast<double>(fi.x) - (fma(cdd, static_cast<double>(xi.x), dx) + static_cast<double>(sx)));
+      const float ry = static_cast<float>(static_cast<double>(fi.y) - (fma(cdd, static_cast<double>(xi.y), dy) + static_cast<double>(sy)));
+      const float rz = static_cast<float>(static_cast<double>(fi.z) - (fma(cdd, static_cast<double>(xi.z), dz) + static_cast<double>(sz)));
       const float zx = di * rx, zy = di * ry, zz = di * rz;
       A.r[i] = make_float4(rx, ry, rz, 0.f);
       A.z[i] = make_float4(zx, zy, zz, 0.f);

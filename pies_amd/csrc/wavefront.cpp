@@ -9,6 +9,8 @@
 // 2 879 launches instead of 49 322 for 20 iterations of the 100k-particle beam, the same result.
 // The collision pass reads and writes arbitrary nodes, so it cuts the DAG into segments.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "solver_state.h"
@@ -119,6 +121,16 @@ bool build_wave_plan(const pies_solver* s, WavePlan& out) {
       const uint32_t lv = level[at++] - 1;
       out.index[out.levels[lv].off[4] + fill[static_cast<size_t>(lv) * kWaveKinds + 4]++] = i;
     }
+  }
+  if (const char* e = std::getenv("PIES_LAYER_DEBUG"); e && e[0] == '1') {  // how large the levels are (development aid)
+    uint32_t small[5] = {0, 0, 0, 0, 0};  // levels with at most 64, 256, 1024, 4096 operations; larger
+    for (const WaveLevel& L : out.levels) {
+      uint64_t ops = 0;
+      for (int kind = 0; kind < kWaveKinds; ++kind) ops += L.cnt[kind];
+      ++small[ops <= 64 ? 0 : ops <= 256 ? 1 : ops <= 1024 ? 2 : ops <= 4096 ? 3 : 4];
+    }
+    std::fprintf(stderr, "[pies] schedule EXACT: %zu levels; operations per level <= 64: %u, <= 256: %u, <= 1024: %u, <= 4096: %u, more: %u\n",
+                 out.levels.size(), small[0], small[1], small[2], small[3], small[4]);
   }
   out.active = true;
   return true;

@@ -49,6 +49,22 @@ def within(test, g, o, gate, what="positions"):
     record(test, what, d, gate)
     assert np.isfinite(getattr(g, what)).all() and d <= gate, (test, what, d, gate)
     return d
+
+
+def yardstick(test, g, o32, o64, spacing=1.0):
+    """The PD tolerance against a yardstick instead of a fitted gate (round 4): o64 is the oracle with its global solve in
+    double (the same fp32 matrix and right-hand side, FLAG_PD_SOLVE_FP64) - what the reference's direct solve would return
+    without fp32 round-off.  Recorded: |device - fp64| and |oracle32 - fp64| (positions).  The device passes when it is no
+    further from the fp64 solve than twice what the reference's own fp32 arithmetic is, or within SURVEY 8c's 1e-4 x spacing."""
+    d_dev = float(np.abs(g.positions - o64.positions).max())
+    d_ref = float(np.abs(o32.positions - o64.positions).max())
+    gate = max(2.0 * d_ref, 1e-4 * spacing)
+    record(test, "device_vs_fp64", d_dev, gate)
+    record(test, "oracle32_vs_fp64", d_ref, gate)
+    assert d_dev <= gate, (test, "device vs fp64 %.3g, oracle32 vs fp64 %.3g, gate %.3g" % (d_dev, d_ref, gate))
+    return d_dev, d_ref
+
+
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -84,15 +100,18 @@ def test_pd_tiny_scene_against_fp64_golden(pies):
 def test_pd_beam_against_oracle(pies, oracle, dims, iters):
     g = pies.Solver(pd_options(pies, iters))
     o = oracle.OracleSolver(pd_options(oracle, iters))
-    for s in (g, o):
+    o64 = oracle.OracleSolver(pd_options(oracle, iters))
+    o64.set_flag(oracle.FLAG_PD_SOLVE_FP64, 1)
+    for s in (g, o, o64):
         build_pd_beam(s, dims)
         scenes.perturb(s, 9, 0.03)
         s.set_prev_positions(s.positions)
     TOL = tol_for(o.positions)
     for t in range(5):
-        g.tick(); o.tick()
+        g.tick(); o.tick(); o64.tick()
         for name in ("positions", "velocities", "prev_positions"):
             within("pd_beam_%dx%dx%d" % dims, g, o, TOL * (1.0 if name != "velocities" else 1.0 / 0.012), name)
+        yardstick("pd_beam_%dx%dx%d" % dims, g, o, o64)
     res, iters_used, solves = g.pcg_stats()
     assert res <= 1e-6 and iters_used < 12 and solves == iters
     assert o.count(oracle.STATICS) > 0  # floor contacts active (duplicated per triangle incidence)
@@ -226,16 +245,19 @@ def test_config3_l100k_against_oracle(pies, oracle):
     bandwidth 421 after sorting along the beam), same tolerance as the small cases."""
     g = pies.Solver(pd_options(pies, 10))
     o = oracle.OracleSolver(pd_options(oracle, 10))
-    for s in (g, o):
+    o64 = oracle.OracleSolver(pd_options(oracle, 10))  # the yardstick: the same loop with the global solve in double
+    o64.set_flag(oracle.FLAG_PD_SOLVE_FP64, 1)
+    for s in (g, o, o64):
         build_pd_beam(s, scenes.L100K, translation=(0.0, 2.0, 0.0))
         scenes.perturb(s, 21, 0.03)
         s.set_prev_positions(s.positions)
     assert g.count(pies.TET) == g.count(pies.VOLUME) == 539334
     tol = GATE["config3_l100k"]
     for t in range(2):
-        g.tick(); o.tick()
+        g.tick(); o.tick(); o64.tick()
         for name in ("positions", "prev_positions", "velocities"):
             within("config3_l100k", g, o, tol * (1.0 if name != "velocities" else 1.0 / 0.012), name)
+        yardstick("config3_l100k", g, o, o64)
     res, iters_used, solves = g.pcg_stats()
     assert solves == 10 and res <= 3e-7 * 1.0001
     assert g.pcg_health()["short_solves"] == 0 and not g.failed

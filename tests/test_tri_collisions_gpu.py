@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import scenes
-from test_pd_parity_gpu import GATE, pd_options, tol_for, within
+from test_pd_parity_gpu import GATE, pd_options, tol_for, within, yardstick
 
 pytestmark = pytest.mark.gpu
 
@@ -256,7 +256,18 @@ def test_config5_l250k_with_binding_contacts(pies, oracle):
     seen = 0
     for t in range(3):
         sync_state(g, o)
+        if t == 0:  # the yardstick (round 4), for the tick in which the contacts bind: the oracle's global solve in double
+            o64 = oracle.OracleSolver(pd_options(oracle, 10))
+            o64.create_tet_box(W, H, D, translation=(0.0, 0.04, 0.0), w=1.0, volume=True, triangles=True)
+            o64.create_tet_box(8, 6, 30, translation=(3.3, 0.04 + (H - 1) + 0.04, 40.4), w=1.0, volume=True, triangles=True)
+            o64.set_positions(o.positions); o64.set_prev_positions(o.prev_positions); o64.set_velocities(o.velocities)
+            o64.set_flag(oracle.FLAG_PD_SOLVE_FP64, 1)
+            o64.tick()
         g.tick(); o.tick()
+        if t == 0:
+            assert np.array_equal(o64.tri_collisions, o.tri_collisions)
+            yardstick("config5_l250k_contacts", g, o, o64)
+            del o64
         cg_, co = g.tri_collisions, o.tri_collisions
         assert np.array_equal(cg_, co), (t, len(cg_), len(co))
         seen = max(seen, len(co))
