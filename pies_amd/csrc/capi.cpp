@@ -413,7 +413,11 @@ static void enqueue_pbd_substep(pies_solver* s, int only, uint32_t* counts, uint
 
 // The global step's CG with one launch per iteration (pd_cg1_kernels.hip): the contact-light graph variant with one lane per
 // matrix row; the contact-heavy variant (contact rows summed by extra workgroups) keeps the two-launch form.
-static bool pd_single_cg(const pies_solver* s) { return s->pdSingleCg && !s->pd.cg.useCAp && s->pd.cg.lanesPerRow == 1u; }
+static bool pd_single_cg(const pies_solver* s) {
+  // (the contact-heavy variant: the rows' contact parts are the merged rows k_contact_csr builds every substep - a gather of a
+  // handful of distinct columns by the row's lane; PIES_PD_CG_SINGLE_ROWS=0 keeps the two-launch form with its extra workgroups there)
+  return s->pdSingleCg && (!s->pd.cg.useCAp || s->pdSingleCgRows) && s->pd.cg.lanesPerRow == 1u;
+}
 
 // One PD substep as a launch sequence (Solver.cpp:228-485).  `only` >= 0 (profile pass) launches one kernel
 // class of the tetrahedral pipeline; units tallies the work items of the launches made.
@@ -490,7 +494,8 @@ static void enqueue_pd_substep(pies_solver* s, int only = -1, uint32_t* counts =
     }
     // Solver.cpp:266, 310-349.  (When a node's records are a few tile sums, the residual kernel of the one-launch-per-iteration
     // CG evaluates the right-hand side itself.)
-    const bool single = pd_single_cg(s), fuseRhs = single && only < 0 && pd.rhsLanes == 1 && s->pdFuseRhs;
+    // (contact-heavy variant: a node's contact records are gathered by four lanes in k_pd_rhs, not by the residual kernel's one)
+    const bool single = pd_single_cg(s), fuseRhs = single && only < 0 && pd.rhsLanes == 1 && s->pdFuseRhs && !pd.cg.useCAp;
     if (!fuseRhs) {
       if (ON(PIES_KERNEL_PD_RHS)) { launch_pd_rhs(st, s->nd, pd); U(s->nd.n); }
       C(PIES_KERNEL_PD_RHS);
@@ -805,6 +810,7 @@ static void apply_schedule_environment(pies_solver* s) {
   if (const char* e = tuning_env("PIES_PD_LOCAL_PACKED")) s->pdLocalPacked = e[0] != '0';
   if (const char* e = tuning_env("PIES_PD_CG_SINGLE")) s->pdSingleCg = e[0] != '0';
   if (const char* e = tuning_env("PIES_PD_FUSE_RHS")) s->pdFuseRhs = e[0] != '0';
+  if (const char* e = tuning_env("PIES_PD_CG_SINGLE_ROWS")) s->pdSingleCgRows = e[0] != '0';
   if (const char* e = tuning_env("PIES_PCG_BUDGET")) {  // diagnostics: the captured CG iterations, never adapted
     const int v = std::atoi(e);
     if (v >= 1 && v <= 4096) { s->pcgPinned = true; s->pcgPinnedBudget = static_cast<uint32_t>(v); s->pcgBudget = std::min(s->pcgMaxIters, s->pcgPinnedBudget); }

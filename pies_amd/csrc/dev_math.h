@@ -104,6 +104,97 @@ PIES_DEV void svd3(const float a[3][3], Svd3& d) {
   }
 }
 
+// ---- the same decomposition with the rotations written on register PAIRS (round 4) ---------------------------------------
+// The compiler packs a rotation's application into v_pk_mul_f32 / v_pk_fma_f32 already, but it assembles the operands of
+// every packed instruction with v_mov_b32: 21 moves in the 80 VALU instructions of a rotation (profiles/r04_svd_isa_counts.txt)
+// - and a colour step of k_layer lasts as long as its wavefronts' instruction streams.  A packed fp32 instruction takes each
+// operand from EITHER half of a 64-bit register pair (op_sel), so no value ever has to be moved: the columns live in pairs,
+//     sweep start:  A[k] = (col 0, -)   B[k] = (col 1, col 2)             k = component, likewise for V
+//     (0,1): x = A.lo, y = B.lo -> N1 = (col 0', col 1');  (0,2): x = N1.lo, y = B.hi -> N2 = (col 0'', col 2');
+//     (1,2): x = N1.hi, y = N2.hi -> N3 = (col 1'', col 2'');  next sweep: A = N2, B = N3
+// and one rotation of (x, y) is   t = (-sn * y, cs * y);  (x', y') = (cs * x + t.lo, sn * x + t.hi)   - the very IEEE
+// operations of jacobi_pair (a product, a negation, a fused multiply-add), so the result is bit for bit that of svd3.
+// A lane whose pair needs no rotation while another lane's does goes through the same instructions with (cs, sn) = (1, 0):
+// x * 1 - 0 and 0 * x + y return x and y; when no lane needs it the pair is only re-packed (v_pk_mov_b32).
+typedef float pk2 __attribute__((ext_vector_type(2)));
+template <int HX, int HY> PIES_DEV pk2 pk_rotate(const pk2 sc, const pk2 xp, const pk2 yp) {  // sc = (cs, sn); x = xp[HX], y = yp[HY]
+  pk2 t, r;
+  if (HY == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[1,0]" : "=v"(t) : "v"(sc), "v"(yp));
+  else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[1,0]" : "=v"(t) : "v"(sc), "v"(yp));
+  if (HX == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(sc), "v"(xp), "v"(t));
+  else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(sc), "v"(xp), "v"(t));
+  return r;
+}
+template <int HX, int HY> PIES_DEV pk2 pk_pair(const pk2 xp, const pk2 yp) {  // (xp[HX], yp[HY])
+  pk2 r;
+  if (HX == 0 && HY == 0) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(r) : "v"(xp), "v"(yp));
+  else if (HX == 0 && HY == 1) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(xp), "v"(yp));
+  else if (HX == 1 && HY == 0) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(xp), "v"(yp));
+  else asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(r) : "v"(xp), "v"(yp));
+  return r;
+}
+// one rotation of the column pair (x, y) = (bx[k][HX], by[k][HY]) and of V's; out[k] = (x', y').  Returns jacobi_pair's flag.
+template <int HX, int HY>
+PIES_DEV bool jacobi_pair_pk(const pk2 bx[3], const pk2 by[3], const pk2 vx[3], const pk2 vy[3], pk2 bo[3], pk2 vo[3]) {
+  const float x[3] = {bx[0][HX], bx[1][HX], bx[2][HX]}, y[3] = {by[0][HY], by[1][HY], by[2][HY]};
+  const float alpha = dot3f(x, x);
+  const float beta = dot3f(y, y);
+  const float gamma = dot3f(x, y);
+  const bool need = gamma * gamma > fmaf(kSvdTol2, alpha * beta, kSvdTiny2);
+  if (__builtin_amdgcn_ballot_w64(need) != 0ull) {  // (uniform: some lane of the wavefront rotates)
+    const float delta = beta - alpha;
+    const float g2 = gamma + gamma;
+    const float hw = fmaf(delta, delta, g2 * g2);
+    const float h = hw * rsqrt_nr(hw);
+    const float c1 = h + fabsf(delta);
+    const float s1 = delta < 0.0f ? -g2 : g2;
+    const float inv = rsqrt_nr(fmaf(c1, c1, s1 * s1));
+    const pk2 sc = {need ? c1 * inv : 1.0f, need ? s1 * inv : 0.0f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      bo[k] = pk_rotate<HX, HY>(sc, bx[k], by[k]);
+      vo[k] = pk_rotate<HX, HY>(sc, vx[k], vy[k]);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      bo[k] = pk_pair<HX, HY>(bx[k], by[k]);
+      vo[k] = pk_pair<HX, HY>(vx[k], vy[k]);
+    }
+  }
+  return need;
+}
+PIES_DEV void svd3_pk(const float a[3][3], Svd3& d) {
+  pk2 A[3], B[3], VA[3], VB[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    A[k] = pk2{a[k][0], 0.0f};
+    B[k] = pk2{a[k][1], a[k][2]};
+    VA[k] = pk2{k == 0 ? 1.0f : 0.0f, 0.0f};
+    VB[k] = pk2{k == 1 ? 1.0f : 0.0f, k == 2 ? 1.0f : 0.0f};
+  }
+  for (int sweep = 0; sweep < kSvdMaxSweeps; ++sweep) {
+    pk2 N1[3], V1[3], N2[3], V2[3], N3[3], V3[3];
+    const bool r01 = jacobi_pair_pk<0, 0>(A, B, VA, VB, N1, V1);
+    const bool r02 = jacobi_pair_pk<0, 1>(N1, B, V1, VB, N2, V2);
+    const bool r12 = jacobi_pair_pk<1, 1>(N1, N2, V1, V2, N3, V3);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { A[k] = N2[k]; B[k] = N3[k]; VA[k] = V2[k]; VB[k] = V3[k]; }
+    if (!(r01 || r02 || r12)) break;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    d.b[0][k] = A[k][0]; d.b[1][k] = B[k][0]; d.b[2][k] = B[k][1];
+    d.v[0][k] = VA[k][0]; d.v[1][k] = VB[k][0]; d.v[2][k] = VB[k][1];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float n2 = dot3f(d.b[i], d.b[i]);
+    d.rs[i] = n2 > kSvdTiny2 ? rsqrt_nr(n2) : 0.0f;
+    d.s[i] = n2 * d.rs[i];
+  }
+}
+
 template <int K, int I, int J> PIES_DEV void complete_t(const Svd3& d, float t[3][3], float sg) {
   float ui[3], uj[3];
 #pragma unroll

@@ -61,9 +61,21 @@ PIES_DEV void box_cell(const GridBox& B, uint64_t key, int& x, int& y, int& z) {
   x = B.mn[0] + static_cast<int>(key >> (B.bits[1] + B.bits[2]));
 }
 // bucket of cell (x, y, z): index slot or ~0
+// A build whose packed key is shorter than the index (every scene but one that spans more cells than it has index slots:
+// 17 bits against 2^23 slots in BASELINE config 4) uses the key itself as the slot - no hashing, no probing, and no
+// compare-and-swap when the index is built (k_grid_cells).  The same test on both sides, from the build's own box.
+PIES_DEV bool direct_index(const HashArrays& H, const GridBox& B) {
+  const uint32_t total = B.bits[0] + B.bits[1] + B.bits[2];
+  return total <= 30u && (1u << total) <= H.mask + 1u;
+}
 PIES_DEV uint32_t find_bucket(const HashArrays& H, const GridBox& B, int x, int y, int z) {
   if (!in_box(B, x, y, z)) return 0xffffffffu;
-  return find_cell(H.keys, H.mask, box_key(B, x, y, z));
+  const uint64_t key = box_key(B, x, y, z);
+  if (direct_index(H, B)) {
+    const uint32_t h = static_cast<uint32_t>(key);
+    return H.keys[h] == key ? h : 0xffffffffu;
+  }
+  return find_cell(H.keys, H.mask, key);
 }
 
 // NodeCompRange (Solver.cpp:877-901).  Returns false for a non-finite position; an over-long range is empty, like the

@@ -52,14 +52,6 @@ __global__ void __launch_bounds__(kBlock) k_grid_reset(HashArrays H) {
     H.keys[s] = kEmpty;
   }
 }
-__global__ void k_grid_zero(HashArrays H) {
-  const uint32_t t = threadIdx.x;
-  if (t == kCounterUsed || t == kCounterEntries || t == 2) H.counters[t] = 0;
-  if (t >= kCounterPass0 && t < kCounterPass0 + 27) H.counters[t] = 0;  // groups per pass   (counters[3] = sticky failure flags)
-  if (t == kCounterTicket) H.counters[t] = 0;                            // k_collide_flow's work queue
-  if (t == kCounterEpoch) H.counters[t] += 1;  // completion stamps of earlier builds are stale by construction
-}
-
 // ---- range: NodeCompRange + cells per node + bounding box ---------------------------------------------------------
 PIES_DEV int wave_min(int v) {
 #pragma unroll
@@ -74,6 +66,13 @@ PIES_DEV int wave_max(int v) {
 __global__ void __launch_bounds__(kBlock) k_grid_range(HashArrays H, const float4* __restrict__ pos, const float* __restrict__ radius,
                                                        uint32_t n, float scale) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (blockIdx.x == 0) {  // the build's counters (k_grid_zero's work: nothing in this launch reads them; k_grid_reset, which needs the
+    const uint32_t t = threadIdx.x;  // previous build's cell count, runs before it)
+    if (t == kCounterUsed || t == kCounterEntries || t == 2) H.counters[t] = 0;
+    if (t >= kCounterPass0 && t < kCounterPass0 + 27) H.counters[t] = 0;
+    if (t == kCounterTicket) H.counters[t] = 0;
+    if (t == kCounterEpoch) H.counters[t] += 1;
+  }
   int mx = 0, my = 0, mz = 0;
   uint32_t lx = 0, ly = 0, lz = 0;
   if (i < n) {
@@ -107,10 +106,30 @@ __global__ void __launch_bounds__(kBlock) k_grid_range(HashArrays H, const float
     H.boxPart[blockIdx.x * 6 + a] = v;
   }
 }
-__global__ void __launch_bounds__(1024) k_grid_box(HashArrays H, uint32_t nparts, uint32_t sortPasses) {
-  __shared__ int red[16][6];
+// ---- exclusive prefix sum of uint32 (tile sums, scan of the sums, add) -----------------------------------------
+constexpr uint32_t kScanTile = 2048;  // 256 threads x 8
+PIES_DEV uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds, uint32_t& total) {  // 256 threads; lds: 8 words
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(incl, off, 64);
+    if (lane >= static_cast<uint32_t>(off)) incl += t;
+  }
+  if (lane == 63) lds[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (uint32_t w = 0; w < wave; ++w) base += lds[w];
+  total = lds[0] + lds[1] + lds[2] + lds[3];
+  __syncthreads();
+  return base + incl - v;
+}
+// the bounding box of the nodes' cell ranges from the workgroups' partial boxes, and the sort this build runs (k_grid_box's
+// work for a workgroup of kBlock threads: it rides behind the tiles of k_scan_tiles, one launch less per rebuild)
+PIES_DEV void grid_box_reduce(const HashArrays& H, uint32_t nparts, uint32_t sortPasses) {
+  __shared__ int red[kBlock / 64][6];
   int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
-  for (uint32_t b = threadIdx.x; b < nparts; b += 1024) {
+  for (uint32_t b = threadIdx.x; b < nparts; b += kBlock) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       lo[a] = min(lo[a], H.boxPart[b * 6 + a]);
@@ -130,10 +149,9 @@ __global__ void __launch_bounds__(1024) k_grid_box(HashArrays H, uint32_t nparts
   if (threadIdx.x < 6) {
     const int a = threadIdx.x;
     int v = red[0][a];
-    for (int w = 1; w < 16; ++w) v = a < 3 ? min(v, red[w][a]) : max(v, red[w][a]);
+    for (int w = 1; w < kBlock / 64; ++w) v = a < 3 ? min(v, red[w][a]) : max(v, red[w][a]);
     H.counters[(a < 3 ? kCounterBoxMin : kCounterBoxMax - 3) + a] = static_cast<uint32_t>(v);
   }
-  __syncthreads();
   if (threadIdx.x == 0) {  // the sort of this build: the captured passes, and whether they can hold the box's key
     H.counters[kCounterSortPasses] = sortPasses;
     uint32_t total = 0;
@@ -141,7 +159,7 @@ __global__ void __launch_bounds__(1024) k_grid_box(HashArrays H, uint32_t nparts
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       int lo_ = red[0][a], hi_ = red[0][3 + a];
-      for (int w = 1; w < 16; ++w) { lo_ = min(lo_, red[w][a]); hi_ = max(hi_, red[w][3 + a]); }
+      for (int w = 1; w < kBlock / 64; ++w) { lo_ = min(lo_, red[w][a]); hi_ = max(hi_, red[w][3 + a]); }
       if (hi_ < lo_) empty = true;
       const uint32_t ext = empty ? 0u : static_cast<uint32_t>(hi_ - lo_);
       total += ext ? 32u - static_cast<uint32_t>(__builtin_clz(ext)) : 0u;
@@ -149,27 +167,12 @@ __global__ void __launch_bounds__(1024) k_grid_box(HashArrays H, uint32_t nparts
     if (!empty && total > kRadixMaxDigit * sortPasses) atomicOr(&H.counters[kCounterFlags], 512u);
   }
 }
-
-// ---- exclusive prefix sum of uint32 (tile sums, scan of the sums, add) -----------------------------------------
-constexpr uint32_t kScanTile = 2048;  // 256 threads x 8
-PIES_DEV uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds, uint32_t& total) {  // 256 threads; lds: 8 words
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  uint32_t incl = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t t = __shfl_up(incl, off, 64);
-    if (lane >= static_cast<uint32_t>(off)) incl += t;
-  }
-  if (lane == 63) lds[wave] = incl;
-  __syncthreads();
-  uint32_t base = 0;
-  for (uint32_t w = 0; w < wave; ++w) base += lds[w];
-  total = lds[0] + lds[1] + lds[2] + lds[3];
-  __syncthreads();
-  return base + incl - v;
-}
 __global__ void __launch_bounds__(kBlock) k_scan_tiles(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n,
-                                                       uint32_t* __restrict__ sums) {
+                                                       uint32_t* __restrict__ sums, HashArrays H, uint32_t boxParts, uint32_t sortPasses) {
+  if (boxParts && blockIdx.x + 1u == gridDim.x) {  // (uniform per workgroup)
+    grid_box_reduce(H, boxParts, sortPasses);
+    return;
+  }
   __shared__ uint32_t lds[8];
   const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 8u;
   uint32_t v[8], s = 0;
@@ -208,14 +211,6 @@ __global__ void __launch_bounds__(1024) k_scan_sums(uint32_t* __restrict__ sums,
     run += v;
   }
 }
-__global__ void __launch_bounds__(kBlock) k_scan_add(uint32_t* __restrict__ out, uint32_t n, const uint32_t* __restrict__ sums) {
-  const uint32_t add = sums[blockIdx.x];
-  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 8u;
-#pragma unroll
-  for (int k = 0; k < 8; ++k)
-    if (base + k < n) out[base + k] += add;
-}
-
 // ---- emit: one (cell key, node) entry per overlapped cell, node-major --------------------------------------------
 // A wavefront's 64 nodes own one contiguous stretch of the entry list (entOff is node-major).  The lanes write it slot by slot -
 // lane l takes slots l, l + 64, ... of the stretch and finds the node a slot belongs to by a binary search over the lanes'
@@ -225,14 +220,14 @@ __global__ void __launch_bounds__(kBlock) k_grid_emit(HashArrays H, uint32_t n) 
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
   if (i == 0) {
-    const uint32_t total = H.entOff[n];
+    const uint32_t total = H.entOff[n] + H.scanSums[n / kScanTile];
     if (total > H.maxEntries) atomicOr(&H.counters[kCounterFlags], 128u);
     H.counters[kCounterEntries] = min(total, H.maxEntries);
   }
   const bool live = i < n;
   const int4 rg = live ? H.rng[i] : make_int4(0, 0, 0, 0);
   const uint32_t lx = rg.w & 0xff, ly = (rg.w >> 8) & 0xff, lz = (rg.w >> 16) & 0xff;
-  const uint32_t base = live ? H.entOff[i] : 0u;
+  const uint32_t base = live ? H.entOff[i] + H.scanSums[i / kScanTile] : 0u;  // (the tile sums are added here: k_scan_add's launch)
   uint32_t cnt = live ? lx * ly * lz : 0u;
   if (base + cnt > H.maxEntries) cnt = 0;  // flagged above: the host latches the failure
   const GridBox B = grid_box(H.counters);
@@ -289,10 +284,16 @@ __global__ void __launch_bounds__(kBlock) k_radix_hist(HashArrays H, uint32_t pa
   const uint64_t* __restrict__ src = H.key[pass & 1u];
   for (uint32_t d = threadIdx.x; d < bins; d += kBlock) h[d] = 0;
   __syncthreads();
-#pragma unroll 4
+  uint64_t kk[kRadixTile / kBlock];  // all sixteen loads in flight before the first LDS atomic
+#pragma unroll
   for (uint32_t k = 0; k < kRadixTile / kBlock; ++k) {
     const uint32_t t = blk * kRadixTile + k * kBlock + threadIdx.x;
-    if (t < E) atomicAdd(&h[static_cast<uint32_t>(src[t] >> shift) & (bins - 1u)], 1u);
+    kk[k] = t < E ? src[t] : ~0ull;
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < kRadixTile / kBlock; ++k) {
+    const uint32_t t = blk * kRadixTile + k * kBlock + threadIdx.x;
+    if (t < E) atomicAdd(&h[static_cast<uint32_t>(kk[k] >> shift) & (bins - 1u)], 1u);
   }
   __syncthreads();
   for (uint32_t d = threadIdx.x; d < bins; d += kBlock) H.hist[d * nblkMax + blk] = h[d];
@@ -401,6 +402,9 @@ __global__ void __launch_bounds__(kBlock) k_radix_scatter(HashArrays H, uint32_t
     }
   }
   __syncthreads();
+  // (Round 4 measured the tile put into sorted order in LDS first and written out from there, so that a store instruction
+  // covers the runs of a few digits instead of 64 entries in 64 cache lines: 41.8 us per pass against 36.5 - the pass is not
+  // bound by its store pattern, and the 32 KB of staging cost a resident workgroup per CU.)
 #pragma unroll
   for (int r = 0; r < kRounds; ++r) {
     const uint32_t t = first + static_cast<uint32_t>(r) * 64u + lane;
@@ -417,7 +421,8 @@ __global__ void __launch_bounds__(kBlock) k_radix_scatter(HashArrays H, uint32_t
 // ---- cells: bucket boundaries -> cell index; groups per pass ------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_grid_cells(HashArrays H) {
   // a workgroup takes kRadixTile consecutive entries; the cells it creates are collected in LDS and appended to the list
-  // of cells in use with ONE global atomic (47k appends on one word took 0.4 ms at 500k nodes)
+  // of cells in use with ONE global atomic (47k appends on one word took 0.4 ms at 500k nodes; round 4 tried one entry per
+  // thread - 16 000 workgroups, 16 000 appends: 184 us against 38).  A thread's sixteen entries are requested together.
   __shared__ uint32_t made[kRadixTile];  // at most one cell per entry of the tile (buckets of one node)
   __shared__ uint32_t nmade, base;
   const uint32_t E = H.counters[kCounterEntries];
@@ -428,16 +433,35 @@ __global__ void __launch_bounds__(kBlock) k_grid_cells(HashArrays H) {
   const GridBox B = grid_box(H.counters);
   const uint32_t fb = grid_passes(B) & 1u;  // the buffer the last pass wrote
   const uint64_t* __restrict__ key = H.key[fb];
-  for (uint32_t r = 0; r < kRadixTile / kBlock; ++r) {
+  const uint32_t ksh = B.packed ? 32u : 0u;  // (a packed entry: the key is the upper word)
+  const bool direct = direct_index(H, B);
+  constexpr uint32_t kRounds = kRadixTile / kBlock;
+  uint64_t kp[kRounds], kc[kRounds], kn[kRounds];
+#pragma unroll
+  for (uint32_t r = 0; r < kRounds; ++r) {
     const uint32_t t = first + r * kBlock + threadIdx.x;
-    if (t >= E) break;
-    const uint32_t ksh = B.packed ? 32u : 0u;  // (a packed entry: the key is the upper word)
-    const uint64_t k = key[t] >> ksh;
-    const bool head = t == 0 || (key[t - 1] >> ksh) != k;
-    const bool tail = t + 1 == E || (key[t + 1] >> ksh) != k;
+    const uint32_t tc = min(t, E - 1u);
+    kc[r] = key[tc] >> ksh;
+    kp[r] = key[tc ? tc - 1u : 0u] >> ksh;
+    kn[r] = key[min(tc + 1u, E - 1u)] >> ksh;
+  }
+#pragma unroll
+  for (uint32_t r = 0; r < kRounds; ++r) {
+    const uint32_t t = first + r * kBlock + threadIdx.x;
+    if (t >= E) continue;
+    const uint64_t k = kc[r];
+    const bool head = t == 0 || kp[r] != k;
+    const bool tail = t + 1 == E || kn[r] != k;
     if (!(head || tail)) continue;
     bool created;
-    const uint32_t slot = insert_cell(H.keys, H.mask, k, created);  // whichever of the bucket's two ends comes first creates it
+    uint32_t slot;
+    if (direct) {  // the key is the slot (hash_device.h: direct_index): the bucket's head entry creates the cell
+      slot = static_cast<uint32_t>(k);
+      created = head;
+      if (head) H.keys[slot] = k;
+    } else {
+      slot = insert_cell(H.keys, H.mask, k, created);  // whichever of the bucket's two ends comes first creates it
+    }
     if (slot == 0xffffffffu) { atomicOr(&H.counters[kCounterFlags], 2u); continue; }
     if (created) made[atomicAdd(&nmade, 1u)] = slot;
     if (head) H.start[slot] = t;
@@ -999,14 +1023,13 @@ uint32_t launch_hash_build(hipStream_t st_, const HashArrays& H, const NodeArray
   const uint32_t n = nd.n;
   uint32_t launches = 0;
   const dim3 wide(std::min<uint32_t>(2048u, (H.capacity / 8 + kBlock - 1) / kBlock));
+  // (round 4: three launches fewer - the counters are zeroed by the first workgroup of k_grid_range, the bounding box is reduced
+  // by an extra workgroup of k_scan_tiles, the tile sums are added by k_grid_emit itself)
   hipLaunchKernelGGL(k_grid_reset, wide, dim3(kBlock), 0, st_, H); ++launches;
-  hipLaunchKernelGGL(k_grid_zero, dim3(1), dim3(64), 0, st_, H); ++launches;
   hipLaunchKernelGGL(k_grid_range, grid_for(n + 1), dim3(kBlock), 0, st_, H, nd.pos, nd.radius, n, scale); ++launches;
-  hipLaunchKernelGGL(k_grid_box, dim3(1), dim3(1024), 0, st_, H, grid_for(n + 1).x, sortPasses); ++launches;
   const uint32_t m = n + 1, tiles = (m + kScanTile - 1) / kScanTile;
-  hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kBlock), 0, st_, H.entCount, H.entOff, m, H.scanSums); ++launches;
+  hipLaunchKernelGGL(k_scan_tiles, dim3(tiles + 1u), dim3(kBlock), 0, st_, H.entCount, H.entOff, m, H.scanSums, H, grid_for(n + 1).x, sortPasses); ++launches;
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st_, H.scanSums, tiles); ++launches;
-  hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kBlock), 0, st_, H.entOff, m, H.scanSums); ++launches;
   hipLaunchKernelGGL(k_grid_emit, grid_for(n), dim3(kBlock), 0, st_, H, n); ++launches;
   const uint32_t nblkMax = (H.maxEntries + kRadixTile - 1) / kRadixTile;
   for (uint32_t pass = 0; pass < sortPasses; ++pass) {  // the key's bits are dealt evenly to the passes (grid_box)

@@ -591,7 +591,7 @@ RhsArrays rhs_arrays(const NodeArrays& nd, const PdArrays& pd) {
 }
 void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd) {
   if (nd.n == 0) return;
-  if (pd.rhsLanes == 1) hipLaunchKernelGGL(k_pd_rhs<1>, grid_for(nd.n), dim3(kBlock), 0, st, rhs_arrays(nd, pd), pd.rhs);
+  if (pd.rhsLanes == 1 && !pd.cg.useCAp) hipLaunchKernelGGL(k_pd_rhs<1>, grid_for(nd.n), dim3(kBlock), 0, st, rhs_arrays(nd, pd), pd.rhs);  // (many contacts: four lanes share a node's contact records)
   else hipLaunchKernelGGL(k_pd_rhs<4>, dim3((nd.n + kBlock / 4 - 1) / (kBlock / 4)), dim3(kBlock), 0, st, rhs_arrays(nd, pd), pd.rhs);
 }
 void launch_pd_local_tet_pair(hipStream_t st, const float4* pos, const uint4* ids, const float4* q0, const float4* q1, const float4* q2,

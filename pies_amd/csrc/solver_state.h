@@ -168,6 +168,7 @@ struct pies_solver {
   bool triLevelsForked = true;
   bool pdLocalPacked = true;    // strain + volume local step two elements per lane in packed fp32 (PIES_PD_LOCAL_PACKED=0: one per lane)
   bool pdSingleCg = true;       // the global step's CG with one launch per iteration where it applies (PIES_PD_CG_SINGLE=0: the two-launch form everywhere)
+  bool pdSingleCgRows = true;   // ... also in the contact-heavy graph variant (merged contact rows gathered inline)
   bool pdFuseRhs = true;        // its residual kernel evaluates the right-hand side when a node's records are tile sums (PIES_PD_FUSE_RHS=0: k_pd_rhs)
   bool pcgOverflow = true;      // a solve above the tolerance after its captured iterations goes on inside the last launch (PIES_PCG_OVERFLOW=0: off)
   bool pcgPinned = false;       // PIES_PCG_BUDGET
