@@ -212,22 +212,47 @@ __global__ void __launch_bounds__(kBlock) k_tri_count(TriArrays T, const float4*
     bool created;
     const uint32_t s = insert_cell(T.keys, T.mask, pack_cell(m[0] + (int)dx, m[1] + (int)dy, m[2] + (int)dz), created);
     if (e < kTriMaxEntries) T.triSlot[t * kTriMaxEntries + e] = s;
-    if (s == 0xffffffffu) { atomicOr(&T.counters[3], 2u); continue; }
-    if (created) {  // (the list of used cells is as long as the entry storage: more distinct cells than that is the
-      const uint32_t u = atomicAdd(&T.counters[0], 1u);  // "more entries than reserved" failure, never a write past it)
-      if (u < T.maxEntries) T.used[u] = s;
-      else atomicOr(&T.counters[3], 2u);
+    if (s == 0xffffffffu) { atomicOr(&T.counters[3], 2u); continue; }  // (a lane that leaves here takes no part in the round's ballot)
+    // the list of used cells: ONE append per wavefront and round for all the cells its lanes created (an atomic per cell on
+    // the one counter word was a third of this launch: atomics on one word take their turns).  The list is as long as the
+    // entry storage: more distinct cells than that is the "more entries than reserved" failure, never a write past it.
+    const unsigned long long makers = __ballot(created);
+    if (makers) {
+      const int leader = __builtin_ctzll(makers);
+      uint32_t base = 0;
+      if (static_cast<int>(threadIdx.x & 63u) == leader) base = atomicAdd(&T.counters[0], static_cast<uint32_t>(__popcll(makers)));
+      base = __shfl(base, leader, 64);
+      if (created) {
+        const uint32_t u = base + static_cast<uint32_t>(__popcll(makers & ((1ull << (threadIdx.x & 63u)) - 1ull)));
+        if (u < T.maxEntries) T.used[u] = s;
+        else atomicOr(&T.counters[3], 2u);
+      }
     }
     atomicAdd(&T.cnt[s], 1u);
   }
 }
 __global__ void __launch_bounds__(kBlock) k_tri_alloc(TriArrays T) {
   const uint32_t used = min(T.counters[0], T.maxEntries);
-  for (uint32_t u = blockIdx.x * kBlock + threadIdx.x; u < used; u += gridDim.x * kBlock) {
-    const uint32_t s = T.used[u];
-    if (T.cnt[s] > 1000u) atomicOr(&T.counters[3], 16u);  // Solver.cpp:751-755: a bucket of more than 1000 triangles fails the sim
-    const uint32_t at = atomicAdd(&T.counters[1], T.cnt[s]);
-    if (at + T.cnt[s] > T.maxEntries) { atomicOr(&T.counters[3], 2u); T.cnt[s] = 0; }  // more (cell, triangle) entries than reserved
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t u0 = (blockIdx.x * kBlock + threadIdx.x) & ~63u; u0 < used; u0 += gridDim.x * kBlock) {  // (uniform per wavefront)
+    const uint32_t u = u0 + lane;
+    const bool live = u < used;
+    const uint32_t s = live ? T.used[u] : 0u;
+    const uint32_t c = live ? T.cnt[s] : 0u;
+    if (c > 1000u) atomicOr(&T.counters[3], 16u);  // Solver.cpp:751-755: a bucket of more than 1000 triangles fails the sim
+    // the wavefront's buckets take one stretch of the storage: one atomic per wavefront on the one counter word
+    uint32_t incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off, 64);
+      if (lane >= static_cast<uint32_t>(off)) incl += t;
+    }
+    uint32_t base = 0;
+    if (lane == 63u) base = atomicAdd(&T.counters[1], incl);
+    base = __shfl(base, 63, 64);
+    if (!live) continue;
+    const uint32_t at = base + incl - c;
+    if (at + c > T.maxEntries) { atomicOr(&T.counters[3], 2u); T.cnt[s] = 0; }  // more (cell, triangle) entries than reserved
     T.start[s] = at;
     T.fill[s] = 0;
   }
