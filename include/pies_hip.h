@@ -256,6 +256,8 @@ int pies_set_collision_rounds(pies_solver_t* s, uint32_t rounds);
  * PIES_NO_GRAPH, PIES_NO_WAVEFRONT, PIES_NO_TET_PAIRS, PIES_PD_LOCAL_PACKED (0: one element per lane in the PD strain + volume step),
  * PIES_PD_REST_DICT (0: per-element constants instead of the rest dictionary), PIES_PD_ROW_DICT (0: the PD system matrix as SELL
  * arrays only, no row dictionary), PIES_LAYER_ONE_STRIP_MAX / _TILE_NODES / _STRIPS_MIN_NODES / PIES_LAYER_BLOCK,
+ * PIES_PD_TILE_ELEMS (0: per-(element, node) records instead of the tile-resident local step), PIES_PD_CG_SINGLE / _SINGLE_ROWS (0: the
+ * two-launch CG everywhere / in the contact-heavy variant), PIES_PD_FUSE_RHS (0: k_pd_rhs), PIES_PD_RHS_LANES,
  * PIES_COLOUR_ROUNDS, PIES_COLOUR_DSATUR, PIES_NO_COLOUR_HINT, PIES_SELL_LANES, PIES_CG_BLOCKS, PIES_COLLIDE_GLOBAL / _PASSES /
  * _SPIN_LIMIT.  They take effect where the library reads them (pies_create, pies_finalize or the next graph capture).  pies_set_tuning must not
  * race with other API calls of the process (a handle reads the switches at different times of its life).  None of
