@@ -23,6 +23,7 @@
 // the saved state, the nodes that left their slack now listing every node they share a cell with; a repeat that fails the
 // same test is counted (pies_get_collision_health: passes_inexact).
 #include <climits>
+#include <cstdlib>
 #include <cstdint>
 
 #include "dev_math.h"
@@ -980,7 +981,12 @@ uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArr
   uint32_t launches = 0;
   const dim3 perNode((n + kBlock - 1) / kBlock);
   const dim3 groups(std::max<uint32_t>(1u, std::min<uint32_t>(8192u, n / 8 + 1)));
-  const dim3 level(std::max<uint32_t>(1u, std::min<uint32_t>(2048u, (n + kRoundBlock - 1u) / kRoundBlock)));
+  // workgroups of a level launch: a settled level of config 4 has ~280 chunks of frontier nodes, and 60 % of the captured level
+  // launches find nothing to do (the repeat's, and the spare ones of the first attempt) - an empty launch of 2 048 workgroups
+  // costs what its dispatch costs.  PIES_PAIR_LEVEL_BLOCKS sets the cap (chunks beyond it are taken in a grid-stride loop).
+  uint32_t levelCap = 2048u;
+  if (const char* e = tuning_env("PIES_PAIR_LEVEL_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && v <= 65535) levelCap = static_cast<uint32_t>(v); }
+  const dim3 level(std::max<uint32_t>(1u, std::min<uint32_t>(levelCap, (n + kRoundBlock - 1u) / kRoundBlock)));
   hipLaunchKernelGGL(k_pair_save, perNode, dim3(kBlock), 0, st, H, P, nd.pos, nd.vel, nd.radius, friction, staticThreshold); ++launches;
   const bool wide = P.nbrM != nullptr;  // ranges of more than two cells per axis: lists node by node
   if (!wide) { hipLaunchKernelGGL(k_pair_groups, dim3(std::min<uint32_t>(2048u, (H.capacity / 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, H, P, 0u); ++launches; }

@@ -8,7 +8,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "benchlib")):
+for p in (ROOT, os.path.join(ROOT, "benchlib"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import numpy as np  # noqa: E402
 
