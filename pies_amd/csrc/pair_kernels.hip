@@ -982,9 +982,10 @@ uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArr
   const dim3 perNode((n + kBlock - 1) / kBlock);
   const dim3 groups(std::max<uint32_t>(1u, std::min<uint32_t>(8192u, n / 8 + 1)));
   // workgroups of a level launch: a settled level of config 4 has ~280 chunks of frontier nodes, and 60 % of the captured level
-  // launches find nothing to do (the repeat's, and the spare ones of the first attempt) - an empty launch of 2 048 workgroups
-  // costs what its dispatch costs.  PIES_PAIR_LEVEL_BLOCKS sets the cap (chunks beyond it are taken in a grid-stride loop).
-  uint32_t levelCap = 2048u;
+  // launches find nothing to do (the repeat's, and the spare ones of the first attempt) - an empty launch costs what its dispatch
+  // costs.  Measured on config 4 (burst / settled substeps/s): cap 256: 55.5 / 76.3, 512: 66.7 / 91.3, 1 024: 68.2 / 97.3, 2 048 (rounds
+  // 3's): 65.3 / 94.2.  PIES_PAIR_LEVEL_BLOCKS sets the cap (chunks beyond it are taken in a grid-stride loop).
+  uint32_t levelCap = 1024u;
   if (const char* e = tuning_env("PIES_PAIR_LEVEL_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && v <= 65535) levelCap = static_cast<uint32_t>(v); }
   const dim3 level(std::max<uint32_t>(1u, std::min<uint32_t>(levelCap, (n + kRoundBlock - 1u) / kRoundBlock)));
   hipLaunchKernelGGL(k_pair_save, perNode, dim3(kBlock), 0, st, H, P, nd.pos, nd.vel, nd.radius, friction, staticThreshold); ++launches;
