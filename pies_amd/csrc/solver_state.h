@@ -253,6 +253,7 @@ struct pies_solver {
   uint32_t pcgBudget = 32;    // iterations currently captured in the graph (adapted to what the solves use)
   uint32_t pcgCalm = 0;       // synchronisations in the current observation window (all solves converged)
   uint32_t pcgWindowMax = 0;  // most CG iterations any solve used in that window
+  uint32_t pcgRecent[3] = {0, 0, 0};  // ... and at the last three synchronisations
   bool triFastRows = false;     // PD graph variant: contact rows of the SpMV summed by k_contact_rows (many contacts)
   uint32_t triQuiet = 0;        // synchronisations without a contact while that variant is active
   uint32_t pcgCooldown = 0;   // synchronisations left before the budget may shrink again after a solve ran out

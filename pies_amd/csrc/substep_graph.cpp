@@ -580,12 +580,20 @@ int adapt_pcg_budget(pies_solver* s) {
     // 5-8 iterations then sat at 8 and ran short on the next fluctuation - back to 32 for 60 frames.)
     // (the one-launch-per-iteration form needs one launch beyond the iterations a solve uses - the one that finds it converged)
     const uint32_t spare8 = std::max(pd_single_cg(s) ? 1u : 2u, (s->pcgWindowMax + 2u) / 3u), spare24 = std::max(1u, (s->pcgWindowMax + 3u) / 4u);
-    if (s->pcgCalm >= 8 && s->pcgWindowMax + spare8 < budget) { budget = s->pcgWindowMax + spare8; restart = true; }
+    // A budget far above what the solves use comes down in two steps: to TWICE (most used + spare) after three calm
+    // synchronisations, to (most used + spare) after eight more.  (Round 4: the budget is switched between instantiated graphs and
+    // a solve that needs more than was captured goes on inside its last launch, so coming down early costs a slower frame at
+    // worst; staying at 32 for fourteen frames after a contact onset cost 30 launches x 2.5 us per solve that found nothing to do.)
+    s->pcgRecent[s->pcgCalm % 3u] = used;  // (the last three synchronisations: what the solves use NOW, whatever the window saw before)
+    const uint32_t recent = std::max(s->pcgRecent[0], std::max(s->pcgRecent[1], s->pcgRecent[2]));
+    const uint32_t spare3 = std::max(pd_single_cg(s) ? 1u : 2u, (recent + 2u) / 3u);
+    if (s->pcgCalm >= 3 && 2u * (recent + spare3) < budget && !s->pdLadder.empty()) { budget = 2u * (recent + spare3); restart = true; }
+    else if (s->pcgCalm >= 8 && s->pcgWindowMax + spare8 < budget) { budget = s->pcgWindowMax + spare8; restart = true; }
     else if (s->pcgCalm >= 24) {
       if (s->pcgWindowMax + spare24 < budget) budget = s->pcgWindowMax + spare24;
       restart = true;  // the window never looks back further than 24 synchronisations
     }
-    if (restart) { s->pcgCalm = 0; s->pcgWindowMax = 0; }
+    if (restart) { s->pcgCalm = 0; s->pcgWindowMax = 0; s->pcgRecent[0] = s->pcgRecent[1] = s->pcgRecent[2] = 0; }
     // (every spare iteration is two launches per local/global iteration that exit at once)
   }
   // Graph variant for contact-heavy substeps: the contact rows of the SpMV get a pass of their own (k_contact_rows, one

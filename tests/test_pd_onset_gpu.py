@@ -169,7 +169,8 @@ def test_following_the_solves_never_instantiates_a_graph_in_a_frame(pies):
     real-time host: one tick and one synchronisation per frame.  The captured CG budget follows the solves (32 at the contact
     onset, 4 once the contacts are gone) and the contact-row variant switches with the contact count - every combination is an
     executable graph of the ladder built at pies_finalize, so no frame pays a capture + instantiation (round 2: 11-14 ms spikes
-    in 2.5 ms frames).  No frame after the first takes twice the median, and no solve ends short."""
+    in 2.5 ms frames).  No frame takes twice the median of the frames of its own regime (contacts binding or not), and no solve
+    ends short."""
     import time
     import bench
     ratios = []
@@ -178,20 +179,23 @@ def test_following_the_solves_never_instantiates_a_graph_in_a_frame(pies):
         g.finalize()
         g.tick_async(1)
         g.synchronize()      # the first replay uploads the executable graph
-        frames, budgets = [], set()
+        frames, contacts, budgets = [], [], set()
         for _ in range(18):
             t0 = time.perf_counter()
             g.tick_async(1)
             g.synchronize()
             frames.append(time.perf_counter() - t0)
+            contacts.append(len(g.tri_collisions))
             budgets.add(g.pcg_health()["budget"])
-        median = sorted(frames)[len(frames) // 2]
-        print("frames (ms):", [round(1e3 * f, 2) for f in frames], "budgets", sorted(budgets))
-        assert len(budgets) >= 2                       # the budget did move (32 at the onset, 4 afterwards)
+        print("frames (ms):", [round(1e3 * f, 2) for f in frames], "contacts", contacts, "budgets", sorted(budgets))
+        assert len(budgets) >= 2                       # the budget did move (32 at the onset, 2-4 afterwards)
         h = g.pcg_health()
         assert h["short_solves"] == 0 and not g.failed, h
         g.close()
-        ratios.append(max(frames) / median)
-        if ratios[-1] < 2.0:
+        # every frame against the median of the frames of its own regime (contacts binding or not): round 4 brings the budget
+        # down three frames after the contacts are gone, a contact-free frame is then a third of a binding one, and the ratio
+        # over all frames would measure that difference instead of stalls (bench.frame_spread)
+        ratios.append(bench.frame_spread(frames, contacts)[0])
+        if ratios[-1] is not None and ratios[-1] < 2.0:
             break
-    assert min(ratios) < 2.0, ratios
+    assert min(r for r in ratios if r is not None) < 2.0, ratios
