@@ -304,6 +304,9 @@ enum { PIES_KERNEL_PREDICT = 0, PIES_KERNEL_POSITION = 1, PIES_KERNEL_DISTANCE =
        PIES_KERNEL_PD_PREDICT = 9, PIES_KERNEL_PD_LOCAL_DISTANCE = 10, PIES_KERNEL_PD_LOCAL_TET = 11,
        PIES_KERNEL_PD_LOCAL_VOLUME = 12, PIES_KERNEL_PD_RHS = 13, PIES_KERNEL_PD_SPMV = 14,
        PIES_KERNEL_PD_CG_UPDATE = 15, PIES_KERNEL_PD_VELOCITY = 16,
+       /* (round 4, graph variants with one launch per CG iteration - pies_count(PIES_PD_CG_SINGLE): PD_SPMV is k_cg1_iter, a whole
+        * PCG iteration; PD_CG_UPDATE has no launches; PD_RHS is k_cg1_init when that kernel evaluates the right-hand side
+        * itself - tile-resident local step, pies_count(PIES_PD_TILES) -, otherwise k_pd_rhs) */
        /* schedule EXACT: one dependency level of the whole-substep DAG (all projection kinds + floor clamps) */
        PIES_KERNEL_WAVE = 17,
        /* schedule LAYERED: the groups of one parity, LDS resident (units = algorithmic bytes of the projections and

@@ -1,18 +1,17 @@
 // Projective-Dynamics substep kernels for gfx950 (Src/Solver.cpp:162-486 of the reference).
 //
 //   predict      pos += h v ; Msn_h2 = pos/invMass/h^2 ; floor-contact detection ; system diagonal
-//   local step   one lane = one constraint, all constraints of a container in ONE launch (the local step
-//                only reads positions, Solver.cpp:270-308) -> writes w*(A^T B p)_i per (constraint, node)
-//                (strain + volume constraints over the same elements share one gather and one SVD; the contacts'
-//                local step rides in a few extra workgroups of that launch)
-//   rhs          four lanes = one node: Msn_h2 + the node's contribution records (Solver.cpp:310-349), gathered without
-//                atomics: interleaved partial sums combined pairwise - deterministic, not the reference's term order
-//   global step  Jacobi-preconditioned CG on (K + C) x = rhs for the 3 coordinate columns at once; K in sliced ELL
-//                form (one row per lane, 64 rows per slice); the reference factors K + C with a sparse Cholesky every
-//                substep (Solver.cpp:258-262,356) -- CG to a relative residual replaces the direct solve; the graph holds a
-//                budget of iterations per solve, a converged solve's remaining launches return on one flag word, a solve
-//                that needs more goes on inside its last launch (k_cg_update, grid barriers), and a substep whose solve still ends above
-//                the tolerance is run again by pies_tick (capi.cpp)
+//   local step   the strain + volume element pairs: tile-resident (k_pd_local_tiles, round 4) - one wavefront per tile of 128
+//                pairs, two elements per lane in packed fp32 (pd_local_packed.h), contributions parked in LDS and added up node
+//                by node: one 12-byte sum per (tile, node) leaves the chip.  Every other container (and scenes without pairs):
+//                one lane = one constraint, the whole container in ONE launch -> w*(A^T B p)_i per (constraint, node)
+//                (Solver.cpp:270-308).  The contacts' local step rides in a few extra workgroups of the element launch.
+//   rhs          Msn_h2 + the node's records (tile sums, per-constraint records, contact / goal / floor terms; Solver.cpp:310-349),
+//                gathered without atomics: by one lane inside the residual kernel of the one-launch CG when a node has a few tile
+//                sums (pd_cg1_kernels.hip), by four lanes per node in k_pd_rhs otherwise - deterministic, not the reference's term order
+//   global step  Jacobi-preconditioned CG on (K + C) x = rhs for the 3 coordinate columns at once (the reference factors K + C
+//                with a sparse Cholesky every substep, Solver.cpp:258-262,356): pd_cg1_kernels.hip (one launch per iteration),
+//                pd_cg_kernels.hip (two launches; the experiments with several lanes per row), helpers in pd_cg_device.h
 //   velocity     v = (1-d)(pos-prev)/h + h f/m ; prev = pos ; floor friction
 //
 // Everything here is bandwidth/latency bound (gathers, streams, SpMV at ~15 nnz/row, 3x3 algebra): no MFMA.
