@@ -988,6 +988,11 @@ uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArr
   uint32_t levelCap = 1024u;
   if (const char* e = tuning_env("PIES_PAIR_LEVEL_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && v <= 65535) levelCap = static_cast<uint32_t>(v); }
   const dim3 level(std::max<uint32_t>(1u, std::min<uint32_t>(levelCap, (n + kRoundBlock - 1u) / kRoundBlock)));
+  // the level launches of the REPEAT almost always find "no repeat" and return: a small grid makes that cheap (a repeat that does
+  // run takes its frontier in a grid-stride loop)
+  uint32_t repeatCap = levelCap;
+  if (const char* e = tuning_env("PIES_PAIR_REPEAT_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && v <= 65535) repeatCap = static_cast<uint32_t>(v); }
+  const dim3 levelRepeat(std::max<uint32_t>(1u, std::min<uint32_t>(repeatCap, level.x)));
   hipLaunchKernelGGL(k_pair_save, perNode, dim3(kBlock), 0, st, H, P, nd.pos, nd.vel, nd.radius, friction, staticThreshold); ++launches;
   const bool wide = P.nbrM != nullptr;  // ranges of more than two cells per axis: lists node by node
   if (!wide) { hipLaunchKernelGGL(k_pair_groups, dim3(std::min<uint32_t>(2048u, (H.capacity / 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, H, P, 0u); ++launches; }
@@ -1003,7 +1008,7 @@ uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArr
     // nothing is repeated)
     const uint32_t captured = repeat ? rounds + rounds / 2u : rounds;
     for (uint32_t r = 1; r <= captured; ++r) {
-      hipLaunchKernelGGL(k_pair_round, level, dim3(kRoundBlock), 0, st, H, P, friction, staticThreshold, r, repeat); ++launches;
+      hipLaunchKernelGGL(k_pair_round, repeat ? levelRepeat : level, dim3(kRoundBlock), 0, st, H, P, friction, staticThreshold, r, repeat); ++launches;
     }
     hipLaunchKernelGGL(k_pair_tail, dim3(1), dim3(1024), 0, st, H, P, friction, staticThreshold, captured + 1u, repeat); ++launches;
     hipLaunchKernelGGL(k_pair_verify, dim3(64), dim3(kBlock), 0, st, H, P, repeat); ++launches;
