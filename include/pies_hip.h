@@ -324,6 +324,14 @@ int pies_profile_substep(pies_solver_t* s, int kernel, uint32_t* launches, doubl
  * kernel durations.  The node state is put back afterwards. */
 int pies_profile_in_situ(pies_solver_t* s, int kernel, uint32_t substeps, uint32_t* launches, double* total_ms, uint64_t* units,
                          double* bracket_overhead_ms);
+/* The tile plan of the PD strain + volume local step, computed from the host-side scene (also on PIES_DEVICE_NONE handles): tiles of
+ * up to 128 element pairs on up to 128 nodes (one wavefront each).  n_tiles = 0 when the scene keeps per-(element, node) records
+ * (no strain + volume pairs).  With info != NULL the plan is copied out at fixed strides per tile: info[t] = nodes | elements << 16,
+ * node[128 t + k] = node of tile node k, elem[128 t + e] = host index of element slot e, local[128 t + e] = its four tile-local
+ * node indices (8 bits each), nptr[132 t + k] .. nptr[132 t + k + 1] = tile node k's entries in inc[512 t + ..] (element << 2 |
+ * corner).  Any array pointer but info may be NULL. */
+int pies_get_pd_tile_plan(pies_solver_t* s, uint32_t* n_tiles, uint32_t* info, uint32_t* node, uint32_t* elem, uint32_t* local, uint16_t* nptr,
+                          uint16_t* inc, uint32_t tile_capacity);
 /* launches per substep of the captured graph, per kernel class (PIES_KERNEL_COUNT entries) */
 int pies_launch_counts(pies_solver_t* s, uint32_t* out);
 

@@ -47,6 +47,7 @@ SYMBOLS = [
     "pies_get_tri_contacts", "pies_tick_begin", "pies_export_acquire", "pies_export_release",
     "pies_read_positions_strided", "pies_set_pcg_retry", "pies_get_pcg_health", "pies_profile_in_situ",
     "pies_collision_stats", "pies_get_collision_health", "pies_set_collision_rounds", "pies_set_solver", "pies_debug_pair_state", "pies_set_tuning",
+    "pies_get_pd_tile_plan",
 ]
 
 
@@ -147,6 +148,7 @@ def load():
         "pies_profile_in_situ": [vp, i32, u32, pu, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)],
     }
     sig["pies_set_tuning"] = [C.c_char_p, C.c_char_p]
+    sig["pies_get_pd_tile_plan"] = [vp, pu, pu, pu, pu, pu, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), u32]
     for name, args in sig.items():
         fn = getattr(L, name)
         fn.argtypes = args
@@ -478,6 +480,21 @@ class Solver:
         out = np.empty(self.count(ctype), dtype=np.uint32)
         self._ck(self._L.pies_get_order(self._h, ctype, _pu(out), out.size))
         return out
+
+    def pd_tile_plan(self):
+        """pies_get_pd_tile_plan: None when the scene keeps per-(element, node) records, otherwise a dict of the plan's arrays
+        (info: nodes | elements << 16 per tile; node, elem, local: 128 per tile; nptr: 132 per tile; inc: 512 per tile)."""
+        nt = C.c_uint32()
+        self._ck(self._L.pies_get_pd_tile_plan(self._h, C.byref(nt), None, None, None, None, None, None, 0))
+        n = nt.value
+        if n == 0:
+            return None
+        info, node, elem, local = (np.empty(k * n, dtype=np.uint32) for k in (1, 128, 128, 128))
+        nptr, inc = np.empty(132 * n, dtype=np.uint16), np.empty(512 * n, dtype=np.uint16)
+        p16 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint16))  # noqa: E731
+        self._ck(self._L.pies_get_pd_tile_plan(self._h, C.byref(nt), _pu(info), _pu(node), _pu(elem), _pu(local), p16(nptr), p16(inc), n))
+        return {"info": info, "node": node.reshape(n, 128), "elem": elem.reshape(n, 128), "local": local.reshape(n, 128),
+                "nptr": nptr.reshape(n, 132), "inc": inc.reshape(n, 512)}
 
     def batches(self, ctype):
         nb = C.c_uint32()

@@ -20,6 +20,19 @@ using namespace pies;
 
 namespace pies {
 
+// strain and volume constraints added pairwise over the same elements (createTetBox and addTriMeshVolume add them that way,
+// PrimitiveUtilities.cpp:401-514): one gather, one SVD, one tile plan for both
+bool tet_volume_pairs(const pies_solver* s) {
+  bool paired = !s->h_tet.empty() && s->h_tet.size() == s->h_volume.size();
+  const bool planned = s->plan[PIES_TET].order.size() == s->h_tet.size();  // (PD: host order; a handle that has not been finalized has no plan yet)
+  for (size_t k = 0; paired && k < s->h_tet.size(); ++k) {
+    const HostTet &a = s->h_tet[planned ? s->plan[PIES_TET].order[k] : k], &b = s->h_volume[k];
+    paired = std::memcmp(a.ids, b.ids, sizeof(a.ids)) == 0 && std::memcmp(a.qinv, b.qinv, sizeof(a.qinv)) == 0;
+  }
+  if (const char* e = tuning_env("PIES_NO_TET_PAIRS"); e && e[0] == '1') paired = false;
+  return paired;
+}
+
 void free_device(pies_solver* s) {
   destroy_graph(s);
   for (void* p : s->allocations) (void)hipFree(p);
@@ -600,12 +613,7 @@ int pies_finalize(pies_solver_t* s) {
     if (int rc = upload(s, q1, &s->d_vc_q1)) return rc;
     if (int rc = upload(s, q2, &s->d_vc_q2)) return rc;
     // strain and volume constraints added pairwise over the same elements share one gather and one SVD
-    s->tetVolumePaired = !s->h_tet.empty() && s->h_tet.size() == s->h_volume.size();
-    for (size_t k = 0; s->tetVolumePaired && k < s->h_tet.size(); ++k) {
-      const HostTet &a = s->h_tet[s->plan[PIES_TET].order[k]], &b = s->h_volume[k];
-      s->tetVolumePaired = std::memcmp(a.ids, b.ids, sizeof(a.ids)) == 0 && std::memcmp(a.qinv, b.qinv, sizeof(a.qinv)) == 0;
-    }
-    if (const char* e = tuning_env("PIES_NO_TET_PAIRS"); e && e[0] == '1') s->tetVolumePaired = false;
+    s->tetVolumePaired = tet_volume_pairs(s);
     // Rest dictionary: the 64 bytes of constants of an element pair are the same for every element of one shape and material.
     // With few distinct sets (a createTetBox lattice: one per orientation) the local step reads a 16-bit index per element.
     s->d_pairDictIndex = nullptr;
@@ -1107,6 +1115,27 @@ int pies_get_batches(pies_solver_t* s, int type, uint32_t* offs, uint32_t capaci
     for (size_t b = 0; b < pl.batches.size(); ++b) offs[b] = pl.batches[b].start;
     offs[pl.batches.size()] = pl.batches.empty() ? 0 : pl.batches.back().start + pl.batches.back().count;
   }
+  return PIES_OK;
+}
+
+// The tile plan of the PD strain + volume local step (pd_tiles.cpp), from the host-side scene alone: works on host-only handles.
+int pies_get_pd_tile_plan(pies_solver_t* s, uint32_t* n_tiles, uint32_t* info, uint32_t* node, uint32_t* elem, uint32_t* local, uint16_t* nptr,
+                          uint16_t* inc, uint32_t tile_capacity) {
+  if (!s || !n_tiles) return PIES_ERR_INVALID;
+  const bool paired = s->tetVolumePaired;
+  s->tetVolumePaired = tet_volume_pairs(s);
+  PdTilePlan plan;
+  const bool ok = pd_plan_tiles(s, plan);
+  s->tetVolumePaired = paired;
+  *n_tiles = ok ? static_cast<uint32_t>(plan.info.size()) : 0u;
+  if (!ok || !info) return PIES_OK;
+  if (plan.info.size() > tile_capacity) return fail(s, PIES_ERR_INVALID, "pies_get_pd_tile_plan: capacity too small");
+  std::memcpy(info, plan.info.data(), plan.info.size() * sizeof(uint32_t));
+  if (node) std::memcpy(node, plan.node.data(), plan.node.size() * sizeof(uint32_t));
+  if (elem) std::memcpy(elem, plan.elem.data(), plan.elem.size() * sizeof(uint32_t));
+  if (local) std::memcpy(local, plan.local.data(), plan.local.size() * sizeof(uint32_t));
+  if (nptr) std::memcpy(nptr, plan.nptr.data(), plan.nptr.size() * sizeof(uint16_t));
+  if (inc) std::memcpy(inc, plan.inc.data(), plan.inc.size() * sizeof(uint16_t));
   return PIES_OK;
 }
 

@@ -33,6 +33,7 @@ int adapt_sort_passes(pies_solver* s);
 int poll_failure(pies_solver* s);
 // ---- capi.cpp ----
 void free_device(pies_solver* s);
+bool tet_volume_pairs(const pies_solver* s);
 
 
 }  // namespace pies

@@ -142,3 +142,49 @@ def test_default_schedule_and_environment_override(monkeypatch):
     monkeypatch.setenv("PIES_SCHEDULE", "exact")
     assert np.array_equal(tet_order(), exact)               # the environment's choice ...
     assert np.array_equal(tet_order(capi.SCHEDULE_LAYERED), layered)  # ... does not override an explicit pies_set_schedule
+
+
+def _check_tile_plan(g, pies):
+    """Invariants of the PD tile plan (pd_tiles.cpp): every element pair in exactly one tile, a tile's node list is exactly the
+    union of its elements' nodes (at most 128), the 8-bit local indices decode to the elements' nodes, and the per-node lists
+    name every (element, corner) incidence exactly once, ascending."""
+    plan = g.pd_tile_plan()
+    assert plan is not None
+    tets = g.ids(pies.TET).reshape(-1, 4)
+    seen = np.zeros(len(tets), dtype=np.int64)
+    records = 0
+    for t, info in enumerate(plan["info"]):
+        nn, ne = int(info & 0xffff), int(info >> 16)
+        assert 1 <= ne <= 128 and 1 <= nn <= 128
+        nodes, elems = plan["node"][t, :nn], plan["elem"][t, :ne]
+        assert np.all(np.diff(nodes.astype(np.int64)) > 0)                      # ascending, distinct
+        np.add.at(seen, elems, 1)
+        loc = plan["local"][t, :ne]
+        dec = np.stack([(loc >> s) & 0xff for s in (0, 8, 16, 24)], axis=1)
+        assert dec.max() < nn and np.array_equal(nodes[dec], tets[elems])       # local indices name the elements' nodes
+        assert set(nodes.tolist()) == set(tets[elems].reshape(-1).tolist())     # and the node list is exactly their union
+        nptr = plan["nptr"][t].astype(np.int64)
+        assert nptr[0] == 0 and nptr[nn] == 4 * ne and np.all(np.diff(nptr[:nn + 1]) >= 1)
+        inc = plan["inc"][t, :4 * ne].astype(np.int64)
+        assert sorted(inc.tolist()) == list(range(4 * ne))                      # every (element, corner) exactly once
+        for k in range(nn):
+            seg = inc[nptr[k]:nptr[k + 1]]
+            assert np.all(np.diff(seg) > 0) and np.all(dec[seg >> 2, seg & 3] == k)
+        records += nn
+    assert np.all(seen == 1)
+    return len(plan["info"]), records
+
+
+def test_pd_tile_plan_invariants_on_a_lattice_and_on_an_unstructured_mesh(pies):
+    g = pies.Solver(pies.Options(solver=pies.PD, iterations=10), device=pies.DEVICE_NONE)
+    g.create_tet_box(7, 6, 23, translation=(0.0, 2.0, 0.0), w=1.0, volume=True, triangles=True)
+    tiles, records = _check_tile_plan(g, pies)
+    assert tiles == -(-g.count(pies.TET) // 128) and records < 5 * g.count(pies.NODES)
+    mesh = scenes.delaunay_beam((6, 5, 14))
+    u = pies.Solver(pies.Options(solver=pies.PD, iterations=10), device=pies.DEVICE_NONE)
+    scenes.build_unstructured_pd(u, mesh)
+    _check_tile_plan(u, pies)
+    # a scene without strain + volume pairs keeps per-(element, node) records
+    p = pies.Solver(pies.Options(solver=pies.PD, iterations=10), device=pies.DEVICE_NONE)
+    p.create_tet_box(3, 3, 3, w=1.0, volume=False)
+    assert p.pd_tile_plan() is None
