@@ -242,6 +242,13 @@ int pies_failed(pies_solver_t* s, int* failed);
 /* Point-triangle contacts of the last PD substep (Solver::_triCollisions, Solver.h:187), in list order:
  * 4 node ids each (point a, triangle b c d).  ids may be NULL to query the count. */
 int pies_get_tri_contacts(pies_solver_t* s, uint32_t* ids, uint32_t capacity, uint32_t* count);
+/* Broad phase of the last PD substep's point-triangle detection (diagnostics; synchronises).  The device lists every surface
+ * triangle once, in the cell of the minimum corner of its swept range, in one of three size classes (cells of 1, 4 and 16 world
+ * cells; pies_amd/csrc/tri_kernels.h) - the reference lists it in every cell of the range (Solver.cpp:692, SpatialHash.h:141-176);
+ * the pairs and the contact list are the same.  out[0] = pairs handed to the CCD (Solver.cpp:775-797 runs it for every pair
+ * without a common node in a shared cell), out[1] = pairs with at least one hit, out[2..4] = longest range listed per class (in
+ * cells of the class), out[5..7] = triangles listed per class. */
+int pies_get_tri_grid_stats(pies_solver_t* s, uint32_t out[8]);
 /* Node-node pairs resolved by the PBD collision pass since the last call (statistics). */
 int pies_collision_pairs(pies_solver_t* s, uint64_t* pairs);
 /* The same plus the candidates the pass looked at (bucket entries visited, the unit of SURVEY 8d's "16 B per candidate

@@ -47,7 +47,7 @@ SYMBOLS = [
     "pies_get_tri_contacts", "pies_tick_begin", "pies_export_acquire", "pies_export_release",
     "pies_read_positions_strided", "pies_set_pcg_retry", "pies_get_pcg_health", "pies_profile_in_situ",
     "pies_collision_stats", "pies_get_collision_health", "pies_set_collision_rounds", "pies_set_solver", "pies_debug_pair_state", "pies_set_tuning",
-    "pies_get_pd_tile_plan",
+    "pies_get_pd_tile_plan", "pies_get_tri_grid_stats",
 ]
 
 
@@ -134,6 +134,7 @@ def load():
         "pies_create_shape_matching_sheet": [vp, u32, u32, pf, f32, f32],
         "pies_get_group": [vp, i32, u32, pu, u32, pu],
         "pies_get_tri_contacts": [vp, pu, u32, pu],
+        "pies_get_tri_grid_stats": [vp, pu],
         "pies_tick_begin": [vp, C.POINTER(C.c_uint64)],
         "pies_export_acquire": [vp, C.c_uint64, C.POINTER(pf), pu],
         "pies_export_release": [vp, C.c_uint64],
@@ -398,6 +399,12 @@ class Solver:
         if n.value:
             self._ck(self._L.pies_get_tri_contacts(self._h, _pu(out), n.value, C.byref(n)))
         return out
+
+    def tri_grid_stats(self):
+        """pies_get_tri_grid_stats: the broad phase of the last PD substep's point-triangle detection."""
+        out = np.zeros(8, dtype=np.uint32)
+        self._ck(self._L.pies_get_tri_grid_stats(self._h, _pu(out)))
+        return {"ccd_pairs": int(out[0]), "hit_pairs": int(out[1]), "longest": out[2:5].tolist(), "listed": out[5:8].tolist()}
 
     @property
     def collision_pairs(self):

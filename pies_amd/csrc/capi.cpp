@@ -896,6 +896,23 @@ int pies_failed(pies_solver_t* s, int* failed) {
   return PIES_OK;
 }
 
+int pies_get_tri_grid_stats(pies_solver_t* s, uint32_t out[8]) {
+  if (!s || !out) return PIES_ERR_INVALID;
+  for (int i = 0; i < 8; ++i) out[i] = 0;
+  if (s->device == PIES_DEVICE_NONE || !s->pd.tri.counters) return PIES_OK;
+  HIP_TRY(s, hipSetDevice(s->device));
+  uint32_t c[16];
+  HIP_TRY(s, hipMemcpyAsync(c, s->pd.tri.counters, sizeof(c), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  uint32_t lists[64 * 16];
+  HIP_TRY(s, hipMemcpyAsync(lists, s->pd.tri.workCnt, sizeof(lists), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  for (int i = 0; i < 64; ++i) out[0] += lists[16 * i];
+  out[1] = c[9];
+  for (int k = 0; k < 3; ++k) { out[2 + k] = c[10 + k]; out[5 + k] = c[13 + k]; }
+  return PIES_OK;
+}
+
 int pies_get_tri_contacts(pies_solver_t* s, uint32_t* ids, uint32_t capacity, uint32_t* count) {
   if (!s || !count) return PIES_ERR_INVALID;
   *count = 0;

@@ -7,6 +7,7 @@
 //   * per node, the number of surface-triangle incidences (one floor contact each, Solver.cpp:829-834).
 // The factorisation itself is replaced by CG on the device (pd_kernels.hip).
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -358,28 +359,58 @@ int pd_build(pies_solver* s) {
     uint32_t* d_tris;
     if (int rc = upload(s, s->h_triangles, &d_tris)) return rc;
     T.tris = d_tris;
-    // (cell, triangle) entries: kTriMaxEntries per triangle on average, and never fewer than 2^18 - a handful of wide
-    // triangles (up to 50 cells per axis each, Solver.cpp:974-976) must not run a small scene out of storage
-    const uint64_t entries = std::max<uint64_t>(static_cast<uint64_t>(kTriMaxEntries) * nt, 1ull << 18);
-    if (entries >= (1ull << 31)) return fail(s, PIES_ERR_UNSUPPORTED, "too many surface triangles for the triangle grid");
-    uint32_t cap = 1024;
-    while (cap < 2ull * entries) cap <<= 1;
-    T.capacity = cap;
-    T.mask = cap - 1;
+    // The cell tables of the three size classes (tri_kernels.h): slots are indexed by the cell coordinates modulo the table's
+    // dimensions - powers of two, the scene's extent at finalize where that fits 2^22 slots, and never fewer than a
+    // search window is long (23 cells of the finest class, 9 and 7 of the coarser ones), so that no window meets a slot twice.
+    // A scene that outgrows its table shares slots between distant cells: more candidates for the exact range test, nothing else.
+    float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};
+    for (uint32_t i = 0; i < n; ++i)
+      for (int k = 0; k < 3; ++k) {
+        const float v = s->h_pos[3ull * i + k];
+        if (!(std::fabs(v) < 1.0e6f)) continue;
+        lo[k] = i == 0 ? v : std::min(lo[k], v);
+        hi[k] = i == 0 ? v : std::max(hi[k], v);
+      }
+    uint32_t lg[3];
+    for (int k = 0; k < 3; ++k) {
+      const double want = (static_cast<double>(hi[k]) - lo[k]) + 2.0;
+      lg[k] = 5;
+      while (lg[k] < 10 && (1u << lg[k]) < want) ++lg[k];
+    }
+    while (lg[0] + lg[1] + lg[2] > 22) {  // the longest axis gives way first
+      int k = lg[0] >= lg[1] && lg[0] >= lg[2] ? 0 : lg[1] >= lg[2] ? 1 : 2;
+      --lg[k];
+    }
+    static const uint32_t shifts[kTriLevels] = {0, 2, 4}, floorLg[kTriLevels] = {5, 4, 3};
+    uint32_t slots = 0;
+    for (int l = 0; l < kTriLevels; ++l) {
+      TriGridLevel& L = T.level[l];
+      L.base = slots;
+      L.shift = shifts[l];
+      L.lx = std::max(floorLg[l], lg[0] > shifts[l] ? lg[0] - shifts[l] : 0u);
+      L.ly = std::max(floorLg[l], lg[1] > shifts[l] ? lg[1] - shifts[l] : 0u);
+      L.lz = std::max(floorLg[l], lg[2] > shifts[l] ? lg[2] - shifts[l] : 0u);
+      slots += 1u << (L.lx + L.ly + L.lz);
+    }
     T.maxContacts = 16 * nt + 1024;
-    T.maxEntries = static_cast<uint32_t>(entries);
-    if (int rc = dev_alloc(s, cap, &T.keys)) return rc;
-    HIP_TRY(s, hipMemsetAsync(T.keys, 0xFF, static_cast<size_t>(cap) * sizeof(uint64_t), s->stream));
-    if (int rc = dev_alloc(s, cap, &T.cnt, true)) return rc;
-    if (int rc = dev_alloc(s, cap, &T.start, true)) return rc;
-    if (int rc = dev_alloc(s, cap, &T.fill, true)) return rc;
-    if (int rc = dev_alloc(s, static_cast<size_t>(T.maxEntries), &T.used, true)) return rc;
+    slots = (slots + 2047u) & ~2047u;  // whole tiles of the prefix sum
+    T.slots = slots;
+    if (int rc = dev_alloc(s, slots, &T.cellCnt, true)) return rc;
+    if (int rc = dev_alloc(s, slots + 1ull, &T.cellStart, true)) return rc;
+    if (int rc = dev_alloc(s, slots / 2048u + 1u, &T.tileSum, true)) return rc;
+    if (int rc = dev_alloc(s, nt, &T.cellOf)) return rc;
+    HIP_TRY(s, hipMemsetAsync(T.cellOf, 0xFF, static_cast<size_t>(nt) * sizeof(uint32_t), s->stream));
+    if (int rc = dev_alloc(s, nt, &T.posIn, true)) return rc;
+    if (int rc = dev_alloc(s, 4ull * nt, &T.ent, true)) return rc;
+    if (int rc = dev_alloc(s, 4ull * nt, &T.boxOf, true)) return rc;
     if (int rc = dev_alloc(s, 16, &T.counters, true)) return rc;
-    if (int rc = dev_alloc(s, static_cast<size_t>(kTriMaxEntries) * nt, &T.triSlot, true)) return rc;
     if (int rc = dev_alloc(s, nt, &T.rng, true)) return rc;
-    if (int rc = dev_alloc(s, 3ull * nt, &T.box, true)) return rc;
-    if (int rc = dev_alloc(s, static_cast<size_t>(T.maxEntries), &T.bucket, true)) return rc;
-    if (int rc = dev_alloc(s, static_cast<size_t>(T.maxEntries), &T.bucketSorted, true)) return rc;
+    if (int rc = dev_alloc(s, nt, &T.head, true)) return rc;
+    if (int rc = dev_alloc(s, T.maxContacts, &T.pool, true)) return rc;
+    if (nt >= (1u << 29)) return fail(s, PIES_ERR_UNSUPPORTED, "too many surface triangles for the contact work list");
+    T.maxWork = static_cast<uint32_t>(std::min<uint64_t>((128ull * nt + 65536ull) & ~63ull, 1ull << 30));  // 64 lists of a 64th each
+    if (int rc = dev_alloc(s, 64u * 16u, &T.workCnt, true)) return rc;
+    if (int rc = dev_alloc(s, T.maxWork, &T.work, true)) return rc;
     if (int rc = dev_alloc(s, nt, &T.cntTri, true)) return rc;
     if (int rc = dev_alloc(s, nt, &T.offTri, true)) return rc;
     if (int rc = dev_alloc(s, T.maxContacts, &T.ids, true)) return rc;

@@ -10,30 +10,52 @@ namespace pies {
 
 // A triangle's box over position and previous position spans up to 50 cells per axis when it is inserted (TriCompRange,
 // Solver.cpp:974-976) and up to 20 when it searches (sweptTriRange, :672-674); a longer range is EMPTY, as in the
-// reference.  Storage is reserved for kTriMaxEntries (cell, triangle) entries per triangle on average (a triangle of a
-// simulation mesh spans 1-8 world-unit cells); the first kTriMaxEntries cells of a triangle have their index slot cached
-// between the count and the fill pass, the rest are looked up again.  More entries in total than reserved latch a failure.
+// reference.
+//
+// Round 4, second half: the reference's grid lists a triangle in EVERY cell of its range (18-27 cells for a moving triangle of a
+// unit lattice: a million (cell, triangle) entries and 2.2 M atomic operations per substep at 42k triangles, and every pair of
+// neighbours met in ~10 shared cells).  The device keeps each triangle ONCE, in the cell of its range's minimum corner, and a
+// searching triangle looks at every cell a partner's minimum corner can lie in (its own range, grown downwards by the longest
+// range inserted - 1): the same pairs, each met once, and the number of cells they share - which the reference's list repeats
+// a hit by - is the volume of the two ranges' intersection.  Three size classes keep the window small when a few triangles are
+// much longer than the rest: class k has cells of 2^kTriLevelShift[k] world cells and takes the triangles whose range spans at most
+// kTriLevelExt of them per axis (the last class takes every insertable triangle: 50 world cells are 5 cells of 16).  Cells are
+// slots of a table indexed by the cell coordinates modulo the table's (power-of-two) dimensions: two cells far apart may
+// share a slot, which only adds candidates that the exact range test drops.
 constexpr uint32_t kTriInsertMaxCells = 50, kTriSearchMaxCells = 20;
-constexpr uint32_t kTriMaxEntries = 64;
+constexpr int kTriLevels = 3;
+constexpr uint32_t kTriLevelExt = 4;
+struct TriGridLevel {
+  uint32_t base;       // first slot of the level in TriArrays::cell
+  uint32_t shift;      // world cells per cell, log2
+  uint32_t lx, ly, lz; // table dimensions, log2
+};
 constexpr float kTriContactW = 10000.0f;                        // PointTriangleCollisionConstraint::w (CollisionConstraint.h:32)
 
 struct TriArrays {
   uint32_t nt;           // surface triangles (0 = pipeline disabled)
   uint32_t threadCount;  // SolverOptions::threadCount: contacts are listed thread by thread (Solver.cpp:714,852)
   const uint32_t* tris;      // 3 node ids per triangle
-  // triangle grid (exact-key cell table, world-unit cells)
-  uint32_t capacity, mask;
-  uint64_t* keys;
-  uint32_t *cnt, *start, *fill, *used;
-  uint32_t* counters;  // [0] used cells [1] bucket entries [2] contacts [3] failure flag [4] nodes with contacts [5] incidences
+  // triangle grid (minimum-corner cells in three size classes, see above)
+  TriGridLevel level[kTriLevels];
+  uint32_t slots;      // slots of the three tables together (a multiple of 2048)
+  uint32_t* cellCnt;   // per slot: triangles listed
+  uint32_t* cellStart; // slots + 1: first entry of the slot (entries are in slot order: a row of cells along z is one stretch)
+  uint32_t* tileSum;   // per 2048 slots: triangles listed
+  uint32_t *cellOf, *posIn;  // per triangle: its slot (0xffffffff: not inserted) and its place among the slot's triangles
+  float4* ent;         // 4 per listed triangle, slot by slot: {box min of its six corner positions, bits(triangle)}, {box max, regular ? 1 : 0},
+                       // {bits: min cell, packed lengths}, {bits: node ids} - all a searching triangle needs of a partner, in one line
+  float4* boxOf;       // the same four records per triangle (k_tri_box), copied into ent once the slots have their storage
+  uint32_t* counters;  // [0] [1] - [2] contacts [3] failure flag [4] nodes with contacts [5] incidences
                        // [8] merged row entries [6] dependency levels of the contact list [7] form of the sequential passes: 0 on an LDS copy of the
                        // touched nodes, 2 through L2, 1 more than kTriMaxLevels levels (single-wavefront walk)
-  uint32_t* triSlot;   // nt x kTriMaxEntries
+                       // [9] hit records [10..12] longest range (in cells of the class) listed per class [13..15] triangles per class
   int4* rng;           // per triangle: min cell, packed lengths
-  float4* box;         // 3 per triangle (k_tri_count): {box min of its six corner positions, regular ? 1 : 0}, {box max, bits(node 0)},
-                       // {bits(node 1), bits(node 2), -, -}: what the detection's reject test needs of a candidate, in one place
-  uint32_t *bucket, *bucketSorted;
-  uint32_t maxEntries;  // (cell, triangle) entries reserved in bucket / bucketSorted
+  uint2* work;         // pairs left for the CCD: {triangle, partner | corners to test << 29}, in 64 lists of maxWork / 64
+  uint32_t maxWork;
+  uint32_t* workCnt;   // the lists' lengths, 16 words apart
+  uint32_t* head;      // per triangle: its first hit record (0xffffffff: none)
+  uint4* pool;         // hit records {triangle, partner, which of the triangle's corners hit (bits 0-2), next record of the triangle}; maxContacts
   // contacts of the current substep, in the reference's list order
   uint32_t maxContacts;
   uint32_t *cntTri, *offTri;  // contacts per triangle and their list offsets, indexed by merge_rank(triangle)
@@ -59,7 +81,7 @@ constexpr uint32_t kTriMaxLevels = 2048;  // longer chains (one node in thousand
 
 struct PdArrays;
 
-// after the predict kernel: grid build, detection (count, scan, fill), per-node incidence + diagonal; returns launches
+// after the predict kernel: grid build, detection (pairs + hit records, scan, contact list), per-node incidence + diagonal; returns launches
 uint32_t launch_tri_detect(hipStream_t st, const TriArrays& T, const NodeArrays& nd, const float* kdiag, float* cdiag, float* dinv,
                            float threshold, float thickness, bool mergedRows);
 // dependency levels of the contact list for the sequential passes (may run on another stream beside the local/global iterations)

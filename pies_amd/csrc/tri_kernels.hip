@@ -1,12 +1,13 @@
 // Point-triangle collisions of the Projective-Dynamics substep.
 //
-//   detection  Src/Solver.cpp:680-875: every surface triangle is inserted into a world-unit cell grid over the
+//   detection  Src/Solver.cpp:680-875: the reference inserts every surface triangle into a world-unit cell grid over the
 //              AABB of its nodes' current and previous positions (TriCompRange :942-979, sweptTriRange :639-677);
 //              for every triangle, every triangle without a common node found in the cells of its swept range
 //              is tested with three point-triangle CCDs (CollisionDetection.cpp:227-302).  Contacts are listed
 //              in the reference's order: thread by thread (triangle id modulo threadCount), triangle by
 //              triangle, cell by cell (dx,dy,dz), bucket entry by entry (ascending triangle id), point by
-//              point -- including the duplicates a pair produces when it shares several cells.
+//              point -- including the duplicates a pair produces when it shares several cells.  The device finds the
+//              same pairs from a grid that holds every triangle once (tri_kernels.h) and writes the same list.
 //   constraint CollisionConstraint.cpp:67-194: differential coordinates w.r.t. the point (A = B), projection
 //              along the triangle normal, w = 1e4; its 4x4 block is added to the system matrix through a
 //              per-node list of contacts (diagonal into cdiag, off-diagonals applied inside the SpMV).
@@ -142,148 +143,164 @@ PIES_DEV bool point_triangle_ccd(F3 ap0, F3 ab0, F3 ac0, F3 ap1, F3 ab1, F3 ac1,
   return !bary_outside(solve_columns(abt, act, n, apt));
 }
 
-// ---- triangle grid -------------------------------------------------------------------------------------
+// ---- triangle grid (tri_kernels.h: every triangle once, in the cell of its range's minimum corner) ----------------------
+constexpr uint32_t kNil = 0xffffffffu;
+constexpr uint32_t kWorkShards = 64;    // lists of the CCD's work list (k_tri_pairs)
+constexpr uint32_t kGridTile = 2048;  // slots per tile of the prefix sum over the slots (256 threads x 8)
+PIES_DEV uint32_t grid_slot(const TriGridLevel& L, int x, int y, int z) {  // cell coordinates of the level -> slot (modulo the table)
+  const uint32_t ux = static_cast<uint32_t>(x) & ((1u << L.lx) - 1u), uy = static_cast<uint32_t>(y) & ((1u << L.ly) - 1u),
+                 uz = static_cast<uint32_t>(z) & ((1u << L.lz) - 1u);
+  return L.base + ((((ux << L.ly) | uy) << L.lz) | uz);
+}
+// cells of the level a range of `len` world cells from `m` spans
+PIES_DEV uint32_t level_extent(int m, uint32_t len, uint32_t shift) { return static_cast<uint32_t>(((m + static_cast<int>(len) - 1) >> shift) - (m >> shift)) + 1u; }
+
+// Before the grid is built: the slots the last substep listed triangles in, the tile sums and the substep's counters back to zero
+// ([0] and [4]-[8] are zeroed by k_tri_box, which runs before their first use: this kernel's own workgroups still read [4]),
+// the per-node incidence counts of the last substep's contacts.
 __global__ void __launch_bounds__(kBlock) k_tri_reset(TriArrays T) {
-  const uint32_t used = min(T.counters[0], T.maxEntries), usedNodes = T.counters[4];
-  for (uint32_t u = blockIdx.x * kBlock + threadIdx.x; u < used; u += gridDim.x * kBlock) {
-    const uint32_t s = T.used[u];
-    T.keys[s] = kEmpty;
-    T.cnt[s] = 0;
+  const uint32_t usedNodes = T.counters[4];
+  const uint32_t tid = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
+  if (tid < 16u && (tid == 1u || tid == 2u || tid >= 9u)) T.counters[tid] = 0;  // ([3] is the sticky failure flag)
+  for (uint32_t b = tid; b < T.slots / kGridTile; b += stride) T.tileSum[b] = 0;
+  if (tid < kWorkShards) T.workCnt[16u * tid] = 0;
+  for (uint32_t t = tid; t < T.nt; t += stride) {
+    const uint32_t s = T.cellOf[t];  // (the slots of the last substep; several triangles of a slot store the same 0)
+    if (s != kNil) T.cellCnt[s] = 0;
   }
-  for (uint32_t u = blockIdx.x * kBlock + threadIdx.x; u < usedNodes; u += gridDim.x * kBlock) {
+  for (uint32_t u = tid; u < usedNodes; u += stride) {
     const uint32_t n = T.usedNodes[u];
     T.incCnt[n] = 0;
     T.usedBits[n >> 5] = 0;  // (several nodes of a word: every writer stores the same 0)
   }
 }
-__global__ void k_tri_zero(TriArrays T) {
-  const uint32_t t = threadIdx.x;
-  if (t < 9 && t != 3) T.counters[t] = 0;  // [3] is the sticky failure flag
-}
 
-// TriCompRange / sweptTriRange: floor(min), ceil(max) - floor(min) over position and prevPosition, world units.
-// TEAM lanes per triangle share the cells of its range; the launch uses TEAM = 1.  (Measured on a moving 100k-particle beam,
-// 42k triangles of 18-27 cells: 1, 2 and 4 lanes per triangle take the same 32 us, 8 lanes 50, 16 lanes 90 - the kernel is bound
-// by its 2.2 M atomic operations on the cell index, and more lanes in flight only put more of them on the same lines at once.)
-template <int TEAM>
-__global__ void __launch_bounds__(kBlock) k_tri_count(TriArrays T, const float4* __restrict__ pos, const float4* __restrict__ prev) {
-  const uint32_t t = (blockIdx.x * kBlock + threadIdx.x) / TEAM, member = threadIdx.x % TEAM;
-  if (t >= T.nt) return;
-  const uint32_t i0 = T.tris[3 * t], i1 = T.tris[3 * t + 1], i2 = T.tris[3 * t + 2];
-  const F3 b1 = xyz(pos[i0]), c1 = xyz(pos[i1]), d1 = xyz(pos[i2]);
-  const F3 b0 = xyz(prev[i0]), c0 = xyz(prev[i1]), d0 = xyz(prev[i2]);
-  const float pv[3][3] = {{b1.x, b1.y, b1.z}, {c1.x, c1.y, c1.z}, {d1.x, d1.y, d1.z}};
-  const float qv[3][3] = {{b0.x, b0.y, b0.z}, {c0.x, c0.y, c0.z}, {d0.x, d0.y, d0.z}};
-  float mn[3], mx[3];
+// TriCompRange / sweptTriRange: floor(min), ceil(max) - floor(min) over position and prevPosition, world units; the triangle's
+// record for the detection (box of its six corner positions, "both normals are non-zero"); its size class and slot.
+__global__ void __launch_bounds__(kBlock) k_tri_box(TriArrays T, const float4* __restrict__ pos, const float4* __restrict__ prev) {
+  __shared__ uint32_t sExt[kTriLevels], sCnt[kTriLevels];
+  if (threadIdx.x < kTriLevels) { sExt[threadIdx.x] = 0; sCnt[threadIdx.x] = 0; }
+  __syncthreads();
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  uint32_t slot = kNil;
+  int cls = -1;
+  uint32_t ext = 0;
+  if (t < T.nt) {
+    const uint32_t i0 = T.tris[3 * t], i1 = T.tris[3 * t + 1], i2 = T.tris[3 * t + 2];
+    const F3 b1 = xyz(pos[i0]), c1 = xyz(pos[i1]), d1 = xyz(pos[i2]);
+    const F3 b0 = xyz(prev[i0]), c0 = xyz(prev[i1]), d0 = xyz(prev[i2]);
+    const float pv[3][3] = {{b1.x, b1.y, b1.z}, {c1.x, c1.y, c1.z}, {d1.x, d1.y, d1.z}};
+    const float qv[3][3] = {{b0.x, b0.y, b0.z}, {c0.x, c0.y, c0.z}, {d0.x, d0.y, d0.z}};
+    float mn[3], mx[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 3; ++i) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      if (i == 0) { mx[k] = pv[i][k]; mn[k] = pv[i][k]; }
-      mx[k] = fmaxf(pv[i][k], mx[k]); mx[k] = fmaxf(qv[i][k], mx[k]);
-      mn[k] = fminf(pv[i][k], mn[k]); mn[k] = fminf(qv[i][k], mn[k]);
-    }
-  }
-  int m[3];
-  uint32_t len[3];
-  bool ok = true;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float f = floorf(mn[k]);
-    ok = ok && (fabsf(f) < 1.0e6f) && (fabsf(mx[k]) < 1.0e6f);
-    m[k] = ok ? static_cast<int>(f) : 0;
-    len[k] = ok ? static_cast<uint32_t>(ceilf(mx[k]) - static_cast<float>(static_cast<long long>(f))) : 0u;
-  }
-  if (!ok && member == 0) atomicOr(&T.counters[3], 32u);  // non-finite
-  if (!ok || len[0] > kTriInsertMaxCells || len[1] > kTriInsertMaxCells || len[2] > kTriInsertMaxCells)
-    len[0] = len[1] = len[2] = 0;  // the reference returns an empty range (Solver.cpp:974-976)
-  if (member == 0) {
-    T.rng[t] = make_int4(m[0], m[1], m[2], static_cast<int>(len[0] | (len[1] << 8) | (len[2] << 16)));
-    // the candidate record of this triangle for k_tri_detect: box of its six corner positions, "both normals are non-zero", node ids
-    const F3 nn0 = cross(c0 - b0, d0 - b0), nn1 = cross(c1 - b1, d1 - b1);
-    const bool regular = dot(nn0, nn0) > 0.0f && dot(nn1, nn1) > 0.0f;
-    T.box[3 * t] = make_float4(mn[0], mn[1], mn[2], regular ? 1.0f : 0.0f);
-    T.box[3 * t + 1] = make_float4(mx[0], mx[1], mx[2], __uint_as_float(i0));
-    T.box[3 * t + 2] = make_float4(__uint_as_float(i1), __uint_as_float(i2), 0.0f, 0.0f);
-  }
-  const uint32_t ncell = len[0] * len[1] * len[2], lyz = len[1] * len[2];
-  for (uint32_t e = member; e < ncell; e += TEAM) {
-    const uint32_t dx = e / lyz, r = e - dx * lyz, dy = r / len[2], dz = r - dy * len[2];
-    bool created;
-    const uint32_t s = insert_cell(T.keys, T.mask, pack_cell(m[0] + (int)dx, m[1] + (int)dy, m[2] + (int)dz), created);
-    if (e < kTriMaxEntries) T.triSlot[t * kTriMaxEntries + e] = s;
-    if (s == 0xffffffffu) { atomicOr(&T.counters[3], 2u); continue; }  // (a lane that leaves here takes no part in the round's ballot)
-    // the list of used cells: ONE append per wavefront and round for all the cells its lanes created (an atomic per cell on
-    // the one counter word was a third of this launch: atomics on one word take their turns).  The list is as long as the
-    // entry storage: more distinct cells than that is the "more entries than reserved" failure, never a write past it.
-    const unsigned long long makers = __ballot(created);
-    if (makers) {
-      const int leader = __builtin_ctzll(makers);
-      uint32_t base = 0;
-      if (static_cast<int>(threadIdx.x & 63u) == leader) base = atomicAdd(&T.counters[0], static_cast<uint32_t>(__popcll(makers)));
-      base = __shfl(base, leader, 64);
-      if (created) {
-        const uint32_t u = base + static_cast<uint32_t>(__popcll(makers & ((1ull << (threadIdx.x & 63u)) - 1ull)));
-        if (u < T.maxEntries) T.used[u] = s;
-        else atomicOr(&T.counters[3], 2u);
+      for (int k = 0; k < 3; ++k) {
+        if (i == 0) { mx[k] = pv[i][k]; mn[k] = pv[i][k]; }
+        mx[k] = fmaxf(pv[i][k], mx[k]); mx[k] = fmaxf(qv[i][k], mx[k]);
+        mn[k] = fminf(pv[i][k], mn[k]); mn[k] = fminf(qv[i][k], mn[k]);
       }
     }
-    atomicAdd(&T.cnt[s], 1u);
-  }
-}
-__global__ void __launch_bounds__(kBlock) k_tri_alloc(TriArrays T) {
-  const uint32_t used = min(T.counters[0], T.maxEntries);
-  const uint32_t lane = threadIdx.x & 63u;
-  for (uint32_t u0 = (blockIdx.x * kBlock + threadIdx.x) & ~63u; u0 < used; u0 += gridDim.x * kBlock) {  // (uniform per wavefront)
-    const uint32_t u = u0 + lane;
-    const bool live = u < used;
-    const uint32_t s = live ? T.used[u] : 0u;
-    const uint32_t c = live ? T.cnt[s] : 0u;
-    if (c > 1000u) atomicOr(&T.counters[3], 16u);  // Solver.cpp:751-755: a bucket of more than 1000 triangles fails the sim
-    // the wavefront's buckets take one stretch of the storage: one atomic per wavefront on the one counter word
-    uint32_t incl = c;
+    int m[3];
+    uint32_t len[3];
+    bool ok = true;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t t = __shfl_up(incl, off, 64);
-      if (lane >= static_cast<uint32_t>(off)) incl += t;
+    for (int k = 0; k < 3; ++k) {
+      const float f = floorf(mn[k]);
+      ok = ok && (fabsf(f) < 1.0e6f) && (fabsf(mx[k]) < 1.0e6f);
+      m[k] = ok ? static_cast<int>(f) : 0;
+      len[k] = ok ? static_cast<uint32_t>(ceilf(mx[k]) - static_cast<float>(static_cast<long long>(f))) : 0u;
     }
-    uint32_t base = 0;
-    if (lane == 63u) base = atomicAdd(&T.counters[1], incl);
-    base = __shfl(base, 63, 64);
-    if (!live) continue;
-    const uint32_t at = base + incl - c;
-    if (at + c > T.maxEntries) { atomicOr(&T.counters[3], 2u); T.cnt[s] = 0; }  // more (cell, triangle) entries than reserved
-    T.start[s] = at;
-    T.fill[s] = 0;
+    if (!ok) atomicOr(&T.counters[3], 32u);  // non-finite
+    if (!ok || len[0] > kTriInsertMaxCells || len[1] > kTriInsertMaxCells || len[2] > kTriInsertMaxCells)
+      len[0] = len[1] = len[2] = 0;  // the reference returns an empty range (Solver.cpp:974-976)
+    T.rng[t] = make_int4(m[0], m[1], m[2], static_cast<int>(len[0] | (len[1] << 8) | (len[2] << 16)));
+    const F3 nn0 = cross(c0 - b0, d0 - b0), nn1 = cross(c1 - b1, d1 - b1);
+    const bool regular = dot(nn0, nn0) > 0.0f && dot(nn1, nn1) > 0.0f;
+    T.boxOf[4 * t] = make_float4(mn[0], mn[1], mn[2], __uint_as_float(t));
+    T.boxOf[4 * t + 1] = make_float4(mx[0], mx[1], mx[2], regular ? 1.0f : 0.0f);
+    T.boxOf[4 * t + 2] = make_float4(__int_as_float(m[0]), __int_as_float(m[1]), __int_as_float(m[2]), __uint_as_float(len[0] | (len[1] << 8) | (len[2] << 16)));
+    T.boxOf[4 * t + 3] = make_float4(__uint_as_float(i0), __uint_as_float(i1), __uint_as_float(i2), 0.0f);
+    T.head[t] = kNil;
+    if (len[0] * len[1] * len[2] != 0u) {
+      int k = 0;
+#pragma unroll
+      for (int l = kTriLevels - 1; l >= 0; --l) {  // the finest class whose cells the range spans at most kTriLevelExt of per axis
+        const uint32_t sh = T.level[l].shift;
+        const uint32_t e = max(max(level_extent(m[0], len[0], sh), level_extent(m[1], len[1], sh)), level_extent(m[2], len[2], sh));
+        if (l == kTriLevels - 1 || e <= kTriLevelExt) { k = l; ext = e; }
+      }
+      cls = k;
+      const uint32_t sh = T.level[k].shift;
+      slot = grid_slot(T.level[k], m[0] >> sh, m[1] >> sh, m[2] >> sh);
+      T.posIn[t] = atomicAdd(&T.cellCnt[slot], 1u);
+    }
+    T.cellOf[t] = slot;
+  }
+  if (blockIdx.x == 0 && (threadIdx.x == 0 || (threadIdx.x >= 4 && threadIdx.x <= 8))) T.counters[threadIdx.x] = 0;
+  // the tiles' sums for the prefix sum over the slots: the triangles of a wavefront are neighbours, so their slots lie in a few
+  // tiles - one atomic per wavefront and tile
+  for (unsigned long long todo = __ballot(slot != kNil); todo;) {
+    const uint32_t tile = __shfl(slot, __builtin_ctzll(todo), 64) / kGridTile;
+    const unsigned long long same = __ballot(slot != kNil && slot / kGridTile == tile);
+    if ((threadIdx.x & 63u) == static_cast<uint32_t>(__builtin_ctzll(same))) atomicAdd(&T.tileSum[tile], static_cast<uint32_t>(__popcll(same)));
+    todo &= ~same;
+  }
+  // the classes' statistics: per wavefront a count per class and - only while it still raises it - the longest range
+#pragma unroll
+  for (int k = 0; k < kTriLevels; ++k) {
+    const unsigned long long in = __ballot(cls == k);
+    if (in == 0ull) continue;
+    if ((threadIdx.x & 63u) == static_cast<uint32_t>(__builtin_ctzll(in))) atomicAdd(&sCnt[k], static_cast<uint32_t>(__popcll(in)));
+    if (cls == k && sExt[k] < ext) atomicMax(&sExt[k], ext);
+  }
+  __syncthreads();
+  if (threadIdx.x < kTriLevels && sCnt[threadIdx.x]) {
+    atomicMax(&T.counters[10 + threadIdx.x], sExt[threadIdx.x]);
+    atomicAdd(&T.counters[13 + threadIdx.x], sCnt[threadIdx.x]);
   }
 }
-__global__ void __launch_bounds__(kBlock) k_tri_fill(TriArrays T) {  // kTriTeam lanes per triangle, like k_tri_count
-  const uint32_t t = (blockIdx.x * kBlock + threadIdx.x) / kTriTeam, member = threadIdx.x % kTriTeam;
+// first entry of every slot = the exclusive prefix sum of the slots' counts, in slot order, so that the slots of a row of cells
+// (consecutive z) have their entries in one stretch.  The sums of tiles of kGridTile slots come from k_tri_box; every tile adds up
+// the sums before it and scans its own slots.
+__global__ void __launch_bounds__(kBlock) k_tri_starts(TriArrays T) {
+  __shared__ uint32_t red[kBlock / 64], wsum[kBlock / 64];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t before = 0;
+  for (uint32_t b = threadIdx.x; b < blockIdx.x; b += kBlock) before += T.tileSum[b];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) before += __shfl_xor(before, off, 64);
+  if (lane == 0u) red[wave] = before;
+  // this thread's 8 consecutive slots
+  const size_t first = static_cast<size_t>(kGridTile) * blockIdx.x + 8u * threadIdx.x;
+  const uint4 a = *reinterpret_cast<const uint4*>(T.cellCnt + first), b = *reinterpret_cast<const uint4*>(T.cellCnt + first + 4);
+  const uint32_t mine = (a.x + a.y) + (a.z + a.w) + (b.x + b.y) + (b.z + b.w);
+  uint32_t incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t v = __shfl_up(incl, off, 64);
+    if (lane >= static_cast<uint32_t>(off)) incl += v;
+  }
+  if (lane == 63u) wsum[wave] = incl;
+  __syncthreads();
+  uint32_t run = (red[0] + red[1]) + (red[2] + red[3]);
+  for (uint32_t w = 0; w < wave; ++w) run += wsum[w];
+  run += incl - mine;
+  uint4 oa, ob;
+  oa.x = run; oa.y = oa.x + a.x; oa.z = oa.y + a.y; oa.w = oa.z + a.z;
+  ob.x = oa.w + a.w; ob.y = ob.x + b.x; ob.z = ob.y + b.y; ob.w = ob.z + b.z;
+  *reinterpret_cast<uint4*>(T.cellStart + first) = oa;
+  *reinterpret_cast<uint4*>(T.cellStart + first + 4) = ob;
+  if (blockIdx.x == gridDim.x - 1u && threadIdx.x == kBlock - 1u) T.cellStart[T.slots] = ob.w + b.w;
+}
+__global__ void __launch_bounds__(kBlock) k_tri_fill(TriArrays T) {
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= T.nt) return;
-  const int4 rg = T.rng[t];
-  const uint32_t lx = rg.w & 0xff, ly = (rg.w >> 8) & 0xff, lz = (rg.w >> 16) & 0xff;
-  const uint32_t ncell = lx * ly * lz, lyz = ly * lz;
-  for (uint32_t e = member; e < ncell; e += kTriTeam) {
-    uint32_t s;
-    if (e < kTriMaxEntries) s = T.triSlot[t * kTriMaxEntries + e];
-    else {
-      const uint32_t dx = e / lyz, r = e - dx * lyz, dy = r / lz, dz = r - dy * lz;
-      s = find_cell(T.keys, T.mask, pack_cell(rg.x + (int)dx, rg.y + (int)dy, rg.z + (int)dz));
-    }
-    if (s == 0xffffffffu) continue;
-    const uint32_t k = atomicAdd(&T.fill[s], 1u);
-    if (k < T.cnt[s]) T.bucket[T.start[s] + k] = t;  // cnt was zeroed for a bucket beyond the reserved storage
-  }
-}
-__global__ void __launch_bounds__(kBlock) k_tri_sort(TriArrays T) {
-  if (T.counters[3]) return;
-  const uint32_t used = min(T.counters[0], T.maxEntries);
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
-  for (uint32_t u = wave; u < used; u += nwaves) {
-    const uint32_t s = T.used[u];
-    rank_sort(T.bucket, T.bucketSorted, T.start[s], T.cnt[s], lane);
-  }
+  const uint32_t s = T.cellOf[t];
+  if (s == kNil) return;
+  const uint32_t at = T.cellStart[s] + T.posIn[t];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) T.ent[4 * at + i] = T.boxOf[4 * t + i];
 }
 
 // Position of triangle t in the reference's merge order: thread (t mod T) owns triangles t, t + T, ... and the
@@ -293,155 +310,331 @@ PIES_DEV uint32_t merge_rank(uint32_t t, uint32_t nt, uint32_t threads) {
   return th * q + min(th, rem) + t / threads;
 }
 
-// ---- detection (Solver.cpp:714-797).  TEAM lanes share a triangle's candidates.  FILL = false counts its contacts (the
-// count does not depend on the order); FILL = true writes them in the reference's order (a prefix sum over the team's lanes
-// per TEAM candidates), only for the triangles that have any.
-// The reference walks the cells of the triangle's range one after the other and each cell's bucket entry by entry.  Here
-// the team looks up TEAM cells at once (a lane per cell: its slot - cached by k_tri_count - and the bucket's start and
-// length), forms the running offsets of the TEAM buckets and then walks their entries as ONE list, TEAM at a time - the same
-// candidates in the same order, but a round of dependent loads (slot, bucket, entry, triangle, nodes) per TEAM cells instead
-// of per cell: a moving triangle spans 18-27 cells, and one cell at a time made this kernel 60 us of a 640 us substep. -----
-template <bool FILL, int TEAM>
-__global__ void __launch_bounds__(kBlock) k_tri_detect(TriArrays T, const float4* __restrict__ pos, const float4* __restrict__ prev,
-                                                       float threshold) {
+struct CellBox {  // a range of world cells [lo, hi) per axis
+  int x0, y0, z0, x1, y1, z1;
+};
+PIES_DEV CellBox range_box(const int4& r, uint32_t lx, uint32_t ly, uint32_t lz) {
+  return {r.x, r.y, r.z, r.x + static_cast<int>(lx), r.y + static_cast<int>(ly), r.z + static_cast<int>(lz)};
+}
+PIES_DEV int4 ent_range(const float4& e) { return make_int4(__float_as_int(e.x), __float_as_int(e.y), __float_as_int(e.z), __float_as_int(e.w)); }
+PIES_DEV CellBox insert_box(const int4& r) { return range_box(r, r.w & 0xff, (r.w >> 8) & 0xff, (r.w >> 16) & 0xff); }
+PIES_DEV CellBox meet(const CellBox& a, const CellBox& b) {
+  return {max(a.x0, b.x0), max(a.y0, b.y0), max(a.z0, b.z0), min(a.x1, b.x1), min(a.y1, b.y1), min(a.z1, b.z1)};
+}
+PIES_DEV bool empty(const CellBox& b) { return b.x1 <= b.x0 || b.y1 <= b.y0 || b.z1 <= b.z0; }
+PIES_DEV uint32_t volume(const CellBox& b) { return static_cast<uint32_t>((b.x1 - b.x0) * (b.y1 - b.y0) * (b.z1 - b.z0)); }
+PIES_DEV bool holds(const CellBox& b, int x, int y, int z) { return x >= b.x0 && x < b.x1 && y >= b.y0 && y < b.y1 && z >= b.z0 && z < b.z1; }
+// cells of the (non-empty) box b that come before cell (x, y, z) when a range is walked x-major (dx, dy, dz: Solver.cpp:722-724)
+PIES_DEV uint32_t cells_before(const CellBox& b, int x, int y, int z) {
+  const int nx = b.x1 - b.x0, ny = b.y1 - b.y0, nz = b.z1 - b.z0;
+  int n = min(max(x - b.x0, 0), nx) * ny * nz;
+  if (x >= b.x0 && x < b.x1) {
+    n += min(max(y - b.y0, 0), ny) * nz;
+    if (y >= b.y0 && y < b.y1) n += min(max(z - b.z0, 0), nz);
+  }
+  return static_cast<uint32_t>(n);
+}
+
+// the window of class L a partner of a triangle with range box S can be listed in: its minimum corner lies in S grown downwards
+// by (the longest range listed in the class - 1) cells of the class
+struct Window {
+  int x0, y0, z0;
+  uint32_t wx, wy, wz;
+};
+PIES_DEV Window window_of(const CellBox& S, uint32_t shift, uint32_t longest) {
+  Window w;
+  const int grow = static_cast<int>(longest) - 1;
+  w.x0 = (S.x0 >> shift) - grow; w.y0 = (S.y0 >> shift) - grow; w.z0 = (S.z0 >> shift) - grow;
+  w.wx = static_cast<uint32_t>(((S.x1 - 1) >> shift) - w.x0 + 1);
+  w.wy = static_cast<uint32_t>(((S.y1 - 1) >> shift) - w.y0 + 1);
+  w.wz = static_cast<uint32_t>(((S.z1 - 1) >> shift) - w.z0 + 1);
+  return w;
+}
+
+// The entries of one row of a window - the cells (x, y, z0 .. z0 + wz) of a class - are one stretch of the entry list, or two
+// when the row runs past the end of the table's z axis and goes on at its start.
+struct RowRun {
+  uint32_t s1, c1, s2, c2;
+};
+PIES_DEV RowRun row_run(const TriArrays& T, const TriGridLevel& L, int x, int y, int z0, uint32_t wz) {
+  const uint32_t ux = static_cast<uint32_t>(x) & ((1u << L.lx) - 1u), uy = static_cast<uint32_t>(y) & ((1u << L.ly) - 1u);
+  const uint32_t nz = 1u << L.lz, uz = static_cast<uint32_t>(z0) & (nz - 1u);
+  const uint32_t row = L.base + (((ux << L.ly) | uy) << L.lz);
+  RowRun r;
+  r.s1 = T.cellStart[row + uz];
+  if (uz + wz <= nz) {
+    r.c1 = T.cellStart[row + uz + wz] - r.s1;
+    r.s2 = 0; r.c2 = 0;
+  } else {
+    r.c1 = T.cellStart[row + nz] - r.s1;
+    r.s2 = T.cellStart[row];
+    r.c2 = T.cellStart[row + (uz + wz - nz)] - r.s2;
+  }
+  return r;
+}
+
+// Solver.cpp:751-755 - a bucket of more than 1000 triangles fails the sim - for a triangle whose windows list more than 1000
+// triangles (otherwise no cell of its range can be in that many ranges): the exact number of ranges every cell of its range lies
+// in.  Rare (a collapsed mesh) and slow: per cell of the range, every listed triangle of the windows.
+template <int TEAM>
+PIES_DEV bool crowded_cell(const TriArrays& T, const CellBox& S, uint32_t member) {
+  for (int x = S.x0; x < S.x1; ++x)
+    for (int y = S.y0; y < S.y1; ++y)
+      for (int z = S.z0; z < S.z1; ++z) {
+        uint32_t cover = 0;
+        for (int k = 0; k < kTriLevels; ++k) {
+          if (T.counters[13 + k] == 0u) continue;
+          const Window W = window_of(S, T.level[k].shift, T.counters[10 + k]);
+          const uint32_t rows = W.wx * W.wy;
+          for (uint32_t w = member; w < rows; w += TEAM) {
+            const uint32_t dx = w / W.wy, dy = w - dx * W.wy;
+            const RowRun r = row_run(T, T.level[k], W.x0 + (int)dx, W.y0 + (int)dy, W.z0, W.wz);
+            for (uint32_t e = 0; e < r.c1 + r.c2; ++e) {
+              const uint32_t at = e < r.c1 ? r.s1 + e : r.s2 + (e - r.c1);
+              if (holds(insert_box(ent_range(T.ent[4 * at + 2])), x, y, z)) ++cover;
+            }
+          }
+        }
+#pragma unroll
+        for (int off = TEAM / 2; off >= 1; off >>= 1) cover += __shfl_xor(cover, off, TEAM);
+        if (cover > 1000u) return true;
+        if (T.counters[3]) return false;  // somebody else has failed the sim already
+      }
+  return false;
+}
+
+// ---- detection (Solver.cpp:714-797).  The reference walks the cells of a triangle's range and tests every triangle listed
+// there without a common node, corner by corner; a pair that shares c cells is tested c times with the same result.  Two launches:
+//
+// k_tri_pairs  TEAM lanes share a triangle.  The team walks the windows of the three size classes row by row, TEAM rows at a time
+//              (a lane per row: where its entries are and how many), forms the running offsets and walks the rows' entries as ONE
+//              list, TEAM at a time; a partner is met once: its box - in the entry - against the box of the triangle's three
+//              swept corners first (most partners of a window end here), then the ranges' intersection (none: the reference
+//              never pairs them), the common nodes, the corners one by one.  What is left - a pair and the corners to test - goes
+//              into the work list.  Nothing here is heavy (with the CCD inlined the kernel held 192 registers - two wavefronts per
+//              SIMD - and took 43 us of a 470 us substep; 20 us now, the CCD's launch 8 on top of its floor).
+// k_tri_ccd    one lane per entry of the work list: the CCD of the listed corners (Solver.cpp:775-797); a pair with hits goes
+//              into the pool of hit records {triangle, partner, corners}, chained per triangle, and adds (hits x shared cells)
+//              to the triangle's contacts (cntTri).  k_tri_emit writes the list from the records.
+constexpr uint32_t kPairStage = 1024;  // pairs a workgroup (16 triangles) collects in LDS; a triangle of a moving lattice leaves ~15
+// The work list is kWorkShards lists with a counter each, 64 bytes apart (workCnt[16 s]): atomics on ONE word take their turns at
+// ~9 ns each on this chip (measured: 29 000 of them made a 10 us kernel a 260 us one), and so do the loads of its neighbours in
+// the line; a workgroup appends to the list of its index modulo kWorkShards.
+PIES_DEV uint32_t shard_capacity(const TriArrays& T) { return T.maxWork / kWorkShards; }
+PIES_DEV void work_append(const TriArrays& T, uint32_t shard, uint2 item) {
+  const uint32_t at = atomicAdd(&T.workCnt[16u * shard], 1u);
+  if (at < shard_capacity(T)) T.work[shard * shard_capacity(T) + at] = item;
+  else atomicOr(&T.counters[3], 64u);
+}
+template <int TEAM>
+__global__ void __launch_bounds__(kBlock) k_tri_pairs(TriArrays T, const float4* __restrict__ pos, const float4* __restrict__ prev, float threshold) {
+  // the workgroup's part of the work list is collected in LDS and appended at the end: one atomic per workgroup on the list's
+  // counter (an append per wavefront and round of candidates put 200 000 atomics on that one word: 370 us)
+  __shared__ uint2 sWork[kPairStage];
+  __shared__ uint32_t sCount, sBase;
+  if (threadIdx.x == 0) sCount = 0;
+  __syncthreads();
   const uint32_t t = (blockIdx.x * kBlock + threadIdx.x) / TEAM, member = threadIdx.x % TEAM;
-  if (t >= T.nt || T.counters[3]) return;  // a team lies inside one wavefront and leaves as a whole
-  const uint32_t rank = merge_rank(t, T.nt, T.threadCount);
-  if (FILL && T.cntTri[rank] == 0u) return;  // nothing to write: the usual case
+  bool search = t < T.nt && T.counters[3] == 0u;  // a team lies inside one wavefront and stays together
+  int4 rg = make_int4(0, 0, 0, 0);
+  uint32_t lx = 0, ly = 0, lz = 0;
+  if (search) {
+    if (member == 0) T.cntTri[merge_rank(t, T.nt, T.threadCount)] = 0;
+    rg = T.rng[t];
+    lx = rg.w & 0xff; ly = (rg.w >> 8) & 0xff; lz = (rg.w >> 16) & 0xff;
+    if (lx > kTriSearchMaxCells || ly > kTriSearchMaxCells || lz > kTriSearchMaxCells) lx = ly = lz = 0;  // sweptTriRange: empty (Solver.cpp:672-674)
+    const uint32_t ncell = lx * ly * lz;
+    if (ncell == 0u || ncell > 1000u) {
+      // Solver.cpp:741-745: more than 1000 buckets in a range fails the sim - every cell of a searching triangle's range has a
+      // bucket, the triangle's own entry
+      if (ncell && member == 0) atomicOr(&T.counters[3], 16u);
+      search = false;
+    }
+  }
+  if (search) {
+  const CellBox S = range_box(rg, lx, ly, lz);
   const uint32_t ia[3] = {T.tris[3 * t], T.tris[3 * t + 1], T.tris[3 * t + 2]};
-  F3 a1[3], a0[3];
+  F3 slo[3], shi[3];  // the corners' swept segments as boxes
 #pragma unroll
-  for (int i = 0; i < 3; ++i) { a1[i] = xyz(pos[ia[i]]); a0[i] = xyz(prev[ia[i]]); }
-  const int4 rg = T.rng[t];
-  uint32_t lx = rg.w & 0xff, ly = (rg.w >> 8) & 0xff, lz = (rg.w >> 16) & 0xff;
-  if (lx > kTriSearchMaxCells || ly > kTriSearchMaxCells || lz > kTriSearchMaxCells) lx = ly = lz = 0;  // sweptTriRange: empty (Solver.cpp:672-674)
-  uint32_t count = 0, nonEmpty = 0;
-  const uint32_t base = FILL ? T.offTri[rank] : 0u;
-  const uint32_t ncell = lx * ly * lz, lyz = ly * lz;
-  for (uint32_t e0 = 0; e0 < ncell; e0 += TEAM) {
-    // this lane's cell of the round: slot, bucket start and length
-    const uint32_t e = e0 + member;
-    uint32_t bs = 0, bc = 0;
-    bool found = false;
-    if (e < ncell) {
-      uint32_t s;
-      if (e < kTriMaxEntries) s = T.triSlot[t * kTriMaxEntries + e];  // (the search range is the range the triangle was inserted with)
-      else {
-        const uint32_t dx = e / lyz, r = e - dx * lyz, dy = r / lz, dz = r - dy * lz;
-        s = find_cell(T.keys, T.mask, pack_cell(rg.x + (int)dx, rg.y + (int)dy, rg.z + (int)dz));
+  for (int i = 0; i < 3; ++i) {
+    const F3 p1 = xyz(pos[ia[i]]), p0 = xyz(prev[ia[i]]);
+    slo[i] = {fminf(p0.x, p1.x), fminf(p0.y, p1.y), fminf(p0.z, p1.z)};
+    shi[i] = {fmaxf(p0.x, p1.x), fmaxf(p0.y, p1.y), fmaxf(p0.z, p1.z)};
+  }
+  const F3 tlo = {fminf(fminf(slo[0].x, slo[1].x), slo[2].x), fminf(fminf(slo[0].y, slo[1].y), slo[2].y), fminf(fminf(slo[0].z, slo[1].z), slo[2].z)};
+  const F3 thi = {fmaxf(fmaxf(shi[0].x, shi[1].x), shi[2].x), fmaxf(fmaxf(shi[0].y, shi[1].y), shi[2].y), fmaxf(fmaxf(shi[0].z, shi[1].z), shi[2].z)};
+  uint32_t listed = 0;
+  for (int k = 0; k < kTriLevels; ++k) {
+    if (T.counters[13 + k] == 0u) continue;
+    const TriGridLevel L = T.level[k];
+    const Window W = window_of(S, L.shift, T.counters[10 + k]);
+    const uint32_t rows = W.wx * W.wy;
+    const float invWy = 1.0f / static_cast<float>(W.wy);
+    for (uint32_t w0 = 0; w0 < rows; w0 += TEAM) {
+      // this lane's row of the round
+      const uint32_t w = w0 + member;
+      RowRun run = {0u, 0u, 0u, 0u};
+      if (w < rows) {
+        const uint32_t dx = static_cast<uint32_t>((static_cast<float>(w) + 0.5f) * invWy), dy = w - dx * W.wy;  // (rows < 2^10: exact)
+        run = row_run(T, L, W.x0 + (int)dx, W.y0 + (int)dy, W.z0, W.wz);
       }
-      if (s != 0xffffffffu) { found = true; bs = T.start[s]; bc = T.cnt[s]; }
-    }
-    if (!FILL) {  // Solver.cpp:741-745: more than 1000 buckets in a range fails the sim
-      uint32_t f = found ? 1u : 0u;
+      const uint32_t bc = run.c1 + run.c2;
+      // offsets of the round's rows in the round's candidate list
+      uint32_t incl = bc;
 #pragma unroll
-      for (int off = TEAM / 2; off >= 1; off >>= 1) f += __shfl_xor(f, off, TEAM);
-      nonEmpty += f;
-      if (nonEmpty > 1000u && member == 0) atomicOr(&T.counters[3], 16u);
-    }
-    // offsets of the round's buckets in the round's candidate list
-    uint32_t incl = bc;
-#pragma unroll
-    for (int off = 1; off < TEAM; off <<= 1) {
-      const uint32_t below = __shfl_up(incl, off, TEAM);
-      if (static_cast<int>(member) >= off) incl += below;
-    }
-    const uint32_t pre = incl - bc, total = __shfl(incl, TEAM - 1, TEAM);
-    for (uint32_t k0 = 0; k0 < total; k0 += TEAM) {  // (total is the team's: its lanes stay together)
-      const uint32_t k = k0 + member;
-      // where candidate k sits in bucketSorted: its bucket is the last one of the round whose offset is <= k (empty buckets
-      // share their offset with the next one, so "the last" is never one of them): a binary search over the team's lanes
-      // (every lane takes part in every shuffle - a lane past the end of the list searches too and drops the result)
-      uint32_t l = 0;
-#pragma unroll
-      for (int step = TEAM / 2; step >= 1; step >>= 1) {
-        const uint32_t pm = __shfl(pre, static_cast<int>(l) + step, TEAM);
-        if (pm <= k) l += static_cast<uint32_t>(step);
+      for (int off = 1; off < TEAM; off <<= 1) {
+        const uint32_t below = __shfl_up(incl, off, TEAM);
+        if (static_cast<int>(member) >= off) incl += below;
       }
-      const uint32_t sl = __shfl(bs, static_cast<int>(l), TEAM), pl = __shfl(pre, static_cast<int>(l), TEAM);
-      const uint32_t at = k < total ? sl + (k - pl) : 0xffffffffu;
-      bool hit[3] = {false, false, false};
-      uint32_t ib = 0, ic = 0, idd = 0;
-      uint32_t times = 1;  // counting pass: in how many cells the two triangles meet
-      bool visit = at != 0xffffffffu;
-      if (!FILL && visit) {
-        // The reference tests a candidate once per cell both triangles were inserted into (every hit is listed that often).
-        // The test gives the same answer every time, so the counting pass takes the pair in ONE of those cells - the minimum
-        // corner of what the two ranges share - and multiplies; the other visits end at the candidate's range.  (A moving
-        // triangle of a 100k-particle beam meets ~700 candidates of which ~60 are distinct.)
-        const uint32_t o = T.bucketSorted[at];
-        const int4 ro = T.rng[o];
-        const uint32_t e = e0 + l, dx = e / lyz, r = e - dx * lyz, dy = r / lz, dz = r - dy * lz;
-        const int cx = rg.x + static_cast<int>(dx), cy = rg.y + static_cast<int>(dy), cz = rg.z + static_cast<int>(dz);
-        visit = cx == max(rg.x, ro.x) && cy == max(rg.y, ro.y) && cz == max(rg.z, ro.z);
-        const int ox = min(rg.x + static_cast<int>(lx), ro.x + (ro.w & 0xff)) - max(rg.x, ro.x);
-        const int oy = min(rg.y + static_cast<int>(ly), ro.y + ((ro.w >> 8) & 0xff)) - max(rg.y, ro.y);
-        const int oz = min(rg.z + static_cast<int>(lz), ro.z + ((ro.w >> 16) & 0xff)) - max(rg.z, ro.z);
-        times = static_cast<uint32_t>(ox * oy * oz);
-      }
-      if (visit) {
-        const uint32_t o = T.bucketSorted[at];
-        const float4 r0 = T.box[3 * o], r1 = T.box[3 * o + 1], r2 = T.box[3 * o + 2];  // k_tri_count's record of the candidate
-        ib = __float_as_uint(r1.w); ic = __float_as_uint(r2.x); idd = __float_as_uint(r2.y);
-        bool common = false;
+      const uint32_t pre = incl - bc, total = __shfl(incl, TEAM - 1, TEAM);
+      listed += total;
+      for (uint32_t k0 = 0; k0 < total; k0 += TEAM) {  // (total is the team's: its lanes stay together)
+        const uint32_t kk = k0 + member;
+        // where candidate kk sits: its row is the last one of the round whose offset is <= kk (empty rows share their
+        // offset with the next one, so "the last" is never one of them): a binary search over the team's lanes (every
+        // lane takes part in every shuffle - a lane past the end of the list searches too and drops the result)
+        uint32_t l = 0;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) common = common || ia[i] == ib || ia[i] == ic || ia[i] == idd;
-        if (!common) {
-          // Conservative reject before the CCD.  A hit puts the point, at some time in [0,1], within `threshold` of a
-          // point of the moving triangle (proximity branch: at t = 1; crossing branch: on it at the root), so the
-          // point's swept segment must meet the box of the triangle's six corner positions grown by the threshold;
-          // the margin adds 5 % and 1e-3 of the box on top of that, orders of magnitude above the rounding of the
-          // barycentric test.  A triangle with a vanishing normal (NaN inside the CCD, which then cannot say
-          // "outside") is never rejected here, nor is anything non-finite: every comparison below is false for NaN.
-          // Box and normals come with the candidate's record: its six corner positions are only fetched for a point that
-          // is not rejected (until round 3 every candidate cost six gathers: 47 of this kernel's 60 us).
-          const bool regular = r0.w != 0.0f;
-          const F3 lo = {r0.x, r0.y, r0.z}, hi = {r1.x, r1.y, r1.z};
+        for (int step = TEAM / 2; step >= 1; step >>= 1) {
+          const uint32_t pm = __shfl(pre, static_cast<int>(l) + step, TEAM);
+          if (pm <= kk) l += static_cast<uint32_t>(step);
+        }
+        const uint32_t pl = __shfl(pre, static_cast<int>(l), TEAM);
+        const uint32_t rs1 = __shfl(run.s1, static_cast<int>(l), TEAM), rc1 = __shfl(run.c1, static_cast<int>(l), TEAM), rs2 = __shfl(run.s2, static_cast<int>(l), TEAM);
+        uint32_t o = 0, tests = 0;
+        if (kk < total) {
+          const uint32_t at = kk - pl < rc1 ? rs1 + (kk - pl) : rs2 + (kk - pl - rc1);
+          const float4 e0 = T.ent[4 * at], e1 = T.ent[4 * at + 1], e2 = T.ent[4 * at + 2], e3 = T.ent[4 * at + 3];  // (all four at once: no load waits for another)
+          // Conservative reject before anything else.  A hit puts a corner, at some time in [0,1], within `threshold` of a
+          // point of the moving partner (proximity branch: at t = 1; crossing branch: on it at the root), so the corner's
+          // swept segment must meet the box of the partner's six corner positions grown by the threshold; the margin adds 5 %
+          // and 1e-3 of the box on top of that, orders of magnitude above the rounding of the barycentric test.  First all
+          // three segments at once (their common box), then one by one.  A partner with a vanishing normal (NaN inside the
+          // CCD, which then cannot say "outside") is never rejected here, nor is anything non-finite: every comparison below
+          // is false for NaN.
+          const bool regular = e1.w != 0.0f;
+          const F3 lo = {e0.x, e0.y, e0.z}, hi = {e1.x, e1.y, e1.z};
           const float margin = 1.05f * threshold + 1.0e-3f * fmaxf(fmaxf(hi.x - lo.x, hi.y - lo.y), hi.z - lo.z);
-          bool test[3];
+          const bool apartAll = (thi.x < lo.x - margin) || (tlo.x > hi.x + margin) || (thi.y < lo.y - margin) || (tlo.y > hi.y + margin) ||
+                                (thi.z < lo.z - margin) || (tlo.z > hi.z + margin);
+          if (!(regular && apartAll)) {
+            o = __float_as_uint(e0.w);
+            if (!empty(meet(S, insert_box(ent_range(e2))))) {  // (no cell lists both: the reference never sees the pair)
+              const uint32_t ib = __float_as_uint(e3.x), ic = __float_as_uint(e3.y), idd = __float_as_uint(e3.z);
+              bool common = false;
 #pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            const bool apart = (fmaxf(a0[i].x, a1[i].x) < lo.x - margin) || (fminf(a0[i].x, a1[i].x) > hi.x + margin) ||
-                               (fmaxf(a0[i].y, a1[i].y) < lo.y - margin) || (fminf(a0[i].y, a1[i].y) > hi.y + margin) ||
-                               (fmaxf(a0[i].z, a1[i].z) < lo.z - margin) || (fminf(a0[i].z, a1[i].z) > hi.z + margin);
-            test[i] = !(regular && apart);
-          }
-          if (test[0] || test[1] || test[2]) {
-            const F3 b1 = xyz(pos[ib]), c1 = xyz(pos[ic]), d1 = xyz(pos[idd]);
-            const F3 b0 = xyz(prev[ib]), c0 = xyz(prev[ic]), d0 = xyz(prev[idd]);
+              for (int i = 0; i < 3; ++i) common = common || ia[i] == ib || ia[i] == ic || ia[i] == idd;
+              if (!common) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-              if (test[i]) hit[i] = point_triangle_ccd(a0[i] - b0, c0 - b0, d0 - b0, a1[i] - b1, c1 - b1, d1 - b1, threshold);
+                for (int i = 0; i < 3; ++i) {
+                  const bool apart = (shi[i].x < lo.x - margin) || (slo[i].x > hi.x + margin) || (shi[i].y < lo.y - margin) || (slo[i].y > hi.y + margin) ||
+                                     (shi[i].z < lo.z - margin) || (slo[i].z > hi.z + margin);
+                  if (!(regular && apart)) tests |= 1u << i;
+                }
+              }
+            }
           }
         }
-      }
-      const uint32_t mine = ((hit[0] ? 1u : 0u) + (hit[1] ? 1u : 0u) + (hit[2] ? 1u : 0u)) * times;
-      if (FILL) {
-        // the reference's list order: bucket entry after bucket entry, for each the triangle's corners 0, 1, 2 - the
-        // team's lanes hold TEAM consecutive candidates, so a lane writes behind the hits of the lanes below it
-        uint32_t inc2 = mine;
-#pragma unroll
-        for (int off = 1; off < TEAM; off <<= 1) {
-          const uint32_t below = __shfl_up(inc2, off, TEAM);
-          if (static_cast<int>(member) >= off) inc2 += below;
-        }
-        uint32_t c = base + count + (inc2 - mine);
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-          if (hit[i]) {
-            if (c < T.maxContacts) T.ids[c] = make_uint4(ia[i], ib, ic, idd);
-            ++c;
+        // the pairs that are left: one LDS append per wavefront for those of its lanes
+        const unsigned long long keep = __ballot(tests != 0u);
+        if (keep) {
+          const int leader = __builtin_ctzll(keep);
+          uint32_t base = 0;
+          if (static_cast<int>(threadIdx.x & 63u) == leader) base = atomicAdd(&sCount, static_cast<uint32_t>(__popcll(keep)));
+          base = __shfl(base, leader, 64);
+          if (tests) {
+            const uint32_t at = base + static_cast<uint32_t>(__popcll(keep & ((1ull << (threadIdx.x & 63u)) - 1ull)));
+            const uint2 item = make_uint2(t, o | (tests << 29));
+            if (at < kPairStage) sWork[at] = item;
+            else work_append(T, blockIdx.x % kWorkShards, item);  // (more than the stage holds: straight to the list)
           }
-        count += __shfl(inc2, TEAM - 1, TEAM);  // the team's running total (the same in all its lanes)
-      } else {
-        count += mine;
+        }
       }
     }
   }
-  if (!FILL) {
+  // Solver.cpp:751-755 (a bucket of more than 1000 triangles): the triangles whose ranges hold a cell are all listed in the windows
+  if (listed > 1000u && crowded_cell<TEAM>(T, S, member) && member == 0) atomicOr(&T.counters[3], 16u);
+  }
+  __syncthreads();
+  const uint32_t staged = min(sCount, kPairStage);
+  const uint32_t shard = blockIdx.x % kWorkShards;
+  if (threadIdx.x == 0 && staged) sBase = atomicAdd(&T.workCnt[16u * shard], staged);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < staged; i += kBlock) {
+    if (sBase + i < shard_capacity(T)) T.work[shard * shard_capacity(T) + sBase + i] = sWork[i];
+    else atomicOr(&T.counters[3], 64u);  // (a mesh folded onto itself: as fatal as the contact list it would overflow)
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_tri_ccd(TriArrays T, const float4* __restrict__ pos, const float4* __restrict__ prev, float threshold) {
+  if (T.counters[3]) return;
+  // workgroup b works on list b % kWorkShards, with the other workgroups of that list
+  const uint32_t shard = blockIdx.x % kWorkShards, cap = shard_capacity(T);
+  const uint32_t n = min(T.workCnt[16u * shard], cap);
+  for (uint32_t w = (blockIdx.x / kWorkShards) * kBlock + threadIdx.x; w < n; w += (gridDim.x / kWorkShards) * kBlock) {
+    const uint2 item = T.work[shard * cap + w];
+    const uint32_t t = item.x, o = item.y & 0x1fffffffu, tests = item.y >> 29;
+    const uint32_t ia[3] = {T.tris[3 * t], T.tris[3 * t + 1], T.tris[3 * t + 2]};
+    const uint32_t ib = T.tris[3 * o], ic = T.tris[3 * o + 1], idd = T.tris[3 * o + 2];
+    const F3 b1 = xyz(pos[ib]), c1 = xyz(pos[ic]), d1 = xyz(pos[idd]);
+    const F3 b0 = xyz(prev[ib]), c0 = xyz(prev[ic]), d0 = xyz(prev[idd]);
+    uint32_t hits = 0;
+    for (int i = 0; i < 3; ++i) {  // (not unrolled: one copy of the CCD)
+      if (!(tests >> i & 1u)) continue;
+      const F3 p1 = xyz(pos[ia[i]]), p0 = xyz(prev[ia[i]]);
+      if (point_triangle_ccd(p0 - b0, c0 - b0, d0 - b0, p1 - b1, c1 - b1, d1 - b1, threshold)) hits |= 1u << i;
+    }
+    // the hit records: one append per wavefront
+    const unsigned long long hot = __ballot(hits != 0u);
+    if (hot == 0ull) continue;
+    const int leader = __builtin_ctzll(hot);
+    uint32_t base = 0;
+    if (static_cast<int>(threadIdx.x & 63u) == leader) base = atomicAdd(&T.counters[9], static_cast<uint32_t>(__popcll(hot)));
+    base = __shfl(base, leader, 64);
+    if (hits == 0u) continue;
+    const int4 rg = T.rng[t];
+    const uint32_t shared = volume(meet(insert_box(rg), insert_box(T.rng[o])));  // (a triangle on the work list searched: its range is the listed one)
+    atomicAdd(&T.cntTri[merge_rank(t, T.nt, T.threadCount)], static_cast<uint32_t>(__popc(hits)) * shared);
+    const uint32_t rec = base + static_cast<uint32_t>(__popcll(hot & ((1ull << (threadIdx.x & 63u)) - 1ull)));
+    if (rec < T.maxContacts) T.pool[rec] = make_uint4(t, o, hits, atomicExch(&T.head[t], rec));
+    else atomicOr(&T.counters[3], 64u);  // more records than contacts fit the list: the list overflows as well
+  }
+}
+
+// The contact list from the hit records (Solver.cpp:721-797 order: the cells of the triangle's range x-major, in each cell the
+// listed triangles by ascending index, for each the triangle's corners 0, 1, 2).  One thread per record {t, o, corners}: for every
+// cell both ranges hold, the entry's position = the triangle's offset + what all of the triangle's records (its chain) put in
+// front of it: a record's hits x (the cells it shares with t that come earlier + this cell, if it holds it and the partner's
+// index is smaller).
+__global__ void __launch_bounds__(kBlock) k_tri_emit(TriArrays T) {
+  if (T.counters[3]) return;
+  const uint32_t nrec = min(T.counters[9], T.maxContacts);
+  for (uint32_t r = blockIdx.x * kBlock + threadIdx.x; r < nrec; r += gridDim.x * kBlock) {
+    const uint4 rec = T.pool[r];
+    const uint32_t t = rec.x, o = rec.y;
+    const int4 rg = T.rng[t];
+    const CellBox S = insert_box(rg);  // (a triangle with records searched: its range is the one it was listed with)
+    const CellBox mine = meet(S, insert_box(T.rng[o]));
+    const uint32_t base = T.offTri[merge_rank(t, T.nt, T.threadCount)];
+    const uint32_t ia[3] = {T.tris[3 * t], T.tris[3 * t + 1], T.tris[3 * t + 2]};
+    const uint32_t ib = T.tris[3 * o], ic = T.tris[3 * o + 1], idd = T.tris[3 * o + 2];
+    for (int x = mine.x0; x < mine.x1; ++x)
+      for (int y = mine.y0; y < mine.y1; ++y)
+        for (int z = mine.z0; z < mine.z1; ++z) {
+          uint32_t c = base;
+          for (uint32_t q = T.head[t]; q != kNil;) {
+            const uint4 other = T.pool[q];
+            const CellBox theirs = meet(S, insert_box(T.rng[other.y]));
+            c += static_cast<uint32_t>(__popc(other.z)) * (cells_before(theirs, x, y, z) + ((other.y < o && holds(theirs, x, y, z)) ? 1u : 0u));
+            q = other.w;
+          }
 #pragma unroll
-    for (int off = TEAM / 2; off >= 1; off >>= 1) count += __shfl_xor(count, off, TEAM);
-    if (member == 0) T.cntTri[rank] = count;
+          for (int i = 0; i < 3; ++i)
+            if (rec.z >> i & 1u) {
+              if (c < T.maxContacts) T.ids[c] = make_uint4(ia[i], ib, ic, idd);
+              ++c;
+            }
+        }
   }
 }
 
@@ -452,6 +645,10 @@ __global__ void __launch_bounds__(kBlock) k_tri_detect(TriArrays T, const float4
 // and a 10-step Hillis-Steele scan over the threads: 10 us at 42k triangles).
 __global__ void __launch_bounds__(1024) k_tri_scan(TriArrays T) {
   __shared__ uint32_t wsum[16];
+  if (T.counters[9] == 0u) {  // no hit record, no contact: the usual substep
+    if (threadIdx.x == 0u) T.counters[2] = 0u;
+    return;
+  }
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, nt = T.nt;
   const uint32_t per = (((nt + 15u) / 16u) + 63u) & ~63u;
   const uint32_t lo = min(nt, wave * per), hi = min(nt, lo + per);
@@ -587,7 +784,7 @@ PIES_DEV void step_boundary() {
 __global__ void __launch_bounds__(1024) k_inc_all(TriArrays T, const float* __restrict__ kdiag, float* __restrict__ cdiag, float* __restrict__ dinv,
                                                   uint32_t words) {
   __shared__ uint32_t part[1024];
-  if (T.counters[2] == 0u) return;  // no contact in this substep (k_tri_zero has cleared the counts this chain would write)
+  if (T.counters[2] == 0u) return;  // no contact in this substep (k_tri_box has cleared the counts this chain would write)
   inc_count(T, cdiag, threadIdx.x, 1024u);
   step_boundary();
   inc_used(T, words, part);
@@ -1205,14 +1402,13 @@ uint32_t launch_tri_detect(hipStream_t st_, const TriArrays& T, const NodeArrays
   if (T.nt == 0) return 0;
   const dim3 wide(std::min<uint32_t>(1024u, (T.nt * 8 + kBlock - 1) / kBlock)), blk(kBlock);
   hipLaunchKernelGGL(k_tri_reset, wide, blk, 0, st_, T);
-  hipLaunchKernelGGL(k_tri_zero, dim3(1), dim3(64), 0, st_, T);
-  hipLaunchKernelGGL(k_tri_count<1>, grid_for(T.nt), blk, 0, st_, T, nd.pos, nd.prev);
-  hipLaunchKernelGGL(k_tri_alloc, wide, blk, 0, st_, T);
-  hipLaunchKernelGGL(k_tri_fill, grid_for(T.nt * kTriTeam), blk, 0, st_, T);
-  hipLaunchKernelGGL(k_tri_sort, wide, blk, 0, st_, T);
-  hipLaunchKernelGGL((k_tri_detect<false, kTriTeam>), grid_for(T.nt * kTriTeam), blk, 0, st_, T, nd.pos, nd.prev, threshold);
+  hipLaunchKernelGGL(k_tri_box, grid_for(T.nt), blk, 0, st_, T, nd.pos, nd.prev);
+  hipLaunchKernelGGL(k_tri_starts, dim3(T.slots / kGridTile), blk, 0, st_, T);
+  hipLaunchKernelGGL(k_tri_fill, grid_for(T.nt), blk, 0, st_, T);
+  hipLaunchKernelGGL((k_tri_pairs<kTriTeam>), grid_for(T.nt * kTriTeam), blk, 0, st_, T, nd.pos, nd.prev, threshold);
+  hipLaunchKernelGGL(k_tri_ccd, dim3(1024), blk, 0, st_, T, nd.pos, nd.prev, threshold);  // (a multiple of kWorkShards)
   hipLaunchKernelGGL(k_tri_scan, dim3(1), dim3(1024), 0, st_, T);
-  hipLaunchKernelGGL((k_tri_detect<true, kTriTeam>), grid_for(T.nt * kTriTeam), blk, 0, st_, T, nd.pos, nd.prev, threshold);
+  hipLaunchKernelGGL(k_tri_emit, dim3(std::min<uint32_t>(256u, (T.maxContacts + kBlock - 1) / kBlock)), blk, 0, st_, T);
   const dim3 cgrid(std::min<uint32_t>(256u, (T.maxContacts + kBlock - 1) / kBlock));
   if (!mergedRows) {  // the variant for substeps with few or no contacts: the incidence chain as one launch of one workgroup
     hipLaunchKernelGGL(k_inc_all, dim3(1), dim3(1024), 0, st_, T, kdiag, cdiag, dinv, (nd.n + 31u) / 32u);

@@ -335,17 +335,23 @@ def test_few_triangles_spanning_many_cells(pies, oracle):
     assert not g.failed and not o.failed
 
 
-def test_more_cells_than_reserved_is_a_latched_failure_not_a_wild_write(pies):
-    """Three slanted triangles spanning 50 cells on every axis = 375 000 (cell, triangle) entries against the 2^18 reserved:
-    the failure latch (like the reference's runaway latches, Solver.cpp:741-755), tick a no-op afterwards."""
+def test_triangles_of_fifty_cells_per_axis_run_like_the_reference(pies, oracle):
+    """Three slanted triangles spanning 50 cells on every axis: the reference lists each in 125 000 cells (TriCompRange accepts
+    50 cells per axis, Solver.cpp:974-976) and searches none of them (sweptTriRange stops at 20, :672-674).  Until round 4 the
+    device's grid held (cell, triangle) entries like the reference's and latched a failure when 375 000 of them met the 2^18
+    reserved; a triangle is now listed once (tri_kernels.h), so the scene runs, without contacts, like the oracle's."""
     c = np.float32([[0.2, 0.3, 0.1], [49.6, 49.5, 0.4], [0.3, 49.7, 49.5]])
-    nodes = np.concatenate([c + np.float32([60.0, 0.0, 0.0]) * k for k in range(3)])  # disjoint cells: 375 000 used cells too
+    nodes = np.concatenate([c + np.float32([60.0, 0.0, 0.0]) * k for k in range(3)])
     g = pies.Solver(pd_options(pies, 2))
-    g.addNodes(nodes)
-    g.add_triangles([[0, 1, 2], [3, 4, 5], [6, 7, 8]])
-    g.set_prev_positions(g.positions)
-    g.tick()
-    assert g.failed
-    p = g.positions.copy()
-    g.tick()
-    assert np.array_equal(p, g.positions)
+    o = oracle.OracleSolver(pd_options(oracle, 2))
+    for s in (g, o):
+        s.addNodes(nodes)
+        s.add_triangles([[0, 1, 2], [3, 4, 5], [6, 7, 8]])
+        s.set_prev_positions(s.positions)
+    tol = tol_for(o.positions)
+    for t in range(3):
+        sync_state(g, o)
+        g.tick(); o.tick()
+        assert np.array_equal(g.tri_collisions, o.tri_collisions), t
+        assert np.abs(g.positions - o.positions).max() <= tol, t
+    assert not g.failed and not o.failed
