@@ -37,8 +37,9 @@ __global__ void __launch_bounds__(kBlock) k_pd_predict(float4* __restrict__ pos,
                                                        float4* __restrict__ msn, const uint32_t* __restrict__ triCount,
                                                        uint32_t* __restrict__ nstatic, const float* __restrict__ kdiag,
                                                        float* __restrict__ cdiag, float* __restrict__ dinv, uint32_t n, float h,
-                                                       float h2, float contactHeight) {
+                                                       float h2, float contactHeight, TriArrays tri) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (tri.nt) tri_reset(tri, i, gridDim.x * kBlock);  // the point-triangle pipeline's reset rides along (tri_kernels.h)
   if (i >= n) return;
   float4 p = pos[i];
   const float4 v = vel[i];
@@ -569,10 +570,12 @@ __global__ void __launch_bounds__(kBlock) k_pd_velocity(const float4* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------------
-void launch_pd_predict(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float h, float contactHeight) {
+void launch_pd_predict(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float h, float contactHeight, bool triReset) {
   if (nd.n == 0) return;
+  TriArrays tri = pd.tri;
+  if (!triReset) tri.nt = 0;
   hipLaunchKernelGGL(k_pd_predict, grid_for(nd.n), dim3(kBlock), 0, st, nd.pos, nd.vel, pd.msn, pd.triCount, pd.nstatic, pd.kdiag,
-                     pd.cg.cdiag, pd.cg.dinv, nd.n, h, h * h, contactHeight);
+                     pd.cg.cdiag, pd.cg.dinv, nd.n, h, h * h, contactHeight, tri);
 }
 void launch_pd_local_distance(hipStream_t st, const float4* pos, const uint2* ids, const float2* rw, Vec3f* contrib, uint32_t count) {
   if (count == 0) return;

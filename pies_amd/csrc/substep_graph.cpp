@@ -339,7 +339,7 @@ void enqueue_pd_substep(pies_solver* s, int only, uint32_t* counts, uint64_t* un
   auto C = [&](int k, uint32_t n = 1) { if (k != PIES_KERNEL_PD_SPMV && k != PIES_KERNEL_PD_CG_UPDATE) probe_mark(s, k); if (counts) counts[k] += n; };
   auto U = [&](uint64_t u) { if (units && (only >= 0 || (s->probe && s->probe->kernel == cur))) *units += u; };
   const uint32_t nDist = (uint32_t)s->h_distance.size(), nTet = (uint32_t)s->h_tet.size(), nVol = (uint32_t)s->h_volume.size();
-  if (ON(PIES_KERNEL_PD_PREDICT)) { launch_pd_predict(st, s->nd, pd, h, s->opt.floorHeight + s->opt.collisionThickness); U(s->nd.n); }
+  if (ON(PIES_KERNEL_PD_PREDICT)) { launch_pd_predict(st, s->nd, pd, h, s->opt.floorHeight + s->opt.collisionThickness, pd.tri.nt != 0 && only < 0); U(s->nd.n); }
   C(PIES_KERNEL_PD_PREDICT);
   const bool tri = pd.tri.nt != 0;
   // the statistics of the substep's last solve are closed by an extra workgroup of the floor-snap launch when there is one

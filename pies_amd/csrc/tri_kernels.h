@@ -77,6 +77,28 @@ struct TriArrays {
   uint32_t* nodeSlot;  // per node with contacts: its index in usedNodes (= its record in the LDS copy of the sequential passes)
   uint2* lvSlots;      // per entry of lvOrder: the four nodeSlots of the contact, 16 bit each
 };
+constexpr uint32_t kTriNil = 0xffffffffu;
+constexpr uint32_t kWorkShards = 64;   // lists of the CCD's work list (k_tri_pairs)
+constexpr uint32_t kGridTile = 2048;   // slots per tile of the prefix sum over the slots (256 threads x 8)
+// Before the grid is built (rides in the substep's first launch, k_pd_predict: one launch less): the slots the last substep listed triangles in, the tile sums and the substep's counters back to zero
+// ([0] and [4]-[8] are zeroed by k_tri_box, which runs before their first use: this kernel's own workgroups still read [4]),
+// the per-node incidence counts of the last substep's contacts.
+__device__ __forceinline__ void tri_reset(const TriArrays& T, uint32_t tid, uint32_t stride) {
+  const uint32_t usedNodes = T.counters[4];
+  if (tid < 16u && (tid == 1u || tid == 2u || tid >= 9u)) T.counters[tid] = 0;  // ([3] is the sticky failure flag)
+  for (uint32_t b = tid; b < T.slots / kGridTile; b += stride) T.tileSum[b] = 0;
+  if (tid < kWorkShards) T.workCnt[16u * tid] = 0;
+  for (uint32_t t = tid; t < T.nt; t += stride) {
+    const uint32_t s = T.cellOf[t];  // (the slots of the last substep; several triangles of a slot store the same 0)
+    if (s != kTriNil) T.cellCnt[s] = 0;
+  }
+  for (uint32_t u = tid; u < usedNodes; u += stride) {
+    const uint32_t n = T.usedNodes[u];
+    T.incCnt[n] = 0;
+    T.usedBits[n >> 5] = 0;  // (several nodes of a word: every writer stores the same 0)
+  }
+}
+
 constexpr uint32_t kTriMaxLevels = 2048;  // longer chains (one node in thousands of contacts) take the single-wavefront path
 
 struct PdArrays;

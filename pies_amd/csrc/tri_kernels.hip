@@ -144,9 +144,7 @@ PIES_DEV bool point_triangle_ccd(F3 ap0, F3 ab0, F3 ac0, F3 ap1, F3 ab1, F3 ac1,
 }
 
 // ---- triangle grid (tri_kernels.h: every triangle once, in the cell of its range's minimum corner) ----------------------
-constexpr uint32_t kNil = 0xffffffffu;
-constexpr uint32_t kWorkShards = 64;    // lists of the CCD's work list (k_tri_pairs)
-constexpr uint32_t kGridTile = 2048;  // slots per tile of the prefix sum over the slots (256 threads x 8)
+constexpr uint32_t kNil = kTriNil;
 PIES_DEV uint32_t grid_slot(const TriGridLevel& L, int x, int y, int z) {  // cell coordinates of the level -> slot (modulo the table)
   const uint32_t ux = static_cast<uint32_t>(x) & ((1u << L.lx) - 1u), uy = static_cast<uint32_t>(y) & ((1u << L.ly) - 1u),
                  uz = static_cast<uint32_t>(z) & ((1u << L.lz) - 1u);
@@ -154,26 +152,6 @@ PIES_DEV uint32_t grid_slot(const TriGridLevel& L, int x, int y, int z) {  // ce
 }
 // cells of the level a range of `len` world cells from `m` spans
 PIES_DEV uint32_t level_extent(int m, uint32_t len, uint32_t shift) { return static_cast<uint32_t>(((m + static_cast<int>(len) - 1) >> shift) - (m >> shift)) + 1u; }
-
-// Before the grid is built: the slots the last substep listed triangles in, the tile sums and the substep's counters back to zero
-// ([0] and [4]-[8] are zeroed by k_tri_box, which runs before their first use: this kernel's own workgroups still read [4]),
-// the per-node incidence counts of the last substep's contacts.
-__global__ void __launch_bounds__(kBlock) k_tri_reset(TriArrays T) {
-  const uint32_t usedNodes = T.counters[4];
-  const uint32_t tid = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
-  if (tid < 16u && (tid == 1u || tid == 2u || tid >= 9u)) T.counters[tid] = 0;  // ([3] is the sticky failure flag)
-  for (uint32_t b = tid; b < T.slots / kGridTile; b += stride) T.tileSum[b] = 0;
-  if (tid < kWorkShards) T.workCnt[16u * tid] = 0;
-  for (uint32_t t = tid; t < T.nt; t += stride) {
-    const uint32_t s = T.cellOf[t];  // (the slots of the last substep; several triangles of a slot store the same 0)
-    if (s != kNil) T.cellCnt[s] = 0;
-  }
-  for (uint32_t u = tid; u < usedNodes; u += stride) {
-    const uint32_t n = T.usedNodes[u];
-    T.incCnt[n] = 0;
-    T.usedBits[n >> 5] = 0;  // (several nodes of a word: every writer stores the same 0)
-  }
-}
 
 // TriCompRange / sweptTriRange: floor(min), ceil(max) - floor(min) over position and prevPosition, world units; the triangle's
 // record for the detection (box of its six corner positions, "both normals are non-zero"); its size class and slot.
@@ -606,10 +584,9 @@ __global__ void __launch_bounds__(kBlock) k_tri_ccd(TriArrays T, const float4* _
 // cell both ranges hold, the entry's position = the triangle's offset + what all of the triangle's records (its chain) put in
 // front of it: a record's hits x (the cells it shares with t that come earlier + this cell, if it holds it and the partner's
 // index is smaller).
-__global__ void __launch_bounds__(kBlock) k_tri_emit(TriArrays T) {
-  if (T.counters[3]) return;
+PIES_DEV void tri_emit(const TriArrays& T, uint32_t first, uint32_t stride) {
   const uint32_t nrec = min(T.counters[9], T.maxContacts);
-  for (uint32_t r = blockIdx.x * kBlock + threadIdx.x; r < nrec; r += gridDim.x * kBlock) {
+  for (uint32_t r = first; r < nrec; r += stride) {
     const uint4 rec = T.pool[r];
     const uint32_t t = rec.x, o = rec.y;
     const int4 rg = T.rng[t];
@@ -643,12 +620,12 @@ __global__ void __launch_bounds__(kBlock) k_tri_emit(TriArrays T) {
 // contacts at all - a second sweep that writes the offsets (wave-wide scans over 64 counts at a time).  A substep without
 // contacts is one sweep of loads that do not depend on each other (the first version gave every thread 41 consecutive counts
 // and a 10-step Hillis-Steele scan over the threads: 10 us at 42k triangles).
-__global__ void __launch_bounds__(1024) k_tri_scan(TriArrays T) {
-  __shared__ uint32_t wsum[16];
-  if (T.counters[9] == 0u) {  // no hit record, no contact: the usual substep
-    if (threadIdx.x == 0u) T.counters[2] = 0u;
-    return;
-  }
+__global__ void __launch_bounds__(kBlock) k_tri_emit(TriArrays T) {
+  if (T.counters[3]) return;
+  tri_emit(T, blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock);
+}
+// (a workgroup of 1024; returns the length of the contact list)
+PIES_DEV uint32_t tri_scan(const TriArrays& T, uint32_t* wsum) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, nt = T.nt;
   const uint32_t per = (((nt + 15u) / 16u) + 63u) & ~63u;
   const uint32_t lo = min(nt, wave * per), hi = min(nt, lo + per);
@@ -683,6 +660,15 @@ __global__ void __launch_bounds__(1024) k_tri_scan(TriArrays T) {
     if (total > T.maxContacts) atomicOr(&T.counters[3], 64u);  // contact list overflow: latch
     T.counters[2] = min(total, T.maxContacts);
   }
+  return total;
+}
+__global__ void __launch_bounds__(1024) k_tri_scan(TriArrays T) {
+  __shared__ uint32_t wsum[16];
+  if (T.counters[9] == 0u) {  // no hit record, no contact: the usual substep
+    if (threadIdx.x == 0u) T.counters[2] = 0u;
+    return;
+  }
+  tri_scan(T, wsum);
 }
 
 // ---- per-node incidence of the contacts + their diagonal blocks ---------------------------------------------
@@ -785,6 +771,30 @@ __global__ void __launch_bounds__(1024) k_inc_all(TriArrays T, const float* __re
                                                   uint32_t words) {
   __shared__ uint32_t part[1024];
   if (T.counters[2] == 0u) return;  // no contact in this substep (k_tri_box has cleared the counts this chain would write)
+  inc_count(T, cdiag, threadIdx.x, 1024u);
+  step_boundary();
+  inc_used(T, words, part);
+  step_boundary();
+  inc_alloc(T, kdiag, cdiag, dinv, threadIdx.x, 1024u);
+  step_boundary();
+  inc_fill(T, threadIdx.x, 1024u);
+  step_boundary();
+  inc_sort(T, threadIdx.x >> 6, 16u);
+}
+// The graph variant for substeps with few or no contacts: the offsets of the contact list, the list and the incidence chain by
+// ONE workgroup (three launches fewer; a substep without a hit record - the usual one - leaves at the first line).
+__global__ void __launch_bounds__(1024) k_tri_tail(TriArrays T, const float* __restrict__ kdiag, float* __restrict__ cdiag, float* __restrict__ dinv,
+                                                   uint32_t words) {
+  __shared__ uint32_t part[1024];
+  if (T.counters[9] == 0u) {
+    if (threadIdx.x == 0u) T.counters[2] = 0u;
+    return;
+  }
+  const uint32_t total = tri_scan(T, part);
+  if (total > T.maxContacts || T.counters[3]) return;  // (latched: the tick ends as a failure)
+  step_boundary();
+  tri_emit(T, threadIdx.x, 1024u);
+  step_boundary();
   inc_count(T, cdiag, threadIdx.x, 1024u);
   step_boundary();
   inc_used(T, words, part);
@@ -1401,19 +1411,18 @@ uint32_t launch_tri_detect(hipStream_t st_, const TriArrays& T, const NodeArrays
                            float threshold, float /*thickness*/, bool mergedRows) {
   if (T.nt == 0) return 0;
   const dim3 wide(std::min<uint32_t>(1024u, (T.nt * 8 + kBlock - 1) / kBlock)), blk(kBlock);
-  hipLaunchKernelGGL(k_tri_reset, wide, blk, 0, st_, T);
   hipLaunchKernelGGL(k_tri_box, grid_for(T.nt), blk, 0, st_, T, nd.pos, nd.prev);
   hipLaunchKernelGGL(k_tri_starts, dim3(T.slots / kGridTile), blk, 0, st_, T);
   hipLaunchKernelGGL(k_tri_fill, grid_for(T.nt), blk, 0, st_, T);
   hipLaunchKernelGGL((k_tri_pairs<kTriTeam>), grid_for(T.nt * kTriTeam), blk, 0, st_, T, nd.pos, nd.prev, threshold);
   hipLaunchKernelGGL(k_tri_ccd, dim3(1024), blk, 0, st_, T, nd.pos, nd.prev, threshold);  // (a multiple of kWorkShards)
+  if (!mergedRows) {  // the variant for substeps with few or no contacts: list offsets, list and incidence chain as one launch of one workgroup
+    hipLaunchKernelGGL(k_tri_tail, dim3(1), dim3(1024), 0, st_, T, kdiag, cdiag, dinv, (nd.n + 31u) / 32u);
+    return 6;
+  }
   hipLaunchKernelGGL(k_tri_scan, dim3(1), dim3(1024), 0, st_, T);
   hipLaunchKernelGGL(k_tri_emit, dim3(std::min<uint32_t>(256u, (T.maxContacts + kBlock - 1) / kBlock)), blk, 0, st_, T);
   const dim3 cgrid(std::min<uint32_t>(256u, (T.maxContacts + kBlock - 1) / kBlock));
-  if (!mergedRows) {  // the variant for substeps with few or no contacts: the incidence chain as one launch of one workgroup
-    hipLaunchKernelGGL(k_inc_all, dim3(1), dim3(1024), 0, st_, T, kdiag, cdiag, dinv, (nd.n + 31u) / 32u);
-    return 10;
-  }
   hipLaunchKernelGGL(k_inc_count, cgrid, blk, 0, st_, T, cdiag);
   hipLaunchKernelGGL(k_inc_used, dim3(1), dim3(1024), 0, st_, T, (nd.n + 31u) / 32u);
   hipLaunchKernelGGL(k_inc_alloc, cgrid, blk, 0, st_, T, kdiag, cdiag, dinv);
@@ -1424,7 +1433,7 @@ uint32_t launch_tri_detect(hipStream_t st_, const TriArrays& T, const NodeArrays
     if (const char* e = tuning_env("PIES_ROW_MAX_UNIQUE")) maxUnique = std::min<uint32_t>(kRowMaxUnique, static_cast<uint32_t>(std::max(0, std::atoi(e))));
     hipLaunchKernelGGL(k_contact_csr, cgrid, blk, 0, st_, T, maxUnique);
   }
-  return 14;
+  return 13;
 }
 void launch_tri_levels(hipStream_t st_, const TriArrays& T) {
   if (T.nt == 0) return;
