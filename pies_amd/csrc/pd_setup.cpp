@@ -392,7 +392,9 @@ int pd_build(pies_solver* s) {
       L.lz = std::max(floorLg[l], lg[2] > shifts[l] ? lg[2] - shifts[l] : 0u);
       slots += 1u << (L.lx + L.ly + L.lz);
     }
-    T.maxContacts = 16 * nt + 1024;
+    // (a hit between two long triangles is listed once per cell they share - up to 1000 times: a floor under the list keeps a
+    // handful of floor quads from overflowing a small scene)
+    T.maxContacts = std::max<uint32_t>(16 * nt + 1024, 1u << 16);
     slots = (slots + 2047u) & ~2047u;  // whole tiles of the prefix sum
     T.slots = slots;
     if (int rc = dev_alloc(s, slots, &T.cellCnt, true)) return rc;

@@ -355,3 +355,70 @@ def test_triangles_of_fifty_cells_per_axis_run_like_the_reference(pies, oracle):
         assert np.array_equal(g.tri_collisions, o.tri_collisions), t
         assert np.abs(g.positions - o.positions).max() <= tol, t
     assert not g.failed and not o.failed
+
+
+def _soup(seed, n_tri=360):
+    """Random triangles of very different sizes in a box of 20 x 10 x 20 world units (edge lengths 0.3-12, three of 25-45: listed
+    but too long to search), every triangle with nodes of its own."""
+    rng = np.random.default_rng(seed)
+    size = np.exp(rng.uniform(np.log(0.3), np.log(9.0), n_tri))
+    size[:3] = rng.uniform(25.0, 45.0, 3)
+    centre = rng.uniform(-10.0, 10.0, (n_tri, 3)) * [1.0, 0.5, 1.0] + [0.0, 30.0, 0.0]      # well above the floor
+    # (flat in y: a range of more than 1000 cells that is short enough to search fails the sim, Solver.cpp:741-745)
+    corners = centre[:, None, :] + rng.uniform(-0.5, 0.5, (n_tri, 3, 3)) * size[:, None, None] * [1.0, 0.3, 1.0]
+    for _ in range(8):  # (a triangle at rest must not trip that latch either: halve the ones that would, jitter included)
+        length = np.ceil(corners.max(1) + 0.3) - np.floor(corners.min(1) - 0.3)
+        heavy = (length <= 23).all(1) & (length.prod(1) > 800)
+        corners[heavy] = centre[heavy, None, :] + 0.5 * (corners[heavy] - centre[heavy, None, :])
+    return corners.reshape(-1, 3).astype(np.float32), np.arange(3 * n_tri, dtype=np.uint32).reshape(-1, 3)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_triangle_soup_contact_lists_equal_the_oracles(pies, oracle, seed):
+    run_soup(pies, oracle, seed)
+
+
+def run_soup(pies, oracle, seed):
+    """The broad phase lists every triangle once (minimum-corner cell, three size classes, slots modulo the table: tri_kernels.h)
+    where the reference lists it in every cell of its range; the contact list must come out the same, entry for entry, duplicates
+    included.  Triangle soup: sizes over two orders of magnitude (all three classes in use), random velocities up to 12 units per
+    tick (swept ranges of every length up to the search limit and beyond), a third of the triangles carried 1 000 and 2 000
+    units away after finalize (their cells share the table's slots with the others'), a new random state every tick."""
+    nodes, tris = _soup(seed)
+    g = pies.Solver(pd_options(pies, 1))
+    o = oracle.OracleSolver(pd_options(oracle, 1))
+    for s in (g, o):
+        s.addNodes(nodes)
+        s.add_triangles(tris)
+        s.set_prev_positions(s.positions)
+    rng = np.random.default_rng(1000 + seed)
+    h = 0.012                                    # SolverOptions::fixedTimestepSize, one substep per tick
+    total, classes = 0, np.zeros(3, dtype=np.int64)
+    for t in range(5):
+        p = nodes + rng.uniform(-0.3, 0.3, nodes.shape).astype(np.float32)
+        far = (np.arange(len(nodes)) // 3) % 3                       # per triangle: 0 stays, 1 and 2 are carried away
+        p[:, 0] += np.float32(1000.0) * far
+        p[:, 2] -= np.float32(500.0) * (far == 2)
+        step = rng.uniform(-1.0, 1.0, nodes.shape) * rng.choice([0.05, 1.0, 12.0], (len(nodes) // 3, 1)).repeat(3, 0)
+        v = (step / h).astype(np.float32)
+        # a triangle whose swept range is short enough to search (20 cells per axis) but holds more than 1000 cells would trip the
+        # reference's latch: it stays where it is in this tick
+        q = p + np.float32(h) * v
+        both = np.concatenate([p.reshape(-1, 3, 3), q.reshape(-1, 3, 3)], axis=1)
+        length = np.ceil(both.max(1)) - np.floor(both.min(1))
+        heavy = (length <= 20).all(1) & (length.prod(1) > 900)
+        v[np.repeat(heavy, 3)] = 0.0
+        for s in (g, o):
+            s.set_positions(p)
+            s.set_prev_positions(p)
+            s.set_velocities(v)
+        g.tick(); o.tick()
+        assert not o.failed and not g.failed, (t, g.last_error())
+        cg_, co = g.tri_collisions, o.tri_collisions
+        assert np.array_equal(cg_, co), (t, len(cg_), len(co))
+        total += len(co)
+        st = g.tri_grid_stats()
+        classes += np.asarray(st["listed"])
+    assert total > 300, total
+    assert (classes > 0).all(), classes      # all three size classes held triangles
+    return total
