@@ -38,6 +38,7 @@ void free_device(pies_solver* s) {
   for (void* p : s->allocations) (void)hipFree(p);
   s->allocations.clear();
   s->nd = NodeArrays{nullptr, nullptr, nullptr, nullptr, 0};
+  s->d_pack = nullptr;
   s->d_pc_id = nullptr; s->d_pc_tw = nullptr;
   s->d_dc_ids = nullptr; s->d_dc_rw = nullptr;
   s->d_tc_ids = nullptr; s->d_tc_q0 = s->d_tc_q1 = s->d_tc_q2 = nullptr;
@@ -86,18 +87,16 @@ static int upload_nodes(pies_solver* s) {
 static int download_nodes(pies_solver* s, uint32_t mask = 7u) {
   const uint32_t n = s->nd.n;
   mask &= s->stale;
-  if (n == 0 || !s->h_stage) { s->stale = 0; return PIES_OK; }
+  if (n == 0 || !s->h_stage || !s->d_pack) { s->stale = 0; return PIES_OK; }
   float* dst[3] = {s->h_pos.data(), s->h_prev.data(), s->h_vel.data()};
   const float4* src[3] = {s->nd.pos, s->nd.prev, s->nd.vel};
   for (int a = 0; a < 3; ++a) {
     if (!(mask & (1u << a))) continue;
-    HIP_TRY(s, hipMemcpyAsync(s->h_stage, src[a], n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+    // packed on the device: 12 bytes per node cross the bus, and the mirror is one memcpy from the pinned stage
+    launch_pack_xyz(s->stream, src[a], s->d_pack, n);
+    HIP_TRY(s, hipMemcpyAsync(s->h_stage, s->d_pack, 3ull * n * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(s, hipStreamSynchronize(s->stream));
-    for (uint32_t i = 0; i < n; ++i) {
-      dst[a][3 * i] = s->h_stage[i].x;
-      dst[a][3 * i + 1] = s->h_stage[i].y;
-      dst[a][3 * i + 2] = s->h_stage[i].z;
-    }
+    std::memcpy(dst[a], s->h_stage, 3ull * n * sizeof(float));
     s->stale &= ~(1u << a);
   }
   return PIES_OK;
@@ -408,6 +407,7 @@ int pies_finalize(pies_solver_t* s) {
     HIP_TRY(s, hipMalloc(&p, n * sizeof(float4))); s->allocations.push_back(p); s->nd.prev = (float4*)p;
     HIP_TRY(s, hipMalloc(&p, n * sizeof(float4))); s->allocations.push_back(p); s->nd.vel = (float4*)p;
     HIP_TRY(s, hipMalloc(&p, n * sizeof(float))); s->allocations.push_back(p); s->nd.radius = (float*)p;
+    HIP_TRY(s, hipMalloc(&p, 3ull * n * sizeof(float))); s->allocations.push_back(p); s->d_pack = (float*)p;
     s->nd.n = n;
     if (s->h_stage_n < n) {
       if (s->h_stage) (void)hipHostFree(s->h_stage);

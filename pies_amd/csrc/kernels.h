@@ -85,6 +85,8 @@ void launch_lcopy(hipStream_t st, const NodeArrays& nd, const LayerData& D, bool
 
 // an empty kernel (one wavefront): calibrates the cost of an event bracket (pies_profile_in_situ)
 void launch_noop(hipStream_t st);
+// x, y, z of n four-float records, packed (the host mirrors' layout)
+void launch_pack_xyz(hipStream_t st, const float4* src, float* dst, uint32_t n);
 // Solver.cpp:47-52
 void launch_predict(hipStream_t st, const NodeArrays& nd, float dt, float gravity);
 // Solver.cpp:132-136

@@ -194,6 +194,18 @@ void launch_velocity(hipStream_t st, const NodeArrays& nd, float dt, float dampi
   PIES_LAUNCH(k_velocity, kBlock, nd.n, st, nd.pos, nd.prev, nd.vel, nd.radius, nd.n, dt, damping, friction, floorHeight);
 }
 __global__ void k_noop() {}
+// the x, y, z of n records of four floats, packed: what the host mirrors keep (pies_tick's read-back moves 12 bytes per node)
+__global__ void __launch_bounds__(kBlock) k_pack_xyz(const float4* __restrict__ src, float* __restrict__ dst, uint32_t n) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float4 v = src[i];
+  dst[3 * i] = v.x;
+  dst[3 * i + 1] = v.y;
+  dst[3 * i + 2] = v.z;
+}
+void launch_pack_xyz(hipStream_t st, const float4* src, float* dst, uint32_t n) {
+  if (n) hipLaunchKernelGGL(k_pack_xyz, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, src, dst, n);
+}
 void launch_noop(hipStream_t st) { hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, st); }
 void launch_position(hipStream_t st, float4* pos, const uint32_t* ids, const float4* target_w, uint32_t start,
                      uint32_t count) {

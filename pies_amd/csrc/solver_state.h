@@ -259,6 +259,7 @@ struct pies_solver {
   uint32_t pcgCooldown = 0;   // synchronisations left before the budget may shrink again after a solve ran out
   std::vector<void*> allocations;
   float4* h_stage = nullptr;  // pinned staging for the per-tick position read-back
+  float* d_pack = nullptr;    // n x 3: a node array's x, y, z packed for the read-back (freed with the device state)
   size_t h_stage_n = 0;
   // ---- render-state export (Solver.h:42-71): frame k is copied out while frame k+1 computes ----
   hipStream_t copyStream = nullptr;
