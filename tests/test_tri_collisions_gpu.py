@@ -422,3 +422,30 @@ def run_soup(pies, oracle, seed):
     assert total > 300, total
     assert (classes > 0).all(), classes      # all three size classes held triangles
     return total
+
+
+def test_a_crowd_below_the_reference_latch_is_no_failure(pies, oracle):
+    """Solver.cpp:751-755 fails the sim when a bucket holds more than 1000 triangles.  The device has no buckets: a triangle whose
+    search windows list more than 1000 triangles counts, cell by cell of its range, the ranges that hold the cell.  Two clusters of
+    600 small triangles in neighbouring cells: every window lists 1 200, no cell holds more than 600 - no failure on either side,
+    the same contacts; with 1 050 in one of the cells both sides latch."""
+    for crowd, fails in ((600, False), (1050, True)):
+        rng = np.random.default_rng(5)
+        a = rng.uniform(0.10, 0.90, (3 * crowd, 3)) + [0.0, 5.0, 0.0]
+        b = rng.uniform(0.10, 0.90, (3 * 600, 3)) + [1.0, 5.0, 0.0]
+        # small triangles: every corner within 0.05 of the first one (a range of one cell)
+        for c in (a, b):
+            c[1::3] = c[0::3] + rng.uniform(-0.04, 0.04, (len(c) // 3, 3))
+            c[2::3] = c[0::3] + rng.uniform(-0.04, 0.04, (len(c) // 3, 3))
+        nodes = np.concatenate([a, b]).astype(np.float32)
+        g = pies.Solver(pd_options(pies, 1))
+        o = oracle.OracleSolver(pd_options(oracle, 1))
+        for s in (g, o):
+            s.addNodes(nodes)
+            s.add_triangles(np.arange(len(nodes), dtype=np.uint32).reshape(-1, 3))
+            s.set_prev_positions(s.positions)
+        g.tick(); o.tick()
+        assert o.failed == fails and g.failed == fails, (crowd, o.failed, g.failed)
+        if not fails:
+            assert g.tri_grid_stats()["listed"][0] == crowd + 600
+            assert np.array_equal(g.tri_collisions, o.tri_collisions)
