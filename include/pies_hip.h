@@ -259,7 +259,7 @@ int pies_collision_stats(pies_solver_t* s, uint64_t* pairs, uint64_t* candidates
  * orders than captured: slow, never wrong. */
 int pies_set_collision_rounds(pies_solver_t* s, uint32_t rounds);
 /* Tuning and diagnostic switches, process wide, by name (value NULL or "" unsets): graph variants and sizes that tests and
- * profiling scripts pin - PIES_PCG_BUDGET, PIES_PCG_OVERFLOW, PIES_TRI_FAST_ROWS, PIES_TRI_LDS, PIES_ROW_MAX_UNIQUE, PIES_TRI_SIDE,
+ * profiling scripts pin - PIES_PCG_BUDGET, PIES_PCG_OVERFLOW, PIES_TRI_FAST_ROWS, PIES_TRI_LDS, PIES_ROW_MAX_UNIQUE, PIES_TRI_SIDE, PIES_TRI_TEAM,
  * PIES_NO_GRAPH, PIES_NO_WAVEFRONT, PIES_NO_TET_PAIRS, PIES_PD_LOCAL_PACKED (0: one element per lane in the PD strain + volume step),
  * PIES_PD_REST_DICT (0: per-element constants instead of the rest dictionary), PIES_PD_ROW_DICT (0: the PD system matrix as SELL
  * arrays only, no row dictionary), PIES_LAYER_ONE_STRIP_MAX / _TILE_NODES / _STRIPS_MIN_NODES / PIES_LAYER_BLOCK,

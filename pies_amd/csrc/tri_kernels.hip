@@ -1414,7 +1414,11 @@ uint32_t launch_tri_detect(hipStream_t st_, const TriArrays& T, const NodeArrays
   hipLaunchKernelGGL(k_tri_box, grid_for(T.nt), blk, 0, st_, T, nd.pos, nd.prev);
   hipLaunchKernelGGL(k_tri_starts, dim3(T.slots / kGridTile), blk, 0, st_, T);
   hipLaunchKernelGGL(k_tri_fill, grid_for(T.nt), blk, 0, st_, T);
-  hipLaunchKernelGGL((k_tri_pairs<kTriTeam>), grid_for(T.nt * kTriTeam), blk, 0, st_, T, nd.pos, nd.prev, threshold);
+  int team = kTriTeam;  // PIES_TRI_TEAM: lanes per triangle in k_tri_pairs (8, 16, 32; speed only)
+  if (const char* e = tuning_env("PIES_TRI_TEAM")) team = std::atoi(e);
+  if (team == 8) hipLaunchKernelGGL((k_tri_pairs<8>), grid_for(T.nt * 8), blk, 0, st_, T, nd.pos, nd.prev, threshold);
+  else if (team == 32) hipLaunchKernelGGL((k_tri_pairs<32>), grid_for(T.nt * 32), blk, 0, st_, T, nd.pos, nd.prev, threshold);
+  else hipLaunchKernelGGL((k_tri_pairs<kTriTeam>), grid_for(T.nt * kTriTeam), blk, 0, st_, T, nd.pos, nd.prev, threshold);
   hipLaunchKernelGGL(k_tri_ccd, dim3(1024), blk, 0, st_, T, nd.pos, nd.prev, threshold);  // (a multiple of kWorkShards)
   if (!mergedRows) {  // the variant for substeps with few or no contacts: list offsets, list and incidence chain as one launch of one workgroup
     hipLaunchKernelGGL(k_tri_tail, dim3(1), dim3(1024), 0, st_, T, kdiag, cdiag, dinv, (nd.n + 31u) / 32u);
