@@ -92,7 +92,9 @@ static int download_nodes(pies_solver* s, uint32_t mask = 7u) {
   const float4* src[3] = {s->nd.pos, s->nd.prev, s->nd.vel};
   for (int a = 0; a < 3; ++a) {
     if (!(mask & (1u << a))) continue;
-    // packed on the device: 12 bytes per node cross the bus, and the mirror is one memcpy from the pinned stage
+    // packed on the device: 12 bytes per node cross the bus, and the mirror is one memcpy from the pinned stage (measured on
+    // config 2: 654 ticks/s against 637 with four floats per node and an unpacking loop; the asynchronous export stays the
+    // fast way out, 680)
     launch_pack_xyz(s->stream, src[a], s->d_pack, n);
     HIP_TRY(s, hipMemcpyAsync(s->h_stage, s->d_pack, 3ull * n * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(s, hipStreamSynchronize(s->stream));

@@ -683,7 +683,7 @@ int poll_failure(pies_solver* s) {
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   if (flag) {  // like the reference's latch (Solver.cpp:741-755, 853-856): tick becomes a no-op
     s->simFailed = true;
-    s->error = flag & 2    ? "collision grid overflow (more cells or (cell, triangle) entries than reserved)"
+    s->error = flag & 2    ? "node-node collision grid overflow (more cells or entries than reserved)"
                : flag & 4  ? "more than 2048 nodes overlap one grid cell (runaway pile-up)"
                : flag & 16 ? "more than 1000 triangles in one grid cell, or more than 1000 cells in a triangle's search range (the reference's safety latches, Solver.cpp:741-755)"
                : flag & 32 ? "a triangle's swept bounding box is non-finite"
