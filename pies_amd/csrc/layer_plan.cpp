@@ -16,11 +16,22 @@
 // distance container runs its even groups first and the tetrahedral container its odd groups first, so that the
 // second distance phase and the first tetrahedral phase (same parity, same resident nodes) share a launch, and
 // likewise the last phase of one iteration and the first phase of the next.
+//
+// Round 4 (second half).  A group's sweep lasts as long as its colours, and a group needs at least as many colours as its busiest
+// node has constraints in it.  On a lattice a node's 24 tetrahedra split 12 / 12 between the group below and the group above
+// it; a breadth-first levelling of an unstructured mesh puts ~83 % of a node's elements into the group below (an element
+// belongs to the group of its LOWEST level, and most elements of a node reach one level down): 38 + 39 colours where the
+// node degree would allow 23 + 23.  Two remedies, tried as candidate plans beside the original one (the cheapest is taken; a
+// tie keeps the original):  (1) an element whose nodes all lie in ONE level may run with the group below it as well as with
+// its own - both keep that level resident - and is dealt to whichever leaves the busiest of its nodes less busy;  (2) levels by
+// position instead of by graph distance: slabs along the longest axis as thick as the longest constraint, so that a
+// constraint still touches at most two adjacent levels and about half of them lie in a single one.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <numeric>
 
 #include "solver_state.h"
@@ -133,7 +144,6 @@ static bool layer_reject(const char* why) {
 
 bool build_layer_plan(pies_solver* s) {
   const uint32_t N = s->nodeCount();
-  LayerPlan L;
   // ---- the containers as id lists ----
   Ops ops[5];
   ops[PIES_POSITION].stride = 1; ops[PIES_POSITION].writeMask = 0x1;
@@ -241,9 +251,19 @@ bool build_layer_plan(pies_solver* s) {
       if (level[v] == kNone) level[v] = rr++ % nLevels;
     return nLevels;
   };
-  std::vector<uint32_t> level1, level2;
-  const uint32_t L1 = bfs(axes[0], level1);
-  if (L1 < 2) return layer_reject("fewer than two levels");
+  // ---- one candidate plan: tiles, groups and colours for a first levelling; its cost = the colour steps of a sweep ----
+  struct Candidate {
+    LayerPlan L;
+    Plan plans[5];
+    uint64_t cost = ~0ull;
+    const char* why = nullptr;
+    const char* name = "";
+  };
+  auto reject = [](Candidate& C, const char* why) { C.why = why; return false; };
+  auto attempt = [&](const std::vector<uint32_t>& level1, const uint32_t L1, const bool balance, Candidate& C) -> bool {
+  LayerPlan& L = C.L;
+  std::vector<uint32_t> level2;
+  if (L1 < 2) return reject(C, "fewer than two levels");
   L.levels = L1;
 
   // ---- one strip (a pair of levels fits a workgroup) or strips of a second levelling across the first ----
@@ -266,9 +286,9 @@ bool build_layer_plan(pies_solver* s) {
   if (maxPair <= std::min(oneStripMax, kLayerMaxGroupNodes)) {
     level2.assign(N, 0);
   } else {
-    if (N < stripsMinNodes) return layer_reject("a pair of levels is too wide for one workgroup and the body too small for strips");
+    if (N < stripsMinNodes) return reject(C, "a pair of levels is too wide for one workgroup and the body too small for strips");
     L2 = bfs(axes[1], level2);
-    if (L2 == 0) return layer_reject("no second levelling");
+    if (L2 == 0) return reject(C, "no second levelling");
     // nodes per (level1, level2) cell, prefix sums along level2
     std::vector<uint32_t> pre(static_cast<size_t>(L1 + 1) * (L2 + 1), 0);
     for (uint32_t v = 0; v < N; ++v) ++pre[static_cast<size_t>(level1[v]) * (L2 + 1) + level2[v] + 1];
@@ -289,7 +309,7 @@ bool build_layer_plan(pies_solver* s) {
     for (uint32_t w = L2; w >= 1; --w)
       if (tile_max(w) <= tileTarget) { width = w; break; }
     if (width == 0) {
-      if (tile_max(1) > kLayerMaxGroupNodes) return layer_reject("a tile of width 1 does not fit in LDS");
+      if (tile_max(1) > kLayerMaxGroupNodes) return reject(C, "a tile of width 1 does not fit in LDS");
       width = 1;
     }
   }
@@ -336,7 +356,7 @@ bool build_layer_plan(pies_solver* s) {
           L.maxGroupNodes = std::max(L.maxGroupNodes, tile.count0 + tile.count1);
         }
     }
-  if (L.maxGroupNodes > kLayerMaxGroupNodes) return layer_reject("tile larger than the LDS budget");
+  if (L.maxGroupNodes > kLayerMaxGroupNodes) return reject(C, "tile larger than the LDS budget");
 
   // ---- per container: tile of every op, colouring inside the tile, execution order ----
   int rounds = 12;
@@ -347,7 +367,7 @@ bool build_layer_plan(pies_solver* s) {
     const uint32_t p = posInList[v];
     return p >= tile.first0 && p < tile.first0 + tile.count0 ? p - tile.first0 : tile.count0 + (p - tile.first1);
   };
-  Plan plans[5];
+  Plan* plans = C.plans;
   for (int k : kinds) {
     const Ops& O = ops[k];
     LayerKind& K = L.kind[k];
@@ -371,6 +391,12 @@ bool build_layer_plan(pies_solver* s) {
     }
     std::vector<std::vector<uint32_t>> members[4];
     for (int ph = 0; ph < 4; ++ph) members[ph].resize(L.tiles[ph].size());
+    // group of every op: the lowest level of its nodes - or, with `balance`, for an op whose nodes share ONE level, that level or
+    // the one below, whichever leaves the busiest of its nodes less busy (below[v] / above[v]: ops of this container that node v
+    // meets as a node of its group's upper / lower level; the ops that span two levels are counted first)
+    std::vector<uint32_t> groupOf(O.count), stripOf(O.count);
+    std::vector<uint32_t> below, above;
+    if (balance && k != PIES_POSITION) { below.assign(N, 0); above.assign(N, 0); }
     for (uint32_t c = 0; c < O.count; ++c) {
       uint32_t l = kNone, lmax = 0, m = kNone, mmax = 0;
       for (uint32_t j = 0; j < O.stride; ++j) {
@@ -378,8 +404,36 @@ bool build_layer_plan(pies_solver* s) {
         l = std::min(l, level1[v]); lmax = std::max(lmax, level1[v]);
         m = std::min(m, level2[v]); mmax = std::max(mmax, level2[v]);
       }
-      if (lmax - l > 1 || mmax - m > 1) return layer_reject("a constraint spans more than two levels");  // cannot happen for breadth-first levellings
-      const uint32_t t = m / width;
+      if (lmax - l > 1 || mmax - m > 1) return reject(C, "a constraint spans more than two levels");  // cannot happen for breadth-first levellings
+      groupOf[c] = l;
+      stripOf[c] = m / width;
+      if (!below.empty() && lmax != l)
+        for (uint32_t j = 0; j < O.stride; ++j) {
+          const uint32_t v = O.ids[static_cast<size_t>(c) * O.stride + j];
+          ++(level1[v] == l ? above[v] : below[v]);
+        }
+    }
+    if (!below.empty())
+      for (uint32_t c = 0; c < O.count; ++c) {
+        const uint32_t* id = &O.ids[static_cast<size_t>(c) * O.stride];
+        const uint32_t l = groupOf[c];
+        bool single = true;
+        for (uint32_t j = 0; j < O.stride; ++j) single = single && level1[id[j]] == l;
+        if (!single) continue;
+        uint32_t stay = 0, down = 0;
+        for (uint32_t j = 0; j < O.stride; ++j) { stay = std::max(stay, above[id[j]]); down = std::max(down, below[id[j]]); }
+        const bool goDown = l >= 1 && down < stay;
+        if (goDown) groupOf[c] = l - 1;
+        for (uint32_t j = 0; j < O.stride; ++j) ++(goDown ? below[id[j]] : above[id[j]]);
+      }
+    if (!below.empty())
+      if (const char* e = std::getenv("PIES_LAYER_DEBUG"); e && e[0] == '1') {
+        uint32_t mb = 0, ma = 0;
+        for (uint32_t v = 0; v < N; ++v) { mb = std::max(mb, below[v]); ma = std::max(ma, above[v]); }
+        std::fprintf(stderr, "[pies]   container %d: busiest node meets %u ops from the level below, %u from its own\n", k, mb, ma);
+      }
+    for (uint32_t c = 0; c < O.count; ++c) {
+      const uint32_t l = groupOf[c], t = stripOf[c];
       if (k == PIES_POSITION) { members[0][static_cast<size_t>(l / 2) * Sp[0]].push_back(c); continue; }  // one strip: with the even tiles
       const int p1 = l & 1u, p2 = t & 1u;
       const uint32_t gi = p1 ? (l + 1) / 2 : l / 2;
@@ -399,7 +453,7 @@ bool build_layer_plan(pies_solver* s) {
         for (uint32_t i = 0; i < T[g].count0; ++i) localOf[L.nodeList[T[g].first0 + i]] = i;
         for (uint32_t i = 0; i < T[g].count1; ++i) localOf[L.nodeList[T[g].first1 + i]] = T[g].count0 + i;
         uint32_t nc = colour_group(O, sel, localOf.data(), m, rounds, keys[g]);
-        if (nc == 0) return layer_reject("more than 128 colours inside a tile");
+        if (nc == 0) return reject(C, "more than 128 colours inside a tile");
         if (!(noHint && std::atoi(noHint)))
           for (int a = 0; a < 3; ++a) {
             std::vector<uint32_t> proposed;
@@ -431,8 +485,73 @@ bool build_layer_plan(pies_solver* s) {
         }
       }
     }
-    if (P.order.size() != O.count) return layer_reject("internal: incomplete order");
+    if (P.order.size() != O.count) return reject(C, "internal: incomplete order");
   }
+  // a colour step lasts as long as one projection of its kind: a tetrahedron's or a bend's ~ 4 distance projections
+  static const uint64_t weight[5] = {1, 1, 4, 0, 4};
+  C.cost = 0;
+  for (int k : kinds)
+    for (int ph = 0; ph < 4; ++ph) C.cost += weight[k] * L.kind[k].ncol[ph];
+  return true;
+  };
+
+  // ---- the candidates ----
+  std::vector<uint32_t> levelBfs, levelSlab;
+  const uint32_t L1bfs = bfs(axes[0], levelBfs);
+  int want = 2;  // PIES_LAYER_PLAN: 0 = the original plan only, 1 = + the balanced groups, 2 = + slabs by position (default)
+  if (const char* e = tuning_env("PIES_LAYER_PLAN")) want = std::atoi(e);
+  std::vector<std::unique_ptr<Candidate>> cands;
+  auto run = [&](const char* name, const std::vector<uint32_t>& lev, uint32_t nl, bool balance) {
+    cands.push_back(std::make_unique<Candidate>());
+    cands.back()->name = name;
+    if (!attempt(lev, nl, balance, *cands.back())) cands.back()->cost = ~0ull;
+  };
+  run("breadth-first levels", levelBfs, L1bfs, false);
+  if (want >= 1) run("breadth-first levels, single-level constraints dealt to either group", levelBfs, L1bfs, true);
+  if (want >= 2) {
+    // slabs along the longest axis, as thick as the longest constraint (times PIES_LAYER_SLAB, default 1): a constraint touches
+    // at most two adjacent slabs
+    const int axis = axes[0];
+    double longest = 0.0;
+    for (int k : linking)
+      for (uint32_t c = 0; c < ops[k].count; ++c) {
+        const uint32_t* id = &ops[k].ids[static_cast<size_t>(c) * ops[k].stride];
+        float mn = INFINITY, mx = -INFINITY;
+        for (uint32_t j = 0; j < ops[k].stride; ++j) { mn = std::min(mn, s->h_pos[3 * id[j] + axis]); mx = std::max(mx, s->h_pos[3 * id[j] + axis]); }
+        if (std::isfinite(mx - mn)) longest = std::max(longest, static_cast<double>(mx) - mn);
+      }
+    double scale = 1.0;
+    if (const char* e = tuning_env("PIES_LAYER_SLAB")) scale = std::max(1.0, std::atof(e));
+    const double d = longest * scale * 1.000001 + 1.0e-6;
+    const double extent = static_cast<double>(hi[axis]) - lo[axis];
+    if (std::isfinite(extent) && longest > 0.0 && extent / d < 1.0e6) {
+      levelSlab.assign(N, 0);
+      uint32_t nl = 0;
+      for (uint32_t v = 0; v < N; ++v) {
+        const double z = static_cast<double>(s->h_pos[3 * v + axis]) - lo[axis];
+        levelSlab[v] = std::isfinite(z) ? static_cast<uint32_t>(z / d) : 0u;
+        nl = std::max(nl, levelSlab[v] + 1);
+      }
+      // (two nodes of a constraint are at most `longest` < d apart: their slabs differ by at most one)
+      run("slabs along the longest axis, single-level constraints dealt to either group", levelSlab, nl, true);
+    }
+  }
+  size_t best = 0;  // (the original plan unless another one saves a twentieth of its colour steps: a lattice keeps its order)
+  for (size_t i = 1; i < cands.size(); ++i)
+    if (cands[i]->cost < cands[best]->cost && (cands[0]->cost == ~0ull || 20 * cands[i]->cost <= 19 * cands[0]->cost)) best = i;
+  if (const char* e = tuning_env("PIES_LAYER_PLAN_FORCE")) {  // tests: take candidate i whatever it costs (if it is a plan at all)
+    const size_t i = static_cast<size_t>(std::max(0, std::atoi(e)));
+    if (i < cands.size() && cands[i]->cost != ~0ull) best = i;
+  }
+  if (const char* e = std::getenv("PIES_LAYER_DEBUG"); e && e[0] == '1')
+    for (size_t i = 0; i < cands.size(); ++i)
+      std::fprintf(stderr, "[pies] LAYERED candidate %zu (%s): %s%s, cost %llu (distance %u + %u, tetrahedra %u + %u colours, %u levels)%s\n", i,
+                   cands[i]->name, cands[i]->why ? "rejected: " : "ok", cands[i]->why ? cands[i]->why : "",
+                   static_cast<unsigned long long>(cands[i]->cost), cands[i]->L.kind[PIES_DISTANCE].ncol[0], cands[i]->L.kind[PIES_DISTANCE].ncol[2],
+                   cands[i]->L.kind[PIES_TET].ncol[0], cands[i]->L.kind[PIES_TET].ncol[2], cands[i]->L.levels, i == best ? "  <- taken" : "");
+  if (cands[best]->cost == ~0ull) return layer_reject(cands[0]->why ? cands[0]->why : "no plan");
+  LayerPlan& L = cands[best]->L;
+  Plan* plans = cands[best]->plans;
   if (const char* e = std::getenv("PIES_LAYER_DEBUG"); e && e[0] == '1') {
     std::fprintf(stderr, "[pies] schedule LAYERED: %u levels, %u strip(s) of width %u, largest tile %u nodes\n", L.levels, L.strips, L.width, L.maxGroupNodes);
     for (int k : kinds)

@@ -272,10 +272,13 @@ def test_layered_wide_body_is_cut_into_strips(pies, oracle):
     _check(g, o)
 
 
+@pytest.mark.parametrize("candidate", [0, 1, 2])
 @pytest.mark.parametrize("collisions", [0, 1])
-def test_layered_strips_small_tiles_all_containers(pies, oracle, monkeypatch, collisions, tune):
+def test_layered_strips_small_tiles_all_containers(pies, oracle, monkeypatch, collisions, tune, candidate):
     """The strip path forced onto small scenes (tiny tiles, ragged strips): beams, a bend sheet, a hinged sheet with
-    position constraints (two of them on one node), with and without the collision pass between the sweeps."""
+    position constraints (two of them on one node), with and without the collision pass between the sweeps - in the original
+    plan and in round 4's two other candidates (layer_plan.cpp; a candidate that is no plan for this scene leaves the original)."""
+    tune("PIES_LAYER_PLAN_FORCE", str(candidate))
     tune("PIES_LAYER_ONE_STRIP_MAX", "40")
     tune("PIES_LAYER_TILE_NODES", "90")
     tune("PIES_LAYER_STRIPS_MIN_NODES", "0")
@@ -335,6 +338,45 @@ def test_unstructured_delaunay_beam(pies, oracle, schedule):
     if schedule == 2:
         assert g.launch_counts()["layer"] == 2 * 5 + 1
     _check(g, o)
+
+
+@pytest.mark.parametrize("candidate", [1, 2])
+@pytest.mark.parametrize("mesh", ["delaunay", "lattice"])
+def test_layered_candidate_plans(pies, oracle, tune, mesh, candidate):
+    """Round 4: schedule LAYERED tries two more plans beside its original one and takes the one with the fewest colour steps
+    (layer_plan.cpp): constraints whose nodes share one breadth-first level dealt to the group below or their own, whichever
+    leaves their busiest node less busy (candidate 1), and the same with slabs by position as levels (candidate 2).  Each one,
+    forced, reproduces the oracle replaying its order bit for bit, on an unstructured beam and on a lattice."""
+    tune("PIES_LAYER_PLAN_FORCE", str(candidate))
+    g = pies.Solver(scenes.pbd_options(pies, 5))
+    o = oracle.OracleSolver(scenes.pbd_options(oracle, 5))
+    for s in (g, o):
+        if mesh == "delaunay":
+            scenes.build_unstructured(s, scenes.delaunay_beam((7, 6, 40)))
+        else:
+            scenes.build_beam(s, (5, 4, 30))
+        scenes.perturb(s, 12, 0.03)
+        s.set_flag(1, 0)
+    g.set_schedule(pies.SCHEDULE_LAYERED)
+    g.finalize()
+    orders = {t: g.order(t) for t in (pies.DISTANCE, pies.TET)}
+    for t, order in orders.items():
+        assert sorted(order.tolist()) == list(range(len(order)))      # a permutation of the container
+        o.permute(t, order)
+    g.tick(3)
+    o.tick(3)
+    assert g.launch_counts()["layer"] == 2 * 5 + 1
+    _check(g, o)
+    # the forced plan is not the original one
+    tune("PIES_LAYER_PLAN_FORCE", "0")
+    h = pies.Solver(scenes.pbd_options(pies, 5), device=-1)
+    if mesh == "delaunay":
+        scenes.build_unstructured(h, scenes.delaunay_beam((7, 6, 40)))
+    else:
+        scenes.build_beam(h, (5, 4, 30))
+    h.set_flag(1, 0)
+    h.set_schedule(pies.SCHEDULE_LAYERED)
+    assert not np.array_equal(h.order(pies.TET), orders[pies.TET]) or not np.array_equal(h.order(pies.DISTANCE), orders[pies.DISTANCE])
 
 
 def test_empty_and_unconstrained(pies, oracle):
