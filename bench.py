@@ -596,20 +596,30 @@ def run_unstructured(device, with_coloured=True):
 
 def run_config5_share(device, with_rooflines=True):
     """configs[4], one GPU's share, with contacts that bind"""
-    g = contact_scene(capi, device)
-    g.finalize()
-    # one tick to take the first replay of the graph (upload of the executable graph, first touch of the scratch arrays: 8-18
-    # ms that are not the solver's), then the scene is put back to its start
-    p0, q0, v0 = g.positions.copy(), g.prev_positions.copy(), g.velocities.copy()
-    g.tick_async(1)
-    g.synchronize()
-    g.set_positions(p0); g.set_prev_positions(q0); g.set_velocities(v0)
-    frames = []
-    for _ in range(18):  # the small body lands in frames 0-4 (thousands of contacts bind), then both bodies - w = 1 against m/h^2 = 6944 is
-        t0 = time.perf_counter()  # jelly - sag together and the contacts are gone: both regimes are reported
+    # The 18 frames are single wall-clock measurements of 1-5 ms on a host this process shares: the scene is run twice, on two
+    # handles (the same deterministic frames: same contacts, same CG budgets), and every frame is given the smaller of its two
+    # times (`runs` in the report; a stall of the library's own - a graph instantiated inside a frame - would show in both).
+    runs = []
+    for rep in range(2):
+        if rep:
+            g.close()
+        g = contact_scene(capi, device)
+        g.finalize()
+        # one tick to take the first replay of the graph (upload of the executable graph, first touch of the scratch arrays: 8-18
+        # ms that are not the solver's), then the scene is put back to its start
+        p0, q0, v0 = g.positions.copy(), g.prev_positions.copy(), g.velocities.copy()
         g.tick_async(1)
         g.synchronize()
-        frames.append((time.perf_counter() - t0, len(g.tri_collisions), g.pcg_health()["budget"]))
+        g.set_positions(p0); g.set_prev_positions(q0); g.set_velocities(v0)
+        run = []
+        for _ in range(18):  # the small body lands in frames 0-4 (thousands of contacts bind), then both bodies - w = 1 against m/h^2 = 6944 is
+            t0 = time.perf_counter()  # jelly - sag together and the contacts are gone: both regimes are reported
+            g.tick_async(1)
+            g.synchronize()
+            run.append((time.perf_counter() - t0, len(g.tri_collisions), g.pcg_health()["budget"]))
+        runs.append(run)
+    same = [a[1:] == b[1:] for a, b in zip(*runs)]
+    frames = [min(a, b) if eq else b for a, b, eq in zip(runs[0], runs[1], same)]
     binding = [f for f in frames if f[1] > 0]
     quiet = [f for f in frames[6:] if f[1] == 0]
     res, iters, solves = g.pcg_stats()
@@ -620,6 +630,9 @@ def run_config5_share(device, with_rooflines=True):
            "that synchronises once per frame; value = the frames in which point-triangle contacts bind (contact onset: the CG "
            "budget starts at 32)",
            "frames_with_contacts": len(binding), "contacts_per_frame": [f[1] for f in frames],
+           "runs": {"count": 2, "frames_identical_in_both": all(same), "ms_per_frame_first": [round(1e3 * f[0], 3) for f in runs[0]],
+                    "ms_per_frame_second": [round(1e3 * f[0], 3) for f in runs[1]],
+                    "note": "every frame's time is the smaller of its two runs (wall-clock frames on a shared host)"},
            "cg_budget_per_frame": [f[2] for f in frames], "ms_per_frame": [round(1e3 * f[0], 3) for f in frames],
            "max_over_median_frame": frame_spread([f[0] for f in frames[1:]], [f[1] for f in frames[1:]])[0],
            "binding_over_quiet_frame": frame_spread([f[0] for f in frames[1:]], [f[1] for f in frames[1:]])[1],
