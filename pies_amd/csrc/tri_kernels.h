@@ -18,8 +18,8 @@ namespace pies {
 // searching triangle looks at every cell a partner's minimum corner can lie in (its own range, grown downwards by the longest
 // range inserted - 1): the same pairs, each met once, and the number of cells they share - which the reference's list repeats
 // a hit by - is the volume of the two ranges' intersection.  Three size classes keep the window small when a few triangles are
-// much longer than the rest: class k has cells of 2^kTriLevelShift[k] world cells and takes the triangles whose range spans at most
-// kTriLevelExt of them per axis (the last class takes every insertable triangle: 50 world cells are 5 cells of 16).  Cells are
+// much longer than the rest: class k has cells of 1, 4 and 16 world cells (TriGridLevel::shift) and takes the triangles whose range spans
+// at most kTriLevelExt of them per axis (the last class takes every insertable triangle: 50 world cells are 5 cells of 16).  Cells are
 // slots of a table indexed by the cell coordinates modulo the table's (power-of-two) dimensions: two cells far apart may
 // share a slot, which only adds candidates that the exact range test drops.
 constexpr uint32_t kTriInsertMaxCells = 50, kTriSearchMaxCells = 20;
