@@ -378,6 +378,13 @@ def test_triangle_soup_contact_lists_equal_the_oracles(pies, oracle, seed):
     run_soup(pies, oracle, seed)
 
 
+def test_triangle_soup_in_the_contact_heavy_graph_variant(pies, oracle, tune):
+    """The same soup with the graph variant for many contacts pinned (list offsets, list and incidence chain as launches of their
+    own - k_tri_scan, k_tri_emit over the whole grid, k_inc_* - instead of the single-workgroup k_tri_tail)."""
+    tune("PIES_TRI_FAST_ROWS", "1")
+    run_soup(pies, oracle, 15)
+
+
 def run_soup(pies, oracle, seed):
     """The broad phase lists every triangle once (minimum-corner cell, three size classes, slots modulo the table: tri_kernels.h)
     where the reference lists it in every cell of its range; the contact list must come out the same, entry for entry, duplicates
