@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """k_layer's time by segment kind (experimental build with PIES_EXP_LAYER_SKIP, scratch/exp/libpies_exp.so): config 2 with the
-distance / tetrahedral segments skipped - results are wrong by construction, only the timing counts."""
+distance / tetrahedral segments skipped - results are wrong by construction, only the timing counts.  The library is built by hand,
+never by build.py:
+  mkdir -p scratch/exp && hipcc -c pies_amd/csrc/layer_kernels.hip -o scratch/exp/layer_kernels.hip.o -O3 -std=c++17 -fPIC \
+      -ffp-contract=off -fno-fast-math -I include --offload-arch=gfx950 -DPIES_EXPERIMENTS
+  hipcc -shared -o scratch/exp/libpies_exp.so $(ls pies_amd/lib/obj/*.o | grep -v layer_kernels.hip.o) scratch/exp/layer_kernels.hip.o \
+      --offload-arch=gfx950"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "benchlib")):
