@@ -345,20 +345,21 @@ void enqueue_pd_substep(pies_solver* s, int only, uint32_t* counts, uint64_t* un
   // the statistics of the substep's last solve are closed by an extra workgroup of the floor-snap launch when there is one
   const bool statsInStabilize = only < 0 && s->opt.collisionStabilizationIterations > 0 && s->opt.iterations > 0 && s->nd.n != 0;
   if (tri && only < 0) {  // Solver.cpp:240, 245-248: detection, contact list, their blocks of the system matrix
+    const char* side = tuning_env("PIES_TRI_SIDE");  // diagnostics: 0 = always in line, 1 = always beside
+    s->triLevelsForked = side ? side[0] != '0' : s->triFastRows;
+    const bool levelsInLine = !s->triLevelsForked && pd.cg.useCAp == 0;  // the contact-light variant computes them with the list
     launch_tri_detect(st, pd.tri, s->nd, pd.kdiag, pd.cg.cdiag, pd.cg.dinv, s->opt.collisionThresholdDistance, s->opt.collisionThickness,
-                      pd.cg.useCAp != 0);
+                      pd.cg.useCAp != 0, levelsInLine);
     // The dependency levels of the list (one workgroup, up to 1 ms with tens of thousands of contacts) are only needed by
     // the sequential passes behind the local/global iterations: a second branch of the substep, joined there.
     // Only in the contact-heavy graph variant: a fork and join inside a hipGraph costs about 100 us per replay (measured:
     // config 3, no contact, 1 257 -> 1 120 substeps/s with the branch; 29k contacts, 197 -> 234 with it).
-    const char* e = tuning_env("PIES_TRI_SIDE");  // diagnostics: 0 = always in line, 1 = always beside
-    s->triLevelsForked = e ? e[0] != '0' : s->triFastRows;
     if (s->triLevelsForked) {
       (void)hipEventRecord(s->evFork, st);
       (void)hipStreamWaitEvent(s->sideStream, s->evFork, 0);
       launch_tri_levels(s->sideStream, pd.tri);
       (void)hipEventRecord(s->evJoin, s->sideStream);
-    } else {
+    } else if (!levelsInLine) {
       launch_tri_levels(st, pd.tri);
     }
   }

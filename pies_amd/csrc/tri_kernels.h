@@ -104,8 +104,10 @@ constexpr uint32_t kTriMaxLevels = 2048;  // longer chains (one node in thousand
 struct PdArrays;
 
 // after the predict kernel: grid build, detection (pairs + hit records, scan, contact list), per-node incidence + diagonal; returns launches
+// (levelsInLine, contact-light variant only: the dependency levels of the list are computed by the same launch as the list -
+// launch_tri_levels must not be called for that substep)
 uint32_t launch_tri_detect(hipStream_t st, const TriArrays& T, const NodeArrays& nd, const float* kdiag, float* cdiag, float* dinv,
-                           float threshold, float thickness, bool mergedRows);
+                           float threshold, float thickness, bool mergedRows, bool levelsInLine);
 // dependency levels of the contact list for the sequential passes (may run on another stream beside the local/global iterations)
 void launch_tri_levels(hipStream_t st, const TriArrays& T);
 void launch_pd_local_tri(hipStream_t st, const TriArrays& T, const float4* pos, float thickness);

@@ -783,15 +783,14 @@ __global__ void __launch_bounds__(1024) k_inc_all(TriArrays T, const float* __re
 }
 // The graph variant for substeps with few or no contacts: the offsets of the contact list, the list and the incidence chain by
 // ONE workgroup (three launches fewer; a substep without a hit record - the usual one - leaves at the first line).
-__global__ void __launch_bounds__(1024) k_tri_tail(TriArrays T, const float* __restrict__ kdiag, float* __restrict__ cdiag, float* __restrict__ dinv,
-                                                   uint32_t words) {
-  __shared__ uint32_t part[1024];
+PIES_DEV bool tri_tail(const TriArrays& T, const float* __restrict__ kdiag, float* __restrict__ cdiag, float* __restrict__ dinv, uint32_t words,
+                       uint32_t* part) {  // (a workgroup of 1024; part: 1024 words of LDS; false: no contact list in this substep)
   if (T.counters[9] == 0u) {
     if (threadIdx.x == 0u) T.counters[2] = 0u;
-    return;
+    return false;
   }
   const uint32_t total = tri_scan(T, part);
-  if (total > T.maxContacts || T.counters[3]) return;  // (latched: the tick ends as a failure)
+  if (total > T.maxContacts || T.counters[3]) return false;  // (latched: the tick ends as a failure)
   step_boundary();
   tri_emit(T, threadIdx.x, 1024u);
   step_boundary();
@@ -804,6 +803,12 @@ __global__ void __launch_bounds__(1024) k_tri_tail(TriArrays T, const float* __r
   inc_fill(T, threadIdx.x, 1024u);
   step_boundary();
   inc_sort(T, threadIdx.x >> 6, 16u);
+  return true;
+}
+__global__ void __launch_bounds__(1024) k_tri_tail(TriArrays T, const float* __restrict__ kdiag, float* __restrict__ cdiag, float* __restrict__ dinv,
+                                                   uint32_t words) {
+  __shared__ uint32_t part[1024];
+  tri_tail(T, kdiag, cdiag, dinv, words, part);
 }
 
 // ---- merged contact rows -------------------------------------------------------------------------------------
@@ -1125,7 +1130,7 @@ PIES_DEV void levels_by_node_owners(const TriArrays& T, uint32_t* heads32, uint3
   }
 }
 
-__global__ void __launch_bounds__(kSeqBlock) k_tri_levels(TriArrays T, int ldsForm) {
+PIES_DEV void tri_levels(const TriArrays& T, int ldsForm) {  // (a workgroup of kSeqBlock)
   __shared__ __align__(16) uint32_t raw[(kTriMaxLevels + 1) + kLevelsLdsCap / 2 + 8];
   static_assert(sizeof(raw) >= kLvMaxContacts + 64, "heads[] of the fast path must fit");
   __shared__ int sMaxLevel;
@@ -1234,6 +1239,17 @@ __global__ void __launch_bounds__(kSeqBlock) k_tri_levels(TriArrays T, int ldsFo
   for (int b = tid; b <= levels; b += kSeqBlock) T.lvStart[b] = hist[b];
   __syncthreads();
   for (uint32_t c = tid; c < M; c += kSeqBlock) T.lvOrder[atomicAdd(&hist[level_of(c)], 1u)] = c;  // any order inside a level
+}
+__global__ void __launch_bounds__(kSeqBlock) k_tri_levels(TriArrays T, int ldsForm) { tri_levels(T, ldsForm); }
+// The contact-light graph variant, levels in line: list offsets, list, incidence chain and dependency levels by ONE workgroup (a
+// substep without a hit record leaves at the first line; k_tri_box has zeroed what the levels would report).
+static_assert(kSeqBlock == 1024, "k_tri_tail_levels runs the tail's steps and the levels with one workgroup size");
+__global__ void __launch_bounds__(1024) k_tri_tail_levels(TriArrays T, const float* __restrict__ kdiag, float* __restrict__ cdiag, float* __restrict__ dinv,
+                                                          uint32_t words, int ldsForm) {
+  __shared__ uint32_t part[1024];
+  if (!tri_tail(T, kdiag, cdiag, dinv, words, part)) return;
+  step_boundary();
+  tri_levels(T, ldsForm);
 }
 
 // A sequential pass over the contact list (stabilisation or friction), level by level: the contacts of a level share no
@@ -1407,8 +1423,12 @@ __global__ void __launch_bounds__(kSeqBlock) k_tri_sequential(TriArrays T, float
 }
 
 // ------------------------------------------------------------------------------------------------------------
+static int tri_lds_form() {
+  const char* e = tuning_env("PIES_TRI_LDS");  // diagnostics, read when the substep is captured: 0 = sequential passes through L2
+  return e && e[0] == '0' ? 0 : 1;
+}
 uint32_t launch_tri_detect(hipStream_t st_, const TriArrays& T, const NodeArrays& nd, const float* kdiag, float* cdiag, float* dinv,
-                           float threshold, float /*thickness*/, bool mergedRows) {
+                           float threshold, float /*thickness*/, bool mergedRows, bool levelsInLine) {
   if (T.nt == 0) return 0;
   const dim3 wide(std::min<uint32_t>(1024u, (T.nt * 8 + kBlock - 1) / kBlock)), blk(kBlock);
   hipLaunchKernelGGL(k_tri_box, grid_for(T.nt), blk, 0, st_, T, nd.pos, nd.prev);
@@ -1421,6 +1441,10 @@ uint32_t launch_tri_detect(hipStream_t st_, const TriArrays& T, const NodeArrays
   else hipLaunchKernelGGL((k_tri_pairs<kTriTeam>), grid_for(T.nt * kTriTeam), blk, 0, st_, T, nd.pos, nd.prev, threshold);
   hipLaunchKernelGGL(k_tri_ccd, dim3(1024), blk, 0, st_, T, nd.pos, nd.prev, threshold);  // (a multiple of kWorkShards)
   if (!mergedRows) {  // the variant for substeps with few or no contacts: list offsets, list and incidence chain as one launch of one workgroup
+    if (levelsInLine) {  // ... and the dependency levels with them (launch_tri_levels is not called then)
+      hipLaunchKernelGGL(k_tri_tail_levels, dim3(1), dim3(1024), 0, st_, T, kdiag, cdiag, dinv, (nd.n + 31u) / 32u, tri_lds_form());
+      return 6;
+    }
     hipLaunchKernelGGL(k_tri_tail, dim3(1), dim3(1024), 0, st_, T, kdiag, cdiag, dinv, (nd.n + 31u) / 32u);
     return 6;
   }
@@ -1441,9 +1465,7 @@ uint32_t launch_tri_detect(hipStream_t st_, const TriArrays& T, const NodeArrays
 }
 void launch_tri_levels(hipStream_t st_, const TriArrays& T) {
   if (T.nt == 0) return;
-  const char* e = tuning_env("PIES_TRI_LDS");  // diagnostics, read when the substep is captured: 0 = sequential passes through L2
-  const int ldsForm = e && e[0] == '0' ? 0 : 1;
-  hipLaunchKernelGGL(k_tri_levels, dim3(1), dim3(kSeqBlock), 0, st_, T, ldsForm);
+  hipLaunchKernelGGL(k_tri_levels, dim3(1), dim3(kSeqBlock), 0, st_, T, tri_lds_form());
 }
 void launch_pd_local_tri(hipStream_t st_, const TriArrays& T, const float4* pos, float thickness) {
   if (T.nt == 0) return;
