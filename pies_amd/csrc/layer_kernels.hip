@@ -325,7 +325,12 @@ void launch_layer(hipStream_t st, const NodeArrays& nd, const LayerData& D, cons
   if (variant == 1) { hipLaunchKernelGGL((k_layer<256, 1>), dim3(L.groups), dim3(256), lds, st, nd, D, L, P); return; }  // no SVD
 #endif
   const uint32_t forceBlock = [] { const char* e = tuning_env("PIES_LAYER_BLOCK"); return e ? (uint32_t)atoi(e) : 0u; }();  // speed only
-  const uint32_t want = forceBlock ? forceBlock : L.maxClass;
+  // A workgroup as wide as the launch's largest colour class runs every colour in one round - what counts while the launch has
+  // fewer tiles than the chip has compute units (config 2: 125).  With more tiles than compute units (strips: 400 at 1M particles)
+  // throughput counts: a workgroup of 1 024 threads leaves the unit to itself and its barriers idle, two of 512 hide each other's
+  // (measured at 1M particles: 162 substeps/s with the class-wide choice, 187 with 512 throughout, 174 with 256, 138 with 1 024).
+  uint32_t want = forceBlock ? forceBlock : L.maxClass;
+  if (!forceBlock && L.groups > 256u) want = std::min<uint32_t>(want, 512u);  // (256 compute units)
   if (want <= 256) hipLaunchKernelGGL((k_layer<256, 0>), dim3(L.groups), dim3(256), lds, st, nd, D, L, P);
   else if (want <= 512) hipLaunchKernelGGL((k_layer<512, 0>), dim3(L.groups), dim3(512), lds, st, nd, D, L, P);
   else hipLaunchKernelGGL((k_layer<1024, 0>), dim3(L.groups), dim3(1024), lds, st, nd, D, L, P);
