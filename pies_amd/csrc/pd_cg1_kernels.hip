@@ -59,7 +59,7 @@ template <class F> PIES_DEV void row_entries(const CgArrays& A, uint32_t sl, uin
 template <bool RHS>
 __global__ void __launch_bounds__(kBlock) k_cg1_init(CgArrays A, const float4* __restrict__ x, const float4* __restrict__ f, RhsArrays R,
                                                      const float* __restrict__ prevPart) {
-  if (blockIdx.x == A.nparts) {
+  if (blockIdx.x == A.npartsI) {
     if (prevPart) solve_statistics(A, prevPart);
     if (threadIdx.x == 0) {
       A.scal[10] = 0.0f;
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(kBlock) k_cg1_init(CgArrays A, const float4* _
     return;
   }
   const uint32_t lane = threadIdx.x & 63u;
-  const SliceSweep sw = slice_sweep<1>(A.n, A.nparts);
+  const SliceSweep sw = slice_sweep<1>(A.n, A.npartsI);
   float acc9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   Vec3f* __restrict__ t0 = A.t1[0];
   for (uint32_t sl = sw.begin; sl < sw.end; sl += sw.step) {
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(kBlock) k_cg1_init(CgArrays A, const float4* _
 // a_0 = D^-1 w_0, w_0 = (K + C) t_0 ; part1[0] = {., w_0.t_0, .}.  Also the solve's first look at the residual.
 __global__ void __launch_bounds__(kBlock) k_cg1_first(CgArrays A, float tol2) {
   float red[9];
-  block_reduce_partials<9>(A.partI, 9, A.nparts, red);
+  block_reduce_partials<9>(A.partI, 9, A.npartsI, red);
   const float rr[3] = {red[3], red[4], red[5]}, bb[3] = {red[6], red[7], red[8]};
   if (blockIdx.x == 0 && threadIdx.x == 0) {
 #pragma unroll
@@ -331,10 +331,10 @@ void launch_pd_solve1(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, 
   const RhsArrays R = rhs_arrays(nd, pd);
   if (fuseRhs) {
     if (hook) hook(hookCtx, 13);  // PIES_KERNEL_PD_RHS: the residual kernel that evaluates the right-hand side
-    hipLaunchKernelGGL(k_cg1_init<true>, dim3(A.nparts + 1u), block, 0, st, A, nd.pos, pd.rhs, R, prev);
+    hipLaunchKernelGGL(k_cg1_init<true>, dim3(A.npartsI + 1u), block, 0, st, A, nd.pos, pd.rhs, R, prev);
     if (hook) hook(hookCtx, 13);
   } else {
-    hipLaunchKernelGGL(k_cg1_init<false>, dim3(A.nparts + 1u), block, 0, st, A, nd.pos, pd.rhs, R, prev);
+    hipLaunchKernelGGL(k_cg1_init<false>, dim3(A.npartsI + 1u), block, 0, st, A, nd.pos, pd.rhs, R, prev);
   }
   hipLaunchKernelGGL(k_cg1_first, grid, block, 0, st, A, tol2);
   for (int it = 1; it <= iters; ++it) {

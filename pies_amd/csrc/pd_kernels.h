@@ -9,6 +9,7 @@
 namespace pies {
 
 constexpr uint32_t kCgRowBlocks = 256;  // extra blocks of k_cg_ap that sum the contact rows (graph variant useCAp)
+constexpr uint32_t kCgInitBlocks = 4096;  // most workgroups of k_cg1_init (CgArrays::npartsI; partI holds that many partials)
 constexpr uint32_t kCgBlocks = 1024;  // CG launch shape: <= 1024 blocks x 256 threads (4 per CU), grid-stride
 
 // One contribution record: w * (A^T B p)_i, packed to 12 bytes (global_load/store_dwordx3).
@@ -19,6 +20,8 @@ struct Vec3f {
 struct CgArrays {
   uint32_t n;
   uint32_t nparts;  // blocks per CG launch (<= kCgBlocks)
+  uint32_t npartsI; // blocks of the launch that writes partI (the one-launch-per-iteration form's k_cg1_init: no grid barrier,
+                    // so not bound by what the device holds at once; = nparts everywhere else)
   // K in sliced ELL form: a slice is one wavefront's rows, 64 / lanesPerRow of them; lane L = lanesPerRow * r + q of the slice
   // takes entries q, q + lanesPerRow, ... of its row r, entry step j of the slice sits at sliceOff[s] + 64 j + L, so a
   // wavefront's loads of col/val are contiguous.  Rows are padded to the slice's longest row with (col = the row itself, val = 0).
