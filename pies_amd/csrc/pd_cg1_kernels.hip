@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(kBlock) k_cg1_first(CgArrays A, float tol2) {
     return;
   }
   const uint32_t lane = threadIdx.x & 63u;
-  const SliceSweep sw = slice_sweep<1>(A.n, A.nparts);
+  const SliceSweep sw = slice_sweep<1>(A.n, gridDim.x);
   const Vec3f* __restrict__ t0 = A.t1[0];
   Vec3f* __restrict__ a0 = A.a1[0];
   float acc[3] = {0, 0, 0};
@@ -153,6 +153,7 @@ __global__ void __launch_bounds__(kBlock) k_cg1_first(CgArrays A, float tol2) {
     }
   }
   block_write_partial<3>(acc, A.part1[0] + 3, 9);
+  if (blockIdx.x == 0 && threadIdx.x == 0) A.partCount[2] = gridDim.x;
 }
 
 // The rows of iteration `it` (the it-th update of x, it >= 1) for this workgroup's slices, given alpha_{it-1} and beta_{it-1}:
@@ -182,7 +183,7 @@ PIES_DEV void cg1_rows(const CgArrays& A, float4* __restrict__ x, int it, const 
     renew(j, ux, uy, uz, cx, cy, cz);
   };
   const uint32_t lane = threadIdx.x & 63u;
-  const SliceSweep sw = slice_sweep<1>(A.n, A.nparts);
+  const SliceSweep sw = slice_sweep<1>(A.n, gridDim.x);
   for (uint32_t sl = sw.begin; sl < sw.end; sl += sw.step) {
     const uint32_t i = sl * 64u + lane;
     float sx = 0.f, sy = 0.f, sz = 0.f;
@@ -245,14 +246,14 @@ __global__ void __launch_bounds__(kBlock) k_cg1_iter(CgArrays A, float4* __restr
 #pragma unroll
   for (int c = 0; c < 3; ++c) bb[c] = A.scal[6 + c];
   if (FIRST) {
-    block_reduce_partials<3>(A.part1[0] + 3, 9, A.nparts, red + 3);
+    block_reduce_partials<3>(A.part1[0] + 3, 9, A.partCount[2], red + 3);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       gam[c] = A.scal[c];
       alpha[c] = red[3 + c] > 0.0f ? gam[c] / red[3 + c] : 0.0f;
     }
   } else {
-    block_reduce_partials<9>(A.part1[(it - 1) & 1], 9, A.nparts, red);
+    block_reduce_partials<9>(A.part1[(it - 1) & 1], 9, A.partCount[(it - 1) & 1], red);
     const float rr[3] = {red[6], red[7], red[8]};
     if (all_converged(rr, bb, tol2)) {
       if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -281,6 +282,7 @@ __global__ void __launch_bounds__(kBlock) k_cg1_iter(CgArrays A, float4* __restr
   float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   cg1_rows<FIRST>(A, x, it, alpha, beta, acc);
   block_write_partial<9>(acc, A.part1[it & 1], 9);
+  if (blockIdx.x == 0 && threadIdx.x == 0) A.partCount[it & 1] = gridDim.x;
   if (overflow <= 0) return;
   // ---- the iterations beyond the captured ones ----------------------------------------------------------------------
   uint32_t passed = 0;
@@ -290,7 +292,7 @@ __global__ void __launch_bounds__(kBlock) k_cg1_iter(CgArrays A, float4* __restr
 #pragma unroll
     for (int c = 0; c < 3; ++c) { gamOld[c] = gam[c]; alphaOld[c] = alpha[c]; }
     if (!grid_barrier(A.ticket, gridDim.x, passed)) return;  // the partials of iteration kk are complete
-    block_reduce_partials<9>(A.part1[kk & 1], 9, A.nparts, red);
+    block_reduce_partials<9>(A.part1[kk & 1], 9, gridDim.x, red);
     const float rr[3] = {red[6], red[7], red[8]};
     if (all_converged(rr, bb, tol2) || kk >= it + overflow) break;
 #pragma unroll
@@ -301,6 +303,7 @@ __global__ void __launch_bounds__(kBlock) k_cg1_iter(CgArrays A, float4* __restr
     for (int c = 0; c < 9; ++c) acc[c] = 0.0f;
     cg1_rows<false>(A, x, kk, alpha, beta, acc);
     block_write_partial<9>(acc, A.part1[kk & 1], 9);
+    if (blockIdx.x == 0 && threadIdx.x == 0) A.partCount[kk & 1] = gridDim.x;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     A.scal[9] = static_cast<float>(kk);
@@ -325,7 +328,10 @@ void launch_pd_solve1(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, 
   A.single = 1;
   A.tol2 = tol * tol;
   const float tol2 = neverExit ? -1.0f : tol * tol;
-  const dim3 grid(A.nparts), block(kBlock);
+  // The launches of a solve are as wide as the rows ask for (npartsI) - except the last one: its continuation synchronises its
+  // workgroups with a grid barrier and may only be as wide as the device holds at once (nparts).  Every launch notes its width with
+  // its partial sums (partCount).
+  const dim3 wide(A.npartsI), narrow(A.nparts), block(kBlock);
   // every solve of a substep captures the same number of launches, so the previous solve's last one left its partials here
   const float* prev = first ? nullptr : A.part1[iters & 1];
   const RhsArrays R = rhs_arrays(nd, pd);
@@ -336,10 +342,11 @@ void launch_pd_solve1(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, 
   } else {
     hipLaunchKernelGGL(k_cg1_init<false>, dim3(A.npartsI + 1u), block, 0, st, A, nd.pos, pd.rhs, R, prev);
   }
-  hipLaunchKernelGGL(k_cg1_first, grid, block, 0, st, A, tol2);
+  hipLaunchKernelGGL(k_cg1_first, wide, block, 0, st, A, tol2);
   for (int it = 1; it <= iters; ++it) {
     if (hook) hook(hookCtx, 14);  // PIES_KERNEL_PD_SPMV
     const int overflow = it == iters && !neverExit ? overflowIters : 0;
+    const dim3 grid = overflow > 0 ? narrow : wide;
     if (it == 1) hipLaunchKernelGGL(k_cg1_iter<true>, grid, block, 0, st, A, nd.pos, it, tol2, overflow);
     else hipLaunchKernelGGL(k_cg1_iter<false>, grid, block, 0, st, A, nd.pos, it, tol2, overflow);
     if (hook) hook(hookCtx, 14);

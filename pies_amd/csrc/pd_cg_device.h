@@ -149,7 +149,8 @@ PIES_DEV void solve_statistics(const CgArrays& A, const float* __restrict__ prev
   const int where = static_cast<int>(A.scal[11]);
   if (done && where == 0) block_reduce_partials<6>(A.partI, 9, A.single ? A.npartsI : A.nparts, red);
   else if (A.single) {  // one launch per iteration: {r.t, w.t, r.r} per workgroup, the residual norms in the last three
-    block_reduce_partials<3>((done ? A.part1[where - 1] : prevPartB) + 6, 9, A.nparts, red + 3);
+    const float* last = done ? A.part1[where - 1] : prevPartB;
+    block_reduce_partials<3>(last + 6, 9, A.partCount[last == A.part1[1] ? 1 : 0], red + 3);
   }
   else block_reduce_partials<6>(done ? (where == 1 ? A.partB0 : A.partB1) : prevPartB, 6, A.nparts, red);
   if (threadIdx.x == 0) {

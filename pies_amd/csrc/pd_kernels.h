@@ -20,6 +20,9 @@ struct Vec3f {
 struct CgArrays {
   uint32_t n;
   uint32_t nparts;  // blocks per CG launch (<= kCgBlocks)
+  uint32_t* partCount;  // one-launch-per-iteration form: how many workgroups wrote part1[0], part1[1] and k_cg1_first's three sums in
+                        // part1[0] - the launches of a solve are not all the same width (only the last one, whose continuation
+                        // synchronises its workgroups with a grid barrier, is bound by what the device holds at once)
   uint32_t npartsI; // blocks of the launch that writes partI (the one-launch-per-iteration form's k_cg1_init: no grid barrier,
                     // so not bound by what the device holds at once; = nparts everywhere else)
   // K in sliced ELL form: a slice is one wavefront's rows, 64 / lanesPerRow of them; lane L = lanesPerRow * r + q of the slice

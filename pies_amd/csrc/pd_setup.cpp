@@ -198,10 +198,12 @@ int pd_build(pies_solver* s) {
     const uint32_t resident = std::min(cg_update_resident_blocks(s->device), cg1_iter_resident_blocks(s->device));
     if (resident >= 2) cg.nparts = std::max(1u, std::min(cg.nparts, resident / 2u));
   }
-  // k_cg1_init (one-launch-per-iteration form) has no grid barrier: as many workgroups as the rows ask for, whatever the device
-  // holds at once (1M rows: 1 024 instead of the 512 the continuation's barrier allows - the launch is a gather, and more
-  // wavefronts in flight hide more of it)
-  cg.npartsI = std::max(cg.nparts, std::min(kCgBlocks, (nslices + 3u) / 4u));
+  // The launches of the one-launch-per-iteration form that have no grid barrier (all but a solve's last): as many workgroups as the
+  // rows ask for, whatever the device holds at once (1M rows: 1 024 instead of the 512 the continuation's barrier allows - the
+  // launches are gathers, and more wavefronts in flight hide more of them)
+  // (two rows per thread and more: at 250k rows 977 workgroups were slower than the 512 the barrier allows - every workgroup
+  // re-reduces every workgroup's partial sums - at 1M rows 1 024 are 12 % faster than 512)
+  cg.npartsI = std::max(cg.nparts, std::min(kCgBlocks, (nslices + 7u) / 8u));
   if (const char* e = tuning_env("PIES_CG_INIT_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && v <= (int)kCgInitBlocks) cg.npartsI = static_cast<uint32_t>(v); }
   uint32_t *d_rowptr, *d_col, *d_incPtr, *d_incSlot, *d_tri;
   float *d_val, *d_kdiag;
@@ -328,6 +330,7 @@ int pd_build(pies_solver* s) {
   if (int rc = dev_alloc(s, n, &cg.p[1], true)) return rc;
   if (int rc = dev_alloc(s, n, &cg.ap)) return rc;
   if (int rc = dev_alloc(s, kCgInitBlocks * 9, &cg.partI, true)) return rc;
+  if (int rc = dev_alloc(s, 4, &cg.partCount, true)) return rc;
   if (int rc = dev_alloc(s, (kCgBlocks + kCgRowBlocks) * 3, &cg.partA, true)) return rc;
   if (int rc = dev_alloc(s, kCgBlocks * 6, &cg.partB, true)) return rc;
   if (int rc = dev_alloc(s, kCgBlocks * 6, &cg.partBnext, true)) return rc;
