@@ -507,6 +507,20 @@ bool build_layer_plan(pies_solver* s) {
     if (!attempt(lev, nl, balance, *cands.back())) cands.back()->cost = ~0ull;
   };
   run("breadth-first levels", levelBfs, L1bfs, false);
+  // A plan whose groups are balanced already - no phase of a container runs more colours than half the constraints at that
+  // container's busiest node, + 1 - cannot gain from the other candidates (a lattice: 12 + 12 colours for 24 tetrahedra at a node);
+  // planning a second and a third time is then skipped (1M particles: 5.5 s instead of 13.5 s at finalize)
+  if (want >= 1 && cands[0]->cost != ~0ull && !tuning_env("PIES_LAYER_PLAN_FORCE")) {
+    bool balanced = true;
+    for (int k : linking) {
+      if (ops[k].count == 0) continue;
+      std::vector<uint32_t> deg(N, 0);
+      for (uint32_t v : ops[k].ids) ++deg[v];
+      const uint32_t half = (*std::max_element(deg.begin(), deg.end()) + 1u) / 2u;
+      for (int ph = 0; ph < 4; ++ph) balanced = balanced && cands[0]->L.kind[k].ncol[ph] <= half + 1u;
+    }
+    if (balanced) want = 0;
+  }
   if (want >= 1) run("breadth-first levels, single-level constraints dealt to either group", levelBfs, L1bfs, true);
   if (want >= 2) {
     // slabs along the longest axis, as thick as the longest constraint (times PIES_LAYER_SLAB, default 1): a constraint touches
