@@ -246,6 +246,12 @@ def pd_bytes(solver):
         # k_cg1_iter IS a whole iteration in one launch; k_cg_ap is the SpMV (+ the direction update) of the two-launch form
         "pd_spmv": (8.0 * nnz + (148.0 if single else 28.0) * n) / n,
         "pd_spmv_only": (8.0 * nnz + 28.0 * n) / n,
+        # what the CG-iteration launch has to move in the form it runs in: the ten vector passes (148 N) + the matrix - one word per
+        # row with the row dictionary (the stencils stay in the vector cache), 6 B per stored entry (value + 16-bit window slot, SELL
+        # padding included) + 2 B per halo column with the windowed matrix, 8 B per entry with the SELL arrays
+        "pd_spmv_required": (148.0 * n + (4.0 * n if solver.count(capi.ROW_STENCILS) and not solver.count(capi.PD_WINDOW_ENTRIES) else
+                                          6.0 * solver.count(capi.PD_WINDOW_ENTRIES) + 2.0 * solver.count(capi.PD_WINDOW_HALO)
+                                          if solver.count(capi.PD_WINDOW_ENTRIES) else 8.0 * nnz)) / n,
         "pd_cg_update": 120,                     # the PCG iteration's 10 three-component vector passes
         "pd_velocity": 60,
     }
@@ -272,6 +278,13 @@ def pd_rooflines(g, workload, substeps):
         "SELL-64 SpMV over 3 right-hand sides + fused direction update; 8 nnz + 28 N bytes per launch (SURVEY 8d)"))
     if sp:
         sp["frac_spmv_bytes_only"] = sp["frac"] * B["pd_spmv_only"] / B["pd_spmv"]
+        # the same launch priced by the bytes its form of the matrix really has to move (the row dictionary streams no matrix)
+        sp["frac_required_bytes"] = sp["frac"] * B["pd_spmv_required"] / B["pd_spmv"]
+        sp["required_bytes_per_row"] = B["pd_spmv_required"]
+        sp["matrix_form"] = ("row dictionary (%d stencils)" % g.count(capi.ROW_STENCILS) if g.count(capi.ROW_STENCILS) and not g.count(capi.PD_WINDOW_ENTRIES)
+                             else "windowed SELL (%.3f stored entries per matrix entry, %.2f halo columns per row)" % (
+                                 g.count(capi.PD_WINDOW_ENTRIES) / max(1, g.count(capi.SYSTEM_NNZ)), g.count(capi.PD_WINDOW_HALO) / max(1, g.count(capi.NODES)))
+                             if g.count(capi.PD_WINDOW_ENTRIES) else "SELL-64")
     out["roofline_spmv"] = sp
     out["roofline_rhs"] = roofline(g, "pd_rhs", B["pd_rhs"], substeps=substeps, workload=workload, note=(
         "the residual kernel of the one-launch CG, which also evaluates the right-hand side (inertia term + the node's 3-4 tile sums "
@@ -807,6 +820,29 @@ def scale_profiles(device, with_coloured=True):
     if not g.count(capi.PD_CG_SINGLE):
         out["pd_1m"]["roofline_cg_update"] = roofline(g, "pd_cg_update", pd_bytes(g)["pd_cg_update"], substeps=1, workload="pd1m")
     g.close()
+    # the same body with the row dictionary off: the lattice streams its matrix like an unstructured mesh does (windowed SELL)
+    log("pd_1m_streamed")
+    capi.set_tuning("PIES_PD_ROW_DICT", "0")
+    try:
+        g = pd_beam(scenes.L1M, device, settle=12)
+        el = timed_ticks(g, 5, 1, lambda: None)
+        out["pd_1m_streamed"] = {"substeps_per_sec": 5 / el, "pcg_health": g.pcg_health(), "row_stencils": g.count(capi.ROW_STENCILS),
+                                 "launches_per_substep": sum(g.launch_counts().values()),
+                                 "note": "PIES_PD_ROW_DICT=0: no row shares its stencil with another, the CG iterations stream the matrix"}
+        B = pd_bytes(g)
+        sp = roofline(g, "pd_spmv", B["pd_spmv"], substeps=1, workload="pd1m_streamed", note=(
+            "k_cg1_iter with the matrix streamed (windowed SELL: value + 16-bit window slot per entry, a chunk's columns staged in LDS "
+            "once): SURVEY 8d's 8 nnz + 148 N bytes per launch; frac_required_bytes prices the launch by what this form has to move"))
+        if sp:
+            sp["frac_spmv_bytes_only"] = sp["frac"] * B["pd_spmv_only"] / B["pd_spmv"]
+            sp["frac_required_bytes"] = sp["frac"] * B["pd_spmv_required"] / B["pd_spmv"]
+            sp["required_bytes_per_row"] = B["pd_spmv_required"]
+            if sp.get("rocprofv3_avg_us"):
+                sp["frac_rocprofv3"] = sp["bytes_per_launch"] / (sp["rocprofv3_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+        out["pd_1m_streamed"]["roofline_spmv"] = sp
+        g.close()
+    finally:
+        capi.set_tuning("PIES_PD_ROW_DICT", None)
     return out
 
 
@@ -877,6 +913,11 @@ def compact_line(full):
     put("pd_1m_frac_spmv", "scale_1m", "pd_1m", "roofline_spmv", "frac_spmv_bytes_only")
     put("pd_1m_frac_pcg_iter", "scale_1m", "pd_1m", "roofline_spmv", "frac")
     put("pd_1m_frac_rhs", "scale_1m", "pd_1m", "roofline_rhs", "frac")
+    put("pd_1m_frac_pcg_iter_required", "scale_1m", "pd_1m", "roofline_spmv", "frac_required_bytes")
+    put("pd_1m_streamed_value", "scale_1m", "pd_1m_streamed", "substeps_per_sec")
+    put("pd_1m_streamed_frac_pcg_iter", "scale_1m", "pd_1m_streamed", "roofline_spmv", "frac")
+    put("pd_1m_streamed_frac_required", "scale_1m", "pd_1m_streamed", "roofline_spmv", "frac_required_bytes")
+    put("pd_1m_streamed_frac_rocprofv3", "scale_1m", "pd_1m_streamed", "roofline_spmv", "frac_rocprofv3")
     put("unstructured_value", "other_configs", "unstructured_config2", "layered", "value")
     put("unstructured_pd_value", "other_configs", "unstructured_config2", "pd", "value")
     put("unstructured_pd_frac_pcg_iter", "other_configs", "unstructured_config2", "pd", "roofline_spmv", "frac")

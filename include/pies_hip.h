@@ -77,7 +77,10 @@ enum {
   PIES_ROW_STENCILS = 12, /* pies_count only: distinct rows in the row dictionary of the PD system matrix (0: SELL arrays only) */
   PIES_PD_TILES = 13,     /* pies_count only: tiles of the PD strain + volume local step (0: one record per (element, node)) */
   PIES_PD_TILE_RECORDS = 14, /* pies_count only: (tile, node) sums the right-hand side gathers */
-  PIES_PD_CG_SINGLE = 15  /* pies_count only: 1 when the captured global step runs one launch per CG iteration */
+  PIES_PD_CG_SINGLE = 15, /* pies_count only: 1 when the captured global step runs one launch per CG iteration */
+  PIES_PD_WINDOW_ENTRIES = 16, /* pies_count only: stored entries (padding included) of the windowed system matrix the CG iterations
+                                  stream - value + 16-bit window slot each -, 0: not built (row dictionary, or the SELL arrays) */
+  PIES_PD_WINDOW_HALO = 17     /* pies_count only: its halo entries over all chunks (columns staged in LDS besides a chunk's own rows) */
 };
 
 /* How the sequential Gauss-Seidel sweeps of tickPBD (Solver.cpp:58-75) are mapped to the device.
@@ -293,6 +296,11 @@ int pies_get_ids(const pies_solver_t* s, int type, uint32_t* out, uint32_t capac
 int pies_get_group(const pies_solver_t* s, int type, uint32_t index, uint32_t* ids, uint32_t capacity, uint32_t* count);
 /* rest data in host order: DISTANCE target (1), TET/VOLUME Qinv column-major (9), BEND angle (1) */
 int pies_get_rest(const pies_solver_t* s, int type, float* out, uint32_t capacity);
+/* replaces the rest data of constraints [first, first + n) of a container (same layout as pies_get_rest; TET / VOLUME: A and AtA follow
+ * from the new Qinv).  The reference's factories take the rest pose from the node positions at creation (Src/Constraints.cpp:39-56,
+ * 130-184, 257-310, 368-394); this is the bulk raw ingestion of SURVEY 8b ("distance (ids, rest, w) ... tet/volume (ids, Qinv,
+ * params, w)") for hosts that restore a saved scene. */
+int pies_set_rest(pies_solver_t* s, int type, uint32_t first, uint32_t n, const float* rest);
 /* Execution order of a container under the current schedule: order[slot] = index in host order.
  * batch_offsets (may be NULL) receives n_batches+1 slot offsets; batches run one after another. */
 int pies_get_order(pies_solver_t* s, int type, uint32_t* order, uint32_t capacity);

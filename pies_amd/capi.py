@@ -31,6 +31,7 @@ ROW_STENCILS = 12
 PD_TILES = 13
 PD_TILE_RECORDS = 14
 PD_CG_SINGLE = 15
+PD_WINDOW_ENTRIES, PD_WINDOW_HALO = 16, 17
 
 # every symbol include/pies_hip.h declares (checked by tests/test_capi_symbols.py against the header)
 SYMBOLS = [
@@ -47,7 +48,7 @@ SYMBOLS = [
     "pies_get_tri_contacts", "pies_tick_begin", "pies_export_acquire", "pies_export_release",
     "pies_read_positions_strided", "pies_set_pcg_retry", "pies_get_pcg_health", "pies_profile_in_situ",
     "pies_collision_stats", "pies_get_collision_health", "pies_set_collision_rounds", "pies_set_solver", "pies_debug_pair_state", "pies_set_tuning",
-    "pies_get_pd_tile_plan", "pies_get_tri_grid_stats",
+    "pies_get_pd_tile_plan", "pies_get_tri_grid_stats", "pies_set_rest",
 ]
 
 
@@ -118,6 +119,7 @@ def load():
         "pies_count": [vp, i32, pu],
         "pies_read_nodes": [vp, i32, pf, u32], "pies_write_nodes": [vp, i32, pf, u32],
         "pies_get_ids": [vp, i32, pu, u32], "pies_get_rest": [vp, i32, pf, u32],
+        "pies_set_rest": [vp, i32, u32, u32, pf],
         "pies_get_order": [vp, i32, pu, u32], "pies_get_batches": [vp, i32, pu, u32, pu],
         "pies_profile_substep": [vp, i32, pu, C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
         "pies_launch_counts": [vp, pu],
@@ -482,6 +484,12 @@ class Solver:
         out = np.empty((n, k) if k > 1 else (n,), dtype=np.float32)
         self._ck(self._L.pies_get_rest(self._h, ctype, _pf(out), out.size))
         return out
+
+    def set_rest(self, ctype, rest, first=0):
+        """pies_set_rest: rest data of constraints first .. of a container (DISTANCE target, TET / VOLUME Qinv column-major, BEND angle)"""
+        r = np.ascontiguousarray(rest, dtype=np.float32)
+        n = r.size // _REST_PER[ctype]
+        self._ck(self._L.pies_set_rest(self._h, ctype, first, n, _pf(r)))
 
     def order(self, ctype):
         out = np.empty(self.count(ctype), dtype=np.uint32)

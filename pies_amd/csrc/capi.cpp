@@ -582,6 +582,7 @@ int pies_finalize(pies_solver_t* s) {
       if (int rc = dev_alloc(s, 4ull * n, &P.node, true)) return rc;
       if (int rc = dev_alloc(s, n, &P.vel0)) return rc;
       if (int rc = dev_alloc(s, n, &P.exc, true)) return rc;
+      if (int rc = dev_alloc(s, n, &P.turnCnt, true)) return rc;
       if (int rc = dev_alloc(s, static_cast<size_t>(P.poolCap) * kPairPools, &P.nbr)) return rc;
       if (!s->collideFast)  // ranges wider than two cells per axis: the shared-cell count of an entry does not fit its four bits
         if (int rc = dev_alloc(s, static_cast<size_t>(P.poolCap) * kPairPools, &P.nbrM)) return rc;
@@ -1019,6 +1020,8 @@ int pies_count(const pies_solver_t* s, int what, uint32_t* out) {
     case PIES_PD_TILES: *out = s->pd.tiles.ntiles; break;
     case PIES_PD_TILE_RECORDS: *out = s->pd.tiles.ntiles ? s->pdTileRecords : 0u; break;
     case PIES_PD_CG_SINGLE: *out = s->opt.solver == PIES_SOLVER_PD && pd_single_cg(s) ? 1u : 0u; break;
+    case PIES_PD_WINDOW_ENTRIES: *out = s->pd.cg.wRows ? s->pdWindowEntries : 0u; break;
+    case PIES_PD_WINDOW_HALO: *out = s->pd.cg.wRows ? s->pdWindowHalo : 0u; break;
     default: return PIES_ERR_INVALID;
   }
   return PIES_OK;

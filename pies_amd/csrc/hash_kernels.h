@@ -54,7 +54,8 @@ constexpr uint32_t kMaxBucket = 2048;  // nodes overlapping one cell before the 
 // rearm: the launch first resets the work queue of k_collide_flow (a replay without a new hash build, profile passes)
 uint32_t launch_collide(hipStream_t st, const HashArrays& H, const NodeArrays& nd, float friction, float staticThreshold, bool rearm = false);
 // the same loop in the reference's order: ascending node index, range from the current position (one sequential chain)
+// gate != nullptr: a device word; the kernel returns at once while it is 0 (the fallback of launch_collide_turns)
 uint32_t launch_collide_reference(hipStream_t st, const HashArrays& H, const NodeArrays& nd, float gridSpacing, float friction,
-                                  float staticThreshold);
+                                  float staticThreshold, const uint32_t* gate = nullptr);
 
 }  // namespace pies

@@ -963,7 +963,8 @@ __global__ void __launch_bounds__(kColBlock) k_collide_flow(HashArrays H, float4
 // pass), buckets are those of the grid built at the start of the iteration, visited in dx, dy, dz order.  The loop is
 // one dependent chain: one wavefront runs it.  Lanes look up to 64 cells of the range at once.
 __global__ void __launch_bounds__(64) k_collide_reference(HashArrays H, float4* pos4, float4* vel4, const float* __restrict__ radius, uint32_t n,
-                                                          float scale, float friction, float staticThreshold) {
+                                                          float scale, float friction, float staticThreshold, const uint32_t* __restrict__ gate) {
+  if (gate && *gate == 0u) return;        // (the fallback of the pass by turns: only when that pass asks for it)
   if (H.counters[kCounterFlags]) return;  // failed: the host latches _simFailed
   float* pos = reinterpret_cast<float*>(pos4);
   float* vel = reinterpret_cast<float*>(vel4);
@@ -1063,9 +1064,10 @@ uint32_t launch_collide(hipStream_t st_, const HashArrays& H, const NodeArrays& 
   return 27;
 }
 
-uint32_t launch_collide_reference(hipStream_t st_, const HashArrays& H, const NodeArrays& nd, float scale, float friction, float staticThreshold) {
+uint32_t launch_collide_reference(hipStream_t st_, const HashArrays& H, const NodeArrays& nd, float scale, float friction, float staticThreshold,
+                                  const uint32_t* gate) {
   if (nd.n == 0) return 0;
-  hipLaunchKernelGGL(k_collide_reference, dim3(1), dim3(64), 0, st_, H, nd.pos, nd.vel, nd.radius, nd.n, scale, friction, staticThreshold);
+  hipLaunchKernelGGL(k_collide_reference, dim3(1), dim3(64), 0, st_, H, nd.pos, nd.vel, nd.radius, nd.n, scale, friction, staticThreshold, gate);
   return 1;
 }
 

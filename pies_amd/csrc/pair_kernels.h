@@ -21,6 +21,8 @@ constexpr uint32_t kPairEdges = 9;      // pairs listed by the last pass (diagno
 constexpr uint32_t kPairDeepest = 12;    // most levels any pass needed since the host last looked (it sizes the captured launches from it)
 constexpr uint32_t kPairGroups = 10;     // groups of this grid (entries of `grp`)
 constexpr uint32_t kPairSpilled = 11;    // groups the small list kernel passed on to the large one (entries of `spill`)
+constexpr uint32_t kPairFallback = 13;   // reference order by turns: the pass could not be proved exact twice - the sequential loop runs it
+constexpr uint32_t kPairFallbacks = 14;  // lifetime: passes the sequential loop had to run
 constexpr uint32_t kPairWords = 16;
 
 constexpr uint32_t kPairLists = 64;     // the frontier is kept as this many sub-lists: a wavefront appends to one of them, so that the
@@ -39,6 +41,8 @@ struct PairArrays {
                            // which the node got there << 16, the current entry itself
   float4 *vel0;            // velocities when the pass started (for the repeat)
   uint32_t *exc;           // per node: how far it has strayed in this pass (float bits)
+  uint32_t byIndex;        // the lists are for the reference order by turns: a node's entries ascending by the partner's INDEX
+  uint32_t *turnCnt;       // reference order by turns: per node, the members of its turn (partners + itself) that are not at it yet
   uint32_t *nbr;           // list entries: other node | (shared cells - 1) << 28, a node's entries ascending by pair key
   uint32_t *nbrM;          // only for scenes with ranges wider than two cells per axis: shared cells of an entry (nbr then holds the node alone)
   float4 *bq;              // per node: position when the grid was built, radius + slack: all the list kernel gathers of a candidate
@@ -57,6 +61,13 @@ struct PairArrays {
 // One pass of Solver.cpp:85-130 in the pair order: save, lists, start, `rounds` level launches, the tail
 // that finishes whatever levels are left, and the (normally skipped) repeat with the widest slack.  Returns the launches.
 uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArrays& P, const NodeArrays& nd, float friction,
+                              float staticThreshold, uint32_t rounds);
+
+// One pass of Solver.cpp:85-130 in the REFERENCE's order - ascending node index, the node's range from its live position, buckets in
+// dx, dy, dz order, every overlapping visit resolved at once - executed by dependency levels of whole TURNS (a node's turn = all of
+// its visits): the turns whose members (the node and the partners within reach) have all had their earlier turns share no node,
+// so a level is one launch.  Same result as k_collide_reference's single chain, bit for bit (see pair_kernels.hip).
+uint32_t launch_collide_turns(hipStream_t st, const HashArrays& H, const PairArrays& P, const NodeArrays& nd, float gridSpacing, float friction,
                               float staticThreshold, uint32_t rounds);
 
 }  // namespace pies

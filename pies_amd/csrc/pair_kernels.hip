@@ -70,6 +70,11 @@ PIES_DEV uint64_t pair_key(uint32_t i, uint32_t j, float pix, float piy, float p
   return (static_cast<uint64_t>(cls) << 58) | (k >> 6);
 }
 
+// The reference order by turns needs every pair within reach to share a cell of the two INSERTED ranges (a node's live range is looked
+// up when its turn starts and may differ from the inserted one; a partner is then met in the cells of the live range its inserted
+// range holds): the ranges cover [p - r - 0.5, p + r + 0.5] per axis (Solver.cpp:877-901), so two nodes whose centres are closer than
+// r_i + r_j + 1 share a cell, and "within reach" is 1.001 (r_i + r_j + s_i + s_j): slacks of at most 0.45 guarantee it (radii up to 50).
+constexpr float kTurnMaxSlack = 0.45f;
 // slack of a node after a pass in which it strayed `exc` from its build-time position
 PIES_DEV float next_slack(float exc, float previous, float r) {
   const float want = fmaxf(2.0f * exc + 0.1f * r, 0.4f * r);
@@ -178,6 +183,7 @@ __global__ void __launch_bounds__(kBlock) k_pair_save(HashArrays H, PairArrays P
     P.ctl[kPairEdges] = 0;
     P.ctl[kPairGroups] = 0;
     P.ctl[kPairSpilled] = 0;
+    P.ctl[kPairFallback] = 0;
   }
   if (i < kPairPools) P.pool[i * kPairPad] = 0;
   if (i < 3u * kPairLists) P.frCount[i * kPairPad] = 0;
@@ -188,15 +194,19 @@ __global__ void __launch_bounds__(kBlock) k_pair_save(HashArrays H, PairArrays P
     const float r = radius[i];
     float sl = P.node[4u * i + 2u].w;
     if (!(sl > 0.0f)) sl = 0.5f * r;  // first pass after pies_finalize
+    if (P.byIndex) sl = fminf(sl, kTurnMaxSlack);
     const float4 p0 = make_float4(p.x, p.y, p.z, sl);
     P.node[4u * i + 2u] = p0;
     P.bq[i] = make_float4(p.x, p.y, p.z, r + sl);
     P.vel0[i] = v;
     P.exc[i] = 0u;
     NodeState a{p.x, p.y, p.z, p.w, v.x, v.y, v.z, r};
-    hits = self_visits(H, P, i, a, p0, friction, staticThreshold);
+    if (!P.byIndex) hits = self_visits(H, P, i, a, p0, friction, staticThreshold);
     store_node(P.node, i, a);
-    store_rec(P.node, i, make_uint4(0u, 0u, 0u, 0u));
+    // (by turns: a node meets itself inside its own turn, at its place in the bucket; a node no list is written for - an empty range -
+    // has its own turn as its only event)
+    store_rec(P.node, i, P.byIndex ? make_uint4(0u, 0u, 0u, i) : make_uint4(0u, 0u, 0u, 0u));
+    if (P.byIndex) P.turnCnt[i] = 1u;
   }
   count_hits(P, hits, lane);
 }
@@ -206,7 +216,10 @@ __global__ void __launch_bounds__(kBlock) k_pair_self(HashArrays H, PairArrays P
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
   uint32_t hits = 0;
-  if (i < P.n) {
+  if (i < P.n && P.byIndex) {  // by turns: the records start over (k_pair_save)
+    store_rec(P.node, i, make_uint4(0u, 0u, 0u, i));
+    P.turnCnt[i] = 1u;
+  } else if (i < P.n) {
     NodeState a = load_node(P.node, i);
     hits = self_visits(H, P, i, a, P.node[4u * i + 2u], friction, staticThreshold);
     if (hits) store_node(P.node, i, a);
@@ -292,12 +305,13 @@ PIES_DEV uint32_t shared_cells(int a0, uint32_t la, int b0, uint32_t lb) {
 // appends the accepted candidates of the wavefront's lanes to the node's partner list in LDS; returns the new length
 template <uint32_t MAXD>
 PIES_DEV uint32_t push_partners(uint64_t* lk, uint32_t* le, uint32_t d, bool accept, uint32_t i, uint32_t j, uint32_t m, float pix, float piy, float piz,
-                                float pjx, float pjy, float pjz, int lane) {
+                                float pjx, float pjy, float pjz, int lane, bool byIndex) {
   const unsigned long long mask = __ballot(accept);
   if (accept) {
     const uint32_t at = d + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
     if (at < MAXD) {
-      lk[at] = i < j ? pair_key(i, j, pix, piy, piz, pjx, pjy, pjz) : pair_key(j, i, pjx, pjy, pjz, pix, piy, piz);
+      // (the reference order by turns walks a node's partners in ascending index: the partner's index is the key)
+      lk[at] = byIndex ? static_cast<uint64_t>(j) : i < j ? pair_key(i, j, pix, piy, piz, pjx, pjy, pjz) : pair_key(j, i, pjx, pjy, pjz, pix, piy, piz);
       le[at] = j | ((m - 1u) << 28);
     }
   }
@@ -334,7 +348,18 @@ PIES_DEV void write_list(const PairArrays& P, const uint64_t* lk, const uint32_t
   // the node's record: first entry, entries, cursor 0 reached in round 0, the current entry itself (from the lane that holds it)
   const unsigned long long who = __ballot(haveFirst);
   const uint32_t v0 = who ? static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(firstEntry), __builtin_ctzll(who))) : 0u;
-  if (lane == 0) store_rec(P.node, i, make_uint4(off, d, 0u, v0));
+  if (P.byIndex) {
+    // reference order by turns (k_turn_round): entries | partners with a lower index << 16, event 0, the node whose turn the first
+    // event is (the first partner if it has a lower index, else the node itself); the turn waits for its d + 1 members
+    uint32_t below = 0;
+    for (uint32_t e = lane; e < d; e += 64) below += lk[e] < static_cast<uint64_t>(i) ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) below += __shfl_xor(below, o, 64);
+    if (lane == 0) {
+      store_rec(P.node, i, make_uint4(off, d | (below << 16), 0u, below ? (v0 & kPairNodeMask) : i));
+      P.turnCnt[i] = d + 1u;
+    }
+  } else if (lane == 0) store_rec(P.node, i, make_uint4(off, d, 0u, v0));
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -448,7 +473,7 @@ __global__ void __launch_bounds__(64 * kBuildWaves) k_pair_build(HashArrays H, P
                       }
                     }
                   }
-                  d = push_partners<MAXD>(lk, le, d, accept, i, j, m, pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, lane);
+                  d = push_partners<MAXD>(lk, le, d, accept, i, j, m, pi.x, pi.y, pi.z, pj.x, pj.y, pj.z, lane, P.byIndex != 0u);
                 }
               }
           __builtin_amdgcn_wave_barrier();
@@ -516,7 +541,7 @@ __global__ void __launch_bounds__(64 * kBuildWaves) k_pair_build(HashArrays H, P
               shared_cells(0, lzi, static_cast<int>((rgj >> 4) & 3u) - 1, ((rgj >> 20) & 63u) + 1u);
           accept = m != 0u;
         }
-        d = push_partners<MAXD>(lk, le, d, accept, i, j, m, pix, piy, piz, pjx, pjy, pjz, lane);
+        d = push_partners<MAXD>(lk, le, d, accept, i, j, m, pix, piy, piz, pjx, pjy, pjz, lane, P.byIndex != 0u);
       }
       __builtin_amdgcn_wave_barrier();
       if (d > MAXD) {
@@ -596,7 +621,7 @@ __global__ void __launch_bounds__(64) k_pair_build_wide(HashArrays H, PairArrays
             if (accept) {
               const uint32_t at = d + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
               if (at < kMaxDeg) {
-                L.lk[at] = i < j ? pair_key(i, j, pi.x, pi.y, pi.z, pj.x, pj.y, pj.z) : pair_key(j, i, pj.x, pj.y, pj.z, pi.x, pi.y, pi.z);
+                L.lk[at] = P.byIndex ? static_cast<uint64_t>(j) : i < j ? pair_key(i, j, pi.x, pi.y, pi.z, pj.x, pj.y, pj.z) : pair_key(j, i, pj.x, pj.y, pj.z, pi.x, pi.y, pi.z);
                 L.le[at] = j;
                 L.lm[at] = m;
               }
@@ -917,19 +942,24 @@ __global__ void __launch_bounds__(kBlock) k_pair_check(HashArrays H, PairArrays 
       store_rec(P.node, i, make_uint4(0u, 0u, 0u, 0u));
       P.exc[i] = 0u;
       if (!(e <= 0.999f * sl)) {  // (the repeat follows the first attempt's course until a newly listed pair touches)
-        const float room = 2.0f * e + 0.2f * r;
+        const float room = P.byIndex ? fminf(2.0f * e + 0.2f * r, kTurnMaxSlack) : 2.0f * e + 0.2f * r;
         P.node[4u * i + 2u].w = room;
         P.bq[i].w = r + room;
       }
     } else {
       const float4 p = P.node[4u * i], v = P.node[4u * i + 1u];
-      pos[i] = p;
-      vel[i] = make_float4(v.x, v.y, v.z, 0.0f);  // (the fourth component of a velocity record is 0 everywhere)
-      P.node[4u * i + 2u].w = next_slack(e, sl, v.w);
+      // (by turns, a pass that could not be proved exact in its repeat either is left to the sequential loop: pos / vel keep the
+      // state the pass started from)
+      if (!(P.byIndex && !first && (flags & 1u))) {
+        pos[i] = p;
+        vel[i] = make_float4(v.x, v.y, v.z, 0.0f);  // (the fourth component of a velocity record is 0 everywhere)
+      }
+      P.node[4u * i + 2u].w = P.byIndex ? fminf(next_slack(e, sl, v.w), kTurnMaxSlack) : next_slack(e, sl, v.w);
     }
   }
-  // the pass's resolved pairs go to the statistics when its result stands (a pass that is repeated counts once)
-  if (blockIdx.x == 0 && !repeat) {
+  // the pass's resolved pairs go to the statistics when its result stands (a pass that is repeated counts once; one that is left to
+  // the sequential loop is counted by that loop)
+  if (blockIdx.x == 0 && !repeat && !(P.byIndex && !first && (flags & 1u))) {
     uint32_t sum = 0;
     for (uint32_t k = threadIdx.x; k < kPairStripes; k += kBlock) { sum += P.hitStripe[k * kPairPad]; P.hitStripe[k * kPairPad] = 0; }
 #pragma unroll
@@ -951,6 +981,7 @@ __global__ void __launch_bounds__(kBlock) k_pair_check(HashArrays H, PairArrays 
   }
   if (i != 0 || first) return;
   if (flags & 1u) P.ctl[kPairInexact] += 1;
+  if (P.byIndex && (flags & 1u)) { P.ctl[kPairFallback] = 1u; P.ctl[kPairFallbacks] += 1u; }
   if (flags & 2u) atomicOr(&H.counters[kCounterFlags], 256u);  // list storage overflow: the host latches the failure
   P.ctl[kPairLeft] = 0;
 }
@@ -972,6 +1003,284 @@ __global__ void k_pair_arm(HashArrays H, PairArrays P) {
   P.ctl[kPairFlags] = 0;
   P.ctl[kPairEdges] = 0;
   P.ctl[kPairSpilled] = 0;
+}
+
+// ======================================================================================================================
+// The REFERENCE's order (Solver.cpp:85-130) by dependency levels of TURNS
+// ======================================================================================================================
+// The reference's loop gives every node its turn in ascending index: the node's cell range is looked up from its LIVE position
+// (SpatialHash.h:101-106), the buckets of that range are walked in dx, dy, dz order and their nodes in ascending index, and every
+// overlapping visit is resolved at once.  k_collide_reference (hash_kernels.hip) runs that as one chain on one wavefront: 20 us
+// per node.  Here the same turns run by dependency levels:
+//   * who a turn can touch: the node's partners within reach when the grid was built (the pair order's filtered lists, sorted by
+//     INDEX here; a visit to anybody else is a miss as long as every node stays within its slack - the pair order's proof obligation,
+//     checked by the same k_pair_verify, repeated with wider slacks, and left to the sequential kernel when that fails too);
+//   * a node j lives through the turns of its partners below it, its own turn, the turns of its partners above it - in that order.
+//     Turn i may run when every member of it (i and its partners) has had all its earlier events.  Two turns that are ready at the
+//     same time share no member, so a level is one launch, one wavefront per turn;
+//   * inside a turn the wavefront holds the partners in its lanes (ascending index).  For every cell of the live range, in order:
+//     the lanes whose partner was INSERTED into that cell test the overlap against the node's current state, the lowest hit is
+//     resolved (Solver.cpp:88-126, the same visit() as the pair order's), the node's new state goes to every lane, the lanes above
+//     test again; the node meets itself at its place in the bucket (quirk Q3).  The visits that are skipped are the ones that miss.
+// The result is the sequential loop's, bit for bit: tests/test_collisions_gpu.py runs both against the oracle's plain loop.
+constexpr uint32_t kTurnDone = 0xffffffffu;
+constexpr uint32_t kTurnBlock = 256;
+
+// the node whose turn event t of node j is: partners below j, j itself, partners above j
+PIES_DEV uint32_t turn_event_node(const PairArrays& P, uint32_t j, uint32_t off, uint32_t d, uint32_t below, uint32_t t) {
+  if (t > d) return kTurnDone;
+  if (t == below) return j;
+  return P.nbr[off + (t < below ? t : t - 1u)] & kPairNodeMask;
+}
+PIES_DEV bool cell_in_range(const int4 rg, int cx, int cy, int cz) {
+  const int lx = rg.w & 0xff, ly = (rg.w >> 8) & 0xff, lz = (rg.w >> 16) & 0xff;
+  return cx >= rg.x && cx < rg.x + lx && cy >= rg.y && cy < rg.y + ly && cz >= rg.z && cz < rg.z + lz;
+}
+PIES_DEV float lane_value(float v, uint32_t srcLane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), static_cast<int>(srcLane))); }
+
+// One bucket of a turn: the lanes with inCell hold the bucket's partners of node a (ascending index over the lanes), selfAt = the
+// lane before which the node meets itself (64: behind the last lane; kTurnDone: not in this bucket / not in this batch).
+PIES_DEV void turn_cell(NodeState& a, NodeState& b, bool inCell, uint32_t selfAt, int lane, float friction, float staticThreshold, uint32_t& hits,
+                        bool& aMoved, bool& bMoved) {
+  unsigned long long pending = __ballot(inCell);
+  for (;;) {
+    bool hit = false;
+    if ((pending >> lane) & 1ull) {  // the overlap test of visit(), on the live states
+      const float dx = b.px - a.px, dy = b.py - a.py, dz = b.pz - a.pz;
+      const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+      hit = a.r + b.r - dist > 0.0f;
+    }
+    const unsigned long long hm = __ballot(hit);
+    const uint32_t first = hm ? static_cast<uint32_t>(__builtin_ctzll(hm)) : 64u;
+    if (selfAt != kTurnDone && selfAt <= first) {  // everything below the node's own place has missed: it meets itself
+      if (visit_self(a, friction, staticThreshold)) { ++hits; aMoved = true; }
+      pending = selfAt >= 64u ? 0ull : pending & ~((1ull << selfAt) - 1ull);
+      selfAt = kTurnDone;
+      continue;  // (its state may have changed: the lanes above test again)
+    }
+    if (first >= 64u) break;
+    NodeState an = a;
+    if (lane == static_cast<int>(first)) {
+      visit(an, b, friction, staticThreshold);
+      bMoved = true;
+    }
+    a.px = lane_value(an.px, first); a.py = lane_value(an.py, first); a.pz = lane_value(an.pz, first);
+    a.vx = lane_value(an.vx, first); a.vy = lane_value(an.vy, first); a.vz = lane_value(an.vz, first);
+    ++hits;
+    aMoved = true;
+    pending = first >= 63u ? 0ull : pending & ~((2ull << first) - 1ull);
+  }
+}
+
+// the members of a finished turn move on: `j` (lane-held, valid where have) to its next event; a node whose turn has all its
+// members waiting for it goes to the next frontier
+PIES_DEV void turn_advance(const PairArrays& P, bool have, uint32_t j, uint32_t* __restrict__ next, uint32_t* __restrict__ nextCount, uint32_t sub, int lane) {
+  uint32_t ready = kTurnDone;
+  if (have) {
+    const uint4 r = load_rec(P.node, j);
+    const uint32_t d = r.y & 0xffffu, below = r.y >> 16, t = r.z + 1u;
+    const uint32_t nxt = turn_event_node(P, j, r.x, d, below, t);
+    store_rec(P.node, j, make_uint4(r.x, r.y, t, nxt));
+    if (nxt != kTurnDone && atomicSub(&P.turnCnt[nxt], 1u) == 1u) ready = nxt;
+  }
+  const unsigned long long rm = __ballot(ready != kTurnDone);
+  if (rm) {
+    uint32_t at = 0;
+    if (lane == 0) at = atomicAdd(&nextCount[sub * kPairPad], static_cast<uint32_t>(__popcll(rm)));
+    at = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(at))) + static_cast<uint32_t>(__popcll(rm & ((1ull << lane) - 1ull)));
+    if (ready != kTurnDone) {
+      if (at < P.frCap) next[static_cast<size_t>(sub) * P.frCap + at] = ready;
+      else atomicOr(&P.ctl[kPairFlags], 2u);  // (frontier storage: the host latches the failure)
+    }
+  }
+}
+
+// the turn of node i, by one wavefront; returns the visits it resolved
+PIES_DEV uint32_t run_turn(const HashArrays& H, const PairArrays& P, uint32_t i, float scale, float friction, float staticThreshold, uint32_t* next,
+                           uint32_t* nextCount, uint32_t sub, int lane) {
+  float4* node = P.node;
+  const uint4 ri = load_rec(node, i);
+  const uint32_t off = ri.x, d = ri.y & 0xffffu, below = ri.y >> 16;
+  NodeState a = load_node(node, i);
+  const int4 rgi = H.rng[i];
+  int mx, my, mz;
+  uint32_t lx, ly, lz;
+  if (!node_range(a.px, a.py, a.pz, a.r, scale, mx, my, mz, lx, ly, lz)) {  // (the sequential loop stops there, Solver.cpp's would not: latched)
+    if (lane == 0) atomicOr(&H.counters[kCounterFlags], 1u);
+    lx = ly = lz = 0;
+  }
+  const uint32_t ncell = lx * ly * lz;
+  // (a node that was inserted with an empty - over-long - range has no list; should its live range hold cells, the lists cannot serve)
+  if (ncell != 0u && (rgi.w & 0xffffff) == 0 && lane == 0) atomicOr(&P.ctl[kPairFlags], 1u);
+  uint32_t hits = 0;
+  bool aMoved = false;
+  if (d <= 64u) {  // the partners in the lanes' registers for the whole turn
+    const bool have = static_cast<uint32_t>(lane) < d;
+    const uint32_t j = have ? P.nbr[off + lane] & kPairNodeMask : 0u;
+    NodeState b = have ? load_node(node, j) : NodeState{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int4 rgj = have ? H.rng[j] : make_int4(0, 0, 0, 0);
+    bool bMoved = false;
+    for (uint32_t c = 0; c < ncell; ++c) {  // dz fastest (SpatialHash.h:108-125)
+      const int cx = mx + static_cast<int>(c / (lz * ly)), cy = my + static_cast<int>((c / lz) % ly), cz = mz + static_cast<int>(c % lz);
+      turn_cell(a, b, have && cell_in_range(rgj, cx, cy, cz), cell_in_range(rgi, cx, cy, cz) ? below : kTurnDone, lane, friction, staticThreshold,
+                hits, aMoved, bMoved);
+    }
+    if (bMoved) {
+      store_node(node, j, b);
+      note_excursion(P, j, b, node[4u * j + 2u]);
+    }
+    if (aMoved && lane == 0) {
+      store_node(node, i, a);
+      note_excursion(P, i, a, node[4u * i + 2u]);
+    }
+    turn_advance(P, have, j, next, nextCount, sub, lane);
+  } else {  // a dense neighbourhood: 64 partners at a time, their states through memory (a partner sits in one batch)
+    for (uint32_t c = 0; c < ncell; ++c) {
+      const int cx = mx + static_cast<int>(c / (lz * ly)), cy = my + static_cast<int>((c / lz) % ly), cz = mz + static_cast<int>(c % lz);
+      const bool selfIn = cell_in_range(rgi, cx, cy, cz);
+      for (uint32_t base = 0; base < d; base += 64u) {
+        const bool have = base + static_cast<uint32_t>(lane) < d;
+        const uint32_t j = have ? P.nbr[off + base + lane] & kPairNodeMask : 0u;
+        NodeState b = have ? load_node(node, j) : NodeState{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int4 rgj = have ? H.rng[j] : make_int4(0, 0, 0, 0);
+        bool bMoved = false;
+        // the node's own place: before lane below - base of the batch that holds it, behind the last batch when every partner is below
+        uint32_t selfAt = kTurnDone;
+        if (selfIn && below >= base && (below < base + 64u || (below == d && base + 64u >= d))) selfAt = below - base;
+        turn_cell(a, b, have && cell_in_range(rgj, cx, cy, cz), selfAt, lane, friction, staticThreshold, hits, aMoved, bMoved);
+        if (bMoved) {
+          store_node(node, j, b);
+          note_excursion(P, j, b, node[4u * j + 2u]);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (aMoved && lane == 0) {
+      store_node(node, i, a);
+      note_excursion(P, i, a, node[4u * i + 2u]);
+    }
+    for (uint32_t base = 0; base < d; base += 64u) {
+      const bool have = base + static_cast<uint32_t>(lane) < d;
+      turn_advance(P, have, have ? P.nbr[off + base + lane] & kPairNodeMask : 0u, next, nextCount, sub, lane);
+    }
+  }
+  turn_advance(P, lane == 0, i, next, nextCount, sub, lane);  // the node itself: on to its first partner above it
+  return hits;
+}
+
+// the first events: every node tells the node whose turn its first event is that it is waiting; turns with all members waiting
+// make the first frontier (the lists of round 2: round 1 means "every node" to frontier_view)
+__global__ void __launch_bounds__(kBlock) k_turn_first(HashArrays H, PairArrays P, uint32_t repeat) {
+  if (repeat && !P.ctl[kPairRetry]) return;
+  if (H.counters[kCounterFlags]) return;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  uint32_t ready = kTurnDone;
+  if (i < P.n) {
+    const uint32_t f = load_rec(P.node, i).w;
+    if (f != kTurnDone && atomicSub(&P.turnCnt[f], 1u) == 1u) ready = f;
+  }
+  const unsigned long long rm = __ballot(ready != kTurnDone);
+  if (rm) {
+    const uint32_t sub = ((blockIdx.x * kBlock + threadIdx.x) >> 6) % kPairLists;
+    uint32_t* nextCount = P.frCount + (2u % 3u) * kPairLists * kPairPad;
+    uint32_t at = 0;
+    if (lane == 0) at = atomicAdd(&nextCount[sub * kPairPad], static_cast<uint32_t>(__popcll(rm)));
+    at = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(at))) + static_cast<uint32_t>(__popcll(rm & ((1ull << lane) - 1ull)));
+    if (ready != kTurnDone) {
+      if (at < P.frCap) P.fr[0][static_cast<size_t>(sub) * P.frCap + at] = ready;
+      else atomicOr(&P.ctl[kPairFlags], 2u);
+    }
+  }
+}
+
+// one level: the turns of the frontier of `round`, one wavefront each
+__global__ void __launch_bounds__(kTurnBlock) k_turn_round(HashArrays H, PairArrays P, float scale, float friction, float staticThreshold, uint32_t round,
+                                                           uint32_t repeat) {
+  if (repeat && !P.ctl[kPairRetry]) return;
+  if (H.counters[kCounterFlags]) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const FrontierView view = frontier_view(P, round, lane);
+  if (blockIdx.x == 0 && wv == 0) {
+    P.frCount[(((round + 2u) % 3u) * kPairLists + static_cast<uint32_t>(lane)) * kPairPad] = 0;  // the lists of the round after the next
+    if (lane == 0 && view.total) { P.ctl[kPairRounds] = round - 1u; if (!repeat && round - 1u > P.ctl[kPairDeepest]) P.ctl[kPairDeepest] = round - 1u; }
+  }
+  const uint32_t count = view.total;
+  if (count == 0u) return;
+  uint32_t* next = P.fr[(round + 1u) & 1u];
+  uint32_t* nextCount = P.frCount + ((round + 1u) % 3u) * kPairLists * kPairPad;
+  const uint32_t wavesPerGrid = gridDim.x * (kTurnBlock / 64u);
+  uint32_t hits = 0;
+  for (uint32_t e = blockIdx.x * (kTurnBlock / 64u) + static_cast<uint32_t>(wv); e < count; e += wavesPerGrid) {  // (wavefront uniform)
+    const uint32_t i = frontier_node(P, view, round, e);
+    hits += run_turn(H, P, i, scale, friction, staticThreshold, next, nextCount, e % kPairLists, lane);
+  }
+  if (lane == 0 && hits) atomicAdd(&P.hitStripe[((blockIdx.x * (kTurnBlock / 64u) + static_cast<uint32_t>(wv)) % kPairStripes) * kPairPad], hits);
+}
+
+// whatever levels are left after the captured launches (and all levels of a repeated pass): one workgroup, a workgroup barrier
+// where the levels have a kernel boundary (slow, never wrong)
+__global__ void __launch_bounds__(1024) k_turn_tail(HashArrays H, PairArrays P, float scale, float friction, float staticThreshold, uint32_t round,
+                                                    uint32_t repeat) {
+  if (repeat && !P.ctl[kPairRetry]) return;
+  if (!repeat && P.ctl[kPairRetry]) return;
+  if (H.counters[kCounterFlags]) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t hits = 0;
+  for (;; ++round) {
+    const FrontierView view = frontier_view(P, round, lane);
+    if (view.total == 0u) break;  // (the same words for every wavefront: all leave together)
+    __syncthreads();              // every wavefront has read the counts before the lists after the next are cleared
+    if (threadIdx.x < kPairLists) __hip_atomic_store(&P.frCount[(((round + 2u) % 3u) * kPairLists + threadIdx.x) * kPairPad], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) { P.ctl[kPairRounds] = round - 1u; if (!repeat && round - 1u > P.ctl[kPairDeepest]) P.ctl[kPairDeepest] = round - 1u; }
+    uint32_t* next = P.fr[(round + 1u) & 1u];
+    uint32_t* nextCount = P.frCount + ((round + 1u) % 3u) * kPairLists * kPairPad;
+    for (uint32_t e = static_cast<uint32_t>(wv); e < view.total; e += blockDim.x / 64u) {
+      const uint32_t i = frontier_node(P, view, round, e);
+      hits += run_turn(H, P, i, scale, friction, staticThreshold, next, nextCount, e % kPairLists, lane);
+    }
+    __threadfence();
+    __syncthreads();
+  }
+  if (lane == 0 && hits) atomicAdd(&P.hitStripe[(static_cast<uint32_t>(wv) % kPairStripes) * kPairPad], hits);
+}
+
+uint32_t launch_collide_turns(hipStream_t st, const HashArrays& H, const PairArrays& Pin, const NodeArrays& nd, float gridSpacing, float friction,
+                              float staticThreshold, uint32_t rounds) {
+  if (nd.n == 0) return 0;
+  PairArrays P = Pin;
+  P.byIndex = 1u;
+  const uint32_t n = nd.n;
+  uint32_t launches = 0;
+  const dim3 perNode((n + kBlock - 1) / kBlock);
+  const dim3 groups(std::max<uint32_t>(1u, std::min<uint32_t>(8192u, n / 8 + 1)));
+  // a level of BASELINE config 4 holds a few hundred turns: one wavefront each
+  const dim3 level(std::max<uint32_t>(1u, std::min<uint32_t>(1024u, (n / 64u + kTurnBlock / 64u) / (kTurnBlock / 64u))));
+  hipLaunchKernelGGL(k_pair_save, perNode, dim3(kBlock), 0, st, H, P, nd.pos, nd.vel, nd.radius, friction, staticThreshold); ++launches;
+  const bool wide = P.nbrM != nullptr;  // ranges of more than two cells per axis: lists node by node
+  if (!wide) { hipLaunchKernelGGL(k_pair_groups, dim3(std::min<uint32_t>(2048u, (H.capacity / 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, H, P, 0u); ++launches; }
+  for (uint32_t repeat = 0; repeat < 2; ++repeat) {
+    if (repeat) { hipLaunchKernelGGL(k_pair_self, perNode, dim3(kBlock), 0, st, H, P, friction, staticThreshold); ++launches; }
+    if (wide) {
+      hipLaunchKernelGGL(k_pair_build_wide, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(16384u, n))), dim3(64), 0, st, H, P, repeat); ++launches;
+    } else {
+      hipLaunchKernelGGL((k_pair_build<384, 96, 64, false>), groups, dim3(64 * kBuildWaves), 0, st, H, P, repeat); ++launches;
+      hipLaunchKernelGGL((k_pair_build<kMaxCand, kMaxDeg, kMaxOwn, true>), dim3(512), dim3(64 * kBuildWaves), 0, st, H, P, repeat); ++launches;
+    }
+    hipLaunchKernelGGL(k_turn_first, perNode, dim3(kBlock), 0, st, H, P, repeat); ++launches;
+    // (a repeated pass - rare: a node left its slack and an unlisted pair may have touched - runs all its levels in the tail kernel)
+    const uint32_t captured = repeat ? 0u : rounds;
+    for (uint32_t r = 2; r < 2u + captured; ++r) {
+      hipLaunchKernelGGL(k_turn_round, level, dim3(kTurnBlock), 0, st, H, P, gridSpacing, friction, staticThreshold, r, repeat); ++launches;
+    }
+    hipLaunchKernelGGL(k_turn_tail, dim3(1), dim3(1024), 0, st, H, P, gridSpacing, friction, staticThreshold, 2u + captured, repeat); ++launches;
+    hipLaunchKernelGGL(k_pair_verify, dim3(64), dim3(kBlock), 0, st, H, P, repeat); ++launches;
+    hipLaunchKernelGGL(k_pair_check, perNode, dim3(kBlock), 0, st, H, P, nd.pos, nd.vel, repeat ? 0u : 1u); ++launches;
+    if (!repeat) { hipLaunchKernelGGL(k_pair_arm, dim3(1), dim3(64), 0, st, H, P); ++launches; }
+  }
+  // a pass that could not be proved exact twice: the sequential loop on the state the pass started from (it returns at once otherwise)
+  launches += launch_collide_reference(st, H, nd, gridSpacing, friction, staticThreshold, P.ctl + kPairFallback);
+  return launches;
 }
 
 uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArrays& P, const NodeArrays& nd, float friction,

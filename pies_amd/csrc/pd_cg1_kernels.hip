@@ -25,9 +25,19 @@
 // contact-heavy one keeps the two-launch form.
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 
 #include "pd_cg_device.h"
 #include "pd_rhs_device.h"
+
+#ifndef PIES_ITER_VARIANT
+#define PIES_ITER_VARIANT 0
+#endif
+#if PIES_ITER_VARIANT == 1 || PIES_ITER_VARIANT == 2
+#define PIES_ITER_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define PIES_ITER_ATTR
+#endif
 
 namespace pies {
 
@@ -53,10 +63,85 @@ template <class F> PIES_DEV void row_entries(const CgArrays& A, uint32_t sl, uin
   }
 }
 
+// ---- windowed rows (CgArrays: wRows ...) -----------------------------------------------------------------------------------
+// The chunks a workgroup sweeps: workgroups that share an XCD (equal blockIdx % 8) take one contiguous part of the chunks, like
+// slice_sweep's wavefronts.
+struct ChunkSweep {
+  uint32_t begin, end, step;
+};
+PIES_DEV ChunkSweep chunk_sweep(uint32_t nchunks, uint32_t nblocks) {
+  const uint32_t labels = nblocks < 8u ? nblocks : 8u;
+  const uint32_t x = blockIdx.x % labels, xb = blockIdx.x / labels;
+  const uint32_t nbx = (nblocks - x + labels - 1u) / labels;
+  const uint32_t segBeg = static_cast<uint32_t>((static_cast<uint64_t>(nchunks) * x) / labels);
+  const uint32_t segEnd = static_cast<uint32_t>((static_cast<uint64_t>(nchunks) * (x + 1u)) / labels);
+  return {segBeg + xb, segEnd, nbx};
+}
+
+// One sweep over the matrix in its windowed form, chunk by chunk:
+//   own(i, aux)         the row's own streaming work, in the natural order (coalesced); returns what its window slot holds and
+//                       may leave 16 bytes for the row's turn behind the sum in `aux` (AUX)
+//   halo(j)             what the slot of column j outside the chunk holds
+//   row(i, sx, sy, sz, u, aux)   what the row does with its sum (u = the row's own slot); the rows of a chunk may come in any
+//                       order here (sorted by length)
+// ACC: float or double sums.  All threads of the workgroup must call (barriers).
+// (Measured and dropped: the first 8-16 entries of a wavefront's first slice requested before the window is filled - they do not
+// depend on it.  The entries in registers across the fill cost 40-60 registers and scalar spills: 12.4 against 10.4 us per launch at
+// 100k rows, 14.1 against 12.7 on the unstructured beam.)
+template <class ACC, bool AUX, class Own, class Halo, class Row>
+PIES_DEV void window_rows(const CgArrays& A, uint32_t nblocks, Own own, Halo halo, Row row) {
+  extern __shared__ float4 pies_window[];
+  float4* __restrict__ win = pies_window;
+  float4* __restrict__ auxv = pies_window + A.wLdsSlots;  // (wRows slots behind the largest window)
+  const ChunkSweep cs = chunk_sweep(A.wChunks, nblocks);
+  const uint32_t R = A.wRows, spc = R >> 6;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  for (uint32_t c = cs.begin; c < cs.end; c += cs.step) {
+    const uint32_t r0 = c * R;
+    const uint2 ch = A.wChunk[c];
+    for (uint32_t lr = threadIdx.x; lr < R; lr += kBlock) {
+      const uint32_t i = r0 + lr;
+      if (i < A.n) {
+        float4 aux = make_float4(0.f, 0.f, 0.f, 0.f);
+        win[lr] = own(i, aux);
+        if (AUX) auxv[lr] = aux;
+      }
+    }
+    if (A.wHalo16) {
+      const uint32_t base = A.wBase[c];
+      const uint16_t* __restrict__ h = A.wHalo16 + ch.x;
+      for (uint32_t k = threadIdx.x; k < ch.y; k += kBlock) win[R + k] = halo(base + h[k]);
+    } else if (A.wHalo32) {
+      const uint32_t* __restrict__ h = A.wHalo32 + ch.x;
+      for (uint32_t k = threadIdx.x; k < ch.y; k += kBlock) win[R + k] = halo(h[k]);
+    }
+    __syncthreads();
+    for (uint32_t sc = wave; sc < spc; sc += kBlock / 64u) {
+      const uint32_t sl = c * spc + sc;
+      const uint32_t lr = A.wPerm ? A.wPerm[static_cast<size_t>(sl) * 64u + lane] : sc * 64u + lane;
+      const uint32_t i = r0 + lr;
+      const uint32_t off = A.wSliceOff[sl], width = (A.wSliceOff[sl + 1] - off) >> 6;
+      const float* __restrict__ wv = A.wVal + off + lane;
+      const uint16_t* __restrict__ wi = A.wIdx + off + lane;
+      ACC sx = 0, sy = 0, sz = 0;
+#pragma unroll 4
+      for (uint32_t kk = 0; kk < width; ++kk) {
+        const ACC a = static_cast<ACC>(wv[kk << 6]);
+        const float4 q = win[wi[kk << 6]];
+        sx = fma(a, static_cast<ACC>(q.x), sx);
+        sy = fma(a, static_cast<ACC>(q.y), sy);
+        sz = fma(a, static_cast<ACC>(q.z), sz);
+      }
+      if (i < A.n) row(i, sx, sy, sz, win[lr], AUX ? auxv[lr] : make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    __syncthreads();  // the next chunk's window overwrites this one
+  }
+}
+
 // r = f - (K + C) x ; t = D^-1 r ; partI = {r.t, r.r, f.f}.  RHS: f is evaluated here (Msn_h2 + the node's records + contacts +
 // shape / goal terms + floor: rhs_of_node with one lane per node) instead of being read from the array k_pd_rhs wrote.
 // prevPart != nullptr: an extra block closes the previous solve's statistics (see k_cg_init).
-template <bool RHS>
+template <bool RHS, bool WIN>
 __global__ void __launch_bounds__(kBlock) k_cg1_init(CgArrays A, const float4* __restrict__ x, const float4* __restrict__ f, RhsArrays R,
                                                      const float* __restrict__ prevPart) {
   if (blockIdx.x == A.npartsI) {
@@ -68,10 +153,40 @@ __global__ void __launch_bounds__(kBlock) k_cg1_init(CgArrays A, const float4* _
     }
     return;
   }
-  const uint32_t lane = threadIdx.x & 63u;
-  const SliceSweep sw = slice_sweep<1>(A.n, A.npartsI);
   float acc9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   Vec3f* __restrict__ t0 = A.t1[0];
+  // what a row does with (K x)_i (fp64 sums, see below), its own x and its right-hand side
+  auto finish = [&](uint32_t i, double sx, double sy, double sz, const float4 xi, float4 fi) {
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    contact_row(A, i, [&](uint32_t j, float& px, float& py, float& pz) { const float4 v = x[j]; px = v.x; py = v.y; pz = v.z; }, cx, cy, cz);
+    if (!RHS) fi = f[i];
+    const float cd = A.cdiag[i], di = A.dinv[i];
+    const double cdd = static_cast<double>(cd);
+    const float rx = static_cast<float>(static_cast<double>(fi.x) - (fma(cdd, static_cast<double>(xi.x), sx) + static_cast<double>(cx)));
+    const float ry = static_cast<float>(static_cast<double>(fi.y) - (fma(cdd, static_cast<double>(xi.y), sy) + static_cast<double>(cy)));
+    const float rz = static_cast<float>(static_cast<double>(fi.z) - (fma(cdd, static_cast<double>(xi.z), sz) + static_cast<double>(cz)));
+    const float tx = di * rx, ty = di * ry, tz = di * rz;
+    t0[i] = Vec3f{tx, ty, tz};
+    acc9[0] += rx * tx; acc9[1] += ry * ty; acc9[2] += rz * tz;
+    acc9[3] += rx * rx; acc9[4] += ry * ry; acc9[5] += rz * rz;
+    acc9[6] += fi.x * fi.x; acc9[7] += fi.y * fi.y; acc9[8] += fi.z * fi.z;
+  };
+  if (WIN) {
+    // (the right-hand side's gather is issued with the window's loads, in the natural order, and waits in LDS for the row's turn)
+    window_rows<double, RHS>(
+        A, A.npartsI,
+        [&](uint32_t i, float4& aux) {
+          const float4 xi = x[i];
+          if (RHS) aux = rhs_of_node<1>(R, i, 0u, true);
+          return xi;
+        },
+        [&](uint32_t j) { return x[j]; },
+        [&](uint32_t i, double sx, double sy, double sz, const float4 xi, const float4 fi) { finish(i, sx, sy, sz, xi, fi); });
+    block_write_partial<9>(acc9, A.partI, 9);
+    return;
+  }
+  const uint32_t lane = threadIdx.x & 63u;
+  const SliceSweep sw = slice_sweep<1>(A.n, A.npartsI);
   for (uint32_t sl = sw.begin; sl < sw.end; sl += sw.step) {
     const uint32_t i = sl * 64u + lane;
     const bool live = i < A.n;
@@ -89,28 +204,13 @@ __global__ void __launch_bounds__(kBlock) k_cg1_init(CgArrays A, const float4* _
       sy = fma(ad, static_cast<double>(xj.y), sy);
       sz = fma(ad, static_cast<double>(xj.z), sz);
     });
-    if (live) {
-      float cx = 0.f, cy = 0.f, cz = 0.f;
-      contact_row(A, i, [&](uint32_t j, float& px, float& py, float& pz) { const float4 v = x[j]; px = v.x; py = v.y; pz = v.z; }, cx, cy, cz);
-      if (!RHS) fi = f[i];
-      const float4 xi = x[i];
-      const float cd = A.cdiag[i], di = A.dinv[i];
-      const double cdd = static_cast<double>(cd);
-      const float rx = static_cast<float>(static_cast<double>(fi.x) - (fma(cdd, static_cast<double>(xi.x), sx) + static_cast<double>(cx)));
-      const float ry = static_cast<float>(static_cast<double>(fi.y) - (fma(cdd, static_cast<double>(xi.y), sy) + static_cast<double>(cy)));
-      const float rz = static_cast<float>(static_cast<double>(fi.z) - (fma(cdd, static_cast<double>(xi.z), sz) + static_cast<double>(cz)));
-      const float tx = di * rx, ty = di * ry, tz = di * rz;
-      t0[i] = Vec3f{tx, ty, tz};
-      acc9[0] += rx * tx; acc9[1] += ry * ty; acc9[2] += rz * tz;
-      acc9[3] += rx * rx; acc9[4] += ry * ry; acc9[5] += rz * rz;
-      acc9[6] += fi.x * fi.x; acc9[7] += fi.y * fi.y; acc9[8] += fi.z * fi.z;
-    }
+    if (live) finish(i, sx, sy, sz, x[i], fi);
   }
   block_write_partial<9>(acc9, A.partI, 9);
 }
 
 // a_0 = D^-1 w_0, w_0 = (K + C) t_0 ; part1[0] = {., w_0.t_0, .}.  Also the solve's first look at the residual.
-__global__ void __launch_bounds__(kBlock) k_cg1_first(CgArrays A, float tol2) {
+template <bool WIN> __global__ void __launch_bounds__(kBlock) k_cg1_first(CgArrays A, float tol2) {
   float red[9];
   block_reduce_partials<9>(A.partI, 9, A.npartsI, red);
   const float rr[3] = {red[3], red[4], red[5]}, bb[3] = {red[6], red[7], red[8]};
@@ -130,26 +230,36 @@ __global__ void __launch_bounds__(kBlock) k_cg1_first(CgArrays A, float tol2) {
     return;
   }
   const uint32_t lane = threadIdx.x & 63u;
-  const SliceSweep sw = slice_sweep<1>(A.n, gridDim.x);
   const Vec3f* __restrict__ t0 = A.t1[0];
   Vec3f* __restrict__ a0 = A.a1[0];
   float acc[3] = {0, 0, 0};
-  for (uint32_t sl = sw.begin; sl < sw.end; sl += sw.step) {
-    const uint32_t i = sl * 64u + lane;
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    row_entries(A, sl, lane, i, [&](float a, uint32_t j) {
-      const Vec3f tj = t0[j];
-      sx = fmaf(a, tj.x, sx);
-      sy = fmaf(a, tj.y, sy);
-      sz = fmaf(a, tj.z, sz);
-    });
-    if (i < A.n) {
-      contact_row(A, i, [&](uint32_t j, float& px, float& py, float& pz) { const Vec3f v = t0[j]; px = v.x; py = v.y; pz = v.z; }, sx, sy, sz);
-      const Vec3f ti = t0[i];
-      const float cd = A.cdiag[i], di = A.dinv[i];
-      const float wx = fmaf(cd, ti.x, sx), wy = fmaf(cd, ti.y, sy), wz = fmaf(cd, ti.z, sz);
-      a0[i] = Vec3f{di * wx, di * wy, di * wz};
-      acc[0] += wx * ti.x; acc[1] += wy * ti.y; acc[2] += wz * ti.z;
+  auto finish = [&](uint32_t i, float sx, float sy, float sz, float tix, float tiy, float tiz) {
+    contact_row(A, i, [&](uint32_t j, float& px, float& py, float& pz) { const Vec3f v = t0[j]; px = v.x; py = v.y; pz = v.z; }, sx, sy, sz);
+    const float cd = A.cdiag[i], di = A.dinv[i];
+    const float wx = fmaf(cd, tix, sx), wy = fmaf(cd, tiy, sy), wz = fmaf(cd, tiz, sz);
+    a0[i] = Vec3f{di * wx, di * wy, di * wz};
+    acc[0] += wx * tix; acc[1] += wy * tiy; acc[2] += wz * tiz;
+  };
+  if (WIN) {
+    auto slot = [&](uint32_t j) { const Vec3f v = t0[j]; return make_float4(v.x, v.y, v.z, 0.f); };
+    window_rows<float, false>(
+        A, gridDim.x, [&](uint32_t i, float4&) { return slot(i); }, slot,
+        [&](uint32_t i, float sx, float sy, float sz, const float4 ti, const float4) { finish(i, sx, sy, sz, ti.x, ti.y, ti.z); });
+  } else {
+    const SliceSweep sw = slice_sweep<1>(A.n, gridDim.x);
+    for (uint32_t sl = sw.begin; sl < sw.end; sl += sw.step) {
+      const uint32_t i = sl * 64u + lane;
+      float sx = 0.f, sy = 0.f, sz = 0.f;
+      row_entries(A, sl, lane, i, [&](float a, uint32_t j) {
+        const Vec3f tj = t0[j];
+        sx = fmaf(a, tj.x, sx);
+        sy = fmaf(a, tj.y, sy);
+        sz = fmaf(a, tj.z, sz);
+      });
+      if (i < A.n) {
+        const Vec3f ti = t0[i];
+        finish(i, sx, sy, sz, ti.x, ti.y, ti.z);
+      }
     }
   }
   block_write_partial<3>(acc, A.part1[0] + 3, 9);
@@ -159,7 +269,7 @@ __global__ void __launch_bounds__(kBlock) k_cg1_first(CgArrays A, float tol2) {
 // The rows of iteration `it` (the it-th update of x, it >= 1) for this workgroup's slices, given alpha_{it-1} and beta_{it-1}:
 // reads the vectors of parity (it - 1) & 1, writes those of parity it & 1; acc += {r.t, w.t, r.r} of the new vectors.
 // FIRST (it == 1): beta = 0 and there is no c / p yet.
-template <bool FIRST>
+template <bool FIRST, bool WIN>
 PIES_DEV void cg1_rows(const CgArrays& A, float4* __restrict__ x, int it, const float alpha[3], const float beta[3], float acc[9]) {
   const Vec3f* __restrict__ tO = A.t1[(it - 1) & 1];
   const Vec3f* __restrict__ aO = A.a1[(it - 1) & 1];
@@ -182,6 +292,48 @@ PIES_DEV void cg1_rows(const CgArrays& A, float4* __restrict__ x, int it, const 
     float cx, cy, cz;
     renew(j, ux, uy, uz, cx, cy, cz);
   };
+  if (WIN) {
+    // The row's own updates - everything that does not wait for the row's sum - happen while its window slot is filled, in the
+    // natural order: x, p, the new t and c, r.t and r.r.  Behind the sum only w = (K + C) t, a = D^-1 w and w.t are left.
+    window_rows<float, false>(
+        A, gridDim.x,
+        [&](uint32_t i, float4&) {
+          float tx, ty, tz, cx, cy, cz;
+          renew(i, tx, ty, tz, cx, cy, cz);
+          const Vec3f told = tO[i];
+          float px = told.x, py = told.y, pz = told.z;
+          if (!FIRST) {
+            const Vec3f po = p[i];
+            px = fmaf(beta[0], po.x, px); py = fmaf(beta[1], po.y, py); pz = fmaf(beta[2], po.z, pz);
+          }
+          float4 xi = x[i];
+          xi.x = fmaf(alpha[0], px, xi.x);
+          xi.y = fmaf(alpha[1], py, xi.y);
+          xi.z = fmaf(alpha[2], pz, xi.z);
+          const float kd = A.kdiag[i] + A.cdiag[i];
+          const float rx = kd * tx, ry = kd * ty, rz = kd * tz;
+          x[i] = xi;
+          p[i] = Vec3f{px, py, pz};
+          tN[i] = Vec3f{tx, ty, tz};
+          cN[i] = Vec3f{cx, cy, cz};
+          acc[0] += rx * tx; acc[1] += ry * ty; acc[2] += rz * tz;
+          acc[6] += rx * rx; acc[7] += ry * ry; acc[8] += rz * rz;
+          return make_float4(tx, ty, tz, 0.f);
+        },
+        [&](uint32_t j) {
+          float ux, uy, uz;
+          fetch(j, ux, uy, uz);
+          return make_float4(ux, uy, uz, 0.f);
+        },
+        [&](uint32_t i, float sx, float sy, float sz, const float4 t, const float4) {
+          contact_row<PIES_ITER_VARIANT == 3 ? 4 : 1>(A, i, fetch, sx, sy, sz);
+          const float cd = A.cdiag[i], di = A.dinv[i];
+          const float wx = fmaf(cd, t.x, sx), wy = fmaf(cd, t.y, sy), wz = fmaf(cd, t.z, sz);
+          aN[i] = Vec3f{di * wx, di * wy, di * wz};
+          acc[3] += wx * t.x; acc[4] += wy * t.y; acc[5] += wz * t.z;
+        });
+    return;
+  }
   const uint32_t lane = threadIdx.x & 63u;
   const SliceSweep sw = slice_sweep<1>(A.n, gridDim.x);
   for (uint32_t sl = sw.begin; sl < sw.end; sl += sw.step) {
@@ -195,7 +347,7 @@ PIES_DEV void cg1_rows(const CgArrays& A, float4* __restrict__ x, int it, const 
       sz = fmaf(a, uz, sz);
     });
     if (i < A.n) {
-      contact_row(A, i, fetch, sx, sy, sz);
+      contact_row<PIES_ITER_VARIANT == 3 ? 4 : 1>(A, i, fetch, sx, sy, sz);
       float tx, ty, tz, cx, cy, cz;
       renew(i, tx, ty, tz, cx, cy, cz);
       const Vec3f told = tO[i];
@@ -223,6 +375,12 @@ PIES_DEV void cg1_rows(const CgArrays& A, float4* __restrict__ x, int it, const 
   }
 }
 
+// three wave-uniform values moved to scalar registers
+PIES_DEV void uniform3(float v[3]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) v[c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v[c])));
+}
+
 // alpha_i and beta_i from {gamma_i, delta_i} and the previous iteration's {gamma_{i-1}, alpha_{i-1}}; a column that has nothing
 // left to do (gamma = 0) or whose recurrence breaks down (a non-positive denominator) stands still
 PIES_DEV void cg1_scalars(const float gam[3], const float del[3], const float gamOld[3], const float alphaOld[3], float alpha[3], float beta[3]) {
@@ -238,8 +396,11 @@ PIES_DEV void cg1_scalars(const float gam[3], const float del[3], const float ga
 // overflow > 0: the solve's last captured launch; when the residual is still above the tolerance after its rows, its
 // workgroups (all resident, see cg_update_resident_blocks) run up to `overflow` more iterations themselves, one grid barrier
 // per iteration where the captured path has a kernel boundary.
-template <bool FIRST>
-__global__ void __launch_bounds__(kBlock) k_cg1_iter(CgArrays A, float4* __restrict__ x, int it, float tol2, int overflow) {
+// (Measured and dropped: __launch_bounds__(kBlock, 5) - the rows fit 85-92 registers without spills, five wavefronts per SIMD
+// instead of four: 41.1 against 39.5 us per launch with the row dictionary at 1M rows, 54.9 against 46.5 windowed: what the
+// scheduler spends the registers on is loads in flight.)
+template <bool FIRST, bool WIN>
+__global__ void PIES_ITER_ATTR __launch_bounds__(kBlock) k_cg1_iter(CgArrays A, float4* __restrict__ x, int it, float tol2, int overflow) {
   if (A.scal[10] != 0.0f) return;  // the solve converged in an earlier launch
   float red[9];
   float alpha[3], beta[3] = {0.f, 0.f, 0.f}, gam[3], bb[3];
@@ -280,7 +441,11 @@ __global__ void __launch_bounds__(kBlock) k_cg1_iter(CgArrays A, float4* __restr
     A.scal[9] = static_cast<float>(it);
   }
   float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  cg1_rows<FIRST>(A, x, it, alpha, beta, acc);
+#if PIES_ITER_VARIANT < 2
+  uniform3(alpha);  // (the same in every lane: scalar registers for the rows' sweep)
+  uniform3(beta);
+#endif
+  cg1_rows<FIRST, WIN>(A, x, it, alpha, beta, acc);
   block_write_partial<9>(acc, A.part1[it & 1], 9);
   if (blockIdx.x == 0 && threadIdx.x == 0) A.partCount[it & 1] = gridDim.x;
   if (overflow <= 0) return;
@@ -301,7 +466,11 @@ __global__ void __launch_bounds__(kBlock) k_cg1_iter(CgArrays A, float4* __restr
     ++kk;
 #pragma unroll
     for (int c = 0; c < 9; ++c) acc[c] = 0.0f;
-    cg1_rows<false>(A, x, kk, alpha, beta, acc);
+#if PIES_ITER_VARIANT < 2
+    uniform3(alpha);
+    uniform3(beta);
+#endif
+    cg1_rows<false, WIN>(A, x, kk, alpha, beta, acc);
     block_write_partial<9>(acc, A.part1[kk & 1], 9);
     if (blockIdx.x == 0 && threadIdx.x == 0) A.partCount[kk & 1] = gridDim.x;
   }
@@ -312,12 +481,28 @@ __global__ void __launch_bounds__(kBlock) k_cg1_iter(CgArrays A, float4* __restr
   }
 }
 
+// the windowed kernel takes its window as dynamic LDS: above 64 KB a kernel has to be told (once per process)
+static bool window_lds_ok(uint32_t bytes) {
+  static uint32_t allowed = 64u * 1024u;
+  if (bytes <= allowed) return true;
+  const void* fns[] = {reinterpret_cast<const void*>(&k_cg1_init<true, true>),  reinterpret_cast<const void*>(&k_cg1_init<false, true>),
+                       reinterpret_cast<const void*>(&k_cg1_first<true>), reinterpret_cast<const void*>(&k_cg1_iter<true, true>),
+                       reinterpret_cast<const void*>(&k_cg1_iter<false, true>)};
+  for (const void* f : fns)
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)) != hipSuccess) return false;
+  allowed = bytes;
+  return true;
+}
+
 // workgroups of k_cg1_iter the device holds at once (its continuation's grid barrier needs all of a launch resident)
-uint32_t cg1_iter_resident_blocks(int device) {
+uint32_t cg1_iter_resident_blocks(int device, uint32_t windowLdsBytes) {
   int perCu = 0;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_cg1_iter<false>, kBlock, 0) != hipSuccess) return 0;
+  if (windowLdsBytes) {
+    if (!window_lds_ok(windowLdsBytes)) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_cg1_iter<false, true>, kBlock, windowLdsBytes) != hipSuccess) return 0;
+  } else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_cg1_iter<false, false>, kBlock, 0) != hipSuccess) return 0;
   return static_cast<uint32_t>(std::max(0, perCu)) * static_cast<uint32_t>(std::max(0, prop.multiProcessorCount));
 }
 
@@ -335,20 +520,40 @@ void launch_pd_solve1(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, 
   // every solve of a substep captures the same number of launches, so the previous solve's last one left its partials here
   const float* prev = first ? nullptr : A.part1[iters & 1];
   const RhsArrays R = rhs_arrays(nd, pd);
+  // Which launches of a solve take the windowed matrix where it was built (PIES_PD_WINDOW_KERNELS: 1 the iterations, 2 the first
+  // product, 4 the residual; default 3).  The iterations gather three vectors per column and gain from the window by themselves
+  // (unstructured 100k beam: 12.7 against 14.3 us per launch).  At 1M rows a second effect is larger: the launches of a solve that
+  // stream the SAME arrays find them in the 256 MB Infinity Cache - the iteration behind a windowed first product takes 46.5 us,
+  // behind one that streamed the SELL arrays 56-57 (its own matrix has to come from HBM then).  The residual kernel (fp64 sums,
+  // the right-hand side's gather) is slower with the window everywhere measured (60.3 against 57.1 us at 1M, 13.0 against 10.8 at
+  // 100k) and keeps the SELL rows.
+  const uint32_t lds = A.wRows ? window_lds_bytes(A) : 0u;
+  const bool win = A.wRows != 0 && window_lds_ok(lds);
+  uint32_t which = 3u;
+  if (const char* e = tuning_env("PIES_PD_WINDOW_KERNELS")) which = static_cast<uint32_t>(std::atoi(e)) & 7u;
+  const bool winIter = win && (which & 1u), winFirst = win && (which & 2u), winAll = win && (which & 4u);
   if (fuseRhs) {
     if (hook) hook(hookCtx, 13);  // PIES_KERNEL_PD_RHS: the residual kernel that evaluates the right-hand side
-    hipLaunchKernelGGL(k_cg1_init<true>, dim3(A.npartsI + 1u), block, 0, st, A, nd.pos, pd.rhs, R, prev);
+    if (winAll) hipLaunchKernelGGL((k_cg1_init<true, true>), dim3(A.npartsI + 1u), block, lds, st, A, nd.pos, pd.rhs, R, prev);
+    else hipLaunchKernelGGL((k_cg1_init<true, false>), dim3(A.npartsI + 1u), block, 0, st, A, nd.pos, pd.rhs, R, prev);
     if (hook) hook(hookCtx, 13);
   } else {
-    hipLaunchKernelGGL(k_cg1_init<false>, dim3(A.npartsI + 1u), block, 0, st, A, nd.pos, pd.rhs, R, prev);
+    if (winAll) hipLaunchKernelGGL((k_cg1_init<false, true>), dim3(A.npartsI + 1u), block, lds, st, A, nd.pos, pd.rhs, R, prev);
+    else hipLaunchKernelGGL((k_cg1_init<false, false>), dim3(A.npartsI + 1u), block, 0, st, A, nd.pos, pd.rhs, R, prev);
   }
-  hipLaunchKernelGGL(k_cg1_first, wide, block, 0, st, A, tol2);
+  if (winFirst) hipLaunchKernelGGL(k_cg1_first<true>, wide, block, lds, st, A, tol2);
+  else hipLaunchKernelGGL(k_cg1_first<false>, wide, block, 0, st, A, tol2);
   for (int it = 1; it <= iters; ++it) {
     if (hook) hook(hookCtx, 14);  // PIES_KERNEL_PD_SPMV
     const int overflow = it == iters && !neverExit ? overflowIters : 0;
     const dim3 grid = overflow > 0 ? narrow : wide;
-    if (it == 1) hipLaunchKernelGGL(k_cg1_iter<true>, grid, block, 0, st, A, nd.pos, it, tol2, overflow);
-    else hipLaunchKernelGGL(k_cg1_iter<false>, grid, block, 0, st, A, nd.pos, it, tol2, overflow);
+    if (winIter) {
+      if (it == 1) hipLaunchKernelGGL((k_cg1_iter<true, true>), grid, block, lds, st, A, nd.pos, it, tol2, overflow);
+      else hipLaunchKernelGGL((k_cg1_iter<false, true>), grid, block, lds, st, A, nd.pos, it, tol2, overflow);
+    } else {
+      if (it == 1) hipLaunchKernelGGL((k_cg1_iter<true, false>), grid, block, 0, st, A, nd.pos, it, tol2, overflow);
+      else hipLaunchKernelGGL((k_cg1_iter<false, false>), grid, block, 0, st, A, nd.pos, it, tol2, overflow);
+    }
     if (hook) hook(hookCtx, 14);
   }
   if (!last) return;

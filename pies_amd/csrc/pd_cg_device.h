@@ -73,7 +73,9 @@ PIES_DEV bool all_converged(const float rr[3], const float bb[3], float tol2) {
 // The terms are added in contact-list order; the loads of four contacts are requested together (index, ids, then
 // the vectors - three dependent trips per batch instead of per contact: a node of a contact patch sits in tens of
 // contacts, and one lane walking them one by one made the SpMV ten times slower than without contacts).
-template <class Fetch> PIES_DEV void contact_row(const CgArrays& A, uint32_t i, Fetch fetch, float& sx, float& sy, float& sz) {
+// (kAhead: contacts whose loads are requested together; the one-launch-per-iteration kernels, whose fetch is three gathers, take 1:
+// twelve fetches in flight cost them 60 registers for a path a contact-light substep takes for a handful of rows)
+template <int kAhead = 4, class Fetch> PIES_DEV void contact_row(const CgArrays& A, uint32_t i, Fetch fetch, float& sx, float& sy, float& sz) {
   if (!A.tIncCnt || *A.tUsedCount == 0u) return;  // (no contact in this substep: one uniform word instead of a load per row)
   const uint32_t tc = A.tIncCnt[i];
   if (!tc) return;
@@ -91,7 +93,6 @@ template <class Fetch> PIES_DEV void contact_row(const CgArrays& A, uint32_t i, 
     }
   }
   const uint32_t ts = A.tIncStart[i];
-  constexpr int kAhead = 4;
   for (uint32_t k0 = 0; k0 < tc; k0 += kAhead) {
     uint32_t v[kAhead];
     uint4 id[kAhead];

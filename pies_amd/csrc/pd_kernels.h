@@ -38,6 +38,24 @@ struct CgArrays {
   // stored entry from HBM.  Same entries in the same order as the SELL arrays: the sums are bit for bit the same.
   const uint32_t* rowStencil;  // per row: first pair of its stencil | pairs << 24 (one word: no second look-up on the row's chain of loads)
   const int2* stencil;         // (column - row, bits of the value)
+  // Windowed SELL (round 5; pd_setup.cpp build_window_matrix; wRows == 0: not built).  The rows are cut into chunks of wRows
+  // consecutive rows; ONE WORKGROUP takes a chunk: it stages the vector entries of the chunk's window - its own rows first (slot
+  // = row - first row), then the distinct columns outside the chunk in ascending order (the halo) - in LDS as 16-byte slots, and
+  // the rows then gather from LDS through 16-bit slot indices.  What streams from HBM per stored entry is the value + a 16-bit
+  // slot (6 bytes instead of 8), a column's vector entries are loaded once per chunk instead of once per row that names it (3-7
+  // loads per row instead of 15), and the loads that remain are runs of consecutive columns.  Inside a chunk the rows may be
+  // sorted by length (wPerm: local row of (slice, lane); nullptr: the natural order), so that a slice is padded to ITS longest
+  // row only (an unstructured mesh: 1.33 -> 1.0x).  Entries keep their order inside a row (ascending column): a row's sum is
+  // bit for bit the SELL arrays' and the dictionary's.
+  uint32_t wRows, wChunks, wLdsSlots;  // rows per chunk (a multiple of 64), chunks, slots of the largest window
+  const uint2* wChunk;       // per chunk: {first halo entry, halo entries}
+  const uint32_t* wBase;     // per chunk: what its 16-bit halo columns are relative to
+  const uint16_t* wHalo16;   // halo columns - base (nullptr: wHalo32 holds the columns themselves)
+  const uint32_t* wHalo32;
+  const uint32_t* wSliceOff; // slices + 1 offsets (in entries) of wVal / wIdx: slice s of chunk c is number c * wRows / 64 + s
+  const float* wVal;
+  const uint16_t* wIdx;
+  const uint16_t* wPerm;     // per (chunk, slice, lane): the row's place in its chunk
   float* cdiag;  // diagonal of the collision matrix (floor contacts)
   float* dinv;   // 1 / diag(K + C)
   float4 *r, *z, *p[2], *ap;
@@ -191,7 +209,8 @@ void launch_pd_velocity(hipStream_t st, const NodeArrays& nd, const PdArrays& pd
 // usedBits (the point-triangle pipeline's bitmap of nodes in contacts): floor friction for the nodes outside it only
 
 // workgroups of k_cg_update the device holds at once (0: unknown); the CG kernels' grid stays below it, see grid_barrier
+inline uint32_t window_lds_bytes(const CgArrays& A) { return (A.wLdsSlots + A.wRows) * 16u; }  // the largest window + a chunk's rows of 16 bytes (window_rows)
 uint32_t cg_update_resident_blocks(int device);
-uint32_t cg1_iter_resident_blocks(int device);
+uint32_t cg1_iter_resident_blocks(int device, uint32_t windowLdsBytes = 0);  // windowLdsBytes != 0: the windowed kernel with that much LDS
 
 }  // namespace pies

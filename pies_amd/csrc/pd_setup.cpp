@@ -30,6 +30,107 @@ struct Entry {
 };
 }  // namespace
 
+// The windowed form of the system matrix (CgArrays: wRows ...).  false: not built - a window beyond what a workgroup may hold in
+// LDS or beyond 16-bit slot indices (an unstructured mesh numbered without locality); the SELL arrays serve such a scene.
+struct WindowMatrix {
+  uint32_t rows = 0, chunks = 0, ldsSlots = 0;
+  bool sorted = false, halo16 = true;
+  std::vector<uint2> chunk;
+  std::vector<uint32_t> base, halo32, sliceOff;
+  std::vector<uint16_t> halo16v, idx, perm;
+  std::vector<float> val;
+  double padding = 1.0;  // stored entries / matrix entries
+};
+constexpr uint32_t kWindowMaxSlots = 6144;  // 96 KB of LDS: one workgroup per compute unit is still resident beside another kernel's
+
+bool build_window_matrix(uint32_t n, const std::vector<uint32_t>& rowptr, const std::vector<uint32_t>& col, const std::vector<float>& val,
+                         uint32_t R, int sortMode, WindowMatrix& W) {
+  if (n == 0 || R == 0 || R % 64u) return false;
+  W.rows = R;
+  W.chunks = (n + R - 1u) / R;
+  const uint32_t spc = R / 64u;  // slices per chunk
+  // (1) per chunk: the halo (distinct columns outside the chunk, ascending)
+  W.chunk.resize(W.chunks);
+  W.base.assign(W.chunks, 0u);
+  std::vector<uint32_t> tmp;
+  std::vector<std::vector<uint32_t>> halos(W.chunks);
+  for (uint32_t c = 0; c < W.chunks; ++c) {
+    const uint32_t r0 = c * R, r1 = std::min(n, r0 + R);
+    tmp.clear();
+    for (uint32_t k = rowptr[r0]; k < rowptr[r1]; ++k)
+      if (col[k] < r0 || col[k] >= r1) tmp.push_back(col[k]);
+    std::sort(tmp.begin(), tmp.end());
+    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+    if (R + tmp.size() > kWindowMaxSlots) return false;
+    W.ldsSlots = std::max<uint32_t>(W.ldsSlots, R + static_cast<uint32_t>(tmp.size()));
+    if (!tmp.empty() && tmp.back() - tmp.front() > 0xffffu) W.halo16 = false;
+    halos[c] = tmp;
+  }
+  uint32_t at = 0;
+  for (uint32_t c = 0; c < W.chunks; ++c) {
+    W.chunk[c] = make_uint2(at, static_cast<uint32_t>(halos[c].size()));
+    W.base[c] = halos[c].empty() ? 0u : halos[c].front();
+    at += static_cast<uint32_t>(halos[c].size());
+  }
+  if (W.halo16) {
+    W.halo16v.reserve(at);
+    for (uint32_t c = 0; c < W.chunks; ++c)
+      for (uint32_t j : halos[c]) W.halo16v.push_back(static_cast<uint16_t>(j - W.base[c]));
+  } else {
+    W.halo32.reserve(at);
+    for (uint32_t c = 0; c < W.chunks; ++c) W.halo32.insert(W.halo32.end(), halos[c].begin(), halos[c].end());
+  }
+  // (2) the rows' order inside a chunk: by length (descending, stable) when the natural order pads a tenth or more
+  auto len = [&](uint32_t i) { return i < n ? rowptr[i + 1] - rowptr[i] : 0u; };
+  uint64_t padNatural = 0;
+  for (uint32_t sl = 0; sl < W.chunks * spc; ++sl) {
+    uint32_t w = 0;
+    for (uint32_t l = 0; l < 64u; ++l) w = std::max(w, len(sl * 64u + l));
+    padNatural += 64ull * w;
+  }
+  const uint64_t nnz = rowptr[n];
+  W.sorted = sortMode == 1 || (sortMode < 0 && padNatural * 10ull >= nnz * 11ull);
+  std::vector<uint16_t> perm(static_cast<size_t>(W.chunks) * R);
+  for (uint32_t c = 0; c < W.chunks; ++c) {
+    uint16_t* pm = perm.data() + static_cast<size_t>(c) * R;
+    for (uint32_t k = 0; k < R; ++k) pm[k] = static_cast<uint16_t>(k);
+    if (W.sorted) std::stable_sort(pm, pm + R, [&](uint16_t a, uint16_t b) { return len(c * R + a) > len(c * R + b); });
+  }
+  // (3) the slices
+  W.sliceOff.assign(static_cast<size_t>(W.chunks) * spc + 1u, 0u);
+  for (uint32_t sl = 0; sl < W.chunks * spc; ++sl) {
+    const uint32_t c = sl / spc;
+    uint32_t w = 0;
+    for (uint32_t l = 0; l < 64u; ++l) w = std::max(w, len(c * R + perm[static_cast<size_t>(sl) * 64u + l]));
+    W.sliceOff[sl + 1] = W.sliceOff[sl] + 64u * w;
+  }
+  const size_t stored = W.sliceOff.back();
+  W.padding = nnz ? static_cast<double>(stored) / static_cast<double>(nnz) : 1.0;
+  W.val.assign(stored, 0.0f);
+  W.idx.assign(stored, 0);
+  for (uint32_t sl = 0; sl < W.chunks * spc; ++sl) {
+    const uint32_t c = sl / spc, r0 = c * R, r1 = std::min(n, r0 + R);
+    const std::vector<uint32_t>& h = halos[c];
+    const uint32_t width = (W.sliceOff[sl + 1] - W.sliceOff[sl]) / 64u;
+    for (uint32_t l = 0; l < 64u; ++l) {
+      const uint32_t lr = perm[static_cast<size_t>(sl) * 64u + l], i = r0 + lr;
+      const uint32_t b = i < n ? rowptr[i] : 0u, ln = len(i);
+      for (uint32_t k = 0; k < width; ++k) {
+        const size_t e = static_cast<size_t>(W.sliceOff[sl]) + 64u * k + l;
+        if (k < ln) {
+          const uint32_t j = col[b + k];
+          W.val[e] = val[b + k];
+          W.idx[e] = static_cast<uint16_t>(j >= r0 && j < r1 ? j - r0 : R + static_cast<uint32_t>(std::lower_bound(h.begin(), h.end(), j) - h.begin()));
+        } else {
+          W.idx[e] = static_cast<uint16_t>(lr);  // padding: the row's own slot, value 0
+        }
+      }
+    }
+  }
+  if (W.sorted) W.perm.swap(perm);
+  return true;
+}
+
 int pd_build(pies_solver* s) {
   const uint32_t n = s->nodeCount();
   const float h = s->opt.fixedTimestepSize / s->opt.timeSubsteps;
@@ -256,6 +357,46 @@ int pd_build(pies_solver* s) {
     }
   }
   cg.lanesPerRow = lpr;
+  // Windowed SELL for the scenes that stream their matrix (no row dictionary: unstructured meshes, lattices with per-node
+  // materials): see CgArrays.  PIES_PD_WINDOW=0 keeps the SELL arrays, =2 builds it beside a row dictionary as well (the kernels
+  // then take the window); PIES_CG_CHUNK_ROWS = rows per chunk (64 ... 1024; default 256: a 100k-row system still fills the chip
+  // with one chunk per workgroup); PIES_PD_WINDOW_SORT = 0 / 1 forces the rows' order inside a chunk.
+  cg.wRows = cg.wChunks = cg.wLdsSlots = 0;
+  cg.wChunk = nullptr; cg.wBase = nullptr; cg.wHalo16 = nullptr; cg.wHalo32 = nullptr; cg.wSliceOff = nullptr; cg.wVal = nullptr;
+  cg.wIdx = nullptr; cg.wPerm = nullptr;
+  s->pdWindowPadding = 0.0f; s->pdWindowHalo = 0; s->pdWindowEntries = 0;
+  {
+    int mode = 1;
+    if (const char* e = tuning_env("PIES_PD_WINDOW")) mode = std::atoi(e);
+    uint32_t R = 256;
+    if (const char* e = tuning_env("PIES_CG_CHUNK_ROWS")) { const int v = std::atoi(e); if (v >= 64 && v <= 1024 && v % 64 == 0) R = static_cast<uint32_t>(v); }
+    int sortMode = -1;
+    if (const char* e = tuning_env("PIES_PD_WINDOW_SORT")) sortMode = std::atoi(e) ? 1 : 0;
+    WindowMatrix W;
+    if (lpr == 1u && n != 0 && s->device >= 0 && (mode == 2 || (mode == 1 && !cg.rowStencil)) && build_window_matrix(n, rowptr, col, val, R, sortMode, W)) {
+      uint2* d_chunk; uint32_t *d_base, *d_h32, *d_so; uint16_t *d_h16, *d_idx, *d_perm; float* d_wv;
+      if (int rc = upload(s, W.chunk, &d_chunk)) return rc;
+      if (int rc = upload(s, W.base, &d_base)) return rc;
+      if (int rc = upload(s, W.halo16v, &d_h16)) return rc;
+      if (int rc = upload(s, W.halo32, &d_h32)) return rc;
+      if (int rc = upload(s, W.sliceOff, &d_so)) return rc;
+      if (int rc = upload(s, W.val, &d_wv)) return rc;
+      if (int rc = upload(s, W.idx, &d_idx)) return rc;
+      if (int rc = upload(s, W.perm, &d_perm)) return rc;
+      cg.wRows = W.rows; cg.wChunks = W.chunks; cg.wLdsSlots = W.ldsSlots;
+      cg.wChunk = d_chunk; cg.wBase = d_base; cg.wHalo16 = W.halo16 ? d_h16 : nullptr; cg.wHalo32 = W.halo16 ? nullptr : d_h32;
+      if (W.halo16 && W.halo16v.empty()) { cg.wHalo16 = nullptr; cg.wHalo32 = nullptr; }  // (no halo at all: a single chunk)
+      cg.wSliceOff = d_so; cg.wVal = d_wv; cg.wIdx = d_idx; cg.wPerm = W.sorted ? d_perm : nullptr;
+      s->pdWindowPadding = static_cast<float>(W.padding);
+      s->pdWindowEntries = static_cast<uint32_t>(W.val.size());
+      s->pdWindowHalo = static_cast<uint32_t>(W.halo16 ? W.halo16v.size() : W.halo32.size());
+      // no more workgroups than chunks; the continuation's grid must fit the device beside the window's LDS
+      cg.nparts = std::max(1u, std::min(cg.nparts, cg.wChunks));
+      cg.npartsI = std::max(cg.nparts, std::min(cg.npartsI, cg.wChunks));
+      const uint32_t resident = cg1_iter_resident_blocks(s->device, window_lds_bytes(cg));
+      if (resident >= 2) cg.nparts = std::max(1u, std::min(cg.nparts, resident / 2u));
+    }
+  }
   // lanes of k_pd_rhs per node: four for the ~24 per-element records of a node, one when they are a few tile sums
   pd.rhsLanes = n && incPtr[n] <= 6ull * n ? 1u : 4u;
   if (const char* e = tuning_env("PIES_PD_RHS_LANES")) pd.rhsLanes = std::atoi(e) == 1 ? 1u : 4u;
@@ -342,7 +483,8 @@ int pd_build(pies_solver* s) {
     if (int rc = dev_alloc(s, n, &cg.t1[b], true)) return rc;
     if (int rc = dev_alloc(s, n, &cg.c1[b], true)) return rc;
     if (int rc = dev_alloc(s, n, &cg.a1[b], true)) return rc;
-    if (int rc = dev_alloc(s, kCgBlocks * 9, &cg.part1[b], true)) return rc;
+    // (k_cg1_first / k_cg1_iter run npartsI workgroups wide, and PIES_CG_INIT_BLOCKS may raise that to kCgInitBlocks)
+    if (int rc = dev_alloc(s, kCgInitBlocks * 9, &cg.part1[b], true)) return rc;
   }
   if (int rc = dev_alloc(s, n, &cg.p1, true)) return rc;
   cg.kdiag = d_kdiag;

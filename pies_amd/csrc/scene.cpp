@@ -60,6 +60,7 @@ bool ids_ok(const pies_solver* s, const uint32_t* ids, size_t count) {
 // Rest data shared by the tetrahedral-strain and volume factories (Constraints.cpp:140-176, 266-302):
 // Qinv = inverse([x2-x1, x3-x1, x4-x1]);  A = [0 ; Qinv_(r,k) * D] with the reference's row-major
 // reading of the column-major inverse (diffToBary_(r,k) = diffToBary[r][k]);  B = I.
+void tet_matrices(HostTet& t);
 HostTet make_tet(const pies_solver* s, const uint32_t ids[4], float w, float lo, float hi) {
   HostTet t{};
   t.hint = kNoColourHint;
@@ -69,6 +70,11 @@ HostTet make_tet(const pies_solver* s, const uint32_t ids[4], float w, float lo,
   t.lo = lo;
   t.hi = hi;
   t.w = w;
+  tet_matrices(t);
+  return t;
+}
+// A = [0; Qinv^T D] and A^T A from the rest data (Constraints.cpp:157-184; also after pies_set_rest replaced Qinv)
+void tet_matrices(HostTet& t) {
   const float D[3][4] = {{-1, 1, 0, 0}, {-1, 0, 1, 0}, {-1, 0, 0, 1}};
   for (int j = 0; j < 4; ++j) t.A[j] = 0.0f;
   for (int r = 0; r < 3; ++r)
@@ -83,7 +89,6 @@ HostTet make_tet(const pies_solver* s, const uint32_t ids[4], float w, float lo,
       for (int k = 0; k < 4; ++k) acc += t.A[4 * k + i] * t.A[4 * k + j];
       t.AtA[4 * i + j] = acc;
     }
-  return t;
 }
 
 void push_distance(pies_solver* s, uint32_t a, uint32_t b, float w, uint16_t hint = kNoColourHint) {
@@ -326,6 +331,38 @@ int pies_add_bend_constraints(pies_solver_t* s, uint32_t n, const uint32_t* ids,
   PIES_BEGIN_EDIT(s);
   if (n && (!ids || !ids_ok(s, ids, 4ull * n))) return fail(s, PIES_ERR_INVALID, "bend constraint: bad node id");
   for (uint32_t i = 0; i < n; ++i) push_bend(s, ids + 4 * i, w);
+  return PIES_OK;
+}
+
+/* Rest data of constraints [first, first + n) of a container, replaced (the counterpart of pies_get_rest, same layout): a host that
+ * restores a saved scene, or pre-strains a material, does not have to move the nodes into the rest pose first.  The reference's
+ * factories take the rest pose from the node positions at creation (Constraints.cpp:39-56, 130-184, 257-310, 368-394). */
+int pies_set_rest(pies_solver_t* s, int type, uint32_t first, uint32_t n, const float* rest) {
+  PIES_BEGIN_EDIT(s);
+  if (n && !rest) return fail(s, PIES_ERR_INVALID, "pies_set_rest: rest is NULL");
+  auto in_range = [&](size_t size) { return static_cast<uint64_t>(first) + n <= size; };
+  switch (type) {
+    case PIES_DISTANCE:
+      if (!in_range(s->h_distance.size())) return fail(s, PIES_ERR_INVALID, "pies_set_rest: range beyond the container");
+      for (uint32_t i = 0; i < n; ++i) s->h_distance[first + i].target = rest[i];
+      break;
+    case PIES_TET:
+    case PIES_VOLUME: {
+      std::vector<HostTet>& list = type == PIES_TET ? s->h_tet : s->h_volume;
+      if (!in_range(list.size())) return fail(s, PIES_ERR_INVALID, "pies_set_rest: range beyond the container");
+      for (uint32_t i = 0; i < n; ++i) {
+        std::memcpy(list[first + i].qinv, rest + 9ull * i, sizeof(float) * 9);
+        tet_matrices(list[first + i]);
+      }
+      break;
+    }
+    case PIES_BEND:
+      if (!in_range(s->h_bend.size())) return fail(s, PIES_ERR_INVALID, "pies_set_rest: range beyond the container");
+      for (uint32_t i = 0; i < n; ++i) s->h_bend[first + i].angle = rest[i];
+      break;
+    default:
+      return fail(s, PIES_ERR_INVALID, "pies_set_rest: container without rest data");
+  }
   return PIES_OK;
 }
 

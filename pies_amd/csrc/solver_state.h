@@ -185,6 +185,9 @@ struct pies_solver {
   std::vector<uint16_t> h_pairDictIndex;  // host copy (the tile plan stores it in tile order)
   uint32_t pdTileRecords = 0;            // sum of the tiles' node counts
   uint32_t pdTiles = 0;                  // PD: tiles of the strain + volume local step (0: per-(element, node) records)
+  float pdWindowPadding = 0.0f;         // PD: stored / real entries of the windowed matrix (0: not built)
+  uint32_t pdWindowEntries = 0;         // its stored entries
+  uint32_t pdWindowHalo = 0;            // its halo entries over all chunks
   uint32_t pdRowStencils = 0;           // PD: distinct rows of the system matrix in its row dictionary (0: none)
   bool tetVolumePaired = false;    // PD: h_volume[k] and h_tet[k] are the same element for every k (fused local step)
   bool triangleCollisions = true;  // PD point-triangle CCD contacts (Solver.cpp:693-797); extension flag to switch off

@@ -181,10 +181,24 @@ int collision_order(const pies_solver* s) {
   if (order == PIES_COLLISION_ORDER_GROUPS && !s->collideFast) order = PIES_COLLISION_ORDER_REFERENCE;
   return order;
 }
-bool needs_grid_groups(const pies_solver* s) { return collision_order(s) != PIES_COLLISION_ORDER_PAIRS || !s->collideFast; }
+// The reference's order runs by dependency levels of turns (pair_kernels.hip: launch_collide_turns) from 1 024 nodes on; below that -
+// and with PIES_REFERENCE_TURNS=0 - as the single chain of k_collide_reference, which is also the turns' fallback.
+bool reference_by_turns(const pies_solver* s) {
+  if (const char* e = tuning_env("PIES_REFERENCE_TURNS")) return e[0] != '0' && s->pairs.turnCnt != nullptr;
+  return s->nd.n >= 1024u && s->pairs.turnCnt != nullptr;
+}
+// (the group lists of k_grid_groups: the group order's, and the list kernels' for ranges wider than two cells per axis)
+bool needs_grid_groups(const pies_solver* s) {
+  const int order = collision_order(s);
+  if (order == PIES_COLLISION_ORDER_GROUPS) return true;
+  if (order == PIES_COLLISION_ORDER_REFERENCE && !reference_by_turns(s)) return false;
+  return !s->collideFast;
+}
 uint32_t enqueue_collide(pies_solver* s, bool rearm) {
   switch (collision_order(s)) {
     case PIES_COLLISION_ORDER_REFERENCE:
+      if (reference_by_turns(s))
+        return launch_collide_turns(s->stream, s->hash, s->pairs, s->nd, s->opt.gridSpacing, s->opt.friction, s->opt.staticFrictionThreshold, s->pairRounds);
       return launch_collide_reference(s->stream, s->hash, s->nd, s->opt.gridSpacing, s->opt.friction, s->opt.staticFrictionThreshold);
     case PIES_COLLISION_ORDER_GROUPS:
       return launch_collide(s->stream, s->hash, s->nd, s->opt.friction, s->opt.staticFrictionThreshold, rearm);
@@ -415,13 +429,17 @@ void enqueue_pd_substep(pies_solver* s, int only, uint32_t* counts, uint64_t* un
     const int overflow = s->pcgOverflow ? (int)(s->pcgMaxIters > s->pcgBudget ? s->pcgMaxIters - s->pcgBudget : 0u) : 0;
     const bool lastSolve = it + 1 == s->opt.iterations && !statsInStabilize;
     if (only < 0) {  // Solver.cpp:356-364
-      const bool probed = s->probe && (s->probe->kernel == PIES_KERNEL_PD_SPMV || s->probe->kernel == PIES_KERNEL_PD_CG_UPDATE);
       // a probed solve never takes the converged early exit: every bracketed launch does a full SpMV / vector update
+      // (PIES_PCG_NEVER_EXIT=1: the same for every solve of a captured substep - a diagnostics switch for profiler passes, so that a
+      // trace of a body at rest holds working CG launches instead of early exits; a converged column stands still, cg1_scalars)
+      const char* neverExitEnv = tuning_env("PIES_PCG_NEVER_EXIT");  // (read when the substep is captured)
+      const bool neverExitTuning = neverExitEnv && neverExitEnv[0] == '1';
+      const bool probed = neverExitTuning || (s->probe && (s->probe->kernel == PIES_KERNEL_PD_SPMV || s->probe->kernel == PIES_KERNEL_PD_CG_UPDATE));
       auto hook = s->probe ? [](void* ctx, int cls) { probe_mark(static_cast<pies_solver*>(ctx), cls); } : (void (*)(void*, int))nullptr;
       if (fuseRhs && units && s->probe && s->probe->kernel == PIES_KERNEL_PD_RHS) *units += s->nd.n;
       if (single) launch_pd_solve1(st, s->nd, pd, (int)s->pcgBudget, s->pcgTol, it == 0, lastSolve, fuseRhs, probed, hook, s, overflow);
       else launch_pd_solve(st, s->nd, pd, (int)s->pcgBudget, s->pcgTol, -1, it == 0, lastSolve, probed, hook, s, overflow);
-      if (probed && units) *units += (uint64_t)s->nd.n * s->pcgBudget;
+      if (probed && s->probe && units) *units += (uint64_t)s->nd.n * s->pcgBudget;
     }
     else if (only == PIES_KERNEL_PD_SPMV) {
       if (single) launch_pd_solve1(st, s->nd, pd, (int)s->pcgBudget, s->pcgTol, true, false, false, true);
@@ -636,7 +654,9 @@ int adapt_pair_rounds(pies_solver* s) {
   if (deepest == 0) return PIES_OK;  // no pass since the last look
   HIP_TRY(s, hipMemsetAsync(s->pairs.ctl + kPairDeepest, 0, sizeof(uint32_t), s->stream));
   uint32_t rounds = s->pairRounds;
-  const uint32_t want = std::min(1024u, ((deepest + deepest / 4u + 8u + 15u) / 16u) * 16u);  // a quarter and eight more, in steps of 16
+  // a quarter and eight more, in steps of 16 (the reference's order by turns runs deeper than the pair order: ~850 levels per pass of config 4)
+  const uint32_t cap = collision_order(s) == PIES_COLLISION_ORDER_REFERENCE ? 4096u : 1024u;
+  const uint32_t want = std::min(cap, ((deepest + deepest / 4u + 8u + 15u) / 16u) * 16u);
   if (deepest > rounds) { rounds = want; s->pairCalm = 0; }
   else if (want < rounds) { if (++s->pairCalm >= 3) { rounds = want; s->pairCalm = 0; } }
   else s->pairCalm = 0;

@@ -439,9 +439,11 @@ def ccd_fp64(ap0, ab0, ac0, ap1, ab1, ac1, thr):
     def lin(a, b):
         return [np.array([a[k], b[k] - a[k]]) for k in range(3)]
     p, q, r = lin(ap0, ap1), lin(ab0, ab1), lin(ac0, ac1)
-    det = (P.polymul(p[0], P.polysub(P.polymul(q[1], r[2]), P.polymul(q[2], r[1])))
-           - P.polymul(p[1], P.polysub(P.polymul(q[0], r[2]), P.polymul(q[2], r[0])))
-           + P.polymul(p[2], P.polysub(P.polymul(q[0], r[1]), P.polymul(q[1], r[0]))))
+    # (polysub / polyadd, not the array operators: polymul trims trailing zero coefficients - a static point has none of degree 1 -
+    # and arrays of different lengths do not subtract; for moving points the coefficients are the same numbers)
+    det = P.polyadd(P.polysub(P.polymul(p[0], P.polysub(P.polymul(q[1], r[2]), P.polymul(q[2], r[1]))),
+                              P.polymul(p[1], P.polysub(P.polymul(q[0], r[2]), P.polymul(q[2], r[0])))),
+                    P.polymul(p[2], P.polysub(P.polymul(q[0], r[1]), P.polymul(q[1], r[0]))))
     roots = np.roots(det[::-1])
     real = sorted(x.real for x in roots if abs(x.imag) < 1e-9 and 0 <= x.real <= 1)
     if not real:

@@ -21,19 +21,31 @@ TOL = 1e-5
 particles = scenes.loose_particles
 
 
+TURNS = "turns"  # rule 0 executed by dependency levels of turns whatever the scene's size (the default from 1 024 nodes on)
+
+
 def pair(pies, oracle, build, iterations, ticks, rule=2, oracle_rule=None, **opt):
-    g = pies.Solver(scenes.pbd_options(pies, iterations, **opt))
-    o = oracle.OracleSolver(scenes.pbd_options(oracle, iterations, **opt))
-    for s in (g, o):
-        build(s)
-    o.set_flag(oracle.FLAG_COLLISION_RULE, rule if oracle_rule is None else oracle_rule)
-    g.set_flag(pies.FLAG_COLLISION_ORDER, rule)
-    g.tick(ticks)
-    o.tick(ticks)
+    """rule: the device's node-node order (0 the reference's - as one sequential chain below 1 024 nodes -, TURNS the reference's by
+    dependency levels of turns, 1 the group order, 2 the pair order); the oracle runs the same rule (TURNS: its plain loop, rule 0)"""
+    turns = rule == TURNS
+    if turns:
+        rule = 0
+    pies.set_tuning("PIES_REFERENCE_TURNS", "1" if turns else ("0" if rule == 0 and opt.pop("chain", False) else None))
+    try:
+        g = pies.Solver(scenes.pbd_options(pies, iterations, **opt))
+        o = oracle.OracleSolver(scenes.pbd_options(oracle, iterations, **opt))
+        for s in (g, o):
+            build(s)
+        o.set_flag(oracle.FLAG_COLLISION_RULE, rule if oracle_rule is None else oracle_rule)
+        g.set_flag(pies.FLAG_COLLISION_ORDER, rule)
+        g.tick(ticks)
+        o.tick(ticks)
+    finally:
+        pies.set_tuning("PIES_REFERENCE_TURNS", None)
     return g, o
 
 
-RULES = pytest.mark.parametrize("rule", [0, 1, 2], ids=["reference-order", "group-order", "pair-order"])
+RULES = pytest.mark.parametrize("rule", [0, TURNS, 1, 2], ids=["reference-order", "reference-order-by-turns", "group-order", "pair-order"])
 
 
 def check(g, o, exact=True):
@@ -146,7 +158,7 @@ def test_device_rule_vs_reference_order_is_a_small_perturbation(oracle):
     assert com < 0.05 and ext < 0.5
 
 
-@pytest.mark.parametrize("rule", [0, 1, 2])
+@pytest.mark.parametrize("rule", [0, TURNS, 1, 2])
 @pytest.mark.parametrize("spacing", [1.0, 0.3, 0.045])
 def test_small_grid_spacing(pies, oracle, spacing, rule):
     """gridSpacing < 2 (r + 0.5): a node spans 3 and more cells per axis (NodeCompRange allows up to 50,
@@ -249,9 +261,9 @@ def test_config4_l500k_one_tick(pies, oracle):
 
 
 def test_config4_l500k_one_iteration_reference_order(pies, oracle):
-    """BASELINE config 4 at full size in the REFERENCE's order (rule 0: ascending node index, range from the node's live position):
-    the loop is one dependent chain on one wavefront (~20 us per node), so one iteration - 500 000 visits, >18 M resolved pairs -
-    against the oracle's plain loop.  Exact equality."""
+    """BASELINE config 4 at full size in the REFERENCE's order (rule 0: ascending node index, range from the node's live position),
+    one iteration - 500 000 turns, >18 M resolved pairs - against the oracle's plain loop.  Exact equality.  (Until round 4 the
+    device ran this as one dependent chain on one wavefront, ~20 us per node: 15 s; since round 5 by dependency levels of turns.)"""
     p, v = particles(scenes.L500K)
 
     def build(s):
@@ -260,6 +272,37 @@ def test_config4_l500k_one_iteration_reference_order(pies, oracle):
     g, o = pair(pies, oracle, build, 1, 1, rule=0)
     check(g, o)
     assert g.collision_pairs == o.collision_pairs > 10_000_000
+    h = g.collision_health()
+    print("config 4, reference order by turns:", h)
+    assert h["levels"] > 100 and h["passes_inexact"] == 0
+
+
+def test_config4_l500k_one_tick_reference_order(pies, oracle):
+    """The whole tick of BASELINE config 4 (four iterations) in the reference's order, by turns, against the oracle's plain loops"""
+    p, v = particles(scenes.L500K)
+
+    def build(s):
+        s.addNodes(p)
+        s.set_velocities(v)
+    g, o = pair(pies, oracle, build, 4, 1, rule=0)
+    check(g, o)
+    assert g.collision_pairs == o.collision_pairs > 50_000_000
+    h = g.collision_health()
+    print("config 4, one tick in the reference order by turns:", h)
+    assert h["passes_inexact"] == 0
+
+
+def test_the_sequential_chain_still_runs_the_reference_order(pies, oracle):
+    """k_collide_reference - the turns' fallback, and the path below 1 024 nodes - on a scene large enough to take the turns by default"""
+    p, v = particles((12, 10, 11))
+
+    def build(s):
+        s.addNodes(p)
+        s.set_velocities(v)
+    g, o = pair(pies, oracle, build, 3, 2, rule=0, chain=True)
+    check(g, o)
+    assert g.collision_pairs == o.collision_pairs > 1000
+    assert g.collision_health()["levels"] == 0
 
 
 def test_dense_cells_take_the_unstaged_path(pies, oracle):
@@ -279,6 +322,8 @@ def test_dense_cells_take_the_unstaged_path(pies, oracle):
         check(g, o)
         assert g.collision_pairs == o.collision_pairs > 700
     g, o = pair(pies, oracle, build, 2, 1, rule=0)  # and the sequential chain over the same dense buckets
+    check(g, o)
+    g, o = pair(pies, oracle, build, 2, 1, rule=TURNS)  # the reference order by turns: partner lists of several batches of 64
     check(g, o)
 
 
@@ -336,12 +381,13 @@ def test_deep_overlaps_leave_the_slack(pies, oracle, spacing):
     def build(s):
         s.addNodes(p)
         s.set_velocities(v)
-    g, o = pair(pies, oracle, build, 2, 2, rule=2)
-    h = g.collision_health()
-    print("deep overlaps, spacing", spacing, h)
-    assert h["passes_inexact"] == 0
-    check(g, o)
-    assert g.collision_pairs == o.collision_pairs > 1000
+    for rule in (2, TURNS):
+        g, o = pair(pies, oracle, build, 2, 2, rule=rule)
+        h = g.collision_health()
+        print("deep overlaps, spacing", spacing, rule, h)
+        assert h["passes_inexact"] == 0
+        check(g, o)
+        assert g.collision_pairs == o.collision_pairs > 1000
 
 
 def test_pair_order_is_deterministic_with_levels_in_the_tail(pies):

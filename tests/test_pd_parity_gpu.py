@@ -210,7 +210,9 @@ def test_row_dictionary_changes_nothing(pies, tune):
         res.append((g.positions, g.velocities, g.pcg_stats()))
         g.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
-    assert res[0][2] == res[1][2]
+    # (the statistics are sums over the rows in the order the kernels' threads own them - the windowed matrix that serves a scene
+    # without a dictionary since round 5 deals its rows differently -, so the largest residual agrees to rounding, not to the bit)
+    assert res[0][2][1:] == res[1][2][1:] and abs(res[0][2][0] - res[1][2][0]) <= 1e-3 * res[1][2][0]
 
 
 def test_pd_flattened_and_inverted_elements(pies, oracle):

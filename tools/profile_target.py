@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """The program tools/profile_round.sh puts under rocprofv3: N ticks of one of bench.py's workloads, whole substeps
-(every kernel in its place), nothing else.  usage: profile_target.py config2|config3|config4|contacts|pdcontacts|pbd1m|pd1m N [NAME=VALUE ...]"""
+(every kernel in its place), nothing else.  usage: profile_target.py config2|config3|config4|contacts|pdcontacts|pbd1m|pd1m|pd1m_work|pd1m_streamed|pd_unstructured|pd_unstructured_1m N [NAME=VALUE ...]
+(the *_work / *_streamed / pd_unstructured* targets run every captured CG launch as a working iteration - PIES_PCG_NEVER_EXIT: a body at
+rest converges at its first look at the residual, and a trace of it holds nothing but early exits; pd1m_streamed switches the row
+dictionary off so that the 100^3 lattice streams its matrix like an unstructured mesh does)"""
 import os
 import sys
 
@@ -28,6 +31,16 @@ elif what == "pbd1m":
     g = bench.build_scene(capi, scenes.L1M, 99, schedule=capi.SCHEDULE_LAYERED, device=0)
 elif what == "pd1m":
     g = bench.pd_beam(scenes.L1M, 0, settle=0, pcg=(3e-7, 3))
+elif what in ("pd1m_work", "pd1m_streamed"):
+    capi.set_tuning("PIES_PCG_NEVER_EXIT", "1")
+    if what == "pd1m_streamed":
+        capi.set_tuning("PIES_PD_ROW_DICT", "0")
+    g = bench.pd_beam(scenes.L1M, 0, settle=0, pcg=(3e-7, 3))
+elif what in ("pd_unstructured", "pd_unstructured_1m"):
+    capi.set_tuning("PIES_PCG_NEVER_EXIT", "1")
+    g = capi.Solver(capi.Options(solver=capi.PD, iterations=10), device=0)
+    scenes.build_unstructured_pd(g, scenes.delaunay_beam(scenes.L1M if what.endswith("_1m") else scenes.L100K))
+    g.set_pcg(3e-7, 3)
 elif what == "config4":
     p, v = bench.config4_particles()
     g = capi.Solver(scenes.pbd_options(capi, 4), device=0)

@@ -20,7 +20,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WORKLOADS = ("config2", "config3", "config4", "contacts", "pdcontacts", "pbd1m", "pd1m")
+WORKLOADS = ("config2", "config3", "config4", "contacts", "pdcontacts", "pbd1m", "pd1m", "pd1m_work", "pd1m_streamed", "pd_unstructured",
+             "pd_unstructured_1m")
 
 
 def short(name):
