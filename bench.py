@@ -147,6 +147,19 @@ def pmc_traffic_of_pass(prefix, workload, anchor):
     return None, None
 
 
+def pmc_valu(kernel_name, workload):
+    """SQ_INSTS_VALU (wave-instructions) per launch of `kernel_name` from the committed rocprofv3 --pmc pass of the workload"""
+    for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_valu_pd.json")), reverse=True):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                v = json.load(f).get(workload, {}).get(kernel_name, {}).get("SQ_INSTS_VALU")
+            if v:
+                return v, "profiles/%s [%s][%s]" % (name, workload, kernel_name)
+        except (OSError, ValueError, AttributeError):
+            pass
+    return None, None
+
+
 def rocprof_average(kernel_name, workload):
     """Average duration (us) of `kernel_name` in the committed rocprofv3 --kernel-trace --stats summary of the workload."""
     import csv
@@ -269,6 +282,16 @@ def pd_rooflines(g, workload, substeps):
         "by VALU issue (about 2 000 instructions per lane), not by HBM" if tiles else
         "fused strain + volume local step: two projections per element from one gather and one SVD, one 12-byte record per "
         "corner; bound by VALU issue at 100k particles"))}
+    rl = out["roofline"]
+    if rl:
+        # the yardstick of a launch bound by VALU issue: wave-instructions x 2 cycles (a SIMD issues a wave64 VALU instruction every 2
+        # cycles when it has two wavefronts to take them from, MI355X_MICROARCH.md "Per-instruction cycle constants") over what the
+        # chip's 1 024 SIMDs offer in the launch's duration at 2.4 GHz
+        insts, src = pmc_valu(rl["kernel"], workload)
+        if insts:
+            rl["valu_wave_instructions_per_launch"] = insts
+            rl["valu_source"] = src
+            rl["valu_frac"] = insts * 2.0 / (1024 * 2.4e9 * rl["avg_launch_us"] * 1e-6)
     sp = roofline(g, "pd_spmv", B["pd_spmv"], substeps=substeps, workload=workload, note=(
         "ONE launch = one whole PCG iteration (Chronopoulos-Gear form: scalars from the previous launch's partial sums, the "
         "neighbours' new preconditioned residual recomputed in the gather, x / r / p / s of the own rows, the next dot products): "
@@ -756,7 +779,32 @@ def run_config4(device):
                                            "entry per node; a node of this scene overlaps 8 cells, i.e. 8 (key, node) entries of 12 bytes "
                                            "that are emitted, counted and scattered twice and scanned once more: `traffic` is the PMC "
                                            "figure of the whole rebuild, about ten times the survey's bytes)")}
+    # The same scene in the REFERENCE's node-node order (ascending node index, range from the live position: Solver.cpp:85-130), by
+    # dependency levels of turns (round 5), from the settled state the run above has reached: frames of one tick + one synchronisation
+    state = (g.positions, g.velocities)
     g.close()
+    try:
+        r = capi.Solver(scenes.pbd_options(capi, 4), device=device)
+        r.addNodes(state[0])
+        r.set_velocities(state[1])
+        r.set_flag(capi.FLAG_COLLISION_ORDER, capi.COLLISION_ORDER_REFERENCE)
+        r.finalize()
+        for _ in range(3):  # (the captured level launches follow the passes at the synchronisations)
+            r.tick_async(1)
+            r.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            r.tick_async(1)
+            r.synchronize()
+        out["reference_order"] = {"value": 5 / (time.perf_counter() - t0), "unit": "substeps/s", "collision_health": r.collision_health(),
+                                  "passes_left_to_the_sequential_loop": r.collision_fallbacks, "failed": r.failed,
+                                  "launches_per_substep": sum(r.launch_counts().values()),
+                                  "note": "the reference's own visiting order, bit-identical to the oracle's plain loop (tests/test_collisions_gpu.py"
+                                          "::test_config4_l500k_one_tick_reference_order_settled); settled state (ticks 23-30); until round 4 this "
+                                          "order was one sequential chain on one wavefront: 0.027 substeps/s"}
+        r.close()
+    except Exception as e:  # noqa: BLE001
+        out["reference_order"] = {"error": str(e)}
     return out
 
 
@@ -777,17 +825,25 @@ def run_config2_default_tick(device, dims, steps, with_exact):
         for name, sched, n in (("layered", capi.SCHEDULE_LAYERED, min(steps, 5)), ("exact", capi.SCHEDULE_EXACT, 1)):
             if name == "exact" and (not with_exact or tets):
                 continue
-            g = capi.Solver(scenes.pbd_options(capi, ITERATIONS), device=device)
-            scenes.build_beam(g, dims, tets=tets)
-            scenes.perturb(g, 1234, 0.05)
-            g.set_flag(capi.FLAG_NODE_COLLISIONS, 1)
-            g.set_schedule(sched)
-            g.finalize()
-            el = timed_ticks(g, n, 0, lambda: None)
-            failed = bool(g.failed)
-            res[name] = {"value": None if failed else n / el, "unit": "substeps/s", "steps": n, "launches_per_substep": sum(g.launch_counts().values()),
-                         "failed": failed, "error": g.last_error() if failed else None, "collision_health": g.collision_health()}
-            g.close()
+            # (a pile the parallel orders cannot run is left to the reference's sequential loop since round 5 - unless the pass would cost
+            # more candidate tests than PIES_FALLBACK_VISITS: the collapsing config-2 body reaches 1e10 per iteration, hours per tick in the
+            # reference as well; the budget is kept small here so that the section ends)
+            capi.set_tuning("PIES_FALLBACK_VISITS", "5000000")
+            try:
+                g = capi.Solver(scenes.pbd_options(capi, ITERATIONS), device=device)
+                scenes.build_beam(g, dims, tets=tets)
+                scenes.perturb(g, 1234, 0.05)
+                g.set_flag(capi.FLAG_NODE_COLLISIONS, 1)
+                g.set_schedule(sched)
+                g.finalize()
+                el = timed_ticks(g, n, 0, lambda: None)
+                failed = bool(g.failed)
+                res[name] = {"value": None if failed else n / el, "unit": "substeps/s", "steps": n, "launches_per_substep": sum(g.launch_counts().values()),
+                             "failed": failed, "error": g.last_error() if failed else None, "collision_health": g.collision_health(),
+                             "passes_left_to_the_sequential_loop": g.collision_fallbacks}
+                g.close()
+            finally:
+                capi.set_tuning("PIES_FALLBACK_VISITS", None)
     return out
 
 
@@ -895,12 +951,15 @@ def compact_line(full):
     put("box100k_collisions_on_exact", "config2_default_tick", "box_100k_distance_only", "exact", "value")
     put("config3_value", "other_configs", "pd_config3", "value")
     put("config3_frac_local", "other_configs", "pd_config3", "roofline", "frac")
+    put("config3_valu_frac_local", "other_configs", "pd_config3", "roofline", "valu_frac")
+    put("pd_1m_valu_frac_local", "scale_1m", "pd_1m", "roofline", "valu_frac")
     put("config3_frac_spmv", "other_configs", "pd_config3", "roofline_spmv", "frac_spmv_bytes_only")
     put("config3_frac_pcg_iter", "other_configs", "pd_config3", "roofline_spmv", "frac")
     put("config4_value", "other_configs", "collisions_config4", "value")
     put("config4_settled", "other_configs", "collisions_config4", "settled_value")
     put("config4_frac_resolve", "other_configs", "collisions_config4", "roofline", "frac")
     put("config4_frac_grid", "other_configs", "collisions_config4", "roofline_grid_build", "frac")
+    put("config4_reference_order", "other_configs", "collisions_config4", "reference_order", "value")
     put("config5_share_value", "other_configs", "pd_config5_per_gpu", "value")
     put("config5_max_over_median_frame", "other_configs", "pd_config5_per_gpu", "max_over_median_frame")
     put("config5_binding_over_quiet_frame", "other_configs", "pd_config5_per_gpu", "binding_over_quiet_frame")

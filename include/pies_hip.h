@@ -281,6 +281,11 @@ int pies_debug_pair_state(pies_solver_t* s, float* slack, float* excursion, uint
  * which a node moved further than even that (more than 0.5 in one pass: the result may then miss visits the documented order
  * makes).  Any pointer may be NULL. */
 int pies_get_collision_health(pies_solver_t* s, uint32_t* levels, uint32_t* pairs_listed, uint32_t* passes_repeated, uint32_t* passes_inexact);
+/* Node-node passes (since the handle's buffers were built) that the SEQUENTIAL loop of the reference ran in place of a parallel order:
+ * a pile the partner lists do not hold (more than 1 024 nodes within reach of one node, more listed pairs than reserved, more than
+ * 65 535 nodes in a cell), or - reference order by turns - a pass that could not be proved exact.  Such a pass has the reference's
+ * own order and result (Src/Solver.cpp:85-130 has no limit and no latch); it is slow, not wrong. */
+int pies_get_collision_fallbacks(pies_solver_t* s, uint32_t* passes);
 
 /* ---- state access --------------------------------------------------------------------------- */
 int pies_count(const pies_solver_t* s, int what, uint32_t* out);

@@ -48,7 +48,7 @@ SYMBOLS = [
     "pies_get_tri_contacts", "pies_tick_begin", "pies_export_acquire", "pies_export_release",
     "pies_read_positions_strided", "pies_set_pcg_retry", "pies_get_pcg_health", "pies_profile_in_situ",
     "pies_collision_stats", "pies_get_collision_health", "pies_set_collision_rounds", "pies_set_solver", "pies_debug_pair_state", "pies_set_tuning",
-    "pies_get_pd_tile_plan", "pies_get_tri_grid_stats", "pies_set_rest",
+    "pies_get_pd_tile_plan", "pies_get_tri_grid_stats", "pies_set_rest", "pies_get_collision_fallbacks",
 ]
 
 
@@ -120,6 +120,7 @@ def load():
         "pies_read_nodes": [vp, i32, pf, u32], "pies_write_nodes": [vp, i32, pf, u32],
         "pies_get_ids": [vp, i32, pu, u32], "pies_get_rest": [vp, i32, pf, u32],
         "pies_set_rest": [vp, i32, u32, u32, pf],
+        "pies_get_collision_fallbacks": [vp, pu],
         "pies_get_order": [vp, i32, pu, u32], "pies_get_batches": [vp, i32, pu, u32, pu],
         "pies_profile_substep": [vp, i32, pu, C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
         "pies_launch_counts": [vp, pu],
@@ -435,6 +436,13 @@ class Solver:
         v = [C.c_uint32() for _ in range(4)]
         self._ck(self._L.pies_get_collision_health(self._h, *[C.byref(x) for x in v]))
         return dict(zip(("levels", "pairs_listed", "passes_repeated", "passes_inexact"), (x.value for x in v)))
+
+    @property
+    def collision_fallbacks(self):
+        """node-node passes the reference's sequential loop ran in place of a parallel order (pies_get_collision_fallbacks)"""
+        v = C.c_uint32()
+        self._ck(self._L.pies_get_collision_fallbacks(self._h, C.byref(v)))
+        return v.value
 
     # -- state ---------------------------------------------------------------------------------
     def count(self, what):

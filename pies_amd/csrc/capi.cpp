@@ -985,6 +985,17 @@ int pies_get_collision_health(pies_solver_t* s, uint32_t* rounds, uint32_t* pair
   return PIES_OK;
 }
 
+int pies_get_collision_fallbacks(pies_solver_t* s, uint32_t* passes) {
+  if (!s || !passes) return PIES_ERR_INVALID;
+  *passes = 0;
+  if (s->pairs.ctl) {
+    HIP_TRY(s, hipSetDevice(s->device));
+    HIP_TRY(s, hipMemcpyAsync(passes, s->pairs.ctl + kPairFallbacks, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+  }
+  return PIES_OK;
+}
+
 int pies_collision_stats(pies_solver_t* s, uint64_t* pairs, uint64_t* candidates) {
   if (!s) return PIES_ERR_INVALID;
   if (pairs) *pairs = 0;

@@ -13,9 +13,9 @@ namespace pies {
 // [32] ticket (k_collide_flow) [33] epoch [34..36] / [37..39] bounding box of the cell ranges (min / max, as int)
 // [44] progress of k_collide_reference (nodes visited, diagnostics) [46..47] candidates tested (64 bit, statistics)
 constexpr uint32_t kCounterUsed = 0, kCounterEntries = 1, kCounterFlags = 3, kCounterPass0 = 4, kCounterPairs = 31, kCounterTicket = 32,
-                   kCounterEpoch = 33, kCounterBoxMin = 34, kCounterBoxMax = 37, kCounterSortPasses = 40, kCounterProgress = 44, kCounterCandidates = 46 /* 64 bit: [46], [47] */,
+                   kCounterEpoch = 33, kCounterBoxMin = 34, kCounterBoxMax = 37, kCounterSortPasses = 40, kCounterDense = 41 /* a cell holds more than kMaxBucket nodes: the group order leaves the pass to the sequential loop */, kCounterProgress = 44, kCounterCandidates = 46 /* 64 bit: [46], [47] */,
                    kHashCounters = 64;
-// failure flags: 1 non-finite position, 2 cell index overflow, 4 more than kMaxBucket nodes in a cell, 8 k_collide_flow wait timed
+// failure flags: 1 non-finite position, 2 cell index overflow, (4: until round 4 more than kMaxBucket nodes in a cell - now kCounterDense), 8 k_collide_flow wait timed
 // out, 128 more cell entries than reserved  (16, 32, 64 belong to the triangle grid's word, tri_kernels.h)
 constexpr uint32_t kRadixTile = 4096;  // entries per workgroup of a radix pass (256 threads x 16)
 
@@ -49,10 +49,13 @@ struct HashArrays {
 // groups: group sizes and pass lists of the group order (k_grid_groups; also its "too many nodes in a cell" latch) - the pair order
 // over ranges of at most two cells looks at the buckets itself (k_pair_groups) and builds without it
 uint32_t launch_hash_build(hipStream_t st, const HashArrays& H, const NodeArrays& nd, float gridSpacing, uint32_t sortPasses, bool groups = true);
-constexpr uint32_t kMaxBucket = 2048;  // nodes overlapping one cell before the simulation is declared failed
+constexpr uint32_t kMaxBucket = 2048;  // nodes overlapping one cell beyond which the parallel orders hand the pass to the sequential loop (the
+                                       // reference's PBD loop has no limit and no latch, Solver.cpp:81-130; until round 4 this was a failure)
 // the resolve of Solver.cpp:85-130 in the parallel visiting order; returns the number of launches.
 // rearm: the launch first resets the work queue of k_collide_flow (a replay without a new hash build, profile passes)
-uint32_t launch_collide(hipStream_t st, const HashArrays& H, const NodeArrays& nd, float friction, float staticThreshold, bool rearm = false);
+// gridSpacing: for the sequential loop that takes a pass over a pile the group order cannot run (kCounterDense)
+uint32_t launch_collide(hipStream_t st, const HashArrays& H, const NodeArrays& nd, float gridSpacing, float friction, float staticThreshold,
+                        bool rearm = false);
 // the same loop in the reference's order: ascending node index, range from the current position (one sequential chain)
 // gate != nullptr: a device word; the kernel returns at once while it is 0 (the fallback of launch_collide_turns)
 uint32_t launch_collide_reference(hipStream_t st, const HashArrays& H, const NodeArrays& nd, float gridSpacing, float friction,

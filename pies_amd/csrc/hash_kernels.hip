@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(kBlock) k_grid_range(HashArrays H, const float
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (blockIdx.x == 0) {  // the build's counters (k_grid_zero's work: nothing in this launch reads them; k_grid_reset, which needs the
     const uint32_t t = threadIdx.x;  // previous build's cell count, runs before it)
-    if (t == kCounterUsed || t == kCounterEntries || t == 2) H.counters[t] = 0;
+    if (t == kCounterUsed || t == kCounterEntries || t == 2 || t == kCounterDense) H.counters[t] = 0;
     if (t >= kCounterPass0 && t < kCounterPass0 + 27) H.counters[t] = 0;
     if (t == kCounterTicket) H.counters[t] = 0;
     if (t == kCounterEpoch) H.counters[t] += 1;
@@ -487,7 +487,7 @@ __global__ void __launch_bounds__(kBlock) k_grid_groups(HashArrays H) {
     if (u < used) {
       s = H.used[u];
       const uint32_t bs = H.start[s], be = H.end[s];
-      if (be - bs > kMaxBucket) atomicOr(&H.counters[kCounterFlags], 4u);  // runaway pile-up: latch, like Solver.cpp:741-755
+      if (be - bs > kMaxBucket) H.counters[kCounterDense] = 1u;  // a pile the group order's tables do not hold: the sequential loop takes the pass
       for (uint32_t e = bs; e < be; ++e) gc += val[e] >> 31;
       H.gcnt[s] = gc;
       if (gc) {
@@ -871,7 +871,7 @@ __global__ void __launch_bounds__(kColBlock) k_collide(HashArrays H, float4* pos
   const int lane = threadIdx.x & 63;
   const LaneRole role = {lane % 3, lane / 3};
   const uint32_t wave = (blockIdx.x * kColBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kColBlock) >> 6;
-  if (H.counters[3]) return;  // failed: the host latches _simFailed
+  if (H.counters[3] || H.counters[kCounterDense]) return;  // failed: the host latches _simFailed; a pile: the sequential loop runs the pass
   const GridBox B = grid_box(H.counters);
   const uint32_t* __restrict__ val = H.val[grid_passes(B) & 1u];
   const uint32_t ngroups = H.counters[4 + pass];
@@ -902,7 +902,7 @@ __global__ void __launch_bounds__(kColBlock) k_collide_flow(HashArrays H, float4
   float* vel = reinterpret_cast<float*>(vel4);
   const int lane = threadIdx.x & 63;
   const LaneRole role = {lane % 3, lane / 3};
-  if (H.counters[3]) return;
+  if (H.counters[3] || H.counters[kCounterDense]) return;
   const GridBox B = grid_box(H.counters);
   const uint32_t* __restrict__ val = H.val[grid_passes(B) & 1u];
   const uint32_t epoch = H.counters[kCounterEpoch];
@@ -963,9 +963,29 @@ __global__ void __launch_bounds__(kColBlock) k_collide_flow(HashArrays H, float4
 // pass), buckets are those of the grid built at the start of the iteration, visited in dx, dy, dz order.  The loop is
 // one dependent chain: one wavefront runs it.  Lanes look up to 64 cells of the range at once.
 __global__ void __launch_bounds__(64) k_collide_reference(HashArrays H, float4* pos4, float4* vel4, const float* __restrict__ radius, uint32_t n,
-                                                          float scale, float friction, float staticThreshold, const uint32_t* __restrict__ gate) {
-  if (gate && *gate == 0u) return;        // (the fallback of the pass by turns: only when that pass asks for it)
+                                                          float scale, float friction, float staticThreshold, const uint32_t* __restrict__ gate,
+                                                          unsigned long long budget) {
+  if (gate && *gate == 0u) return;        // (the fallback of a parallel order: only when that pass asks for it)
   if (H.counters[kCounterFlags]) return;  // failed: the host latches _simFailed
+  if (gate) {
+    // What the pass costs here: the sum over the cells of (nodes in the cell)^2 candidate tests, ~15 M of them per second on this one
+    // wavefront.  A pile whose pass would take minutes (BASELINE config 2 with the node-node pass on collapses 100 000 nodes into a few
+    // cells - quirk Q2 -: 10^10 tests per iteration, hours per tick in the reference as well) is declared failed instead of keeping
+    // the device busy for longer than a host waits: the one limit of this build the reference does not have (PIES_FALLBACK_VISITS, 1e9).
+    const uint32_t used = H.counters[kCounterUsed];
+    unsigned long long est = 0;
+    for (uint32_t u = threadIdx.x; u < used; u += 64u) {
+      const uint32_t sl = H.used[u];
+      const unsigned long long len = H.end[sl] - H.start[sl];
+      est += len * len;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) est += __shfl_xor(est, o, 64);
+    if (est > budget) {
+      if (threadIdx.x == 0) atomicOr(&H.counters[kCounterFlags], 4u);
+      return;
+    }
+  }
   float* pos = reinterpret_cast<float*>(pos4);
   float* vel = reinterpret_cast<float*>(vel4);
   const int lane = threadIdx.x & 63;
@@ -1044,7 +1064,7 @@ uint32_t launch_hash_build(hipStream_t st_, const HashArrays& H, const NodeArray
   return launches;
 }
 
-uint32_t launch_collide(hipStream_t st_, const HashArrays& H, const NodeArrays& nd, float friction, float staticThreshold, bool rearm) {
+uint32_t launch_collide(hipStream_t st_, const HashArrays& H, const NodeArrays& nd, float scale, float friction, float staticThreshold, bool rearm) {
   if (nd.n == 0) return 0;
   const dim3 grid(std::max<uint32_t>(1u, std::min<uint32_t>(2048u, (nd.n / 8 + 1) / 2)));
   auto flag = [](const char* name) { const char* e = tuning_env(name); return e && e[0] == '1' ? 1 : 0; };
@@ -1057,17 +1077,20 @@ uint32_t launch_collide(hipStream_t st_, const HashArrays& H, const NodeArrays& 
     if (rearm) hipLaunchKernelGGL(k_collide_rearm, dim3(1), dim3(64), 0, st_, H);
     hipLaunchKernelGGL(k_collide_flow, grid, dim3(kColBlock), 0, st_, H, nd.pos, nd.vel, nd.radius, friction, staticThreshold, forceGlobal,
                        maxSpins);
-    return 1;
+    // a cell with more nodes than the group order's tables hold: the pass in the reference's own order (returns at once otherwise)
+    return 1 + launch_collide_reference(st_, H, nd, scale, friction, staticThreshold, H.counters + kCounterDense);
   }
   for (uint32_t pass = 0; pass < 27; ++pass)
     hipLaunchKernelGGL(k_collide, grid, dim3(kColBlock), 0, st_, H, nd.pos, nd.vel, nd.radius, pass, friction, staticThreshold, forceGlobal);
-  return 27;
+  return 27 + launch_collide_reference(st_, H, nd, scale, friction, staticThreshold, H.counters + kCounterDense);
 }
 
 uint32_t launch_collide_reference(hipStream_t st_, const HashArrays& H, const NodeArrays& nd, float scale, float friction, float staticThreshold,
                                   const uint32_t* gate) {
   if (nd.n == 0) return 0;
-  hipLaunchKernelGGL(k_collide_reference, dim3(1), dim3(64), 0, st_, H, nd.pos, nd.vel, nd.radius, nd.n, scale, friction, staticThreshold, gate);
+  unsigned long long budget = 1000000000ull;  // candidate tests a fallback pass may cost (a minute on the one wavefront; BASELINE config 4: 3.4e8)
+  if (const char* e = tuning_env("PIES_FALLBACK_VISITS")) budget = std::strtoull(e, nullptr, 10);
+  hipLaunchKernelGGL(k_collide_reference, dim3(1), dim3(64), 0, st_, H, nd.pos, nd.vel, nd.radius, nd.n, scale, friction, staticThreshold, gate, budget);
   return 1;
 }
 

@@ -21,7 +21,8 @@ constexpr uint32_t kPairEdges = 9;      // pairs listed by the last pass (diagno
 constexpr uint32_t kPairDeepest = 12;    // most levels any pass needed since the host last looked (it sizes the captured launches from it)
 constexpr uint32_t kPairGroups = 10;     // groups of this grid (entries of `grp`)
 constexpr uint32_t kPairSpilled = 11;    // groups the small list kernel passed on to the large one (entries of `spill`)
-constexpr uint32_t kPairFallback = 13;   // reference order by turns: the pass could not be proved exact twice - the sequential loop runs it
+constexpr uint32_t kPairFallback = 13;   // the sequential loop runs this pass: by turns it could not be proved exact twice, or (either order) a pile
+                                         // the lists do not hold (more than 1 024 partners of a node, more entries than reserved)
 constexpr uint32_t kPairFallbacks = 14;  // lifetime: passes the sequential loop had to run
 constexpr uint32_t kPairWords = 16;
 
@@ -60,7 +61,7 @@ struct PairArrays {
 
 // One pass of Solver.cpp:85-130 in the pair order: save, lists, start, `rounds` level launches, the tail
 // that finishes whatever levels are left, and the (normally skipped) repeat with the widest slack.  Returns the launches.
-uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArrays& P, const NodeArrays& nd, float friction,
+uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArrays& P, const NodeArrays& nd, float gridSpacing, float friction,
                               float staticThreshold, uint32_t rounds);
 
 // One pass of Solver.cpp:85-130 in the REFERENCE's order - ascending node index, the node's range from its live position, buckets in

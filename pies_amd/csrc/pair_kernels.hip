@@ -70,11 +70,15 @@ PIES_DEV uint64_t pair_key(uint32_t i, uint32_t j, float pix, float piy, float p
   return (static_cast<uint64_t>(cls) << 58) | (k >> 6);
 }
 
-// The reference order by turns needs every pair within reach to share a cell of the two INSERTED ranges (a node's live range is looked
-// up when its turn starts and may differ from the inserted one; a partner is then met in the cells of the live range its inserted
-// range holds): the ranges cover [p - r - 0.5, p + r + 0.5] per axis (Solver.cpp:877-901), so two nodes whose centres are closer than
-// r_i + r_j + 1 share a cell, and "within reach" is 1.001 (r_i + r_j + s_i + s_j): slacks of at most 0.45 guarantee it (radii up to 50).
-constexpr float kTurnMaxSlack = 0.45f;
+// The reference order by turns looks a node's range up from its LIVE position when its turn starts, so a node can be met in a cell its
+// partner was not inserted into when the lists were built.  The lists hold the pairs within reach that share a cell of the two INSERTED
+// ranges; the ranges cover [p - r - 0.5, p + r + 0.5] per axis (Solver.cpp:877-901), so two nodes whose inserted ranges share no cell
+// are r_i + r_j + 1 apart on some axis and can only touch in a pass in which their excursions add up to 1: while every node's
+// excursion stays below kTurnMaxExcursion the lists (and k_pair_verify's test of the unlisted nodes that DO share a cell) cover every
+// visit that can hit.  The nodes that stray further are looked at one by one after the pass (k_pair_verify); only a pass in which
+// one of them can have touched a node it shares no inserted cell with is left to the sequential loop.
+constexpr float kTurnMaxExcursion = 0.45f;
+PIES_DEV float lane_value(float v, uint32_t srcLane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), static_cast<int>(srcLane))); }
 // slack of a node after a pass in which it strayed `exc` from its build-time position
 PIES_DEV float next_slack(float exc, float previous, float r) {
   const float want = fmaxf(2.0f * exc + 0.1f * r, 0.4f * r);
@@ -194,7 +198,6 @@ __global__ void __launch_bounds__(kBlock) k_pair_save(HashArrays H, PairArrays P
     const float r = radius[i];
     float sl = P.node[4u * i + 2u].w;
     if (!(sl > 0.0f)) sl = 0.5f * r;  // first pass after pies_finalize
-    if (P.byIndex) sl = fminf(sl, kTurnMaxSlack);
     const float4 p0 = make_float4(p.x, p.y, p.z, sl);
     P.node[4u * i + 2u] = p0;
     P.bq[i] = make_float4(p.x, p.y, p.z, r + sl);
@@ -249,7 +252,7 @@ __global__ void __launch_bounds__(kBlock) k_pair_groups(HashArrays H, PairArrays
       // a group exists where some node has its minimum cell (kMinFlag).  (k_grid_groups leaves that count in gcnt for the
       // group order; builds for the pair order skip that launch and look here.)
       const uint32_t bs = H.start[s], be = H.end[s];
-      if (be - bs > kMaxBucket) atomicOr(&H.counters[kCounterFlags], 4u);  // runaway pile-up: latch, like Solver.cpp:741-755
+      if (be - bs > 0xffffu) atomicOr(&P.ctl[kPairFlags], 2u);  // (a descriptor holds 16-bit bucket lengths; such a pile is the sequential loop's)
       for (uint32_t e = bs; e < be && !have; ++e) have = (val[e] >> 31) != 0u;
       if (have) rank = atomicAdd(&lcount, 1u);
     }
@@ -883,15 +886,58 @@ __global__ void __launch_bounds__(1024) k_pair_tail(HashArrays H, PairArrays P, 
 // ---- after the pass: can an unlisted pair have touched? -----------------------------------------------------------------
 // One wavefront per node that left its slack: the nodes it shares a cell with but did not list (d0 >= cut) are tested with the
 // largest excursions of the pass.
-__global__ void __launch_bounds__(kBlock) k_pair_verify(HashArrays H, PairArrays P, uint32_t repeat) {
+__global__ void __launch_bounds__(kBlock) k_pair_verify(HashArrays H, PairArrays P, uint32_t repeat, float scale) {
   if (repeat && !P.ctl[kPairRetry]) return;
   if (H.counters[kCounterFlags]) return;
-  const uint32_t count = min(P.ctl[kPairLeft], P.n);
-  if (count == 0u) return;
   const int lane = threadIdx.x & 63;
   const GridBox B = grid_box(H.counters);
   const uint32_t* __restrict__ val = H.val[grid_passes(B) & 1u];
   const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
+  if (P.byIndex) {
+    // By turns: the nodes that strayed far (see kTurnMaxExcursion) may have walked buckets of cells their inserted range does not
+    // hold and met nodes no list knows.  One wavefront per such node looks at every node inserted into a cell its live range can
+    // have reached - the range of a sphere of radius r + excursion around its build-time position - that shares NO inserted cell
+    // with it, and tests with the largest excursions of the pass whether the two can have touched.  If so the pass is the
+    // sequential loop's (a repeat would list the same pairs).
+    bool lost = false;
+    for (uint32_t base = wave * 64u; base < P.n; base += nwaves * 64u) {  // (wavefront uniform)
+      const uint32_t mine = base + static_cast<uint32_t>(lane);
+      const float em = mine < P.n ? __uint_as_float(P.exc[mine]) : 0.0f;
+      unsigned long long far = __ballot(!(em < kTurnMaxExcursion));
+      while (far) {
+        const uint32_t q = static_cast<uint32_t>(__builtin_ctzll(far));
+        far &= far - 1ull;
+        const uint32_t i = base + q;
+        const float4 pi = P.node[4u * i + 2u];
+        const float ri = P.node[4u * i + 1u].w, ei = lane_value(em, q);
+        const int4 rgi = H.rng[i];
+        int mx, my, mz;
+        uint32_t lx, ly, lz;
+        if (!node_range(pi.x, pi.y, pi.z, ri + ei, scale, mx, my, mz, lx, ly, lz) || lx * ly * lz == 0u) { lost = true; continue; }
+        for (uint32_t c = 0; c < lx * ly * lz; ++c) {
+          const uint32_t cs = find_bucket(H, B, mx + static_cast<int>(c / (lz * ly)), my + static_cast<int>((c / lz) % ly), mz + static_cast<int>(c % lz));
+          if (cs == 0xffffffffu) continue;
+          const uint32_t bs = H.start[cs], bc = H.end[cs] - bs;
+          for (uint32_t b0 = 0; b0 < bc; b0 += 64u) {
+            if (b0 + lane >= bc) continue;
+            const uint32_t j = val[bs + b0 + lane] & kNodeMask;
+            if (j == i) continue;
+            const int4 rgj = H.rng[j];
+            if (shared_cells(rgi.x, rgi.w & 0xff, rgj.x, rgj.w & 0xff) * shared_cells(rgi.y, (rgi.w >> 8) & 0xff, rgj.y, (rgj.w >> 8) & 0xff) *
+                    shared_cells(rgi.z, (rgi.w >> 16) & 0xff, rgj.z, (rgj.w >> 16) & 0xff) != 0u)
+              continue;  // (they share an inserted cell: the lists and the test below cover the pair)
+            const float4 pj = P.node[4u * j + 2u];
+            const float ddx = pj.x - pi.x, ddy = pj.y - pi.y, ddz = pj.z - pi.z;
+            const float reach = 1.001f * (ri + P.node[4u * j + 1u].w + ei + __uint_as_float(P.exc[j]));
+            if (!(ddx * ddx + ddy * ddy + ddz * ddz >= reach * reach)) lost = true;
+          }
+        }
+      }
+    }
+    if (__ballot(lost) && lane == 0) atomicOr(&P.ctl[kPairFlags], 2u);
+  }
+  const uint32_t count = min(P.ctl[kPairLeft], P.n);
+  if (count == 0u) return;
   bool bad = false;
   for (uint32_t u = wave; u < count; u += nwaves) {
     const uint32_t i = P.left[u];
@@ -929,7 +975,8 @@ __global__ void __launch_bounds__(kBlock) k_pair_verify(HashArrays H, PairArrays
 __global__ void __launch_bounds__(kBlock) k_pair_check(HashArrays H, PairArrays P, float4* pos, float4* vel, uint32_t first) {
   const uint32_t flags = P.ctl[kPairFlags];
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  const bool repeat = first && (flags & 1u);
+  const bool overflow = (flags & 2u) != 0u;  // the lists are incomplete: the pass is the sequential loop's, nothing of it is kept
+  const bool repeat = first && (flags & 1u) && !overflow;
   if (!first && !P.ctl[kPairRetry]) return;  // nothing was repeated: the first check has done everything
   if (i < P.n && !H.counters[kCounterFlags]) {
     const float4 p0 = P.node[4u * i + 2u];
@@ -942,7 +989,7 @@ __global__ void __launch_bounds__(kBlock) k_pair_check(HashArrays H, PairArrays 
       store_rec(P.node, i, make_uint4(0u, 0u, 0u, 0u));
       P.exc[i] = 0u;
       if (!(e <= 0.999f * sl)) {  // (the repeat follows the first attempt's course until a newly listed pair touches)
-        const float room = P.byIndex ? fminf(2.0f * e + 0.2f * r, kTurnMaxSlack) : 2.0f * e + 0.2f * r;
+        const float room = 2.0f * e + 0.2f * r;
         P.node[4u * i + 2u].w = room;
         P.bq[i].w = r + room;
       }
@@ -950,16 +997,16 @@ __global__ void __launch_bounds__(kBlock) k_pair_check(HashArrays H, PairArrays 
       const float4 p = P.node[4u * i], v = P.node[4u * i + 1u];
       // (by turns, a pass that could not be proved exact in its repeat either is left to the sequential loop: pos / vel keep the
       // state the pass started from)
-      if (!(P.byIndex && !first && (flags & 1u))) {
+      if (!(P.byIndex && !first && (flags & 1u)) && !overflow) {
         pos[i] = p;
         vel[i] = make_float4(v.x, v.y, v.z, 0.0f);  // (the fourth component of a velocity record is 0 everywhere)
       }
-      P.node[4u * i + 2u].w = P.byIndex ? fminf(next_slack(e, sl, v.w), kTurnMaxSlack) : next_slack(e, sl, v.w);
+      P.node[4u * i + 2u].w = next_slack(e, sl, v.w);
     }
   }
   // the pass's resolved pairs go to the statistics when its result stands (a pass that is repeated counts once; one that is left to
   // the sequential loop is counted by that loop)
-  if (blockIdx.x == 0 && !repeat && !(P.byIndex && !first && (flags & 1u))) {
+  if (blockIdx.x == 0 && !repeat && !(P.byIndex && !first && (flags & 1u)) && !overflow) {
     uint32_t sum = 0;
     for (uint32_t k = threadIdx.x; k < kPairStripes; k += kBlock) { sum += P.hitStripe[k * kPairPad]; P.hitStripe[k * kPairPad] = 0; }
 #pragma unroll
@@ -981,8 +1028,7 @@ __global__ void __launch_bounds__(kBlock) k_pair_check(HashArrays H, PairArrays 
   }
   if (i != 0 || first) return;
   if (flags & 1u) P.ctl[kPairInexact] += 1;
-  if (P.byIndex && (flags & 1u)) { P.ctl[kPairFallback] = 1u; P.ctl[kPairFallbacks] += 1u; }
-  if (flags & 2u) atomicOr(&H.counters[kCounterFlags], 256u);  // list storage overflow: the host latches the failure
+  if ((P.byIndex && (flags & 1u)) || (flags & 2u)) { P.ctl[kPairFallback] = 1u; P.ctl[kPairFallbacks] += 1u; }  // (list storage overflow in the repeat)
   P.ctl[kPairLeft] = 0;
 }
 // (one thread, after every block of the first k_pair_check has read the flags)
@@ -994,10 +1040,12 @@ __global__ void k_pair_arm(HashArrays H, PairArrays P) {
   if (threadIdx.x != 0) return;
   const uint32_t flags = P.ctl[kPairFlags];
   P.ctl[kPairLeft] = 0;
-  if (!(flags & 1u)) {
-    if (flags & 2u) atomicOr(&H.counters[kCounterFlags], 256u);
+  if (flags & 2u) {  // a pile the lists do not hold (more than 1 024 partners of a node, more entries than reserved): no repeat - the
+    P.ctl[kPairFallback] = 1u;  // sequential loop runs the pass from the state it started with (the reference has no such limit)
+    P.ctl[kPairFallbacks] += 1u;
     return;
   }
+  if (!(flags & 1u)) return;
   P.ctl[kPairRetry] = 1;
   P.ctl[kPairRetries] += 1;
   P.ctl[kPairFlags] = 0;
@@ -1036,7 +1084,6 @@ PIES_DEV bool cell_in_range(const int4 rg, int cx, int cy, int cz) {
   const int lx = rg.w & 0xff, ly = (rg.w >> 8) & 0xff, lz = (rg.w >> 16) & 0xff;
   return cx >= rg.x && cx < rg.x + lx && cy >= rg.y && cy < rg.y + ly && cz >= rg.z && cz < rg.z + lz;
 }
-PIES_DEV float lane_value(float v, uint32_t srcLane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), static_cast<int>(srcLane))); }
 
 // One bucket of a turn: the lanes with inCell hold the bucket's partners of node a (ascending index over the lanes), selfAt = the
 // lane before which the node meets itself (64: behind the last lane; kTurnDone: not in this bucket / not in this batch).
@@ -1114,11 +1161,17 @@ PIES_DEV uint32_t run_turn(const HashArrays& H, const PairArrays& P, uint32_t i,
   if (ncell != 0u && (rgi.w & 0xffffff) == 0 && lane == 0) atomicOr(&P.ctl[kPairFlags], 1u);
   uint32_t hits = 0;
   bool aMoved = false;
-  if (d <= 64u) {  // the partners in the lanes' registers for the whole turn
+  if (d < 64u) {  // the partners in the lanes' registers for the whole turn (lane d: the node itself, for the bookkeeping behind the turn)
     const bool have = static_cast<uint32_t>(lane) < d;
     const uint32_t j = have ? P.nbr[off + lane] & kPairNodeMask : 0u;
     NodeState b = have ? load_node(node, j) : NodeState{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int4 rgj = have ? H.rng[j] : make_int4(0, 0, 0, 0);
+    // what the members need when the turn is over - their records (the same cache line as their state) and the nodes whose turns
+    // their NEXT events are - is requested now, beside the states: behind the turn these would be two more dependent round trips
+    const bool member = static_cast<uint32_t>(lane) <= d;
+    const uint32_t mj = have ? j : i;
+    const uint4 mr = member ? (have ? load_rec(node, j) : ri) : make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t mnext = member ? turn_event_node(P, mj, mr.x, mr.y & 0xffffu, mr.y >> 16, mr.z + 1u) : kTurnDone;
     bool bMoved = false;
     for (uint32_t c = 0; c < ncell; ++c) {  // dz fastest (SpatialHash.h:108-125)
       const int cx = mx + static_cast<int>(c / (lz * ly)), cy = my + static_cast<int>((c / lz) % ly), cz = mz + static_cast<int>(c % lz);
@@ -1133,7 +1186,23 @@ PIES_DEV uint32_t run_turn(const HashArrays& H, const PairArrays& P, uint32_t i,
       store_node(node, i, a);
       note_excursion(P, i, a, node[4u * i + 2u]);
     }
-    turn_advance(P, have, j, next, nextCount, sub, lane);
+    // every member moves on to its next event; a node whose turn has all its members waiting for it goes to the next frontier
+    uint32_t ready = kTurnDone;
+    if (member) {
+      store_rec(node, mj, make_uint4(mr.x, mr.y, mr.z + 1u, mnext));
+      if (mnext != kTurnDone && atomicSub(&P.turnCnt[mnext], 1u) == 1u) ready = mnext;
+    }
+    const unsigned long long rm = __ballot(ready != kTurnDone);
+    if (rm) {
+      uint32_t at = 0;
+      if (lane == 0) at = atomicAdd(&nextCount[sub * kPairPad], static_cast<uint32_t>(__popcll(rm)));
+      at = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(at))) + static_cast<uint32_t>(__popcll(rm & ((1ull << lane) - 1ull)));
+      if (ready != kTurnDone) {
+        if (at < P.frCap) next[static_cast<size_t>(sub) * P.frCap + at] = ready;
+        else atomicOr(&P.ctl[kPairFlags], 2u);
+      }
+    }
+    return hits;
   } else {  // a dense neighbourhood: 64 partners at a time, their states through memory (a partner sits in one batch)
     for (uint32_t c = 0; c < ncell; ++c) {
       const int cx = mx + static_cast<int>(c / (lz * ly)), cy = my + static_cast<int>((c / lz) % ly), cz = mz + static_cast<int>(c % lz);
@@ -1274,7 +1343,7 @@ uint32_t launch_collide_turns(hipStream_t st, const HashArrays& H, const PairArr
       hipLaunchKernelGGL(k_turn_round, level, dim3(kTurnBlock), 0, st, H, P, gridSpacing, friction, staticThreshold, r, repeat); ++launches;
     }
     hipLaunchKernelGGL(k_turn_tail, dim3(1), dim3(1024), 0, st, H, P, gridSpacing, friction, staticThreshold, 2u + captured, repeat); ++launches;
-    hipLaunchKernelGGL(k_pair_verify, dim3(64), dim3(kBlock), 0, st, H, P, repeat); ++launches;
+    hipLaunchKernelGGL(k_pair_verify, dim3(64), dim3(kBlock), 0, st, H, P, repeat, gridSpacing); ++launches;
     hipLaunchKernelGGL(k_pair_check, perNode, dim3(kBlock), 0, st, H, P, nd.pos, nd.vel, repeat ? 0u : 1u); ++launches;
     if (!repeat) { hipLaunchKernelGGL(k_pair_arm, dim3(1), dim3(64), 0, st, H, P); ++launches; }
   }
@@ -1283,7 +1352,7 @@ uint32_t launch_collide_turns(hipStream_t st, const HashArrays& H, const PairArr
   return launches;
 }
 
-uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArrays& P, const NodeArrays& nd, float friction,
+uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArrays& P, const NodeArrays& nd, float gridSpacing, float friction,
                               float staticThreshold, uint32_t rounds) {
   if (nd.n == 0) return 0;
   const uint32_t n = nd.n;
@@ -1320,10 +1389,12 @@ uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArr
       hipLaunchKernelGGL(k_pair_round, repeat ? levelRepeat : level, dim3(kRoundBlock), 0, st, H, P, friction, staticThreshold, r, repeat); ++launches;
     }
     hipLaunchKernelGGL(k_pair_tail, dim3(1), dim3(1024), 0, st, H, P, friction, staticThreshold, captured + 1u, repeat); ++launches;
-    hipLaunchKernelGGL(k_pair_verify, dim3(64), dim3(kBlock), 0, st, H, P, repeat); ++launches;
+    hipLaunchKernelGGL(k_pair_verify, dim3(64), dim3(kBlock), 0, st, H, P, repeat, gridSpacing); ++launches;
     hipLaunchKernelGGL(k_pair_check, perNode, dim3(kBlock), 0, st, H, P, nd.pos, nd.vel, repeat ? 0u : 1u); ++launches;
     if (!repeat) { hipLaunchKernelGGL(k_pair_arm, dim3(1), dim3(64), 0, st, H, P); ++launches; }
   }
+  // a pile the lists do not hold: the pass in the reference's own order, from the state it started with (returns at once otherwise)
+  launches += launch_collide_reference(st, H, nd, gridSpacing, friction, staticThreshold, P.ctl + kPairFallback);
   return launches;
 }
 

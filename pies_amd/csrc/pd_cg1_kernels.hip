@@ -30,14 +30,6 @@
 #include "pd_cg_device.h"
 #include "pd_rhs_device.h"
 
-#ifndef PIES_ITER_VARIANT
-#define PIES_ITER_VARIANT 0
-#endif
-#if PIES_ITER_VARIANT == 1 || PIES_ITER_VARIANT == 2
-#define PIES_ITER_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
-#else
-#define PIES_ITER_ATTR
-#endif
 
 namespace pies {
 
@@ -224,7 +216,11 @@ template <bool WIN> __global__ void __launch_bounds__(kBlock) k_cg1_first(CgArra
   }
   if (all_converged(rr, bb, tol2)) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-      A.scal[11] = 0.0f;  // the final residual partials are partI
+      // the final residual norms themselves, for the statistics: partI is overwritten by the next solve's k_cg1_init while the
+      // extra workgroup of that very launch closes this solve's statistics (a mix of two solves could read as "short")
+#pragma unroll
+      for (int c = 0; c < 3; ++c) A.scal[18 + c] = rr[c];
+      A.scal[11] = 0.0f;  // converged at the first look
       A.scal[10] = 1.0f;
     }
     return;
@@ -326,7 +322,7 @@ PIES_DEV void cg1_rows(const CgArrays& A, float4* __restrict__ x, int it, const 
           return make_float4(ux, uy, uz, 0.f);
         },
         [&](uint32_t i, float sx, float sy, float sz, const float4 t, const float4) {
-          contact_row<PIES_ITER_VARIANT == 3 ? 4 : 1>(A, i, fetch, sx, sy, sz);
+          contact_row<1>(A, i, fetch, sx, sy, sz);
           const float cd = A.cdiag[i], di = A.dinv[i];
           const float wx = fmaf(cd, t.x, sx), wy = fmaf(cd, t.y, sy), wz = fmaf(cd, t.z, sz);
           aN[i] = Vec3f{di * wx, di * wy, di * wz};
@@ -347,7 +343,7 @@ PIES_DEV void cg1_rows(const CgArrays& A, float4* __restrict__ x, int it, const 
       sz = fmaf(a, uz, sz);
     });
     if (i < A.n) {
-      contact_row<PIES_ITER_VARIANT == 3 ? 4 : 1>(A, i, fetch, sx, sy, sz);
+      contact_row<1>(A, i, fetch, sx, sy, sz);
       float tx, ty, tz, cx, cy, cz;
       renew(i, tx, ty, tz, cx, cy, cz);
       const Vec3f told = tO[i];
@@ -396,11 +392,12 @@ PIES_DEV void cg1_scalars(const float gam[3], const float del[3], const float ga
 // overflow > 0: the solve's last captured launch; when the residual is still above the tolerance after its rows, its
 // workgroups (all resident, see cg_update_resident_blocks) run up to `overflow` more iterations themselves, one grid barrier
 // per iteration where the captured path has a kernel boundary.
-// (Measured and dropped: __launch_bounds__(kBlock, 5) - the rows fit 85-92 registers without spills, five wavefronts per SIMD
-// instead of four: 41.1 against 39.5 us per launch with the row dictionary at 1M rows, 54.9 against 46.5 windowed: what the
-// scheduler spends the registers on is loads in flight.)
+// (Measured and dropped: register targets for this kernel.  __launch_bounds__(kBlock, 5) - five wavefronts per SIMD, the rows fit 85-92
+// registers without spills: 41.1 against 39.5 us per launch with the row dictionary at 1M rows; amdgpu_waves_per_eu(4, 4): 43.9
+// against 39.6 with the dictionary, 69.3 against 57.1 windowed behind a SELL first product.  What the windowed iteration's time
+// depends on at 1M rows is whether the launch before it streamed the same matrix arrays - see launch_pd_solve1.)
 template <bool FIRST, bool WIN>
-__global__ void PIES_ITER_ATTR __launch_bounds__(kBlock) k_cg1_iter(CgArrays A, float4* __restrict__ x, int it, float tol2, int overflow) {
+__global__ void __launch_bounds__(kBlock) k_cg1_iter(CgArrays A, float4* __restrict__ x, int it, float tol2, int overflow) {
   if (A.scal[10] != 0.0f) return;  // the solve converged in an earlier launch
   float red[9];
   float alpha[3], beta[3] = {0.f, 0.f, 0.f}, gam[3], bb[3];
@@ -441,10 +438,8 @@ __global__ void PIES_ITER_ATTR __launch_bounds__(kBlock) k_cg1_iter(CgArrays A, 
     A.scal[9] = static_cast<float>(it);
   }
   float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#if PIES_ITER_VARIANT < 2
   uniform3(alpha);  // (the same in every lane: scalar registers for the rows' sweep)
   uniform3(beta);
-#endif
   cg1_rows<FIRST, WIN>(A, x, it, alpha, beta, acc);
   block_write_partial<9>(acc, A.part1[it & 1], 9);
   if (blockIdx.x == 0 && threadIdx.x == 0) A.partCount[it & 1] = gridDim.x;
@@ -466,10 +461,8 @@ __global__ void PIES_ITER_ATTR __launch_bounds__(kBlock) k_cg1_iter(CgArrays A, 
     ++kk;
 #pragma unroll
     for (int c = 0; c < 9; ++c) acc[c] = 0.0f;
-#if PIES_ITER_VARIANT < 2
     uniform3(alpha);
     uniform3(beta);
-#endif
     cg1_rows<false, WIN>(A, x, kk, alpha, beta, acc);
     block_write_partial<9>(acc, A.part1[kk & 1], 9);
     if (blockIdx.x == 0 && threadIdx.x == 0) A.partCount[kk & 1] = gridDim.x;

@@ -148,7 +148,11 @@ PIES_DEV void solve_statistics(const CgArrays& A, const float* __restrict__ prev
   // (scal[10] = 1, scal[11] = 0: partI, 1 / 2: the ping-pong pair); otherwise the last k_cg_update wrote prevPartB
   const bool done = A.scal[10] != 0.0f;
   const int where = static_cast<int>(A.scal[11]);
-  if (done && where == 0) block_reduce_partials<6>(A.partI, 9, A.single ? A.npartsI : A.nparts, red);
+  if (done && where == 0 && A.single) {  // (k_cg1_first left the norms in scal[18..20]: partI belongs to the next solve by now)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) red[3 + c] = A.scal[18 + c];
+  }
+  else if (done && where == 0) block_reduce_partials<6>(A.partI, 9, A.nparts, red);
   else if (A.single) {  // one launch per iteration: {r.t, w.t, r.r} per workgroup, the residual norms in the last three
     const float* last = done ? A.part1[where - 1] : prevPartB;
     block_reduce_partials<3>(last + 6, 9, A.partCount[last == A.part1[1] ? 1 : 0], red + 3);

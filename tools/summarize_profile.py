@@ -92,6 +92,19 @@ def main(rnd, srcname=None):
         lines.append("== config4 VALU counters per launch, averaged over the launches of a kernel (same counters)")
         for k, cs in sorted(out.items()):
             lines.append("%-28s %s" % (k, "  ".join("%s=%.0f" % kv for kv in sorted(cs.items()))))
+    # VALU counters of the PD workloads (k_pd_local_tiles): <round>_pmc_valu_pd.json = {workload: {kernel: {counter: average per launch}}}
+    pd = {}
+    for w in ("config3", "pd1m", "pd1m_work", "pd_unstructured"):
+        cs = counters_of(newest(os.path.join(src, "valu_%s" % w, "*", "*counter_collection.csv")))
+        if cs:
+            pd[w] = {k: {c: sum(v) / len(v) for c, v in kc.items()} for k, kc in cs.items()}
+            lines.append("")
+            lines.append("== %s VALU counters per launch (rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY)" % w)
+            for k, kc in sorted(pd[w].items()):
+                lines.append("%-28s %s" % (k, "  ".join("%s=%.0f" % kv for kv in sorted(kc.items()))))
+    if pd:
+        with open(os.path.join(dst, "%s_pmc_valu_pd.json" % rnd), "w") as f:
+            json.dump(pd, f, indent=1)
     text = "\n".join(lines) + "\n"
     with open(os.path.join(dst, "%s_summary.txt" % rnd), "w") as f:
         f.write(text)
