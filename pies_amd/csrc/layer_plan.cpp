@@ -547,7 +547,14 @@ bool build_layer_plan(pies_solver* s) {
         nl = std::max(nl, levelSlab[v] + 1);
       }
       // (two nodes of a constraint are at most `longest` < d apart: their slabs differ by at most one)
-      run("slabs along the longest axis, single-level constraints dealt to either group", levelSlab, nl, true);
+      // the candidates are compared by colour steps alone, so slabs must not buy theirs with launches of empty or
+      // countless tiles - several bodies apart along the axis leave slabs without a node, a thin long body makes thousands: the
+      // candidate only runs when every slab holds a node and there are at most twice as many as breadth-first levels.
+      std::vector<uint8_t> seen(nl, 0);
+      for (uint32_t v = 0; v < N; ++v) seen[levelSlab[v]] = 1;
+      const bool noneEmpty = std::find(seen.begin(), seen.end(), uint8_t(0)) == seen.end();
+      if ((noneEmpty && nl <= 2u * L1bfs + 2u) || tuning_env("PIES_LAYER_PLAN_FORCE"))
+        run("slabs along the longest axis, single-level constraints dealt to either group", levelSlab, nl, true);
     }
   }
   size_t best = 0;  // (the original plan unless another one saves a twentieth of its colour steps: a lattice keeps its order)

@@ -400,9 +400,11 @@ constexpr uint32_t kPairStage = 1024;  // pairs a workgroup (16 triangles) colle
 // the line; a workgroup appends to the list of its index modulo kWorkShards.
 PIES_DEV uint32_t shard_capacity(const TriArrays& T) { return T.maxWork / kWorkShards; }
 PIES_DEV void work_append(const TriArrays& T, uint32_t shard, uint2 item) {
-  const uint32_t at = atomicAdd(&T.workCnt[16u * shard], 1u);
-  if (at < shard_capacity(T)) T.work[shard * shard_capacity(T) + at] = item;
-  else atomicOr(&T.counters[3], 64u);
+  for (uint32_t tries = 0; tries < kWorkShards; ++tries, shard = (shard + 1u) % kWorkShards) {  // (a full list passes the item on)
+    const uint32_t at = atomicAdd(&T.workCnt[16u * shard], 1u);
+    if (at < shard_capacity(T)) { T.work[shard * shard_capacity(T) + at] = item; return; }
+  }
+  atomicOr(&T.counters[3], 64u);
 }
 template <int TEAM>
 __global__ void __launch_bounds__(kBlock) k_tri_pairs(TriArrays T, const float4* __restrict__ pos, const float4* __restrict__ prev, float threshold) {
@@ -535,13 +537,22 @@ __global__ void __launch_bounds__(kBlock) k_tri_pairs(TriArrays T, const float4*
   }
   __syncthreads();
   const uint32_t staged = min(sCount, kPairStage);
-  const uint32_t shard = blockIdx.x % kWorkShards;
-  if (threadIdx.x == 0 && staged) sBase = atomicAdd(&T.workCnt[16u * shard], staged);
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < staged; i += kBlock) {
-    if (sBase + i < shard_capacity(T)) T.work[shard * shard_capacity(T) + sBase + i] = sWork[i];
-    else atomicOr(&T.counters[3], 64u);  // (a mesh folded onto itself: as fatal as the contact list it would overflow)
+  // The workgroup's list, and - when that one is full (a mesh folded locally fills ONE list while the others are nearly empty:
+  // ADVICE r4) - the lists behind it, each taking what it has room for; only when every list is full is the work list as a whole
+  // (128 pairs per triangle) exhausted, which is as fatal as the contact list it would overflow.  (A list's counter may run past its
+  // capacity: k_tri_ccd reads min(counter, capacity) entries, and exactly those were written.)
+  const uint32_t cap = shard_capacity(T);
+  uint32_t done = 0;
+  for (uint32_t tries = 0; tries < kWorkShards && done < staged; ++tries) {  // (workgroup uniform)
+    const uint32_t shard = (blockIdx.x + tries) % kWorkShards;
+    __syncthreads();
+    if (threadIdx.x == 0) sBase = atomicAdd(&T.workCnt[16u * shard], staged - done);
+    __syncthreads();
+    const uint32_t base = min(sBase, cap), fit = min(staged - done, cap - base);
+    for (uint32_t i = threadIdx.x; i < fit; i += kBlock) T.work[shard * cap + base + i] = sWork[done + i];
+    done += fit;
   }
+  if (done < staged && threadIdx.x == 0) atomicOr(&T.counters[3], 64u);
 }
 
 __global__ void __launch_bounds__(kBlock) k_tri_ccd(TriArrays T, const float4* __restrict__ pos, const float4* __restrict__ prev, float threshold) {
