@@ -1085,6 +1085,52 @@ PIES_DEV bool cell_in_range(const int4 rg, int cx, int cy, int cz) {
   return cx >= rg.x && cx < rg.x + lx && cy >= rg.y && cy < rg.y + ly && cz >= rg.z && cz < rg.z + lz;
 }
 
+// One resolved visit of a turn (Solver.cpp:92-125) with its fifteen divisions dealt to the lanes: `a` (wave uniform) visits the node
+// held by lane `src` (self: itself).  visit() runs all of it in one lane - ~350 instructions, a turn of config 4 resolves ~20 visits
+// one after the other: 15 us of a 45-us level.  Here lane t computes ONE quotient (the three components of the direction on lanes
+// 0-2, then the twelve corrections ((coef * vec_k) * mass) / wSum on lanes 0-11) and the quotients are broadcast: the same operations
+// on the same operands in the same order as visit() / visit_self(), so the same bits (k_collide_reference's resolve_pair does the
+// same).  The overlap is known (the caller's test): the visit resolves.
+PIES_DEV float pick3(int k, float x, float y, float z) { return k == 0 ? x : (k == 1 ? y : z); }
+PIES_DEV void visit_wide(NodeState& a, NodeState& b, uint32_t src, bool self, float friction, float staticThreshold, int lane) {
+  NodeState o = a;
+  if (!self) o = NodeState{lane_value(b.px, src), lane_value(b.py, src), lane_value(b.pz, src), lane_value(b.w, src),
+                           lane_value(b.vx, src), lane_value(b.vy, src), lane_value(b.vz, src), lane_value(b.r, src)};
+  const float dx = o.px - a.px, dy = o.py - a.py, dz = o.pz - a.pz;
+  const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float disp = a.r + o.r - dist;
+  const int k3 = lane % 3, kind = (lane / 3) & 3;
+  float ux = 1.0f, uy = 0.0f, uz = 0.0f;
+  if (dist > 0.00001f) {
+    const float quot = pick3(k3, dx, dy, dz) / dist;
+    ux = lane_value(quot, 0); uy = lane_value(quot, 1); uz = lane_value(quot, 2);
+  }
+  const float wSum = a.w + o.w;
+  const float sa = 0.85f * -disp, sb = 0.85f * disp;
+  const float rx = o.vx - a.vx, ry = o.vy - a.vy, rz = o.vz - a.vz;
+  const float rd = rx * ux + ry * uy + rz * uz;
+  const float qx = rx - rd * ux, qy = ry - rd * uy, qz = rz - rd * uz;
+  float fr = friction;
+  if (staticThreshold > 0.0f)  // sqrt(x) < t is false for every t <= 0
+    if (sqrtf(qx * qx + qy * qy + qz * qz) < staticThreshold) fr = 1.0f;
+  const float vec = kind < 2 ? pick3(k3, ux, uy, uz) : pick3(k3, qx, qy, qz);
+  const float coef = kind == 0 ? sa : (kind == 1 ? sb : (kind == 2 ? -fr : fr));
+  const float mass = (kind & 1) ? o.w : a.w;
+  const float corr = ((coef * vec) * mass) / wSum;
+  if (self) {  // (visit_self: the second update of each line sees the first)
+    a.px += lane_value(corr, 0); a.py += lane_value(corr, 1); a.pz += lane_value(corr, 2);
+    a.px += lane_value(corr, 3); a.py += lane_value(corr, 4); a.pz += lane_value(corr, 5);
+    a.vx += lane_value(corr, 6); a.vy += lane_value(corr, 7); a.vz += lane_value(corr, 8);
+    a.vx += lane_value(corr, 9); a.vy += lane_value(corr, 10); a.vz += lane_value(corr, 11);
+    return;
+  }
+  a.px += lane_value(corr, 0); a.py += lane_value(corr, 1); a.pz += lane_value(corr, 2);
+  o.px += lane_value(corr, 3); o.py += lane_value(corr, 4); o.pz += lane_value(corr, 5);
+  a.vx += lane_value(corr, 6); a.vy += lane_value(corr, 7); a.vz += lane_value(corr, 8);
+  o.vx += lane_value(corr, 9); o.vy += lane_value(corr, 10); o.vz += lane_value(corr, 11);
+  if (lane == static_cast<int>(src)) b = o;
+}
+
 // One bucket of a turn: the lanes with inCell hold the bucket's partners of node a (ascending index over the lanes), selfAt = the
 // lane before which the node meets itself (64: behind the last lane; kTurnDone: not in this bucket / not in this batch).
 PIES_DEV void turn_cell(NodeState& a, NodeState& b, bool inCell, uint32_t selfAt, int lane, float friction, float staticThreshold, uint32_t& hits,
@@ -1100,19 +1146,18 @@ PIES_DEV void turn_cell(NodeState& a, NodeState& b, bool inCell, uint32_t selfAt
     const unsigned long long hm = __ballot(hit);
     const uint32_t first = hm ? static_cast<uint32_t>(__builtin_ctzll(hm)) : 64u;
     if (selfAt != kTurnDone && selfAt <= first) {  // everything below the node's own place has missed: it meets itself
-      if (visit_self(a, friction, staticThreshold)) { ++hits; aMoved = true; }
+      if (a.r + a.r > 0.0f) {  // (visit_self's test: the distance to itself is 0)
+        visit_wide(a, b, 0u, true, friction, staticThreshold, lane);
+        ++hits;
+        aMoved = true;
+      }
       pending = selfAt >= 64u ? 0ull : pending & ~((1ull << selfAt) - 1ull);
       selfAt = kTurnDone;
       continue;  // (its state may have changed: the lanes above test again)
     }
     if (first >= 64u) break;
-    NodeState an = a;
-    if (lane == static_cast<int>(first)) {
-      visit(an, b, friction, staticThreshold);
-      bMoved = true;
-    }
-    a.px = lane_value(an.px, first); a.py = lane_value(an.py, first); a.pz = lane_value(an.pz, first);
-    a.vx = lane_value(an.vx, first); a.vy = lane_value(an.vy, first); a.vz = lane_value(an.vz, first);
+    visit_wide(a, b, first, false, friction, staticThreshold, lane);
+    if (lane == static_cast<int>(first)) bMoved = true;
     ++hits;
     aMoved = true;
     pending = first >= 63u ? 0ull : pending & ~((2ull << first) - 1ull);
