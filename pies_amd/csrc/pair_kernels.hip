@@ -862,6 +862,163 @@ __global__ void __launch_bounds__(kRoundBlock) k_pair_round(HashArrays H, PairAr
   count_hits(P, hits, lane);
 }
 
+// ---- the same level with FOUR LANES PER PAIR (round 5) ---------------------------------------------------------------------
+// A lane that takes a pair runs up to sixteen visits of ~350 instructions - fifteen correctly rounded divisions each - while a level
+// waits for its slowest lane.  Here a pair is taken by a quad of lanes, lane k holding component k of the positions and velocities
+// (lane 3 idles along with a copy of component 0): the three sums of a visit (|d|^2, r.u, |q|^2) are quad permutes (v_mov_dpp) added
+// in visit()'s order, every lane divides for its own component only - five divisions instead of fifteen, ~120 instructions
+// instead of ~350 -, same operations on the same operands: the bits of visit().  A workgroup looks at 64 frontier nodes (its first
+// wavefront), the pairs taken go through LDS, and all four wavefronts run their visits.
+// Measured on BASELINE config 4: a settled frame 9.16 -> 8.76-8.9 ms (burst window 71.8 -> 73.0 substeps/s): a third of the
+// instructions in the slowest lane buys 4 % - a level (32 us) is its chain of dependent memory round trips (frontier, the two records,
+// the next list entries, the excursion and frontier atomics) and its kernel boundary, not the visits' issue slots.
+PIES_DEV float quad_lane(float v, int j) {  // the value of lane j (0-3) of the lane's quad
+  switch (j) {
+    case 0: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x00, 0xf, 0xf, false));
+    case 1: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x55, 0xf, 0xf, false));
+    case 2: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xaa, 0xf, 0xf, false));
+    default: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xff, 0xf, 0xf, false));
+  }
+}
+PIES_DEV float quad_sum3(float t) { return (quad_lane(t, 0) + quad_lane(t, 1)) + quad_lane(t, 2); }  // x + y + z in visit()'s order
+struct QuadNode {
+  float p, v;  // component k of position and velocity
+  float w, r;  // inverse mass, radius (every lane)
+};
+// node a visits node b (visit(), one component per lane; the result of the overlap test is the same in the quad's lanes)
+PIES_DEV bool visit_quad(QuadNode& a, QuadNode& b, int k, float friction, float staticThreshold) {
+  const float d = b.p - a.p;
+  const float dist = sqrtf(quad_sum3(d * d));
+  const float disp = a.r + b.r - dist;
+  if (!(disp > 0.0f)) return false;
+  float u = k == 0 ? 1.0f : 0.0f;
+  if (dist > 0.00001f) u = d / dist;
+  const float wSum = a.w + b.w;
+  const float sa = 0.85f * -disp, sb = 0.85f * disp;
+  const float r = b.v - a.v;
+  const float rd = quad_sum3(r * u);
+  const float q = r - rd * u;
+  float fr = friction;
+  if (staticThreshold > 0.0f)  // sqrt(x) < t is false for every t <= 0
+    if (sqrtf(quad_sum3(q * q)) < staticThreshold) fr = 1.0f;
+  a.p += ((sa * u) * a.w) / wSum;
+  b.p += ((sb * u) * b.w) / wSum;
+  a.v += ((-fr * q) * a.w) / wSum;
+  b.v += ((fr * q) * b.w) / wSum;
+  return true;
+}
+PIES_DEV float comp4(const float4 v, int k) { return k == 1 ? v.y : (k == 2 ? v.z : v.x); }  // (lane 3: a copy of component 0)
+
+constexpr uint32_t kQuadNodes = 64;  // frontier nodes a workgroup looks at per round of its loop (one wavefront); pairs taken: at most as many
+__global__ void __launch_bounds__(kRoundBlock) k_pair_round4(HashArrays H, PairArrays P, float friction, float staticThreshold, uint32_t round, uint32_t repeat) {
+  __shared__ TakenPair taken[kQuadNodes];
+  __shared__ uint32_t nTaken;
+  if (repeat && !P.ctl[kPairRetry]) return;
+  if (H.counters[kCounterFlags]) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const FrontierView view = frontier_view(P, round, lane);
+  if (blockIdx.x == 0 && wv == 0) {
+    P.frCount[(((round + 2u) % 3u) * kPairLists + static_cast<uint32_t>(lane)) * kPairPad] = 0;  // the lists of the round after the next
+    if (lane == 0 && view.total) { P.ctl[kPairRounds] = round; if (!repeat && round > P.ctl[kPairDeepest]) P.ctl[kPairDeepest] = round; }
+  }
+  const uint32_t count = view.total;
+  if (count == 0u) return;
+  float4* node = P.node;
+  uint32_t* next = P.fr[(round + 1u) & 1u];
+  uint32_t* nextCount = P.frCount + ((round + 1u) % 3u) * kPairLists * kPairPad;
+  const uint32_t stampNow = round & 0xffffu, stampPrev = (round - 1u) & 0xffffu;
+  auto move_on = [&](uint32_t i, const uint4 r) {
+    const uint32_t c = (r.z & 0xffffu) + 1u;
+    const uint32_t entry = (c < r.y ? P.nbr[r.x + c] : 0u) | ((c & 7u) << kPairTagShift);
+    store_rec(node, i, make_uint4(r.x, r.y, c | (stampNow << 16), entry));
+    return c < r.y;
+  };
+  const int k = lane & 3;
+  uint32_t hits = 0;
+  for (uint32_t chunk = blockIdx.x; chunk * kQuadNodes < count; chunk += gridDim.x) {  // (workgroup uniform)
+    // ---- who takes a pair: the first wavefront looks at the chunk's 64 frontier nodes
+    if (wv == 0) {
+      const uint32_t e = chunk * kQuadNodes + static_cast<uint32_t>(lane);
+      bool take = false;
+      uint32_t x = 0, y = 0;
+      uint4 rx = make_uint4(0u, 0u, 0u, 0u), ry = rx;
+      const uint32_t xe = frontier_node(P, view, round, min(e, count - 1u));  // (every lane takes part in the shuffles)
+      if (e < count) {
+        x = xe;
+        rx = load_rec(node, x);
+        // (x's own record must still be the one it reached in the last round: its partner's lane may have moved it on already)
+        if (rec_consistent(rx) && (rx.z & 0xffffu) < rx.y && (rx.z >> 16) == stampPrev) {
+          y = rx.w & kPairNodeMask;
+          ry = load_rec(node, y);
+          const uint32_t sy = ry.z >> 16;
+          take = rec_consistent(ry) && (ry.z & 0xffffu) < ry.y && sy != stampNow && (ry.w & kPairNodeMask) == x;
+          if (take && sy == stampPrev && y < x) take = false;  // y is in this frontier as well and takes the pair
+        }
+      }
+      const unsigned long long tm = __ballot(take);
+      if (take) taken[__popcll(tm & ((1ull << lane) - 1ull))] = TakenPair{x, y, rx, ry};
+      if (lane == 0) nTaken = static_cast<uint32_t>(__popcll(tm));
+    }
+    __syncthreads();
+    const uint32_t total = nTaken;
+    // ---- the visits: quad q of the workgroup takes pair q
+    const uint32_t q = threadIdx.x >> 2;
+    bool moveX = false, moveY = false;
+    uint32_t x = 0, y = 0;
+    if (q < total) {
+      const TakenPair t = taken[q];
+      x = t.x; y = t.y;
+      const bool xLow = x < y;
+      const uint32_t lo = xLow ? x : y, hi = xLow ? y : x;
+      const float4 ap = node[4u * lo], av = node[4u * lo + 1u], bp = node[4u * hi], bv = node[4u * hi + 1u];
+      QuadNode a{comp4(ap, k), comp4(av, k), ap.w, av.w}, b{comp4(bp, k), comp4(bv, k), bp.w, bv.w};
+      const float d = b.p - a.p;
+      const float dist = sqrtf(quad_sum3(d * d));
+      if (a.r + b.r - dist > 0.0f) {
+        const uint32_t m = P.nbrM ? P.nbrM[t.rx.x + (t.rx.z & 0xffffu)] : (t.rx.w >> 28) + 1u;  // (wide ranges keep the count beside the entry)
+        uint32_t h = 0;
+        for (uint32_t v = 0; v < m; ++v) h += visit_quad(a, b, k, friction, staticThreshold) ? 1u : 0u;
+        for (uint32_t v = 0; v < m; ++v) h += visit_quad(b, a, k, friction, staticThreshold) ? 1u : 0u;
+        // the quad's first lane puts the components together and stores the two nodes
+        const float apy = quad_lane(a.p, 1), apz = quad_lane(a.p, 2), avy = quad_lane(a.v, 1), avz = quad_lane(a.v, 2);
+        const float bpy = quad_lane(b.p, 1), bpz = quad_lane(b.p, 2), bvy = quad_lane(b.v, 1), bvz = quad_lane(b.v, 2);
+        if (k == 0) {
+          const NodeState na{a.p, apy, apz, a.w, a.v, avy, avz, a.r}, nb{b.p, bpy, bpz, b.w, b.v, bvy, bvz, b.r};
+          const float4 a0 = node[4u * lo + 2u], b0 = node[4u * hi + 2u];
+          store_node(node, lo, na);
+          store_node(node, hi, nb);
+          note_excursion(P, lo, na, a0);
+          note_excursion(P, hi, nb, b0);
+          hits += h;
+        }
+      }
+      if (k == 0) {
+        moveX = move_on(x, t.rx);
+        moveY = move_on(y, t.ry);
+      }
+    }
+    // the nodes that moved on and have entries left go to the sub-list this wavefront's part of the chunk is dealt to (one atomic
+    // per wavefront: 16 pairs, at most 32 nodes)
+    if (static_cast<uint32_t>(wv) * 16u < total) {  // (wavefront uniform)
+      const unsigned long long mx = __ballot(moveX), my = __ballot(moveY);
+      const uint32_t nx = static_cast<uint32_t>(__popcll(mx)), ny = static_cast<uint32_t>(__popcll(my));
+      if (nx + ny) {
+        const uint32_t sub = (chunk * (kRoundBlock / 64) + static_cast<uint32_t>(wv)) % kPairLists;
+        uint32_t at = 0;
+        if (lane == 0) at = atomicAdd(&nextCount[sub * kPairPad], nx + ny);
+        at = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(at)));
+        uint32_t* dst = next + static_cast<size_t>(sub) * P.frCap;
+        const uint32_t ix = at + static_cast<uint32_t>(__popcll(mx & ((1ull << lane) - 1ull)));
+        const uint32_t iy = at + nx + static_cast<uint32_t>(__popcll(my & ((1ull << lane) - 1ull)));
+        if (moveX && ix < P.frCap) dst[ix] = x;
+        if (moveY && iy < P.frCap) dst[iy] = y;
+      }
+    }
+    __syncthreads();  // (the table is reused by the next chunk)
+  }
+  count_hits(P, hits, lane);
+}
+
 // Whatever levels are left after the captured rounds (and all levels of a repeated pass): one workgroup, a workgroup barrier
 // where the rounds have a kernel boundary.  Global memory written before the barrier is visible to the workgroup after it.
 __global__ void __launch_bounds__(1024) k_pair_tail(HashArrays H, PairArrays P, float friction, float staticThreshold, uint32_t round, uint32_t repeat) {
@@ -1416,6 +1573,13 @@ uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArr
   uint32_t repeatCap = levelCap;
   if (const char* e = tuning_env("PIES_PAIR_REPEAT_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && v <= 65535) repeatCap = static_cast<uint32_t>(v); }
   const dim3 levelRepeat(std::max<uint32_t>(1u, std::min<uint32_t>(repeatCap, level.x)));
+  // four lanes per pair (k_pair_round4): a workgroup takes 64 frontier nodes per round of its loop; PIES_PAIR_QUADS=0: one lane per pair
+  bool quads = true;
+  if (const char* e = tuning_env("PIES_PAIR_QUADS")) quads = e[0] != '0';
+  uint32_t cap4 = 2048u;  // (measured on config 4, burst / settled substeps/s: 1 024: 70.8 / 98.1, 2 048: 73.0 / 101.4, 4 096: 69.9 / 100.3, 8 192: 65.1 / 96.0)
+  if (const char* e = tuning_env("PIES_PAIR_QUAD_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && v <= 65535) cap4 = static_cast<uint32_t>(v); }
+  const dim3 level4(std::max<uint32_t>(1u, std::min<uint32_t>(cap4, (n + kQuadNodes - 1u) / kQuadNodes)));
+  const dim3 levelRepeat4(std::max<uint32_t>(1u, std::min<uint32_t>(repeatCap, level4.x)));
   hipLaunchKernelGGL(k_pair_save, perNode, dim3(kBlock), 0, st, H, P, nd.pos, nd.vel, nd.radius, friction, staticThreshold); ++launches;
   const bool wide = P.nbrM != nullptr;  // ranges of more than two cells per axis: lists node by node
   if (!wide) { hipLaunchKernelGGL(k_pair_groups, dim3(std::min<uint32_t>(2048u, (H.capacity / 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, H, P, 0u); ++launches; }
@@ -1431,7 +1595,9 @@ uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArr
     // nothing is repeated)
     const uint32_t captured = repeat ? rounds + rounds / 2u : rounds;
     for (uint32_t r = 1; r <= captured; ++r) {
-      hipLaunchKernelGGL(k_pair_round, repeat ? levelRepeat : level, dim3(kRoundBlock), 0, st, H, P, friction, staticThreshold, r, repeat); ++launches;
+      if (quads) hipLaunchKernelGGL(k_pair_round4, repeat ? levelRepeat4 : level4, dim3(kRoundBlock), 0, st, H, P, friction, staticThreshold, r, repeat);
+      else hipLaunchKernelGGL(k_pair_round, repeat ? levelRepeat : level, dim3(kRoundBlock), 0, st, H, P, friction, staticThreshold, r, repeat);
+      ++launches;
     }
     hipLaunchKernelGGL(k_pair_tail, dim3(1), dim3(1024), 0, st, H, P, friction, staticThreshold, captured + 1u, repeat); ++launches;
     hipLaunchKernelGGL(k_pair_verify, dim3(64), dim3(kBlock), 0, st, H, P, repeat, gridSpacing); ++launches;

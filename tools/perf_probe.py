@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Quick throughput probe of one bench workload (development aid): perf_probe.py config2|config3|config4|contacts [ticks]"""
+"""Quick throughput probe of one bench workload (development aid): perf_probe.py config2|config3|config4|contacts [ticks] [NAME=VALUE ...]"""
 import os
 import sys
 import time
@@ -12,7 +12,11 @@ import scenes  # noqa: E402
 from pies_amd import capi  # noqa: E402
 
 what = sys.argv[1]
-ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+ticks = int(sys.argv[2]) if len(sys.argv) > 2 and "=" not in sys.argv[2] else 20
+for kv in sys.argv[2:]:  # NAME=VALUE: tunings (pies_set_tuning)
+    if "=" in kv:
+        name, _, value = kv.partition("=")
+        capi.set_tuning(name, value)
 if what == "config2":
     g = bench.build_scene(capi, scenes.L100K, 1234, schedule=capi.SCHEDULE_LAYERED, device=0)
     classes = {"layer": 1}
