@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised soak of the node-node pass in the pair order (development aid): loose particles with random sizes, radii, grid
 spacings (cell ranges of 2 to 4 cells per axis), jitter and iteration counts; two ticks each against the oracle's rule 2, exact
-equality, and the device run repeated (bit-identical).  usage: soak_collisions.py [scenes] [seed]"""
+equality, and the device run repeated (bit-identical).  usage: soak_collisions.py [scenes] [seed] [pairs|turns]
+(turns: the reference's order executed by dependency levels of turns - PIES_REFERENCE_TURNS=1 whatever the scene's size - against
+the oracle's plain loop, rule 0)"""
 import os
 import sys
 import time
@@ -16,7 +18,9 @@ import scenes  # noqa: E402
 from pies_amd import capi  # noqa: E402
 
 
-def main(nscenes, seed):
+def main(nscenes, seed, order="pairs"):
+    turns = order == "turns"
+    capi.set_tuning("PIES_REFERENCE_TURNS", "1" if turns else None)
     rng = np.random.default_rng(seed)
     t0 = time.time()
     for sc in range(nscenes):
@@ -38,13 +42,13 @@ def main(nscenes, seed):
             s = (mod.OracleSolver if which == "oracle" else mod.Solver)(scenes.pbd_options(mod, iters, gridSpacing=grid))
             s.add_nodes_raw(p, vel=v, radius=r, invMass=np.ones(len(p), np.float32))
             if which == "oracle":
-                s.set_flag(ora.FLAG_COLLISION_RULE, 2)
+                s.set_flag(ora.FLAG_COLLISION_RULE, 0 if turns else 2)
             else:
-                s.set_flag(capi.FLAG_COLLISION_ORDER, capi.COLLISION_ORDER_PAIRS)
+                s.set_flag(capi.FLAG_COLLISION_ORDER, capi.COLLISION_ORDER_REFERENCE if turns else capi.COLLISION_ORDER_PAIRS)
             s.tick(2)
             res.append((s.positions.copy(), s.velocities.copy(), s.collision_pairs, s.failed))
             if which != "oracle":
-                h = s.collision_health()
+                h = dict(s.collision_health(), fallbacks=s.collision_fallbacks)
                 s.close()
         assert not res[1][3], ("failed", state)
         for k in range(2):
@@ -56,4 +60,4 @@ def main(nscenes, seed):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 20, int(sys.argv[2]) if len(sys.argv) > 2 else 5)
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 20, int(sys.argv[2]) if len(sys.argv) > 2 else 5, sys.argv[3] if len(sys.argv) > 3 else "pairs")
