@@ -50,7 +50,7 @@ BYTES = {"predict": 48, "position": 44, "distance": 52, "tet": 160, "bend": 136,
 ITERATIONS = 20
 K = {name: i for i, name in enumerate(capi.KERNEL_NAMES)}
 DEVICE_KERNEL = {"layer": "k_layer", "tet": "k_tet", "wave": "k_wave", "pd_local_tet": "k_pd_local_tet_pair", "pd_spmv": "k_cg_ap",
-                 "pd_rhs": "k_pd_rhs", "pd_cg_update": "k_cg_update", "collide": "k_pair_round", "hash": "k_radix_scatter"}
+                 "pd_rhs": "k_pd_rhs", "pd_cg_update": "k_cg_update", "collide": "k_pair_round4", "hash": "k_radix_scatter"}
 
 
 def device_kernel(solver, cls):

@@ -258,7 +258,7 @@ int pies_collision_pairs(pies_solver_t* s, uint64_t* pairs);
  * neighbour"); both counters restart. */
 int pies_collision_stats(pies_solver_t* s, uint64_t* pairs, uint64_t* candidates);
 /* Pair order: level launches captured per pass.  By default the library follows what the passes need at host synchronisations
- * (it starts at 96; BASELINE config 4 settles at 48-64); a call pins the count.  A single-workgroup kernel finishes deeper
+ * (it starts at 96; BASELINE config 4 settles at 48 in the pair order, at ~1 100 in the reference's order by turns); a call pins the count.  A single-workgroup kernel finishes deeper
  * orders than captured: slow, never wrong. */
 int pies_set_collision_rounds(pies_solver_t* s, uint32_t rounds);
 /* Tuning and diagnostic switches, process wide, by name (value NULL or "" unsets): graph variants and sizes that tests and
@@ -269,7 +269,11 @@ int pies_set_collision_rounds(pies_solver_t* s, uint32_t rounds);
  * PIES_PD_TILE_ELEMS (0: per-(element, node) records instead of the tile-resident local step), PIES_PD_CG_SINGLE / _SINGLE_ROWS (0: the
  * two-launch CG everywhere / in the contact-heavy variant), PIES_PD_FUSE_RHS (0: k_pd_rhs), PIES_PD_RHS_LANES,
  * PIES_COLOUR_ROUNDS, PIES_COLOUR_DSATUR, PIES_NO_COLOUR_HINT, PIES_SELL_LANES, PIES_CG_BLOCKS, PIES_COLLIDE_GLOBAL / _PASSES /
- * _SPIN_LIMIT.  They take effect where the library reads them (pies_create, pies_finalize or the next graph capture).  pies_set_tuning must not
+ * _SPIN_LIMIT; round 5: PIES_PD_WINDOW (0: no windowed matrix, 2: also beside a row dictionary) / _WINDOW_KERNELS (1 iterations, 2 first
+ * product, 4 residual; default 3) / _WINDOW_SORT, PIES_CG_CHUNK_ROWS, PIES_PCG_NEVER_EXIT (profiling: every captured CG launch works),
+ * PIES_REFERENCE_TURNS (0: the reference's node-node order as one sequential chain, 1: by turns whatever the size; default: by turns from
+ * 1 024 nodes on), PIES_FALLBACK_VISITS (candidate tests a pass left to the sequential loop may cost before it latches: 1e9),
+ * PIES_PAIR_QUADS (0: one lane per pair in the pair order's levels) / _QUAD_BLOCKS.  They take effect where the library reads them (pies_create, pies_finalize or the next graph capture).  pies_set_tuning must not
  * race with other API calls of the process (a handle reads the switches at different times of its life).  None of
  * them is read from the environment: the only environment variables the library looks at are PIES_SCHEDULE (default schedule
  * of new handles), PIES_PROFILER_SAFE (profiling runs) and the print-only PIES_PCG_DEBUG / PIES_LAYER_DEBUG. */
