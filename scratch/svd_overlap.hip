@@ -1,0 +1,67 @@
+// Micro-benchmark for VERDICT r4 item 5 (development aid, not part of the product): does the dependency chain of the PBD tetrahedral
+// projection (pbd_project.h tet_core: F, one-sided Jacobi SVD with rsqrt_nr, clamp, recomposition, blend) leave issue slots that
+// co-resident wavefronts could fill?
+//
+// One workgroup per compute unit runs STEPS dependent projections per lane (each step's input is the previous step's output: like
+// the colour steps of k_layer, which an LDS barrier separates, consecutive projections of a lane cannot overlap).  The workgroup
+// has 256, 512, 768 or 1 024 threads = 1, 2, 3 or 4 wavefronts per SIMD doing the SAME per-wavefront work.  If a wavefront alone
+// filled its SIMD, w wavefronts per SIMD would take w times as long; whatever they take less is what co-residency hides.
+//
+// build: hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -I pies_amd/csrc -I include scratch/svd_overlap.hip -o /tmp/svd_overlap
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+#include "pbd_project.h"
+
+using namespace pies;
+
+__global__ void k_chain(float4* out, int steps) {
+  const int t = threadIdx.x + blockIdx.x * blockDim.x;
+  // a perturbed unit tetrahedron per lane; the rest state is the unit tetrahedron (Qinv = I), limits 0.8 .. 1.0, w = 0.05 (config 2)
+  const float e = 0.001f * static_cast<float>(t % 97);
+  float4 x1 = make_float4(0.01f + e, 0.02f, -0.01f, 1.f), x2 = make_float4(1.1f + e, 0.05f, 0.02f, 1.f);
+  float4 x3 = make_float4(-0.03f, 0.93f + e, 0.04f, 1.f), x4 = make_float4(0.02f, -0.04f, 1.07f - e, 1.f);
+  const float4 a0 = make_float4(1.f, 0.f, 0.f, 0.f), a1 = make_float4(1.f, 0.f, 0.f, 0.f), a2 = make_float4(1.f, 0.8f, 1.0f, 0.05f);
+  for (int s = 0; s < steps; ++s) {
+    tet_core<0>(x1, x2, x3, x4, a0, a1, a2);
+    // (keep the element from collapsing towards the origin - quirk Q2 - so that every step does a full decomposition)
+    x2.x += 1.0f; x3.y += 1.0f; x4.z += 1.0f;
+    x2.y += 0.31f; x3.z += 0.23f; x4.x -= 0.27f; x2.z -= 0.19f;  // (sheared, so that the Jacobi iteration takes its usual three sweeps)
+  }
+  out[t] = make_float4(x1.x + x2.x, x1.y + x3.y, x1.z + x4.z, x2.y + x3.z + x4.x);
+}
+
+int main() {
+  const int cus = 256, steps = 200;
+  float4* d;
+  hipMalloc(&d, sizeof(float4) * cus * 1024);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  double base = 0.0;
+  for (int waves = 1; waves <= 4; ++waves) {
+    const int threads = 256 * waves;
+    hipLaunchKernelGGL(k_chain, dim3(cus), dim3(threads), 0, 0, d, steps);  // warm
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; ++rep) {
+      hipEventRecord(e0, 0);
+      hipLaunchKernelGGL(k_chain, dim3(cus), dim3(threads), 0, 0, d, steps);
+      hipEventRecord(e1, 0);
+      hipEventSynchronize(e1);
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, e0, e1);
+      best = ms < best ? ms : best;
+    }
+    const double us_per_step = 1e3 * best / steps;
+    if (waves == 1) base = us_per_step;
+    std::printf("%d wavefront(s) per SIMD (%4d threads per workgroup, one workgroup per CU): %.3f us per projection step = %.2f x one wavefront's\n",
+                waves, threads, us_per_step, us_per_step / base);
+  }
+  std::vector<float4> h(4);
+  hipMemcpy(h.data(), d, sizeof(float4) * 4, hipMemcpyDeviceToHost);
+  std::printf("(checksum %.6f)\n", h[0].x + h[1].y + h[2].z + h[3].w);
+  return 0;
+}
