@@ -24,7 +24,8 @@ constexpr uint32_t kPairSpilled = 11;    // groups the small list kernel passed 
 constexpr uint32_t kPairFallback = 13;   // the sequential loop runs this pass: by turns it could not be proved exact twice, or (either order) a pile
                                          // the lists do not hold (more than 1 024 partners of a node, more entries than reserved)
 constexpr uint32_t kPairFallbacks = 14;  // lifetime: passes the sequential loop had to run
-constexpr uint32_t kPairWords = 16;
+constexpr uint32_t kPairBarrier = 16;   // [16] counter and [17] abort word of the grid barrier of a repeated pass (k_pair_repeat)
+constexpr uint32_t kPairWords = 32;
 
 constexpr uint32_t kPairLists = 64;     // the frontier is kept as this many sub-lists: a wavefront appends to one of them, so that the
                                         // appends of a level are spread over 64 counters (same-address atomics take ~8 ns each)

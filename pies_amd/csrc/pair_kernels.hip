@@ -910,19 +910,11 @@ PIES_DEV bool visit_quad(QuadNode& a, QuadNode& b, int k, float friction, float 
 PIES_DEV float comp4(const float4 v, int k) { return k == 1 ? v.y : (k == 2 ? v.z : v.x); }  // (lane 3: a copy of component 0)
 
 constexpr uint32_t kQuadNodes = 64;  // frontier nodes a workgroup looks at per round of its loop (one wavefront); pairs taken: at most as many
-__global__ void __launch_bounds__(kRoundBlock) k_pair_round4(HashArrays H, PairArrays P, float friction, float staticThreshold, uint32_t round, uint32_t repeat) {
-  __shared__ TakenPair taken[kQuadNodes];
-  __shared__ uint32_t nTaken;
-  if (repeat && !P.ctl[kPairRetry]) return;
-  if (H.counters[kCounterFlags]) return;
+// one level by the workgroups of the calling launch (all threads of a workgroup call: barriers); taken / nTaken: the workgroup's LDS
+PIES_DEV void pair_level4(const HashArrays& H, const PairArrays& P, float friction, float staticThreshold, uint32_t round, const FrontierView& view,
+                          TakenPair* taken, uint32_t* nTaken, uint32_t& hits) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const FrontierView view = frontier_view(P, round, lane);
-  if (blockIdx.x == 0 && wv == 0) {
-    P.frCount[(((round + 2u) % 3u) * kPairLists + static_cast<uint32_t>(lane)) * kPairPad] = 0;  // the lists of the round after the next
-    if (lane == 0 && view.total) { P.ctl[kPairRounds] = round; if (!repeat && round > P.ctl[kPairDeepest]) P.ctl[kPairDeepest] = round; }
-  }
   const uint32_t count = view.total;
-  if (count == 0u) return;
   float4* node = P.node;
   uint32_t* next = P.fr[(round + 1u) & 1u];
   uint32_t* nextCount = P.frCount + ((round + 1u) % 3u) * kPairLists * kPairPad;
@@ -934,7 +926,6 @@ __global__ void __launch_bounds__(kRoundBlock) k_pair_round4(HashArrays H, PairA
     return c < r.y;
   };
   const int k = lane & 3;
-  uint32_t hits = 0;
   for (uint32_t chunk = blockIdx.x; chunk * kQuadNodes < count; chunk += gridDim.x) {  // (workgroup uniform)
     // ---- who takes a pair: the first wavefront looks at the chunk's 64 frontier nodes
     if (wv == 0) {
@@ -957,10 +948,10 @@ __global__ void __launch_bounds__(kRoundBlock) k_pair_round4(HashArrays H, PairA
       }
       const unsigned long long tm = __ballot(take);
       if (take) taken[__popcll(tm & ((1ull << lane) - 1ull))] = TakenPair{x, y, rx, ry};
-      if (lane == 0) nTaken = static_cast<uint32_t>(__popcll(tm));
+      if (lane == 0) *nTaken = static_cast<uint32_t>(__popcll(tm));
     }
     __syncthreads();
-    const uint32_t total = nTaken;
+    const uint32_t total = *nTaken;
     // ---- the visits: quad q of the workgroup takes pair q
     const uint32_t q = threadIdx.x >> 2;
     bool moveX = false, moveY = false;
@@ -1016,7 +1007,86 @@ __global__ void __launch_bounds__(kRoundBlock) k_pair_round4(HashArrays H, PairA
     }
     __syncthreads();  // (the table is reused by the next chunk)
   }
+}
+
+__global__ void __launch_bounds__(kRoundBlock) k_pair_round4(HashArrays H, PairArrays P, float friction, float staticThreshold, uint32_t round, uint32_t repeat) {
+  __shared__ TakenPair taken[kQuadNodes];
+  __shared__ uint32_t nTaken;
+  if (repeat && !P.ctl[kPairRetry]) return;
+  if (H.counters[kCounterFlags]) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const FrontierView view = frontier_view(P, round, lane);
+  if (blockIdx.x == 0 && wv == 0) {
+    P.frCount[(((round + 2u) % 3u) * kPairLists + static_cast<uint32_t>(lane)) * kPairPad] = 0;  // the lists of the round after the next
+    if (lane == 0 && view.total) { P.ctl[kPairRounds] = round; if (!repeat && round > P.ctl[kPairDeepest]) P.ctl[kPairDeepest] = round; }
+  }
+  if (view.total == 0u) return;
+  uint32_t hits = 0;
+  pair_level4(H, P, friction, staticThreshold, round, view, taken, &nTaken, hits);
   count_hits(P, hits, lane);
+}
+
+// ---- the levels of a REPEATED pass in one launch ----------------------------------------------------------------------------------
+// A pass is repeated when a node left its slack and an unlisted pair may have touched: twice in the first three ticks of BASELINE
+// config 4, never afterwards.  Until round 5 every pass captured its repeat's level launches all the same - half as many again as
+// the first attempt's, 72 per settled pass of config 4, each returning on the "no repeat" word for the price of its dispatch (0.7 ms
+// of a 9-ms tick).  Now the repeat's levels are ONE launch: its workgroups - all resident - run level after level with a grid
+// barrier where the captured launches have a kernel boundary (release, counter, bounded wait, acquire: the CG continuation's
+// barrier, pd_cg_device.h), slower per level than a launch and run twice in a simulation's life.  A wait that times out hands the
+// pass to the sequential loop (flag 2).
+PIES_DEV bool pair_grid_barrier(uint32_t* counter, uint32_t nblocks, uint32_t& passed) {
+  __shared__ uint32_t sOk;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    atomicAdd(counter, 1u);
+    const uint32_t target = (passed + 1u) * nblocks;
+    uint32_t spins = 0, ok = 1u;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 20)) { ok = 0u; break; }  // ~1 s
+    }
+    // (a workgroup that gives up says so; one that arrives late and finds the counter past its target checks the word)
+    if (!ok) __hip_atomic_store(counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (__hip_atomic_load(counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = 0u;
+    __threadfence();
+    sOk = ok;
+  }
+  __syncthreads();
+  ++passed;
+  return sOk != 0u;
+}
+__global__ void __launch_bounds__(kRoundBlock) k_pair_repeat(HashArrays H, PairArrays P, float friction, float staticThreshold) {
+  __shared__ TakenPair taken[kQuadNodes];
+  __shared__ uint32_t nTaken;
+  if (!P.ctl[kPairRetry]) return;
+  if (H.counters[kCounterFlags]) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t hits = 0, passed = 0;
+  for (uint32_t round = 1;; ++round) {
+    const FrontierView view = frontier_view(P, round, lane);
+    if (view.total == 0u) break;  // (the same words in every workgroup: all leave together)
+    if (blockIdx.x == 0 && wv == 0) {
+      __hip_atomic_store(&P.frCount[(((round + 2u) % 3u) * kPairLists + static_cast<uint32_t>(lane)) * kPairPad], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) P.ctl[kPairRounds] = round;
+    }
+    pair_level4(H, P, friction, staticThreshold, round, view, taken, &nTaken, hits);
+    if (!pair_grid_barrier(P.ctl + kPairBarrier, gridDim.x, passed)) {
+      if (threadIdx.x == 0) atomicOr(&P.ctl[kPairFlags], 2u);
+      break;
+    }
+  }
+  count_hits(P, hits, lane);
+}
+// workgroups of k_pair_repeat the device holds at once (its grid barrier needs all of them resident); half of that, so that a second
+// solver on the card leaves room
+uint32_t pair_repeat_blocks(int device) {
+  int perCu = 0, dev = device;
+  hipDeviceProp_t prop;
+  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_pair_repeat, kRoundBlock, 0) != hipSuccess) return 0;
+  return static_cast<uint32_t>(std::max(0, perCu)) * static_cast<uint32_t>(std::max(0, prop.multiProcessorCount)) / 2u;
 }
 
 // Whatever levels are left after the captured rounds (and all levels of a repeated pass): one workgroup, a workgroup barrier
@@ -1204,6 +1274,8 @@ __global__ void k_pair_arm(HashArrays H, PairArrays P) {
   }
   if (!(flags & 1u)) return;
   P.ctl[kPairRetry] = 1;
+  P.ctl[kPairBarrier] = 0;      // k_pair_repeat's grid barrier: counter, abort word
+  P.ctl[kPairBarrier + 1] = 0;
   P.ctl[kPairRetries] += 1;
   P.ctl[kPairFlags] = 0;
   P.ctl[kPairEdges] = 0;
@@ -1580,6 +1652,10 @@ uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArr
   if (const char* e = tuning_env("PIES_PAIR_QUAD_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && v <= 65535) cap4 = static_cast<uint32_t>(v); }
   const dim3 level4(std::max<uint32_t>(1u, std::min<uint32_t>(cap4, (n + kQuadNodes - 1u) / kQuadNodes)));
   const dim3 levelRepeat4(std::max<uint32_t>(1u, std::min<uint32_t>(repeatCap, level4.x)));
+  // the repeat's levels in one launch of resident workgroups (PIES_PAIR_REPEAT_LAUNCHES=1: captured level launches as in rounds 3-4)
+  static const uint32_t residentRepeat = pair_repeat_blocks(-1);
+  uint32_t repeatBlocks = std::min<uint32_t>(std::min<uint32_t>(512u, residentRepeat), level4.x);
+  if (const char* e = tuning_env("PIES_PAIR_REPEAT_LAUNCHES"); e && e[0] == '1') repeatBlocks = 0;
   hipLaunchKernelGGL(k_pair_save, perNode, dim3(kBlock), 0, st, H, P, nd.pos, nd.vel, nd.radius, friction, staticThreshold); ++launches;
   const bool wide = P.nbrM != nullptr;  // ranges of more than two cells per axis: lists node by node
   if (!wide) { hipLaunchKernelGGL(k_pair_groups, dim3(std::min<uint32_t>(2048u, (H.capacity / 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, H, P, 0u); ++launches; }
@@ -1593,13 +1669,17 @@ uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArr
     }
     // (the repeat lists more partners and runs deeper: half as many launches again; they return at once - 2.5 us each - when
     // nothing is repeated)
-    const uint32_t captured = repeat ? rounds + rounds / 2u : rounds;
-    for (uint32_t r = 1; r <= captured; ++r) {
-      if (quads) hipLaunchKernelGGL(k_pair_round4, repeat ? levelRepeat4 : level4, dim3(kRoundBlock), 0, st, H, P, friction, staticThreshold, r, repeat);
-      else hipLaunchKernelGGL(k_pair_round, repeat ? levelRepeat : level, dim3(kRoundBlock), 0, st, H, P, friction, staticThreshold, r, repeat);
-      ++launches;
+    if (repeat && quads && repeatBlocks) {  // the repeat's levels: one launch (k_pair_repeat runs until the frontier is empty)
+      hipLaunchKernelGGL(k_pair_repeat, dim3(repeatBlocks), dim3(kRoundBlock), 0, st, H, P, friction, staticThreshold); ++launches;
+    } else {
+      const uint32_t captured = repeat ? rounds + rounds / 2u : rounds;
+      for (uint32_t r = 1; r <= captured; ++r) {
+        if (quads) hipLaunchKernelGGL(k_pair_round4, repeat ? levelRepeat4 : level4, dim3(kRoundBlock), 0, st, H, P, friction, staticThreshold, r, repeat);
+        else hipLaunchKernelGGL(k_pair_round, repeat ? levelRepeat : level, dim3(kRoundBlock), 0, st, H, P, friction, staticThreshold, r, repeat);
+        ++launches;
+      }
+      hipLaunchKernelGGL(k_pair_tail, dim3(1), dim3(1024), 0, st, H, P, friction, staticThreshold, captured + 1u, repeat); ++launches;
     }
-    hipLaunchKernelGGL(k_pair_tail, dim3(1), dim3(1024), 0, st, H, P, friction, staticThreshold, captured + 1u, repeat); ++launches;
     hipLaunchKernelGGL(k_pair_verify, dim3(64), dim3(kBlock), 0, st, H, P, repeat, gridSpacing); ++launches;
     hipLaunchKernelGGL(k_pair_check, perNode, dim3(kBlock), 0, st, H, P, nd.pos, nd.vel, repeat ? 0u : 1u); ++launches;
     if (!repeat) { hipLaunchKernelGGL(k_pair_arm, dim3(1), dim3(64), 0, st, H, P); ++launches; }
