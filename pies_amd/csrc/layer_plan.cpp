@@ -368,6 +368,18 @@ bool build_layer_plan(pies_solver* s) {
     return p >= tile.first0 && p < tile.first0 + tile.count0 ? p - tile.first0 : tile.count0 + (p - tile.first1);
   };
   Plan* plans = C.plans;
+  // The cost of a plan = the time of a sweep in units of a distance projection's step / 16: a phase lasts as long as its slowest
+  // tile, a tile as long as its colour steps, and a colour step as long as one projection of its kind (a tetrahedron's or a bend's
+  // ~ 4 distance projections) issued by the wavefronts that share a SIMD (measured, profiles/r05_svd_overlap.txt: 1 / 1.5 / 2.06 /
+  // 2.55 for 1 / 2 / 3 / 4 wavefronts per SIMD; round 5: thick slabs with 74 colour steps ran at 210 substeps/s against 270 for
+  // breadth-first levels with 71, because their classes are twice as large).
+  static const uint64_t weight[5] = {1, 1, 4, 0, 4};
+  auto step_time = [](uint32_t n) -> uint64_t {
+    const uint32_t w = ((n + 63) / 64 + 3) / 4;  // wavefronts per SIMD of a compute unit
+    static const uint64_t t[5] = {0, 16, 24, 33, 41};
+    return w <= 4 ? t[w] : 41 + 10ull * (w - 4);
+  };
+  C.cost = 0;
   for (int k : kinds) {
     const Ops& O = ops[k];
     LayerKind& K = L.kind[k];
@@ -395,6 +407,7 @@ bool build_layer_plan(pies_solver* s) {
     // the one below, whichever leaves the busiest of its nodes less busy (below[v] / above[v]: ops of this container that node v
     // meets as a node of its group's upper / lower level; the ops that span two levels are counted first)
     std::vector<uint32_t> groupOf(O.count), stripOf(O.count);
+    std::vector<uint8_t> alone(O.count, 0);  // dealt to the tile "level 0 alone" (the group below group 0, first tile of the odd parity)
     std::vector<uint32_t> below, above;
     if (balance && k != PIES_POSITION) { below.assign(N, 0); above.assign(N, 0); }
     for (uint32_t c = 0; c < O.count; ++c) {
@@ -422,8 +435,9 @@ bool build_layer_plan(pies_solver* s) {
         if (!single) continue;
         uint32_t stay = 0, down = 0;
         for (uint32_t j = 0; j < O.stride; ++j) { stay = std::max(stay, above[id[j]]); down = std::max(down, below[id[j]]); }
-        const bool goDown = l >= 1 && down < stay;
-        if (goDown) groupOf[c] = l - 1;
+        const bool goDown = down < stay;
+        if (goDown && l >= 1) groupOf[c] = l - 1;
+        else if (goDown) alone[c] = 1;
         for (uint32_t j = 0; j < O.stride; ++j) ++(goDown ? below[id[j]] : above[id[j]]);
       }
     if (!below.empty())
@@ -435,8 +449,8 @@ bool build_layer_plan(pies_solver* s) {
     for (uint32_t c = 0; c < O.count; ++c) {
       const uint32_t l = groupOf[c], t = stripOf[c];
       if (k == PIES_POSITION) { members[0][static_cast<size_t>(l / 2) * Sp[0]].push_back(c); continue; }  // one strip: with the even tiles
-      const int p1 = l & 1u, p2 = t & 1u;
-      const uint32_t gi = p1 ? (l + 1) / 2 : l / 2;
+      const int p1 = alone[c] ? 1 : static_cast<int>(l & 1u), p2 = t & 1u;
+      const uint32_t gi = alone[c] ? 0u : p1 ? (l + 1) / 2 : l / 2;
       members[2 * p1 + p2][static_cast<size_t>(gi) * Sp[p2] + t / 2].push_back(c);
     }
     P.order.reserve(O.count);
@@ -465,11 +479,15 @@ bool build_layer_plan(pies_solver* s) {
       K.ncol[ph] = ncol;
       if (ncol == 0) continue;  // no constraint of this container in this phase
       K.colOff[ph].assign(T.size() * (ncol + 1), 0);
+      uint64_t slowest = 0;
       for (size_t g = 0; g < T.size(); ++g) {
         const std::vector<uint32_t>& sel = members[ph][g];
         std::vector<uint32_t> offs(ncol + 2, 0);
         for (uint32_t key : keys[g]) ++offs[key + 1];
         for (uint32_t c = 0; c <= ncol; ++c) offs[c + 1] += offs[c];
+        uint64_t tileTime = 0;
+        for (uint32_t c = 0; c < ncol; ++c) tileTime += step_time(offs[c + 1] - offs[c]);
+        slowest = std::max(slowest, tileTime);
         const uint32_t slot0 = static_cast<uint32_t>(P.order.size());
         for (uint32_t c = 0; c <= ncol; ++c) K.colOff[ph][g * (ncol + 1) + c] = slot0 + offs[c];
         for (uint32_t c = 0; c < ncol; ++c)
@@ -484,14 +502,10 @@ bool build_layer_plan(pies_solver* s) {
           for (uint32_t j = 0; j < O.stride; ++j) K.local.push_back(local_index(T[g], O.ids[static_cast<size_t>(c) * O.stride + j]));
         }
       }
+      C.cost += weight[k] * slowest;
     }
     if (P.order.size() != O.count) return reject(C, "internal: incomplete order");
   }
-  // a colour step lasts as long as one projection of its kind: a tetrahedron's or a bend's ~ 4 distance projections
-  static const uint64_t weight[5] = {1, 1, 4, 0, 4};
-  C.cost = 0;
-  for (int k : kinds)
-    for (int ph = 0; ph < 4; ++ph) C.cost += weight[k] * L.kind[k].ncol[ph];
   return true;
   };
 
@@ -536,6 +550,8 @@ bool build_layer_plan(pies_solver* s) {
       }
     double scale = 1.0;
     if (const char* e = tuning_env("PIES_LAYER_SLAB")) scale = std::max(1.0, std::atof(e));
+    double offset = 0.0;  // the first slab is this fraction of a thickness thinner
+    if (const char* e = tuning_env("PIES_LAYER_SLAB_OFFSET")) offset = std::min(0.999, std::max(0.0, std::atof(e)));
     const double d = longest * scale * 1.000001 + 1.0e-6;
     const double extent = static_cast<double>(hi[axis]) - lo[axis];
     if (std::isfinite(extent) && longest > 0.0 && extent / d < 1.0e6) {
@@ -543,7 +559,7 @@ bool build_layer_plan(pies_solver* s) {
       uint32_t nl = 0;
       for (uint32_t v = 0; v < N; ++v) {
         const double z = static_cast<double>(s->h_pos[3 * v + axis]) - lo[axis];
-        levelSlab[v] = std::isfinite(z) ? static_cast<uint32_t>(z / d) : 0u;
+        levelSlab[v] = std::isfinite(z) ? static_cast<uint32_t>(z / d + offset) : 0u;
         nl = std::max(nl, levelSlab[v] + 1);
       }
       // (two nodes of a constraint are at most `longest` < d apart: their slabs differ by at most one)
