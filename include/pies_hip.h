@@ -265,7 +265,7 @@ int pies_set_collision_rounds(pies_solver_t* s, uint32_t rounds);
  * profiling scripts pin - PIES_PCG_BUDGET, PIES_PCG_OVERFLOW, PIES_TRI_FAST_ROWS, PIES_TRI_LDS, PIES_ROW_MAX_UNIQUE, PIES_TRI_SIDE, PIES_TRI_TEAM,
  * PIES_NO_GRAPH, PIES_NO_WAVEFRONT, PIES_NO_TET_PAIRS, PIES_PD_LOCAL_PACKED (0: one element per lane in the PD strain + volume step),
  * PIES_PD_REST_DICT (0: per-element constants instead of the rest dictionary), PIES_PD_ROW_DICT (0: the PD system matrix as SELL
- * arrays only, no row dictionary), PIES_LAYER_PLAN (0: schedule LAYERED's original plan only, 1: + single-level constraints dealt to either group, 2: + slabs by position; default 2) / _PLAN_FORCE (candidate index) / _SLAB, PIES_LAYER_ONE_STRIP_MAX / _TILE_NODES / _STRIPS_MIN_NODES / PIES_LAYER_BLOCK,
+ * arrays only, no row dictionary), PIES_LAYER_PLAN (0: schedule LAYERED's original plan only, 1: + single-level constraints dealt to either group, 2: + slabs by position; default 2) / _PLAN_FORCE (candidate index) / _SLAB / _SLAB_OFFSET, PIES_LAYER_ONE_STRIP_MAX / _TILE_NODES / _STRIPS_MIN_NODES / PIES_LAYER_BLOCK,
  * PIES_PD_TILE_ELEMS (0: per-(element, node) records instead of the tile-resident local step), PIES_PD_CG_SINGLE / _SINGLE_ROWS (0: the
  * two-launch CG everywhere / in the contact-heavy variant), PIES_PD_FUSE_RHS (0: k_pd_rhs), PIES_PD_RHS_LANES,
  * PIES_COLOUR_ROUNDS, PIES_COLOUR_DSATUR, PIES_NO_COLOUR_HINT, PIES_SELL_LANES, PIES_CG_BLOCKS, PIES_COLLIDE_GLOBAL / _PASSES /
