@@ -159,6 +159,17 @@ PIES_DEV void note_excursion(const PairArrays& P, uint32_t i, const NodeState& a
     if (at < P.n) P.left[at] = i;
   }
 }
+// the same for a caller that owns the node for the whole launch step (no other lane can touch it) and has read its excursion already
+PIES_DEV void note_excursion_owned(const PairArrays& P, uint32_t i, const NodeState& a, const float4 p0, uint32_t oldBits) {
+  const float dx = a.px - p0.x, dy = a.py - p0.y, dz = a.pz - p0.z;
+  const float e = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float thr = 0.999f * p0.w;
+  if (__float_as_uint(e) > oldBits) P.exc[i] = __float_as_uint(e);
+  if (!(e <= thr) && __uint_as_float(oldBits) <= thr) {
+    const uint32_t at = atomicAdd(&P.ctl[kPairLeft], 1u);
+    if (at < P.n) P.left[at] = i;
+  }
+}
 // resolved pairs are counted per wavefront into one of kPairStripes words (k_pair_check adds them up)
 PIES_DEV void count_hits(const PairArrays& P, uint32_t hits, int lane) {
 #pragma unroll
@@ -919,12 +930,6 @@ PIES_DEV void pair_level4(const HashArrays& H, const PairArrays& P, float fricti
   uint32_t* next = P.fr[(round + 1u) & 1u];
   uint32_t* nextCount = P.frCount + ((round + 1u) % 3u) * kPairLists * kPairPad;
   const uint32_t stampNow = round & 0xffffu, stampPrev = (round - 1u) & 0xffffu;
-  auto move_on = [&](uint32_t i, const uint4 r) {
-    const uint32_t c = (r.z & 0xffffu) + 1u;
-    const uint32_t entry = (c < r.y ? P.nbr[r.x + c] : 0u) | ((c & 7u) << kPairTagShift);
-    store_rec(node, i, make_uint4(r.x, r.y, c | (stampNow << 16), entry));
-    return c < r.y;
-  };
   const int k = lane & 3;
   for (uint32_t chunk = blockIdx.x; chunk * kQuadNodes < count; chunk += gridDim.x) {  // (workgroup uniform)
     // ---- who takes a pair: the first wavefront looks at the chunk's 64 frontier nodes
@@ -952,57 +957,67 @@ PIES_DEV void pair_level4(const HashArrays& H, const PairArrays& P, float fricti
     }
     __syncthreads();
     const uint32_t total = *nTaken;
-    // ---- the visits: quad q of the workgroup takes pair q
-    const uint32_t q = threadIdx.x >> 2;
-    bool moveX = false, moveY = false;
-    uint32_t x = 0, y = 0;
-    if (q < total) {
-      const TakenPair t = taken[q];
-      x = t.x; y = t.y;
-      const bool xLow = x < y;
-      const uint32_t lo = xLow ? x : y, hi = xLow ? y : x;
-      const float4 ap = node[4u * lo], av = node[4u * lo + 1u], bp = node[4u * hi], bv = node[4u * hi + 1u];
-      QuadNode a{comp4(ap, k), comp4(av, k), ap.w, av.w}, b{comp4(bp, k), comp4(bv, k), bp.w, bv.w};
-      const float d = b.p - a.p;
-      const float dist = sqrtf(quad_sum3(d * d));
-      if (a.r + b.r - dist > 0.0f) {
-        const uint32_t m = P.nbrM ? P.nbrM[t.rx.x + (t.rx.z & 0xffffu)] : (t.rx.w >> 28) + 1u;  // (wide ranges keep the count beside the entry)
-        uint32_t h = 0;
-        for (uint32_t v = 0; v < m; ++v) h += visit_quad(a, b, k, friction, staticThreshold) ? 1u : 0u;
-        for (uint32_t v = 0; v < m; ++v) h += visit_quad(b, a, k, friction, staticThreshold) ? 1u : 0u;
-        // the quad's first lane puts the components together and stores the two nodes
-        const float apy = quad_lane(a.p, 1), apz = quad_lane(a.p, 2), avy = quad_lane(a.v, 1), avz = quad_lane(a.v, 2);
-        const float bpy = quad_lane(b.p, 1), bpz = quad_lane(b.p, 2), bvy = quad_lane(b.v, 1), bvz = quad_lane(b.v, 2);
+    // ---- the visits: the workgroup's quads take the pairs, blockDim.x / 4 at a time (a workgroup of one wavefront: 16; of four: all 64)
+    const uint32_t quads = blockDim.x >> 2;
+    for (uint32_t q0 = 0; q0 < total; q0 += quads) {  // (workgroup uniform)
+      const uint32_t q = q0 + (threadIdx.x >> 2);
+      bool moveX = false, moveY = false;
+      uint32_t x = 0, y = 0;
+      if (q < total) {
+        const TakenPair t = taken[q];
+        x = t.x; y = t.y;
+        const bool xLow = x < y;
+        const uint32_t lo = xLow ? x : y, hi = xLow ? y : x;
+        // everything the pair may need is requested at once (one round trip instead of four dependent ones: the positions the
+        // lists were built from, the excursions so far and the next list entries used to be fetched when they were needed)
+        const float4 ap = node[4u * lo], av = node[4u * lo + 1u], bp = node[4u * hi], bv = node[4u * hi + 1u];
+        const float4 a0 = node[4u * lo + 2u], b0 = node[4u * hi + 2u];
+        const uint32_t ea = P.exc[lo], eb = P.exc[hi];  // (a node is in one pair of a level: nobody else touches its excursion now)
+        const uint32_t cx = (t.rx.z & 0xffffu) + 1u, cy = (t.ry.z & 0xffffu) + 1u;
+        const uint32_t nextX = P.nbr[t.rx.x + min(cx, t.rx.y - 1u)], nextY = P.nbr[t.ry.x + min(cy, t.ry.y - 1u)];  // (unconditional: clamped)
+        QuadNode a{comp4(ap, k), comp4(av, k), ap.w, av.w}, b{comp4(bp, k), comp4(bv, k), bp.w, bv.w};
+        const float d = b.p - a.p;
+        const float dist = sqrtf(quad_sum3(d * d));
+        if (a.r + b.r - dist > 0.0f) {
+          const uint32_t m = P.nbrM ? P.nbrM[t.rx.x + (t.rx.z & 0xffffu)] : (t.rx.w >> 28) + 1u;  // (wide ranges keep the count beside the entry)
+          uint32_t h = 0;
+          for (uint32_t v = 0; v < m; ++v) h += visit_quad(a, b, k, friction, staticThreshold) ? 1u : 0u;
+          for (uint32_t v = 0; v < m; ++v) h += visit_quad(b, a, k, friction, staticThreshold) ? 1u : 0u;
+          // the quad's first lane puts the components together and stores the two nodes
+          const float apy = quad_lane(a.p, 1), apz = quad_lane(a.p, 2), avy = quad_lane(a.v, 1), avz = quad_lane(a.v, 2);
+          const float bpy = quad_lane(b.p, 1), bpz = quad_lane(b.p, 2), bvy = quad_lane(b.v, 1), bvz = quad_lane(b.v, 2);
+          if (k == 0) {
+            const NodeState na{a.p, apy, apz, a.w, a.v, avy, avz, a.r}, nb{b.p, bpy, bpz, b.w, b.v, bvy, bvz, b.r};
+            store_node(node, lo, na);
+            store_node(node, hi, nb);
+            note_excursion_owned(P, lo, na, a0, ea);
+            note_excursion_owned(P, hi, nb, b0, eb);
+            hits += h;
+          }
+        }
         if (k == 0) {
-          const NodeState na{a.p, apy, apz, a.w, a.v, avy, avz, a.r}, nb{b.p, bpy, bpz, b.w, b.v, bvy, bvz, b.r};
-          const float4 a0 = node[4u * lo + 2u], b0 = node[4u * hi + 2u];
-          store_node(node, lo, na);
-          store_node(node, hi, nb);
-          note_excursion(P, lo, na, a0);
-          note_excursion(P, hi, nb, b0);
-          hits += h;
+          store_rec(node, x, make_uint4(t.rx.x, t.rx.y, cx | (stampNow << 16), (cx < t.rx.y ? nextX : 0u) | ((cx & 7u) << kPairTagShift)));
+          store_rec(node, y, make_uint4(t.ry.x, t.ry.y, cy | (stampNow << 16), (cy < t.ry.y ? nextY : 0u) | ((cy & 7u) << kPairTagShift)));
+          moveX = cx < t.rx.y;
+          moveY = cy < t.ry.y;
         }
       }
-      if (k == 0) {
-        moveX = move_on(x, t.rx);
-        moveY = move_on(y, t.ry);
-      }
-    }
-    // the nodes that moved on and have entries left go to the sub-list this wavefront's part of the chunk is dealt to (one atomic
-    // per wavefront: 16 pairs, at most 32 nodes)
-    if (static_cast<uint32_t>(wv) * 16u < total) {  // (wavefront uniform)
-      const unsigned long long mx = __ballot(moveX), my = __ballot(moveY);
-      const uint32_t nx = static_cast<uint32_t>(__popcll(mx)), ny = static_cast<uint32_t>(__popcll(my));
-      if (nx + ny) {
-        const uint32_t sub = (chunk * (kRoundBlock / 64) + static_cast<uint32_t>(wv)) % kPairLists;
-        uint32_t at = 0;
-        if (lane == 0) at = atomicAdd(&nextCount[sub * kPairPad], nx + ny);
-        at = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(at)));
-        uint32_t* dst = next + static_cast<size_t>(sub) * P.frCap;
-        const uint32_t ix = at + static_cast<uint32_t>(__popcll(mx & ((1ull << lane) - 1ull)));
-        const uint32_t iy = at + nx + static_cast<uint32_t>(__popcll(my & ((1ull << lane) - 1ull)));
-        if (moveX && ix < P.frCap) dst[ix] = x;
-        if (moveY && iy < P.frCap) dst[iy] = y;
+      // the nodes that moved on and have entries left go to the sub-list this sixteenth of the chunk is dealt to (one atomic per
+      // wavefront and turn: 16 pairs, at most 32 nodes; a chunk has four such parts whatever the workgroup's size)
+      if (q0 + static_cast<uint32_t>(wv) * 16u < total) {  // (wavefront uniform)
+        const unsigned long long mx = __ballot(moveX), my = __ballot(moveY);
+        const uint32_t nx = static_cast<uint32_t>(__popcll(mx)), ny = static_cast<uint32_t>(__popcll(my));
+        if (nx + ny) {
+          const uint32_t sub = (chunk * 4u + (q0 >> 4) + static_cast<uint32_t>(wv)) % kPairLists;
+          uint32_t at = 0;
+          if (lane == 0) at = atomicAdd(&nextCount[sub * kPairPad], nx + ny);
+          at = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(at)));
+          uint32_t* dst = next + static_cast<size_t>(sub) * P.frCap;
+          const uint32_t ix = at + static_cast<uint32_t>(__popcll(mx & ((1ull << lane) - 1ull)));
+          const uint32_t iy = at + nx + static_cast<uint32_t>(__popcll(my & ((1ull << lane) - 1ull)));
+          if (moveX && ix < P.frCap) dst[ix] = x;
+          if (moveY && iy < P.frCap) dst[iy] = y;
+        }
       }
     }
     __syncthreads();  // (the table is reused by the next chunk)
@@ -1648,7 +1663,17 @@ uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArr
   // four lanes per pair (k_pair_round4): a workgroup takes 64 frontier nodes per round of its loop; PIES_PAIR_QUADS=0: one lane per pair
   bool quads = true;
   if (const char* e = tuning_env("PIES_PAIR_QUADS")) quads = e[0] != '0';
-  uint32_t cap4 = 2048u;  // (measured on config 4, burst / settled substeps/s: 1 024: 70.8 / 98.1, 2 048: 73.0 / 101.4, 4 096: 69.9 / 100.3, 8 192: 65.1 / 96.0)
+  // threads of a level's workgroups (PIES_PAIR_QUAD_THREADS: 64, 128 or 256): a workgroup looks at 64 frontier nodes per turn of its
+  // loop whatever its size, and as many workgroups as the chip holds at once take part (8 of 256 threads per compute unit).
+  // Measured on config 4 (burst / settled): 256: 75.6 / 109.9, 128: 68.8 / 102.0, 64: 63.4 / 94.3 - more, smaller workgroups put
+  // every chunk of a level in flight at once but run a chunk's pairs sixteen at a time; and requesting all of a pair's operands
+  // at once (the built-from positions, the excursions, the next list entries: one round trip instead of four) changed nothing
+  // (75.2 / 109.1): the heavy levels (45-59 us, levels 1-25 of ~36) are not their memory round trips but the visits' own chains -
+  // a pair shares up to eight cells and is visited that often from both sides, ~0.3 us of dependent square roots and correctly
+  // rounded divisions per visit - at eight wavefronts per SIMD.
+  uint32_t threads4 = kRoundBlock;
+  if (const char* e = tuning_env("PIES_PAIR_QUAD_THREADS")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) threads4 = static_cast<uint32_t>(v); }
+  uint32_t cap4 = 2048u * (kRoundBlock / threads4);  // (measured on config 4 with 256 threads, burst / settled substeps/s: 1 024: 70.8 / 98.1, 2 048: 73.0 / 101.4, 4 096: 69.9 / 100.3, 8 192: 65.1 / 96.0)
   if (const char* e = tuning_env("PIES_PAIR_QUAD_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && v <= 65535) cap4 = static_cast<uint32_t>(v); }
   const dim3 level4(std::max<uint32_t>(1u, std::min<uint32_t>(cap4, (n + kQuadNodes - 1u) / kQuadNodes)));
   const dim3 levelRepeat4(std::max<uint32_t>(1u, std::min<uint32_t>(repeatCap, level4.x)));
@@ -1674,7 +1699,7 @@ uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArr
     } else {
       const uint32_t captured = repeat ? rounds + rounds / 2u : rounds;
       for (uint32_t r = 1; r <= captured; ++r) {
-        if (quads) hipLaunchKernelGGL(k_pair_round4, repeat ? levelRepeat4 : level4, dim3(kRoundBlock), 0, st, H, P, friction, staticThreshold, r, repeat);
+        if (quads) hipLaunchKernelGGL(k_pair_round4, repeat ? levelRepeat4 : level4, dim3(threads4), 0, st, H, P, friction, staticThreshold, r, repeat);
         else hipLaunchKernelGGL(k_pair_round, repeat ? levelRepeat : level, dim3(kRoundBlock), 0, st, H, P, friction, staticThreshold, r, repeat);
         ++launches;
       }

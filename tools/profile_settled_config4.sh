@@ -22,6 +22,11 @@ for r in seg:
 print("per tick (us): total %.1f   wall %.1f"%(sum(dur.values())/T,(int(seg[-1]['End_Timestamp'])-int(seg[0]['Start_Timestamp']))/1e3/T))
 for n in sorted(dur,key=lambda n:-dur[n])[:22]:
     print("  %-36s x%6.1f  avg %8.2f  per tick %8.1f   (>6us: x%.1f avg %.1f)"%(n,cnt[n]/T,dur[n]/cnt[n],dur[n]/T,wcnt[n]/T,work[n]/max(1,wcnt[n])))
+# the level launches of the last pass, in order
+last=[r for r in seg if 'k_pair_round' in r['Kernel_Name'] or 'k_pair_save' in r['Kernel_Name']]
+cut=max(i for i,r in enumerate(last) if 'k_pair_save' in r['Kernel_Name'])
+lv=[(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3 for r in last[cut+1:]]
+print("level launches of the last pass (us):"," ".join("%.0f"%d for d in lv))
 PY
 
 rm -f $out/t_kernel_trace.csv
