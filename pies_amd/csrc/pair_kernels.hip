@@ -920,10 +920,17 @@ PIES_DEV bool visit_quad(QuadNode& a, QuadNode& b, int k, float friction, float 
 }
 PIES_DEV float comp4(const float4 v, int k) { return k == 1 ? v.y : (k == 2 ? v.z : v.x); }  // (lane 3: a copy of component 0)
 
-constexpr uint32_t kQuadNodes = 64;  // frontier nodes a workgroup looks at per round of its loop (one wavefront); pairs taken: at most as many
-// one level by the workgroups of the calling launch (all threads of a workgroup call: barriers); taken / nTaken: the workgroup's LDS
+constexpr uint32_t kQuadNodes = 64;     // frontier nodes a wavefront looks at per turn of a workgroup's loop
+constexpr uint32_t kQuadLookMax = 4;    // wavefronts of a workgroup that look (PIES_PAIR_LOOK_WAVES: 1, 2 or 4): the table holds 64 pairs for each
+constexpr uint32_t kQuadBins = 9;       // pairs by visits per side: 8 and more ... 1, and the ones that do not overlap
+struct QuadTable {
+  TakenPair taken[kQuadNodes * kQuadLookMax];
+  uint32_t bins[kQuadLookMax][kQuadBins];
+};
+// one level by the workgroups of the calling launch (all threads of a workgroup call: barriers); T: the workgroup's LDS; look: the
+// wavefronts of the workgroup that look at frontier nodes (at most blockDim.x / 64)
 PIES_DEV void pair_level4(const HashArrays& H, const PairArrays& P, float friction, float staticThreshold, uint32_t round, const FrontierView& view,
-                          TakenPair* taken, uint32_t* nTaken, uint32_t& hits) {
+                          QuadTable& T, uint32_t look, uint32_t& hits) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t count = view.total;
   float4* node = P.node;
@@ -931,13 +938,15 @@ PIES_DEV void pair_level4(const HashArrays& H, const PairArrays& P, float fricti
   uint32_t* nextCount = P.frCount + ((round + 1u) % 3u) * kPairLists * kPairPad;
   const uint32_t stampNow = round & 0xffffu, stampPrev = (round - 1u) & 0xffffu;
   const int k = lane & 3;
-  for (uint32_t chunk = blockIdx.x; chunk * kQuadNodes < count; chunk += gridDim.x) {  // (workgroup uniform)
-    // ---- who takes a pair: the first wavefront looks at the chunk's 64 frontier nodes
-    if (wv == 0) {
-      const uint32_t e = chunk * kQuadNodes + static_cast<uint32_t>(lane);
-      bool take = false;
-      uint32_t x = 0, y = 0;
-      uint4 rx = make_uint4(0u, 0u, 0u, 0u), ry = rx;
+  const uint32_t per = kQuadNodes * look;  // frontier nodes per turn
+  TakenPair* taken = T.taken;
+  for (uint32_t chunk = blockIdx.x; chunk * per < count; chunk += gridDim.x) {  // (workgroup uniform)
+    // ---- who takes a pair: the first wavefronts look at the chunk's frontier nodes, 64 each
+    bool take = false;
+    uint32_t x = 0, y = 0, key = 0;
+    uint4 rx = make_uint4(0u, 0u, 0u, 0u), ry = rx;
+    if (static_cast<uint32_t>(wv) < look) {
+      const uint32_t e = chunk * per + static_cast<uint32_t>(wv) * kQuadNodes + static_cast<uint32_t>(lane);
       const uint32_t xe = frontier_node(P, view, round, min(e, count - 1u));  // (every lane takes part in the shuffles)
       if (e < count) {
         x = xe;
@@ -951,19 +960,78 @@ PIES_DEV void pair_level4(const HashArrays& H, const PairArrays& P, float fricti
           if (take && sy == stampPrev && y < x) take = false;  // y is in this frontier as well and takes the pair
         }
       }
-      const unsigned long long tm = __ballot(take);
-      if (take) taken[__popcll(tm & ((1ull << lane) - 1ull))] = TakenPair{x, y, rx, ry};
-      if (lane == 0) *nTaken = static_cast<uint32_t>(__popcll(tm));
+      // The pairs go into the table sorted: the ones that overlap first, by descending number of shared cells (= visits from either
+      // side), the ones that do not (most, once a pile has settled: they only move on) last.  A wavefront of the visits runs as long
+      // as its busiest quad, and the level launches of config 4 turned out to be bound by VALU issue (profiles/
+      // r05_levels_pmc_config4.txt: 20 M wavefront instructions in level 1, SQ_ACTIVE_INST_ANY x 8 resident wavefronts > a SIMD's
+      // cycles): in arrival order a wavefront's sixteen pairs held ~6 overlapping ones with 1-8 shared cells each.  The overlap test
+      // is visit()'s own (same operands, same order), on lines the records' loads have just brought in.
+      if (take) {
+        const bool xLow = x < y;
+        const uint32_t lo = xLow ? x : y, hi = xLow ? y : x;
+        const float4 ap = node[4u * lo], av = node[4u * lo + 1u], bp = node[4u * hi], bv = node[4u * hi + 1u];
+        const float dx = bp.x - ap.x, dy = bp.y - ap.y, dz = bp.z - ap.z;
+        const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+        if (av.w + bv.w - dist > 0.0f) {
+          const uint32_t m = P.nbrM ? P.nbrM[rx.x + (rx.z & 0xffffu)] : (rx.w >> 28) + 1u;
+          key = min(m, kQuadBins - 1u);
+        }
+      }
+      // (bin b of the table = key kQuadBins - 1 - b: descending)
+#pragma unroll
+      for (uint32_t b = 0; b < kQuadBins; ++b) {
+        const unsigned long long mk = __ballot(take && key == kQuadBins - 1u - b);
+        if (lane == 0) T.bins[wv][b] = static_cast<uint32_t>(__popcll(mk));
+      }
     }
     __syncthreads();
-    const uint32_t total = *nTaken;
-    // ---- the visits: the workgroup's quads take the pairs, blockDim.x / 4 at a time (a workgroup of one wavefront: 16; of four: all 64)
+    uint32_t total = 0, nOv = 0;  // pairs taken; the ones of them that overlap (they come first)
+    {
+      // a pair's place: the pairs of the bins before its own, its bin's pairs of the wavefronts before its own, the lanes before it
+      uint32_t at = 0;
+      const uint32_t myBin = kQuadBins - 1u - key;
+#pragma unroll
+      for (uint32_t b = 0; b < kQuadBins; ++b)
+        for (uint32_t w = 0; w < look; ++w) {
+          const uint32_t c = T.bins[w][b];
+          total += c;
+          if (b + 1u < kQuadBins) nOv += c;
+          if (b < myBin || (b == myBin && w < static_cast<uint32_t>(wv))) at += c;
+        }
+      if (static_cast<uint32_t>(wv) < look) {  // (wavefront uniform)
+#pragma unroll
+        for (uint32_t b = 0; b < kQuadBins; ++b) {
+          const bool mine = take && myBin == b;
+          const unsigned long long mb = __ballot(mine);
+          if (mine) taken[at + static_cast<uint32_t>(__popcll(mb & ((1ull << lane) - 1ull)))] = TakenPair{x, y, rx, ry};
+        }
+      }
+    }
+    __syncthreads();
+    // the nodes of a wavefront's pairs that moved on and have entries left go to the sub-list their 64 places of the table are dealt
+    // to (at most 128 nodes for every 64 frontier nodes looked at: frCap covers that); one atomic per wavefront and turn
+    auto append = [&](bool moveX, bool moveY, uint32_t x, uint32_t y, uint32_t place) {
+      const unsigned long long mx = __ballot(moveX), my = __ballot(moveY);
+      const uint32_t nx = static_cast<uint32_t>(__popcll(mx)), ny = static_cast<uint32_t>(__popcll(my));
+      if (nx + ny) {
+        const uint32_t sub = (chunk * look + (place >> 6)) % kPairLists;
+        uint32_t at = 0;
+        if (lane == 0) at = atomicAdd(&nextCount[sub * kPairPad], nx + ny);
+        at = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(at)));
+        uint32_t* dst = next + static_cast<size_t>(sub) * P.frCap;
+        const uint32_t ix = at + static_cast<uint32_t>(__popcll(mx & ((1ull << lane) - 1ull)));
+        const uint32_t iy = at + nx + static_cast<uint32_t>(__popcll(my & ((1ull << lane) - 1ull)));
+        if (moveX && ix < P.frCap) dst[ix] = x;
+        if (moveY && iy < P.frCap) dst[iy] = y;
+      }
+    };
+    // ---- the visits: the workgroup's quads take the overlapping pairs, blockDim.x / 4 at a time (a workgroup of one wavefront: 16; of four: 64)
     const uint32_t quads = blockDim.x >> 2;
-    for (uint32_t q0 = 0; q0 < total; q0 += quads) {  // (workgroup uniform)
+    for (uint32_t q0 = 0; q0 < nOv; q0 += quads) {  // (workgroup uniform)
       const uint32_t q = q0 + (threadIdx.x >> 2);
       bool moveX = false, moveY = false;
       uint32_t x = 0, y = 0;
-      if (q < total) {
+      if (q < nOv) {
         const TakenPair t = taken[q];
         x = t.x; y = t.y;
         const bool xLow = x < y;
@@ -1002,31 +1070,34 @@ PIES_DEV void pair_level4(const HashArrays& H, const PairArrays& P, float fricti
           moveY = cy < t.ry.y;
         }
       }
-      // the nodes that moved on and have entries left go to the sub-list this sixteenth of the chunk is dealt to (one atomic per
-      // wavefront and turn: 16 pairs, at most 32 nodes; a chunk has four such parts whatever the workgroup's size)
-      if (q0 + static_cast<uint32_t>(wv) * 16u < total) {  // (wavefront uniform)
-        const unsigned long long mx = __ballot(moveX), my = __ballot(moveY);
-        const uint32_t nx = static_cast<uint32_t>(__popcll(mx)), ny = static_cast<uint32_t>(__popcll(my));
-        if (nx + ny) {
-          const uint32_t sub = (chunk * 4u + (q0 >> 4) + static_cast<uint32_t>(wv)) % kPairLists;
-          uint32_t at = 0;
-          if (lane == 0) at = atomicAdd(&nextCount[sub * kPairPad], nx + ny);
-          at = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(at)));
-          uint32_t* dst = next + static_cast<size_t>(sub) * P.frCap;
-          const uint32_t ix = at + static_cast<uint32_t>(__popcll(mx & ((1ull << lane) - 1ull)));
-          const uint32_t iy = at + nx + static_cast<uint32_t>(__popcll(my & ((1ull << lane) - 1ull)));
-          if (moveX && ix < P.frCap) dst[ix] = x;
-          if (moveY && iy < P.frCap) dst[iy] = y;
-        }
+      const uint32_t first = q0 + static_cast<uint32_t>(wv) * 16u;  // the wavefront's sixteen places of the table
+      if (first < nOv) append(moveX, moveY, x, y, first);  // (wavefront uniform)
+    }
+    // ---- the pairs that do not overlap only move on: a lane each, the table's 64-places at a time (the first of them may begin
+    //      with overlapping pairs: the quads had those)
+    for (uint32_t base = (nOv & ~63u) + static_cast<uint32_t>(wv) * 64u; base < total; base += blockDim.x) {  // (wavefront uniform)
+      const uint32_t p = base + static_cast<uint32_t>(lane);
+      bool moveX = false, moveY = false;
+      uint32_t x = 0, y = 0;
+      if (p >= nOv && p < total) {
+        const TakenPair t = taken[p];
+        x = t.x; y = t.y;
+        const uint32_t cx = (t.rx.z & 0xffffu) + 1u, cy = (t.ry.z & 0xffffu) + 1u;
+        const uint32_t nextX = P.nbr[t.rx.x + min(cx, t.rx.y - 1u)], nextY = P.nbr[t.ry.x + min(cy, t.ry.y - 1u)];  // (unconditional: clamped)
+        store_rec(node, x, make_uint4(t.rx.x, t.rx.y, cx | (stampNow << 16), (cx < t.rx.y ? nextX : 0u) | ((cx & 7u) << kPairTagShift)));
+        store_rec(node, y, make_uint4(t.ry.x, t.ry.y, cy | (stampNow << 16), (cy < t.ry.y ? nextY : 0u) | ((cy & 7u) << kPairTagShift)));
+        moveX = cx < t.rx.y;
+        moveY = cy < t.ry.y;
       }
+      append(moveX, moveY, x, y, base);
     }
     __syncthreads();  // (the table is reused by the next chunk)
   }
 }
 
-__global__ void __launch_bounds__(kRoundBlock) k_pair_round4(HashArrays H, PairArrays P, float friction, float staticThreshold, uint32_t round, uint32_t repeat) {
-  __shared__ TakenPair taken[kQuadNodes];
-  __shared__ uint32_t nTaken;
+__global__ void __launch_bounds__(kRoundBlock) k_pair_round4(HashArrays H, PairArrays P, float friction, float staticThreshold, uint32_t round, uint32_t repeat,
+                                                             uint32_t look) {
+  __shared__ QuadTable table;
   if (repeat && !P.ctl[kPairRetry]) return;
   if (H.counters[kCounterFlags]) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1037,7 +1108,7 @@ __global__ void __launch_bounds__(kRoundBlock) k_pair_round4(HashArrays H, PairA
   }
   if (view.total == 0u) return;
   uint32_t hits = 0;
-  pair_level4(H, P, friction, staticThreshold, round, view, taken, &nTaken, hits);
+  pair_level4(H, P, friction, staticThreshold, round, view, table, look, hits);
   count_hits(P, hits, lane);
 }
 
@@ -1072,8 +1143,7 @@ PIES_DEV bool pair_grid_barrier(uint32_t* counter, uint32_t nblocks, uint32_t& p
   return sOk != 0u;
 }
 __global__ void __launch_bounds__(kRoundBlock) k_pair_repeat(HashArrays H, PairArrays P, float friction, float staticThreshold) {
-  __shared__ TakenPair taken[kQuadNodes];
-  __shared__ uint32_t nTaken;
+  __shared__ QuadTable table;
   if (!P.ctl[kPairRetry]) return;
   if (H.counters[kCounterFlags]) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1085,7 +1155,7 @@ __global__ void __launch_bounds__(kRoundBlock) k_pair_repeat(HashArrays H, PairA
       __hip_atomic_store(&P.frCount[(((round + 2u) % 3u) * kPairLists + static_cast<uint32_t>(lane)) * kPairPad], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (lane == 0) P.ctl[kPairRounds] = round;
     }
-    pair_level4(H, P, friction, staticThreshold, round, view, taken, &nTaken, hits);
+    pair_level4(H, P, friction, staticThreshold, round, view, table, 1u, hits);
     if (!pair_grid_barrier(P.ctl + kPairBarrier, gridDim.x, passed)) {
       if (threadIdx.x == 0) atomicOr(&P.ctl[kPairFlags], 2u);
       break;
@@ -1673,9 +1743,14 @@ uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArr
   // rounded divisions per visit - at eight wavefronts per SIMD.
   uint32_t threads4 = kRoundBlock;
   if (const char* e = tuning_env("PIES_PAIR_QUAD_THREADS")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) threads4 = static_cast<uint32_t>(v); }
-  uint32_t cap4 = 2048u * (kRoundBlock / threads4);  // (measured on config 4 with 256 threads, burst / settled substeps/s: 1 024: 70.8 / 98.1, 2 048: 73.0 / 101.4, 4 096: 69.9 / 100.3, 8 192: 65.1 / 96.0)
+  uint32_t cap4 = 1024u * (kRoundBlock / threads4);  // (measured on config 4 with 256 threads, burst / settled substeps/s: 1 024: 70.8 / 98.1, 2 048: 73.0 / 101.4, 4 096: 69.9 / 100.3, 8 192: 65.1 / 96.0)
   if (const char* e = tuning_env("PIES_PAIR_QUAD_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && v <= 65535) cap4 = static_cast<uint32_t>(v); }
-  const dim3 level4(std::max<uint32_t>(1u, std::min<uint32_t>(cap4, (n + kQuadNodes - 1u) / kQuadNodes)));
+  // wavefronts of a level's workgroup that look at frontier nodes, 64 each (PIES_PAIR_LOOK_WAVES: 1, 2 or 4): the pairs they take are
+  // sorted by visits across the whole workgroup, so more of them make the visiting wavefronts denser and more alike
+  uint32_t look4 = 4u;
+  if (const char* e = tuning_env("PIES_PAIR_LOOK_WAVES")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) look4 = static_cast<uint32_t>(v); }
+  look4 = std::min(look4, threads4 / 64u);
+  const dim3 level4(std::max<uint32_t>(1u, std::min<uint32_t>(cap4, (n + kQuadNodes * look4 - 1u) / (kQuadNodes * look4))));
   const dim3 levelRepeat4(std::max<uint32_t>(1u, std::min<uint32_t>(repeatCap, level4.x)));
   // the repeat's levels in one launch of resident workgroups (PIES_PAIR_REPEAT_LAUNCHES=1: captured level launches as in rounds 3-4)
   static const uint32_t residentRepeat = pair_repeat_blocks(-1);
@@ -1699,7 +1774,7 @@ uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArr
     } else {
       const uint32_t captured = repeat ? rounds + rounds / 2u : rounds;
       for (uint32_t r = 1; r <= captured; ++r) {
-        if (quads) hipLaunchKernelGGL(k_pair_round4, repeat ? levelRepeat4 : level4, dim3(threads4), 0, st, H, P, friction, staticThreshold, r, repeat);
+        if (quads) hipLaunchKernelGGL(k_pair_round4, repeat ? levelRepeat4 : level4, dim3(threads4), 0, st, H, P, friction, staticThreshold, r, repeat, look4);
         else hipLaunchKernelGGL(k_pair_round, repeat ? levelRepeat : level, dim3(kRoundBlock), 0, st, H, P, friction, staticThreshold, r, repeat);
         ++launches;
       }
