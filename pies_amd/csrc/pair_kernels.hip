@@ -1108,7 +1108,10 @@ __global__ void __launch_bounds__(kRoundBlock) k_pair_round4(HashArrays H, PairA
   }
   if (view.total == 0u) return;
   uint32_t hits = 0;
-  pair_level4(H, P, friction, staticThreshold, round, view, table, look, hits);
+  // as many looking wavefronts as it takes to give every workgroup of the launch one turn (a small frontier in chunks of 256 would
+  // leave most compute units idle: the levels 26-36 of a settled pass of config 4 took 20 us instead of 14)
+  const uint32_t need = (view.total + kQuadNodes * gridDim.x - 1u) / (kQuadNodes * gridDim.x);
+  pair_level4(H, P, friction, staticThreshold, round, view, table, min(look, max(need, 1u)), hits);
   count_hits(P, hits, lane);
 }
 
