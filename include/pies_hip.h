@@ -273,7 +273,7 @@ int pies_set_collision_rounds(pies_solver_t* s, uint32_t rounds);
  * product, 4 residual; default 3) / _WINDOW_SORT, PIES_CG_CHUNK_ROWS, PIES_PCG_NEVER_EXIT (profiling: every captured CG launch works),
  * PIES_REFERENCE_TURNS (0: the reference's node-node order as one sequential chain, 1: by turns whatever the size; default: by turns from
  * 1 024 nodes on), PIES_FALLBACK_VISITS (candidate tests a pass left to the sequential loop may cost before it latches: 1e9),
- * PIES_PAIR_QUADS (0: one lane per pair in the pair order's levels) / _QUAD_BLOCKS.  They take effect where the library reads them (pies_create, pies_finalize or the next graph capture).  pies_set_tuning must not
+ * PIES_PAIR_QUADS (0: one lane per pair in the pair order's levels) / _QUAD_BLOCKS / _QUAD_THREADS / PIES_PAIR_LOOK_WAVES (wavefronts of a level workgroup that look at frontier nodes, at most).  They take effect where the library reads them (pies_create, pies_finalize or the next graph capture).  pies_set_tuning must not
  * race with other API calls of the process (a handle reads the switches at different times of its life).  None of
  * them is read from the environment: the only environment variables the library looks at are PIES_SCHEDULE (default schedule
  * of new handles), PIES_PROFILER_SAFE (profiling runs) and the print-only PIES_PCG_DEBUG / PIES_LAYER_DEBUG. */

@@ -881,8 +881,9 @@ __global__ void __launch_bounds__(kRoundBlock) k_pair_round(HashArrays H, PairAr
 // instead of ~350 -, same operations on the same operands: the bits of visit().  A workgroup looks at 64 frontier nodes (its first
 // wavefront), the pairs taken go through LDS, and all four wavefronts run their visits.
 // Measured on BASELINE config 4: a settled frame 9.16 -> 8.76-8.9 ms (burst window 71.8 -> 73.0 substeps/s): a third of the
-// instructions in the slowest lane buys 4 % - a level (32 us) is its chain of dependent memory round trips (frontier, the two records,
-// the next list entries, the excursion and frontier atomics) and its kernel boundary, not the visits' issue slots.
+// instructions in the slowest lane bought 4 %, because the levels are bound by the NUMBER of wavefront instructions issued (per-level
+// counters: profiles/r05_levels_pmc_config4_before.txt), and a quad wavefront holds 16 pairs where a lane-per-pair one holds 64: what
+// pays is full wavefronts of quads with equal numbers of visits - the sorted table of pair_level4.
 PIES_DEV float quad_lane(float v, int j) {  // the value of lane j (0-3) of the lane's quad
   switch (j) {
     case 0: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x00, 0xf, 0xf, false));
@@ -1738,15 +1739,12 @@ uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArr
   if (const char* e = tuning_env("PIES_PAIR_QUADS")) quads = e[0] != '0';
   // threads of a level's workgroups (PIES_PAIR_QUAD_THREADS: 64, 128 or 256): a workgroup looks at 64 frontier nodes per turn of its
   // loop whatever its size, and as many workgroups as the chip holds at once take part (8 of 256 threads per compute unit).
-  // Measured on config 4 (burst / settled): 256: 75.6 / 109.9, 128: 68.8 / 102.0, 64: 63.4 / 94.3 - more, smaller workgroups put
-  // every chunk of a level in flight at once but run a chunk's pairs sixteen at a time; and requesting all of a pair's operands
-  // at once (the built-from positions, the excursions, the next list entries: one round trip instead of four) changed nothing
-  // (75.2 / 109.1): the heavy levels (45-59 us, levels 1-25 of ~36) are not their memory round trips but the visits' own chains -
-  // a pair shares up to eight cells and is visited that often from both sides, ~0.3 us of dependent square roots and correctly
-  // rounded divisions per visit - at eight wavefronts per SIMD.
+  // Measured on config 4 (burst / settled), before the table was sorted: 256: 75.6 / 109.9, 128: 68.8 / 102.0, 64: 63.4 / 94.3 - more,
+  // smaller workgroups put every chunk of a level in flight at once and were slower, and requesting all of a pair's operands at once
+  // (one round trip instead of four) changed nothing (75.2 / 109.1): a level is bound by VALU issue, not by its round trips.
   uint32_t threads4 = kRoundBlock;
   if (const char* e = tuning_env("PIES_PAIR_QUAD_THREADS")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) threads4 = static_cast<uint32_t>(v); }
-  uint32_t cap4 = 1024u * (kRoundBlock / threads4);  // (measured on config 4 with 256 threads, burst / settled substeps/s: 1 024: 70.8 / 98.1, 2 048: 73.0 / 101.4, 4 096: 69.9 / 100.3, 8 192: 65.1 / 96.0)
+  uint32_t cap4 = 1024u * (kRoundBlock / threads4);  // (measured on config 4 with 256 threads and the sorted table, burst / settled substeps/s: 512: 81 / 116, 768: 87 / 121, 1 024: 90 / 127, 1 536: 86 / 123, 2 048: 82 / 117)
   if (const char* e = tuning_env("PIES_PAIR_QUAD_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && v <= 65535) cap4 = static_cast<uint32_t>(v); }
   // wavefronts of a level's workgroup that look at frontier nodes, 64 each (PIES_PAIR_LOOK_WAVES: 1, 2 or 4): the pairs they take are
   // sorted by visits across the whole workgroup, so more of them make the visiting wavefronts denser and more alike
