@@ -926,7 +926,7 @@ constexpr uint32_t kQuadLookMax = 4;    // wavefronts of a workgroup that look (
 constexpr uint32_t kQuadBins = 9;       // pairs by visits per side: 8 and more ... 1, and the ones that do not overlap
 struct QuadTable {
   TakenPair taken[kQuadNodes * kQuadLookMax];
-  uint32_t bins[kQuadLookMax][kQuadBins];
+  uint32_t bins[64];  // [bin * look + wavefront] (9 x 4 used)
 };
 // one level by the workgroups of the calling launch (all threads of a workgroup call: barriers); T: the workgroup's LDS; look: the
 // wavefronts of the workgroup that look at frontier nodes (at most blockDim.x / 64)
@@ -944,7 +944,7 @@ PIES_DEV void pair_level4(const HashArrays& H, const PairArrays& P, float fricti
   for (uint32_t chunk = blockIdx.x; chunk * per < count; chunk += gridDim.x) {  // (workgroup uniform)
     // ---- who takes a pair: the first wavefronts look at the chunk's frontier nodes, 64 each
     bool take = false;
-    uint32_t x = 0, y = 0, key = 0;
+    uint32_t x = 0, y = 0, key = 0, rank = 0;
     uint4 rx = make_uint4(0u, 0u, 0u, 0u), ry = rx;
     if (static_cast<uint32_t>(wv) < look) {
       const uint32_t e = chunk * per + static_cast<uint32_t>(wv) * kQuadNodes + static_cast<uint32_t>(lane);
@@ -978,35 +978,33 @@ PIES_DEV void pair_level4(const HashArrays& H, const PairArrays& P, float fricti
           key = min(m, kQuadBins - 1u);
         }
       }
-      // (bin b of the table = key kQuadBins - 1 - b: descending)
+      // (bin b of the table = key kQuadBins - 1 - b: descending; the counts lie bin by bin, wavefront by wavefront: the table's order)
 #pragma unroll
       for (uint32_t b = 0; b < kQuadBins; ++b) {
-        const unsigned long long mk = __ballot(take && key == kQuadBins - 1u - b);
-        if (lane == 0) T.bins[wv][b] = static_cast<uint32_t>(__popcll(mk));
+        const bool mine = take && key == kQuadBins - 1u - b;
+        const unsigned long long mk = __ballot(mine);
+        if (mine) rank = static_cast<uint32_t>(__popcll(mk & ((1ull << lane) - 1ull)));
+        if (lane == 0) T.bins[b * look + static_cast<uint32_t>(wv)] = static_cast<uint32_t>(__popcll(mk));
       }
     }
     __syncthreads();
-    uint32_t total = 0, nOv = 0;  // pairs taken; the ones of them that overlap (they come first)
+    // a pair's place: the pairs of the bins before its own, its bin's pairs of the wavefronts before its own, the lanes before it -
+    // a prefix sum over the 9 x look counts, one per lane
+    uint32_t total, nOv;  // pairs taken; the ones of them that overlap (they come first)
     {
-      // a pair's place: the pairs of the bins before its own, its bin's pairs of the wavefronts before its own, the lanes before it
-      uint32_t at = 0;
-      const uint32_t myBin = kQuadBins - 1u - key;
+      const uint32_t cells = kQuadBins * look;
+      const uint32_t c = static_cast<uint32_t>(lane) < cells ? T.bins[lane] : 0u;
+      uint32_t incl = c;
 #pragma unroll
-      for (uint32_t b = 0; b < kQuadBins; ++b)
-        for (uint32_t w = 0; w < look; ++w) {
-          const uint32_t c = T.bins[w][b];
-          total += c;
-          if (b + 1u < kQuadBins) nOv += c;
-          if (b < myBin || (b == myBin && w < static_cast<uint32_t>(wv))) at += c;
-        }
-      if (static_cast<uint32_t>(wv) < look) {  // (wavefront uniform)
-#pragma unroll
-        for (uint32_t b = 0; b < kQuadBins; ++b) {
-          const bool mine = take && myBin == b;
-          const unsigned long long mb = __ballot(mine);
-          if (mine) taken[at + static_cast<uint32_t>(__popcll(mb & ((1ull << lane) - 1ull)))] = TakenPair{x, y, rx, ry};
-        }
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
       }
+      total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+      nOv = static_cast<uint32_t>(__shfl(incl, static_cast<int>((kQuadBins - 1u) * look - 1u), 64));
+      const uint32_t mine = (kQuadBins - 1u - key) * look + min(static_cast<uint32_t>(wv), look - 1u);
+      const uint32_t at = static_cast<uint32_t>(__shfl(incl - c, static_cast<int>(mine), 64));
+      if (take) taken[at + rank] = TakenPair{x, y, rx, ry};
     }
     __syncthreads();
     // the nodes of a wavefront's pairs that moved on and have entries left go to the sub-list their 64 places of the table are dealt
