@@ -70,6 +70,14 @@ PIES_DEV uint64_t pair_key(uint32_t i, uint32_t j, float pix, float piy, float p
   return (static_cast<uint64_t>(cls) << 58) | (k >> 6);
 }
 
+// the key of the pair {i, j} in either order of the arguments: ONE evaluation of pair_key on swapped operands (a wavefront's lanes
+// hold pairs of both orders: `i < j ? pair_key(i, j, ..) : pair_key(j, i, ..)` made it run both - ~150 instructions each, a quarter
+// of the list kernel's)
+PIES_DEV uint64_t pair_key_of(uint32_t i, uint32_t j, float pix, float piy, float piz, float pjx, float pjy, float pjz) {
+  const bool low = i < j;
+  return pair_key(low ? i : j, low ? j : i, low ? pix : pjx, low ? piy : pjy, low ? piz : pjz, low ? pjx : pix, low ? pjy : piy, low ? pjz : piz);
+}
+
 // The reference order by turns looks a node's range up from its LIVE position when its turn starts, so a node can be met in a cell its
 // partner was not inserted into when the lists were built.  The lists hold the pairs within reach that share a cell of the two INSERTED
 // ranges; the ranges cover [p - r - 0.5, p + r + 0.5] per axis (Solver.cpp:877-901), so two nodes whose inserted ranges share no cell
@@ -305,9 +313,10 @@ struct BuildLds {
   uint32_t rg[MAXC];                                 // (min cell - group cell + 1) per axis, 2 bits each; (length - 1) per axis from bit 8
   uint16_t own[MAXOWN];                              // candidates that are the group's own nodes
   uint32_t ncand, nown, spill;
+  uint32_t looked[8];                                // candidates in the cells of a range of (1 or 2) x (1 or 2) x (1 or 2) cells from the group's cell
   uint64_t lk[kBuildWaves][MAXD];                    // one node's partners: pair key
   uint32_t le[kBuildWaves][MAXD];                    //                     partner | (shared cells - 1) << 28
-  uint16_t near[kBuildWaves][MAXD];                  // table slots of the candidates within reach of the node (first sweep)
+  uint16_t near[kBuildWaves][2][MAXD];               // table slots of the candidates within reach of the wavefront's two nodes (first sweep)
 };
 
 // cells two ranges share on one axis: [a0, a0 + la) and [b0, b0 + lb)
@@ -325,7 +334,7 @@ PIES_DEV uint32_t push_partners(uint64_t* lk, uint32_t* le, uint32_t d, bool acc
     const uint32_t at = d + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
     if (at < MAXD) {
       // (the reference order by turns walks a node's partners in ascending index: the partner's index is the key)
-      lk[at] = byIndex ? static_cast<uint64_t>(j) : i < j ? pair_key(i, j, pix, piy, piz, pjx, pjy, pjz) : pair_key(j, i, pjx, pjy, pjz, pix, piy, piz);
+      lk[at] = byIndex ? static_cast<uint64_t>(j) : pair_key_of(i, j, pix, piy, piz, pjx, pjy, pjz);
       le[at] = j | ((m - 1u) << 28);
     }
   }
@@ -404,6 +413,13 @@ __global__ void __launch_bounds__(64 * kBuildWaves) k_pair_build(HashArrays H, P
     const uint32_t cStart[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
     const uint32_t cCnt[8] = {d2.x & 0xffffu, d2.x >> 16, d2.y & 0xffffu, d2.y >> 16, d2.z & 0xffffu, d2.z >> 16, d2.w & 0xffffu, d2.w >> 16};
     if (threadIdx.x == 0) { L.ncand = 0; L.nown = 0; L.spill = 0; }
+    if (threadIdx.x < 8u) {  // (statistics: what the reference's loop would look at for a node of this group, by the lengths of its range)
+      uint32_t sum = 0;
+#pragma unroll
+      for (uint32_t c = 0; c < 8u; ++c)
+        if ((c & ~threadIdx.x) == 0u) sum += cCnt[c];
+      L.looked[threadIdx.x] = sum;
+    }
     __syncthreads();
     // ---- the distinct nodes of the eight buckets, each from its canonical cell; the group's own nodes.  Cells are dealt to the
     // wavefronts; a wavefront reserves a run of the table per 64 entries (the order of the table does not matter)
@@ -507,46 +523,68 @@ __global__ void __launch_bounds__(64 * kBuildWaves) k_pair_build(HashArrays H, P
       L.px[t] = p.x; L.py[t] = p.y; L.pz[t] = p.z; L.rs[t] = p.w;
     }
     __syncthreads();
-    for (uint32_t o = wv; o < nown; o += kBuildWaves) {
-      const uint32_t si = L.own[o];
-      const uint32_t i = L.id[si];
-      const float pix = L.px[si], piy = L.py[si], piz = L.pz[si], rsi = L.rs[si];
-      const uint32_t rgi = L.rg[si];
-      const uint32_t lxi = ((rgi >> 8) & 63u) + 1u, lyi = ((rgi >> 14) & 63u) + 1u, lzi = ((rgi >> 20) & 63u) + 1u;
-      // the candidates the reference's loop would look at for this node (statistics: SURVEY 8d counts 16 B for each)
-      uint32_t looked = 0;
-      for (uint32_t dx = 0; dx < lxi; ++dx)
-        for (uint32_t dy = 0; dy < lyi; ++dy)
-          for (uint32_t dz = 0; dz < lzi; ++dz) looked += cCnt[(dx * 4 + dy * 2 + dz) & 7u];
-      // Two sweeps.  The first one is the distance test alone over all ~300 candidates and leaves the slots of the ~25 within reach
-      // in LDS; the second one - shared cells and the pair key, 60 % of the instructions of a candidate round - runs over those
-      // only, usually one round instead of five (with one sweep a round paid for the key as soon as one of its lanes passed).
-      uint16_t* near = L.near[wv];
-      uint32_t nn = 0;
-      for (uint32_t base = 0; base < ncand; base += 64) {
-        const uint32_t t = base + static_cast<uint32_t>(lane);
-        bool reach = false;
-        if (t < ncand && t != si) {
-          const float ddx = L.px[t] - pix, ddy = L.py[t] - piy, ddz = L.pz[t] - piz;
-          const float cut = 1.001f * (rsi + L.rs[t]);  // (wide for a node that left its slack in the first attempt)
-          reach = !(ddx * ddx + ddy * ddy + ddz * ddz >= cut * cut);
+    // Two own nodes per turn of a wavefront.  The first sweep - the distance test over all ~300 candidates - runs node after node
+    // with all 64 lanes and leaves the slots of the ~25 within reach in LDS; when both nodes have at most 32 of them (nearly
+    // always) the second sweep - shared cells and the pair key, 60 % of the instructions of a candidate round - and the rank sort
+    // run for both at once, a half of the wavefront each: the kernel is bound by VALU issue (~350 wavefront instructions per
+    // node) and these two parts kept 25 and 11 of 64 lanes busy.
+    bool stop = false;
+    for (uint32_t o = 2u * static_cast<uint32_t>(wv); o < nown && !stop; o += 2u * kBuildWaves) {
+      const bool haveB = o + 1u < nown;
+      uint32_t nnAB[2] = {0u, 0u};
+      for (uint32_t h = 0; h < (haveB ? 2u : 1u); ++h) {  // ---- first sweep
+        const uint32_t si = L.own[o + h];
+        const float pix = L.px[si], piy = L.py[si], piz = L.pz[si], rsi = L.rs[si];
+        uint16_t* near = L.near[wv][h];
+        // a lane keeps the rounds in which its candidate was within reach as bits and the slots are compacted once at the end (a
+        // ballot, two bit counts and a bounds test per round were two thirds of a round's instructions); up to 32 rounds (MAXC <= 2048)
+        uint32_t bits = 0;
+        for (uint32_t base = 0, r = 0; base < ncand; base += 64, ++r) {
+          const uint32_t t = base + static_cast<uint32_t>(lane);
+          if (t < ncand && t != si) {
+            const float ddx = L.px[t] - pix, ddy = L.py[t] - piy, ddz = L.pz[t] - piz;
+            const float cut = 1.001f * (rsi + L.rs[t]);  // (wide for a node that left its slack in the first attempt)
+            if (!(ddx * ddx + ddy * ddy + ddz * ddz >= cut * cut)) bits |= 1u << r;
+          }
         }
-        const unsigned long long mask = __ballot(reach);
-        if (reach) {
-          const uint32_t at = nn + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
-          if (at < MAXD) near[at] = static_cast<uint16_t>(t);
+        const uint32_t mine = static_cast<uint32_t>(__popc(bits));
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t up = __shfl_up(incl, off, 64);
+          if (lane >= off) incl += up;
         }
-        nn += static_cast<uint32_t>(__popcll(mask));
+        const uint32_t nn = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+        uint32_t at = incl - mine;
+        while (bits) {
+          const uint32_t r = static_cast<uint32_t>(__builtin_ctz(bits));
+          bits &= bits - 1u;
+          if (at < MAXD) near[at] = static_cast<uint16_t>(r * 64u + static_cast<uint32_t>(lane));
+          ++at;
+        }
+        nnAB[h] = nn;
       }
       __builtin_amdgcn_wave_barrier();
-      uint32_t d = nn > MAXD ? MAXD + 1u : 0u;  // (more within reach than a list holds: handled below like a list that is too long)
-      for (uint32_t base = 0; base < nn && nn <= MAXD; base += 64) {
-        const uint32_t e = base + static_cast<uint32_t>(lane);
+      // the candidates the reference's loop would look at for a node (statistics: SURVEY 8d counts 16 B for each): the cells
+      // (dx, dy, dz) below its range's lengths, from the group's table (a loop over cCnt[] here cost 150-260 instructions per node)
+      auto looked_of = [&](uint32_t rgi) { return L.looked[(((rgi >> 8) & 1u) << 2) | (((rgi >> 14) & 1u) << 1) | ((rgi >> 20) & 1u)]; };
+      if (!BIG && haveB && nnAB[0] <= 32u && nnAB[1] <= 32u && P.byIndex == 0u) {
+        // ---- second sweep and lists of both nodes, a half of the wavefront each
+        const uint32_t h = static_cast<uint32_t>(lane) >> 5, hl = static_cast<uint32_t>(lane) & 31u;
+        const unsigned long long halfMask = 0xffffffffull << (32u * h);
+        const uint32_t si = L.own[o + h];
+        const uint32_t i = L.id[si];
+        const float pix = L.px[si], piy = L.py[si], piz = L.pz[si];
+        const uint32_t rgi = L.rg[si];
+        const uint32_t lxi = ((rgi >> 8) & 63u) + 1u, lyi = ((rgi >> 14) & 63u) + 1u, lzi = ((rgi >> 20) & 63u) + 1u;
+        const uint32_t nn = h ? nnAB[1] : nnAB[0];
+        uint64_t* lkh = lk + h * (MAXD / 2u);
+        uint32_t* leh = le + h * (MAXD / 2u);
         bool accept = false;
         uint32_t j = 0, m = 0;
         float pjx = 0.f, pjy = 0.f, pjz = 0.f;
-        if (e < nn) {
-          const uint32_t t = near[e];
+        if (hl < nn) {
+          const uint32_t t = L.near[wv][h][hl];
           pjx = L.px[t]; pjy = L.py[t]; pjz = L.pz[t];
           j = L.id[t];
           const uint32_t rgj = L.rg[t];
@@ -555,17 +593,87 @@ __global__ void __launch_bounds__(64 * kBuildWaves) k_pair_build(HashArrays H, P
               shared_cells(0, lzi, static_cast<int>((rgj >> 4) & 3u) - 1, ((rgj >> 20) & 63u) + 1u);
           accept = m != 0u;
         }
-        d = push_partners<MAXD>(lk, le, d, accept, i, j, m, pix, piy, piz, pjx, pjy, pjz, lane, P.byIndex != 0u);
+        const unsigned long long am = __ballot(accept) & halfMask;
+        const uint32_t d = static_cast<uint32_t>(__popcll(am));
+        if (accept) {
+          const uint32_t at = static_cast<uint32_t>(__popcll(am & ((1ull << lane) - 1ull)));
+          lkh[at] = pair_key_of(i, j, pix, piy, piz, pjx, pjy, pjz);
+          leh[at] = j | ((m - 1u) << 28);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // storage from a pool (a full pool passes the node on to the next one, like write_list)
+        uint32_t poolH = pool, at = 0;
+        bool placed = false, failed = false;
+        for (uint32_t tries = 0; tries < kPairPools; ++tries) {
+          uint32_t got = 0;
+          if (!placed && hl == 0u && d) got = atomicAdd(&P.pool[poolH * kPairPad], d);
+          got = static_cast<uint32_t>(__shfl(static_cast<int>(got), static_cast<int>(32u * h), 64));
+          if (!placed) {
+            if (got + d <= P.poolCap) { at = got; placed = true; }
+            else if (tries + 1u == kPairPools) { failed = true; placed = true; }
+            else poolH = (poolH + 1u) % kPairPools;
+          }
+          if (__ballot(!placed) == 0ull) break;
+        }
+        if (failed && hl == 0u) atomicOr(&P.ctl[kPairFlags], 2u);  // (the node keeps an empty list: flagged, the pass goes to the sequential loop)
+        const uint32_t off = poolH * P.poolCap + at;
+        uint32_t firstEntry = 0;
+        bool haveFirst = false;
+        const uint32_t dMax = max(static_cast<uint32_t>(__shfl(static_cast<int>(d), 0, 64)), static_cast<uint32_t>(__shfl(static_cast<int>(d), 32, 64)));
+        if (!failed) {
+          const uint64_t k = hl < d ? lkh[hl] : 0ull;
+          uint32_t rank = 0;
+          for (uint32_t f = 0; f < dMax; ++f) rank += (f < d && lkh[min(f, MAXD / 2u - 1u)] < k) ? 1u : 0u;
+          if (hl < d) {
+            const uint32_t v = leh[hl];
+            P.nbr[off + rank] = v;
+            if (rank == 0u) { firstEntry = v; haveFirst = true; }
+          }
+        }
+        const unsigned long long who = __ballot(haveFirst) & halfMask;
+        const uint32_t v0 = static_cast<uint32_t>(__shfl(static_cast<int>(firstEntry), who ? __builtin_ctzll(who) : 0, 64));
+        if (hl == 0u && !failed) store_rec(P.node, i, make_uint4(off, d, 0u, who ? v0 : 0u));
+        __builtin_amdgcn_wave_barrier();
+        tested += looked_of(L.rg[L.own[o]]) + looked_of(L.rg[L.own[o + 1u]]);
+        edges += static_cast<uint32_t>(__shfl(static_cast<int>(d), 0, 64)) + static_cast<uint32_t>(__shfl(static_cast<int>(d), 32, 64));
+        continue;
       }
-      __builtin_amdgcn_wave_barrier();
-      if (d > MAXD) {
-        if (!BIG) { if (lane == 0) L.spill = 1; break; }  // (the large kernel redoes the group; lists written so far are replaced)
-        if (lane == 0) atomicOr(&P.ctl[kPairFlags], 2u);  // a pile-up beyond anything a simulation survives: latch
-        d = MAXD;
+      for (uint32_t h = 0; h < (haveB ? 2u : 1u) && !stop; ++h) {  // ---- a node at a time (long lists, the large kernel, the order by turns)
+        const uint32_t si = L.own[o + h];
+        const uint32_t i = L.id[si];
+        const float pix = L.px[si], piy = L.py[si], piz = L.pz[si];
+        const uint32_t rgi = L.rg[si];
+        const uint32_t lxi = ((rgi >> 8) & 63u) + 1u, lyi = ((rgi >> 14) & 63u) + 1u, lzi = ((rgi >> 20) & 63u) + 1u;
+        const uint16_t* near = L.near[wv][h];
+        const uint32_t nn = nnAB[h];
+        uint32_t d = nn > MAXD ? MAXD + 1u : 0u;  // (more within reach than a list holds: handled below like a list that is too long)
+        for (uint32_t base = 0; base < nn && nn <= MAXD; base += 64) {
+          const uint32_t e = base + static_cast<uint32_t>(lane);
+          bool accept = false;
+          uint32_t j = 0, m = 0;
+          float pjx = 0.f, pjy = 0.f, pjz = 0.f;
+          if (e < nn) {
+            const uint32_t t = near[e];
+            pjx = L.px[t]; pjy = L.py[t]; pjz = L.pz[t];
+            j = L.id[t];
+            const uint32_t rgj = L.rg[t];
+            m = shared_cells(0, lxi, static_cast<int>(rgj & 3u) - 1, ((rgj >> 8) & 63u) + 1u) *
+                shared_cells(0, lyi, static_cast<int>((rgj >> 2) & 3u) - 1, ((rgj >> 14) & 63u) + 1u) *
+                shared_cells(0, lzi, static_cast<int>((rgj >> 4) & 3u) - 1, ((rgj >> 20) & 63u) + 1u);
+            accept = m != 0u;
+          }
+          d = push_partners<MAXD>(lk, le, d, accept, i, j, m, pix, piy, piz, pjx, pjy, pjz, lane, P.byIndex != 0u);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (d > MAXD) {
+          if (!BIG) { if (lane == 0) L.spill = 1; stop = true; break; }  // (the large kernel redoes the group; lists written so far are replaced)
+          if (lane == 0) atomicOr(&P.ctl[kPairFlags], 2u);  // a pile-up beyond anything a simulation survives: latch
+          d = MAXD;
+        }
+        tested += looked_of(rgi);
+        write_list(P, lk, le, i, d, pool, lane);
+        edges += d;
       }
-      tested += looked;
-      write_list(P, lk, le, i, d, pool, lane);
-      edges += d;
     }
     __syncthreads();  // (the table is reused by the next group)
     if (!BIG && L.spill) {
@@ -635,7 +743,7 @@ __global__ void __launch_bounds__(64) k_pair_build_wide(HashArrays H, PairArrays
             if (accept) {
               const uint32_t at = d + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
               if (at < kMaxDeg) {
-                L.lk[at] = P.byIndex ? static_cast<uint64_t>(j) : i < j ? pair_key(i, j, pi.x, pi.y, pi.z, pj.x, pj.y, pj.z) : pair_key(j, i, pj.x, pj.y, pj.z, pi.x, pi.y, pi.z);
+                L.lk[at] = P.byIndex ? static_cast<uint64_t>(j) : pair_key_of(i, j, pi.x, pi.y, pi.z, pj.x, pj.y, pj.z);
                 L.le[at] = j;
                 L.lm[at] = m;
               }
