@@ -20,6 +20,8 @@ p, v = bench.config4_particles()
 g = capi.Solver(scenes.pbd_options(capi, 4), device=0)
 g.addNodes(p)
 g.set_velocities(v)
+if os.environ.get("PROBE_ROUNDS"):
+    g.set_collision_rounds(int(os.environ["PROBE_ROUNDS"]))  # (pins the captured level launches)
 g.finalize()
 g.tick_async(2)
 g.synchronize()
