@@ -387,6 +387,36 @@ def test_resolve_variants_agree(pies, monkeypatch, tune):
         assert alt[3] == (84 if name == "PIES_COLLIDE_PASSES" else 6)
 
 
+def test_pair_level_variants_agree(pies, monkeypatch, tune):
+    """(pair order) The level launches exist in several shapes - one lane or four per pair, workgroups of 64 / 128 / 256 threads, one
+    to four of their wavefronts looking at frontier nodes with the taken pairs sorted by their visits across the workgroup, the
+    repeat's levels as one launch or as captured launches, few workgroups (several turns of the loop each).  They run the same
+    visits in the same order of conflicting pairs: identical results, bit for bit (30 000 particles: a level's frontier is tens of
+    thousands of nodes in the first rounds and a handful in the last)."""
+    p, v = particles((30, 25, 40), jitter=0.08)
+
+    def run():
+        g = pies.Solver(scenes.pbd_options(pies, 3))
+        g.addNodes(p)
+        g.set_velocities(v)
+        g.tick(2)
+        assert not g.failed
+        return g.positions, g.velocities, g.collision_pairs
+    ref = run()
+    assert ref[2] > 50_000
+    variants = [{"PIES_PAIR_QUADS": "0"}, {"PIES_PAIR_LOOK_WAVES": "1"}, {"PIES_PAIR_LOOK_WAVES": "2"},
+                {"PIES_PAIR_QUAD_THREADS": "64"}, {"PIES_PAIR_QUAD_THREADS": "128", "PIES_PAIR_LOOK_WAVES": "2"},
+                {"PIES_PAIR_QUAD_BLOCKS": "7"}, {"PIES_PAIR_QUAD_BLOCKS": "3", "PIES_PAIR_LOOK_WAVES": "4"},
+                {"PIES_PAIR_REPEAT_LAUNCHES": "1"}]
+    for var in variants:
+        for name, value in var.items():
+            tune(name, value)
+        alt = run()
+        for name in var:
+            tune(name, None)
+        assert np.array_equal(ref[0], alt[0]) and np.array_equal(ref[1], alt[1]) and ref[2] == alt[2], var
+
+
 @RULES
 def test_distant_clusters_use_wide_keys(pies, oracle, rule):
     """The sort key packs the cell coordinates relative to the bounding box of all ranges: two clusters 300 000 apart on
