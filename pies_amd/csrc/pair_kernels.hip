@@ -1265,7 +1265,8 @@ __global__ void __launch_bounds__(kRoundBlock) k_pair_repeat(HashArrays H, PairA
       __hip_atomic_store(&P.frCount[(((round + 2u) % 3u) * kPairLists + static_cast<uint32_t>(lane)) * kPairPad], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (lane == 0) P.ctl[kPairRounds] = round;
     }
-    pair_level4(H, P, friction, staticThreshold, round, view, table, 1u, hits);
+    const uint32_t need = (view.total + kQuadNodes * gridDim.x - 1u) / (kQuadNodes * gridDim.x);  // (looking wavefronts: as in k_pair_round4)
+    pair_level4(H, P, friction, staticThreshold, round, view, table, min(kQuadLookMax, max(need, 1u)), hits);
     if (!pair_grid_barrier(P.ctl + kPairBarrier, gridDim.x, passed)) {
       if (threadIdx.x == 0) atomicOr(&P.ctl[kPairFlags], 2u);
       break;
