@@ -387,8 +387,11 @@ PIES_DEV void write_list(const PairArrays& P, const uint64_t* lk, const uint32_t
 }
 
 // BIG: the groups the small kernel passed on (and, beyond MAXC candidates, node by node straight from the buckets)
+// (The small instance asks for six wavefronts per SIMD: with two nodes per wavefront it took 100 registers - four wavefronts per
+// SIMD, eight groups in flight per compute unit instead of twelve - and the third fewer instructions bought 10 %; at 80 registers
+// and 11 spilled words config 4 went 95 / 137 -> 100 / 143.  The level kernel at the same setting was slower: 94 / 136.)
 template <uint32_t MAXC, uint32_t MAXD, uint32_t MAXOWN, bool BIG>
-__global__ void __launch_bounds__(64 * kBuildWaves) k_pair_build(HashArrays H, PairArrays P, uint32_t repeat) {
+__global__ void __launch_bounds__(64 * kBuildWaves, BIG ? 1 : 6) k_pair_build(HashArrays H, PairArrays P, uint32_t repeat) {
   __shared__ BuildLds<MAXC, MAXD, MAXOWN> L;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (repeat && !P.ctl[kPairRetry]) return;
