@@ -207,6 +207,8 @@ __global__ void __launch_bounds__(kBlock) k_pair_save(HashArrays H, PairArrays P
     P.ctl[kPairGroups] = 0;
     P.ctl[kPairSpilled] = 0;
     P.ctl[kPairFallback] = 0;
+    P.ctl[kPairBarrier] = 0;  // (the grid barrier of the levels behind the captured launches: counter, abort word)
+    P.ctl[kPairBarrier + 1] = 0;
   }
   if (i < kPairPools) P.pool[i * kPairPad] = 0;
   if (i < 3u * kPairLists) P.frCount[i * kPairPad] = 0;
@@ -1255,18 +1257,24 @@ PIES_DEV bool pair_grid_barrier(uint32_t* counter, uint32_t nblocks, uint32_t& p
   ++passed;
   return sOk != 0u;
 }
-__global__ void __launch_bounds__(kRoundBlock) k_pair_repeat(HashArrays H, PairArrays P, float friction, float staticThreshold) {
+// (repeat = 0: the same launch as the TAIL of the first attempt - whatever levels are left behind the captured launches, from
+// `firstRound` on.  Until round 5 that was one workgroup (k_pair_tail): a pass deeper than the captured count - the first ticks of a
+// scene, a pile that forms between two looks of the host - ran its surplus levels on one compute unit, ten times slower than the
+// launches (config 4 pinned at 48 captured levels: 8 substeps/s instead of 100).)
+__global__ void __launch_bounds__(kRoundBlock) k_pair_repeat(HashArrays H, PairArrays P, float friction, float staticThreshold, uint32_t firstRound,
+                                                             uint32_t repeat) {
   __shared__ QuadTable table;
-  if (!P.ctl[kPairRetry]) return;
+  if (repeat && !P.ctl[kPairRetry]) return;
+  if (!repeat && P.ctl[kPairRetry]) return;
   if (H.counters[kCounterFlags]) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   uint32_t hits = 0, passed = 0;
-  for (uint32_t round = 1;; ++round) {
+  for (uint32_t round = firstRound;; ++round) {
     const FrontierView view = frontier_view(P, round, lane);
     if (view.total == 0u) break;  // (the same words in every workgroup: all leave together)
     if (blockIdx.x == 0 && wv == 0) {
       __hip_atomic_store(&P.frCount[(((round + 2u) % 3u) * kPairLists + static_cast<uint32_t>(lane)) * kPairPad], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (lane == 0) P.ctl[kPairRounds] = round;
+      if (lane == 0) { P.ctl[kPairRounds] = round; if (!repeat && round > P.ctl[kPairDeepest]) P.ctl[kPairDeepest] = round; }
     }
     const uint32_t need = (view.total + kQuadNodes * gridDim.x - 1u) / (kQuadNodes * gridDim.x);  // (looking wavefronts: as in k_pair_round4)
     pair_level4(H, P, friction, staticThreshold, round, view, table, min(kQuadLookMax, max(need, 1u)), hits);
@@ -1881,7 +1889,13 @@ uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArr
     // (the repeat lists more partners and runs deeper: half as many launches again; they return at once - 2.5 us each - when
     // nothing is repeated)
     if (repeat && quads && repeatBlocks) {  // the repeat's levels: one launch (k_pair_repeat runs until the frontier is empty)
-      hipLaunchKernelGGL(k_pair_repeat, dim3(repeatBlocks), dim3(kRoundBlock), 0, st, H, P, friction, staticThreshold); ++launches;
+      hipLaunchKernelGGL(k_pair_repeat, dim3(repeatBlocks), dim3(kRoundBlock), 0, st, H, P, friction, staticThreshold, 1u, 1u); ++launches;
+    } else if (quads && repeatBlocks) {  // the first attempt: captured level launches, then whatever is left in one launch of resident workgroups
+      for (uint32_t r = 1; r <= rounds; ++r) {
+        hipLaunchKernelGGL(k_pair_round4, level4, dim3(threads4), 0, st, H, P, friction, staticThreshold, r, 0u, look4);
+        ++launches;
+      }
+      hipLaunchKernelGGL(k_pair_repeat, dim3(repeatBlocks), dim3(kRoundBlock), 0, st, H, P, friction, staticThreshold, rounds + 1u, 0u); ++launches;
     } else {
       const uint32_t captured = repeat ? rounds + rounds / 2u : rounds;
       for (uint32_t r = 1; r <= captured; ++r) {
