@@ -74,8 +74,8 @@ def main(rnd, srcname=None):
                                                           "%.0f" % t if t is not None else "-"))
         if w == "config4":
             lines.append("(the first six ticks = the burst.  Under the profiler the library does not re-capture its graph, so the captured level")
-            lines.append(" launches stay at their initial count and the burst's deeper passes are finished by the single-workgroup k_pair_tail - an")
-            lines.append(" artefact of PIES_PROFILER_SAFE, as is the share of k_pair_repeat (two repeated passes in 24); the settled state, level by")
+            lines.append(" launches stay at their initial count and the burst's deeper passes are finished behind the grid barrier of k_pair_repeat -")
+            lines.append(" an artefact of PIES_PROFILER_SAFE (in a run the host re-captures with the deepest pass + 8 launches); the settled state, level by")
             lines.append(" level: %s_settled_config4.txt, %s_levels_pmc_config4.txt, %s_build_pmc_config4.txt)" % (rnd, rnd, rnd))
         lines.append("")
     with open(os.path.join(dst, "%s_pmc_traffic.json" % rnd), "w") as f:
