@@ -1795,6 +1795,45 @@ __global__ void __launch_bounds__(1024) k_turn_tail(HashArrays H, PairArrays P, 
   if (lane == 0 && hits) atomicAdd(&P.hitStripe[(static_cast<uint32_t>(wv) % kPairStripes) * kPairPad], hits);
 }
 
+// The same with resident workgroups and a grid barrier between the levels (k_pair_repeat's): a pass deeper than the captured launches
+// no longer finishes on one compute unit, and a repeated pass runs here whole.
+__global__ void __launch_bounds__(kTurnBlock) k_turn_finish(HashArrays H, PairArrays P, float scale, float friction, float staticThreshold, uint32_t round,
+                                                            uint32_t repeat) {
+  if (repeat && !P.ctl[kPairRetry]) return;
+  if (!repeat && P.ctl[kPairRetry]) return;
+  if (H.counters[kCounterFlags]) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t wavesPerGrid = gridDim.x * (kTurnBlock / 64u);
+  uint32_t hits = 0, passed = 0;
+  for (;; ++round) {
+    const FrontierView view = frontier_view(P, round, lane);
+    if (view.total == 0u) break;  // (the same words in every workgroup: all leave together)
+    if (blockIdx.x == 0 && wv == 0) {
+      __hip_atomic_store(&P.frCount[(((round + 2u) % 3u) * kPairLists + static_cast<uint32_t>(lane)) * kPairPad], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) { P.ctl[kPairRounds] = round - 1u; if (!repeat && round - 1u > P.ctl[kPairDeepest]) P.ctl[kPairDeepest] = round - 1u; }
+    }
+    uint32_t* next = P.fr[(round + 1u) & 1u];
+    uint32_t* nextCount = P.frCount + ((round + 1u) % 3u) * kPairLists * kPairPad;
+    for (uint32_t e = blockIdx.x * (kTurnBlock / 64u) + static_cast<uint32_t>(wv); e < view.total; e += wavesPerGrid) {  // (wavefront uniform)
+      const uint32_t i = frontier_node(P, view, round, e);
+      hits += run_turn(H, P, i, scale, friction, staticThreshold, next, nextCount, e % kPairLists, lane);
+    }
+    if (!pair_grid_barrier(P.ctl + kPairBarrier, gridDim.x, passed)) {
+      if (threadIdx.x == 0) atomicOr(&P.ctl[kPairFlags], 2u);
+      break;
+    }
+  }
+  if (lane == 0 && hits) atomicAdd(&P.hitStripe[((blockIdx.x * (kTurnBlock / 64u) + static_cast<uint32_t>(wv)) % kPairStripes) * kPairPad], hits);
+}
+uint32_t turn_finish_blocks(int device) {
+  int perCu = 0, dev = device;
+  hipDeviceProp_t prop;
+  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_turn_finish, kTurnBlock, 0) != hipSuccess) return 0;
+  return static_cast<uint32_t>(std::max(0, perCu)) * static_cast<uint32_t>(std::max(0, prop.multiProcessorCount)) / 2u;
+}
+
 uint32_t launch_collide_turns(hipStream_t st, const HashArrays& H, const PairArrays& Pin, const NodeArrays& nd, float gridSpacing, float friction,
                               float staticThreshold, uint32_t rounds) {
   if (nd.n == 0) return 0;
@@ -1819,11 +1858,18 @@ uint32_t launch_collide_turns(hipStream_t st, const HashArrays& H, const PairArr
     }
     hipLaunchKernelGGL(k_turn_first, perNode, dim3(kBlock), 0, st, H, P, repeat); ++launches;
     // (a repeated pass - rare: a node left its slack and an unlisted pair may have touched - runs all its levels in the tail kernel)
-    const uint32_t captured = repeat ? 0u : rounds;
+    // PIES_TURN_LEVEL_LAUNCHES=0: no captured level launches at all - every level behind the grid barrier
+    uint32_t captured = repeat ? 0u : rounds;
+    if (const char* e = tuning_env("PIES_TURN_LEVEL_LAUNCHES"); e && e[0] == '0') captured = 0u;
     for (uint32_t r = 2; r < 2u + captured; ++r) {
       hipLaunchKernelGGL(k_turn_round, level, dim3(kTurnBlock), 0, st, H, P, gridSpacing, friction, staticThreshold, r, repeat); ++launches;
     }
-    hipLaunchKernelGGL(k_turn_tail, dim3(1), dim3(1024), 0, st, H, P, gridSpacing, friction, staticThreshold, 2u + captured, repeat); ++launches;
+    static const uint32_t residentFinish = turn_finish_blocks(-1);
+    uint32_t finishCap = 128u;  // PIES_TURN_FINISH_BLOCKS: workgroups behind the grid barrier (a level of config 4 holds ~460 turns, one wavefront each; measured with every level behind the barrier: 512 workgroups 293 ms per tick, 128: 217, 64: 284 - captured launches: 160-172)
+    if (const char* e = tuning_env("PIES_TURN_FINISH_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) finishCap = static_cast<uint32_t>(v); }
+    const uint32_t finishBlocks = std::min<uint32_t>(std::min<uint32_t>(finishCap, residentFinish), level.x);
+    if (finishBlocks) { hipLaunchKernelGGL(k_turn_finish, dim3(finishBlocks), dim3(kTurnBlock), 0, st, H, P, gridSpacing, friction, staticThreshold, 2u + captured, repeat); ++launches; }
+    else { hipLaunchKernelGGL(k_turn_tail, dim3(1), dim3(1024), 0, st, H, P, gridSpacing, friction, staticThreshold, 2u + captured, repeat); ++launches; }
     hipLaunchKernelGGL(k_pair_verify, dim3(64), dim3(kBlock), 0, st, H, P, repeat, gridSpacing); ++launches;
     hipLaunchKernelGGL(k_pair_check, perNode, dim3(kBlock), 0, st, H, P, nd.pos, nd.vel, repeat ? 0u : 1u); ++launches;
     if (!repeat) { hipLaunchKernelGGL(k_pair_arm, dim3(1), dim3(64), 0, st, H, P); ++launches; }
