@@ -1647,6 +1647,12 @@ PIES_DEV uint32_t run_turn(const HashArrays& H, const PairArrays& P, uint32_t i,
     const uint32_t j = have ? P.nbr[off + lane] & kPairNodeMask : 0u;
     NodeState b = have ? load_node(node, j) : NodeState{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int4 rgj = have ? H.rng[j] : make_int4(0, 0, 0, 0);
+    // (the build-time positions and the excursions so far of the members, for the bookkeeping behind the turn: requested now -
+    // behind the turn a load and a returning atomic were two more dependent round trips; a member belongs to this turn alone
+    // for the whole level, so its excursion is read and written plainly)
+    const uint32_t mj0 = have ? j : i;
+    const float4 p0m = static_cast<uint32_t>(lane) <= d ? node[4u * mj0 + 2u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t excm = static_cast<uint32_t>(lane) <= d ? P.exc[mj0] : 0u;
     // what the members need when the turn is over - their records (the same cache line as their state) and the nodes whose turns
     // their NEXT events are - is requested now, beside the states: behind the turn these would be two more dependent round trips
     const bool member = static_cast<uint32_t>(lane) <= d;
@@ -1661,11 +1667,11 @@ PIES_DEV uint32_t run_turn(const HashArrays& H, const PairArrays& P, uint32_t i,
     }
     if (bMoved) {
       store_node(node, j, b);
-      note_excursion(P, j, b, node[4u * j + 2u]);
+      note_excursion_owned(P, j, b, p0m, excm);
     }
-    if (aMoved && lane == 0) {
+    if (aMoved && static_cast<uint32_t>(lane) == d) {  // (lane d holds the node's own build-time position and excursion)
       store_node(node, i, a);
-      note_excursion(P, i, a, node[4u * i + 2u]);
+      note_excursion_owned(P, i, a, p0m, excm);
     }
     // every member moves on to its next event; a node whose turn has all its members waiting for it goes to the next frontier
     uint32_t ready = kTurnDone;
