@@ -1107,7 +1107,9 @@ PIES_DEV void levels_by_node_owners(const TriArrays& T, uint32_t* heads32, uint3
       // (a node that consumed nothing since the last refill has its four requested entries already: a node of a 28k-contact
       // patch moves on in one round of ten, and 16 uncoalesced requests per thread every four rounds - 16 000 from ONE compute
       // unit - cost a sixth of the kernel: 1 063 -> 887 us for the 610 levels of that patch.  Fewer owning threads with more
-      // nodes each are slower: 512 threads 1 126 us, 256 threads 2 906 us.)
+      // nodes each are slower: 512 threads 1 126 us, 256 threads 2 906 us.  ONE barrier per round instead of two - two copies of the
+      // counters, a round reads one and adds to the other, the copy it read gets the addition a round later - is slower too: 938 us:
+      // a round is its LDS operations and its ~150 instructions per wavefront, sixteen wavefronts on one compute unit.)
       if (s != 0u) {
 #pragma unroll
         for (uint32_t i = 0; i < 4; ++i) pend[j][i] = entry_at(j, k[j] + 5u + i);
