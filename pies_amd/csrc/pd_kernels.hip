@@ -289,6 +289,10 @@ __global__ void __launch_bounds__(kBlock) k_pd_local_tet_pair(const float4* __re
 // and k + 64 in list order.  A single wavefront's LDS operations execute in order, so the barrier below is only the
 // compiler's and the hardware's s_waitcnt; wavefronts never wait for each other, and the chip balances 4 213 tiles of config 3
 // like it balanced the 4 213 wavefronts of k_pd_local_tet_pair.
+// (Round 5: config 3's 4 470 tiles are 1.09 rounds of the 4 096 wavefronts the chip holds at 114 registers and 9 KB of LDS each.  Five
+// wavefronts per SIMD - the staged positions sharing their LDS with the parked contributions, 7 KB, and __launch_bounds__(64, 5): 96
+// registers, 27 spilled words - put every tile in one round and were slower: 22.1 against 16.5 us per launch, 1 920 against 2 190
+// substeps/s.)
 constexpr uint32_t kTileLanes = 64;
 template <bool DICT>
 __global__ void __launch_bounds__(kTileLanes) k_pd_local_tiles(PdTileArrays T, const float4* __restrict__ pos, const float4* __restrict__ dictTable,
