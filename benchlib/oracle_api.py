@@ -10,7 +10,7 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _SO = os.path.join(_ROOT, "oracle", "_build", "libpies_oracle.so")
 
 POSITION, DISTANCE, TET, VOLUME, BEND, SHAPE, GOAL, TRIANGLES, LINES, NODES, STATICS, TRI_CONTACTS = range(12)
-FLAG_RELEASE_HINGE, FLAG_NODE_COLLISIONS, FLAG_COLLISION_RULE, FLAG_TRIANGLE_COLLISIONS, FLAG_PD_SOLVE_FP64 = 0, 1, 2, 3, 4
+FLAG_RELEASE_HINGE, FLAG_NODE_COLLISIONS, FLAG_COLLISION_RULE, FLAG_TRIANGLE_COLLISIONS, FLAG_PD_SOLVE_FP64, FLAG_SVD_PLAIN = 0, 1, 2, 3, 4, 5
 PBD, PD = 0, 1
 
 

@@ -201,7 +201,10 @@ struct Svd3 {
   float v[3][3];  // v[i] = i-th column of V
   float s[3];     // singular values (>= 0, unsorted)
   float rs[3];    // 1 / s[i]
-  int sweeps = 0;
+  int sweeps = 0;      // sweeps of the certifying loop that rotated, + 1 (statistics)
+  int rotations = 0;   // rotations applied (statistics)
+  bool closed_form = false;
+  int dbg[6] = {0, 0, 0, 0, 0, 0};
 };
 
 // 1/sqrt(x) from an integer seed and three Newton steps (relative error ~1e-7).  Only *, fma and integer operations:
@@ -223,15 +226,14 @@ inline float rsqrt_nr(float x) {
 
 inline float dot3f(const float* x, const float* y) { return std::fmaf(x[2], y[2], std::fmaf(x[1], y[1], x[0] * y[0])); }
 
-inline bool jacobi_pair(Svd3& d, int p, int q) {
-  float* bp = d.b[p];
-  float* bq = d.b[q];
-  const float alpha = dot3f(bp, bp);
-  const float beta = dot3f(bq, bq);
-  const float gamma = dot3f(bp, bq);
+inline bool pair_needs(float alpha, float beta, float gamma) {
   // + kSvdTiny2: numerically zero columns (collapsed element) are never rotated against; for every other pair the fused
   // sum rounds to kSvdTol2 * (alpha * beta) itself
-  if (!(gamma * gamma > std::fmaf(kSvdTol2, alpha * beta, kSvdTiny2))) return false;
+  return gamma * gamma > std::fmaf(kSvdTol2, alpha * beta, kSvdTiny2);
+}
+inline void jacobi_rotate(Svd3& d, int p, int q, float alpha, float beta, float gamma) {
+  float* bp = d.b[p];
+  float* bq = d.b[q];
   const float delta = beta - alpha;
   const float g2 = gamma + gamma;
   const float hw = std::fmaf(delta, delta, g2 * g2);
@@ -248,11 +250,25 @@ inline bool jacobi_pair(Svd3& d, int p, int q) {
     d.v[p][k] = std::fmaf(cs, vx, -(sn * vy));
     d.v[q][k] = std::fmaf(sn, vx, cs * vy);
   }
+}
+inline bool jacobi_pair(Svd3& d, int p, int q) {
+  const float alpha = dot3f(d.b[p], d.b[p]);
+  const float beta = dot3f(d.b[q], d.b[q]);
+  const float gamma = dot3f(d.b[p], d.b[q]);
+  if (!pair_needs(alpha, beta, gamma)) return false;
+  jacobi_rotate(d, p, q, alpha, beta, gamma);
   return true;
 }
+inline void svd3_finish(Svd3& d) {
+  for (int i = 0; i < 3; ++i) {
+    const float n2 = dot3f(d.b[i], d.b[i]);
+    d.rs[i] = n2 > kSvdTiny2 ? rsqrt_nr(n2) : 0.0f;
+    d.s[i] = n2 * d.rs[i];
+  }
+}
 
-// a[r][c] row-major input.
-inline Svd3 svd3(const float a[3][3]) {
+// The plain iteration from V = I (what rounds 1-5 ran).  a[r][c] row-major input.
+inline Svd3 svd3_jacobi(const float a[3][3]) {
   Svd3 d;
   for (int i = 0; i < 3; ++i)
     for (int k = 0; k < 3; ++k) {
@@ -263,13 +279,133 @@ inline Svd3 svd3(const float a[3][3]) {
     bool r01 = jacobi_pair(d, 0, 1);
     bool r02 = jacobi_pair(d, 0, 2);
     bool r12 = jacobi_pair(d, 1, 2);
+    d.rotations += (r01 ? 1 : 0) + (r02 ? 1 : 0) + (r12 ? 1 : 0);
     if (!(r01 || r02 || r12)) break;
   }
-  for (int i = 0; i < 3; ++i) {
-    const float n2 = dot3f(d.b[i], d.b[i]);
-    d.rs[i] = n2 > kSvdTiny2 ? rsqrt_nr(n2) : 0.0f;
-    d.s[i] = n2 * d.rs[i];
+  svd3_finish(d);
+  return d;
+}
+
+// Round 6: the iteration is started where it would end.  S = A^T A is symmetric 3x3, so the frame the sweeps converge to
+// has a closed form: the eigenvector n of S's most isolated eigenvalue (trigonometric solution of the characteristic cubic,
+// with cos(acos(x)/3) on [0, 1] as a degree-7 polynomial; n = the largest column of adj(S - lambda I)), an orthonormal
+// completion V0 = [t1, t2, n] (Duff et al., JCGT 2017), B = A V0 and one rotation of the pair (0, 1).  The sweeps then run
+// until one passes without a rotation: they certify every pair to the same tolerance as before and repair what the closed
+// form left (ill-conditioned A), so the result is that of the one-sided iteration.  An element with at most one pair out
+// of tolerance takes that rotation from the entries of S instead.  The device (dev_math.h svd3) executes this very IEEE
+// sequence.  Only U f(S) V^T is consumed, which does not depend on how the decomposition was found.
+constexpr float kCos3[8] = {8.660253882e-01f, 1.666651964e-01f,  -4.807964712e-02f, 2.440584078e-02f,
+                            -1.432729699e-02f, 7.718813606e-03f, -2.961986931e-03f, 5.536798271e-04f};
+inline float recip12(float t) {  // 1 / t for t in [1, 2]
+  float y = std::fmaf(-0.47058824f, t, 1.4117647f);
+  y = y * std::fmaf(-t, y, 2.0f);
+  y = y * std::fmaf(-t, y, 2.0f);
+  y = y * std::fmaf(-t, y, 2.0f);
+  return y;
+}
+// 1 / x to ~2e-4 (integer seed, two Newton steps), any sign: enough for a correction that is itself of the order of 1e-6
+inline float recip_rough(float x) {
+  int32_t i;
+  std::memcpy(&i, &x, 4);
+  i = 0x7EF311C7 - (i & 0x7fffffff);
+  float y;
+  std::memcpy(&y, &i, 4);
+  const float ax = std::fabs(x);
+  y = y * std::fmaf(-ax, y, 2.0f);
+  y = y * std::fmaf(-ax, y, 2.0f);
+  return std::copysign(y, x);
+}
+// The small-angle form of the rotation of the pair (p, q): (cos, sin) ~ (1, t), t = g / (b - a), applied unnormalised
+// (the columns grow by t^2 / 2 < 3e-8).  What the closed-form frame leaves between its isolated direction and the other two
+// is a rounding-level angle (~1e-6) - but one that an ill-conditioned element (a nearly flat one: the smallest column is 20x
+// shorter than the others) fails the relative test on; this takes it out for 30 instructions instead of a full rotation's 70.
+inline void jacobi_polish(Svd3& d, int p, int q) {
+  float* bp = d.b[p];
+  float* bq = d.b[q];
+  const float alpha = dot3f(bp, bp);
+  const float beta = dot3f(bq, bq);
+  const float gamma = dot3f(bp, bq);
+  float t = gamma * recip_rough(beta - alpha);
+  if (!(std::fabs(t) < 2.5e-4f)) { t = 0.0f; d.dbg[3] += 1; }  // (also NaN: equal norms)
+  for (int k = 0; k < 3; ++k) {
+    const float x = bp[k], y = bq[k];
+    bp[k] = std::fmaf(-t, y, x);
+    bq[k] = std::fmaf(t, x, y);
+    const float vx = d.v[p][k], vy = d.v[q][k];
+    d.v[p][k] = std::fmaf(-t, vy, vx);
+    d.v[q][k] = std::fmaf(t, vx, vy);
   }
+}
+inline Svd3 svd3(const float a[3][3]) {
+  Svd3 d;
+  float A[3][3];  // A[i] = column i
+  for (int i = 0; i < 3; ++i)
+    for (int k = 0; k < 3; ++k) A[i][k] = a[k][i];
+  const float s00 = dot3f(A[0], A[0]), s11 = dot3f(A[1], A[1]), s22 = dot3f(A[2], A[2]);
+  const float s01 = dot3f(A[0], A[1]), s02 = dot3f(A[0], A[2]), s12 = dot3f(A[1], A[2]);
+  const bool n01 = pair_needs(s00, s11, s01), n02 = pair_needs(s00, s22, s02), n12 = pair_needs(s11, s22, s12);
+  const int cnt = (n01 ? 1 : 0) + (n02 ? 1 : 0) + (n12 ? 1 : 0);
+  const float q = ((s00 + s11) + s22) * 0.333333343f;
+  const float d0 = s00 - q, d1 = s11 - q, d2 = s22 - q;
+  const float p1 = std::fmaf(s12, s12, std::fmaf(s02, s02, s01 * s01));
+  const float p2 = std::fmaf(d0, d0, std::fmaf(d1, d1, std::fmaf(d2, d2, p1 + p1)));
+  if (cnt >= 2 && p2 > 1.0e-30f && p2 < 1.0e16f) {
+    const float w = p2 * 0.166666672f;
+    const float ip = rsqrt_nr(w);
+    const float p = w * ip;
+    const float det = std::fmaf(d0, std::fmaf(d1, d2, -(s12 * s12)),
+                                std::fmaf(s02, std::fmaf(s01, s12, -(d1 * s02)), -(s01 * std::fmaf(s01, d2, -(s12 * s02)))));
+    const float r = ((0.5f * det) * ip) * (ip * ip);
+    const float x = std::fmin(std::fabs(r), 1.0f);
+    float c = kCos3[7];
+    for (int k = 6; k >= 0; --k) c = std::fmaf(c, x, kCos3[k]);
+    const float lam = q + std::copysign((p + p) * c, r);
+    const float m00 = s00 - lam, m11 = s11 - lam, m22 = s22 - lam;
+    const float c00 = std::fmaf(m11, m22, -(s12 * s12)), c11 = std::fmaf(m00, m22, -(s02 * s02)), c22 = std::fmaf(m00, m11, -(s01 * s01));
+    const float c01 = std::fmaf(s02, s12, -(s01 * m22)), c02 = std::fmaf(s01, s12, -(s02 * m11)), c12 = std::fmaf(s01, s02, -(s12 * m00));
+    const float a0 = std::fabs(c00), a1 = std::fabs(c11), a2 = std::fabs(c22);
+    const bool k0 = a0 >= a1 && a0 >= a2, k1 = !k0 && a1 >= a2;
+    const float v0 = k0 ? c00 : (k1 ? c01 : c02), v1 = k0 ? c01 : (k1 ? c11 : c12), v2 = k0 ? c02 : (k1 ? c12 : c22);
+    const float n2 = std::fmaf(v2, v2, std::fmaf(v1, v1, v0 * v0));
+    const bool okn = n2 > kSvdTiny2;
+    const float in = rsqrt_nr(okn ? n2 : 1.0f);
+    const float nx = okn ? v0 * in : 0.0f, ny = okn ? v1 * in : 0.0f, nz = okn ? v2 * in : 1.0f;
+    const float sg = std::copysign(1.0f, nz);
+    const float aa = -recip12(std::fabs(nz) + 1.0f) * sg;  // -1 / (sg + nz)
+    const float bb = (nx * ny) * aa;
+    const float V[3][3] = {{std::fmaf(sg * nx, nx * aa, 1.0f), sg * bb, -(sg * nx)}, {bb, std::fmaf(ny, ny * aa, sg), -ny}, {nx, ny, nz}};
+    for (int i = 0; i < 3; ++i)
+      for (int k = 0; k < 3; ++k) {
+        d.v[i][k] = V[i][k];
+        d.b[i][k] = std::fmaf(A[2][k], V[i][2], std::fmaf(A[1][k], V[i][1], A[0][k] * V[i][0]));
+      }
+    d.closed_form = true;
+    d.rotations += jacobi_pair(d, 0, 1) ? 1 : 0;
+    jacobi_polish(d, 0, 2);
+    jacobi_polish(d, 1, 2);
+    jacobi_polish(d, 0, 1);
+  } else {
+    for (int i = 0; i < 3; ++i)
+      for (int k = 0; k < 3; ++k) {
+        d.b[i][k] = A[i][k];
+        d.v[i][k] = (i == k) ? 1.0f : 0.0f;
+      }
+    if (n01) jacobi_rotate(d, 0, 1, s00, s11, s01);
+    else if (n02) jacobi_rotate(d, 0, 2, s00, s22, s02);
+    else if (n12) jacobi_rotate(d, 1, 2, s11, s22, s12);
+    d.rotations += cnt != 0 ? 1 : 0;
+  }
+  if (cnt != 0) {
+    for (d.sweeps = 0; d.sweeps < kSvdMaxSweeps; ++d.sweeps) {
+      const bool r02 = jacobi_pair(d, 0, 2);
+      const bool r12 = jacobi_pair(d, 1, 2);
+      const bool r01 = jacobi_pair(d, 0, 1);
+      if (d.sweeps == 0) { d.dbg[0] = r02; d.dbg[1] = r12; d.dbg[2] = r01; }
+      d.rotations += (r02 ? 1 : 0) + (r12 ? 1 : 0) + (r01 ? 1 : 0);
+      if (!(r02 || r12 || r01)) break;
+    }
+  }
+  svd3_finish(d);
   return d;
 }
 
@@ -292,12 +428,10 @@ inline void svd3_recompose(const Svd3& d, const float snew[3], float out[3][3]) 
     int k = !ok[0] ? 0 : (!ok[1] ? 1 : 2);
     int i = (k + 1) % 3, j = (k + 2) % 3;
     float ui[3], uj[3];
-    for (int c = 0; c < 3; ++c) { ui[c] = d.b[i][c] / d.s[i]; uj[c] = d.b[j][c] / d.s[j]; }
-    // orientation of the completion follows det(V): keeps det(U)*det(V) = +1
-    float detv = d.v[0][0] * (d.v[1][1] * d.v[2][2] - d.v[1][2] * d.v[2][1]) -
-                 d.v[0][1] * (d.v[1][0] * d.v[2][2] - d.v[1][2] * d.v[2][0]) +
-                 d.v[0][2] * (d.v[1][0] * d.v[2][1] - d.v[1][1] * d.v[2][0]);
-    float sg = (detv < 0.0f ? -1.0f : 1.0f) * snew[k];
+    for (int c = 0; c < 3; ++c) { ui[c] = d.b[i][c] * d.rs[i]; uj[c] = d.b[j][c] * d.rs[j]; }
+    // orientation of the completion: det(U) * det(V) = +1, and V is a rotation by construction (the identity or the
+    // completed frame, times Givens rotations)
+    float sg = snew[k];
     t[k][0] = sg * (ui[1] * uj[2] - ui[2] * uj[1]);
     t[k][1] = sg * (ui[2] * uj[0] - ui[0] * uj[2]);
     t[k][2] = sg * (ui[0] * uj[1] - ui[1] * uj[0]);

@@ -133,6 +133,22 @@ static inline void tet_emit(const float Fhat[3][3], std::array<vec3, 4>& out) {
   for (int c = 0; c < 3; ++c) out[1 + c] = vec3(Fhat[c][0], Fhat[c][1], Fhat[c][2]);
 }
 
+// Statistics of the decompositions the strain projection ran (what a workload asks of svd3: ora_svd_stats).  Not thread safe:
+// read after single-threaded ticks only.
+static bool g_svd_plain = false;  // ora_set_flag(*, 5, 1): the plain iteration from V = I (a process-wide replay switch: statistics, and the test that
+                                  // both decompositions give the same projections)
+static uint64_t g_svd_stats[8];
+static uint64_t g_svd_dbg[6];  // calls, closed-form starts, rotations, certifying sweeps, sweeps histogram (1, 2, 3, >= 4)
+static inline void svd_stats_add(const Svd3& d) {
+  g_svd_stats[0] += 1;
+  g_svd_stats[1] += d.closed_form ? 1 : 0;
+  g_svd_stats[2] += static_cast<uint64_t>(d.rotations);
+  const int sw = d.sweeps + 1;  // sweeps run, the clean one included (0 + 1 for an element that needed none: see svd3)
+  g_svd_stats[3] += static_cast<uint64_t>(sw);
+  g_svd_stats[4 + (sw >= 4 ? 3 : sw - 1)] += 1;
+  for (int i = 0; i < 6; ++i) g_svd_dbg[i] += d.dbg[i];
+}
+
 // Constraints.cpp:76-128
 struct TetCon : ConBase<4> {
   mat3 Qinv;
@@ -141,7 +157,8 @@ struct TetCon : ConBase<4> {
     mat3 F;
     float F_[3][3];
     tet_deformation(nodes, nodeIds, Qinv, F, F_);
-    Svd3 d = svd3(F_);
+    Svd3 d = g_svd_plain ? svd3_jacobi(F_) : svd3(F_);
+    svd_stats_add(d);
     float s[3];
     for (int i = 0; i < 3; ++i) s[i] = clampf(d.s[i], minStrain, maxStrain);
     if (determinant(F) < 0.0f) {
@@ -1465,6 +1482,7 @@ void ora_set_flag(ora_solver* s, int flag, int value) {
   if (flag == 2) { s->collisionRule = value; s->collisionOrder.clear(); }
   if (flag == 3) s->triangleCollisions = value != 0;
   if (flag == 4) s->solveFp64 = value != 0;  // FLAG_PD_SOLVE_FP64
+  if (flag == 5) g_svd_plain = value != 0;   // FLAG_SVD_PLAIN (process-wide)
 }
 int ora_failed(ora_solver* s) { return s->simFailed ? 1 : 0; }
 
@@ -1931,6 +1949,11 @@ void ora_tick(ora_solver* s) { s->tick(); }
 
 // ------------------------------- single-operation entry points (KATs) ------------------------
 // a: row-major 3x3; out: row-major U*diag(snew)*V^T with snew = clamp(s) (+ flip) as the tet functor
+void ora_svd_dbg(uint64_t* out) { for (int i = 0; i < 6; ++i) { out[i] = g_svd_dbg[i]; g_svd_dbg[i] = 0; } }
+void ora_svd_stats(uint64_t* out, int reset) {
+  for (int i = 0; i < 8; ++i) out[i] = g_svd_stats[i];
+  if (reset) for (int i = 0; i < 8; ++i) g_svd_stats[i] = 0;
+}
 int ora_svd3(const float* a, float* s_out, float* b_out, float* v_out) {
   float A[3][3];
   for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) A[r][c] = a[3 * r + c];

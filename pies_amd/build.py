@@ -47,14 +47,15 @@ def _newest_header():
     return max(t, os.path.getmtime(os.path.abspath(__file__)))
 
 
-def _compile(src, force):
-    obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
+def _compile(src, force, exp=False):
+    obj = os.path.join(OBJDIR + ("_exp" if exp else ""), os.path.basename(src) + ".o")
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), _newest_header()):
         return obj, False
+    extra = ["-DPIES_EXPERIMENTS"] if exp else []
     if src.endswith(".hip"):
-        cmd = [_hipcc(), "-c", src, "-o", obj] + COMMON + DEVICE
+        cmd = [_hipcc(), "-c", src, "-o", obj] + COMMON + DEVICE + extra
     else:  # host-only translation units: plain C++ against the HIP runtime API
-        cmd = [_hipcc(), "-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-c", src, "-o", obj] + COMMON
+        cmd = [_hipcc(), "-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-c", src, "-o", obj] + COMMON + extra
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
@@ -63,22 +64,25 @@ def _compile(src, force):
     return obj, True
 
 
-def build(force=False, verbose=False):
-    os.makedirs(OBJDIR, exist_ok=True)
+def build(force=False, verbose=False, exp=False):
+    """exp=True: the diagnostic library libpies_hip_exp.so (-DPIES_EXPERIMENTS: timing experiments that change the work done,
+    in-kernel time stamps).  Never loaded by the product or the tests; tools select it with PIES_LIB."""
+    lib = LIB.replace(".so", "_exp.so") if exp else LIB
+    os.makedirs(OBJDIR + ("_exp" if exp else ""), exist_ok=True)
     srcs = sources()
     with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
-        res = list(ex.map(lambda s: _compile(s, force), srcs))
+        res = list(ex.map(lambda s: _compile(s, force, exp), srcs))
     objs = [o for o, _ in res]
     rebuilt = any(c for _, c in res)
-    if rebuilt or not os.path.exists(LIB):
-        cmd = [_hipcc(), "-shared", "-o", LIB] + objs + DEVICE + ["-Wl,--no-undefined"]
+    if rebuilt or not os.path.exists(lib):
+        cmd = [_hipcc(), "-shared", "-o", lib] + objs + DEVICE + ["-Wl,--no-undefined"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
         if verbose:
-            print("built", LIB)
-    return LIB
+            print("built", lib)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, exp="--exp" in sys.argv))

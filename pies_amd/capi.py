@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libpies_hip.so")
+# PIES_LIB: development tools load the diagnostic build (pies_amd/build.py --exp) instead; tests and bench.py never set it
+LIB_PATH = os.environ.get("PIES_LIB") or os.path.join(HERE, "lib", "libpies_hip.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(5)
 PBD, PD = 0, 1

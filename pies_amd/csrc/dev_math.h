@@ -53,14 +53,13 @@ PIES_DEV float rsqrt_nr(float x) {
 }
 PIES_DEV float dot3f(const float x[3], const float y[3]) { return fmaf(x[2], y[2], fmaf(x[1], y[1], x[0] * y[0])); }
 
-template <int P, int Q> PIES_DEV bool jacobi_pair(Svd3& d) {
-  const float alpha = dot3f(d.b[P], d.b[P]);
-  const float beta = dot3f(d.b[Q], d.b[Q]);
-  const float gamma = dot3f(d.b[P], d.b[Q]);
-  // + kSvdTiny2: a column whose squared norm has fallen to ~1e-36 is numerically zero (a collapsed element); since
-  // gamma^2 <= alpha*beta the pair is then skipped instead of sending rsqrt_nr out of its range.  For every other
-  // pair the fused sum rounds to kSvdTol2 * (alpha * beta) itself.
-  if (!(gamma * gamma > fmaf(kSvdTol2, alpha * beta, kSvdTiny2))) return false;
+// a pair (alpha, beta, gamma) = (|b_p|^2, |b_q|^2, b_p.b_q) is out of tolerance.  + kSvdTiny2: a column whose squared
+// norm has fallen to ~1e-36 is numerically zero (a collapsed element); since gamma^2 <= alpha*beta the pair is then skipped
+// instead of sending rsqrt_nr out of its range.  For every other pair the fused sum rounds to kSvdTol2 * (alpha * beta).
+PIES_DEV bool pair_needs(float alpha, float beta, float gamma) { return gamma * gamma > fmaf(kSvdTol2, alpha * beta, kSvdTiny2); }
+
+// the rotation that makes columns P and Q of B orthogonal, applied to B and V
+template <int P, int Q> PIES_DEV void jacobi_rotate(Svd3& d, const float alpha, const float beta, const float gamma) {
   const float delta = beta - alpha;
   const float g2 = gamma + gamma;
   const float hw = fmaf(delta, delta, g2 * g2);
@@ -78,11 +77,31 @@ template <int P, int Q> PIES_DEV bool jacobi_pair(Svd3& d) {
     d.v[P][k] = fmaf(cs, vx, -(sn * vy));
     d.v[Q][k] = fmaf(sn, vx, cs * vy);
   }
-  return true;
+}
+// Test of the pair (P, Q) and, where needed, its rotation.  The rotation stands behind a WAVE-UNIFORM branch: left to itself
+// the compiler turns "if (needed) rotate" into straight-line code with selects (profiles/r06_layer_isa.txt: 68 instructions per
+// pair whether anything rotates or not), and most tests of a decomposition - the certifying sweep, the pairs of a flattened
+// element - rotate nothing in any lane.  With the branch a test costs its 13 instructions.
+template <int P, int Q> PIES_DEV bool jacobi_pair(Svd3& d) {
+  const float alpha = dot3f(d.b[P], d.b[P]);
+  const float beta = dot3f(d.b[Q], d.b[Q]);
+  const float gamma = dot3f(d.b[P], d.b[Q]);
+  const bool need = pair_needs(alpha, beta, gamma);
+  if (__builtin_amdgcn_ballot_w64(need) == 0ull) return false;  // (uniform: no lane of the wavefront rotates)
+  if (need) jacobi_rotate<P, Q>(d, alpha, beta, gamma);
+  return need;
+}
+PIES_DEV void svd3_finish(Svd3& d) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float n2 = dot3f(d.b[i], d.b[i]);
+    d.rs[i] = n2 > kSvdTiny2 ? rsqrt_nr(n2) : 0.0f;  // a collapsed direction: s = 0, handled by svd3_recompose
+    d.s[i] = n2 * d.rs[i];
+  }
 }
 
-// a[r][c]: row-major input.  A*V = B with orthogonal columns; s_i = |b_i|.
-PIES_DEV void svd3(const float a[3][3], Svd3& d) {
+// The plain iteration from V = I (rounds 1-5): a[r][c] row-major.  A*V = B with orthogonal columns; s_i = |b_i|.
+PIES_DEV void svd3_jacobi(const float a[3][3], Svd3& d) {
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -96,111 +115,151 @@ PIES_DEV void svd3(const float a[3][3], Svd3& d) {
     const bool r12 = jacobi_pair<1, 2>(d);
     if (!(r01 || r02 || r12)) break;
   }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const float n2 = dot3f(d.b[i], d.b[i]);
-    d.rs[i] = n2 > kSvdTiny2 ? rsqrt_nr(n2) : 0.0f;  // a collapsed direction: s = 0, handled by svd3_recompose
-    d.s[i] = n2 * d.rs[i];
-  }
+  svd3_finish(d);
 }
 
-// ---- the same decomposition with the rotations written on register PAIRS (round 4) ---------------------------------------
-// The compiler packs a rotation's application into v_pk_mul_f32 / v_pk_fma_f32 already, but it assembles the operands of
-// every packed instruction with v_mov_b32: 21 moves in the 80 VALU instructions of a rotation (profiles/r04_svd_isa_counts.txt)
-// - and a colour step of k_layer lasts as long as its wavefronts' instruction streams.  A packed fp32 instruction takes each
-// operand from EITHER half of a 64-bit register pair (op_sel), so no value ever has to be moved: the columns live in pairs,
-//     sweep start:  A[k] = (col 0, -)   B[k] = (col 1, col 2)             k = component, likewise for V
-//     (0,1): x = A.lo, y = B.lo -> N1 = (col 0', col 1');  (0,2): x = N1.lo, y = B.hi -> N2 = (col 0'', col 2');
-//     (1,2): x = N1.hi, y = N2.hi -> N3 = (col 1'', col 2'');  next sweep: A = N2, B = N3
-// and one rotation of (x, y) is   t = (-sn * y, cs * y);  (x', y') = (cs * x + t.lo, sn * x + t.hi)   - the very IEEE
-// operations of jacobi_pair (a product, a negation, a fused multiply-add), so the result is bit for bit that of svd3.
-// A lane whose pair needs no rotation while another lane's does goes through the same instructions with (cs, sn) = (1, 0):
-// x * 1 - 0 and 0 * x + y return x and y; when no lane needs it the pair is only re-packed (v_pk_mov_b32).
-typedef float pk2 __attribute__((ext_vector_type(2)));
-template <int HX, int HY> PIES_DEV pk2 pk_rotate(const pk2 sc, const pk2 xp, const pk2 yp) {  // sc = (cs, sn); x = xp[HX], y = yp[HY]
-  pk2 t, r;
-  if (HY == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[1,0]" : "=v"(t) : "v"(sc), "v"(yp));
-  else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[1,0]" : "=v"(t) : "v"(sc), "v"(yp));
-  if (HX == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(sc), "v"(xp), "v"(t));
-  else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(sc), "v"(xp), "v"(t));
-  return r;
+// ---- round 6: the iteration is STARTED where it would end -----------------------------------------------------------------
+// From V = I a generic deformation gradient takes 3-4 rotating sweeps (9-12 rotations of ~80 instructions); what a sweep
+// converges to is the eigenvector frame of S = A^T A, and for a symmetric 3x3 that frame has a closed form:
+//   * S's most isolated eigenvalue lambda = q +- 2 p cos(acos(|r|) / 3)  (q = tr S / 3, 6 p^2 = |S - qI|_F^2,
+//     r = det(S - qI) / 2 p^3; the largest eigenvalue when r >= 0, else the smallest - the one whose cosine is insensitive to
+//     r, so near-double eigenvalues cost no accuracy).  cos(acos(x)/3) on [0, 1] is analytic (the root of 4c^3 - 3c = x above
+//     sqrt(3)/2): a degree-7 polynomial, |error| < 8e-8; no inverse trigonometric function is evaluated.
+//   * its eigenvector n = the largest column of adj(S - lambda I) (the cross product of two rows), normalised;
+//   * V0 = [t1, t2, n] with (t1, t2) the branch-free orthonormal completion of Duff et al. (JCGT 2017), det V0 = +1;
+//   * B = A V0, and ONE rotation of the pair (0, 1) diagonalises what is left (a 2x2 problem: exact).
+// The same sweeps as before then run until one passes without a rotation - they CERTIFY the result to the same tolerance
+// as in rounds 1-5 and repair whatever the closed form left (ill-conditioned A: S squares the condition number), so accuracy
+// is that of the one-sided iteration, not of the closed form.  On a perturbed rest state: 1 rotation + 3 tests instead of
+// 10-12 rotations + 12 tests.  An element with at most one pair out of tolerance (rest state; a flattened element
+// whose zero column is a coordinate axis - BASELINE config 2 after its first tick) skips the closed form: that pair is
+// rotated from the entries of S.  Every choice is made per element from its own data: bit-reproducible on a host.
+constexpr float kCos3[8] = {8.660253882e-01f, 1.666651964e-01f,  -4.807964712e-02f, 2.440584078e-02f,
+                            -1.432729699e-02f, 7.718813606e-03f, -2.961986931e-03f, 5.536798271e-04f};
+// 1 / t for t in [1, 2]: a linear seed (error < 1/17) and three Newton steps
+PIES_DEV float recip12(float t) {
+  float y = fmaf(-0.47058824f, t, 1.4117647f);
+  y = y * fmaf(-t, y, 2.0f);
+  y = y * fmaf(-t, y, 2.0f);
+  y = y * fmaf(-t, y, 2.0f);
+  return y;
 }
-template <int HX, int HY> PIES_DEV pk2 pk_pair(const pk2 xp, const pk2 yp) {  // (xp[HX], yp[HY])
-  pk2 r;
-  if (HX == 0 && HY == 0) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(r) : "v"(xp), "v"(yp));
-  else if (HX == 0 && HY == 1) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(xp), "v"(yp));
-  else if (HX == 1 && HY == 0) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(xp), "v"(yp));
-  else asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(r) : "v"(xp), "v"(yp));
-  return r;
+// 1 / x to ~2e-4 (integer seed, two Newton steps), any sign: enough for a correction that is itself of the order of 1e-6
+PIES_DEV float recip_rough(float x) {
+  float y = __int_as_float(0x7EF311C7 - (__float_as_int(x) & 0x7fffffff));
+  const float ax = fabsf(x);
+  y = y * fmaf(-ax, y, 2.0f);
+  y = y * fmaf(-ax, y, 2.0f);
+  return __builtin_copysignf(y, x);
 }
-// one rotation of the column pair (x, y) = (bx[k][HX], by[k][HY]) and of V's; out[k] = (x', y').  Returns jacobi_pair's flag.
-template <int HX, int HY>
-PIES_DEV bool jacobi_pair_pk(const pk2 bx[3], const pk2 by[3], const pk2 vx[3], const pk2 vy[3], pk2 bo[3], pk2 vo[3]) {
-  const float x[3] = {bx[0][HX], bx[1][HX], bx[2][HX]}, y[3] = {by[0][HY], by[1][HY], by[2][HY]};
-  const float alpha = dot3f(x, x);
-  const float beta = dot3f(y, y);
-  const float gamma = dot3f(x, y);
-  const bool need = gamma * gamma > fmaf(kSvdTol2, alpha * beta, kSvdTiny2);
-  if (__builtin_amdgcn_ballot_w64(need) != 0ull) {  // (uniform: some lane of the wavefront rotates)
-    const float delta = beta - alpha;
-    const float g2 = gamma + gamma;
-    const float hw = fmaf(delta, delta, g2 * g2);
-    const float h = hw * rsqrt_nr(hw);
-    const float c1 = h + fabsf(delta);
-    const float s1 = delta < 0.0f ? -g2 : g2;
-    const float inv = rsqrt_nr(fmaf(c1, c1, s1 * s1));
-    const pk2 sc = {need ? c1 * inv : 1.0f, need ? s1 * inv : 0.0f};
+// The small-angle form of the rotation of the pair (P, Q): (cos, sin) ~ (1, t), t = g / (b - a), applied unnormalised (the
+// columns grow by t^2 / 2 < 3e-8).  What the closed-form frame leaves between its isolated direction and the other two - and
+// what the full rotation of the pair (0, 1) leaves between a long and a short column - is a rounding-level angle (~1e-6), but
+// one that an ill-conditioned element (a nearly flat one: its smallest column 20x shorter than the others - every element of
+// BASELINE config 2 between the floor clamps) fails the relative test on.  This takes it out for ~30 instructions in every
+// lane; left to the certifying sweeps it costs a rotating sweep (3 x 70) and another clean one in every WAVEFRONT that holds
+// such an element (measured on config 2: 18 % of the elements, i.e. every wavefront).
+template <int P, int Q> PIES_DEV void jacobi_polish(Svd3& d) {
+  const float alpha = dot3f(d.b[P], d.b[P]);
+  const float beta = dot3f(d.b[Q], d.b[Q]);
+  const float gamma = dot3f(d.b[P], d.b[Q]);
+  float t = gamma * recip_rough(beta - alpha);
+  if (!(fabsf(t) < 2.5e-4f)) t = 0.0f;  // (also NaN: equal norms)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      bo[k] = pk_rotate<HX, HY>(sc, bx[k], by[k]);
-      vo[k] = pk_rotate<HX, HY>(sc, vx[k], vy[k]);
-    }
+  for (int k = 0; k < 3; ++k) {
+    const float x = d.b[P][k], y = d.b[Q][k];
+    d.b[P][k] = fmaf(-t, y, x);
+    d.b[Q][k] = fmaf(t, x, y);
+    const float vx = d.v[P][k], vy = d.v[Q][k];
+    d.v[P][k] = fmaf(-t, vy, vx);
+    d.v[Q][k] = fmaf(t, vx, vy);
+  }
+}
+// a[r][c]: row-major input.  A*V = B with orthogonal columns; s_i = |b_i|.
+PIES_DEV void svd3(const float a[3][3], Svd3& d) {
+  float A[3][3];  // A[i] = column i
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) A[i][k] = a[k][i];
+  const float s00 = dot3f(A[0], A[0]), s11 = dot3f(A[1], A[1]), s22 = dot3f(A[2], A[2]);
+  const float s01 = dot3f(A[0], A[1]), s02 = dot3f(A[0], A[2]), s12 = dot3f(A[1], A[2]);
+  const bool n01 = pair_needs(s00, s11, s01), n02 = pair_needs(s00, s22, s02), n12 = pair_needs(s11, s22, s12);
+  const int cnt = (n01 ? 1 : 0) + (n02 ? 1 : 0) + (n12 ? 1 : 0);
+  float q = 0.0f, d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, p2 = 0.0f;
+  if (cnt >= 2) {
+    q = ((s00 + s11) + s22) * 0.333333343f;
+    d0 = s00 - q; d1 = s11 - q; d2 = s22 - q;
+    const float p1 = fmaf(s12, s12, fmaf(s02, s02, s01 * s01));
+    p2 = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, p1 + p1)));  // 6 p^2
+  }
+  if (cnt >= 2 && p2 > 1.0e-30f && p2 < 1.0e16f) {  // (the range in which nothing below leaves single precision)
+    const float w = p2 * 0.166666672f;
+    const float ip = rsqrt_nr(w);
+    const float p = w * ip;
+    const float det = fmaf(d0, fmaf(d1, d2, -(s12 * s12)), fmaf(s02, fmaf(s01, s12, -(d1 * s02)), -(s01 * fmaf(s01, d2, -(s12 * s02)))));
+    const float r = ((0.5f * det) * ip) * (ip * ip);
+    const float x = fminf(fabsf(r), 1.0f);
+    float c = kCos3[7];
+#pragma unroll
+    for (int k = 6; k >= 0; --k) c = fmaf(c, x, kCos3[k]);
+    const float lam = q + __builtin_copysignf((p + p) * c, r);
+    const float m00 = s00 - lam, m11 = s11 - lam, m22 = s22 - lam;
+    const float c00 = fmaf(m11, m22, -(s12 * s12)), c11 = fmaf(m00, m22, -(s02 * s02)), c22 = fmaf(m00, m11, -(s01 * s01));
+    const float c01 = fmaf(s02, s12, -(s01 * m22)), c02 = fmaf(s01, s12, -(s02 * m11)), c12 = fmaf(s01, s02, -(s12 * m00));
+    const float a0 = fabsf(c00), a1 = fabsf(c11), a2 = fabsf(c22);
+    const bool k0 = a0 >= a1 && a0 >= a2, k1 = !k0 && a1 >= a2;
+    const float v0 = k0 ? c00 : (k1 ? c01 : c02), v1 = k0 ? c01 : (k1 ? c11 : c12), v2 = k0 ? c02 : (k1 ? c12 : c22);
+    const float n2 = fmaf(v2, v2, fmaf(v1, v1, v0 * v0));
+    const bool okn = n2 > kSvdTiny2;
+    const float in = rsqrt_nr(okn ? n2 : 1.0f);
+    const float nx = okn ? v0 * in : 0.0f, ny = okn ? v1 * in : 0.0f, nz = okn ? v2 * in : 1.0f;
+    const float sg = __builtin_copysignf(1.0f, nz);
+    const float aa = -recip12(fabsf(nz) + 1.0f) * sg;  // -1 / (sg + nz)
+    const float bb = (nx * ny) * aa;
+    const float V[3][3] = {{fmaf(sg * nx, nx * aa, 1.0f), sg * bb, -(sg * nx)}, {bb, fmaf(ny, ny * aa, sg), -ny}, {nx, ny, nz}};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        d.v[i][k] = V[i][k];
+        d.b[i][k] = fmaf(A[2][k], V[i][2], fmaf(A[1][k], V[i][1], A[0][k] * V[i][0]));
+      }
+    (void)jacobi_pair<0, 1>(d);
+    jacobi_polish<0, 2>(d);
+    jacobi_polish<1, 2>(d);
+    jacobi_polish<0, 1>(d);
   } else {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      bo[k] = pk_pair<HX, HY>(bx[k], by[k]);
-      vo[k] = pk_pair<HX, HY>(vx[k], vy[k]);
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        d.b[i][k] = A[i][k];
+        d.v[i][k] = (i == k) ? 1.0f : 0.0f;
+      }
+    if (n01) jacobi_rotate<0, 1>(d, s00, s11, s01);
+    else if (n02) jacobi_rotate<0, 2>(d, s00, s22, s02);
+    else if (n12) jacobi_rotate<1, 2>(d, s11, s22, s12);
+  }
+  if (cnt != 0) {
+    for (int sweep = 0; sweep < kSvdMaxSweeps; ++sweep) {
+      const bool r02 = jacobi_pair<0, 2>(d);
+      const bool r12 = jacobi_pair<1, 2>(d);
+      const bool r01 = jacobi_pair<0, 1>(d);
+      if (!(r02 || r12 || r01)) break;
     }
   }
-  return need;
-}
-PIES_DEV void svd3_pk(const float a[3][3], Svd3& d) {
-  pk2 A[3], B[3], VA[3], VB[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    A[k] = pk2{a[k][0], 0.0f};
-    B[k] = pk2{a[k][1], a[k][2]};
-    VA[k] = pk2{k == 0 ? 1.0f : 0.0f, 0.0f};
-    VB[k] = pk2{k == 1 ? 1.0f : 0.0f, k == 2 ? 1.0f : 0.0f};
-  }
-  for (int sweep = 0; sweep < kSvdMaxSweeps; ++sweep) {
-    pk2 N1[3], V1[3], N2[3], V2[3], N3[3], V3[3];
-    const bool r01 = jacobi_pair_pk<0, 0>(A, B, VA, VB, N1, V1);
-    const bool r02 = jacobi_pair_pk<0, 1>(N1, B, V1, VB, N2, V2);
-    const bool r12 = jacobi_pair_pk<1, 1>(N1, N2, V1, V2, N3, V3);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { A[k] = N2[k]; B[k] = N3[k]; VA[k] = V2[k]; VB[k] = V3[k]; }
-    if (!(r01 || r02 || r12)) break;
-  }
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    d.b[0][k] = A[k][0]; d.b[1][k] = B[k][0]; d.b[2][k] = B[k][1];
-    d.v[0][k] = VA[k][0]; d.v[1][k] = VB[k][0]; d.v[2][k] = VB[k][1];
-  }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const float n2 = dot3f(d.b[i], d.b[i]);
-    d.rs[i] = n2 > kSvdTiny2 ? rsqrt_nr(n2) : 0.0f;
-    d.s[i] = n2 * d.rs[i];
-  }
+  svd3_finish(d);
 }
 
+// t[K] = sg * (u_I x u_J): the direction a collapsed column K leaves open, oriented so that det(U) det(V) = +1
+// (V is a rotation: the identity or the completed frame of svd3, times Givens rotations)
 template <int K, int I, int J> PIES_DEV void complete_t(const Svd3& d, float t[3][3], float sg) {
   float ui[3], uj[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    ui[c] = d.b[I][c] / d.s[I];
-    uj[c] = d.b[J][c] / d.s[J];
+    ui[c] = d.b[I][c] * d.rs[I];
+    uj[c] = d.b[J][c] * d.rs[J];
   }
   t[K][0] = sg * (ui[1] * uj[2] - ui[2] * uj[1]);
   t[K][1] = sg * (ui[2] * uj[0] - ui[0] * uj[2]);
@@ -223,14 +282,10 @@ PIES_DEV void svd3_recompose(const Svd3& d, const float snew[3], float out[3][3]
     t[2][k] = d.b[2][k] * g2;
   }
   const int nbad = (ok0 ? 0 : 1) + (ok1 ? 0 : 1) + (ok2 ? 0 : 1);
-  if (nbad == 1) {  // rare: a flattened element
-    const float detv = d.v[0][0] * (d.v[1][1] * d.v[2][2] - d.v[1][2] * d.v[2][1]) -
-                       d.v[0][1] * (d.v[1][0] * d.v[2][2] - d.v[1][2] * d.v[2][0]) +
-                       d.v[0][2] * (d.v[1][0] * d.v[2][1] - d.v[1][1] * d.v[2][0]);
-    const float sgn = detv < 0.0f ? -1.0f : 1.0f;
-    if (!ok0) complete_t<0, 1, 2>(d, t, sgn * snew[0]);
-    else if (!ok1) complete_t<1, 2, 0>(d, t, sgn * snew[1]);
-    else complete_t<2, 0, 1>(d, t, sgn * snew[2]);
+  if (nbad == 1) {  // a flattened element
+    if (!ok0) complete_t<0, 1, 2>(d, t, snew[0]);
+    else if (!ok1) complete_t<1, 2, 0>(d, t, snew[1]);
+    else complete_t<2, 0, 1>(d, t, snew[2]);
   }
 #pragma unroll
   for (int r = 0; r < 3; ++r)

@@ -53,6 +53,9 @@ struct LayerLaunch {
   uint32_t phase, groups, nseg, maxClass;  // phase = 2 * (level parity) + (strip parity); groups = tiles of that phase
   uint32_t loadGlobal, storeGlobal;  // node records from / to the node array instead of the layer-ordered copy
   LayerSeg seg[kLayerMaxSegs];
+#ifdef PIES_EXPERIMENTS
+  uint32_t stampSlot;  // diagnostic build: the launch's place in the time-stamp buffer (layer_kernels.hip)
+#endif
 };
 struct LayerData {
   const uint32_t* nodeList;

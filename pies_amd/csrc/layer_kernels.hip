@@ -28,6 +28,20 @@ PIES_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" :
 constexpr int kDistPreload = 12;  // colours of a distance segment whose records a lane requests up front
 constexpr int kBatch = 4;         // node records a lane requests before it consumes the first (the load phase is written out for 4)
 
+#ifdef PIES_EXPERIMENTS  // in-kernel time stamps of a diagnostic build (tools/layer_timeline.py): never part of the product build
+__device__ unsigned long long* g_layer_stamps = nullptr;  // [launch slot][tile][kStampsPerTile]
+__device__ unsigned int g_layer_stamp_slot = 0;
+constexpr int kStampsPerTile = 128;
+#define PIES_STAMP_DECL unsigned long long* stampBase = nullptr; int stampIdx = 0; \
+  if (g_layer_stamps && tid == 0) stampBase = g_layer_stamps + (static_cast<size_t>(L.stampSlot) * 4096u + g) * kStampsPerTile;
+#define PIES_STAMP() do { if (stampBase && stampIdx < kStampsPerTile) stampBase[stampIdx++] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PIES_STAMP_REAL() do { if (stampBase && stampIdx < kStampsPerTile) stampBase[stampIdx++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PIES_STAMP_DECL
+#define PIES_STAMP()
+#define PIES_STAMP_REAL()
+#endif
+
 PIES_DEV uint32_t lo16(uint32_t v) { return v & 0xFFFFu; }
 PIES_DEV uint32_t hi16(uint32_t v) { return v >> 16; }
 
@@ -42,6 +56,9 @@ __global__ void __launch_bounds__(BLOCK) k_layer(NodeArrays nd, LayerData D, Lay
   const uint4 tile = D.tiles[L.phase][g];
   const uint32_t m = tile.y + tile.w;
   if (m == 0) return;  // uniform: an empty tile
+  PIES_STAMP_DECL
+  PIES_STAMP_REAL();
+  PIES_STAMP();
   // LDS index -> position in the level-ordered node list (two runs: the tile's part of its two levels)
   auto lp = [&](uint32_t i) { return i < tile.y ? tile.x + i : tile.z + (i - tile.y); };
 
@@ -82,6 +99,7 @@ __global__ void __launch_bounds__(BLOCK) k_layer(NodeArrays nd, LayerData D, Lay
     for (uint32_t c = tid; c <= nc + 1; c += BLOCK) soff[s * kOffStride + c] = src[c <= nc ? c : nc];
   }
   __syncthreads();
+  PIES_STAMP();
 
   for (uint32_t s = 0; s < L.nseg; ++s) {
     const uint32_t kind = L.seg[s].kind, ncol = L.seg[s].ncol;
@@ -104,7 +122,13 @@ __global__ void __launch_bounds__(BLOCK) k_layer(NodeArrays nd, LayerData D, Lay
         if (have) {
           const uint32_t i1 = lo16(id.x), i2 = hi16(id.x), i3 = lo16(id.y), i4 = hi16(id.y);
           float4 x1 = sp[i1], x2 = sp[i2], x3 = sp[i3], x4 = sp[i4];
+#ifdef PIES_EXPERIMENTS
+          if (stampBase) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PIES_STAMP(); }  // the gather has landed
+#endif
           tet_core<TETV>(x1, x2, x3, x4, a0, a1, a2);
+#ifdef PIES_EXPERIMENTS
+          if (stampBase) { asm volatile("" : "+v"(x1.x), "+v"(x2.x), "+v"(x3.x), "+v"(x4.x)); PIES_STAMP(); }  // the projection is done
+#endif
           sp[i1] = x1; sp[i2] = x2; sp[i3] = x3; sp[i4] = x4;
         }
         for (uint32_t t = lo + tid + BLOCK; t < hi; t += BLOCK) {  // classes larger than the workgroup
@@ -115,6 +139,7 @@ __global__ void __launch_bounds__(BLOCK) k_layer(NodeArrays nd, LayerData D, Lay
           sp[i1] = x1; sp[i2] = x2; sp[i3] = x3; sp[i4] = x4;
         }
         lds_barrier();
+        PIES_STAMP();
         lo = nlo; hi = nhi; have = nhave; id = nid; a0 = b0; a1 = b1; a2 = b2;
       }
     } else if (kind == LAYER_DISTANCE) {
@@ -145,6 +170,7 @@ __global__ void __launch_bounds__(BLOCK) k_layer(NodeArrays nd, LayerData D, Lay
             sp[lo16(jd)] = a;
           }
           lds_barrier();
+          PIES_STAMP();
         }
       }
       for (uint32_t c = kDistPreload; c < ncol; ++c) {
@@ -232,6 +258,8 @@ __global__ void __launch_bounds__(BLOCK) k_layer(NodeArrays nd, LayerData D, Lay
   } else {
     for (uint32_t i = tid; i < m; i += BLOCK) D.lpos[lp(i)] = sp[i];
   }
+  PIES_STAMP();
+  PIES_STAMP_REAL();
 }
 
 // ---- per-node steps over the level-ordered copy (bodies cut into strips) -----------------------------------------
@@ -297,6 +325,11 @@ void launch_lcopy(hipStream_t st, const NodeArrays& nd, const LayerData& D, bool
   else hipLaunchKernelGGL(k_lcopy<false>, node_grid(nd.n), dim3(kNodeBlock), 0, st, nd.pos, D.nodeList, D.lpos, nd.n);
 }
 
+#ifdef PIES_EXPERIMENTS
+extern "C" int pies_exp_layer_stamps(unsigned long long* deviceBuffer) {  // 64 x 4096 x 128 x 8 bytes, or nullptr
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_layer_stamps), &deviceBuffer, sizeof(deviceBuffer)) == hipSuccess ? 0 : 1;
+}
+#endif
 static size_t layer_lds_bytes(uint32_t maxGroupNodes) {
   return static_cast<size_t>(maxGroupNodes) * (sizeof(float4) + sizeof(float)) + kLayerMaxSegs * kOffStride * sizeof(uint32_t);
 }
@@ -320,6 +353,10 @@ void launch_layer(hipStream_t st, const NodeArrays& nd, const LayerData& D, cons
     L.nseg = 0;
     for (uint32_t s = 0; s < L0.nseg; ++s)
       if (!((skipMask >> L0.seg[s].kind) & 1)) L.seg[L.nseg++] = L0.seg[s];
+  }
+  {
+    static unsigned int slot = 0;  // the launch's place in the stamp buffer (64 launches are kept)
+    L.stampSlot = slot++ & 63u;
   }
   const int variant = [] { const char* e = getenv("PIES_EXP_TET"); return e ? atoi(e) : 0; }();
   if (variant == 1) { hipLaunchKernelGGL((k_layer<256, 1>), dim3(L.groups), dim3(256), lds, st, nd, D, L, P); return; }  // no SVD

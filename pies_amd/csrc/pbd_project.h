@@ -75,11 +75,8 @@ PIES_DEV void tet_core(float4& x1, float4& x2, float4& x3, float4& x4, const flo
     return;
   }
   Svd3 d;
-#ifdef PIES_SVD_PAIRS  // the rotations written on register pairs (dev_math.h svd3_pk): bit-identical, 16 % fewer VALU instructions per
-  svd3_pk(F, d);     // rotation, and measured SLOWER in k_layer (37.9 against 35.3 us per launch, profiles/r04_svd_isa_counts.txt)
-#else
-  svd3(F, d);
-#endif
+  if (VARIANT == 2) svd3_jacobi(F, d);  // experiment: the iteration from V = I (rounds 1-5; tools/svd_bench.hip)
+  else svd3(F, d);
   float s[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) s[i] = clampf(d.s[i], minStrain, maxStrain);
