@@ -7,7 +7,8 @@ import subprocess
 import numpy as np
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_SO = os.path.join(_ROOT, "oracle", "_build", "libpies_oracle.so")
+# PIES_ORACLE_LIB: tests/test_sanitizers.py points a child process at the ASan/UBSan build (make -C oracle asan)
+_SO = os.environ.get("PIES_ORACLE_LIB") or os.path.join(_ROOT, "oracle", "_build", "libpies_oracle.so")
 
 POSITION, DISTANCE, TET, VOLUME, BEND, SHAPE, GOAL, TRIANGLES, LINES, NODES, STATICS, TRI_CONTACTS = range(12)
 FLAG_RELEASE_HINGE, FLAG_NODE_COLLISIONS, FLAG_COLLISION_RULE, FLAG_TRIANGLE_COLLISIONS, FLAG_PD_SOLVE_FP64, FLAG_SVD_PLAIN = 0, 1, 2, 3, 4, 5

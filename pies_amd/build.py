@@ -52,6 +52,7 @@ def _compile(src, force, exp=False):
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), _newest_header()):
         return obj, False
     extra = ["-DPIES_EXPERIMENTS"] if exp else []
+    extra += os.environ.get("PIES_EXTRA_FLAGS", "").split()  # compiler-flag experiments (development aid)
     if src.endswith(".hip"):
         cmd = [_hipcc(), "-c", src, "-o", obj] + COMMON + DEVICE + extra
     else:  # host-only translation units: plain C++ against the HIP runtime API
@@ -84,5 +85,46 @@ def build(force=False, verbose=False, exp=False):
     return lib
 
 
+def build_asan(verbose=False):
+    """libpies_hip_asan.so: the HOST side of the library (scene construction, schedules, planners, PD set-up, the C ABI) compiled
+    by g++ with -fsanitize=address,undefined and linked with the kernels' ordinary objects.  Loaded only by
+    tests/test_sanitizers.py, in a child process with the sanitizer runtime preloaded, through host-only handles
+    (PIES_DEVICE_NONE): no GPU is needed, nothing on a device is instrumented."""
+    build()  # the kernels' objects
+    lib = LIB.replace(".so", "_asan.so")
+    objdir = OBJDIR + "_asan"
+    os.makedirs(objdir, exist_ok=True)
+    gxx = shutil.which("g++")
+    if not gxx:
+        raise RuntimeError("g++ not found: the sanitizer build needs it")
+    objs, rebuilt = [], False
+    for src in sources():
+        if src.endswith(".hip"):
+            objs.append(os.path.join(OBJDIR, os.path.basename(src) + ".o"))
+            continue
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), _newest_header()):
+            continue
+        cmd = [gxx, "-std=c++17", "-O1", "-g", "-fPIC", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-ffp-contract=off",
+               "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I", INCLUDE, "-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("g++ failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        rebuilt = True
+    if rebuilt or not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(LIB):
+        cmd = [gxx, "-shared", "-fsanitize=address,undefined", "-o", lib] + objs + ["-L/opt/rocm/lib", "-lamdhip64", "-Wl,--no-undefined",
+                                                                                     "-Wl,-rpath,/opt/rocm/lib"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        if verbose:
+            print("built", lib)
+    return lib
+
+
 if __name__ == "__main__":
+    if "--asan" in sys.argv:
+        print(build_asan(verbose=True))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True, exp="--exp" in sys.argv))

@@ -95,7 +95,9 @@ PIES_DEV void svd3_finish(Svd3& d) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const float n2 = dot3f(d.b[i], d.b[i]);
-    d.rs[i] = n2 > kSvdTiny2 ? rsqrt_nr(n2) : 0.0f;  // a collapsed direction: s = 0, handled by svd3_recompose
+    const bool ok = n2 > kSvdTiny2;
+    const float r = rsqrt_nr(ok ? n2 : 1.0f);  // (straight-line: the three Newton chains interleave instead of standing behind three branches)
+    d.rs[i] = ok ? r : 0.0f;                   // a collapsed direction: s = 0, handled by svd3_recompose
     d.s[i] = n2 * d.rs[i];
   }
 }

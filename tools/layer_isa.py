@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 with tempfile.TemporaryDirectory() as tmp:
     out = os.path.join(tmp, "layer.s")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-S", os.path.join(ROOT, "pies_amd/csrc/layer_kernels.hip"), "-o", out, "-O3", "-std=c++17",
-                           "-ffp-contract=off", "-fno-fast-math", "--offload-arch=gfx950", "--cuda-device-only", "-I", os.path.join(ROOT, "include")],
+                           "-ffp-contract=off", "-fno-fast-math"] + sys.argv[1:] + ["--offload-arch=gfx950", "--cuda-device-only", "-I", os.path.join(ROOT, "include")],
                           stderr=subprocess.DEVNULL)
     txt = open(out).read()
 m = re.search(r"^_ZN4pies7k_layerILi256ELi0EEE.*?s_endpgm", txt, re.S | re.M)
