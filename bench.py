@@ -199,7 +199,7 @@ def roofline(solver, cls, bytes_per_unit, substeps=3, note=None, workload="confi
             out["note"] = note
         if ref:
             out["frac_rocprofv3"] = nbytes / launches / (ref * 1e-6) / 1e9 / HBM_PEAK_GBS
-        return out
+        return primary_from_profile(out)
     launches, ms, units, overhead_ms = solver.profile_in_situ(K[cls], substeps)
     if launches == 0 or ms <= 0:
         return None
@@ -231,6 +231,21 @@ def roofline(solver, cls, bytes_per_unit, substeps=3, note=None, workload="confi
         # overhead is in it, the bracket correction of the in-situ figure is not).  Not from a trace whose launches are mostly early
         # exits (an average far below the working launch's time).
         out["frac_rocprofv3"] = nbytes / launches / (out["rocprofv3_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+    return primary_from_profile(out)
+
+
+def primary_from_profile(out):
+    """`frac` / `achieved` are the figures anyone can recompute from the committed profile: bytes per launch / the kernel's AverageNs
+    in profiles/*_kernel_stats.csv / 8 TB/s.  The live measurement of this run moves to frac_in_situ / achieved_in_situ (it is 10-15 %
+    higher where both exist: its event brackets are corrected for their own cost, rocprofv3's durations are not).  Without a
+    committed profile of the kernel the live figure stays the primary one and `frac_source` says so."""
+    out["frac_in_situ"], out["achieved_in_situ"] = out["frac"], out["achieved"]
+    if out.get("frac_rocprofv3"):
+        out["frac"] = out["frac_rocprofv3"]
+        out["achieved"] = out["frac"] * HBM_PEAK_GBS
+        out["frac_source"] = "bytes_per_launch / rocprofv3_avg_us (%s) / peak" % out.get("rocprofv3_source")
+    else:
+        out["frac_source"] = "live HIP events of this run (no committed rocprofv3 trace of this kernel in this workload)"
     return out
 
 
@@ -314,6 +329,16 @@ def pd_rooflines(g, workload, substeps):
         # the same launch priced by the bytes its form of the matrix really has to move (the row dictionary streams no matrix)
         sp["frac_required_bytes"] = sp["frac"] * B["pd_spmv_required"] / B["pd_spmv"]
         sp["required_bytes_per_row"] = B["pd_spmv_required"]
+        if g.count(capi.ROW_STENCILS) and not g.count(capi.PD_WINDOW_ENTRIES):
+            # the row dictionary streams no matrix: SURVEY 8d's 8 nnz + 148 N would price bytes the launch never moves.  `frac` is
+            # the fraction by the bytes this form has to move; the survey's pricing stays as frac_survey_bytes
+            for k in ("frac", "frac_in_situ", "frac_rocprofv3", "achieved", "achieved_in_situ"):
+                if sp.get(k) is not None:
+                    sp[k + "_survey_bytes"] = sp[k]
+                    sp[k] = sp[k] * B["pd_spmv_required"] / B["pd_spmv"]
+            sp["frac_required_bytes"] = sp["frac"]
+            sp["bytes_per_launch_survey"] = sp["bytes_per_launch"]
+            sp["bytes_per_launch"] = sp["bytes_per_launch"] * B["pd_spmv_required"] / B["pd_spmv"]
         sp["matrix_form"] = ("row dictionary (%d stencils)" % g.count(capi.ROW_STENCILS) if g.count(capi.ROW_STENCILS) and not g.count(capi.PD_WINDOW_ENTRIES)
                              else "windowed SELL (%.3f stored entries per matrix entry, %.2f halo columns per row)" % (
                                  g.count(capi.PD_WINDOW_ENTRIES) / max(1, g.count(capi.SYSTEM_NNZ)), g.count(capi.PD_WINDOW_HALO) / max(1, g.count(capi.NODES)))
@@ -778,6 +803,13 @@ def run_config4(device):
     settled = 10 / (time.perf_counter() - t0)
     _, cand_settled = g.collision_stats()
     per_node = 32.0 + 27 * 8.0 + 16.0 * cand_settled / (10 * 4 * n)  # (the brackets below are taken in this state)
+    # The grid rebuild: SURVEY 8d's 92 B (key generation 20 + four sort passes of 16 + cell index 8) are the bytes of ONE (cell, node)
+    # entry; a node is entered into every cell of its range (NodeCompRange, Solver.cpp:877-901: ceil(fract(min) + 2R) cells per axis -
+    # 2 x 2 x 2 for this scene's radius 0.5, padding 0.5 and grid spacing 2).  Priced per entry:
+    pos_now, rad_now = g.positions.astype(np.float32), g.radii.astype(np.float32)
+    Rn = ((rad_now + np.float32(0.5)) / np.float32(2.0))[:, None]
+    mn = pos_now / np.float32(2.0) - Rn
+    entries_per_node = float(np.prod(np.ceil((mn - np.floor(mn)) + 2 * Rn), axis=1).mean())
     out = {"value": 10 / el, "unit": "substeps/s", "settled_value": settled,
            "settled_note": "ticks 12-21, one tick and one synchronisation per frame (the burst of the over-packed block is over, the "
                            "captured level launches have followed the passes down)",
@@ -788,11 +820,11 @@ def run_config4(device):
            "roofline": roofline(g, "collide", per_node, substeps=1, workload="config4", note="one bracket = the resolve pass of one "
                                 "iteration, taken after tick 22 (settled state); bytes per node = 32 + 27 x 8 + 16 x candidates the "
                                 "reference's loop looks at in that state"),
-           "roofline_grid_build": roofline(g, "hash", 92.0, substeps=1, workload="config4", note="one bracket = one grid rebuild: range, prefix "
-                                           "sum, emit, radix sort passes, cell index (about 92 B per node, SURVEY 8d - a figure for one "
-                                           "entry per node; a node of this scene overlaps 8 cells, i.e. 8 (key, node) entries of 12 bytes "
-                                           "that are emitted, counted and scattered twice and scanned once more: `traffic` is the PMC "
-                                           "figure of the whole rebuild, about ten times the survey's bytes)")}
+           "grid_entries_per_node": entries_per_node,
+           "roofline_grid_build": roofline(g, "hash", 92.0 * entries_per_node, substeps=1, workload="config4", note="one bracket = one grid "
+                                           "rebuild: range, prefix sum, emit, radix sort passes, cell index.  Bytes = SURVEY 8d's 92 B per "
+                                           "(cell, node) ENTRY x %.2f entries per node (a node is entered into every cell of its range; "
+                                           "rounds 1-5 priced one entry per node, which made this fraction unusable)" % entries_per_node)}
     # The same scene in the REFERENCE's node-node order (ascending node index, range from the live position: Solver.cpp:85-130), by
     # dependency levels of turns (round 5), from the settled state the run above has reached: frames of one tick + one synchronisation
     state = (g.positions, g.velocities)
@@ -937,7 +969,7 @@ def compact_line(full):
     c["projections_per_sec"] = _r(full["projections_per_sec"], 6)
     if full.get("roofline"):
         c["roofline"] = _pick(full["roofline"], ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us",
-                                                 "bytes_per_launch", "rocprofv3_avg_us", "overhead_clamped"))
+                                                 "bytes_per_launch", "rocprofv3_avg_us", "frac_in_situ", "valu_issue_frac", "overhead_clamped"))
     else:
         c["roofline"] = None
     cb = full.get("cpu_baseline")
@@ -954,7 +986,10 @@ def compact_line(full):
             if d is None:
                 return
         s[name] = _r(d)
-    put("exact_order", "exact_order", "value")
+    put("exact_order", "exact_order", "value")  # the reference's own visiting order on the same scene (the headline's LAYERED order is a re-ordered sweep)
+    put("unstructured_value", "other_configs", "unstructured_config2", "layered", "value")  # BASELINE says "tetgen beam": the Delaunay stand-in
+    put("unstructured_pd_value", "other_configs", "unstructured_config2", "pd", "value")
+    put("unstructured_pd_frac_pcg_iter", "other_configs", "unstructured_config2", "pd", "roofline_spmv", "frac")
     put("coloured", "coloured_schedule", "value")
     put("pies_tick", "tick_inclusive", "pies_tick_substeps_per_sec")
     put("config2_collisions_on", "config2_default_tick", "config2", "layered", "value")
@@ -991,9 +1026,6 @@ def compact_line(full):
     put("pd_1m_streamed_frac_pcg_iter", "scale_1m", "pd_1m_streamed", "roofline_spmv", "frac")
     put("pd_1m_streamed_frac_required", "scale_1m", "pd_1m_streamed", "roofline_spmv", "frac_required_bytes")
     put("pd_1m_streamed_frac_rocprofv3", "scale_1m", "pd_1m_streamed", "roofline_spmv", "frac_rocprofv3")
-    put("unstructured_value", "other_configs", "unstructured_config2", "layered", "value")
-    put("unstructured_pd_value", "other_configs", "unstructured_config2", "pd", "value")
-    put("unstructured_pd_frac_pcg_iter", "other_configs", "unstructured_config2", "pd", "roofline_spmv", "frac")
     put("config5_value", "config5_all_ranks", "value")
     put("value_export_inclusive", "tick_inclusive", "async_export_substeps_per_sec")
     c.update(s)

@@ -204,7 +204,6 @@ struct Svd3 {
   int sweeps = 0;      // sweeps of the certifying loop that rotated, + 1 (statistics)
   int rotations = 0;   // rotations applied (statistics)
   bool closed_form = false;
-  int dbg[6] = {0, 0, 0, 0, 0, 0};
 };
 
 // 1/sqrt(x) from an integer seed and three Newton steps (relative error ~1e-7).  Only *, fma and integer operations:
@@ -326,7 +325,7 @@ inline void jacobi_polish(Svd3& d, int p, int q) {
   const float beta = dot3f(bq, bq);
   const float gamma = dot3f(bp, bq);
   float t = gamma * recip_rough(beta - alpha);
-  if (!(std::fabs(t) < 2.5e-4f)) { t = 0.0f; d.dbg[3] += 1; }  // (also NaN: equal norms)
+  if (!(std::fabs(t) < 2.5e-4f)) t = 0.0f;  // (also NaN: equal norms)
   for (int k = 0; k < 3; ++k) {
     const float x = bp[k], y = bq[k];
     bp[k] = std::fmaf(-t, y, x);
@@ -395,17 +394,30 @@ inline Svd3 svd3(const float a[3][3]) {
     else if (n12) jacobi_rotate(d, 1, 2, s11, s22, s12);
     d.rotations += cnt != 0 ? 1 : 0;
   }
+  // the certifying sweeps: the three pairs tested on one snapshot of the six inner products; a clean snapshot ends the
+  // decomposition (its squared norms are the singular values'), otherwise a sweep of the plain iteration runs
+  float n0 = s00, n1 = s11, n2 = s22;
   if (cnt != 0) {
+    bool clean = false;
     for (d.sweeps = 0; d.sweeps < kSvdMaxSweeps; ++d.sweeps) {
+      n0 = dot3f(d.b[0], d.b[0]); n1 = dot3f(d.b[1], d.b[1]); n2 = dot3f(d.b[2], d.b[2]);
+      const float g02 = dot3f(d.b[0], d.b[2]), g12 = dot3f(d.b[1], d.b[2]), g01 = dot3f(d.b[0], d.b[1]);
+      clean = !(pair_needs(n0, n2, g02) || pair_needs(n1, n2, g12) || pair_needs(n0, n1, g01));
+      if (clean) break;
       const bool r02 = jacobi_pair(d, 0, 2);
       const bool r12 = jacobi_pair(d, 1, 2);
       const bool r01 = jacobi_pair(d, 0, 1);
-      if (d.sweeps == 0) { d.dbg[0] = r02; d.dbg[1] = r12; d.dbg[2] = r01; }
       d.rotations += (r02 ? 1 : 0) + (r12 ? 1 : 0) + (r01 ? 1 : 0);
-      if (!(r02 || r12 || r01)) break;
     }
+    if (!clean) { n0 = dot3f(d.b[0], d.b[0]); n1 = dot3f(d.b[1], d.b[1]); n2 = dot3f(d.b[2], d.b[2]); }
   }
-  svd3_finish(d);
+  const float nn[3] = {n0, n1, n2};
+  for (int i = 0; i < 3; ++i) {
+    const bool ok = nn[i] > kSvdTiny2;
+    const float r = rsqrt_nr(ok ? nn[i] : 1.0f);
+    d.rs[i] = ok ? r : 0.0f;
+    d.s[i] = nn[i] * d.rs[i];
+  }
   return d;
 }
 

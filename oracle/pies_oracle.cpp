@@ -137,8 +137,7 @@ static inline void tet_emit(const float Fhat[3][3], std::array<vec3, 4>& out) {
 // read after single-threaded ticks only.
 static bool g_svd_plain = false;  // ora_set_flag(*, 5, 1): the plain iteration from V = I (a process-wide replay switch: statistics, and the test that
                                   // both decompositions give the same projections)
-static uint64_t g_svd_stats[8];
-static uint64_t g_svd_dbg[6];  // calls, closed-form starts, rotations, certifying sweeps, sweeps histogram (1, 2, 3, >= 4)
+static uint64_t g_svd_stats[8];  // calls, closed-form starts, rotations, certifying sweeps, sweeps histogram (1, 2, 3, >= 4)
 static inline void svd_stats_add(const Svd3& d) {
   g_svd_stats[0] += 1;
   g_svd_stats[1] += d.closed_form ? 1 : 0;
@@ -146,7 +145,6 @@ static inline void svd_stats_add(const Svd3& d) {
   const int sw = d.sweeps + 1;  // sweeps run, the clean one included (0 + 1 for an element that needed none: see svd3)
   g_svd_stats[3] += static_cast<uint64_t>(sw);
   g_svd_stats[4 + (sw >= 4 ? 3 : sw - 1)] += 1;
-  for (int i = 0; i < 6; ++i) g_svd_dbg[i] += d.dbg[i];
 }
 
 // Constraints.cpp:76-128
@@ -1949,7 +1947,6 @@ void ora_tick(ora_solver* s) { s->tick(); }
 
 // ------------------------------- single-operation entry points (KATs) ------------------------
 // a: row-major 3x3; out: row-major U*diag(snew)*V^T with snew = clamp(s) (+ flip) as the tet functor
-void ora_svd_dbg(uint64_t* out) { for (int i = 0; i < 6; ++i) { out[i] = g_svd_dbg[i]; g_svd_dbg[i] = 0; } }
 void ora_svd_stats(uint64_t* out, int reset) {
   for (int i = 0; i < 8; ++i) out[i] = g_svd_stats[i];
   if (reset) for (int i = 0; i < 8; ++i) g_svd_stats[i] = 0;

@@ -243,15 +243,32 @@ PIES_DEV void svd3(const float a[3][3], Svd3& d) {
     else if (n02) jacobi_rotate<0, 2>(d, s00, s22, s02);
     else if (n12) jacobi_rotate<1, 2>(d, s11, s22, s12);
   }
+  // The certifying sweeps: all three pairs are tested on one snapshot of the six inner products; a clean snapshot ends the
+  // decomposition and its squared norms are the singular values' (one branch and 30 instructions where three separate tests
+  // cost three branches and 41, and svd3_finish's norms another 9); otherwise a sweep of the plain iteration runs.
+  float n0 = s00, n1 = s11, n2 = s22;  // (cnt == 0: B = A, nothing was rotated)
   if (cnt != 0) {
+    bool clean = false;
     for (int sweep = 0; sweep < kSvdMaxSweeps; ++sweep) {
-      const bool r02 = jacobi_pair<0, 2>(d);
-      const bool r12 = jacobi_pair<1, 2>(d);
-      const bool r01 = jacobi_pair<0, 1>(d);
-      if (!(r02 || r12 || r01)) break;
+      n0 = dot3f(d.b[0], d.b[0]); n1 = dot3f(d.b[1], d.b[1]); n2 = dot3f(d.b[2], d.b[2]);
+      const float g02 = dot3f(d.b[0], d.b[2]), g12 = dot3f(d.b[1], d.b[2]), g01 = dot3f(d.b[0], d.b[1]);
+      const bool t02 = pair_needs(n0, n2, g02), t12 = pair_needs(n1, n2, g12), t01 = pair_needs(n0, n1, g01);
+      clean = !(int(t02) | int(t12) | int(t01));  // (no short circuit: one branch)
+      if (clean) break;
+      (void)jacobi_pair<0, 2>(d);
+      (void)jacobi_pair<1, 2>(d);
+      (void)jacobi_pair<0, 1>(d);
     }
+    if (!clean) { n0 = dot3f(d.b[0], d.b[0]); n1 = dot3f(d.b[1], d.b[1]); n2 = dot3f(d.b[2], d.b[2]); }  // (sweeps exhausted)
   }
-  svd3_finish(d);
+  const float nn[3] = {n0, n1, n2};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const bool ok = nn[i] > kSvdTiny2;
+    const float r = rsqrt_nr(ok ? nn[i] : 1.0f);
+    d.rs[i] = ok ? r : 0.0f;  // a collapsed direction: s = 0, handled by svd3_recompose
+    d.s[i] = nn[i] * d.rs[i];
+  }
 }
 
 // t[K] = sg * (u_I x u_J): the direction a collapsed column K leaves open, oriented so that det(U) det(V) = +1
