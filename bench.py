@@ -1100,7 +1100,9 @@ def main():
 
     rank, local_rank, world = dist_env()
     dist = None
-    if world > 1:
+    # PIES_BENCH_FORCE_DIST=1: the N > 1 branch with a world of ONE rank (tests/test_bench_distributed.py): process-group init over RCCL,
+    # the 4-byte all-reduce barrier and aggregate() on device tensors, on a one-GPU box
+    if world > 1 or os.environ.get("PIES_BENCH_FORCE_DIST") == "1":
         import torch
         import torch.distributed as dist
         backend = os.environ.get("PIES_BENCH_BACKEND", "nccl")  # "gloo": test hook for boxes with fewer GPUs than ranks

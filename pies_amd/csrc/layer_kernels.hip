@@ -25,7 +25,7 @@ constexpr uint32_t kOffStride = kLayerMaxCols + 2;  // colour offsets of one seg
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also drains the global loads in flight
 // (s_waitcnt vmcnt(0)), i.e. the constraint records requested ahead for the next colours.
 PIES_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-constexpr int kDistPreload = 12;  // colours of a distance segment whose records a lane requests up front
+constexpr int kDistPreloadMax = 12;  // colours of a distance segment whose records a lane requests up front (fewer in the 128-register variants)
 constexpr int kBatch = 4;         // node records a lane requests before it consumes the first (the load phase is written out for 4)
 
 #ifdef PIES_EXPERIMENTS  // in-kernel time stamps of a diagnostic build (tools/layer_timeline.py): never part of the product build
@@ -45,8 +45,13 @@ constexpr int kStampsPerTile = 128;
 PIES_DEV uint32_t lo16(uint32_t v) { return v & 0xFFFFu; }
 PIES_DEV uint32_t hi16(uint32_t v) { return v >> 16; }
 
-template <int BLOCK, int TETV>
-__global__ void __launch_bounds__(BLOCK) k_layer(NodeArrays nd, LayerData D, LayerLaunch L, LayerParams P) {
+// WPE: wavefronts per SIMD the kernel is compiled for (the second argument of HIP's __launch_bounds__).  A launch with fewer tiles
+// than compute units (config 2: 125) lasts as long as one wavefront's instruction stream and takes all the registers that shorten
+// it (1: up to 256 at 256 / 512 threads); a launch with several tiles per compute unit (1M particles: 400, the unstructured beam) is
+// bound by throughput and wants two 512-thread workgroups resident per compute unit: 4 wavefronts per SIMD, 128 registers.
+template <int BLOCK, int TETV, int WPE = 1>
+__global__ void __launch_bounds__(BLOCK, WPE) k_layer(NodeArrays nd, LayerData D, LayerLaunch L, LayerParams P) {
+  constexpr int kDistPreload = (WPE > 1 || BLOCK > 512) ? 6 : kDistPreloadMax;
   extern __shared__ float4 lds[];
   float4* __restrict__ sp = lds;                                                  // node records of the group
   float* __restrict__ srad = reinterpret_cast<float*>(sp + D.maxGroupNodes);      // their radii
@@ -104,7 +109,20 @@ __global__ void __launch_bounds__(BLOCK) k_layer(NodeArrays nd, LayerData D, Lay
   for (uint32_t s = 0; s < L.nseg; ++s) {
     const uint32_t kind = L.seg[s].kind, ncol = L.seg[s].ncol;
     const uint32_t* __restrict__ off = soff + s * kOffStride;
-    if (kind == LAYER_TET) {
+    if (kind == LAYER_TET && (WPE > 1 || BLOCK > 512)) {
+      // the 128-register variants: no record is held across a projection (the next colour's records in flight cost 14 registers,
+      // and with four wavefronts per SIMD another wavefront's arithmetic covers the load)
+      for (uint32_t c = 0; c < ncol; ++c) {
+        for (uint32_t t = off[c] + tid; t < off[c + 1]; t += BLOCK) {
+          const uint2 jd = D.tc_lid[t];
+          const uint32_t i1 = lo16(jd.x), i2 = hi16(jd.x), i3 = lo16(jd.y), i4 = hi16(jd.y);
+          float4 x1 = sp[i1], x2 = sp[i2], x3 = sp[i3], x4 = sp[i4];
+          tet_core<TETV>(x1, x2, x3, x4, D.tc_q0[t], D.tc_q1[t], D.tc_q2[t]);
+          sp[i1] = x1; sp[i2] = x2; sp[i3] = x3; sp[i4] = x4;
+        }
+        lds_barrier();
+      }
+    } else if (kind == LAYER_TET) {
       // the record of the next colour is requested before this colour's SVD (unconditionally, from a clamped slot:
       // a conditional load would have to be waited for where the branches join)
       const uint32_t last = off[ncol] > off[0] ? off[ncol] - 1 : 0;  // a valid slot (the segment is not empty)
@@ -339,6 +357,8 @@ hipError_t layer_prepare(uint32_t maxGroupNodes) {
   if (bytes <= 64 * 1024) return hipSuccess;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer<256, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer<512, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer<512, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer<256, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer<1024, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   return e;
 }
@@ -368,7 +388,10 @@ void launch_layer(hipStream_t st, const NodeArrays& nd, const LayerData& D, cons
   // (measured at 1M particles: 162 substeps/s with the class-wide choice, 187 with 512 throughout, 174 with 256, 138 with 1 024).
   uint32_t want = forceBlock ? forceBlock : L.maxClass;
   if (!forceBlock && L.groups > 256u) want = std::min<uint32_t>(want, 512u);  // (256 compute units)
-  if (want <= 256) hipLaunchKernelGGL((k_layer<256, 0>), dim3(L.groups), dim3(256), lds, st, nd, D, L, P);
+  const bool throughput = L.groups > 256u;  // several tiles per compute unit
+  if (want <= 256 && throughput) hipLaunchKernelGGL((k_layer<256, 0, 4>), dim3(L.groups), dim3(256), lds, st, nd, D, L, P);
+  else if (want <= 256) hipLaunchKernelGGL((k_layer<256, 0>), dim3(L.groups), dim3(256), lds, st, nd, D, L, P);
+  else if (want <= 512 && throughput) hipLaunchKernelGGL((k_layer<512, 0, 4>), dim3(L.groups), dim3(512), lds, st, nd, D, L, P);
   else if (want <= 512) hipLaunchKernelGGL((k_layer<512, 0>), dim3(L.groups), dim3(512), lds, st, nd, D, L, P);
   else hipLaunchKernelGGL((k_layer<1024, 0>), dim3(L.groups), dim3(1024), lds, st, nd, D, L, P);
 }

@@ -77,3 +77,25 @@ def test_two_rank_bench_end_to_end_on_one_gpu():
     assert r["roofline"]["frac"] > 0 and r["cpu_baseline"]["value"] > 0
     # the second timed region: BASELINE configs[4]'s pattern (PD + contacts), one body per rank, the same max / sum reduce
     assert r["config5_value"] > 0
+
+
+@pytest.mark.gpu
+def test_rccl_branch_runs_on_one_gpu():
+    """The RCCL branch itself - init_process_group("nccl"), the 4-byte all-reduce barrier on a device tensor, aggregate() on device
+    tensors - executed on real hardware: a world of ONE rank started the way the driver starts N (a fresh process through
+    torch.distributed.run; nothing re-executes after the GPU is initialised), with PIES_BENCH_FORCE_DIST=1 taking main() down the
+    N > 1 path.  (The two-rank test above has to carry its record over gloo: two ranks cannot share one card under RCCL.)"""
+    import json
+    import subprocess
+    env = dict(os.environ, PIES_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PIES_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+           "--dims", "10", "10", "60", "--quick"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["steps"] == 5 and r["value"] > 0
+    assert r["value"] * r["ms_per_step"] * r["steps"] / 1e3 == pytest.approx(5, rel=1e-4)

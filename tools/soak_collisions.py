@@ -18,13 +18,15 @@ import scenes  # noqa: E402
 from pies_amd import capi  # noqa: E402
 
 
-def main(nscenes, seed, order="pairs"):
+def main(nscenes, seed, order="pairs", max_dim=34):
+    """order: pairs (the device's pair order against the oracle's rule 2), turns (the reference's order by dependency levels of
+    turns against the oracle's plain loop), groups (the group order against the oracle's rule 1)"""
     turns = order == "turns"
     capi.set_tuning("PIES_REFERENCE_TURNS", "1" if turns else None)
     rng = np.random.default_rng(seed)
     t0 = time.time()
     for sc in range(nscenes):
-        dims = tuple(int(v) for v in rng.integers(4, 34, 3))
+        dims = tuple(int(v) for v in rng.integers(4, max_dim, 3))
         spacing = float(rng.choice([0.8, 0.9, 1.0]))
         jitter = float(rng.choice([0.02, 0.05, 0.15]))
         grid = float(rng.choice([2.0, 2.0, 1.0, 0.6]))
@@ -42,9 +44,10 @@ def main(nscenes, seed, order="pairs"):
             s = (mod.OracleSolver if which == "oracle" else mod.Solver)(scenes.pbd_options(mod, iters, gridSpacing=grid))
             s.add_nodes_raw(p, vel=v, radius=r, invMass=np.ones(len(p), np.float32))
             if which == "oracle":
-                s.set_flag(ora.FLAG_COLLISION_RULE, 0 if turns else 2)
+                s.set_flag(ora.FLAG_COLLISION_RULE, 0 if turns else 1 if order == "groups" else 2)
             else:
-                s.set_flag(capi.FLAG_COLLISION_ORDER, capi.COLLISION_ORDER_REFERENCE if turns else capi.COLLISION_ORDER_PAIRS)
+                s.set_flag(capi.FLAG_COLLISION_ORDER, capi.COLLISION_ORDER_REFERENCE if turns else
+                           capi.COLLISION_ORDER_GROUPS if order == "groups" else capi.COLLISION_ORDER_PAIRS)
             s.tick(2)
             res.append((s.positions.copy(), s.velocities.copy(), s.collision_pairs, s.failed))
             if which != "oracle":
@@ -56,6 +59,7 @@ def main(nscenes, seed, order="pairs"):
             assert np.array_equal(res[1][k], res[2][k]), ("run to run", k, state)
         assert res[0][2] == res[1][2] == res[2][2], ("pairs", state, res[0][2], res[1][2])
         print("scene %d ok: %s, %d particles, %d resolved pairs, health %s, %.0f s" % (sc, state, len(p), res[1][2], h, time.time() - t0), flush=True)
+    capi.set_tuning("PIES_REFERENCE_TURNS", None)
     print("done: %d scenes" % nscenes)
 
 

@@ -44,12 +44,12 @@ def device_run(state, ticks, forced, env):
     return out
 
 
-def main(nscenes, seed):
+def main(nscenes, seed, max_w=15, max_d=21):
     rng = np.random.default_rng(seed)
     worst = 0.0
     t0 = time.time()
     for sc in range(nscenes):
-        state = (int(rng.integers(4, 15)), int(rng.integers(4, 21)), int(rng.integers(3, 13)), int(rng.integers(3, 19)),
+        state = (int(rng.integers(4, max_w)), int(rng.integers(4, max_d)), int(rng.integers(3, max_w - 2)), int(rng.integers(3, max_d - 2)),
                  float(rng.uniform(0.0, 1.5)), float(rng.uniform(0.0, 1.5)), float(rng.uniform(0.01, 0.08)), float(rng.uniform(-2.5, -0.5)),
                  int(rng.integers(2, 6)))
         ticks = 5
