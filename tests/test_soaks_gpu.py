@@ -25,14 +25,14 @@ def test_soak_triangle_soups(pies):
 @pytest.mark.parametrize("order", ["pairs", "turns", "groups"])
 def test_soak_collision_scenes(pies, order):
     import soak_collisions
-    soak_collisions.main(10, 61, order, max_dim=16)
+    soak_collisions.main(10, 61, order, max_dim=24)
 
 
 def test_soak_layered_plans(pies):
     import soak_layered
-    soak_layered.main(5, 41)
+    soak_layered.main(8, 41)
 
 
 def test_soak_pd_contact_scenes(pies):
     import soak_pd
-    soak_pd.main(5, 29, max_w=9, max_d=12)
+    soak_pd.main(5, 29, max_w=12, max_d=16)

@@ -44,7 +44,8 @@ def main(nscenes, seed, order="pairs", max_dim=34):
             s = (mod.OracleSolver if which == "oracle" else mod.Solver)(scenes.pbd_options(mod, iters, gridSpacing=grid))
             s.add_nodes_raw(p, vel=v, radius=r, invMass=np.ones(len(p), np.float32))
             if which == "oracle":
-                s.set_flag(ora.FLAG_COLLISION_RULE, 0 if turns else 1 if order == "groups" else 2)
+                # (the group order needs cell ranges of at most 2 cells per axis: with a finer grid the device runs the reference's loop)
+                s.set_flag(ora.FLAG_COLLISION_RULE, 0 if turns else (1 if grid >= 2.0 else 0) if order == "groups" else 2)
             else:
                 s.set_flag(capi.FLAG_COLLISION_ORDER, capi.COLLISION_ORDER_REFERENCE if turns else
                            capi.COLLISION_ORDER_GROUPS if order == "groups" else capi.COLLISION_ORDER_PAIRS)
