@@ -15,10 +15,10 @@ with tempfile.TemporaryDirectory() as tmp:
                            "-ffp-contract=off", "-fno-fast-math"] + sys.argv[1:] + ["--offload-arch=gfx950", "--cuda-device-only", "-I", os.path.join(ROOT, "include")],
                           stderr=subprocess.DEVNULL)
     txt = open(out).read()
-m = re.search(r"^_ZN4pies7k_layerILi256ELi0EEE.*?s_endpgm", txt, re.S | re.M)
+m = re.search(r"^_ZN4pies7k_layerILi256ELi0ELi1EEE.*?s_endpgm", txt, re.S | re.M)
 lines = m.group(0).splitlines()
-meta = re.search(r"_ZN4pies7k_layerILi256ELi0EEE.*?; NumVgprs: (\d+).*?; ScratchSize: (\d+).*?; Occupancy: (\d+)", txt, re.S)
-print("k_layer<256, 0>: %d lines of ISA, %s VGPRs, scratch %s bytes, occupancy %s" % (len(lines), meta.group(1), meta.group(2), meta.group(3)))
+meta = re.search(r"_ZN4pies7k_layerILi256ELi0ELi1EEE.*?; NumVgprs: (\d+).*?; ScratchSize: (\d+).*?; Occupancy: (\d+)", txt, re.S)
+print("k_layer<256, 0, 1>: %d lines of ISA, %s VGPRs, scratch %s bytes, occupancy %s" % (len(lines), meta.group(1), meta.group(2), meta.group(3)))
 # the tetrahedral colour loop: the first loop whose body holds four 12/16-byte LDS reads followed (later) by four LDS writes and a barrier
 blocks, cur = [], None
 for l in lines:
