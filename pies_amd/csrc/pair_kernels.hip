@@ -22,6 +22,9 @@
 // pass, whether the two can have touched (d0 - e_i - e_j < r_i + r_j).  Only if one such pair exists is the pass repeated from
 // the saved state, the nodes that left their slack now listing every node they share a cell with; a repeat that fails the
 // same test is counted (pies_get_collision_health: passes_inexact).
+#include <map>
+#include <mutex>
+#include <utility>
 #include <climits>
 #include <cstdlib>
 #include <cstdint>
@@ -1135,6 +1138,9 @@ PIES_DEV void pair_level4(const HashArrays& H, const PairArrays& P, float fricti
         const uint32_t iy = at + nx + static_cast<uint32_t>(__popcll(my & ((1ull << lane) - 1ull)));
         if (moveX && ix < P.frCap) dst[ix] = x;
         if (moveY && iy < P.frCap) dst[iy] = y;
+        // a sub-list that is full: the node's remaining pairs would never be visited - the pass goes to the sequential loop
+        // instead (flag 2, like turn_advance; the capacity leaves ~120 entries of margin, this is the net under it)
+        if (lane == 0 && at + nx + ny > P.frCap) atomicOr(&P.ctl[kPairFlags], 2u);
       }
     };
     // ---- the visits: the workgroup's quads take the overlapping pairs, blockDim.x / 4 at a time (a workgroup of one wavefront: 16; of four: 64)
@@ -1245,7 +1251,7 @@ PIES_DEV bool pair_grid_barrier(uint32_t* counter, uint32_t nblocks, uint32_t& p
     uint32_t spins = 0, ok = 1u;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 20)) { ok = 0u; break; }  // ~1 s
+      if (++spins > (1u << 14)) { ok = 0u; break; }  // ~16 ms: a starved barrier (not all workgroups resident) gives the pass to the sequential loop quickly
     }
     // (a workgroup that gives up says so; one that arrives late and finds the counter past its target checks the word)
     if (!ok) __hip_atomic_store(counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1294,6 +1300,23 @@ uint32_t pair_repeat_blocks(int device) {
   if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_pair_repeat, kRoundBlock, 0) != hipSuccess) return 0;
   return static_cast<uint32_t>(std::max(0, perCu)) * static_cast<uint32_t>(std::max(0, prop.multiProcessorCount)) / 2u;
+}
+
+uint32_t turn_finish_blocks(int device);
+// The grid-barrier kernels' resident workgroup counts, per DEVICE (a process may hold handles on several): looked up for
+// the device that is current at the launch (the solver's), computed once per device under a mutex.
+static uint32_t resident_blocks_of_current_device(int which, uint32_t (*count)(int)) {
+  static std::mutex mu;
+  static std::map<std::pair<int, int>, uint32_t> cache;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_pair(which, dev);
+  const auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  const uint32_t v = count(dev);
+  cache[key] = v;
+  return v;
 }
 
 // Whatever levels are left after the captured rounds (and all levels of a repeated pass): one workgroup, a workgroup barrier
@@ -1870,7 +1893,7 @@ uint32_t launch_collide_turns(hipStream_t st, const HashArrays& H, const PairArr
     for (uint32_t r = 2; r < 2u + captured; ++r) {
       hipLaunchKernelGGL(k_turn_round, level, dim3(kTurnBlock), 0, st, H, P, gridSpacing, friction, staticThreshold, r, repeat); ++launches;
     }
-    static const uint32_t residentFinish = turn_finish_blocks(-1);
+    const uint32_t residentFinish = resident_blocks_of_current_device(1, turn_finish_blocks);
     uint32_t finishCap = 128u;  // PIES_TURN_FINISH_BLOCKS: workgroups behind the grid barrier (a level of config 4 holds ~460 turns, one wavefront each; measured with every level behind the barrier: 512 workgroups 293 ms per tick, 128: 217, 64: 284 - captured launches: 160-172)
     if (const char* e = tuning_env("PIES_TURN_FINISH_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) finishCap = static_cast<uint32_t>(v); }
     const uint32_t finishBlocks = std::min<uint32_t>(std::min<uint32_t>(finishCap, residentFinish), level.x);
@@ -1924,7 +1947,7 @@ uint32_t launch_collide_pairs(hipStream_t st, const HashArrays& H, const PairArr
   const dim3 level4(std::max<uint32_t>(1u, std::min<uint32_t>(cap4, (n + kQuadNodes * look4 - 1u) / (kQuadNodes * look4))));
   const dim3 levelRepeat4(std::max<uint32_t>(1u, std::min<uint32_t>(repeatCap, level4.x)));
   // the repeat's levels in one launch of resident workgroups (PIES_PAIR_REPEAT_LAUNCHES=1: captured level launches as in rounds 3-4)
-  static const uint32_t residentRepeat = pair_repeat_blocks(-1);
+  const uint32_t residentRepeat = resident_blocks_of_current_device(0, pair_repeat_blocks);
   uint32_t repeatBlocks = std::min<uint32_t>(std::min<uint32_t>(512u, residentRepeat), level4.x);
   if (const char* e = tuning_env("PIES_PAIR_REPEAT_LAUNCHES"); e && e[0] == '1') repeatBlocks = 0;
   hipLaunchKernelGGL(k_pair_save, perNode, dim3(kBlock), 0, st, H, P, nd.pos, nd.vel, nd.radius, friction, staticThreshold); ++launches;

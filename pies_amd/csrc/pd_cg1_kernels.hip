@@ -26,6 +26,8 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 #include "pd_cg_device.h"
 #include "pd_rhs_device.h"
@@ -149,14 +151,14 @@ __global__ void __launch_bounds__(kBlock) k_cg1_init(CgArrays A, const float4* _
   Vec3f* __restrict__ t0 = A.t1[0];
   // what a row does with (K x)_i (fp64 sums, see below), its own x and its right-hand side
   auto finish = [&](uint32_t i, double sx, double sy, double sz, const float4 xi, float4 fi) {
-    float cx = 0.f, cy = 0.f, cz = 0.f;
-    contact_row(A, i, [&](uint32_t j, float& px, float& py, float& pz) { const float4 v = x[j]; px = v.x; py = v.y; pz = v.z; }, cx, cy, cz);
+    double cx = 0.0, cy = 0.0, cz = 0.0;
+    contact_row<4, double>(A, i, [&](uint32_t j, float& px, float& py, float& pz) { const float4 v = x[j]; px = v.x; py = v.y; pz = v.z; }, cx, cy, cz);
     if (!RHS) fi = f[i];
     const float cd = A.cdiag[i], di = A.dinv[i];
     const double cdd = static_cast<double>(cd);
-    const float rx = static_cast<float>(static_cast<double>(fi.x) - (fma(cdd, static_cast<double>(xi.x), sx) + static_cast<double>(cx)));
-    const float ry = static_cast<float>(static_cast<double>(fi.y) - (fma(cdd, static_cast<double>(xi.y), sy) + static_cast<double>(cy)));
-    const float rz = static_cast<float>(static_cast<double>(fi.z) - (fma(cdd, static_cast<double>(xi.z), sz) + static_cast<double>(cz)));
+    const float rx = static_cast<float>(static_cast<double>(fi.x) - (fma(cdd, static_cast<double>(xi.x), sx) + cx));
+    const float ry = static_cast<float>(static_cast<double>(fi.y) - (fma(cdd, static_cast<double>(xi.y), sy) + cy));
+    const float rz = static_cast<float>(static_cast<double>(fi.z) - (fma(cdd, static_cast<double>(xi.z), sz) + cz));
     const float tx = di * rx, ty = di * ry, tz = di * rz;
     t0[i] = Vec3f{tx, ty, tz};
     acc9[0] += rx * tx; acc9[1] += ry * ty; acc9[2] += rz * tz;
@@ -474,16 +476,24 @@ __global__ void __launch_bounds__(kBlock) k_cg1_iter(CgArrays A, float4* __restr
   }
 }
 
-// the windowed kernel takes its window as dynamic LDS: above 64 KB a kernel has to be told (once per process)
+// The windowed kernels take their window as dynamic LDS: above 64 KB a kernel has to be told - per DEVICE (the attribute belongs to
+// the function on the device that is current when it is set), so the limit that has been raised is remembered per device, under a
+// mutex (handles on different devices finalise from different threads).
 static bool window_lds_ok(uint32_t bytes) {
-  static uint32_t allowed = 64u * 1024u;
-  if (bytes <= allowed) return true;
+  if (bytes <= 64u * 1024u) return true;
+  static std::mutex mu;
+  static std::map<int, uint32_t> allowed;  // device -> the limit its five windowed kernels have been raised to
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lock(mu);
+  const auto it = allowed.find(dev);
+  if (it != allowed.end() && bytes <= it->second) return true;
   const void* fns[] = {reinterpret_cast<const void*>(&k_cg1_init<true, true>),  reinterpret_cast<const void*>(&k_cg1_init<false, true>),
                        reinterpret_cast<const void*>(&k_cg1_first<true>), reinterpret_cast<const void*>(&k_cg1_iter<true, true>),
                        reinterpret_cast<const void*>(&k_cg1_iter<false, true>)};
   for (const void* f : fns)
     if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)) != hipSuccess) return false;
-  allowed = bytes;
+  allowed[dev] = bytes;
   return true;
 }
 

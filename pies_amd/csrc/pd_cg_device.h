@@ -75,7 +75,10 @@ PIES_DEV bool all_converged(const float rr[3], const float bb[3], float tol2) {
 // contacts, and one lane walking them one by one made the SpMV ten times slower than without contacts).
 // (kAhead: contacts whose loads are requested together; the one-launch-per-iteration kernels, whose fetch is three gathers, take 1:
 // twelve fetches in flight cost them 60 registers for a path a contact-light substep takes for a handful of rows)
-template <int kAhead = 4, class Fetch> PIES_DEV void contact_row(const CgArrays& A, uint32_t i, Fetch fetch, float& sx, float& sy, float& sz) {
+// ACC: float, or double in the residual kernels (the row's contact terms are w = 1e4 times coordinates and cancel against the
+// right-hand side like the elastic terms do: summed in fp32 with thousands of contacts the residual - and with it the solution -
+// carried 2.6 x the deviation of the reference's own fp32 solve from the fp64 yardstick; tests/test_tri_collisions_gpu.py)
+template <int kAhead = 4, class ACC = float, class Fetch> PIES_DEV void contact_row(const CgArrays& A, uint32_t i, Fetch fetch, ACC& sx, ACC& sy, ACC& sz) {
   if (!A.tIncCnt || *A.tUsedCount == 0u) return;  // (no contact in this substep: one uniform word instead of a load per row)
   const uint32_t tc = A.tIncCnt[i];
   if (!tc) return;
@@ -87,7 +90,8 @@ template <int kAhead = 4, class Fetch> PIES_DEV void contact_row(const CgArrays&
         const float coef = A.rowCoef[off + t];
         float q[3];
         fetch(A.rowCol[off + t], q[0], q[1], q[2]);
-        sx = fmaf(coef, q[0], sx); sy = fmaf(coef, q[1], sy); sz = fmaf(coef, q[2], sz);
+        sx = fma(static_cast<ACC>(coef), static_cast<ACC>(q[0]), sx); sy = fma(static_cast<ACC>(coef), static_cast<ACC>(q[1]), sy);
+        sz = fma(static_cast<ACC>(coef), static_cast<ACC>(q[2]), sz);
       }
       return;
     }
@@ -115,9 +119,9 @@ template <int kAhead = 4, class Fetch> PIES_DEV void contact_row(const CgArrays&
 #pragma unroll
       for (int t = 0; t < 3; ++t)
         if (t < terms) {
-          sx = fmaf(-kTriContactW, q[u][t][0], sx);
-          sy = fmaf(-kTriContactW, q[u][t][1], sy);
-          sz = fmaf(-kTriContactW, q[u][t][2], sz);
+          sx = fma(static_cast<ACC>(-kTriContactW), static_cast<ACC>(q[u][t][0]), sx);
+          sy = fma(static_cast<ACC>(-kTriContactW), static_cast<ACC>(q[u][t][1]), sy);
+          sz = fma(static_cast<ACC>(-kTriContactW), static_cast<ACC>(q[u][t][2]), sz);
         }
     }
   }

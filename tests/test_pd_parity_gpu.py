@@ -23,12 +23,10 @@ def tol_for(p):
 
 # Every comparison with the oracle is also RECORDED: the largest |device - oracle| per test, as a multiple of the lattice spacing
 # (1.0 in all these scenes) and of the gate it was held against.  The record goes to gpurun_out/pd_deviation.json (DESIGN.md
-# section 7 quotes it; profiles/r03_pd_deviation.json is a copy).  GATE[...] are the gates of the full-size scenes, in units of the
-# lattice spacing: at most four times the largest deviation measured on the MI355X in round 3 - 7.2e-4 on config 3 (two ticks,
-# coordinates up to 250), 7.4e-4 on config 5's body with binding contacts (three teacher-forced ticks, coordinates up to 400),
-# 1.25e-4 on the 5 000-contact plates.  (1e-4 x spacing, SURVEY 8c's proposal, is what the 10^3 lattice meets: 1.5e-4.)
+# section 7 quotes it; profiles/r06_pd_deviation.json is a copy).  The full-size scenes (config 3, config 5's body with binding
+# contacts, the 5 000-contact plates) have NO fitted gate (rounds 3-5 held them against "four times the largest deviation
+# measured"): they are held against the yardstick - yardstick() below - and their distance from the fp32 oracle is recorded only.
 _RECORD = {}
-GATE = {"config3_l100k": 2.8e-3, "config5_l250k_contacts": 2.9e-3, "thousands_of_contacts": 4.0e-4}
 
 
 def record(test, what, deviation, gate):
@@ -51,18 +49,26 @@ def within(test, g, o, gate, what="positions"):
     return d
 
 
-def yardstick(test, g, o32, o64, spacing=1.0):
-    """The PD tolerance against a yardstick instead of a fitted gate (round 4): o64 is the oracle with its global solve in
-    double (the same fp32 matrix and right-hand side, FLAG_PD_SOLVE_FP64) - what the reference's direct solve would return
-    without fp32 round-off.  Recorded: |device - fp64| and |oracle32 - fp64| (positions).  The device passes when it is no
-    further from the fp64 solve than twice what the reference's own fp32 arithmetic is, or within SURVEY 8c's 1e-4 x spacing."""
-    d_dev = float(np.abs(g.positions - o64.positions).max())
-    d_ref = float(np.abs(o32.positions - o64.positions).max())
-    gate = max(2.0 * d_ref, 1e-4 * spacing)
-    record(test, "device_vs_fp64", d_dev, gate)
-    record(test, "oracle32_vs_fp64", d_ref, gate)
-    assert d_dev <= gate, (test, "device vs fp64 %.3g, oracle32 vs fp64 %.3g, gate %.3g" % (d_dev, d_ref, gate))
-    return d_dev, d_ref
+def yardstick(test, g, o32, o64, spacing=1.0, names=("positions",), dt=0.012):
+    """The PD tolerance against a yardstick instead of a fitted gate: o64 is the oracle with its global solve in double (the same
+    fp32 matrix and right-hand side, FLAG_PD_SOLVE_FP64) - what the reference's direct solve would return without fp32 round-off.
+    Per state array: |device - fp64| and |oracle32 - fp64| are recorded, and the device passes when it is no further from the fp64
+    solve than twice what the reference's own fp32 arithmetic is, or within SURVEY 8c's 1e-4 x spacing (velocities: that / dt).
+    |device - oracle32| is recorded without a gate of its own."""
+    out = None
+    for name in names:
+        a, b, c = getattr(g, name), getattr(o32, name), getattr(o64, name)
+        assert np.isfinite(a).all(), (test, name)
+        d_dev, d_ref = float(np.abs(a - c).max()), float(np.abs(b - c).max())
+        gate = max(2.0 * d_ref, 1e-4 * spacing / (dt if name == "velocities" else 1.0))
+        suffix = "" if name == "positions" else "[%s]" % name
+        record(test, "device_vs_fp64" + suffix, d_dev, gate)
+        record(test, "oracle32_vs_fp64" + suffix, d_ref, gate)
+        record(test, "device_vs_oracle32" + suffix, float(np.abs(a - b).max()), 0.0)
+        assert d_dev <= gate, (test, name, "device vs fp64 %.3g, oracle32 vs fp64 %.3g, gate %.3g" % (d_dev, d_ref, gate))
+        if out is None:
+            out = (d_dev, d_ref)
+    return out
 
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -254,12 +260,9 @@ def test_config3_l100k_against_oracle(pies, oracle):
         scenes.perturb(s, 21, 0.03)
         s.set_prev_positions(s.positions)
     assert g.count(pies.TET) == g.count(pies.VOLUME) == 539334
-    tol = GATE["config3_l100k"]
     for t in range(2):
         g.tick(); o.tick(); o64.tick()
-        for name in ("positions", "prev_positions", "velocities"):
-            within("config3_l100k", g, o, tol * (1.0 if name != "velocities" else 1.0 / 0.012), name)
-        yardstick("config3_l100k", g, o, o64)
+        yardstick("config3_l100k", g, o, o64, names=("positions", "prev_positions", "velocities"))
     res, iters_used, solves = g.pcg_stats()
     assert solves == 10 and res <= 3e-7 * 1.0001
     assert g.pcg_health()["short_solves"] == 0 and not g.failed
