@@ -11,6 +11,7 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _SO = os.environ.get("PIES_ORACLE_LIB") or os.path.join(_ROOT, "oracle", "_build", "libpies_oracle.so")
 
 POSITION, DISTANCE, TET, VOLUME, BEND, SHAPE, GOAL, TRIANGLES, LINES, NODES, STATICS, TRI_CONTACTS = range(12)
+NODE_PAIRS = 18
 FLAG_RELEASE_HINGE, FLAG_NODE_COLLISIONS, FLAG_COLLISION_RULE, FLAG_TRIANGLE_COLLISIONS, FLAG_PD_SOLVE_FP64, FLAG_SVD_PLAIN = 0, 1, 2, 3, 4, 5
 PBD, PD = 0, 1
 
@@ -71,6 +72,7 @@ def lib():
         L.ora_add_tet.argtypes = [vp, u32, pu, f32, f32, f32]
         L.ora_add_volume.argtypes = [vp, u32, pu, f32, f32, f32]
         L.ora_add_bend.argtypes = [vp, u32, pu, f32]
+        L.ora_add_node_pairs.argtypes = [vp, u32, pu]
         L.ora_add_shape.argtypes = [vp, u32, pu, f32]
         L.ora_add_goal.argtypes = [vp, u32, pu, f32]
         L.ora_set_goal_transform.argtypes = [vp, u32, pf]
@@ -182,6 +184,10 @@ class OracleSolver:
     def add_bend(self, ids, w):
         ids = _u32(ids).reshape(-1, 4)
         lib().ora_add_bend(self._h, len(ids), _pu(ids), w)
+
+    def add_node_pairs(self, ids):
+        ids = _u32(ids).reshape(-1, 2)
+        lib().ora_add_node_pairs(self._h, len(ids), _pu(ids))
 
     def add_shape(self, ids, w):
         ids = _u32(ids).reshape(-1)

@@ -27,7 +27,7 @@ extern "C" {
 /* 2: PIES_SCHEDULE_LAYERED, PIES_KERNEL_LAYER (pies_launch_counts now fills PIES_KERNEL_COUNT = 19 entries)
  * 3: pies_tick_begin / pies_export_acquire / pies_export_release, pies_read_positions_strided, pies_get_pcg_health,
  *    pies_set_pcg_retry, PIES_FLAG_REFERENCE_COLLISION_ORDER, pies_profile_in_situ; PIES_SCHEDULE_DEFAULT */
-#define PIES_ABI_VERSION 3
+#define PIES_ABI_VERSION 4
 
 typedef struct pies_solver pies_solver_t;
 
@@ -80,7 +80,9 @@ enum {
   PIES_PD_CG_SINGLE = 15, /* pies_count only: 1 when the captured global step runs one launch per CG iteration */
   PIES_PD_WINDOW_ENTRIES = 16, /* pies_count only: stored entries (padding included) of the windowed system matrix the CG iterations
                                   stream - value + 16-bit window slot each -, 0: not built (row dictionary, or the SELL arrays) */
-  PIES_PD_WINDOW_HALO = 17     /* pies_count only: its halo entries over all chunks (columns staged in LDS besides a chunk's own rows) */
+  PIES_PD_WINDOW_HALO = 17,    /* pies_count only: its halo entries over all chunks (columns staged in LDS besides a chunk's own rows) */
+  PIES_NODE_PAIRS = 18         /* CollisionConstraint (node-node, PD)  CollisionConstraint.cpp:7-65: an EXTENSION container, see
+                                  pies_add_node_pair_constraints */
 };
 
 /* How the sequential Gauss-Seidel sweeps of tickPBD (Solver.cpp:58-75) are mapped to the device.
@@ -162,6 +164,14 @@ int pies_add_distance_constraints(pies_solver_t* s, uint32_t n, const uint32_t* 
 int pies_add_tet_constraints(pies_solver_t* s, uint32_t n, const uint32_t* ids, float w, float min_strain, float max_strain);
 int pies_add_volume_constraints(pies_solver_t* s, uint32_t n, const uint32_t* ids, float w, float compression, float stretching);
 int pies_add_bend_constraints(pies_solver_t* s, uint32_t n, const uint32_t* ids, float w);
+/* EXTENSION (not reachable in the reference): n node-node CollisionConstraints over the node pairs ids[2 i], ids[2 i + 1]
+ * (Src/CollisionConstraint.cpp:7-65, w = 1e5 of Include/Pies/CollisionConstraint.h:14).  The reference's only source of these
+ * constraints, Solver::_parallelComputeCollisions (Solver.cpp:509-637), is never called, and tickPD calls none of the type's three
+ * methods - only its friction loop (Solver.cpp:398-428) walks the always-empty list.  Here a host may list pairs itself; PD then
+ * treats them the way it treats the live collision constraints: projection in every local step (:10-41), w on both diagonal entries
+ * of the system (:43-47), w * projected in the right-hand side (:49-65), the friction loop after the velocity update.  PBD scenes
+ * ignore the list (the PBD tick has its own node-node pass, Solver.cpp:85-130).  Default: none. */
+int pies_add_node_pair_constraints(pies_solver_t* s, uint32_t n, const uint32_t* ids);
 /* ShapeMatchingConstraint over the listed nodes (ShapeMatchingConstraint.cpp:6-48); material coordinates
  * are the nodes' current positions, as createShapeMatching* / addLinkedRegions pass them.  PD only. */
 int pies_add_shape_constraint(pies_solver_t* s, uint32_t n, const uint32_t* ids, float w);

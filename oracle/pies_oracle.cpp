@@ -397,6 +397,38 @@ struct GoalCon {
   }
 };
 
+// Src/CollisionConstraint.cpp:7-65 (node-node, PD); w = 1e5 (Include/Pies/CollisionConstraint.h:14).  The reference never
+// creates one: its only source, Solver::_parallelComputeCollisions (Solver.cpp:509-637), is never called, and tickPD calls none of
+// the three methods - only the friction loop (Solver.cpp:398-428) walks the always-empty list.  Here the constraint is an EXTENSION
+// container (ora_add_node_pairs, default empty) wired the way the reference wires its live collision constraints (triangle,
+// static): projection in the local step, w on both diagonal entries of the per-substep collision matrix, w * projected into the
+// right-hand side, and the friction loop after the velocity update.
+struct NodePairCollision {
+  float w = 100000.0f;
+  uint32_t nodeIds[2] = {0, 0};
+  vec3 projectedPositions[2];
+  // CollisionConstraint.cpp:10-41
+  void project(const std::vector<Node>& nodes) {
+    const Node& nodeA = nodes[nodeIds[0]];
+    const Node& nodeB = nodes[nodeIds[1]];
+    projectedPositions[0] = nodeA.position;
+    projectedPositions[1] = nodeB.position;
+    vec3 diff = nodeB.position - nodeA.position;
+    float distSq = dot(diff, diff);
+    float r = nodeA.radius + nodeB.radius;
+    float rSq = r * r;
+    if (distSq >= rSq) return;
+    float dist = std::sqrt(distSq);
+    float dispLength = r - dist;
+    vec3 disp;
+    if (dist > 0.00001f) disp = dispLength * diff / dist;
+    else disp = vec3(dispLength, 0.0f, 0.0f);
+    float wSum = nodeA.invMass + nodeB.invMass;
+    projectedPositions[0] -= disp * nodeA.invMass / wSum;
+    projectedPositions[1] += disp * nodeB.invMass / wSum;
+  }
+};
+
 // Src/CollisionConstraint.cpp:439-463 (floor); w = 1e4 (Include/Pies/CollisionConstraint.h:78)
 struct StaticCollision {
   float w = 10000.0f;
@@ -847,6 +879,7 @@ struct ora_solver {
   NodeHash hashNodes;
   std::vector<StaticCollision> staticCollisions;
   std::vector<TriCollision> triCollisions;
+  std::vector<NodePairCollision> nodePairs;  // extension: Solver.h:186 _collisions, which the reference never fills
 
   // PD state (Solver.h:163-171)
   bool pdDirty = true;
@@ -1213,6 +1246,10 @@ void ora_solver::tickPD() {
       for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) col.ref(c.nodeIds[i], c.nodeIds[j]) += c.w * c.AtA[i][j];
     for (const StaticCollision& c : staticCollisions) col.ref(c.nodeId, c.nodeId) += c.w;  // :441-445
+    for (const NodePairCollision& c : nodePairs) {  // CollisionConstraint.cpp:43-47 (extension: see NodePairCollision)
+      col.ref(c.nodeIds[0], c.nodeIds[0]) += c.w;
+      col.ref(c.nodeIds[1], c.nodeIds[1]) += c.w;
+    }
     SparseSym sys = stiffness;
     for (uint32_t i = 0; i < nodeCount; ++i)
       for (const auto& kv : col.rows[i]) {
@@ -1254,6 +1291,7 @@ void ora_solver::tickPD() {
         c.projectedPosition = node.position;
         if (node.position.y < 0.0f) c.projectedPosition.y = 0.0f;
       }
+      for (auto& c : nodePairs) c.project(nodes);
       // RHS :310-349.  `f` is the reference's float force vector - or, for the fp64 yardstick (FLAG_PD_SOLVE_FP64), a double
       // copy of it: the contributions w * (AtB p) are the same fp32 values, but they are ADDED without the round-off of a
       // float accumulator that starts at M s_n / h^2 ~ 1e6 (an ulp of 0.1 per addition, ~50 additions per node)
@@ -1295,6 +1333,12 @@ void ora_solver::tickPD() {
         f[n + c.nodeId] += c.w * c.projectedPosition.y;
         f[2 * n + c.nodeId] += c.w * c.projectedPosition.z;
       }
+      for (auto& c : nodePairs)  // CollisionConstraint.cpp:49-65 (every thread's share: both nodes)
+        for (int k = 0; k < 2; ++k) {
+          f[c.nodeIds[k]] += c.w * c.projectedPositions[k].x;
+          f[n + c.nodeIds[k]] += c.w * c.projectedPositions[k].y;
+          f[2 * n + c.nodeIds[k]] += c.w * c.projectedPositions[k].z;
+        }
       };
       if (solveFp64) {
         force64.assign(force.begin(), force.end());
@@ -1336,6 +1380,21 @@ void ora_solver::tickPD() {
       Node& node = nodes[i];
       node.velocity = (1.0f - opt.damping) * (node.position - node.prevPosition) / h + h * node.force * node.invMass;
       node.prevPosition = node.position;
+    }
+    for (const NodePairCollision& collision : nodePairs) {  // :398-428
+      Node& a = nodes[collision.nodeIds[0]];
+      Node& b = nodes[collision.nodeIds[1]];
+      vec3 diff = b.position - a.position;
+      float dist = length(diff);
+      if (dist > a.radius + b.radius) continue;
+      vec3 nrm = diff / dist;
+      vec3 relativeVelocity = b.velocity - a.velocity;
+      vec3 perpVel = relativeVelocity - dot(relativeVelocity, nrm) * nrm;
+      float friction = -opt.friction;
+      if (length(perpVel) < opt.staticFrictionThreshold) friction = 1.0f;
+      float wSum = a.invMass + b.invMass;
+      a.velocity += -friction * perpVel * a.invMass / wSum;
+      b.velocity += friction * perpVel * b.invMass / wSum;
     }
     for (const TriCollision& col : triCollisions) {  // :431-471
       Node& a = nodes[col.nodeIds[0]];
@@ -1526,6 +1585,15 @@ void ora_add_volume(ora_solver* s, uint32_t n, const uint32_t* ids, float w, flo
     s->volumeCons.push_back(makeVolume(s->constraintId++, w, s->nodes[ids[4 * i]], s->nodes[ids[4 * i + 1]],
                                        s->nodes[ids[4 * i + 2]], s->nodes[ids[4 * i + 3]], compression, stretching));
   s->pdDirty = true;
+}
+// extension: n node-node CollisionConstraints (CollisionConstraint.cpp:7-8: ids only; w stays the type's 1e5)
+void ora_add_node_pairs(ora_solver* s, uint32_t n, const uint32_t* ids) {
+  for (uint32_t i = 0; i < n; ++i) {
+    NodePairCollision c;
+    c.nodeIds[0] = ids[2 * i];
+    c.nodeIds[1] = ids[2 * i + 1];
+    s->nodePairs.push_back(c);
+  }
 }
 void ora_add_bend(ora_solver* s, uint32_t n, const uint32_t* ids, float w) {
   for (uint32_t i = 0; i < n; ++i)
@@ -1896,6 +1964,7 @@ uint32_t ora_count(ora_solver* s, int what) {
     case 9: return (uint32_t)s->nodes.size();
     case 10: return (uint32_t)s->staticCollisions.size();
     case 11: return (uint32_t)s->triCollisions.size();
+    case 18: return (uint32_t)s->nodePairs.size();
   }
   return 0;
 }

@@ -48,10 +48,11 @@ def _newest_header():
 
 
 def _compile(src, force, exp=False):
-    obj = os.path.join(OBJDIR + ("_exp" if exp else ""), os.path.basename(src) + ".o")
+    # exp: False (product), True (-DPIES_EXPERIMENTS), "bounds" (-DPIES_BOUNDS: device-side bounds checks, dev_math.h)
+    obj = os.path.join(OBJDIR + ("_bounds" if exp == "bounds" else "_exp" if exp else ""), os.path.basename(src) + ".o")
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), _newest_header()):
         return obj, False
-    extra = ["-DPIES_EXPERIMENTS"] if exp else []
+    extra = ["-DPIES_BOUNDS"] if exp == "bounds" else ["-DPIES_EXPERIMENTS"] if exp else []
     extra += os.environ.get("PIES_EXTRA_FLAGS", "").split()  # compiler-flag experiments (development aid)
     if src.endswith(".hip"):
         cmd = [_hipcc(), "-c", src, "-o", obj] + COMMON + DEVICE + extra
@@ -68,8 +69,8 @@ def _compile(src, force, exp=False):
 def build(force=False, verbose=False, exp=False):
     """exp=True: the diagnostic library libpies_hip_exp.so (-DPIES_EXPERIMENTS: timing experiments that change the work done,
     in-kernel time stamps).  Never loaded by the product or the tests; tools select it with PIES_LIB."""
-    lib = LIB.replace(".so", "_exp.so") if exp else LIB
-    os.makedirs(OBJDIR + ("_exp" if exp else ""), exist_ok=True)
+    lib = LIB.replace(".so", "_bounds.so") if exp == "bounds" else LIB.replace(".so", "_exp.so") if exp else LIB
+    os.makedirs(OBJDIR + ("_bounds" if exp == "bounds" else "_exp" if exp else ""), exist_ok=True)
     srcs = sources()
     with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
         res = list(ex.map(lambda s: _compile(s, force, exp), srcs))
@@ -127,4 +128,4 @@ if __name__ == "__main__":
     if "--asan" in sys.argv:
         print(build_asan(verbose=True))
         sys.exit(0)
-    print(build(force="--force" in sys.argv, verbose=True, exp="--exp" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True, exp="bounds" if "--bounds" in sys.argv else "--exp" in sys.argv))

@@ -33,6 +33,7 @@ PD_TILES = 13
 PD_TILE_RECORDS = 14
 PD_CG_SINGLE = 15
 PD_WINDOW_ENTRIES, PD_WINDOW_HALO = 16, 17
+NODE_PAIRS = 18  # the node-node CollisionConstraint extension container (PD)
 
 # every symbol include/pies_hip.h declares (checked by tests/test_capi_symbols.py against the header)
 SYMBOLS = [
@@ -50,6 +51,7 @@ SYMBOLS = [
     "pies_read_positions_strided", "pies_set_pcg_retry", "pies_get_pcg_health", "pies_profile_in_situ",
     "pies_collision_stats", "pies_get_collision_health", "pies_set_collision_rounds", "pies_set_solver", "pies_debug_pair_state", "pies_set_tuning",
     "pies_get_pd_tile_plan", "pies_get_tri_grid_stats", "pies_set_rest", "pies_get_collision_fallbacks",
+    "pies_add_node_pair_constraints",
 ]
 
 
@@ -109,6 +111,7 @@ def load():
         "pies_add_tet_constraints": [vp, u32, pu, f32, f32, f32],
         "pies_add_volume_constraints": [vp, u32, pu, f32, f32, f32],
         "pies_add_bend_constraints": [vp, u32, pu, f32],
+        "pies_add_node_pair_constraints": [vp, u32, pu],
         "pies_add_triangles": [vp, u32, pu],
         "pies_create_tet_box": [vp, u32, u32, u32, pf, f32, pf, f32, f32, u32],
         "pies_create_box": [vp, u32, u32, u32, pf, f32, f32, i32, u32, u32],
@@ -182,7 +185,7 @@ def _u32(a):
     return np.ascontiguousarray(a, dtype=np.uint32)
 
 
-_IDS_PER = {POSITION: 1, DISTANCE: 2, TET: 4, VOLUME: 4, BEND: 4, TRIANGLES: 3, LINES: 1}
+_IDS_PER = {POSITION: 1, DISTANCE: 2, TET: 4, VOLUME: 4, BEND: 4, TRIANGLES: 3, LINES: 1, NODE_PAIRS: 2}
 _REST_PER = {DISTANCE: 1, TET: 9, VOLUME: 9, BEND: 1}
 
 
@@ -251,6 +254,11 @@ class Solver:
     def add_bend(self, ids, w):
         ids = _u32(ids).reshape(-1, 4)
         self._ck(self._L.pies_add_bend_constraints(self._h, len(ids), _pu(ids), w))
+
+    def add_node_pairs(self, ids):
+        """extension: node-node CollisionConstraints (CollisionConstraint.cpp:7-65) over the listed pairs; PD only"""
+        ids = _u32(ids).reshape(-1, 2)
+        self._ck(self._L.pies_add_node_pair_constraints(self._h, len(ids), _pu(ids)))
 
     def add_triangles(self, ids):
         ids = _u32(ids).reshape(-1, 3)

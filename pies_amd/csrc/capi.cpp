@@ -43,6 +43,7 @@ void free_device(pies_solver* s) {
   s->d_dc_ids = nullptr; s->d_dc_rw = nullptr;
   s->d_tc_ids = nullptr; s->d_tc_q0 = s->d_tc_q1 = s->d_tc_q2 = nullptr;
   s->d_bc_ids = nullptr; s->d_bc_aw = nullptr;
+  s->d_np_ids = nullptr;
   s->d_vc_ids = nullptr; s->d_vc_q0 = s->d_vc_q1 = s->d_vc_q2 = nullptr;
   s->pd = PdArrays{};
   s->hash = HashArrays{};
@@ -220,7 +221,7 @@ int pies_clear(pies_solver_t* s) {
     free_device(s);
   }
   s->h_pos.clear(); s->h_prev.clear(); s->h_vel.clear(); s->h_radius.clear(); s->h_invMass.clear();
-  s->h_position.clear(); s->h_distance.clear(); s->h_tet.clear(); s->h_volume.clear(); s->h_bend.clear();
+  s->h_position.clear(); s->h_distance.clear(); s->h_tet.clear(); s->h_volume.clear(); s->h_bend.clear(); s->h_nodePair.clear();
   s->h_triangles.clear(); s->h_lines.clear();
   s->h_shape.clear(); s->h_goal.clear();  // like the reference, the fixed-region list survives clear() (Solver.cpp:488-507)
   for (Plan& p : s->plan) { p.order.clear(); p.batches.clear(); }
@@ -475,6 +476,11 @@ int pies_finalize(pies_solver_t* s) {
     if (int rc = upload(s, id, &s->d_bc_ids)) return rc;
     if (int rc = upload(s, aw, &s->d_bc_aw)) return rc;
     HIP_TRY(s, hipStreamSynchronize(s->stream));
+  }
+  if (isPD && !s->h_nodePair.empty()) {  // the node-pair extension (container order: a pair's slot is its index)
+    std::vector<uint2> id(s->h_nodePair.size());
+    for (size_t k = 0; k < id.size(); ++k) id[k] = make_uint2(s->h_nodePair[k].ids[0], s->h_nodePair[k].ids[1]);
+    if (int rc = upload(s, id, &s->d_np_ids)) return rc;
   }
   if (s->layer.active && !isPD) {
     const LayerPlan& L = s->layer;
@@ -1020,6 +1026,7 @@ int pies_count(const pies_solver_t* s, int what, uint32_t* out) {
     case PIES_TET: *out = (uint32_t)s->h_tet.size(); break;
     case PIES_VOLUME: *out = (uint32_t)s->h_volume.size(); break;
     case PIES_BEND: *out = (uint32_t)s->h_bend.size(); break;
+    case PIES_NODE_PAIRS: *out = (uint32_t)s->h_nodePair.size(); break;
     case PIES_SHAPE: *out = (uint32_t)s->h_shape.size(); break;
     case PIES_GOAL: *out = (uint32_t)s->h_goal.size(); break;
     case PIES_TRIANGLES: *out = (uint32_t)(s->h_triangles.size() / 3); break;
@@ -1092,6 +1099,7 @@ int pies_get_ids(const pies_solver_t* s, int type, uint32_t* out, uint32_t capac
     case PIES_TET: for (auto& c : s->h_tet) for (uint32_t v : c.ids) put(v); break;
     case PIES_VOLUME: for (auto& c : s->h_volume) for (uint32_t v : c.ids) put(v); break;
     case PIES_BEND: for (auto& c : s->h_bend) for (uint32_t v : c.ids) put(v); break;
+    case PIES_NODE_PAIRS: for (auto& c : s->h_nodePair) { put(c.ids[0]); put(c.ids[1]); } break;
     case PIES_TRIANGLES: for (uint32_t v : s->h_triangles) put(v); break;
     case PIES_LINES: for (uint32_t v : s->h_lines) put(v); break;
     default: return PIES_ERR_INVALID;
@@ -1181,3 +1189,14 @@ int pies_launch_counts(pies_solver_t* s, uint32_t* out) {
 }
 }  // extern "C"
 
+
+#ifdef PIES_BOUNDS
+// The diagnostic build's record of device-side bounds violations (dev_math.h PIES_IN_BOUNDS), per kernel file: out[2 k] = the first
+// failing site, out[2 k + 1] = how many, for k = layer, pd, cg1.  Reading clears.  tests/conftest.py asks after the session.
+extern "C" int pies_exp_bounds_layer(unsigned int*);
+extern "C" int pies_exp_bounds_pd(unsigned int*);
+extern "C" int pies_exp_bounds_cg1(unsigned int*);
+extern "C" int pies_exp_bounds_report(unsigned int* out6) {
+  return pies_exp_bounds_layer(out6) | pies_exp_bounds_pd(out6 + 2) | pies_exp_bounds_cg1(out6 + 4);
+}
+#endif

@@ -10,6 +10,35 @@ namespace pies {
 
 #define PIES_DEV __device__ __forceinline__
 
+// Device-side bounds checks of a diagnostic build (python -m pies_amd.build --bounds: -DPIES_BOUNDS; libpies_hip_bounds.so, never
+// loaded by the product): PIES_IN_BOUNDS(cond, site) is `cond`, and a false one is RECORDED (first failing site id + a count, read by
+// pies_exp_bounds_report) and the guarded access skipped - no trap: a faulting kernel can take the whole node down.  In the product
+// build the macro is the constant true and the guards compile away.  Sites: 1x k_layer, 2x PD local tiles, 3x the windowed CG
+// rows, 4x the node-node pair lists, 5x the triangle contact lists.
+#ifdef PIES_BOUNDS
+static __device__ unsigned int g_pies_bounds[2];  // (one per translation unit: the library is not built as relocatable device code)
+PIES_DEV bool pies_bounds_note(bool ok, unsigned int site) {
+  if (!ok) {
+    atomicCAS(&g_pies_bounds[0], 0u, site);
+    atomicAdd(&g_pies_bounds[1], 1u);
+  }
+  return ok;
+}
+#define PIES_IN_BOUNDS(cond, site) (::pies::pies_bounds_note((cond), (site)))
+#define PIES_CLAMP_INDEX(i, n) ((i) < (n) ? (i) : 0u)
+// in every kernel file: the host function that reads (and clears) the file's record: out[0] first failing site, out[1] count
+#define PIES_BOUNDS_REPORT(name)                                                                                     \
+  extern "C" int pies_exp_bounds_##name(unsigned int* out) {                                                         \
+    unsigned int zero[2] = {0u, 0u};                                                                                 \
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(::pies::g_pies_bounds), sizeof(zero)) != hipSuccess) return 1;           \
+    return hipMemcpyToSymbol(HIP_SYMBOL(::pies::g_pies_bounds), zero, sizeof(zero)) == hipSuccess ? 0 : 1;           \
+  }
+#else
+#define PIES_IN_BOUNDS(cond, site) (true)
+#define PIES_CLAMP_INDEX(i, n) (i)
+#define PIES_BOUNDS_REPORT(name)
+#endif
+
 // Workgroups are dealt round-robin over the 8 XCDs (observed, MI355X_MICROARCH.md "Workgroup dispatch"), each
 // with a private 4 MiB L2.  Gather kernels whose work items are stored in mesh order use this bijective
 // relabelling so that one XCD processes one contiguous eighth of the items and neighbouring items' node

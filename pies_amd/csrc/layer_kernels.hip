@@ -61,6 +61,7 @@ __global__ void __launch_bounds__(BLOCK, WPE) k_layer(NodeArrays nd, LayerData D
   const uint4 tile = D.tiles[L.phase][g];
   const uint32_t m = tile.y + tile.w;
   if (m == 0) return;  // uniform: an empty tile
+  if (!PIES_IN_BOUNDS(m <= D.maxGroupNodes, 10u)) return;  // (uniform) the tile's node records fit the LDS the launch asked for
   PIES_STAMP_DECL
   PIES_STAMP_REAL();
   PIES_STAMP();
@@ -137,7 +138,7 @@ __global__ void __launch_bounds__(BLOCK, WPE) k_layer(NodeArrays nd, LayerData D
         t0 = min(nlo + tid, last);
         const uint2 nid = D.tc_lid[t0];
         const float4 b0 = D.tc_q0[t0], b1 = D.tc_q1[t0], b2 = D.tc_q2[t0];
-        if (have) {
+        if (have && PIES_IN_BOUNDS(max(max(lo16(id.x), hi16(id.x)), max(lo16(id.y), hi16(id.y))) < m, 11u)) {
           const uint32_t i1 = lo16(id.x), i2 = hi16(id.x), i3 = lo16(id.y), i4 = hi16(id.y);
           float4 x1 = sp[i1], x2 = sp[i2], x3 = sp[i3], x4 = sp[i4];
 #ifdef PIES_EXPERIMENTS
@@ -176,7 +177,7 @@ __global__ void __launch_bounds__(BLOCK, WPE) k_layer(NodeArrays nd, LayerData D
 #pragma unroll
       for (int c = 0; c < kDistPreload; ++c) {
         if (static_cast<uint32_t>(c) < ncol) {
-          if (off[c] + tid < off[c + 1]) {
+          if (off[c] + tid < off[c + 1] && PIES_IN_BOUNDS(max(lo16(id[c]), hi16(id[c])) < m, 12u)) {
             float4 a = sp[lo16(id[c])];
             distance_core(a, sp[hi16(id[c])], rw[c]);
             sp[lo16(id[c])] = a;
@@ -214,6 +215,7 @@ __global__ void __launch_bounds__(BLOCK, WPE) k_layer(NodeArrays nd, LayerData D
       for (uint32_t c = 0; c < ncol; ++c) {
         for (uint32_t t = off[c] + tid; t < off[c + 1]; t += BLOCK) {
           const uint32_t i = D.pc_lid[t];
+          if (!PIES_IN_BOUNDS(i < m, 13u)) continue;
           float4 p = sp[i];
           position_core(p, D.pc_tw[t]);
           sp[i] = p;
@@ -348,6 +350,7 @@ extern "C" int pies_exp_layer_stamps(unsigned long long* deviceBuffer) {  // 64 
   return hipMemcpyToSymbol(HIP_SYMBOL(g_layer_stamps), &deviceBuffer, sizeof(deviceBuffer)) == hipSuccess ? 0 : 1;
 }
 #endif
+PIES_BOUNDS_REPORT(layer)
 static size_t layer_lds_bytes(uint32_t maxGroupNodes) {
   return static_cast<size_t>(maxGroupNodes) * (sizeof(float4) + sizeof(float)) + kLayerMaxSegs * kOffStride * sizeof(uint32_t);
 }

@@ -104,10 +104,12 @@ PIES_DEV void window_rows(const CgArrays& A, uint32_t nblocks, Own own, Halo hal
     if (A.wHalo16) {
       const uint32_t base = A.wBase[c];
       const uint16_t* __restrict__ h = A.wHalo16 + ch.x;
-      for (uint32_t k = threadIdx.x; k < ch.y; k += kBlock) win[R + k] = halo(base + h[k]);
+      for (uint32_t k = threadIdx.x; k < ch.y; k += kBlock)
+        if (PIES_IN_BOUNDS(R + k < A.wLdsSlots && base + h[k] < A.n, 32u)) win[R + k] = halo(base + h[k]);
     } else if (A.wHalo32) {
       const uint32_t* __restrict__ h = A.wHalo32 + ch.x;
-      for (uint32_t k = threadIdx.x; k < ch.y; k += kBlock) win[R + k] = halo(h[k]);
+      for (uint32_t k = threadIdx.x; k < ch.y; k += kBlock)
+        if (PIES_IN_BOUNDS(R + k < A.wLdsSlots && h[k] < A.n, 33u)) win[R + k] = halo(h[k]);
     }
     __syncthreads();
     for (uint32_t sc = wave; sc < spc; sc += kBlock / 64u) {
@@ -121,6 +123,7 @@ PIES_DEV void window_rows(const CgArrays& A, uint32_t nblocks, Own own, Halo hal
 #pragma unroll 4
       for (uint32_t kk = 0; kk < width; ++kk) {
         const ACC a = static_cast<ACC>(wv[kk << 6]);
+        if (!PIES_IN_BOUNDS(wi[kk << 6] < A.wLdsSlots, 31u)) continue;
         const float4 q = win[wi[kk << 6]];
         sx = fma(a, static_cast<ACC>(q.x), sx);
         sy = fma(a, static_cast<ACC>(q.y), sy);
@@ -497,6 +500,7 @@ static bool window_lds_ok(uint32_t bytes) {
   return true;
 }
 
+PIES_BOUNDS_REPORT(cg1)
 // workgroups of k_cg1_iter the device holds at once (its continuation's grid barrier needs all of a launch resident)
 uint32_t cg1_iter_resident_blocks(int device, uint32_t windowLdsBytes) {
   int perCu = 0;

@@ -162,6 +162,11 @@ struct PdArrays {
 
 void launch_pd_predict(hipStream_t st, const NodeArrays& nd, const PdArrays& pd, float h, float contactHeight, bool triReset);
 void launch_pd_local_distance(hipStream_t st, const float4* pos, const uint2* ids, const float2* rw, Vec3f* contrib, uint32_t count);
+// the node-pair extension container (CollisionConstraint.cpp:7-65; Solver.cpp:398-428)
+constexpr float kNodePairW = 100000.0f;  // Include/Pies/CollisionConstraint.h:14
+void launch_pd_local_node_pair(hipStream_t st, const float4* pos, const float* radius, const uint2* ids, Vec3f* contrib, uint32_t count);
+void launch_pd_node_pair_friction(hipStream_t st, const float4* pos, float4* vel, const float* radius, const uint2* ids, uint32_t count,
+                                  float friction, float staticThreshold);
 void launch_pd_local_tet(hipStream_t st, bool volume, const float4* pos, const uint4* ids, const float4* q0, const float4* q1,
                          const float4* q2, Vec3f* contrib, uint32_t count);
 // strain + volume constraints over identical elements (same ids, same Qinv), fused

@@ -88,6 +88,57 @@ __global__ void __launch_bounds__(kBlock) k_pd_local_distance(const float4* __re
                              w * ((0.0f + -0.5f * p0z) + 0.5f * b.z)};
 }
 
+// CollisionConstraint (node-node; CollisionConstraint.cpp:10-41 and :49-65), the extension container of
+// pies_add_node_pair_constraints: both nodes' projected positions, weighted (A = B = I: contribution_i = w * projected_i).
+__global__ void __launch_bounds__(kBlock) k_pd_local_node_pair(const float4* __restrict__ pos, const float* __restrict__ radius,
+                                                               const uint2* __restrict__ ids, Vec3f* __restrict__ contrib, uint32_t count) {
+  const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= count) return;
+  const uint2 id = ids[c];
+  const float4 a = pos[id.x], b = pos[id.y];  // (.w = invMass)
+  float pax = a.x, pay = a.y, paz = a.z, pbx = b.x, pby = b.y, pbz = b.z;
+  const float dx = b.x - a.x, dy = b.y - a.y, dz = b.z - a.z;
+  const float distSq = dx * dx + dy * dy + dz * dz;
+  const float r = radius[id.x] + radius[id.y];
+  if (distSq < r * r) {
+    const float dist = sqrtf(distSq);
+    const float dispLength = r - dist;
+    float ex, ey, ez;
+    if (dist > 0.00001f) { ex = dispLength * dx / dist; ey = dispLength * dy / dist; ez = dispLength * dz / dist; }
+    else { ex = dispLength; ey = 0.0f; ez = 0.0f; }
+    const float wSum = a.w + b.w;
+    pax -= ex * a.w / wSum; pay -= ey * a.w / wSum; paz -= ez * a.w / wSum;
+    pbx += ex * b.w / wSum; pby += ey * b.w / wSum; pbz += ez * b.w / wSum;
+  }
+  contrib[c] = Vec3f{kNodePairW * pax, kNodePairW * pay, kNodePairW * paz};
+  contrib[count + c] = Vec3f{kNodePairW * pbx, kNodePairW * pby, kNodePairW * pbz};
+}
+// The friction loop over the node-node constraints (Solver.cpp:398-428), in list order: pairs may share nodes, so the list is walked
+// by one lane (an extension container a host fills by hand; the live collision constraints have their own level-ordered passes).
+__global__ void k_pd_node_pair_friction(const float4* __restrict__ pos, float4* __restrict__ vel, const float* __restrict__ radius,
+                                        const uint2* __restrict__ ids, uint32_t count, float frictionOpt, float staticThreshold) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  for (uint32_t c = 0; c < count; ++c) {
+    const uint2 id = ids[c];
+    const float4 a = pos[id.x], b = pos[id.y];
+    const float dx = b.x - a.x, dy = b.y - a.y, dz = b.z - a.z;
+    const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+    if (dist > radius[id.x] + radius[id.y]) continue;
+    const float nx = dx / dist, ny = dy / dist, nz = dz / dist;
+    float4 va = vel[id.x], vb = vel[id.y];
+    const float rx = vb.x - va.x, ry = vb.y - va.y, rz = vb.z - va.z;
+    const float rn = rx * nx + ry * ny + rz * nz;
+    const float px = rx - rn * nx, py = ry - rn * ny, pz = rz - rn * nz;
+    float friction = -frictionOpt;
+    if (sqrtf(px * px + py * py + pz * pz) < staticThreshold) friction = 1.0f;
+    const float wSum = a.w + b.w;
+    va.x += -friction * px * a.w / wSum; va.y += -friction * py * a.w / wSum; va.z += -friction * pz * a.w / wSum;
+    vb.x += friction * px * b.w / wSum; vb.y += friction * py * b.w / wSum; vb.z += friction * pz * b.w / wSum;
+    vel[id.x] = va;
+    vel[id.y] = vb;
+  }
+}
+
 // Constraints.cpp:186-203.  The reference divides the three components by `den`; here one reciprocal (a correctly rounded
 // division) and three products - the last bit of D may differ, PD parity is by tolerance, and the
 // ten iterations of this loop were a quarter of the local step's instructions with three divisions each.
@@ -330,8 +381,14 @@ __global__ void __launch_bounds__(kTileLanes) k_pd_local_tiles(PdTileArrays T, c
   __syncthreads();
   const uint32_t na[4] = {lab.x & 0xffu, (lab.x >> 8) & 0xffu, (lab.x >> 16) & 0xffu, lab.x >> 24};
   const uint32_t nb[4] = {lab.y & 0xffu, (lab.y >> 8) & 0xffu, (lab.y >> 16) & 0xffu, lab.y >> 24};
-  const float4 xa[4] = {sPos[na[0]], sPos[na[1]], sPos[na[2]], sPos[na[3]]};
-  const float4 xb[4] = {sPos[nb[0]], sPos[nb[1]], sPos[nb[2]], sPos[nb[3]]};
+  // (bounds build: an element's local node indices lie inside the tile's node list)
+  const bool inb = PIES_IN_BOUNDS(2u * lane >= cnt || max(max(na[0], na[1]), max(na[2], na[3])) < max(nn, 1u), 21u) &&
+                   PIES_IN_BOUNDS(2u * lane + 1u >= cnt || max(max(nb[0], nb[1]), max(nb[2], nb[3])) < max(nn, 1u), 22u);
+  (void)inb;
+  const float4 xa[4] = {sPos[PIES_CLAMP_INDEX(na[0], kTileNodes)], sPos[PIES_CLAMP_INDEX(na[1], kTileNodes)],
+                        sPos[PIES_CLAMP_INDEX(na[2], kTileNodes)], sPos[PIES_CLAMP_INDEX(na[3], kTileNodes)]};
+  const float4 xb[4] = {sPos[PIES_CLAMP_INDEX(nb[0], kTileNodes)], sPos[PIES_CLAMP_INDEX(nb[1], kTileNodes)],
+                        sPos[PIES_CLAMP_INDEX(nb[2], kTileNodes)], sPos[PIES_CLAMP_INDEX(nb[3], kTileNodes)]};
   f2 rec[4][3];
   pair_project_packed(xa, xb, a0, a1, a2, av, b0c, b1c, b2c, bvc, rec);
 #pragma unroll
@@ -348,6 +405,7 @@ __global__ void __launch_bounds__(kTileLanes) k_pd_local_tiles(PdTileArrays T, c
     for (uint32_t r = b; r < e; ++r) {
       const uint32_t v = sInc[r];
       const uint32_t at = kTileElems * (v & 3u) + (v >> 2);
+      if (!PIES_IN_BOUNDS(r < 4u * kTileElems && (v >> 2) < kTileElems, 23u)) continue;
       ax += sX[at]; ay += sY[at]; az += sZ[at];
     }
   };
@@ -581,6 +639,15 @@ void launch_pd_predict(hipStream_t st, const NodeArrays& nd, const PdArrays& pd,
   hipLaunchKernelGGL(k_pd_predict, grid_for(nd.n), dim3(kBlock), 0, st, nd.pos, nd.vel, pd.msn, pd.triCount, pd.nstatic, pd.kdiag,
                      pd.cg.cdiag, pd.cg.dinv, nd.n, h, h * h, contactHeight, tri);
 }
+void launch_pd_local_node_pair(hipStream_t st, const float4* pos, const float* radius, const uint2* ids, Vec3f* contrib, uint32_t count) {
+  if (count == 0) return;
+  hipLaunchKernelGGL(k_pd_local_node_pair, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, st, pos, radius, ids, contrib, count);
+}
+void launch_pd_node_pair_friction(hipStream_t st, const float4* pos, float4* vel, const float* radius, const uint2* ids, uint32_t count,
+                                  float friction, float staticThreshold) {
+  if (count == 0) return;
+  hipLaunchKernelGGL(k_pd_node_pair_friction, dim3(1), dim3(64), 0, st, pos, vel, radius, ids, count, friction, staticThreshold);
+}
 void launch_pd_local_distance(hipStream_t st, const float4* pos, const uint2* ids, const float2* rw, Vec3f* contrib, uint32_t count) {
   if (count == 0) return;
   hipLaunchKernelGGL(k_pd_local_distance, grid_for(count), dim3(kBlock), 0, st, pos, ids, rw, contrib, count);
@@ -600,6 +667,7 @@ void launch_pd_rhs(hipStream_t st, const NodeArrays& nd, const PdArrays& pd) {
   if (pd.rhsLanes == 1 && !pd.cg.useCAp) hipLaunchKernelGGL(k_pd_rhs<1>, grid_for(nd.n), dim3(kBlock), 0, st, rhs_arrays(nd, pd), pd.rhs);  // (many contacts: four lanes share a node's contact records)
   else hipLaunchKernelGGL(k_pd_rhs<4>, dim3((nd.n + kBlock / 4 - 1) / (kBlock / 4)), dim3(kBlock), 0, st, rhs_arrays(nd, pd), pd.rhs);
 }
+PIES_BOUNDS_REPORT(pd)
 void launch_pd_local_tet_pair(hipStream_t st, const float4* pos, const uint4* ids, const float4* q0, const float4* q1, const float4* q2,
                               const float4* vq2, Vec3f* contribTet, Vec3f* contribVol, uint32_t count, const TriArrays* tri,
                               float thickness, bool packed, const uint16_t* dictIndex, const float4* dictTable) {

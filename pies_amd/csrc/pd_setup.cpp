@@ -156,6 +156,8 @@ int pd_build(pies_solver* s) {
     for (uint32_t id : c.ids) rows[id].push_back({id, c.w});
   for (const HostBend& c : s->h_bend)  // A = I: w on the diagonal (the off-diagonal terms are w*0)
     for (uint32_t id : c.ids) rows[id].push_back({id, c.w * 1.0f});
+  for (const HostNodePair& c : s->h_nodePair)  // CollisionConstraint.cpp:43-47 (extension container: the pairs are the scene's, so
+    for (uint32_t id : c.ids) rows[id].push_back({id, kNodePairW});  // their diagonal terms are part of K, not rebuilt every substep)
 
   std::vector<uint32_t> rowptr(n + 1, 0), col;
   std::vector<float> val, kdiag(n, 0.f);
@@ -208,16 +210,16 @@ int pd_build(pies_solver* s) {
   }
 
   // ---- contribution slots and per-node incidence lists -------------------------------------------------
-  const uint32_t cnt[5] = {(uint32_t)s->h_position.size(), (uint32_t)s->h_distance.size(), (uint32_t)s->h_tet.size(),
-                           (uint32_t)s->h_volume.size(), (uint32_t)s->h_bend.size()};
-  const uint32_t arity[5] = {1, 2, 4, 4, 4};
+  const uint32_t cnt[6] = {(uint32_t)s->h_position.size(), (uint32_t)s->h_distance.size(), (uint32_t)s->h_tet.size(),
+                           (uint32_t)s->h_volume.size(), (uint32_t)s->h_bend.size(), (uint32_t)s->h_nodePair.size()};
+  const uint32_t arity[6] = {1, 2, 4, 4, 4, 2};
   // strain + volume element pairs in tiles: one record per (tile, node) instead of four per element (pd_tiles.cpp)
   PdTilePlan tiles;
   const bool tiled = pd_plan_tiles(s, tiles);
   s->pdTiles = tiled ? static_cast<uint32_t>(tiles.info.size()) : 0u;
   s->pdTileRecords = tiled ? static_cast<uint32_t>(tiles.tileNodes) : 0u;
   uint32_t total = 0;
-  for (int t = 0; t < 5; ++t) {
+  for (int t = 0; t < 6; ++t) {
     s->slotBase[t] = total;
     if (!(tiled && (t == PIES_TET || t == PIES_VOLUME))) total += cnt[t] * arity[t];
   }
@@ -240,6 +242,8 @@ int pd_build(pies_solver* s) {
       for (uint32_t i = 0; i < 4; ++i) fn(s->h_volume[c].ids[i], s->slotBase[3] + i * cnt[3] + c);
     for (uint32_t c = 0; c < cnt[4]; ++c)
       for (uint32_t i = 0; i < 4; ++i) fn(s->h_bend[c].ids[i], s->slotBase[4] + i * cnt[4] + c);
+    for (uint32_t c = 0; c < cnt[5]; ++c)  // (the reference adds collision terms after every other container, Solver.cpp:337-349)
+      for (uint32_t i = 0; i < 2; ++i) fn(s->h_nodePair[c].ids[i], s->slotBase[5] + i * cnt[5] + c);
   };
   for_each_incidence([&](uint32_t node, uint32_t) { ++incPtr[node + 1]; });
   for (uint32_t i = 0; i < n; ++i) incPtr[i + 1] += incPtr[i];

@@ -334,6 +334,16 @@ int pies_add_bend_constraints(pies_solver_t* s, uint32_t n, const uint32_t* ids,
   return PIES_OK;
 }
 
+int pies_add_node_pair_constraints(pies_solver_t* s, uint32_t n, const uint32_t* ids) {
+  PIES_BEGIN_EDIT(s);
+  if (n && (!ids || !ids_ok(s, ids, 2ull * n))) return fail(s, PIES_ERR_INVALID, "node-pair constraint: bad node id");
+  for (uint32_t i = 0; i < n; ++i) {
+    if (ids[2 * i] == ids[2 * i + 1]) return fail(s, PIES_ERR_INVALID, "node-pair constraint: a node paired with itself");
+    s->h_nodePair.push_back(pies::HostNodePair{{ids[2 * i], ids[2 * i + 1]}});
+  }
+  return PIES_OK;
+}
+
 /* Rest data of constraints [first, first + n) of a container, replaced (the counterpart of pies_get_rest, same layout): a host that
  * restores a saved scene, or pre-strains a material, does not have to move the nodes into the rest pose first.  The reference's
  * factories take the rest pose from the node positions at creation (Constraints.cpp:39-56, 130-184, 257-310, 368-394). */

@@ -46,6 +46,9 @@ struct HostBend {
   float angle;
   float w;
 };
+struct HostNodePair {  // CollisionConstraint (Src/CollisionConstraint.cpp:7-65): an extension container, pies_add_node_pair_constraints
+  uint32_t ids[2];
+};
 
 struct HostShape {  // ShapeMatchingConstraint (Src/ShapeMatchingConstraint.cpp:6-48)
   std::vector<uint32_t> ids;
@@ -207,6 +210,7 @@ struct pies_solver {
   std::vector<pies::HostDistance> h_distance;
   std::vector<pies::HostTet> h_tet, h_volume;
   std::vector<pies::HostBend> h_bend;
+  std::vector<pies::HostNodePair> h_nodePair;  // extension container (PD): pies_add_node_pair_constraints
   std::vector<pies::HostShape> h_shape;
   std::vector<pies::HostGoal> h_goal;
   std::vector<pies::HostFixedRegion> h_fixedRegions;
@@ -239,6 +243,7 @@ struct pies_solver {
   float4 *d_tc_q0 = nullptr, *d_tc_q1 = nullptr, *d_tc_q2 = nullptr;
   uint4* d_bc_ids = nullptr;
   float2* d_bc_aw = nullptr;
+  uint2* d_np_ids = nullptr;  // node-pair extension (PD)
   uint4* d_vc_ids = nullptr;  // volume constraints (PD only), host order
   float4 *d_vc_q0 = nullptr, *d_vc_q1 = nullptr, *d_vc_q2 = nullptr;
 
@@ -248,7 +253,7 @@ struct pies_solver {
 
   // ---- Projective Dynamics ----
   pies::PdArrays pd{};
-  uint32_t slotBase[5] = {0, 0, 0, 0, 0};  // first contribution slot of each container
+  uint32_t slotBase[6] = {0, 0, 0, 0, 0, 0};  // first contribution slot of each container (5: the node-pair extension)
   uint32_t pd_nnz = 0;
   uint32_t goalSlotBase = 0;  // first fp64 contribution slot of the goal constraints
   float pcgTol = 3.0e-7f;     // relative residual ||r|| / ||b|| per coordinate column

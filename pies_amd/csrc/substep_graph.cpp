@@ -414,6 +414,7 @@ void enqueue_pd_substep(pies_solver* s, int only, uint32_t* counts, uint64_t* un
     if (only < 0) {
       launch_pd_local_bend(st, s->nd.pos, s->d_bc_ids, s->d_bc_aw, pd.contrib + s->slotBase[PIES_BEND], (uint32_t)s->h_bend.size());
       launch_pd_local_shape(st, s->nd.pos, pd);                        // goal targets are constants between transform updates
+      launch_pd_local_node_pair(st, s->nd.pos, s->nd.radius, s->d_np_ids, pd.contrib + s->slotBase[5], (uint32_t)s->h_nodePair.size());
       if (tri && !(s->tetVolumePaired && nTet)) launch_pd_local_tri(st, pd.tri, s->nd.pos, s->opt.collisionThickness);  // Solver.cpp:298-300
     }
     // Solver.cpp:266, 310-349.  (When a node's records are a few tile sums, the residual kernel of the one-launch-per-iteration
@@ -459,6 +460,8 @@ void enqueue_pd_substep(pies_solver* s, int only, uint32_t* counts, uint64_t* un
     // velocities, then the contacts' friction (:431-471), then the floor friction (:473-484).  The floor friction of a node that is
     // in no contact does not wait for the contacts: the velocity kernel applies it; the contacts' pass ends with that of its own nodes
     launch_pd_velocity(st, s->nd, pd, h, s->opt.damping, s->opt.gravity, s->opt.friction, s->opt.staticFrictionThreshold, false, pd.tri.usedBits);
+    if (only < 0) launch_pd_node_pair_friction(st, s->nd.pos, s->nd.vel, s->nd.radius, s->d_np_ids, (uint32_t)s->h_nodePair.size(), s->opt.friction,
+                                               s->opt.staticFrictionThreshold);  // Solver.cpp:398-428 comes before the triangles' (:431-471)
     launch_tri_friction(st, pd.tri, s->nd, s->opt.friction, s->opt.staticFrictionThreshold, pd.nstatic);
   } else {
     if (only < 0 && s->opt.collisionStabilizationIterations > 0) launch_pd_stabilize(st, s->nd, pd, statsInStabilize, (int)s->pcgBudget, s->pcgTol, pd_single_cg(s));  // the floor snap is idempotent
@@ -466,6 +469,8 @@ void enqueue_pd_substep(pies_solver* s, int only, uint32_t* counts, uint64_t* un
       launch_pd_velocity(st, s->nd, pd, h, s->opt.damping, s->opt.gravity, s->opt.friction, s->opt.staticFrictionThreshold, true);
       U(s->nd.n);
     }
+    if (only < 0) launch_pd_node_pair_friction(st, s->nd.pos, s->nd.vel, s->nd.radius, s->d_np_ids, (uint32_t)s->h_nodePair.size(), s->opt.friction,
+                                               s->opt.staticFrictionThreshold);
   }
   C(PIES_KERNEL_PD_VELOCITY);
 }

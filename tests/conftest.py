@@ -40,3 +40,20 @@ def tune(pies):
     yield _set
     for name in touched:
         pies.set_tuning(name, None)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def bounds_report():
+    """With the bounds-checking build loaded (PIES_LIB=.../libpies_hip_bounds.so, python -m pies_amd.build --bounds): after the
+    session, no kernel may have recorded an out-of-range index (dev_math.h PIES_IN_BOUNDS)."""
+    yield
+    if "bounds" not in os.environ.get("PIES_LIB", ""):
+        return
+    import ctypes
+    from pies_amd import capi
+    L = capi.load()
+    out = (ctypes.c_uint * 6)()
+    L.pies_exp_bounds_report.argtypes = [ctypes.POINTER(ctypes.c_uint)]
+    assert L.pies_exp_bounds_report(out) == 0
+    print("\n[bounds build] violations (first site, count) layer %s pd %s cg1 %s" % (tuple(out[0:2]), tuple(out[2:4]), tuple(out[4:6])))
+    assert not any(out), tuple(out)

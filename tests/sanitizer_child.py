@@ -60,6 +60,7 @@ def pd_setup_soak():
         region = np.eye(4, dtype=np.float32)
         region[3, :3] = (1.0, 1.0, 1.0)
         g.add_fixed_regions(region.reshape(16), 7.0)
+        g.add_node_pairs(np.uint32([[0, 5], [5, 9], [2, 11]]))  # the node-pair extension container
         g.finalize()
         g.pd_tile_plan()
         g.close()
@@ -93,6 +94,7 @@ def oracle_soak():
     o.create_tet_box(4, 4, 8, translation=(0.0, 0.02, 0.0), w=1.0, volume=True, triangles=True)
     o.create_tet_box(3, 3, 3, translation=(0.6, 4.3, 2.2), w=1.0, volume=True, triangles=True)  # lands on the first
     o.create_shape_matching_box((12.0, 0.5, 0.0), 3, 3, 4, 2.0)
+    o.add_node_pairs(np.uint32([[0, 5], [5, 9], [2, 140]]))
     scenes.perturb(o, 9, 0.03)
     o.set_prev_positions(o.positions)
     o.tick(4)

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_functions():
         assert hasattr(lib, name), name
     lib.pies_abi_version.restype = ctypes.c_int
-    assert lib.pies_abi_version() == 3
+    assert lib.pies_abi_version() == 4
 
 
 def test_options_struct_matches_reference_layout():

@@ -402,3 +402,45 @@ def test_pd_unstructured_full_size_properties(pies, tune):
     d = float(np.abs(a[0] - c[0]).max())
     record("pd_unstructured_l100k_tiles_vs_records", "positions", d, tol_for(c[0]))
     assert d <= tol_for(c[0]), d
+
+
+@pytest.mark.gpu
+def test_pd_node_pair_collision_constraints(pies, oracle):
+    """K2, the PD node-node CollisionConstraint (Src/CollisionConstraint.cpp:7-65; friction loop Solver.cpp:398-428) - an EXTENSION
+    container here, because the reference never creates one (its only source, _parallelComputeCollisions, is never called, and
+    tickPD calls none of the type's methods).  Scene: two small tet boxes pushed into each other with the overlapping node pairs
+    listed by hand, plus loose spheres that overlap, touch and miss.  Device against the oracle's restatement, ticks of its own."""
+    def build(s):
+        s.create_tet_box(3, 3, 3, translation=(0.0, 1.0, 0.0), w=1.0)
+        s.create_tet_box(3, 3, 3, translation=(2.6, 1.1, 0.2), w=1.0)           # overlaps the first box's x = 2 face
+        s.addNodes(np.float32([[6.0, 2.0, 0.0], [6.6, 2.1, 0.1], [8.0, 2.0, 0.0], [9.0, 2.0, 0.0], [12.0, 2.0, 0.0], [14.5, 2.0, 0.0]]))
+        r = s.radii
+        r[:] = 0.5
+        s.set_radii(r)
+        v = s.velocities
+        v[27:54, 0] = -1.5   # the second box moves into the first
+        v[54:, 1] = 0.7
+        s.set_velocities(v)
+        s.set_prev_positions(s.positions)
+        p = s.positions
+        pairs = [(i, 27 + j) for i in range(27) for j in range(27) if np.linalg.norm(p[i] - p[27 + j]) < 1.2]
+        pairs += [(54, 55), (56, 57), (58, 59)]  # overlapping, exactly touching, apart
+        s.add_node_pairs(np.uint32(pairs))
+        return len(pairs)
+    g = pies.Solver(pd_options(pies, 6, friction=0.3, staticFrictionThreshold=0.05))
+    o = oracle.OracleSolver(pd_options(oracle, 6, friction=0.3, staticFrictionThreshold=0.05))
+    o64 = oracle.OracleSolver(pd_options(oracle, 6, friction=0.3, staticFrictionThreshold=0.05))
+    o64.set_flag(oracle.FLAG_PD_SOLVE_FP64, 1)
+    n = [build(s) for s in (g, o, o64)]
+    assert n[0] == n[1] > 20 and g.count(pies.NODE_PAIRS) == o.count(oracle.NODE_PAIRS) == n[0]
+    assert g.ids(pies.NODE_PAIRS).shape == (n[0], 2)
+    g.set_pcg(3e-7, 256)  # w = 1e5 on the diagonal beside elastic terms of order 1: more CG iterations than the default cap
+    start = g.positions.copy()
+    for t in range(4):
+        g.tick(); o.tick(); o64.tick()
+        yardstick("pd_node_pairs", g, o, o64, names=("positions", "velocities"))
+    # the constraint did something: the overlapping loose pair was pushed apart to about the sum of the radii, the distant pair not
+    p = g.positions
+    assert np.linalg.norm(p[54] - p[55]) > np.linalg.norm(start[54] - start[55]) + 0.2
+    assert abs(np.linalg.norm(p[58] - p[59]) - np.linalg.norm(start[58] - start[59])) < 1e-3
+    assert g.pcg_health()["short_solves"] == 0 and not g.failed
