@@ -234,6 +234,23 @@ def roofline(solver, cls, bytes_per_unit, substeps=3, note=None, workload="confi
     return primary_from_profile(out)
 
 
+def valu_issue_of_layer(duration_us):
+    """The OTHER roofline of k_layer at 100k particles: a launch with fewer tiles than compute units lasts as long
+    as its busiest wavefront's instruction stream, and a wavefront alone on its SIMD issues one VALU instruction per 4 cycles
+    (MI355X_MICROARCH.md).  Fraction = that wavefront's VALU instructions (counted in the ISA: profiles/*_layer_critical_path.json)
+    x 4 cycles / 2.4 GHz / the launch's duration: the share of the launch in which the critical wavefront is issuing arithmetic."""
+    for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_layer_critical_path.json")), reverse=True):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                c = json.load(f)
+            insts = c["tet_colour_valu"] * c["tet_colours"] + c["distance_colour_valu"] * c["distance_colours"] + c["load_store_valu"]
+            us = insts * c["cycles_per_valu_one_wavefront_per_simd"] / 2.4e3
+            return {"critical_wavefront_valu": insts, "critical_wavefront_issue_us": us, "frac": us / duration_us, "source": "profiles/" + name}
+        except (OSError, ValueError, KeyError):
+            pass
+    return None
+
+
 def primary_from_profile(out):
     """`frac` / `achieved` are the figures anyone can recompute from the committed profile: bytes per launch / the kernel's AverageNs
     in profiles/*_kernel_stats.csv / 8 TB/s.  The live measurement of this run moves to frac_in_situ / achieved_in_situ (it is 10-15 %
@@ -1169,6 +1186,11 @@ def main():
         }
         if result["roofline"]:
             result["roofline"]["timed_region_us_per_launch"] = 1e6 * (elapsed / args.steps) / max(1, sum(lc.values()))
+            if dom == "layer" and dims == tuple(scenes.L100K):
+                vi = valu_issue_of_layer(result["roofline"].get("rocprofv3_avg_us") or result["roofline"]["avg_launch_us"])
+                if vi:
+                    result["roofline"]["valu_issue"] = vi
+                    result["roofline"]["valu_issue_frac"] = vi["frac"]
         # whole-substep algorithmic traffic over wall time (includes launch gaps)
         per_substep_bytes = (BYTES["predict"] + BYTES["velocity"] + ITERATIONS * BYTES["floor"]) * g.count(capi.NODES) + ITERATIONS * (
             BYTES["distance"] * g.count(capi.DISTANCE) + BYTES["tet"] * g.count(capi.TET) + BYTES["position"] * g.count(capi.POSITION)

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def asm(src):
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "x.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-S", os.path.join(ROOT, "scratch", src), "-o", out, "-O3", "-std=c++17",
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-S", os.path.join(ROOT, "tools", src), "-o", out, "-O3", "-std=c++17",
                                "-ffp-contract=off", "-fno-fast-math", "--offload-arch=gfx950", "--cuda-device-only"], stderr=subprocess.DEVNULL)
         return open(out).read()
 
@@ -46,7 +46,7 @@ rot = asm("rotation_isa.hip")
 body = re.search(r"; ---- rotation begin(.*?); ---- rotation end", rot, re.S).group(1)
 c = classes(instructions(body))
 print("ONE rotation of the product's one-sided Jacobi SVD (jacobi_pair<0,1>, dev_math.h) as hipcc 7.2 emits it for gfx950")
-print("(-O3 -ffp-contract=off; scratch/rotation_isa.hip):")
+print("(-O3 -ffp-contract=off; tools/rotation_isa.hip):")
 for k, v in sorted(c.items(), key=lambda kv: -kv[1]):
     print("  %-62s %4d" % (k, v))
 print()
@@ -56,7 +56,7 @@ print("instructions with v_mov_b32: a quarter of the rotation's instructions mov
 print("instructions) are serial by construction (the second normalises what the first produced) and cannot be paired.")
 print()
 sw = asm("sweep_isa.hip")
-print("Whole decomposition, static instruction counts of the kernels in scratch/sweep_isa.hip (loop body counted once: three")
+print("Whole decomposition, static instruction counts of the kernels in tools/sweep_isa.hip (loop body counted once: three")
 print("rotations of one sweep + prologue + the final normalisation):")
 for name, what in (("svd_scalar", "svd3    (the product: hipcc's own packing)"), ("svd_packed", "svd3_pk (rotations on register pairs, op_sel instead of moves)")):
     b = re.search(r"^" + name + r":(.*?)s_endpgm", sw, re.S | re.M).group(1)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""VALU instructions of ONE Jacobi sweep (three rotations) of the 3x3 SVD variants in scratch/svd_variants.hip, counted in the
+"""VALU instructions of ONE Jacobi sweep (three rotations) of the 3x3 SVD variants in tools/svd_variants.hip, counted in the
 gfx950 ISA hipcc emits (is there a cheaper SVD for k_layer?).  Runs on the CPU (cross-compilation only).
 usage: python tools/svd_isa_counts.py > profiles/r03_svd_isa_counts.txt"""
 import os
@@ -8,7 +8,7 @@ import subprocess
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "scratch", "svd_variants.hip")
+src = os.path.join(ROOT, "tools", "svd_variants.hip")
 with tempfile.TemporaryDirectory() as tmp:
     out = os.path.join(tmp, "svd.s")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-S", src, "-o", out, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",

@@ -7,7 +7,7 @@
 // has 256, 512, 768 or 1 024 threads = 1, 2, 3 or 4 wavefronts per SIMD doing the SAME per-wavefront work.  If a wavefront alone
 // filled its SIMD, w wavefronts per SIMD would take w times as long; whatever they take less is what co-residency hides.
 //
-// build: hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -I pies_amd/csrc -I include scratch/svd_overlap.hip -o /tmp/svd_overlap
+// build: hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -I pies_amd/csrc -I include tools/svd_overlap.hip -o /tmp/svd_overlap
 #include <hip/hip_runtime.h>
 
 #include <cstdio>

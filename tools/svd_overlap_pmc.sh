@@ -1,12 +1,12 @@
 #!/bin/bash
-# Counters of the co-residency micro-benchmark of the PBD tetrahedral projection (scratch/svd_overlap.hip, built to
-# scratch/svd_overlap.bin): one workgroup per compute unit of 256 / 512 / 768 / 1 024 threads = 1 / 2 / 3 / 4 wavefronts per SIMD
+# Counters of the co-residency micro-benchmark of the PBD tetrahedral projection (tools/svd_overlap.hip, built to
+# tools/_bin/svd_overlap): one workgroup per compute unit of 256 / 512 / 768 / 1 024 threads = 1 / 2 / 3 / 4 wavefronts per SIMD
 # running the SAME dependent chain of 200 projections per lane.  VERDICT r4 item 5 asked for SQ_INSTS_VALU, SQ_BUSY_CYCLES,
 # SQ_WAIT_INST_ANY of both variants.  On the GPU box: bash tools/svd_overlap_pmc.sh > gpurun_out/r05_svd_overlap_pmc.txt
 cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/svdpmc; rm -rf $out; mkdir -p $out
 for pass in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   d=$out/$(echo $pass | tr ' ' '_')
-  timeout -k 10 120 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $d -o t -- $R/scratch/svd_overlap.bin > $d.log 2>&1 || { tail -5 $d.log; exit 1; }
+  timeout -k 10 120 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $d -o t -- $R/tools/_bin/svd_overlap > $d.log 2>&1 || { tail -5 $d.log; exit 1; }
   grep "wavefront(s) per SIMD" $d.log | head -4
 done
 cd $R && python3 - <<'PY'

@@ -3,7 +3,7 @@
 //   B  two-sided Jacobi on S = F^T F with the exact rotation (two rsqrt_nr), V accumulated as a matrix, fixed sweeps
 //   C  two-sided Jacobi on S with McAdams' approximate Givens rotation (one rsqrt_nr, half-angle clamp at pi/8), V accumulated
 //      as a quaternion, fixed sweeps (Computing the SVD of 3x3 matrices with minimal branching ..., 2011)
-// Each kernel runs ONE sweep (three rotations) on registers; `make -C scratch svd_counts` prints the VALU instructions of one
+// Each kernel runs ONE sweep (three rotations) on registers; `python tools/svd_isa_counts.py` prints the VALU instructions of one
 // sweep.  B and C also need S = F^T F up front (18 instructions) and B = F V afterwards (15): charged in the table of DESIGN.md.
 #include <hip/hip_runtime.h>
 #include "../pies_amd/csrc/dev_math.h"
