@@ -1,6 +1,6 @@
 """pbd 1M and the unstructured 100k beam (PBD, LAYERED): substeps/s"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "benchlib")):
     sys.path.insert(0, p)
 import bench, scenes

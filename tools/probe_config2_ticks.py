@@ -1,6 +1,6 @@
 """config 2 tick by tick: ms per tick (41 launches of k_layer) as the beam collapses onto the floor."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "benchlib")):
     sys.path.insert(0, p)
 import numpy as np

@@ -1,5 +1,5 @@
-import sys, numpy as np, ctypes
-sys.path.insert(0, "benchlib"); sys.path.insert(0, ".")
+import os, sys, numpy as np, ctypes
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [ROOT, os.path.join(ROOT, "benchlib")]
 import oracle_api as ora, scenes
 L = ora.lib()
 L.ora_svd_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
