@@ -444,3 +444,32 @@ def test_pd_node_pair_collision_constraints(pies, oracle):
     assert np.linalg.norm(p[54] - p[55]) > np.linalg.norm(start[54] - start[55]) + 0.2
     assert abs(np.linalg.norm(p[58] - p[59]) - np.linalg.norm(start[58] - start[59])) < 1e-3
     assert g.pcg_health()["short_solves"] == 0 and not g.failed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sort,kernels,chunk", [("0", "3", "256"), ("1", "3", "256"), ("1", "1", "64"), ("0", "7", "1024"), ("1", "7", "64")])
+def test_windowed_matrix_changes_nothing(pies, tune, sort, kernels, chunk):
+    """The windowed SELL matrix (its only coverage was the row-dictionary test) against the plain SELL arrays
+    (PIES_PD_WINDOW=0) on an unstructured beam: rows sorted by length or not (PIES_PD_WINDOW_SORT), the window taken by the
+    iterations only / + the first product / + the residual kernel with its fp64 sums and the right-hand side parked in LDS
+    (PIES_PD_WINDOW_KERNELS 1 / 3 / 7), chunks of 64 / 256 / 1 024 rows (a partial last chunk, and at 1 024 rows a window above 64 KB
+    of dynamic LDS on this mesh).  Entries keep their order inside a row, so a row's sum is the same fused multiply-add chain in
+    every form: positions and velocities equal bit for bit after three ticks."""
+    mesh = scenes.delaunay_beam((6, 5, 30), seed=11)
+    res = []
+    for window in ("0", "1"):
+        tune("PIES_PD_WINDOW", window)
+        tune("PIES_PD_WINDOW_SORT", sort)
+        tune("PIES_PD_WINDOW_KERNELS", kernels)
+        tune("PIES_CG_CHUNK_ROWS", chunk)
+        g = pies.Solver(pd_options(pies, 6))
+        scenes.build_unstructured_pd(g, mesh)
+        scenes.perturb(g, 5, 0.03)
+        g.set_prev_positions(g.positions)
+        g.finalize()
+        assert (g.count(pies.PD_WINDOW_ENTRIES) > 0) == (window == "1") and g.count(pies.ROW_STENCILS) == 0
+        g.tick(3)
+        assert not g.failed and g.pcg_health()["short_solves"] == 0
+        res.append((g.positions, g.velocities))
+        g.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]), float(np.abs(res[0][0] - res[1][0]).max())
