@@ -316,3 +316,57 @@ def test_collision_orders_agree_where_order_cannot_matter():
         assert np.abs(out[0][0] - out[rule][0]).max() < 1e-5 and np.abs(out[0][1] - out[rule][1]).max() < 1e-3, rule
     # (a pair's overlap shrinks by 0.15 per resolved visit: the last of its visits see overlaps at rounding level and count or not)
     assert max(o[2] for o in out) - min(o[2] for o in out) < 0.02 * out[0][2], [o[2] for o in out]
+
+
+def test_svd_closed_form_start_on_every_matrix_class():
+    """Round 6's decomposition (ora_math.h svd3: closed-form eigenvector frame of A^T A, one rotation, three small-angle polishes,
+    certifying sweeps) on the classes that could break a closed form: generic, near rest, double and triple singular values,
+    nearly flat (sigma_3 down to 1e-5 sigma_1), needles, exactly rank-deficient (a zero column; a generic rank-2 matrix), zero,
+    tiny and huge scale (outside the closed form's range: the plain iteration takes them).  For every matrix: A V = B to rounding,
+    V orthonormal, the columns of B orthogonal to the certified tolerance, the singular values LAPACK's in fp64 - and the plain
+    iteration from V = I (FLAG_SVD_PLAIN's routine through project_tet) gives the same projection."""
+    rng = np.random.default_rng(77)
+
+    def rot(n):
+        q, _ = np.linalg.qr(rng.normal(size=(n, 3, 3)))
+        return q
+
+    def diag(s, n):
+        return rot(n) @ (np.asarray(s, dtype=np.float64)[None, :, None] * rot(n).transpose(0, 2, 1))
+    n = 300
+    classes = {
+        "generic": rng.normal(size=(n, 3, 3)),
+        "near rest": rot(n) @ (np.eye(3) + 0.05 * rng.normal(size=(n, 3, 3))),
+        "exact rotation": rot(n),
+        "double": diag([1.3, 1.3, 0.7], n), "double low": diag([1.3, 0.7, 0.7], n), "triple": 1.3 * rot(n),
+        "flat 5e-2": diag([1.3, 0.9, 0.05], n), "flat 1e-5": diag([1.3, 0.9, 1e-5], n), "needle": diag([1.3, 1e-4, 2e-4], n),
+        "zero column": rng.normal(size=(n, 3, 3)) * np.array([1.0, 0.0, 1.0])[None, None, :],
+        "rank 2": diag([1.3, 0.9, 0.0], n), "zero": np.zeros((4, 3, 3)),
+        "tiny": 1e-12 * rng.normal(size=(n, 3, 3)), "huge": 1e6 * rng.normal(size=(n, 3, 3)),
+    }
+    tol = 4.76837158203125e-07
+    for name, As in classes.items():
+        for A in As.astype(np.float32):
+            s, b, v = O.svd3(A)  # b[i] = column i of A V, v[i] = column i of V
+            scale = max(float(np.abs(A).max()), 1e-30)
+            assert np.isfinite(s).all() and np.isfinite(b).all() and np.isfinite(v).all(), name
+            assert np.abs(v @ v.T - np.eye(3)).max() < 2e-6, (name, "V orthonormal")
+            assert np.abs(A.astype(np.float64) @ v.T.astype(np.float64) - b.T).max() < 4e-6 * scale, (name, "A V = B")
+            for i, j in ((0, 1), (0, 2), (1, 2)):
+                ni, nj = float(b[i] @ b[i]), float(b[j] @ b[j])
+                if ni * nj > 1e-36:  # (numerically zero columns are exempt, like in the routine)
+                    assert abs(float(b[i] @ b[j])) <= 1.05 * tol * np.sqrt(ni * nj) + 1e-18, (name, i, j)
+            if name not in ("tiny",):  # (below 1e-18 a column counts as collapsed: s = 0 by contract)
+                ref = np.linalg.svd(A.astype(np.float64), compute_uv=False)
+                assert np.abs(np.sort(s)[::-1] - ref).max() < 3e-6 * max(ref[0], 1e-30) + 1e-18, (name, s, ref)
+    # the plain iteration and the closed-form start give the same projection (up to fp32 rounding)
+    x = np.vstack([np.zeros(3, np.float32), classes["flat 5e-2"][0].astype(np.float32).T])
+    q = np.eye(3, dtype=np.float32).reshape(9)
+    o = O.OracleSolver(O.Options())
+    a = O.project_tet(x, q, 0.8, 1.0)
+    o.set_flag(O.FLAG_SVD_PLAIN, 1)
+    try:
+        bplain = O.project_tet(x, q, 0.8, 1.0)
+    finally:
+        o.set_flag(O.FLAG_SVD_PLAIN, 0)
+    assert np.abs(a - bplain).max() < 2e-6
