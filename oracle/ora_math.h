@@ -309,30 +309,31 @@ inline float recip_rough(float x) {
   i = 0x7EF311C7 - (i & 0x7fffffff);
   float y;
   std::memcpy(&y, &i, 4);
-  const float ax = std::fabs(x);
-  y = y * std::fmaf(-ax, y, 2.0f);
-  y = y * std::fmaf(-ax, y, 2.0f);
+  y = y * std::fmaf(-std::fabs(x), y, 2.0f);
+  y = y * std::fmaf(-std::fabs(x), y, 2.0f);
   return std::copysign(y, x);
 }
-// The small-angle form of the rotation of the pair (p, q): (cos, sin) ~ (1, t), t = g / (b - a), applied unnormalised
-// (the columns grow by t^2 / 2 < 3e-8).  What the closed-form frame leaves between its isolated direction and the other two
-// is a rounding-level angle (~1e-6) - but one that an ill-conditioned element (a nearly flat one: the smallest column is 20x
-// shorter than the others) fails the relative test on; this takes it out for 30 instructions instead of a full rotation's 70.
-inline void jacobi_polish(Svd3& d, int p, int q) {
-  float* bp = d.b[p];
-  float* bq = d.b[q];
-  const float alpha = dot3f(bp, bp);
-  const float beta = dot3f(bq, bq);
-  const float gamma = dot3f(bp, bq);
-  float t = gamma * recip_rough(beta - alpha);
-  if (!(std::fabs(t) < 2.5e-4f)) t = 0.0f;  // (also NaN: equal norms)
+// The small-angle form of the three rotations, applied together and unnormalised: B <- B (I + T), V <- V (I + T), T antisymmetric,
+// t_pq = g_pq / (|b_q|^2 - |b_p|^2) from one snapshot of the six inner products (|t| < 2.5e-4: the columns grow by t^2 / 2 < 3e-8).
+// What the closed-form frame leaves between its isolated direction and the other two - and what the full rotation of the pair
+// (0, 1) leaves between a long and a short column - is a rounding-level angle (~1e-6), but one that an ill-conditioned element
+// (a nearly flat one) fails the relative test on; this takes it out without a rotating sweep.
+inline void jacobi_polish(Svd3& d) {
+  const float n0 = dot3f(d.b[0], d.b[0]), n1 = dot3f(d.b[1], d.b[1]), n2 = dot3f(d.b[2], d.b[2]);
+  const float g01 = dot3f(d.b[0], d.b[1]), g02 = dot3f(d.b[0], d.b[2]), g12 = dot3f(d.b[1], d.b[2]);
+  float t01 = g01 * recip_rough(n1 - n0), t02 = g02 * recip_rough(n2 - n0), t12 = g12 * recip_rough(n2 - n1);
+  if (!(std::fabs(t01) < 2.5e-4f)) t01 = 0.0f;  // (also NaN: equal norms)
+  if (!(std::fabs(t02) < 2.5e-4f)) t02 = 0.0f;
+  if (!(std::fabs(t12) < 2.5e-4f)) t12 = 0.0f;
   for (int k = 0; k < 3; ++k) {
-    const float x = bp[k], y = bq[k];
-    bp[k] = std::fmaf(-t, y, x);
-    bq[k] = std::fmaf(t, x, y);
-    const float vx = d.v[p][k], vy = d.v[q][k];
-    d.v[p][k] = std::fmaf(-t, vy, vx);
-    d.v[q][k] = std::fmaf(t, vx, vy);
+    const float x = d.b[0][k], y = d.b[1][k], z = d.b[2][k];
+    d.b[0][k] = std::fmaf(-t02, z, std::fmaf(-t01, y, x));
+    d.b[1][k] = std::fmaf(-t12, z, std::fmaf(t01, x, y));
+    d.b[2][k] = std::fmaf(t12, y, std::fmaf(t02, x, z));
+    const float vx = d.v[0][k], vy = d.v[1][k], vz = d.v[2][k];
+    d.v[0][k] = std::fmaf(-t02, vz, std::fmaf(-t01, vy, vx));
+    d.v[1][k] = std::fmaf(-t12, vz, std::fmaf(t01, vx, vy));
+    d.v[2][k] = std::fmaf(t12, vy, std::fmaf(t02, vx, vz));
   }
 }
 inline Svd3 svd3(const float a[3][3]) {
@@ -380,9 +381,7 @@ inline Svd3 svd3(const float a[3][3]) {
       }
     d.closed_form = true;
     d.rotations += jacobi_pair(d, 0, 1) ? 1 : 0;
-    jacobi_polish(d, 0, 2);
-    jacobi_polish(d, 1, 2);
-    jacobi_polish(d, 0, 1);
+    jacobi_polish(d);
   } else {
     for (int i = 0; i < 3; ++i)
       for (int k = 0; k < 3; ++k) {

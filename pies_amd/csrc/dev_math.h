@@ -178,32 +178,35 @@ PIES_DEV float recip12(float t) {
 // 1 / x to ~2e-4 (integer seed, two Newton steps), any sign: enough for a correction that is itself of the order of 1e-6
 PIES_DEV float recip_rough(float x) {
   float y = __int_as_float(0x7EF311C7 - (__float_as_int(x) & 0x7fffffff));
-  const float ax = fabsf(x);
-  y = y * fmaf(-ax, y, 2.0f);
-  y = y * fmaf(-ax, y, 2.0f);
+  y = y * fmaf(-fabsf(x), y, 2.0f);
+  y = y * fmaf(-fabsf(x), y, 2.0f);
   return __builtin_copysignf(y, x);
 }
-// The small-angle form of the rotation of the pair (P, Q): (cos, sin) ~ (1, t), t = g / (b - a), applied unnormalised (the
-// columns grow by t^2 / 2 < 3e-8).  What the closed-form frame leaves between its isolated direction and the other two - and
-// what the full rotation of the pair (0, 1) leaves between a long and a short column - is a rounding-level angle (~1e-6), but
-// one that an ill-conditioned element (a nearly flat one: its smallest column 20x shorter than the others - every element of
-// BASELINE config 2 between the floor clamps) fails the relative test on.  This takes it out for ~30 instructions in every
-// lane; left to the certifying sweeps it costs a rotating sweep (3 x 70) and another clean one in every WAVEFRONT that holds
-// such an element (measured on config 2: 18 % of the elements, i.e. every wavefront).
-template <int P, int Q> PIES_DEV void jacobi_polish(Svd3& d) {
-  const float alpha = dot3f(d.b[P], d.b[P]);
-  const float beta = dot3f(d.b[Q], d.b[Q]);
-  const float gamma = dot3f(d.b[P], d.b[Q]);
-  float t = gamma * recip_rough(beta - alpha);
-  if (!(fabsf(t) < 2.5e-4f)) t = 0.0f;  // (also NaN: equal norms)
+// The small-angle form of the three rotations, applied TOGETHER and unnormalised: B <- B (I + T), V <- V (I + T) with T
+// antisymmetric, t_pq = g_pq / (|b_q|^2 - |b_p|^2) from one snapshot of the six inner products (|t| < 2.5e-4: the columns grow by
+// t^2 / 2 < 3e-8, the cross terms are of second order).  What the closed-form frame leaves between its isolated direction and the
+// other two - and what the full rotation of the pair (0, 1) leaves between a long and a short column - is a rounding-level
+// angle (~1e-6), but one that an ill-conditioned element (a nearly flat one: its smallest column 20x shorter than the others -
+// every element of BASELINE config 2 between the floor clamps) fails the relative test on.  This takes it out for ~85
+// instructions in every lane; left to the certifying sweeps it costs a rotating sweep (3 x 70) and another clean one in every
+// WAVEFRONT that holds such an element (measured on config 2: 18 % of the elements, i.e. every wavefront).
+PIES_DEV void jacobi_polish(Svd3& d) {
+  const float n0 = dot3f(d.b[0], d.b[0]), n1 = dot3f(d.b[1], d.b[1]), n2 = dot3f(d.b[2], d.b[2]);
+  const float g01 = dot3f(d.b[0], d.b[1]), g02 = dot3f(d.b[0], d.b[2]), g12 = dot3f(d.b[1], d.b[2]);
+  float t01 = g01 * recip_rough(n1 - n0), t02 = g02 * recip_rough(n2 - n0), t12 = g12 * recip_rough(n2 - n1);
+  if (!(fabsf(t01) < 2.5e-4f)) t01 = 0.0f;  // (also NaN: equal norms)
+  if (!(fabsf(t02) < 2.5e-4f)) t02 = 0.0f;
+  if (!(fabsf(t12) < 2.5e-4f)) t12 = 0.0f;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const float x = d.b[P][k], y = d.b[Q][k];
-    d.b[P][k] = fmaf(-t, y, x);
-    d.b[Q][k] = fmaf(t, x, y);
-    const float vx = d.v[P][k], vy = d.v[Q][k];
-    d.v[P][k] = fmaf(-t, vy, vx);
-    d.v[Q][k] = fmaf(t, vx, vy);
+    const float x = d.b[0][k], y = d.b[1][k], z = d.b[2][k];
+    d.b[0][k] = fmaf(-t02, z, fmaf(-t01, y, x));
+    d.b[1][k] = fmaf(-t12, z, fmaf(t01, x, y));
+    d.b[2][k] = fmaf(t12, y, fmaf(t02, x, z));
+    const float vx = d.v[0][k], vy = d.v[1][k], vz = d.v[2][k];
+    d.v[0][k] = fmaf(-t02, vz, fmaf(-t01, vy, vx));
+    d.v[1][k] = fmaf(-t12, vz, fmaf(t01, vx, vy));
+    d.v[2][k] = fmaf(t12, vy, fmaf(t02, vx, vz));
   }
 }
 // a[r][c]: row-major input.  A*V = B with orthogonal columns; s_i = |b_i|.
@@ -257,9 +260,7 @@ PIES_DEV void svd3(const float a[3][3], Svd3& d) {
         d.b[i][k] = fmaf(A[2][k], V[i][2], fmaf(A[1][k], V[i][1], A[0][k] * V[i][0]));
       }
     (void)jacobi_pair<0, 1>(d);
-    jacobi_polish<0, 2>(d);
-    jacobi_polish<1, 2>(d);
-    jacobi_polish<0, 1>(d);
+    jacobi_polish(d);
   } else {
 #pragma unroll
     for (int i = 0; i < 3; ++i)

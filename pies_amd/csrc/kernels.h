@@ -52,6 +52,8 @@ struct LayerSeg {
 struct LayerLaunch {
   uint32_t phase, groups, nseg, maxClass;  // phase = 2 * (level parity) + (strip parity); groups = tiles of that phase
   uint32_t loadGlobal, storeGlobal;  // node records from / to the node array instead of the layer-ordered copy
+  const uint4* tileList;             // = LayerData::tiles[phase], resolved by launch_layer (one dependent load less at the kernel's start)
+  uint32_t needRadius;               // a floor / velocity segment is in the launch (set by launch_layer)
   LayerSeg seg[kLayerMaxSegs];
 #ifdef PIES_EXPERIMENTS
   uint32_t stampSlot;  // diagnostic build: the launch's place in the time-stamp buffer (layer_kernels.hip)

@@ -57,8 +57,11 @@ __global__ void __launch_bounds__(BLOCK, WPE) k_layer(NodeArrays nd, LayerData D
   float* __restrict__ srad = reinterpret_cast<float*>(sp + D.maxGroupNodes);      // their radii
   uint32_t* __restrict__ soff = reinterpret_cast<uint32_t*>(srad + D.maxGroupNodes);  // colour offsets, per segment
   const uint32_t tid = threadIdx.x;
-  const uint32_t g = xcd_block(blockIdx.x, gridDim.x);  // neighbouring groups (shared levels) meet in one XCD's L2
-  const uint4 tile = D.tiles[L.phase][g];
+  // (the grid size and the phase's tile list come with the launch record: the kernel's first loads are then ONE line of its
+  // arguments and the tile's descriptor - gridDim.x lives in the hidden arguments, another cache line, and D.tiles[L.phase] is a
+  // pointer fetched through a pointer: each a dependent scalar round trip of ~0.2 us before the first node record is requested)
+  const uint32_t g = xcd_block(blockIdx.x, L.groups);  // neighbouring groups (shared levels) meet in one XCD's L2
+  const uint4 tile = L.tileList[g];
   const uint32_t m = tile.y + tile.w;
   if (m == 0) return;  // uniform: an empty tile
   if (!PIES_IN_BOUNDS(m <= D.maxGroupNodes, 10u)) return;  // (uniform) the tile's node records fit the LDS the launch asked for
@@ -68,41 +71,85 @@ __global__ void __launch_bounds__(BLOCK, WPE) k_layer(NodeArrays nd, LayerData D
   // LDS index -> position in the level-ordered node list (two runs: the tile's part of its two levels)
   auto lp = [&](uint32_t i) { return i < tile.y ? tile.x + i : tile.z + (i - tile.y); };
 
-  bool needRadius = false;
-  for (uint32_t s = 0; s < L.nseg; ++s) needRadius |= L.seg[s].kind == LAYER_FLOOR || L.seg[s].kind == LAYER_VELOCITY;
+  // The prologue is ONE round trip to memory: every load that depends only on the tile descriptor - the colour offsets of the
+  // launch's segments, the radii, the first four node records of every lane - is requested before anything is waited for, then
+  // LDS is written.  (Rounds 2-5 ran node records -> radii -> colour offsets as three load-wait-store loops behind each other and
+  // found out whether the radii are needed by walking the segment list with scalar loads: ~1 us of a 1.9-us prologue.)
+  const bool needRadius = L.needRadius != 0;
+  // (all six segment records are read unconditionally - unused ones hold ncol = 0, launch_layer sees to that - so that their
+  // scalar loads are issued together instead of one dependent round trip per segment)
+  uint32_t segCols[kLayerMaxSegs];
+  const uint32_t* segOff[kLayerMaxSegs];
+#pragma unroll
+  for (int s = 0; s < kLayerMaxSegs; ++s) { segCols[s] = L.seg[s].ncol; segOff[s] = L.seg[s].colOff; }
+  uint32_t offReg[kLayerMaxSegs];
+  float radReg[kBatch];
+  auto request_early = [&]() {  // (called inside both branches of the node load below: a branch waits for every load in flight)
+#pragma unroll
+    for (int s = 0; s < kLayerMaxSegs; ++s) {
+      offReg[s] = 0u;
+      const uint32_t nc = segCols[s];
+      if (nc != 0 && tid <= nc + 1) offReg[s] = (segOff[s] + static_cast<size_t>(g) * (nc + 1))[min(tid, nc)];
+    }
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) radReg[k] = needRadius ? D.lrad[lp(min(k * BLOCK + tid, m - 1))] : 0.0f;
+  };
   // Node records in: from the level-ordered copy (the tile's two runs are contiguous: coalesced) or, with one strip, in
   // the first launch of a substep / after a collision pass, gathered from the node array.  Four requests per lane are in flight before
   // the first is consumed (clamped indices keep the loads unconditional, so nothing waits at a branch join).
-  if (L.loadGlobal) {
-    for (uint32_t base = 0; base < m; base += kBatch * BLOCK) {
+  // (the first four records of every lane outside the loop: a loop header waits for every load in flight)
+  auto load4 = [&](uint32_t base, float4& r0, float4& r1, float4& r2, float4& r3) {
+    const uint32_t i = base + tid;
+    if (L.loadGlobal) {
       uint32_t v[kBatch];
 #pragma unroll
-      for (int k = 0; k < kBatch; ++k) v[k] = D.nodeList[lp(min(base + k * BLOCK + tid, m - 1))];
-      const float4 r0 = nd.pos[v[0]], r1 = nd.pos[v[1]], r2 = nd.pos[v[2]], r3 = nd.pos[v[3]];
-      const uint32_t i = base + tid;
-      if (i < m) sp[i] = r0;
-      if (i + BLOCK < m) sp[i + BLOCK] = r1;
-      if (i + 2 * BLOCK < m) sp[i + 2 * BLOCK] = r2;
-      if (i + 3 * BLOCK < m) sp[i + 3 * BLOCK] = r3;
+      for (int k = 0; k < kBatch; ++k) v[k] = D.nodeList[lp(min(i + k * BLOCK, m - 1))];
+      r0 = nd.pos[v[0]]; r1 = nd.pos[v[1]]; r2 = nd.pos[v[2]]; r3 = nd.pos[v[3]];
+    } else {
+      r0 = D.lpos[lp(min(i, m - 1))]; r1 = D.lpos[lp(min(i + BLOCK, m - 1))]; r2 = D.lpos[lp(min(i + 2 * BLOCK, m - 1))];
+      r3 = D.lpos[lp(min(i + 3 * BLOCK, m - 1))];
     }
-  } else {
-    for (uint32_t base = 0; base < m; base += kBatch * BLOCK) {
-      const uint32_t i = base + tid;
-      const float4 r0 = D.lpos[lp(min(i, m - 1))], r1 = D.lpos[lp(min(i + BLOCK, m - 1))], r2 = D.lpos[lp(min(i + 2 * BLOCK, m - 1))],
-                   r3 = D.lpos[lp(min(i + 3 * BLOCK, m - 1))];
-      if (i < m) sp[i] = r0;
-      if (i + BLOCK < m) sp[i + BLOCK] = r1;
-      if (i + 2 * BLOCK < m) sp[i + 2 * BLOCK] = r2;
-      if (i + 3 * BLOCK < m) sp[i + 3 * BLOCK] = r3;
+  };
+  auto store4 = [&](uint32_t base, const float4& r0, const float4& r1, const float4& r2, const float4& r3) {
+    const uint32_t i = base + tid;
+    if (i < m) sp[i] = r0;
+    if (i + BLOCK < m) sp[i + BLOCK] = r1;
+    if (i + 2 * BLOCK < m) sp[i + 2 * BLOCK] = r2;
+    if (i + 3 * BLOCK < m) sp[i + 3 * BLOCK] = r3;
+  };
+  {
+    float4 r0, r1, r2, r3;
+    if (L.loadGlobal) {  // (uniform)
+      request_early();
+      uint32_t v[kBatch];
+#pragma unroll
+      for (int k = 0; k < kBatch; ++k) v[k] = D.nodeList[lp(min(tid + k * BLOCK, m - 1))];
+      r0 = nd.pos[v[0]]; r1 = nd.pos[v[1]]; r2 = nd.pos[v[2]]; r3 = nd.pos[v[3]];
+    } else {
+      request_early();
+      r0 = D.lpos[lp(min(tid, m - 1))]; r1 = D.lpos[lp(min(tid + BLOCK, m - 1))]; r2 = D.lpos[lp(min(tid + 2 * BLOCK, m - 1))];
+      r3 = D.lpos[lp(min(tid + 3 * BLOCK, m - 1))];
     }
+    store4(0u, r0, r1, r2, r3);
   }
-  if (needRadius)
-    for (uint32_t i = tid; i < m; i += BLOCK) srad[i] = D.lrad[lp(i)];
-  for (uint32_t s = 0; s < L.nseg; ++s) {
-    const uint32_t nc = L.seg[s].ncol;
-    if (nc == 0) continue;
-    const uint32_t* __restrict__ src = L.seg[s].colOff + static_cast<size_t>(g) * (nc + 1);
-    for (uint32_t c = tid; c <= nc + 1; c += BLOCK) soff[s * kOffStride + c] = src[c <= nc ? c : nc];
+  for (uint32_t base = kBatch * BLOCK; base < m; base += kBatch * BLOCK) {  // (tiles of more than 4 x BLOCK nodes)
+    float4 r0, r1, r2, r3;
+    load4(base, r0, r1, r2, r3);
+    store4(base, r0, r1, r2, r3);
+  }
+  if (needRadius) {
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k)
+      if (k * BLOCK + tid < m) srad[k * BLOCK + tid] = radReg[k];
+    for (uint32_t i = kBatch * BLOCK + tid; i < m; i += BLOCK) srad[i] = D.lrad[lp(i)];  // (tiles of more than 4 x BLOCK nodes)
+  }
+#pragma unroll
+  for (int s = 0; s < kLayerMaxSegs; ++s) {
+    const uint32_t nc = segCols[s];
+    if (nc != 0) {
+      if (tid <= nc + 1) soff[s * kOffStride + tid] = offReg[s];
+      for (uint32_t c = tid + BLOCK; c <= nc + 1; c += BLOCK) soff[s * kOffStride + c] = (segOff[s] + static_cast<size_t>(g) * (nc + 1))[min(c, nc)];
+    }
   }
   __syncthreads();
   PIES_STAMP();
@@ -369,6 +416,10 @@ hipError_t layer_prepare(uint32_t maxGroupNodes) {
 void launch_layer(hipStream_t st, const NodeArrays& nd, const LayerData& D, const LayerLaunch& L0, const LayerParams& P) {
   if (L0.groups == 0 || L0.nseg == 0) return;
   LayerLaunch L = L0;
+  L.tileList = D.tiles[L.phase];
+  for (uint32_t s = L.nseg; s < static_cast<uint32_t>(kLayerMaxSegs); ++s) L.seg[s] = LayerSeg{};  // (the kernel reads all six)
+  L.needRadius = 0u;
+  for (uint32_t s = 0; s < L.nseg; ++s) L.needRadius |= (L.seg[s].kind == LAYER_FLOOR || L.seg[s].kind == LAYER_VELOCITY) ? 1u : 0u;
   const size_t lds = layer_lds_bytes(D.maxGroupNodes);
 #ifdef PIES_EXPERIMENTS  // timing experiments that change the work done: never part of the product build (build.py)
   const int skipMask = [] { const char* e = getenv("PIES_EXP_LAYER_SKIP"); return e ? atoi(e) : 0; }();
