@@ -52,6 +52,7 @@ PIES_DEV uint32_t hi16(uint32_t v) { return v >> 16; }
 template <int BLOCK, int TETV, int WPE = 1>
 __global__ void __launch_bounds__(BLOCK, WPE) k_layer(NodeArrays nd, LayerData D, LayerLaunch L, LayerParams P) {
   constexpr int kDistPreload = (WPE > 1 || BLOCK > 512) ? 6 : kDistPreloadMax;
+  constexpr int kDistAhead = 3;  // colours of a distance segment whose records are in flight
   extern __shared__ float4 lds[];
   float4* __restrict__ sp = lds;                                                  // node records of the group
   float* __restrict__ srad = reinterpret_cast<float*>(sp + D.maxGroupNodes);      // their radii
@@ -209,13 +210,18 @@ __global__ void __launch_bounds__(BLOCK, WPE) k_layer(NodeArrays nd, LayerData D
         lo = nlo; hi = nhi; have = nhave; id = nid; a0 = b0; a1 = b1; a2 = b2;
       }
     } else if (kind == LAYER_DISTANCE) {
-      // a projection is ~40 instructions, far shorter than a record's way from HBM: every lane requests its record
-      // of each of the first kDistPreload colours at once and the latency is paid once per segment
+      // a projection is ~40 instructions, far shorter than a record's way from HBM: every lane keeps the records of kDistAhead
+      // colours in flight - those of colour c + kDistAhead are requested when colour c begins - so the latency is paid once per
+      // segment.  (Rounds 2-5 requested all kDistPreload colours at once: a tile's 36 KB of records are ~290 cache lines against
+      // the ~64 a compute unit keeps in flight, and the first colour waited for most of them - 2.1 us against 0.48 for the others
+      // in the in-kernel stamps; 1.3 us now.  2, 3, 4 and 6 ahead measure the same.)
       const uint32_t last = off[ncol] > off[0] ? off[ncol] - 1 : 0;
       uint32_t id[kDistPreload];
       float2 rw[kDistPreload];
 #pragma unroll
-      for (int c = 0; c < kDistPreload; ++c) {
+      for (int c = 0; c < kDistPreload; ++c) { id[c] = 0u; rw[c] = make_float2(0.f, 0.f); }
+#pragma unroll
+      for (int c = 0; c < kDistAhead; ++c) {
         const uint32_t cc = min(static_cast<uint32_t>(c), ncol - 1);
         const uint32_t t = min(off[cc] + tid, last);
         id[c] = D.dc_lid[t];
@@ -224,6 +230,12 @@ __global__ void __launch_bounds__(BLOCK, WPE) k_layer(NodeArrays nd, LayerData D
 #pragma unroll
       for (int c = 0; c < kDistPreload; ++c) {
         if (static_cast<uint32_t>(c) < ncol) {
+          if (c + kDistAhead < kDistPreload) {  // (compile time) the records of colour c + kDistAhead, requested kDistAhead colours ahead
+            const uint32_t cc = min(static_cast<uint32_t>(c + kDistAhead), ncol - 1);
+            const uint32_t t = min(off[cc] + tid, last);
+            id[(c + kDistAhead) % kDistPreload] = D.dc_lid[t];
+            rw[(c + kDistAhead) % kDistPreload] = D.dc_rw[t];
+          }
           if (off[c] + tid < off[c + 1] && PIES_IN_BOUNDS(max(lo16(id[c]), hi16(id[c])) < m, 12u)) {
             float4 a = sp[lo16(id[c])];
             distance_core(a, sp[hi16(id[c])], rw[c]);
