@@ -35,6 +35,33 @@
 
 namespace pies {
 
+// In-kernel time stamps of a diagnostic build (python -m pies_amd.build --exp; tools/cg_timeline.py): lane 0 of every workgroup of
+// k_cg1_iter notes s_memtime at the points marked CG_STAMP.  Never part of the product build: there CgStamp is empty.
+#ifdef PIES_EXPERIMENTS
+__device__ unsigned long long* g_cg_stamps = nullptr;  // [iteration & 7][workgroup < 4096][32]
+struct CgStamp {
+  unsigned long long* base = nullptr;
+  int idx = 0;
+  PIES_DEV void open(int it) {
+    if (g_cg_stamps && threadIdx.x == 0 && blockIdx.x < 4096u) {
+      base = g_cg_stamps + (static_cast<size_t>(it & 7) * 4096u + blockIdx.x) * 32u;
+      base[idx++] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
+  PIES_DEV void mark() { if (base && idx < 31) base[idx++] = __builtin_amdgcn_s_memtime(); }
+  PIES_DEV void close() { if (base) base[31] = __builtin_amdgcn_s_memrealtime(); }
+};
+extern "C" int pies_exp_cg_stamps(unsigned long long* deviceBuffer) {  // 8 x 4096 x 32 x 8 bytes, or nullptr
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_cg_stamps), &deviceBuffer, sizeof(deviceBuffer)) == hipSuccess ? 0 : 1;
+}
+#else
+struct CgStamp {
+  PIES_DEV void open(int) {}
+  PIES_DEV void mark() {}
+  PIES_DEV void close() {}
+};
+#endif
+
 // f(value, column) for every stored entry of row i (lane `lane` of slice `sl`): the row dictionary or the SELL arrays
 template <class F> PIES_DEV void row_entries(const CgArrays& A, uint32_t sl, uint32_t lane, uint32_t i, F f) {
   if (A.rowStencil) {
@@ -83,7 +110,9 @@ PIES_DEV ChunkSweep chunk_sweep(uint32_t nchunks, uint32_t nblocks) {
 // depend on it.  The entries in registers across the fill cost 40-60 registers and scalar spills: 12.4 against 10.4 us per launch at
 // 100k rows, 14.1 against 12.7 on the unstructured beam.)
 template <class ACC, bool AUX, class Own, class Halo, class Row>
-PIES_DEV void window_rows(const CgArrays& A, uint32_t nblocks, Own own, Halo halo, Row row) {
+PIES_DEV void window_rows(const CgArrays& A, uint32_t nblocks, Own own, Halo halo, Row row, CgStamp* stamp = nullptr) {
+  CgStamp none;
+  CgStamp& st = stamp ? *stamp : none;
   extern __shared__ float4 pies_window[];
   float4* __restrict__ win = pies_window;
   float4* __restrict__ auxv = pies_window + A.wLdsSlots;  // (wRows slots behind the largest window)
@@ -101,6 +130,11 @@ PIES_DEV void window_rows(const CgArrays& A, uint32_t nblocks, Own own, Halo hal
         if (AUX) auxv[lr] = aux;
       }
     }
+    st.mark();  // the own rows are done (their stores issued)
+    // (Measured and dropped in round 6: the halo's column indices requested before the own rows' loads, without a branch, and the
+    // gathers of eight columns per lane in flight together.  In the in-kernel stamps of tools/cg_timeline.py the halo phase falls from
+    // 2.65 to 1.6 us on the unstructured beam (6.4 halo columns per row) and the own rows' rises from 1.6 to 1.85; a launch as a whole
+    // - 391 workgroups on 256 compute units, the last one ends 3 us after the median - and the substep do not change.)
     if (A.wHalo16) {
       const uint32_t base = A.wBase[c];
       const uint16_t* __restrict__ h = A.wHalo16 + ch.x;
@@ -111,7 +145,9 @@ PIES_DEV void window_rows(const CgArrays& A, uint32_t nblocks, Own own, Halo hal
       for (uint32_t k = threadIdx.x; k < ch.y; k += kBlock)
         if (PIES_IN_BOUNDS(R + k < A.wLdsSlots && h[k] < A.n, 33u)) win[R + k] = halo(h[k]);
     }
+    st.mark();  // the halo is requested and stored
     __syncthreads();
+    st.mark();  // the window is complete
     for (uint32_t sc = wave; sc < spc; sc += kBlock / 64u) {
       const uint32_t sl = c * spc + sc;
       const uint32_t lr = A.wPerm ? A.wPerm[static_cast<size_t>(sl) * 64u + lane] : sc * 64u + lane;
@@ -120,7 +156,7 @@ PIES_DEV void window_rows(const CgArrays& A, uint32_t nblocks, Own own, Halo hal
       const float* __restrict__ wv = A.wVal + off + lane;
       const uint16_t* __restrict__ wi = A.wIdx + off + lane;
       ACC sx = 0, sy = 0, sz = 0;
-#pragma unroll 4
+#pragma unroll 4  // (8 and 16 measure the same: round 6)
       for (uint32_t kk = 0; kk < width; ++kk) {
         const ACC a = static_cast<ACC>(wv[kk << 6]);
         if (!PIES_IN_BOUNDS(wi[kk << 6] < A.wLdsSlots, 31u)) continue;
@@ -129,9 +165,15 @@ PIES_DEV void window_rows(const CgArrays& A, uint32_t nblocks, Own own, Halo hal
         sy = fma(a, static_cast<ACC>(q.y), sy);
         sz = fma(a, static_cast<ACC>(q.z), sz);
       }
+#ifdef PIES_EXPERIMENTS
+      asm volatile("" : "+v"(sx), "+v"(sy), "+v"(sz));
+      st.mark();  // the row's sum
+#endif
       if (i < A.n) row(i, sx, sy, sz, win[lr], AUX ? auxv[lr] : make_float4(0.f, 0.f, 0.f, 0.f));
+      st.mark();  // the row's turn behind the sum
     }
     __syncthreads();  // the next chunk's window overwrites this one
+    st.mark();
   }
 }
 
@@ -271,7 +313,7 @@ template <bool WIN> __global__ void __launch_bounds__(kBlock) k_cg1_first(CgArra
 // reads the vectors of parity (it - 1) & 1, writes those of parity it & 1; acc += {r.t, w.t, r.r} of the new vectors.
 // FIRST (it == 1): beta = 0 and there is no c / p yet.
 template <bool FIRST, bool WIN>
-PIES_DEV void cg1_rows(const CgArrays& A, float4* __restrict__ x, int it, const float alpha[3], const float beta[3], float acc[9]) {
+PIES_DEV void cg1_rows(const CgArrays& A, float4* __restrict__ x, int it, const float alpha[3], const float beta[3], float acc[9], CgStamp* stamp = nullptr) {
   const Vec3f* __restrict__ tO = A.t1[(it - 1) & 1];
   const Vec3f* __restrict__ aO = A.a1[(it - 1) & 1];
   const Vec3f* __restrict__ cO = A.c1[(it - 1) & 1];
@@ -332,7 +374,7 @@ PIES_DEV void cg1_rows(const CgArrays& A, float4* __restrict__ x, int it, const 
           const float wx = fmaf(cd, t.x, sx), wy = fmaf(cd, t.y, sy), wz = fmaf(cd, t.z, sz);
           aN[i] = Vec3f{di * wx, di * wy, di * wz};
           acc[3] += wx * t.x; acc[4] += wy * t.y; acc[5] += wz * t.z;
-        });
+        }, stamp);
     return;
   }
   const uint32_t lane = threadIdx.x & 63u;
@@ -404,6 +446,13 @@ PIES_DEV void cg1_scalars(const float gam[3], const float del[3], const float ga
 template <bool FIRST, bool WIN>
 __global__ void __launch_bounds__(kBlock) k_cg1_iter(CgArrays A, float4* __restrict__ x, int it, float tol2, int overflow) {
   if (A.scal[10] != 0.0f) return;  // the solve converged in an earlier launch
+  CgStamp st;
+  st.open(it);
+  st.mark();
+  // (Measured and dropped in round 6: the flag, the scalars, the count and the first two partial sums of every lane requested
+  // together - one round trip instead of three.  The in-kernel stamps of tools/cg_timeline.py show the prologue at 2.2 instead of
+  // 3.0 us and an isolated launch is 0.8 us shorter, but config 3 as a whole runs 1 % slower, 2 197 against 2 225 substeps/s in
+  // three A/B pairs: two of a solve's three captured launches are early exits, which then carry the requests for nothing.)
   float red[9];
   float alpha[3], beta[3] = {0.f, 0.f, 0.f}, gam[3], bb[3];
 #pragma unroll
@@ -445,9 +494,13 @@ __global__ void __launch_bounds__(kBlock) k_cg1_iter(CgArrays A, float4* __restr
   float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   uniform3(alpha);  // (the same in every lane: scalar registers for the rows' sweep)
   uniform3(beta);
-  cg1_rows<FIRST, WIN>(A, x, it, alpha, beta, acc);
+  st.mark();  // the scalars of this iteration
+  cg1_rows<FIRST, WIN>(A, x, it, alpha, beta, acc, &st);
+  st.mark();
   block_write_partial<9>(acc, A.part1[it & 1], 9);
   if (blockIdx.x == 0 && threadIdx.x == 0) A.partCount[it & 1] = gridDim.x;
+  st.mark();
+  st.close();
   if (overflow <= 0) return;
   // ---- the iterations beyond the captured ones ----------------------------------------------------------------------
   uint32_t passed = 0;
