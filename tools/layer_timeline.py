@@ -35,7 +35,9 @@ print("launch slots with stamps: %d; config 2 after %d ticks; 20 x 20 x 250 beam
 for s in used[:6] + used[-2:]:
     tiles = np.nonzero(st[s, :, 1])[0]
     rows = st[s, tiles]
-    n = int((rows[0] != 0).sum())
+    counts = (rows != 0).sum(axis=1)
+    n = int(np.bincount(counts).argmax())  # (a phase's first or last tile may hold one level only: fewer colours, fewer stamps)
+    tiles, rows = tiles[counts == n], rows[counts == n]
     real0, t = rows[:, 0], rows[:, 1:n - 1].astype(np.float64)
     real1 = rows[:, n - 1]
     dur_real = (real1 - real0) * 10.0  # ns (100 MHz)
