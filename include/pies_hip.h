@@ -280,7 +280,7 @@ int pies_set_collision_rounds(pies_solver_t* s, uint32_t rounds);
  * two-launch CG everywhere / in the contact-heavy variant), PIES_PD_FUSE_RHS (0: k_pd_rhs), PIES_PD_RHS_LANES,
  * PIES_COLOUR_ROUNDS, PIES_COLOUR_DSATUR, PIES_NO_COLOUR_HINT, PIES_SELL_LANES, PIES_CG_BLOCKS, PIES_COLLIDE_GLOBAL / _PASSES /
  * _SPIN_LIMIT; round 5: PIES_PD_WINDOW (0: no windowed matrix, 2: also beside a row dictionary) / _WINDOW_KERNELS (1 iterations, 2 first
- * product, 4 residual; default 3) / _WINDOW_SORT, PIES_CG_CHUNK_ROWS, PIES_PCG_NEVER_EXIT (profiling: every captured CG launch works),
+ * product, 4 residual; default 3) / _WINDOW_SORT / _WINDOW_HALO32 (tests: 32-bit halo list), PIES_CG_CHUNK_ROWS, PIES_PCG_NEVER_EXIT (profiling: every captured CG launch works),
  * PIES_REFERENCE_TURNS (0: the reference's node-node order as one sequential chain, 1: by turns whatever the size; default: by turns from
  * 1 024 nodes on), PIES_FALLBACK_VISITS (candidate tests a pass left to the sequential loop may cost before it latches: 1e9),
  * PIES_PAIR_QUADS (0: one lane per pair in the pair order's levels) / _QUAD_BLOCKS / _QUAD_THREADS / PIES_PAIR_LOOK_WAVES (wavefronts of a level workgroup that look at frontier nodes, at most).  They take effect where the library reads them (pies_create, pies_finalize or the next graph capture).  pies_set_tuning must not

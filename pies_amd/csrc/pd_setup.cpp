@@ -66,6 +66,7 @@ bool build_window_matrix(uint32_t n, const std::vector<uint32_t>& rowptr, const 
     if (!tmp.empty() && tmp.back() - tmp.front() > 0xffffu) W.halo16 = false;
     halos[c] = tmp;
   }
+  if (const char* e = tuning_env("PIES_PD_WINDOW_HALO32"); e && e[0] == '1') W.halo16 = false;  // tests: the 32-bit halo list on a small mesh
   uint32_t at = 0;
   for (uint32_t c = 0; c < W.chunks; ++c) {
     W.chunk[c] = make_uint2(at, static_cast<uint32_t>(halos[c].size()));

@@ -447,13 +447,14 @@ def test_pd_node_pair_collision_constraints(pies, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sort,kernels,chunk", [("0", "3", "256"), ("1", "3", "256"), ("1", "1", "64"), ("0", "7", "1024"), ("1", "7", "64")])
-def test_windowed_matrix_changes_nothing(pies, tune, sort, kernels, chunk):
+@pytest.mark.parametrize("sort,kernels,chunk,halo32", [("0", "3", "256", ""), ("1", "3", "256", ""), ("1", "1", "64", ""), ("0", "7", "1024", ""),
+                                                     ("1", "7", "64", ""), ("1", "7", "256", "1")])
+def test_windowed_matrix_changes_nothing(pies, tune, sort, kernels, chunk, halo32):
     """The windowed SELL matrix (its only coverage was the row-dictionary test) against the plain SELL arrays
     (PIES_PD_WINDOW=0) on an unstructured beam: rows sorted by length or not (PIES_PD_WINDOW_SORT), the window taken by the
     iterations only / + the first product / + the residual kernel with its fp64 sums and the right-hand side parked in LDS
     (PIES_PD_WINDOW_KERNELS 1 / 3 / 7), chunks of 64 / 256 / 1 024 rows (a partial last chunk, and at 1 024 rows a window above 64 KB
-    of dynamic LDS on this mesh).  Entries keep their order inside a row, so a row's sum is the same fused multiply-add chain in
+    of dynamic LDS on this mesh), the halo list in 16-bit offsets or 32-bit indices.  Entries keep their order inside a row, so a row's sum is the same fused multiply-add chain in
     every form: positions and velocities equal bit for bit after three ticks."""
     mesh = scenes.delaunay_beam((6, 5, 30), seed=11)
     res = []
@@ -462,6 +463,7 @@ def test_windowed_matrix_changes_nothing(pies, tune, sort, kernels, chunk):
         tune("PIES_PD_WINDOW_SORT", sort)
         tune("PIES_PD_WINDOW_KERNELS", kernels)
         tune("PIES_CG_CHUNK_ROWS", chunk)
+        tune("PIES_PD_WINDOW_HALO32", halo32)  # (the halo list with 32-bit entries: what a mesh whose chunks reach further than 65 535 rows takes)
         g = pies.Solver(pd_options(pies, 6))
         scenes.build_unstructured_pd(g, mesh)
         scenes.perturb(g, 5, 0.03)
