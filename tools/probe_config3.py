@@ -5,6 +5,8 @@ for p in (ROOT, os.path.join(ROOT, "benchlib")):
     sys.path.insert(0, p)
 import bench, scenes
 from pies_amd import capi
+for kv in sys.argv[1:]:
+    capi.set_tuning(*kv.split("=", 1))
 vals = []
 for rep in range(3):
     g = bench.pd_beam(scenes.L100K, 0)

@@ -1,11 +1,13 @@
 """The unstructured 100k beam under PD: substeps/s and the in-situ averages of the residual kernel (13) and the CG iteration (14).
-Tunables come from the environment (PIES_CG_CHUNK_ROWS, PIES_CG_INIT_BLOCKS, PIES_PD_WINDOW_KERNELS, ...)."""
+Tunables as arguments NAME=VALUE (PIES_CG_CHUNK_ROWS=512 ...): pies_set_tuning - the library does not read them from the environment."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "benchlib")):
     sys.path.insert(0, p)
 import bench, scenes
 from pies_amd import capi
+for kv in sys.argv[1:]:
+    capi.set_tuning(*kv.split("=", 1))
 mesh = scenes.delaunay_beam(scenes.L100K)
 g = capi.Solver(capi.Options(solver=capi.PD, iterations=10), device=0)
 scenes.build_unstructured_pd(g, mesh)
