@@ -30,7 +30,6 @@ constexpr int kBatch = 4;         // node records a lane requests before it cons
 
 #ifdef PIES_EXPERIMENTS  // in-kernel time stamps of a diagnostic build (tools/layer_timeline.py): never part of the product build
 __device__ unsigned long long* g_layer_stamps = nullptr;  // [launch slot][tile][kStampsPerTile]
-__device__ unsigned int g_layer_stamp_slot = 0;
 constexpr int kStampsPerTile = 128;
 #define PIES_STAMP_DECL unsigned long long* stampBase = nullptr; int stampIdx = 0; \
   if (g_layer_stamps && tid == 0) stampBase = g_layer_stamps + (static_cast<size_t>(L.stampSlot) * 4096u + g) * kStampsPerTile;
